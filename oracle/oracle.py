@@ -1,0 +1,127 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY -- see mb_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SUM_TABLE, SUM_EXACT, MAX = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libmboracle.so")
+    src = os.path.join(_HERE, "mb_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libmboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, i32p, u32p, u16p, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.POINTER(C.c_double)
+        L.mbo_init.restype = None
+        L.mbo_log_sum_exp.restype = C.c_double
+        L.mbo_log_sum_exp.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.mbo_machine_create.restype = vp
+        L.mbo_machine_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, u32p, u32p, u16p, u16p, dp]
+        L.mbo_machine_set_weights.argtypes = [vp, dp]
+        L.mbo_machine_destroy.argtypes = [vp]
+        L.mbo_incoming_order.argtypes = [vp, u32p]
+        L.mbo_outgoing_order.argtypes = [vp, u32p]
+        L.mbo_fill_forward.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, C.c_int, C.c_int, dp]
+        L.mbo_fill_backward.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, C.c_int, dp]
+        L.mbo_forward_loglike.restype = C.c_double
+        L.mbo_forward_loglike.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, C.c_int]
+        L.mbo_get_counts.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, dp, dp]
+        L.mbo_counts_add.restype = C.c_double
+        L.mbo_counts_add.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, C.c_int, dp]
+        L.mbo_traceback.restype = C.c_long
+        L.mbo_traceback.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, u32p, C.c_long]
+        L.mbo_init()
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OracleMachine:
+    """Oracle-side flattened machine built from a machineboss_amd.evalmachine.EvaluatedMachine."""
+
+    def __init__(self, em):
+        self.em = em
+        self.L = lib()
+        self._keep = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+                      np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+                      np.ascontiguousarray(em.logWeight, np.float64)]
+        k = self._keep
+        self.h = self.L.mbo_machine_create(em.nStates, em.nInTok, em.nOutTok, em.nTransitions,
+                                           _p(k[0], C.c_uint32), _p(k[1], C.c_uint32), _p(k[2], C.c_uint16),
+                                           _p(k[3], C.c_uint16), _p(k[4], C.c_double))
+        self.S = em.nStates
+        self.nT = em.nTransitions
+
+    def __del__(self):
+        try:
+            self.L.mbo_machine_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_weights(self, lw):
+        lw = np.ascontiguousarray(lw, np.float64)
+        self.L.mbo_machine_set_weights(self.h, _p(lw, C.c_double))
+
+    def incoming_order(self):
+        o = np.empty(self.nT, np.uint32); self.L.mbo_incoming_order(self.h, _p(o, C.c_uint32)); return o
+
+    def outgoing_order(self):
+        o = np.empty(self.nT, np.uint32); self.L.mbo_outgoing_order(self.h, _p(o, C.c_uint32)); return o
+
+    @staticmethod
+    def _seqs(inp, out):
+        return np.ascontiguousarray(inp, np.int32), np.ascontiguousarray(out, np.int32)
+
+    def forward(self, inp, out, mode=SUM_TABLE, startState=0):
+        """Full Forward (mode SUM_*) or Viterbi (mode MAX) matrix, shape [outLen+1][inLen+1][nStates]."""
+        i, o = self._seqs(inp, out)
+        cells = np.empty((len(o) + 1, len(i) + 1, self.S), np.float64)
+        self.L.mbo_fill_forward(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), mode, startState, _p(cells, C.c_double))
+        return cells
+
+    def viterbi(self, inp, out):
+        return self.forward(inp, out, MAX, 0)
+
+    def backward(self, inp, out, mode=SUM_TABLE):
+        i, o = self._seqs(inp, out)
+        cells = np.empty((len(o) + 1, len(i) + 1, self.S), np.float64)
+        self.L.mbo_fill_backward(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), mode, _p(cells, C.c_double))
+        return cells
+
+    def loglike(self, inp, out, mode=SUM_TABLE):
+        i, o = self._seqs(inp, out)
+        return self.L.mbo_forward_loglike(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), mode)
+
+    def counts_add(self, inp, out, counts, mode=SUM_TABLE):
+        i, o = self._seqs(inp, out)
+        assert counts.dtype == np.float64 and counts.shape == (self.nT,)
+        return self.L.mbo_counts_add(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), mode, _p(counts, C.c_double))
+
+    def traceback(self, inp, out, cells):
+        i, o = self._seqs(inp, out)
+        cap = (len(i) + len(o) + 2) * (self.S + 1)
+        path = np.empty(cap, np.uint32)
+        n = self.L.mbo_traceback(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), _p(cells, C.c_double), _p(path, C.c_uint32), cap)
+        if n < 0:
+            raise RuntimeError("Can't do traceback: no finite-weight paths" if n == -1 else "traceback error %d" % n)
+        return path[:n].copy()
