@@ -1,0 +1,129 @@
+/* mbhip.h -- C-ABI of the MI355X (gfx950) Forward / Backward / Viterbi DP engine for Machine Boss.
+ *
+ * This is the drop-in boundary for the reference's DP hot path.  The reference has no FFI layer: its
+ * boundary is the C++ class interface of src/{dpmatrix,forward,backward,viterbi,counts,logsumexp}.h
+ * ("construction is computation").  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the C++ shim that re-implements
+ * those classes on top of this header.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all buffers are caller-owned host memory unless stated otherwise;
+ *    the library owns device memory.  Calls are synchronous.
+ *  - every function returning int returns 0 on success, non-zero on error; mb_last_error() then gives the
+ *    message the reference would have put into its runtime_error (src/util.cpp:39-48).
+ *  - tokens are int32, token 0 = epsilon, tokens 1..N index the sorted alphabet (src/eval.h:13-22).
+ *  - transitions ("edges") are identified by their GLOBAL id e = transOffset[src] + transIndex, the order in
+ *    which EvaluatedMachine::init visits them (src/eval.cpp:47-69).  counts[] and Viterbi paths use these ids.
+ *  - matrices use the reference's IdentityIndexMapper layout with a full envelope (src/dpmatrix.h:34-44,90-96):
+ *        cell(inPos,outPos,state) = cells[((outPos*(inLen+1)) + inPos)*nStates + state]      (double)
+ *  - only full envelopes are supported in this round (the reference ignores the Envelope argument of the
+ *    3-argument DPMatrix constructor, src/dpmatrix.defs.h:16-17; path envelopes of aligned SeqPairs are "next").
+ */
+#ifndef MBHIP_H_INCLUDED
+#define MBHIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mb_machine mb_machine; /* device-resident flattened EvaluatedMachine (src/eval.h:59-98) */
+typedef struct mb_batch mb_batch;     /* device-resident tokenised SeqPairList (src/seqpair.h:56-121)   */
+
+/* fill modes for mb_fill / mb_batch_fill */
+enum { MB_FORWARD = 0, MB_VITERBI = 1, MB_BACKWARD = 2 };
+
+/* mb_batch_forward flags */
+enum {
+  MB_MATERIALISE = 0, /* ForwardMatrix: full (inLen+1)(outLen+1)nStates matrix kept in HBM (src/forward.h:19-27)  */
+  MB_ROLLING = 1      /* RollingOutputForwardMatrix: log-likelihood only (src/dpmatrix.h:46-58, target/boss.cpp:799) */
+};
+
+/* ---- process / device ------------------------------------------------------------------------------------ */
+int mb_device_count(void);        /* number of visible HIP devices (0 if none)                                 */
+int mb_set_device(int device);    /* one process drives one GPU (rank-local device)                            */
+const char *mb_last_error(void);  /* thread-local message of the last failing call                             */
+double mb_last_device_ms(void);   /* device time (HIP events on the library's stream) of the last batch call   */
+const char *mb_last_kernel_name(void); /* name of the dominant kernel of the last batch call (for profiles)     */
+
+/* ---- machine ----------------------------------------------------------------------------------------------
+ * Replaces the per-state incoming/outgoing maps built by EvaluatedMachine::init (src/eval.cpp:40-70).
+ * Edges are passed in global-id order (ascending src, then transIndex).  The library derives
+ *   - the `incoming` iteration order (dst, inTok, outTok, src, insertion order)   src/eval.h:66-68, eval.cpp:60-61
+ *   - the `outgoing` iteration order (src, inTok, outTok, dst, insertion order)
+ *   - silent-transition levels (the reference relies on state order; src/eval.cpp:44, machine.cpp:758-764)
+ * Returns NULL on error (e.g. "Machine is not topologically sorted").  nInTok/nOutTok exclude epsilon. */
+mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans,
+                              const uint32_t *src, const uint32_t *dst, const uint16_t *inTok,
+                              const uint16_t *outTok, const double *logWeight);
+/* New log-weights for the same topology: one call per EM iteration (src/fitter.cpp:28-29). */
+int mb_machine_set_weights(mb_machine *m, const double *logWeight);
+void mb_machine_destroy(mb_machine *m);
+int32_t mb_machine_n_states(const mb_machine *m);
+int64_t mb_machine_n_trans(const mb_machine *m);
+int32_t mb_machine_n_levels(const mb_machine *m); /* depth of the silent-transition DAG + 1 */
+/* Edge ids in the reference's iteration order, for tests: which = 0 incoming, 1 outgoing. out[nTrans]. */
+int mb_machine_edge_order(const mb_machine *m, int which, uint32_t *out);
+
+/* ---- batch of sequence pairs ------------------------------------------------------------------------------
+ * Replaces the `for (const auto& seqPair: data.seqPairs)` loops of target/boss.cpp:796,826 and
+ * src/counts.cpp:40-42: the whole list is tokenised by the caller (Tokenizer::tokenize, src/eval.h:29-41),
+ * handed over once, and kept resident in HBM.  Pair p has input tokens inTok[inOff[p]..inOff[p+1]) and output
+ * tokens outTok[outOff[p]..outOff[p+1]).  Tokens outside [1,nInTok] / [1,nOutTok] are rejected with the
+ * reference's "Can't tokenize symbol" condition (src/eval.h:33-37). */
+mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
+                          const int32_t *outTok, const int64_t *outOff);
+void mb_batch_destroy(mb_batch *b);
+int64_t mb_batch_cells(const mb_batch *b); /* sum over pairs of (inLen+1)(outLen+1)nStates */
+
+/* Forward log-likelihoods, loglike[nPairs] (-inf allowed).
+ * MB_MATERIALISE = ForwardMatrix(eval, sp).logLike()             src/forward.defs.h:23-55, src/api.cpp:32-35
+ * MB_ROLLING     = RollingOutputForwardMatrix(eval, sp).logLike() target/boss.cpp:799-800               */
+int mb_batch_forward(mb_batch *b, int flags, double *loglike);
+
+/* ViterbiMatrix(eval, sp): logLike() and path()                   src/viterbi.cpp:18-51, dpmatrix.defs.h:61-110
+ * loglike[nPairs]; pathOff[nPairs+1] (output) delimits each pair's start->end list of global edge ids in
+ * pathEdges[pathCap].  A pair whose end cell is -inf gets an empty path (the reference refuses to trace it,
+ * src/dpmatrix.defs.h:84, target/boss.cpp:831).  pathEdges may be NULL to skip tracebacks.
+ * mb_viterbi_path_bound gives a sufficient pathCap contribution for one pair. */
+int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen);
+int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap);
+
+/* MachineCounts(eval, seqPairList): E-step                        src/counts.cpp:37-64, src/backward.cpp:58-87
+ * counts[nTrans] += posterior expected usage of every transition, summed over the batch;
+ * *loglikeSum += sum of forward.logLike() (MachineCounts::loglike); loglike[nPairs] optional (may be NULL).
+ * Pairs with a -inf likelihood contribute nothing to counts (the reference would produce NaN there). */
+int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike);
+
+/* One full matrix back to the host, for DPMatrix::cell()/writeJson() (src/dpmatrix.defs.h:39-53), the golden
+ * matrix tests (t/src/testforward.cpp, testbackward.cpp) and Machine::downsample (src/machine.cpp:2053-2076).
+ * mode MB_FORWARD uses startState (ForwardMatrix 4-argument ctor, src/forward.h:24); Viterbi seeds state 0
+ * (src/viterbi.cpp:30); Backward seeds the last state (src/backward.cpp:33).
+ * cellsOut[(inLen+1)*(outLen+1)*nStates]. */
+int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
+            int32_t startState, double *cellsOut);
+
+/* ---- convenience wrappers over host buffers (create batch, run, destroy) ----------------------------------
+ * forwardLogLike / viterbiLogLike+viterbiAlign / forwardBackwardCounts of src/api.h:20-34.                   */
+int mb_forward_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
+                     const int32_t *outTok, const int64_t *outOff, int flags, double *loglike);
+int mb_viterbi_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
+                     const int32_t *outTok, const int64_t *outOff, double *loglike, int64_t *pathOff,
+                     uint32_t *pathEdges, int64_t pathCap);
+int mb_counts_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
+                    const int32_t *outTok, const int64_t *outOff, double *counts, double *loglikeSum,
+                    double *loglike);
+
+/* ---- tuning / introspection (not part of the reference surface) ------------------------------------------ */
+/* Select the kernel family: 0 = auto, 1 = generic (any machine), 2 = small-S lanes=cells, 3 = medium-S
+ * lanes=states.  Used by tests to cross-check kernels against each other and by bench.py. */
+int mb_set_kernel(int which);
+/* Bytes of device memory the library may use for DP matrices (default: 80 % of free HBM). */
+int mb_set_memory_budget(size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBHIP_H_INCLUDED */

@@ -1,0 +1,217 @@
+"""ctypes binding of the C-ABI in include/mbhip.h (libmbhip.so, built in-tree by machineboss_amd.build).
+
+This is the stub a Python caller of the reference (python/machineboss/boss.py shells out to the ``boss`` CLI) would
+use instead.  There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmbhip.so")
+
+MB_FORWARD, MB_VITERBI, MB_BACKWARD = 0, 1, 2
+MB_MATERIALISE, MB_ROLLING = 0, 1
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SMALL, KERNEL_MEDIUM = 0, 1, 2, 3
+
+EXPORTS = [
+    "mb_device_count", "mb_set_device", "mb_last_error", "mb_last_device_ms", "mb_last_kernel_name",
+    "mb_machine_create", "mb_machine_set_weights", "mb_machine_destroy", "mb_machine_n_states", "mb_machine_n_trans",
+    "mb_machine_n_levels", "mb_machine_edge_order",
+    "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
+    "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
+    "mb_set_kernel", "mb_set_memory_budget",
+]
+
+_lib = None
+
+
+class MbError(RuntimeError):
+    """The library's non-zero status, carrying mb_last_error() -- the reference throws runtime_error (src/util.cpp:39-48)."""
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MbError("libmbhip.so is not built (run `python -m machineboss_amd.build`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    i32p, i64p, u32p, u16p, dp = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint16), C.POINTER(C.c_double))
+    L.mb_device_count.restype = C.c_int
+    L.mb_set_device.argtypes = [C.c_int]
+    L.mb_last_error.restype = C.c_char_p
+    L.mb_last_device_ms.restype = C.c_double
+    L.mb_last_kernel_name.restype = C.c_char_p
+    L.mb_machine_create.restype = vp
+    L.mb_machine_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp]
+    L.mb_machine_set_weights.argtypes = [vp, dp]
+    L.mb_machine_destroy.argtypes = [vp]
+    L.mb_machine_destroy.restype = None
+    L.mb_machine_n_states.argtypes = [vp]; L.mb_machine_n_states.restype = C.c_int32
+    L.mb_machine_n_trans.argtypes = [vp]; L.mb_machine_n_trans.restype = C.c_int64
+    L.mb_machine_n_levels.argtypes = [vp]; L.mb_machine_n_levels.restype = C.c_int32
+    L.mb_machine_edge_order.argtypes = [vp, C.c_int, u32p]
+    L.mb_batch_create.restype = vp
+    L.mb_batch_create.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p]
+    L.mb_batch_destroy.argtypes = [vp]; L.mb_batch_destroy.restype = None
+    L.mb_batch_cells.argtypes = [vp]; L.mb_batch_cells.restype = C.c_int64
+    L.mb_batch_forward.argtypes = [vp, C.c_int, dp]
+    L.mb_viterbi_path_bound.argtypes = [vp, C.c_int64, C.c_int64]; L.mb_viterbi_path_bound.restype = C.c_int64
+    L.mb_batch_viterbi.argtypes = [vp, dp, i64p, u32p, C.c_int64]
+    L.mb_batch_counts.argtypes = [vp, dp, dp, dp]
+    L.mb_fill.argtypes = [vp, C.c_int, i32p, C.c_int64, i32p, C.c_int64, C.c_int32, dp]
+    L.mb_forward_batch.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p, C.c_int, dp]
+    L.mb_viterbi_batch.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p, dp, i64p, u32p, C.c_int64]
+    L.mb_counts_batch.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p, dp, dp, dp]
+    L.mb_set_kernel.argtypes = [C.c_int]
+    L.mb_set_memory_budget.argtypes = [C.c_size_t]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise MbError(load().mb_last_error().decode() or "mbhip error")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def device_count() -> int:
+    return load().mb_device_count()
+
+
+def set_device(d: int):
+    _check(load().mb_set_device(d))
+
+
+def set_kernel(which: int):
+    _check(load().mb_set_kernel(which))
+
+
+def set_memory_budget(nbytes: int):
+    _check(load().mb_set_memory_budget(nbytes))
+
+
+def last_device_ms() -> float:
+    return load().mb_last_device_ms()
+
+
+def last_kernel_name() -> str:
+    return load().mb_last_kernel_name().decode()
+
+
+class DeviceMachine:
+    """Device-resident flattened machine (mb_machine*), built from an evalmachine.EvaluatedMachine."""
+
+    def __init__(self, em):
+        L = load()
+        self.em = em
+        a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+             np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+             np.ascontiguousarray(em.logWeight, np.float64)]
+        self.h = L.mb_machine_create(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                     _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double))
+        if not self.h:
+            raise MbError(L.mb_last_error().decode())
+        self.nStates, self.nTrans = em.nStates, em.nTransitions
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().mb_machine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_weights(self, logWeight):
+        lw = np.ascontiguousarray(logWeight, np.float64)
+        assert lw.shape == (self.nTrans,)
+        _check(load().mb_machine_set_weights(self.h, _p(lw, C.c_double)))
+
+    def n_levels(self) -> int:
+        return load().mb_machine_n_levels(self.h)
+
+    def edge_order(self, which: int) -> np.ndarray:
+        o = np.empty(self.nTrans, np.uint32)
+        _check(load().mb_machine_edge_order(self.h, which, _p(o, C.c_uint32)))
+        return o
+
+    def fill(self, mode: int, inp, out, startState: int = 0) -> np.ndarray:
+        """Full matrix [outLen+1][inLen+1][nStates] (DPMatrix cell storage, src/dpmatrix.h:90-96)."""
+        i = np.ascontiguousarray(inp, np.int32); o = np.ascontiguousarray(out, np.int32)
+        cells = np.empty((len(o) + 1, len(i) + 1, self.nStates), np.float64)
+        _check(load().mb_fill(self.h, mode, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), startState, _p(cells, C.c_double)))
+        return cells
+
+    def path_bound(self, inLen: int, outLen: int) -> int:
+        return load().mb_viterbi_path_bound(self.h, inLen, outLen)
+
+
+class DeviceBatch:
+    """Device-resident tokenised pair list (mb_batch*)."""
+
+    def __init__(self, dm: DeviceMachine, inTok, inOff, outTok, outOff):
+        self.dm = dm
+        self.inTok = np.ascontiguousarray(inTok, np.int32); self.outTok = np.ascontiguousarray(outTok, np.int32)
+        self.inOff = np.ascontiguousarray(inOff, np.int64); self.outOff = np.ascontiguousarray(outOff, np.int64)
+        self.nPairs = len(self.inOff) - 1
+        assert len(self.outOff) == self.nPairs + 1
+        L = load()
+        self.h = L.mb_batch_create(dm.h, self.nPairs, _p(self.inTok, C.c_int32), _p(self.inOff, C.c_int64),
+                                   _p(self.outTok, C.c_int32), _p(self.outOff, C.c_int64))
+        if not self.h:
+            raise MbError(L.mb_last_error().decode())
+
+    @classmethod
+    def from_pairs(cls, dm: DeviceMachine, pairs):
+        """pairs: iterable of (inputTokens, outputTokens)."""
+        pairs = list(pairs)
+        inOff = np.zeros(len(pairs) + 1, np.int64); outOff = np.zeros(len(pairs) + 1, np.int64)
+        for k, (a, b) in enumerate(pairs):
+            inOff[k + 1] = inOff[k] + len(a); outOff[k + 1] = outOff[k] + len(b)
+        cat = lambda xs: (np.concatenate([np.asarray(x, np.int32) for x in xs]) if len(xs) else np.zeros(0, np.int32)).astype(np.int32)
+        return cls(dm, cat([a for a, _ in pairs]), inOff, cat([b for _, b in pairs]), outOff)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().mb_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def cells(self) -> int:
+        return load().mb_batch_cells(self.h)
+
+    def forward(self, flags: int = MB_MATERIALISE) -> np.ndarray:
+        ll = np.empty(self.nPairs, np.float64)
+        _check(load().mb_batch_forward(self.h, flags, _p(ll, C.c_double)))
+        return ll
+
+    def viterbi(self, paths: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray], Optional[np.ndarray]]:
+        ll = np.empty(self.nPairs, np.float64)
+        if not paths:
+            _check(load().mb_batch_viterbi(self.h, _p(ll, C.c_double), None, None, 0))
+            return ll, None, None
+        cap = sum(self.dm.path_bound(int(self.inOff[k + 1] - self.inOff[k]), int(self.outOff[k + 1] - self.outOff[k]))
+                  for k in range(self.nPairs))
+        off = np.zeros(self.nPairs + 1, np.int64); edges = np.empty(max(cap, 1), np.uint32)
+        _check(load().mb_batch_viterbi(self.h, _p(ll, C.c_double), _p(off, C.c_int64), _p(edges, C.c_uint32), cap))
+        return ll, off, edges[:off[-1]].copy()
+
+    def counts(self, counts: Optional[np.ndarray] = None):
+        """Returns (counts[nTrans], loglikeSum, loglike[nPairs]); accumulates into ``counts`` if given."""
+        if counts is None:
+            counts = np.zeros(self.dm.nTrans, np.float64)
+        assert counts.dtype == np.float64 and counts.shape == (self.dm.nTrans,) and counts.flags.c_contiguous
+        s = C.c_double(0.0)
+        ll = np.empty(self.nPairs, np.float64)
+        _check(load().mb_batch_counts(self.h, _p(counts, C.c_double), C.byref(s), _p(ll, C.c_double)))
+        return counts, s.value, ll

@@ -1,0 +1,426 @@
+// mb_api.hip -- implementation of the C-ABI declared in include/mbhip.h.
+//
+// Host orchestration only: device memory pools, chunking of a batch so that materialised matrices fit the HBM
+// budget (288 GB per MI355X), kernel-family selection, HIP-event timing on the library stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mb_internal.h"
+
+namespace mb {
+
+thread_local std::string g_err;
+thread_local double g_last_ms = 0.0;
+thread_local const char *g_last_kernel = "";
+hipStream_t g_stream = nullptr;
+int g_kernel_choice = 0;
+size_t g_mem_budget = 0;
+static bool g_init = false;
+
+void set_error(const std::string &msg) { g_err = msg; }
+
+bool hip_ok(hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+static int ensure_init() {
+  if (g_init) return 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    set_error("no HIP device visible: the Machine Boss DP engine has no CPU fallback");
+    return 1;
+  }
+  MB_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_init = true;
+  return 0;
+}
+
+static size_t budget_bytes() {
+  if (g_mem_budget) return g_mem_budget;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return (size_t)8 << 30;
+  return (size_t)((double)freeB * 0.80);
+}
+
+// kernel launchers implemented in the kernel files
+int launch_generic_fill(const mb_machine *, int, const PairDesc *, long long, const int *, const int *, double *, int, hipStream_t);
+int launch_gather_loglike(const PairDesc *, long long, const double *, int, int, double *, hipStream_t);
+int launch_generic_counts(const mb_machine *, const PairDesc *, long long, long long, const int *, const int *,
+                          const double *, const double *, double *, hipStream_t);
+int launch_traceback(const mb_machine *, const PairDesc *, long long, const int *, const int *, const double *,
+                     const long long *, uint32_t *, long long *, hipStream_t);
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool ok = false;
+  Timer() { ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
+  ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  void start() { if (ok) (void)hipEventRecord(a, g_stream); }
+  double stop() {
+    if (!ok) return 0.0;
+    (void)hipEventRecord(b, g_stream);
+    (void)hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+  }
+};
+
+// Split [0,nPairs) into chunks whose matrices (nMatrices per pair, doubles) fit the budget.
+struct Chunk { long long p0, p1, cells; };
+static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &out) {
+  const size_t budget = budget_bytes();
+  const long long maxCells = (long long)(budget / (8ull * nMatrices));
+  long long p0 = 0, acc = 0;
+  for (long long p = 0; p < b->nPairs; ++p) {
+    const PairDesc &pd = b->pairs[p];
+    const long long c = (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S;
+    if (c > maxCells) {
+      set_error("a single DP matrix (" + std::to_string(c * 8ll * nMatrices) + " bytes) exceeds the device memory budget");
+      return false;
+    }
+    if (acc + c > maxCells) { out.push_back({p0, p, acc}); p0 = p; acc = 0; }
+    acc += c;
+  }
+  if (b->nPairs > p0) out.push_back({p0, b->nPairs, acc});
+  return true;
+}
+
+// Upload PairDescs of a chunk with cellBase rebased to the chunk's pool.
+static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_out) {
+  std::vector<PairDesc> tmp(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
+  long long base = 0;
+  for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S; }
+  MB_HIP(hipMalloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
+  MB_HIP(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream));
+  MB_HIP(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+}  // namespace mb
+
+using namespace mb;
+
+extern "C" {
+
+int mb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mb_set_device(int device) {
+  MB_HIP(hipSetDevice(device));
+  return 0;
+}
+
+const char *mb_last_error(void) { return g_err.c_str(); }
+double mb_last_device_ms(void) { return g_last_ms; }
+const char *mb_last_kernel_name(void) { return g_last_kernel; }
+
+int mb_set_kernel(int which) {
+  if (which < 0 || which > 3) { set_error("mb_set_kernel: unknown kernel family"); return 1; }
+  g_kernel_choice = which;
+  return 0;
+}
+
+int mb_set_memory_budget(size_t bytes) { g_mem_budget = bytes; return 0; }
+
+mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
+                              const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight) {
+  if (nStates <= 0) { set_error("EvaluatedMachine has no states"); return nullptr; }
+  if (nInTok < 0 || nOutTok < 0 || nTrans < 0) { set_error("mb_machine_create: negative size"); return nullptr; }
+  if (ensure_init()) return nullptr;
+  mb_machine *m = new mb_machine();
+  m->S = nStates; m->nIn = nInTok; m->nOut = nOutTok; m->nTrans = nTrans;
+  m->src.assign(src, src + nTrans); m->dst.assign(dst, dst + nTrans);
+  m->inTok.assign(inTok, inTok + nTrans); m->outTok.assign(outTok, outTok + nTrans);
+  m->logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(m, &err)) { set_error(err); delete m; return nullptr; }
+  if (!upload_machine(m)) { free_machine_device(m); delete m; return nullptr; }
+  return m;
+}
+
+int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
+  if (!m) { set_error("null machine"); return 1; }
+  m->logW.assign(logWeight, logWeight + m->nTrans);
+  return upload_weights(m) ? 0 : 1;
+}
+
+void mb_machine_destroy(mb_machine *m) {
+  if (!m) return;
+  free_machine_device(m);
+  delete m;
+}
+
+int32_t mb_machine_n_states(const mb_machine *m) { return m ? m->S : 0; }
+int64_t mb_machine_n_trans(const mb_machine *m) { return m ? m->nTrans : 0; }
+int32_t mb_machine_n_levels(const mb_machine *m) { return m ? m->nLevF : 0; }
+
+int mb_machine_edge_order(const mb_machine *m, int which, uint32_t *out) {
+  if (!m) { set_error("null machine"); return 1; }
+  const std::vector<uint32_t> &p = which ? m->outPerm : m->inPerm;
+  std::memcpy(out, p.data(), p.size() * sizeof(uint32_t));
+  return 0;
+}
+
+mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff, const int32_t *outTok,
+                          const int64_t *outOff) {
+  if (!m) { set_error("null machine"); return nullptr; }
+  if (nPairs < 0) { set_error("negative pair count"); return nullptr; }
+  mb_batch *b = new mb_batch();
+  b->m = m; b->nPairs = nPairs;
+  b->pairs.resize(nPairs);
+  long long base = 0;
+  for (long long p = 0; p < nPairs; ++p) {
+    PairDesc &pd = b->pairs[p];
+    const long long il = inOff[p + 1] - inOff[p], ol = outOff[p + 1] - outOff[p];
+    if (il < 0 || ol < 0 || il > 0x3fffffff || ol > 0x3fffffff) { set_error("bad sequence offsets"); delete b; return nullptr; }
+    pd.inBase = inOff[p] - inOff[0]; pd.outBase = outOff[p] - outOff[0];
+    pd.inLen = (int)il; pd.outLen = (int)ol; pd.cellBase = base;
+    const long long c = (il + 1) * (ol + 1) * m->S;
+    base += c;
+    b->maxPairCells = std::max(b->maxPairCells, c);
+  }
+  b->totalCells = base;
+  b->nInTokTotal = nPairs ? inOff[nPairs] - inOff[0] : 0;
+  b->nOutTokTotal = nPairs ? outOff[nPairs] - outOff[0] : 0;
+  const int32_t *in0 = inTok + (nPairs ? inOff[0] : 0), *out0 = outTok + (nPairs ? outOff[0] : 0);
+  // Tokenizer::tokenize throws on symbols outside the alphabet (src/eval.h:33-37); token 0 (epsilon) is not a symbol
+  for (long long k = 0; k < b->nInTokTotal; ++k)
+    if (in0[k] < 1 || in0[k] > m->nIn) { set_error("Can't tokenize symbol: input token outside the machine's alphabet"); delete b; return nullptr; }
+  for (long long k = 0; k < b->nOutTokTotal; ++k)
+    if (out0[k] < 1 || out0[k] > m->nOut) { set_error("Can't tokenize symbol: output token outside the machine's alphabet"); delete b; return nullptr; }
+  auto fail = [&]() { mb_batch_destroy(b); return (mb_batch *)nullptr; };
+  if (!hip_ok(hipMalloc((void **)&b->d_in, std::max<long long>(b->nInTokTotal, 1) * sizeof(int)), "hipMalloc(tokens)")) return fail();
+  if (!hip_ok(hipMalloc((void **)&b->d_out, std::max<long long>(b->nOutTokTotal, 1) * sizeof(int)), "hipMalloc(tokens)")) return fail();
+  if (!hip_ok(hipMalloc((void **)&b->d_pairs, std::max<long long>(nPairs, 1) * sizeof(PairDesc)), "hipMalloc(pairs)")) return fail();
+  if (b->nInTokTotal && !hip_ok(hipMemcpy(b->d_in, in0, b->nInTokTotal * sizeof(int), hipMemcpyHostToDevice), "H2D tokens")) return fail();
+  if (b->nOutTokTotal && !hip_ok(hipMemcpy(b->d_out, out0, b->nOutTokTotal * sizeof(int), hipMemcpyHostToDevice), "H2D tokens")) return fail();
+  if (nPairs && !hip_ok(hipMemcpy(b->d_pairs, b->pairs.data(), nPairs * sizeof(PairDesc), hipMemcpyHostToDevice), "H2D pairs")) return fail();
+  return b;
+}
+
+void mb_batch_destroy(mb_batch *b) {
+  if (!b) return;
+  if (b->d_in) (void)hipFree(b->d_in);
+  if (b->d_out) (void)hipFree(b->d_out);
+  if (b->d_pairs) (void)hipFree(b->d_pairs);
+  delete b;
+}
+
+int64_t mb_batch_cells(const mb_batch *b) { return b ? b->totalCells : 0; }
+
+// ---- Forward ------------------------------------------------------------------------------------------------
+static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
+  (void)flags;
+  g_last_ms = 0.0;
+  g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : "k_generic_fill_fwd<0>";
+  if (b->nPairs == 0) return 0;
+  std::vector<Chunk> chunks;
+  if (!plan_chunks(b, 1, chunks)) return 1;
+  double *d_ll = nullptr;
+  MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
+  int rc = 0;
+  Timer tm;
+  for (const Chunk &c : chunks) {
+    PairDesc *d_desc = nullptr; double *pool = nullptr;
+    if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
+    if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { (void)hipFree(d_desc); rc = 1; break; }
+    tm.start();
+    rc = launch_generic_fill(b->m, mode, d_desc, c.p1 - c.p0, b->d_in, b->d_out, pool, 0, g_stream);
+    if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, b->m->S, 0, d_ll + c.p0, g_stream);
+    g_last_ms += tm.stop();
+    if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+    (void)hipFree(pool); (void)hipFree(d_desc);
+    if (rc) break;
+  }
+  if (!rc && !hip_ok(hipMemcpy(loglike, d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
+  (void)hipFree(d_ll);
+  return rc;
+}
+
+int mb_batch_forward(mb_batch *b, int flags, double *loglike) {
+  if (!b || !loglike) { set_error("null argument"); return 1; }
+  return run_fill_loglike(b, MB_FORWARD, flags, loglike);
+}
+
+// ---- Viterbi ------------------------------------------------------------------------------------------------
+int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen) {
+  if (!m) return 0;
+  // between two emitting steps the traceback follows silent edges to strictly lower states through at most
+  // nLevF-1 levels; one more run may precede the first emission.
+  return (inLen + outLen + 1) * (int64_t)m->nLevF + 1;
+}
+
+int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
+  if (!b || !loglike) { set_error("null argument"); return 1; }
+  g_last_ms = 0.0;
+  g_last_kernel = "k_generic_fill_fwd<1>";
+  const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
+  if (pathOff) pathOff[0] = 0;
+  if (b->nPairs == 0) return 0;
+  std::vector<Chunk> chunks;
+  if (!plan_chunks(b, 1, chunks)) return 1;
+  int rc = 0;
+  Timer tm;
+  long long written = 0;
+  for (const Chunk &c : chunks) {
+    const long long np = c.p1 - c.p0;
+    PairDesc *d_desc = nullptr; double *pool = nullptr, *d_ll = nullptr;
+    long long *d_slot = nullptr, *d_len = nullptr; uint32_t *d_path = nullptr;
+    std::vector<long long> slot(np + 1, 0), len(np, 0);
+    std::vector<uint32_t> hpath;
+    std::vector<double> hll(np);
+    do {
+      if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
+      if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { rc = 1; break; }
+      if (!hip_ok(hipMalloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+      tm.start();
+      if ((rc = launch_generic_fill(b->m, MB_VITERBI, d_desc, np, b->d_in, b->d_out, pool, 0, g_stream))) break;
+      if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
+      if (wantPaths) {
+        for (long long p = 0; p < np; ++p)
+          slot[p + 1] = slot[p] + mb_viterbi_path_bound(b->m, b->pairs[c.p0 + p].inLen, b->pairs[c.p0 + p].outLen);
+        if (!hip_ok(hipMalloc((void **)&d_slot, (np + 1) * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
+        if (!hip_ok(hipMalloc((void **)&d_len, np * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
+        if (!hip_ok(hipMalloc((void **)&d_path, std::max<long long>(slot[np], 1) * sizeof(uint32_t)), "hipMalloc(paths)")) { rc = 1; break; }
+        if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
+        if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
+      }
+      g_last_ms += tm.stop();
+      if (!hip_ok(hipStreamSynchronize(g_stream), "viterbi kernels")) { rc = 1; break; }
+      if (!hip_ok(hipMemcpy(hll.data(), d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
+      std::memcpy(loglike + c.p0, hll.data(), np * sizeof(double));
+      if (wantPaths) {
+        hpath.resize(slot[np]);
+        if (!hip_ok(hipMemcpy(len.data(), d_len, np * sizeof(long long), hipMemcpyDeviceToHost), "D2H path lengths")) { rc = 1; break; }
+        if (slot[np] && !hip_ok(hipMemcpy(hpath.data(), d_path, slot[np] * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H paths")) { rc = 1; break; }
+        for (long long p = 0; p < np && !rc; ++p) {
+          long long n = len[p];
+          if (n == -1) n = 0;  // -inf end cell: no path (src/dpmatrix.defs.h:84)
+          if (n < 0) { set_error(n == -2 ? "Viterbi traceback exceeded its path bound" : "Viterbi traceback reached a dead end"); rc = 1; break; }
+          if (written + n > pathCap) { set_error("pathCap too small for the Viterbi paths of this batch"); rc = 1; break; }
+          const uint32_t *srcp = hpath.data() + slot[p + 1] - n;  // stored backwards from the slot end == start->end order
+          std::memcpy(pathEdges + written, srcp, n * sizeof(uint32_t));
+          written += n;
+          pathOff[c.p0 + p + 1] = written;
+        }
+      }
+    } while (0);
+    void *ptrs[] = {d_desc, pool, d_ll, d_slot, d_len, d_path};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (rc) break;
+  }
+  return rc;
+}
+
+// ---- Forward-Backward counts --------------------------------------------------------------------------------
+int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
+  if (!b || !counts) { set_error("null argument"); return 1; }
+  g_last_ms = 0.0;
+  g_last_kernel = "k_generic_fill_fwd<0>";
+  if (b->nPairs == 0) return 0;
+  const long long nT = b->m->nTrans;
+  std::vector<Chunk> chunks;
+  if (!plan_chunks(b, 2, chunks)) return 1;
+  double *d_counts = nullptr, *d_ll = nullptr;
+  MB_HIP(hipMalloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)));
+  MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
+  MB_HIP(hipMemsetAsync(d_counts, 0, std::max<long long>(nT, 1) * sizeof(double), g_stream));
+  int rc = 0;
+  Timer tm;
+  for (const Chunk &c : chunks) {
+    const long long np = c.p1 - c.p0;
+    PairDesc *d_desc = nullptr; double *fwd = nullptr, *bwd = nullptr;
+    do {
+      if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
+      if (!hip_ok(hipMalloc((void **)&fwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(forward pool)")) { rc = 1; break; }
+      if (!hip_ok(hipMalloc((void **)&bwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(backward pool)")) { rc = 1; break; }
+      long long maxc = 0;
+      for (long long p = c.p0; p < c.p1; ++p)
+        maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
+      tm.start();
+      if ((rc = launch_generic_fill(b->m, MB_FORWARD, d_desc, np, b->d_in, b->d_out, fwd, 0, g_stream))) break;
+      if ((rc = launch_generic_fill(b->m, MB_BACKWARD, d_desc, np, b->d_in, b->d_out, bwd, 0, g_stream))) break;
+      if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
+      if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
+      g_last_ms += tm.stop();
+      if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
+    } while (0);
+    void *ptrs[] = {d_desc, fwd, bwd};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (rc) break;
+  }
+  if (!rc) {
+    std::vector<double> hc(nT), hll(b->nPairs);
+    if (nT && !hip_ok(hipMemcpy(hc.data(), d_counts, nT * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) rc = 1;
+    if (!rc && !hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
+    if (!rc) {
+      for (long long e = 0; e < nT; ++e) counts[e] += hc[e];
+      double s = 0;
+      for (long long p = 0; p < b->nPairs; ++p) { s += hll[p]; if (loglike) loglike[p] = hll[p]; }  // loglike += forward.logLike()
+      if (loglikeSum) *loglikeSum += s;
+    }
+  }
+  (void)hipFree(d_counts); (void)hipFree(d_ll);
+  return rc;
+}
+
+// ---- single full matrix -------------------------------------------------------------------------------------
+int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
+            int32_t startState, double *cellsOut) {
+  if (!m || !cellsOut) { set_error("null argument"); return 1; }
+  if (mode < MB_FORWARD || mode > MB_BACKWARD) { set_error("mb_fill: unknown mode"); return 1; }
+  if (startState < 0 || startState >= m->S) { set_error("mb_fill: start state out of range"); return 1; }
+  const int64_t inOff[2] = {0, inLen}, outOff[2] = {0, outLen};
+  mb_batch *b = mb_batch_create(m, 1, in, inOff, out, outOff);
+  if (!b) return 1;
+  const long long n = b->totalCells;
+  double *pool = nullptr;
+  int rc = 0;
+  if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
+  if (!rc && !hip_ok(hipMalloc((void **)&pool, n * sizeof(double)), "hipMalloc(matrix)")) rc = 1;
+  if (!rc) rc = launch_generic_fill(m, mode, b->d_pairs, 1, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, g_stream);
+  if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+  if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
+  if (pool) (void)hipFree(pool);
+  mb_batch_destroy(b);
+  return rc;
+}
+
+// ---- host-buffer convenience wrappers -------------------------------------------------------------------------
+int mb_forward_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff, const int32_t *outTok,
+                     const int64_t *outOff, int flags, double *loglike) {
+  mb_batch *b = mb_batch_create(m, nPairs, inTok, inOff, outTok, outOff);
+  if (!b) return 1;
+  const int rc = mb_batch_forward(b, flags, loglike);
+  mb_batch_destroy(b);
+  return rc;
+}
+
+int mb_viterbi_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff, const int32_t *outTok,
+                     const int64_t *outOff, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
+  mb_batch *b = mb_batch_create(m, nPairs, inTok, inOff, outTok, outOff);
+  if (!b) return 1;
+  const int rc = mb_batch_viterbi(b, loglike, pathOff, pathEdges, pathCap);
+  mb_batch_destroy(b);
+  return rc;
+}
+
+int mb_counts_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff, const int32_t *outTok,
+                    const int64_t *outOff, double *counts, double *loglikeSum, double *loglike) {
+  mb_batch *b = mb_batch_create(m, nPairs, inTok, inOff, outTok, outOff);
+  if (!b) return 1;
+  const int rc = mb_batch_counts(b, counts, loglikeSum, loglike);
+  mb_batch_destroy(b);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,291 @@
+// mb_generic.hip -- generic HIP kernels: correct for ANY advancing machine, no LDS tiling.
+//
+// One workgroup per sequence pair; the lattice is swept along anti-diagonals; inside one anti-diagonal the
+// states of all its supercells are finalised silent-level by silent-level (one __syncthreads() per level).
+// The matrix lives in HBM in the reference's layout (src/dpmatrix.h:90-96), so this family is also what backs
+// mb_fill(), Backward matrices, the posterior-count sweep and the Viterbi traceback for every machine size.
+// The fast families (mb_small.hip: lanes = supercells; mb_medium.hip: lanes = states) are checked against it.
+#include "mb_internal.h"
+#include "mb_device_math.h"
+
+namespace mb {
+
+// ---- DPMatrix::accumulate over `incoming` (src/dpmatrix.h:101-115) -----------------------------------------
+template <int MODE>
+__device__ __forceinline__ double fold_in(const DevMachine &m, double acc, int d, int it, int ot,
+                                          const double *srcCell, bool silent) {
+  const int row = (d * (m.nIn + 1) + it) * (m.nOut + 1) + ot;
+  const int a0 = m.inOff[row], a1 = m.inOff[row + 1];
+  for (int a = a0; a < a1; ++a) {
+    const int s = (int)m.inSrc[a];
+    if (silent && s >= d) continue;  // silent self-loop on state 0: reads a not-yet-written (-inf) cell in the reference
+    const double v = srcCell[s] + m.inW[a];
+    acc = (MODE == MB_VITERBI) ? dmax(acc, v) : lse2_exact(acc, v);
+  }
+  return acc;
+}
+
+template <int MODE>
+__device__ __forceinline__ double fold_out(const DevMachine &m, double acc, int s, int it, int ot,
+                                           const double *dstCell, bool silent) {
+  const int row = (s * (m.nIn + 1) + it) * (m.nOut + 1) + ot;
+  const int a0 = m.outOff[row], a1 = m.outOff[row + 1];
+  for (int a = a0; a < a1; ++a) {
+    const int d = (int)m.outDst[a];
+    if (silent && d <= s) continue;
+    acc = lse2_exact(acc, dstCell[d] + m.outW[a]);
+  }
+  return acc;
+}
+
+// MappedForwardMatrix::fill (src/forward.defs.h:23-49) / ViterbiMatrix::fill (src/viterbi.cpp:18-43)
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_generic_fill_fwd(DevMachine m, const PairDesc *__restrict__ pairs,
+                                                           const int *__restrict__ inTok,
+                                                           const int *__restrict__ outTok,
+                                                           double *pool, int startState) {
+  const PairDesc pd = pairs[blockIdx.x];
+  const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  double *cells = pool + pd.cellBase;
+  for (int diag = 0; diag <= inLen + outLen; ++diag) {
+    const int iLo = diag > outLen ? diag - outLen : 0;
+    const int iHi = diag < inLen ? diag : inLen;
+    const int n = iHi - iLo + 1;
+    for (int lev = 0; lev < m.nLevF; ++lev) {
+      const int l0 = m.levFOff[lev], ns = m.levFOff[lev + 1] - l0;
+      for (int idx = threadIdx.x; idx < n * ns; idx += blockDim.x) {
+        const int k = idx / ns, j = idx - k * ns;
+        const int i = iLo + k, o = diag - i;
+        const int d = m.levFState[l0 + j];
+        const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+        double *cur = cells + ((long long)o * I + i) * S;
+        double acc = (i || o || d != startState) ? -INFINITY : 0.0;
+        if (i && o) acc = fold_in<MODE>(m, acc, d, it, ot, cur - (I + 1) * S, false);
+        if (i) acc = fold_in<MODE>(m, acc, d, it, 0, cur - S, false);
+        if (o) acc = fold_in<MODE>(m, acc, d, 0, ot, cur - I * S, false);
+        acc = fold_in<MODE>(m, acc, d, 0, 0, cur, true);
+        cur[d] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// BackwardMatrix::fill (src/backward.cpp:18-46)
+__global__ __launch_bounds__(1024) void k_generic_fill_bwd(DevMachine m, const PairDesc *__restrict__ pairs,
+                                                           const int *__restrict__ inTok,
+                                                           const int *__restrict__ outTok,
+                                                           double *pool) {
+  const PairDesc pd = pairs[blockIdx.x];
+  const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  double *cells = pool + pd.cellBase;
+  for (int diag = inLen + outLen; diag >= 0; --diag) {
+    const int iLo = diag > outLen ? diag - outLen : 0;
+    const int iHi = diag < inLen ? diag : inLen;
+    const int n = iHi - iLo + 1;
+    for (int lev = 0; lev < m.nLevB; ++lev) {
+      const int l0 = m.levBOff[lev], ns = m.levBOff[lev + 1] - l0;
+      for (int idx = threadIdx.x; idx < n * ns; idx += blockDim.x) {
+        const int k = idx / ns, j = idx - k * ns;
+        const int i = iLo + k, o = diag - i;
+        const int s = m.levBState[l0 + j];
+        const bool endIn = (i == inLen), endOut = (o == outLen);
+        const int it = endIn ? 0 : in[i], ot = endOut ? 0 : out[o];
+        double *cur = cells + ((long long)o * I + i) * S;
+        double acc = (endIn && endOut && s == S - 1) ? 0.0 : -INFINITY;
+        if (!endIn && !endOut) acc = fold_out<MB_FORWARD>(m, acc, s, it, ot, cur + (I + 1) * S, false);
+        if (!endIn) acc = fold_out<MB_FORWARD>(m, acc, s, it, 0, cur + S, false);
+        if (!endOut) acc = fold_out<MB_FORWARD>(m, acc, s, 0, ot, cur + I * S, false);
+        acc = fold_out<MB_FORWARD>(m, acc, s, 0, 0, cur, true);
+        cur[s] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// loglike[p] = cell(inLen,outLen,endState) (forward / Viterbi, src/forward.defs.h:51-55, viterbi.cpp:45-47)
+// or cell(0,0,startState) (backward, src/backward.cpp:48-50)
+__global__ void k_gather_loglike(const PairDesc *__restrict__ pairs, long long nPairs, const double *__restrict__ pool,
+                                 int S, int backward, double *__restrict__ loglike) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nPairs) return;
+  const PairDesc pd = pairs[p];
+  const long long n = (long long)(pd.inLen + 1) * (pd.outLen + 1) * S;
+  loglike[p] = backward ? pool[pd.cellBase] : pool[pd.cellBase + n - 1];
+}
+
+// BackwardMatrix::getCounts (src/backward.cpp:58-87): for every cell and every outgoing edge
+//   count[src][ti] += exp( F(i,o,src) - B(0,0,start) + (B(i',o',dst) + logW) )
+// The sweep has no dependencies, so it is a flat grid over (pair, supercell, state); per-workgroup partial
+// counts are kept in LDS when the transition table is small and flushed once with fp64 atomics.
+#define MB_COUNTS_LDS_MAX 8192
+__global__ __launch_bounds__(256) void k_generic_counts(DevMachine m, const PairDesc *__restrict__ pairs,
+                                                        const int *__restrict__ inTok, const int *__restrict__ outTok,
+                                                        const double *__restrict__ fwdPool,
+                                                        const double *__restrict__ bwdPool, long long nTrans,
+                                                        int chunksPerPair, double *__restrict__ counts) {
+  __shared__ double lcount[MB_COUNTS_LDS_MAX];
+  const bool useLds = nTrans <= MB_COUNTS_LDS_MAX;
+  if (useLds) {
+    for (int e = threadIdx.x; e < nTrans; e += blockDim.x) lcount[e] = 0.0;
+    __syncthreads();
+  }
+  const int p = blockIdx.x / chunksPerPair, chunk = blockIdx.x % chunksPerPair;
+  const PairDesc pd = pairs[p];
+  const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
+  const long long I = inLen + 1, O = outLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  const double *F = fwdPool + pd.cellBase, *B = bwdPool + pd.cellBase;
+  const double ll = B[0];  // backward.logLike() (src/backward.cpp:66)
+  if (ll > -INFINITY) {
+    const long long nItems = I * O * S;
+    for (long long idx = (long long)chunk * blockDim.x + threadIdx.x; idx < nItems;
+         idx += (long long)chunksPerPair * blockDim.x) {
+      const long long sc = idx / S;
+      const int s = (int)(idx - sc * S);
+      const int o = (int)(sc / I), i = (int)(sc - (long long)o * I);
+      const double f = F[idx];
+      if (!(f > -INFINITY)) continue;
+      const double logOdds = f - ll;
+      const bool endIn = (i == inLen), endOut = (o == outLen);
+      const int it = endIn ? 0 : in[i], ot = endOut ? 0 : out[o];
+      const double *cur = B + sc * S;
+      for (int grp = 0; grp < 4; ++grp) {
+        int kit, kot; const double *dc;
+        if (grp == 0) { if (endIn || endOut) continue; kit = it; kot = ot; dc = cur + (I + 1) * S; }
+        else if (grp == 1) { if (endIn) continue; kit = it; kot = 0; dc = cur + S; }
+        else if (grp == 2) { if (endOut) continue; kit = 0; kot = ot; dc = cur + I * S; }
+        else { kit = 0; kot = 0; dc = cur; }
+        const int row = (s * (m.nIn + 1) + kit) * (m.nOut + 1) + kot;
+        for (int a = m.outOff[row]; a < m.outOff[row + 1]; ++a) {
+          const double tll = dc[m.outDst[a]] + m.outW[a];
+          const double c = exp(logOdds + tll);
+          if (c != 0.0) {
+            if (useLds) atomicAdd(&lcount[m.outEid[a]], c);
+            else atomicAdd(&counts[m.outEid[a]], c);
+          }
+        }
+      }
+    }
+  }
+  if (useLds) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < nTrans; e += blockDim.x)
+      if (lcount[e] != 0.0) atomicAdd(&counts[e], lcount[e]);
+  }
+}
+
+// DPMatrix::traceBack with selectMaxTrans (src/dpmatrix.defs.h:82-110,171-174).  One wavefront per pair: the
+// candidate list of the current cell is enumerated in the reference order (match, in-only, out-only, silent;
+// within a group the `incoming` order), lanes take candidates round-robin, and the FIRST maximum wins
+// (max value, then lowest enumeration index) exactly as std::max_element does.
+// Edge ids are written backwards from the end of the pair's slot; pathLen[p] = number of transitions
+// (-1: end cell is -inf, -2: slot too small, -3: dead end).
+__global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *__restrict__ pairs,
+                                                  const int *__restrict__ inTok, const int *__restrict__ outTok,
+                                                  const double *__restrict__ pool,
+                                                  const long long *__restrict__ slotOff,
+                                                  uint32_t *__restrict__ pathBuf, long long *__restrict__ pathLen) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const PairDesc pd = pairs[p];
+  const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  const double *cells = pool + pd.cellBase;
+  const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  int i = inLen, o = outLen, s = S - 1;
+  if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
+  long long n = 0;
+  while (i > 0 || o > 0 || s != 0) {
+    const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+    const double *cur = cells + ((long long)o * I + i) * S;
+    double best = -INFINITY; int bestIdx = 0x7fffffff; int bestA = -1;
+    int base = 0;
+    for (int grp = 0; grp < 4; ++grp) {
+      int kit, kot; const double *sc;
+      if (grp == 0) { if (!(i && o)) continue; kit = it; kot = ot; sc = cur - (I + 1) * S; }
+      else if (grp == 1) { if (!i) continue; kit = it; kot = 0; sc = cur - S; }
+      else if (grp == 2) { if (!o) continue; kit = 0; kot = ot; sc = cur - I * S; }
+      else { kit = 0; kot = 0; sc = cur; }
+      const int row = (s * (m.nIn + 1) + kit) * (m.nOut + 1) + kot;
+      const int a0 = m.inOff[row], a1 = m.inOff[row + 1];
+      for (int a = a0 + lane; a < a1; a += 64) {
+        const int src = (int)m.inSrc[a];
+        // a silent self-loop on state 0 is a genuine candidate in the reference's traceback (it reads the final
+        // cell value); keep it: v = cell + w can only tie or lose against the real predecessor unless w >= 0.
+        const double v = sc[src] + m.inW[a];
+        const int idx = base + (a - a0);
+        if (bestA < 0 || v > best || (v == best && idx < bestIdx)) { best = v; bestIdx = idx; bestA = a; }
+      }
+      base += a1 - a0;
+    }
+    // wave-wide arg-max with first-index tie-break; lanes without a candidate carry bestA = -1
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bestIdx, off), oa = __shfl_xor(bestA, off);
+      const bool take = oa >= 0 && (bestA < 0 || ov > best || (ov == best && oi < bestIdx));
+      if (take) { best = ov; bestIdx = oi; bestA = oa; }
+    }
+    if (bestA < 0) { if (lane == 0) pathLen[p] = -3; return; }
+    if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
+    const uint32_t eid = m.inEid[bestA];
+    if (lane == 0) pathBuf[slot0 + cap - 1 - n] = eid;
+    ++n;
+    if (m.eInTok[eid]) --i;
+    if (m.eOutTok[eid]) --o;
+    s = (int)m.inSrc[bestA];
+  }
+  if (lane == 0) pathLen[p] = n;
+}
+
+// ---- launch helpers (host) -----------------------------------------------------------------------------------
+int launch_generic_fill(const mb_machine *m, int mode, const PairDesc *d_pairs, long long nPairs, const int *d_in,
+                        const int *d_out, double *d_pool, int startState, hipStream_t st) {
+  if (nPairs == 0) return 0;
+  const dim3 grid((unsigned)nPairs), block(m->S * 64 >= 1024 ? 1024 : 256);
+  if (mode == MB_FORWARD)
+    hipLaunchKernelGGL(k_generic_fill_fwd<MB_FORWARD>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, startState);
+  else if (mode == MB_VITERBI)
+    hipLaunchKernelGGL(k_generic_fill_fwd<MB_VITERBI>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, 0);
+  else
+    hipLaunchKernelGGL(k_generic_fill_bwd, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool);
+  return hip_ok(hipGetLastError(), "generic fill launch") ? 0 : 1;
+}
+
+int launch_gather_loglike(const PairDesc *d_pairs, long long nPairs, const double *d_pool, int S, int backward,
+                          double *d_loglike, hipStream_t st) {
+  if (nPairs == 0) return 0;
+  hipLaunchKernelGGL(k_gather_loglike, dim3((unsigned)((nPairs + 255) / 256)), dim3(256), 0, st, d_pairs, nPairs, d_pool, S,
+                     backward, d_loglike);
+  return hip_ok(hipGetLastError(), "gather launch") ? 0 : 1;
+}
+
+int launch_generic_counts(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, long long maxPairCells,
+                          const int *d_in, const int *d_out, const double *d_fwd, const double *d_bwd, double *d_counts,
+                          hipStream_t st) {
+  if (nPairs == 0) return 0;
+  // enough workgroups to fill the chip (256 CUs x 8), bounded by the work one pair offers
+  long long chunks = (2048 + nPairs - 1) / nPairs;
+  const long long maxChunks = (maxPairCells + 255) / 256;
+  if (chunks > maxChunks) chunks = maxChunks;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(k_generic_counts, dim3((unsigned)(nPairs * chunks)), dim3(256), 0, st, m->dev, d_pairs, d_in, d_out,
+                     d_fwd, d_bwd, m->nTrans, (int)chunks, d_counts);
+  return hip_ok(hipGetLastError(), "counts launch") ? 0 : 1;
+}
+
+int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_in, const int *d_out,
+                     const double *d_pool, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen,
+                     hipStream_t st) {
+  if (nPairs == 0) return 0;
+  hipLaunchKernelGGL(k_traceback, dim3((unsigned)nPairs), dim3(64), 0, st, m->dev, d_pairs, d_in, d_out, d_pool, d_slotOff,
+                     d_pathBuf, d_pathLen);
+  return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
+}
+
+}  // namespace mb

@@ -1,0 +1,93 @@
+// mb_internal.h -- structures shared by the host-side machine compiler and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "mbhip.h"
+
+namespace mb {
+
+// ---- device view of a flattened machine (all pointers are device memory) --------------------------------
+// Label key of an edge: key(inTok,outTok) = inTok*(nOut+1) + outTok over the (nIn+1)x(nOut+1) grid incl. epsilon.
+// CSR row = state*K + key.  Edge arrays are permuted into the reference's iteration order (see mbhip.h).
+struct DevMachine {
+  int S, nIn, nOut, K;
+  int nLevF, nLevB;          // number of silent levels, forward / backward direction
+  // incoming view (Forward, Viterbi, traceback):   src/eval.h:66-68 `incoming`
+  const int *inOff;          // [S*K + 1]
+  const uint32_t *inSrc;     // [nTrans] source state
+  const double *inW;         // [nTrans] log weight
+  const uint32_t *inEid;     // [nTrans] global edge id
+  // outgoing view (Backward, counts):               src/eval.h:66-68 `outgoing`
+  const int *outOff;         // [S*K + 1]
+  const uint32_t *outDst;    // [nTrans]
+  const double *outW;        // [nTrans]
+  const uint32_t *outEid;    // [nTrans]
+  const uint16_t *eInTok, *eOutTok;  // [nTrans] labels by global edge id (traceback steps)
+  // states grouped by silent level
+  const int *levFOff, *levFState;    // [nLevF+1], [S]
+  const int *levBOff, *levBState;    // [nLevB+1], [S]
+};
+
+// One sequence pair of a batch.
+struct PairDesc {
+  long long inBase, outBase;   // offsets into the batch token arrays
+  int inLen, outLen;
+  long long cellBase;          // offset (in doubles) of this pair's matrix inside a matrix pool
+};
+
+}  // namespace mb
+
+// ---- host objects behind the opaque C handles --------------------------------------------------------------
+struct mb_machine {
+  int S = 0, nIn = 0, nOut = 0, K = 0;
+  long long nTrans = 0;
+  // host copies (global edge id order)
+  std::vector<uint32_t> src, dst;
+  std::vector<uint16_t> inTok, outTok;
+  std::vector<double> logW;
+  // derived on host
+  std::vector<int> inOff, outOff;
+  std::vector<uint32_t> inPerm, outPerm;   // CSR position -> global edge id
+  std::vector<int> levF, levB;             // per-state level
+  std::vector<int> levFOff, levFState, levBOff, levBState;
+  int nLevF = 0, nLevB = 0;
+  bool hasMatch = false, hasIns = false, hasDel = false;
+  int maxInDeg = 0;
+  // device arrays
+  int *d_inOff = nullptr, *d_outOff = nullptr;
+  uint32_t *d_inSrc = nullptr, *d_inEid = nullptr, *d_outDst = nullptr, *d_outEid = nullptr;
+  double *d_inW = nullptr, *d_outW = nullptr;
+  uint16_t *d_eInTok = nullptr, *d_eOutTok = nullptr;
+  int *d_levFOff = nullptr, *d_levFState = nullptr, *d_levBOff = nullptr, *d_levBState = nullptr;
+  mb::DevMachine dev{};
+  void *fast = nullptr;   // kernel-family specific compiled tables (owned; see mb_fast_*.hip)
+};
+
+struct mb_batch {
+  mb_machine *m = nullptr;
+  long long nPairs = 0;
+  std::vector<mb::PairDesc> pairs;   // host copy, cellBase for a fully materialised pool
+  long long totalCells = 0;          // sum (inLen+1)(outLen+1)S
+  long long maxPairCells = 0;
+  int *d_in = nullptr, *d_out = nullptr;
+  mb::PairDesc *d_pairs = nullptr;
+  long long nInTokTotal = 0, nOutTokTotal = 0;
+};
+
+namespace mb {
+void set_error(const std::string &msg);
+bool hip_ok(hipError_t e, const char *what);
+extern hipStream_t g_stream;
+extern int g_kernel_choice;
+extern size_t g_mem_budget;
+#define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)
+
+// host-side machine compiler (mb_machine.cpp)
+bool compile_machine(mb_machine *m, std::string *err);
+bool upload_machine(mb_machine *m);
+bool upload_weights(mb_machine *m);
+void free_machine_device(mb_machine *m);
+}  // namespace mb

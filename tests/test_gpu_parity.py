@@ -1,0 +1,219 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C-ABI, against the CPU oracle on the same inputs.
+
+Bars: Viterbi matrices, log-likelihoods and tracebacks are BIT-EXACT (integer/index work + one rounded fp64 add per
+candidate); Forward/Backward cells and log-likelihoods agree with the oracle's exact-logsumexp mode to REL_EXACT and
+with the reference's table mode to REL_TABLE (the north-star tolerance is 1e-4 relative; both bars are far tighter);
+posterior counts agree to COUNT_TOL (summation order differs: fp64 atomics).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_json, load_matrix_json
+from machineboss_amd.seqgen import synth_batch, synth_tokens
+
+pytestmark = pytest.mark.gpu
+
+REL_EXACT = 1e-11   # device exp/log1p vs libm, accumulated over the lattice
+ABS_TABLE = 2e-5    # table-interpolation slack measured in SURVEY.md section 6 (<= 5e-6 abs)
+REL_TABLE = 1e-6
+COUNT_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from machineboss_amd import capi as c
+    if c.device_count() == 0:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    return c
+
+
+def close(a, b, rel, abs_=0.0):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    both_ninf = np.isneginf(a) & np.isneginf(b)
+    fin = np.isfinite(a) & np.isfinite(b)
+    if not np.all(both_ninf | fin):
+        return False
+    return bool(np.all(np.abs(a[fin] - b[fin]) <= abs_ + rel * np.abs(b[fin])))
+
+
+CASES = [  # (preset?, name, params, inLen, outLen)
+    (False, "bitnoise", "io", 3, 3),
+    (False, "bitstutter-noise", "io", 5, 9),
+    (True, "dnapsw", None, 37, 53),
+    (True, "protpsw", None, 50, 50),
+    (True, "psw2dna", None, 11, 40),
+    (True, "translate", None, 6, 25),
+]
+
+
+def setup_case(machines, case, seed=7):
+    preset, name, params, il, ol = case
+    if params == "io":
+        m, em = machines(name, load_json("io", "params.json"))
+    else:
+        m, em = machines(name, None, useDefaults=True, preset=preset)
+    i, o = synth_tokens(seed, il, ol, em.nInTok, em.nOutTok)
+    return m, em, i, o
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[1] for c in CASES])
+def test_fill_matrices(capi, oracle_mod, machines, case):
+    m, em, i, o = setup_case(machines, case)
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    assert list(dm.edge_order(0)) == list(om.incoming_order()) and list(dm.edge_order(1)) == list(om.outgoing_order())
+    # Viterbi: bit-exact
+    V = dm.fill(capi.MB_VITERBI, i, o)
+    assert np.array_equal(V, om.viterbi(i, o))
+    # Forward / Backward
+    F = dm.fill(capi.MB_FORWARD, i, o)
+    assert close(F, om.forward(i, o, oracle_mod.SUM_EXACT), REL_EXACT)
+    assert close(F, om.forward(i, o, oracle_mod.SUM_TABLE), REL_TABLE, ABS_TABLE)
+    B = dm.fill(capi.MB_BACKWARD, i, o)
+    assert close(B, om.backward(i, o, oracle_mod.SUM_EXACT), REL_EXACT)
+    assert close(B[0, 0, 0], F[-1, -1, -1], 1e-10)   # posterior LL = Forward LL (js/webgpu/test/test-cpu.mjs invariant)
+    assert np.all(V <= F + 1e-9)                       # Viterbi <= Forward
+
+
+def test_forward_start_state(capi, oracle_mod, machines):
+    """ForwardMatrix 4-argument constructor: caller-chosen start state (src/forward.defs.h:16-21,36)."""
+    m, em, i, o = setup_case(machines, CASES[2])
+    F = capi.DeviceMachine(em).fill(capi.MB_FORWARD, i, o, startState=2)
+    assert close(F, oracle_mod.OracleMachine(em).forward(i, o, oracle_mod.SUM_EXACT, startState=2), REL_EXACT)
+
+
+def test_reference_goldens_through_gpu(capi, machines):
+    """The reference's own expected outputs, reproduced by the HIP path (Makefile:493-522,567-572)."""
+    from machineboss_amd.dp import ForwardMatrix, BackwardMatrix, ViterbiMatrix, MachineCounts, SeqPair
+    p = load_json("io", "params.json")
+    m, em = machines("bitnoise", p)
+    sp = SeqPair.fromJson(load_json("io", "tiny.json"))
+    fwd, bwd = ForwardMatrix(em, sp), BackwardMatrix(em, sp)
+    for mat, name in ((fwd, "fwd"), (bwd, "back")):
+        for (ip, op, _), v in load_matrix_json("expect", name + "-bitnoise-params-tiny.json").items():
+            got = mat.cell(ip, op, 0)
+            assert (got == v) if not math.isfinite(v) else float("%.5g" % got) == v
+    mc = MachineCounts(em, [sp])
+    assert [[float("%.6g" % x) for x in row] for row in mc.count] == load_json("expect", "fwdback-bitnoise-params-tiny.json")
+    mc2 = MachineCounts(em, [SeqPair(list("101"), list("001"))])
+    assert {k: float("%.6g" % v) for k, v in mc2.paramCounts(m, p).items()} == load_json("expect", "counts.json")
+    # Viterbi alignment through silent states
+    m2, em2 = machines("bitstutter-noise", p)
+    sp2 = SeqPair.fromJson(load_json("io", "difflen.json")[0])
+    path = ViterbiMatrix(em2, sp2).path(m2)
+    exp = load_json("expect", "align-stutter-noise-difflen.json")[0]["meta"]["path"]["trans"]
+    got = [dict({"to": t.dest}, **({"in": t.inp} if t.inp else {}), **({"out": t.out} if t.out else {})) for t in path.trans]
+    assert got == [{k: v for k, v in tr.items() if k in ("to", "in", "out")} for tr in exp]
+
+
+@pytest.mark.parametrize("name,il,ol,n", [("dnapsw", 60, 45, 9), ("protpsw", 33, 41, 6), ("psw2dna", 9, 30, 5)])
+def test_batch_api_ragged(capi, oracle_mod, machines, name, il, ol, n):
+    """Batches with ragged lengths, including empty sequences on either tape."""
+    m, em = machines(name, None, useDefaults=True, preset=True)
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(3)
+    pairs = []
+    for k in range(n):
+        a = 0 if k == 1 else int(rng.randint(1, il + 1)); b = 0 if k in (1, 2) else int(rng.randint(1, ol + 1))
+        pairs.append(synth_tokens(100 + k, a, b, em.nInTok, em.nOutTok))
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    assert b.cells() == sum((len(x) + 1) * (len(y) + 1) * em.nStates for x, y in pairs)
+    for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
+        ll = b.forward(flags)
+        ref = [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs]
+        assert close(ll, ref, 1e-10)
+        assert close(ll, [om.loglike(x, y) for x, y in pairs], 1e-4)   # north-star tolerance vs the table build
+    vll, off, edges = b.viterbi()
+    for k, (x, y) in enumerate(pairs):
+        V = om.viterbi(x, y)
+        assert vll[k] == V[-1, -1, -1]                                   # bit-exact
+        got = edges[off[k]:off[k + 1]]
+        if V[-1, -1, -1] > -math.inf:
+            assert np.array_equal(got, om.traceback(x, y, V))          # bit-exact traceback incl. tie-breaking
+        else:
+            assert len(got) == 0
+    counts, s, cll = b.counts()
+    ref_c = np.zeros(em.nTransitions); ref_s = 0.0
+    for x, y in pairs:
+        l = om.loglike(x, y, oracle_mod.SUM_EXACT)
+        if l > -math.inf:
+            ref_s += om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
+        else:
+            ref_s += l
+    assert close(counts, ref_c, COUNT_TOL, 1e-12)
+    assert close(s, ref_s, 1e-10) if math.isfinite(ref_s) else s == ref_s
+
+
+def test_viterbi_ties_uniform_params(capi, oracle_mod, machines):
+    """Uniform default parameters create many exact ties; tie-breaking must follow max_element (quirk Q4)."""
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    x = np.ones(40, np.int32); y = np.ones(40, np.int32)   # homopolymers: every alignment of equal shape ties
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+    vll, off, edges = b.viterbi()
+    V = om.viterbi(x, y)
+    assert vll[0] == V[-1, -1, -1] and np.array_equal(edges, om.traceback(x, y, V))
+
+
+def test_set_weights(capi, oracle_mod, machines):
+    """mb_machine_set_weights: new parameters, same topology (one call per EM iteration, src/fitter.cpp:28-29)."""
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    x, y = synth_tokens(5, 30, 30, 4, 4)
+    lw = em.logWeight.copy()
+    lw[np.isfinite(lw)] *= 1.25
+    dm.set_weights(lw)
+    om = oracle_mod.OracleMachine(em.withLogWeights(lw))
+    assert np.array_equal(dm.fill(capi.MB_VITERBI, x, y), om.viterbi(x, y))
+    assert close(dm.fill(capi.MB_FORWARD, x, y), om.forward(x, y, oracle_mod.SUM_EXACT), REL_EXACT)
+
+
+def test_errors(capi, machines):
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    with pytest.raises(capi.MbError, match="tokenize"):
+        capi.DeviceBatch.from_pairs(dm, [(np.array([5], np.int32), np.array([1], np.int32))])
+    with pytest.raises(capi.MbError, match="tokenize"):
+        capi.DeviceBatch.from_pairs(dm, [(np.array([0], np.int32), np.array([1], np.int32))])
+    # non-advancing machine is refused at creation (src/eval.cpp:44)
+    bad = em.withLogWeights(em.logWeight)
+    bad.src = em.src.copy(); bad.dst = em.dst.copy()
+    e = int(np.where((em.inTok == 0) & (em.outTok == 0) & (em.src >= 1))[0][0])
+    bad.dst[e] = bad.src[e]
+    with pytest.raises(capi.MbError, match="topologically"):
+        capi.DeviceMachine(bad)
+    # empty batch is fine
+    b = capi.DeviceBatch.from_pairs(dm, [])
+    assert len(b.forward()) == 0
+
+
+def test_unreachable_is_minus_infinity(capi, machines):
+    """-L on a pair the machine cannot produce prints "-Infinity" (t/expect/tiny_uc_fail.json behaviour)."""
+    m, em = machines("bitstutter-noise", load_json("io", "params.json"))
+    dm = capi.DeviceMachine(em)
+    x = em.inputTokenizer.tokenize(list("01")); y = np.zeros(0, np.int32)   # stutter machine must emit >= 1 per input
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+    assert b.forward()[0] == -math.inf
+    vll, off, edges = b.viterbi()
+    assert vll[0] == -math.inf and off[1] == 0
+
+
+@pytest.mark.parametrize("idx", [0, 1, 3])
+def test_survey_anchors_gpu(capi, machines, idx):
+    """Benchmark-scale reference outputs through the GPU path: Forward within 1e-4 relative
+    (observed ~1e-8), Viterbi log-likelihood and path length exact at 10 significant digits."""
+    a = load_json("survey_anchors.json")["anchors"][idx]
+    m, em = machines(a["preset"], None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    i, o = synth_tokens(a["seed"], a["inLen"], a["outLen"], em.nInTok, em.nOutTok)
+    b = capi.DeviceBatch.from_pairs(dm, [(i, o)])
+    ll = b.forward()[0]
+    assert abs(ll - a["forward"]) <= 1e-4 * abs(a["forward"])
+    if a["forward_exact"] is not None:
+        assert float("%.9g" % ll) == float("%.9g" % a["forward_exact"])
+    vll, off, edges = b.viterbi()
+    assert float("%.10g" % vll[0]) == a["viterbi"] and off[1] == a["pathLen"]

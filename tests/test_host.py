@@ -1,0 +1,101 @@
+"""CPU tests of the host logic and of the C-ABI library's export surface (no compute calls)."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_path, load_json
+from machineboss_amd.machine import Machine, MachineError, evalWeight
+from machineboss_amd.evalmachine import EvaluatedMachine, Tokenizer
+
+
+def test_weight_expressions():
+    d = {"p": 0.25, "q": {"not": "p"}, "r": {"*": ["p", "q"]}}
+    assert evalWeight("q", d) == 0.75
+    assert evalWeight("r", d) == 0.25 * 0.75
+    assert evalWeight({"/": [1, {"-": [1, "p"]}]}, d) == 1 / 0.75
+    assert evalWeight({"geomsum": "p"}, d) == 1 / 0.75
+    assert evalWeight({"exp": {"log": "p"}}, d) == math.exp(math.log(0.25))
+    assert evalWeight(True, d) == 1.0 and evalWeight(None, d) == 0.0
+    with pytest.raises(MachineError):
+        evalWeight("zz", d)
+    with pytest.raises(MachineError):
+        evalWeight({"p2": "p"}, d)
+    with pytest.raises(MachineError):  # cyclic definition
+        evalWeight("a", {"a": {"not": "a"}})
+
+
+def test_default_params_and_alphabets():
+    m = Machine.fromFile(golden_path("preset", "dnapsw.json"))
+    p = m.getParamDefs(True)
+    assert p["gapOpen"] == 0.5 and p["eqmA"] == 0.25 and p["subAC"] == 0.25
+    assert m.inputAlphabet() == ["A", "C", "G", "T"] and m.outputAlphabet() == ["A", "C", "G", "T"]
+    em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    assert em.nStates == 8 and em.nTransitions == 34
+    # parameter-free constructor: all log-weights zero (src/eval.cpp:59)
+    em0 = EvaluatedMachine.fromMachine(m)
+    assert not em0.logWeight.any()
+    with pytest.raises(MachineError):
+        EvaluatedMachine.fromMachine(m, {})  # parameters missing
+
+
+def test_state_references_and_errors():
+    j = {"state": [{"id": "a", "trans": [{"to": "b", "in": "x"}]}, {"id": "b"}]}
+    m = Machine.fromJson(j)
+    assert m.state[0].trans[0].dest == 1
+    with pytest.raises(MachineError):
+        Machine.fromJson({"state": [{"id": "a", "trans": [{"to": "zz"}]}]})
+    with pytest.raises(MachineError):
+        Machine.fromJson({"state": [{"n": 1}]})
+    # not advancing: silent edge backwards from a state >= 1 (src/machine.cpp:758-764)
+    bad = Machine.fromJson({"state": [{"trans": [{"to": 1}]}, {"trans": [{"to": 1}]}]})
+    assert not bad.isAdvancingMachine()
+    with pytest.raises(MachineError):
+        EvaluatedMachine.fromMachine(bad, {})
+
+
+def test_tokenizer():
+    t = Tokenizer(["A", "C"])
+    assert list(t.tokenize(["C", "A"])) == [2, 1] and t.detokenize([1, 2]) == ["A", "C"]
+    assert not t.canTokenize(["G"])
+    with pytest.raises(MachineError):
+        t.tokenize(["G"])
+
+
+def test_abi_exports_match_header():
+    """The shared library loads and exports every symbol include/mbhip.h declares."""
+    from machineboss_amd import build, capi
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "mbhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mb_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Product path must fail loudly when there is no device (this test only asserts on GPU-less hosts)."""
+    from machineboss_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    m = Machine.fromFile(golden_path("machine", "bitnoise.json"))
+    em = EvaluatedMachine.fromMachine(m, load_json("io", "params.json"))
+    with pytest.raises(capi.MbError):
+        capi.DeviceMachine(em)
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing in the package may import, link or dlopen it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|libmboracle|\bmbo_[a-z]|mb_oracle\.c", re.M)
+    pkg = os.path.join(ROOT, "machineboss_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(txt), (dirpath, f)
