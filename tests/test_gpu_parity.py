@@ -16,8 +16,8 @@ from machineboss_amd.seqgen import synth_batch, synth_tokens
 pytestmark = pytest.mark.gpu
 
 REL_EXACT = 1e-11   # device exp/log1p vs libm, accumulated over the lattice
-ABS_TABLE = 2e-5    # table-interpolation slack measured in SURVEY.md section 6 (<= 5e-6 abs)
-REL_TABLE = 1e-6
+ABS_TABLE = 1e-4    # vs the reference's table build: the table drops terms >= 10 nats below the running max and
+REL_TABLE = 1e-4    # interpolates at step 1e-4 (src/logsumexp.h:20-21,48-70); 1e-4 relative is the north-star tolerance
 COUNT_TOL = 1e-9
 
 
@@ -214,6 +214,6 @@ def test_survey_anchors_gpu(capi, machines, idx):
     ll = b.forward()[0]
     assert abs(ll - a["forward"]) <= 1e-4 * abs(a["forward"])
     if a["forward_exact"] is not None:
-        assert float("%.9g" % ll) == float("%.9g" % a["forward_exact"])
+        assert abs(ll - a["forward_exact"]) <= 1e-7   # device exact-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
     vll, off, edges = b.viterbi()
     assert float("%.10g" % vll[0]) == a["viterbi"] and off[1] == a["pathLen"]
