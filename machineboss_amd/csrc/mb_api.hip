@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "mb_internal.h"
+#include "mb_medium.h"
 
 namespace mb {
 
@@ -92,14 +93,72 @@ static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &ou
 }
 
 // Upload PairDescs of a chunk with cellBase rebased to the chunk's pool.
-static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_out) {
-  std::vector<PairDesc> tmp(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
+static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_out, std::vector<PairDesc> &tmp) {
+  tmp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
   long long base = 0;
   for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S; }
   MB_HIP(hipMalloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
   MB_HIP(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream));
   MB_HIP(hipStreamSynchronize(g_stream));
   return 0;
+}
+
+
+// ---- kernel-family state attached to a machine ------------------------------------------------------------
+struct FastState {
+  bool tried = false, mediumOk = false;
+  int G = 0;
+  MedProgram fwd, bwd;
+  MedGeom geoF, geoB;
+};
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+static FastState *fast_state(mb_machine *m) {
+  if (!m->fast) m->fast = new FastState();
+  FastState *f = (FastState *)m->fast;
+  if (!f->tried) {
+    f->tried = true;
+    // lanes = states pays once a supercell has clearly more states than a lane group; tiny machines stay on the
+    // generic family until the lanes = supercells family exists.
+    if (m->S > 16 && m->S <= 4096) {
+      int G = env_int("MB_MEDIUM_G", 0);
+      if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 384 ? 2 : 4);
+      f->G = G;
+      f->mediumOk = medium_build(m, false, G, f->fwd) && medium_build(m, true, G, f->bwd) &&
+                    medium_geometry(m, f->fwd, f->geoF) && medium_geometry(m, f->bwd, f->geoB);
+    }
+  }
+  return f;
+}
+
+static bool use_medium(mb_machine *m) {
+  if (g_kernel_choice == 1) return false;
+  FastState *f = fast_state(m);
+  if (g_kernel_choice == 3 && !f->mediumOk) return false;
+  return f->mediumOk;
+}
+
+// Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
+static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
+                      const int *d_out, double *pool, int startState) {
+  if (use_medium(m)) {
+    FastState *f = fast_state(m);
+    const bool bw = mode == MB_BACKWARD;
+    MedProgram &P = bw ? f->bwd : f->fwd;
+    const int saved = P.dev.startNode;
+    if (mode == MB_FORWARD) P.dev.startNode = startState;
+    g_last_kernel = mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>";
+    const int rc = medium_fill_materialised(m, P, bw ? f->geoB : f->geoF, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, d_desc, hp,
+                                            d_in, d_out, pool, g_stream);
+    P.dev.startNode = saved;
+    return rc;
+  }
+  g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
+  return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream);
 }
 
 }  // namespace mb
@@ -150,11 +209,21 @@ mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, 
 int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
   if (!m) { set_error("null machine"); return 1; }
   m->logW.assign(logWeight, logWeight + m->nTrans);
-  return upload_weights(m) ? 0 : 1;
+  if (!upload_weights(m)) return 1;
+  if (m->fast) {
+    FastState *f = (FastState *)m->fast;
+    if (f->mediumOk && !(medium_refresh_weights(m, f->fwd) && medium_refresh_weights(m, f->bwd))) return 1;
+  }
+  return 0;
 }
 
 void mb_machine_destroy(mb_machine *m) {
   if (!m) return;
+  if (m->fast) {
+    FastState *f = (FastState *)m->fast;
+    medium_free(f->fwd); medium_free(f->bwd);
+    delete f;
+  }
   free_machine_device(m);
   delete m;
 }
@@ -219,27 +288,49 @@ int64_t mb_batch_cells(const mb_batch *b) { return b ? b->totalCells : 0; }
 
 // ---- Forward ------------------------------------------------------------------------------------------------
 static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
-  (void)flags;
   g_last_ms = 0.0;
-  g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : "k_generic_fill_fwd<0>";
+  g_last_kernel = "";
   if (b->nPairs == 0) return 0;
-  std::vector<Chunk> chunks;
-  if (!plan_chunks(b, 1, chunks)) return 1;
+  mb_machine *m = b->m;
   double *d_ll = nullptr;
   MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
   Timer tm;
-  for (const Chunk &c : chunks) {
-    PairDesc *d_desc = nullptr; double *pool = nullptr;
-    if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
-    if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { (void)hipFree(d_desc); rc = 1; break; }
-    tm.start();
-    rc = launch_generic_fill(b->m, mode, d_desc, c.p1 - c.p0, b->d_in, b->d_out, pool, 0, g_stream);
-    if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, b->m->S, 0, d_ll + c.p0, g_stream);
-    g_last_ms += tm.stop();
-    if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
-    (void)hipFree(pool); (void)hipFree(d_desc);
-    if (rc) break;
+  if (mode == MB_FORWARD && (flags & MB_ROLLING) && use_medium(m)) {
+    // RollingOutputForwardMatrix: no matrix in HBM, only two halo columns per pair
+    FastState *f = fast_state(m);
+    std::vector<long long> hb(b->nPairs);
+    long long tot = 0;
+    for (long long p = 0; p < b->nPairs; ++p) { hb[p] = tot; tot += 2ll * (b->pairs[p].outLen + 1) * m->S; }
+    double *d_halo = nullptr; long long *d_hb = nullptr;
+    do {
+      if (!hip_ok(hipMalloc((void **)&d_halo, std::max<long long>(tot, 1) * sizeof(double)), "hipMalloc(halo columns)")) { rc = 1; break; }
+      if (!hip_ok(hipMalloc((void **)&d_hb, b->nPairs * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
+      if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
+      g_last_kernel = "k_medium_tile<0>";
+      tm.start();
+      rc = medium_forward_rolling(m, f->fwd, f->geoF, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
+      g_last_ms += tm.stop();
+      if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
+    } while (0);
+    if (d_halo) (void)hipFree(d_halo);
+    if (d_hb) (void)hipFree(d_hb);
+  } else {
+    std::vector<Chunk> chunks;
+    if (!plan_chunks(b, 1, chunks)) { (void)hipFree(d_ll); return 1; }
+    for (const Chunk &c : chunks) {
+      PairDesc *d_desc = nullptr; double *pool = nullptr;
+      std::vector<PairDesc> hp;
+      if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
+      if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { (void)hipFree(d_desc); rc = 1; break; }
+      tm.start();
+      rc = fill_chunk(m, mode, d_desc, hp, b->d_in, b->d_out, pool, 0);
+      if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, m->S, 0, d_ll + c.p0, g_stream);
+      g_last_ms += tm.stop();
+      if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+      (void)hipFree(pool); (void)hipFree(d_desc);
+      if (rc) break;
+    }
   }
   if (!rc && !hip_ok(hipMemcpy(loglike, d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
   (void)hipFree(d_ll);
@@ -262,7 +353,7 @@ int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen
 int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
   if (!b || !loglike) { set_error("null argument"); return 1; }
   g_last_ms = 0.0;
-  g_last_kernel = "k_generic_fill_fwd<1>";
+  g_last_kernel = "";
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
   if (pathOff) pathOff[0] = 0;
   if (b->nPairs == 0) return 0;
@@ -278,12 +369,13 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
     std::vector<long long> slot(np + 1, 0), len(np, 0);
     std::vector<uint32_t> hpath;
     std::vector<double> hll(np);
+    std::vector<PairDesc> hp;
     do {
-      if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
+      if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
       if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       tm.start();
-      if ((rc = launch_generic_fill(b->m, MB_VITERBI, d_desc, np, b->d_in, b->d_out, pool, 0, g_stream))) break;
+      if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0))) break;
       if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
       if (wantPaths) {
         for (long long p = 0; p < np; ++p)
@@ -325,7 +417,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
   if (!b || !counts) { set_error("null argument"); return 1; }
   g_last_ms = 0.0;
-  g_last_kernel = "k_generic_fill_fwd<0>";
+  g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   const long long nT = b->m->nTrans;
   std::vector<Chunk> chunks;
@@ -339,16 +431,17 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   for (const Chunk &c : chunks) {
     const long long np = c.p1 - c.p0;
     PairDesc *d_desc = nullptr; double *fwd = nullptr, *bwd = nullptr;
+    std::vector<PairDesc> hp;
     do {
-      if ((rc = upload_chunk_descs(b, c, &d_desc))) break;
+      if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
       if (!hip_ok(hipMalloc((void **)&fwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(forward pool)")) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&bwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(backward pool)")) { rc = 1; break; }
       long long maxc = 0;
       for (long long p = c.p0; p < c.p1; ++p)
         maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
       tm.start();
-      if ((rc = launch_generic_fill(b->m, MB_FORWARD, d_desc, np, b->d_in, b->d_out, fwd, 0, g_stream))) break;
-      if ((rc = launch_generic_fill(b->m, MB_BACKWARD, d_desc, np, b->d_in, b->d_out, bwd, 0, g_stream))) break;
+      if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0))) break;
+      if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0))) break;
       if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
       if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
       g_last_ms += tm.stop();
@@ -387,7 +480,7 @@ int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int
   int rc = 0;
   if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
   if (!rc && !hip_ok(hipMalloc((void **)&pool, n * sizeof(double)), "hipMalloc(matrix)")) rc = 1;
-  if (!rc) rc = launch_generic_fill(m, mode, b->d_pairs, 1, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, g_stream);
+  if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0);
   if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
   if (pool) (void)hipFree(pool);

@@ -217,3 +217,88 @@ def test_survey_anchors_gpu(capi, machines, idx):
         assert abs(ll - a["forward_exact"]) <= 1e-7   # device exact-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
     vll, off, edges = b.viterbi()
     assert float("%.10g" % vll[0]) == a["viterbi"] and off[1] == a["pathLen"]
+
+
+# ---- tiled "lanes = states" family (mb_medium.hip) ---------------------------------------------------------------
+FAST_REL = 2e-6     # fp32 exp/log correction term: ~1e-7 abs per cell, accumulated along the lattice
+FAST_ABS = 2e-5
+
+
+def _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch):
+    monkeypatch.setenv("MB_MEDIUM_G", str(G))
+    om = oracle_mod.OracleMachine(em)
+    capi.set_kernel(capi.KERNEL_MEDIUM)
+    try:
+        dm = capi.DeviceMachine(em)
+        V = dm.fill(capi.MB_VITERBI, x, y)
+        F = dm.fill(capi.MB_FORWARD, x, y)
+        B = dm.fill(capi.MB_BACKWARD, x, y)
+        assert "medium" in capi.last_kernel_name()
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+        llr = b.forward(capi.MB_ROLLING)[0]
+    finally:
+        capi.set_kernel(capi.KERNEL_AUTO)
+    assert np.array_equal(V, om.viterbi(x, y))                                   # bit-exact
+    Fe = om.forward(x, y, oracle_mod.SUM_EXACT)
+    assert close(F, Fe, FAST_REL, FAST_ABS)
+    assert close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+    assert close(llr, Fe[-1, -1, -1], FAST_REL, FAST_ABS)
+    assert close(llr, om.loglike(x, y), 1e-4)                                     # north-star bar vs the table build
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+@pytest.mark.parametrize("shape", [(5, 40), (70, 300), (0, 33), (41, 0), (130, 17)])
+def test_medium_psw2dna(capi, oracle_mod, machines, monkeypatch, G, shape):
+    """psw2dna (271 states, 10 silent levels): multi-strip (inLen > columns per workgroup) and multi-tile sweeps."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    x, y = synth_tokens(11, shape[0], shape[1], em.nInTok, em.nOutTok)
+    _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch)
+
+
+@pytest.mark.parametrize("G", [1, 4])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_medium_random_machines(capi, oracle_mod, monkeypatch, G, seed):
+    """Random machines with match edges (3-slot ring), duplicate edges, several edges per label, -inf weights."""
+    from randmachine import random_machine, random_seq
+    S = [37, 90, 150][seed - 1]
+    em = random_machine(S, 3, 4, seed, allow_inf=(seed == 2))
+    rng = np.random.RandomState(seed)
+    for il, ol in [(25, 31), (0, 9), (60, 45)]:
+        _medium_case(capi, oracle_mod, em, random_seq(rng, il, 3), random_seq(rng, ol, 4), G, monkeypatch)
+
+
+def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
+    """Viterbi tracebacks and posterior counts on top of medium-family matrices (ragged batch)."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    pairs = [synth_tokens(40 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(12, 50), (40, 90), (3, 7)])]
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    vll, off, edges = b.viterbi()
+    assert "medium" in capi.last_kernel_name()
+    for k, (x, y) in enumerate(pairs):
+        V = om.viterbi(x, y)
+        assert vll[k] == V[-1, -1, -1] and np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, V))
+    counts, s, ll = b.counts()
+    ref_c = np.zeros(em.nTransitions); ref_s = 0.0
+    for x, y in pairs:
+        ref_s += om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
+    assert close(counts, ref_c, 1e-5, 1e-7) and close(s, ref_s, FAST_REL, FAST_ABS)
+
+
+def test_medium_vs_generic_large(capi, machines):
+    """Size-independent check at a larger shape: both kernel families fill identical Viterbi matrices and agree on
+    Forward; rolling == materialised log-likelihood."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    x, y = synth_tokens(77, 200, 1500, em.nInTok, em.nOutTok)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y)] * 3)
+    llm = b.forward(capi.MB_MATERIALISE); llr = b.forward(capi.MB_ROLLING)
+    vm, _, _ = b.viterbi(paths=False)
+    capi.set_kernel(capi.KERNEL_GENERIC)
+    try:
+        llg = b.forward(capi.MB_MATERIALISE); vg, _, _ = b.viterbi(paths=False)
+    finally:
+        capi.set_kernel(capi.KERNEL_AUTO)
+    assert np.array_equal(vm, vg) and np.all(vm == vm[0])
+    assert close(llm, llg, FAST_REL, FAST_ABS) and close(llr, llg, FAST_REL, FAST_ABS) and np.all(llm == llm[0])
