@@ -122,6 +122,8 @@ int mb_counts_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const i
 int mb_set_kernel(int which);
 /* Bytes of device memory the library may use for DP matrices (default: 80 % of free HBM). */
 int mb_set_memory_budget(size_t bytes);
+/* The library keeps its matrix pools allocated between calls (grow-only); this frees them. */
+int mb_release_workspace(void);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ EXPORTS = [
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
-    "mb_set_kernel", "mb_set_memory_budget",
+    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace",
 ]
 
 _lib = None
@@ -99,6 +99,10 @@ def set_kernel(which: int):
 
 def set_memory_budget(nbytes: int):
     _check(load().mb_set_memory_budget(nbytes))
+
+
+def release_workspace():
+    _check(load().mb_release_workspace())
 
 
 def last_device_ms() -> float:

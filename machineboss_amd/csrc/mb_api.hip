@@ -41,11 +41,31 @@ static int ensure_init() {
   return 0;
 }
 
+// Grow-only device workspaces, kept across calls so that steady-state batch calls do no hipMalloc/hipFree
+// (a 200 GB hipMalloc costs far more than the kernels it feeds).  Slot 0/1: matrix pools, 2: halo columns.
+struct Workspace { void *p = nullptr; size_t bytes = 0; };
+static Workspace g_ws[3];
+
+static size_t cached_bytes() { return g_ws[0].bytes + g_ws[1].bytes + g_ws[2].bytes; }
+
+static void *ws_get(int slot, size_t bytes) {
+  Workspace &w = g_ws[slot];
+  if (w.bytes >= bytes && w.p) return w.p;
+  if (w.p) { (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+  if (!hip_ok(hipMalloc(&w.p, std::max<size_t>(bytes, 256)), "hipMalloc(workspace)")) { w.p = nullptr; return nullptr; }
+  w.bytes = std::max<size_t>(bytes, 256);
+  return w.p;
+}
+
+static void ws_release() {
+  for (Workspace &w : g_ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+}
+
 static size_t budget_bytes() {
   if (g_mem_budget) return g_mem_budget;
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return (size_t)8 << 30;
-  return (size_t)((double)freeB * 0.80);
+  return (size_t)((double)(freeB + cached_bytes()) * 0.80);
 }
 
 // kernel launchers implemented in the kernel files
@@ -76,7 +96,14 @@ struct Timer {
 struct Chunk { long long p0, p1, cells; };
 static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &out) {
   const size_t budget = budget_bytes();
-  const long long maxCells = (long long)(budget / (8ull * nMatrices));
+  long long maxCells = (long long)(budget / (8ull * nMatrices));
+  // balance: the same number of chunks as a greedy fill needs, but of even size (a short last chunk would leave
+  // most of the chip idle)
+  if (b->totalCells > maxCells && maxCells > 0) {
+    const long long nChunks = (b->totalCells + maxCells - 1) / maxCells;
+    const long long even = (b->totalCells + nChunks - 1) / nChunks + b->maxPairCells;
+    if (even < maxCells) maxCells = std::max(even, b->maxPairCells);
+  }
   long long p0 = 0, acc = 0;
   for (long long p = 0; p < b->nPairs; ++p) {
     const PairDesc &pd = b->pairs[p];
@@ -189,6 +216,8 @@ int mb_set_kernel(int which) {
 }
 
 int mb_set_memory_budget(size_t bytes) { g_mem_budget = bytes; return 0; }
+
+int mb_release_workspace(void) { ws_release(); return 0; }
 
 mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                               const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight) {
@@ -304,7 +333,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     for (long long p = 0; p < b->nPairs; ++p) { hb[p] = tot; tot += 2ll * (b->pairs[p].outLen + 1) * m->S; }
     double *d_halo = nullptr; long long *d_hb = nullptr;
     do {
-      if (!hip_ok(hipMalloc((void **)&d_halo, std::max<long long>(tot, 1) * sizeof(double)), "hipMalloc(halo columns)")) { rc = 1; break; }
+      if (!(d_halo = (double *)ws_get(2, std::max<long long>(tot, 1) * sizeof(double)))) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&d_hb, b->nPairs * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
       g_last_kernel = "k_medium_tile<0>";
@@ -313,7 +342,6 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
-    if (d_halo) (void)hipFree(d_halo);
     if (d_hb) (void)hipFree(d_hb);
   } else {
     std::vector<Chunk> chunks;
@@ -322,13 +350,13 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       PairDesc *d_desc = nullptr; double *pool = nullptr;
       std::vector<PairDesc> hp;
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { (void)hipFree(d_desc); rc = 1; break; }
+      if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { (void)hipFree(d_desc); rc = 1; break; }
       tm.start();
       rc = fill_chunk(m, mode, d_desc, hp, b->d_in, b->d_out, pool, 0);
       if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, m->S, 0, d_ll + c.p0, g_stream);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
-      (void)hipFree(pool); (void)hipFree(d_desc);
+      (void)hipFree(d_desc);
       if (rc) break;
     }
   }
@@ -372,7 +400,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
     std::vector<PairDesc> hp;
     do {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!hip_ok(hipMalloc((void **)&pool, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(matrix pool)")) { rc = 1; break; }
+      if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       tm.start();
       if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0))) break;
@@ -406,7 +434,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         }
       }
     } while (0);
-    void *ptrs[] = {d_desc, pool, d_ll, d_slot, d_len, d_path};
+    void *ptrs[] = {d_desc, d_ll, d_slot, d_len, d_path};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (rc) break;
   }
@@ -434,8 +462,8 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
     std::vector<PairDesc> hp;
     do {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!hip_ok(hipMalloc((void **)&fwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(forward pool)")) { rc = 1; break; }
-      if (!hip_ok(hipMalloc((void **)&bwd, std::max<long long>(c.cells, 1) * sizeof(double)), "hipMalloc(backward pool)")) { rc = 1; break; }
+      if (!(fwd = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
+      if (!(bwd = (double *)ws_get(1, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       long long maxc = 0;
       for (long long p = c.p0; p < c.p1; ++p)
         maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
@@ -447,7 +475,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
     } while (0);
-    void *ptrs[] = {d_desc, fwd, bwd};
+    void *ptrs[] = {d_desc};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (rc) break;
   }
@@ -479,11 +507,10 @@ int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int
   double *pool = nullptr;
   int rc = 0;
   if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
-  if (!rc && !hip_ok(hipMalloc((void **)&pool, n * sizeof(double)), "hipMalloc(matrix)")) rc = 1;
+  if (!rc && !(pool = (double *)ws_get(0, n * sizeof(double)))) rc = 1;
   if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0);
   if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
-  if (pool) (void)hipFree(pool);
   mb_batch_destroy(b);
   return rc;
 }

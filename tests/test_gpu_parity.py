@@ -16,6 +16,8 @@ from machineboss_amd.seqgen import synth_batch, synth_tokens
 pytestmark = pytest.mark.gpu
 
 REL_EXACT = 1e-11   # device exp/log1p vs libm, accumulated over the lattice
+FAST_REL = 2e-6     # tiled families: fp32 exp/log correction term, ~1e-7 abs per cell, accumulated along the lattice
+FAST_ABS = 2e-5
 ABS_TABLE = 1e-4    # vs the reference's table build: the table drops terms >= 10 nats below the running max and
 REL_TABLE = 1e-4    # interpolates at step 1e-4 (src/logsumexp.h:20-21,48-70); 1e-4 relative is the north-star tolerance
 COUNT_TOL = 1e-9
@@ -58,23 +60,30 @@ def setup_case(machines, case, seed=7):
     return m, em, i, o
 
 
+@pytest.mark.parametrize("family", ["generic", "auto"])
 @pytest.mark.parametrize("case", CASES, ids=[c[1] for c in CASES])
-def test_fill_matrices(capi, oracle_mod, machines, case):
+def test_fill_matrices(capi, oracle_mod, machines, case, family):
+    """Full matrices vs the oracle.  The generic family evaluates log(1+exp(-x)) in fp64 (REL_EXACT); the tiled
+    families evaluate that correction term in fp32 (FAST_REL / FAST_ABS, still ~3 orders inside the 1e-4 bar)."""
     m, em, i, o = setup_case(machines, case)
     om = oracle_mod.OracleMachine(em)
-    dm = capi.DeviceMachine(em)
-    assert list(dm.edge_order(0)) == list(om.incoming_order()) and list(dm.edge_order(1)) == list(om.outgoing_order())
-    # Viterbi: bit-exact
-    V = dm.fill(capi.MB_VITERBI, i, o)
-    assert np.array_equal(V, om.viterbi(i, o))
-    # Forward / Backward
-    F = dm.fill(capi.MB_FORWARD, i, o)
-    assert close(F, om.forward(i, o, oracle_mod.SUM_EXACT), REL_EXACT)
+    capi.set_kernel(capi.KERNEL_GENERIC if family == "generic" else capi.KERNEL_AUTO)
+    try:
+        dm = capi.DeviceMachine(em)
+        assert list(dm.edge_order(0)) == list(om.incoming_order()) and list(dm.edge_order(1)) == list(om.outgoing_order())
+        V = dm.fill(capi.MB_VITERBI, i, o)
+        F = dm.fill(capi.MB_FORWARD, i, o)
+        B = dm.fill(capi.MB_BACKWARD, i, o)
+        fast = "generic" not in capi.last_kernel_name()
+    finally:
+        capi.set_kernel(capi.KERNEL_AUTO)
+    rel, abs_ = (FAST_REL, FAST_ABS) if fast else (REL_EXACT, 0.0)
+    assert np.array_equal(V, om.viterbi(i, o))        # Viterbi: bit-exact in every family
+    assert close(F, om.forward(i, o, oracle_mod.SUM_EXACT), rel, abs_)
     assert close(F, om.forward(i, o, oracle_mod.SUM_TABLE), REL_TABLE, ABS_TABLE)
-    B = dm.fill(capi.MB_BACKWARD, i, o)
-    assert close(B, om.backward(i, o, oracle_mod.SUM_EXACT), REL_EXACT)
-    assert close(B[0, 0, 0], F[-1, -1, -1], 1e-10)   # posterior LL = Forward LL (js/webgpu/test/test-cpu.mjs invariant)
-    assert np.all(V <= F + 1e-9)                       # Viterbi <= Forward
+    assert close(B, om.backward(i, o, oracle_mod.SUM_EXACT), rel, abs_)
+    assert close(B[0, 0, 0], F[-1, -1, -1], 1e-10, abs_)   # posterior LL = Forward LL (js/webgpu/test/test-cpu.mjs invariant)
+    assert np.all(V <= F + 1e-6)                       # Viterbi <= Forward
 
 
 def test_forward_start_state(capi, oracle_mod, machines):
@@ -124,7 +133,8 @@ def test_batch_api_ragged(capi, oracle_mod, machines, name, il, ol, n):
     for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
         ll = b.forward(flags)
         ref = [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs]
-        assert close(ll, ref, 1e-10)
+        fast = "generic" not in capi.last_kernel_name()
+        assert close(ll, ref, FAST_REL if fast else 1e-10, FAST_ABS if fast else 0.0)
         assert close(ll, [om.loglike(x, y) for x, y in pairs], 1e-4)   # north-star tolerance vs the table build
     vll, off, edges = b.viterbi()
     for k, (x, y) in enumerate(pairs):
@@ -143,8 +153,9 @@ def test_batch_api_ragged(capi, oracle_mod, machines, name, il, ol, n):
             ref_s += om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
         else:
             ref_s += l
-    assert close(counts, ref_c, COUNT_TOL, 1e-12)
-    assert close(s, ref_s, 1e-10) if math.isfinite(ref_s) else s == ref_s
+    fast = "generic" not in capi.last_kernel_name()
+    assert close(counts, ref_c, 1e-5 if fast else COUNT_TOL, 1e-7 if fast else 1e-12)
+    assert (close(s, ref_s, FAST_REL if fast else 1e-10, FAST_ABS if fast else 0.0)) if math.isfinite(ref_s) else s == ref_s
 
 
 def test_viterbi_ties_uniform_params(capi, oracle_mod, machines):
@@ -214,16 +225,12 @@ def test_survey_anchors_gpu(capi, machines, idx):
     ll = b.forward()[0]
     assert abs(ll - a["forward"]) <= 1e-4 * abs(a["forward"])
     if a["forward_exact"] is not None:
-        assert abs(ll - a["forward_exact"]) <= 1e-7   # device exact-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
+        assert abs(ll - a["forward_exact"]) <= 1e-5   # device direct-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
     vll, off, edges = b.viterbi()
     assert float("%.10g" % vll[0]) == a["viterbi"] and off[1] == a["pathLen"]
 
 
 # ---- tiled "lanes = states" family (mb_medium.hip) ---------------------------------------------------------------
-FAST_REL = 2e-6     # fp32 exp/log correction term: ~1e-7 abs per cell, accumulated along the lattice
-FAST_ABS = 2e-5
-
-
 def _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch):
     monkeypatch.setenv("MB_MEDIUM_G", str(G))
     om = oracle_mod.OracleMachine(em)
