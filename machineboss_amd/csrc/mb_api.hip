@@ -508,6 +508,7 @@ int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int
   int rc = 0;
   if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
   if (!rc && !(pool = (double *)ws_get(0, n * sizeof(double)))) rc = 1;
+  if (!rc && env_int("MB_DEBUG_POISON", 0)) (void)hipMemsetAsync(pool, 0xFF, n * sizeof(double), g_stream);
   if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0);
   if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;

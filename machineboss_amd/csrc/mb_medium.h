@@ -6,37 +6,36 @@
 
 namespace mb {
 
-struct MedTabDev {
-  const uint16_t *src;   // [slots] candidate source state (padding: 0)
-  const double *w;       // [slots] candidate log-weight   (padding: -inf)
-  const int *base;       // [R]  first slot of round r
-  const int *nslots;     // [R]  candidate slots per (token, lane) in round r (wave-uniform loop bound)
-};
+constexpr int MED_MAXSLOT = 8;   // candidate slots evaluated together (two-pass max / sum-exp in registers)
 
-// tables: 0 = match (token pair), 1 = input-only, 2 = output-only, 3 = silent;
-// slot index = base[r] + (token*nslots[r] + k)*LPG + laneInGroup
+// The compiled "program" of a machine for one sweep direction.
+//   round  = up to LPG states of one silent level, one state per lane of a lane group;
+//   slot   = one candidate (source state, log-weight) per lane; slots of a round are grouped by table
+//            (0 match -> (i-1,o-1), 1 input-only -> (i-1,o), 2 output-only -> (i,o-1), 3 silent -> (i,o));
+//   chunk  = up to MED_MAXSLOT slots of one round, the unit the kernel software-pipelines.
+// meta[chunk*(1+MED_MAXSLOT)]: word 0 = ns | first<<4 | last<<5 | sync<<6 | round<<8;
+//                              word 1+k = slot offset (28 bits) | table<<28.
+// slot arrays: src/w[offset + token*LPG + laneInGroup], token = table-specific (pair index, inTok, outTok, 0).
 struct MedProgDev {
-  int S, Spad, R, LPG, G, NS;
+  int S, Spad, R, LPG, G, NS, nChunks;
   int nIn, nOut, startNode, endNode;
-  const short *dest;            // [R*LPG] state finalised by (round, laneInGroup), -1 = idle
-  const unsigned char *sync;    // [R] 1: a silent-level boundary follows round r
-  MedTabDev tab[4];
+  const int *meta;
+  const short *dest;        // [R*LPG] state finalised by (round, laneInGroup), -1 = idle
+  const uint16_t *src;      // candidate source state (padding: S, the -inf sentinel)
+  const double *w;          // candidate log-weight   (padding: -inf)
 };
 
 struct MedProgram {
-  int G = 0, LPG = 0, R = 0, NS = 0, Spad = 0;
+  int G = 0, LPG = 0, R = 0, NS = 0, Spad = 0, nChunks = 0;
   bool backward = false;
+  std::vector<int> meta;
   std::vector<short> dest;
-  std::vector<unsigned char> sync;
-  std::vector<int> base[4], nslots[4];
-  std::vector<uint16_t> src[4];
-  std::vector<uint32_t> eid[4];   // slot -> global edge id (0xFFFFFFFF = padding), to refresh weights per EM iteration
+  std::vector<uint16_t> src;
+  std::vector<uint32_t> eid;   // slot entry -> global edge id (0xFFFFFFFF = padding), to refresh weights per EM iteration
+  int *d_meta = nullptr;
   short *d_dest = nullptr;
-  unsigned char *d_sync = nullptr;
-  uint16_t *d_src[4] = {nullptr, nullptr, nullptr, nullptr};
-  double *d_w[4] = {nullptr, nullptr, nullptr, nullptr};
-  int *d_base[4] = {nullptr, nullptr, nullptr, nullptr};
-  int *d_nslots[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint16_t *d_src = nullptr;
+  double *d_w = nullptr;
   MedProgDev dev{};
 };
 

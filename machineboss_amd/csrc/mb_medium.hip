@@ -25,6 +25,7 @@
 // v_exp_f32 / v_log_f32 (abs. error ~1e-7 per cell, far inside the 1e-4 relative tolerance); a state with a
 // single candidate is exact.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 
@@ -37,29 +38,6 @@ namespace mb {
 // ------------------------------------------------------------------------------------------------------------
 // device side
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void acc_sum(double &m, float &s, double v) {
-  const double d64 = (v == m) ? 0.0 : (v - m);       // (-inf) - (-inf) guarded like src/logsumexp.h:79
-  const float d = (float)d64;
-  const float e = __builtin_amdgcn_exp2f(-fabsf(d) * 1.44269504088896f);
-  const bool up = d > 0.0f;
-  s = up ? fmaf(s, e, 1.0f) : (s + e);
-  m = up ? v : m;
-}
-
-__device__ __forceinline__ double fin_sum(double m, float s) {
-  return m + (double)(__builtin_amdgcn_logf(s) * 0.693147180559945f);
-}
-
-template <int MODE>
-struct Acc {
-  double m; float s;
-  __device__ __forceinline__ void init() { m = -INFINITY; s = 0.0f; }
-  __device__ __forceinline__ void add(double v) {
-    if (MODE == MB_VITERBI) m = dmax(m, v); else acc_sum(m, s, v);
-  }
-  __device__ __forceinline__ double result() const { return MODE == MB_VITERBI ? m : fin_sum(m, s); }
-};
-
 struct MedTileArgs {
   const PairDesc *pairs;
   const int *inTok, *outTok;
@@ -70,10 +48,14 @@ struct MedTileArgs {
   int C, TS, launch, rev, materialise, startNode;
 };
 
+#define MED_L2E 1.44269504088896f
+#define MED_LN2 0.693147180559945f
+
 template <int MODE, int G>
 __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs A) {
   extern __shared__ double lds[];
   constexpr int LPG = 64 / G;
+  constexpr int MS = MED_MAXSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   const int S = P.S, Spad = P.Spad, NS = P.NS, C = A.C;
@@ -108,7 +90,14 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
     return cells + (ro * I + ri) * S;
   };
   auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
+  int *ldsMeta = (int *)(lds + (long long)NS * (C + 1) * Spad);
+  short *ldsDest = (short *)(ldsMeta + P.nChunks * (1 + MS));
 
+  // ---- program metadata into LDS --------------------------------------------------------------------------------
+  for (int j = tid; j < P.nChunks * (1 + MS); j += blockDim.x) ldsMeta[j] = P.meta[j];
+  for (int j = tid; j < P.R * LPG; j += blockDim.x) ldsDest[j] = P.dest[j];
+  // sentinel: padding candidates (source index S, weight -inf) must read -inf, never stale LDS (NaN + -inf = NaN)
+  for (int j = tid; j < NS * (C + 1); j += blockDim.x) lds[(long long)j * Spad + S] = -INFINITY;
   // ---- preload the ring state of steps t0-1 (and t0-2 when match edges exist) --------------------------------
   for (int dt = 1; dt < NS; ++dt) {
     const int tp = t0 - dt;
@@ -126,11 +115,23 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   }
   __syncthreads();
 
+  const uint16_t *__restrict__ gsrc = P.src;
+  const double *__restrict__ gw = P.w;
   int slotCur = t0 % NS;
+  // output token of the first step
+  int otNext = 0;
+  {
+    const int o = t0 - c;
+    if (colValid && o > 0 && o <= outLen) otNext = rev ? out[outLen - o] : out[o - 1];
+  }
   for (int t = t0; t < t1; ++t) {
     const int o = t - c;
     const bool active = colValid && o >= 0 && o <= outLen;
-    const int ot = (active && o > 0) ? (rev ? out[outLen - o] : out[o - 1]) : 0;
+    const int ot = otNext;
+    {  // prefetch the next step's output token
+      const int on = o + 1;
+      otNext = (colValid && on > 0 && on <= outLen) ? (rev ? out[outLen - on] : out[on - 1]) : 0;
+    }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
     // halo supercell (i0-1, t+1) for the next step, fetched cooperatively by the whole workgroup
     double hv[4];
@@ -145,69 +146,81 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
     }
     double *cur = ring(slotCur, c + 1);
     const double *down = ring(slotPrev, c + 1), *left = ring(slotPrev, c), *diag = ring(slotPrev2, c);
-    const bool origin = (i == 0 && o == 0);
-    for (int r = 0; r < P.R; ++r) {
-      const int d = P.dest[r * LPG + q];
-      Acc<MODE> acc;
-      acc.init();
-      if (origin && d == A.startNode) acc.add(0.0);
-      {  // match: (i-1,o-1)
-        const int ns = P.tab[0].nslots[r];
-        if (ns) {
-          const bool ok = active && i > 0 && o > 0;
-          const int base = P.tab[0].base[r] + ((it * (P.nOut + 1) + ot) * ns) * LPG + q;
-          for (int k = 0; k < ns; ++k) {
-            const int sidx = P.tab[0].src[base + k * LPG];
-            const double w = P.tab[0].w[base + k * LPG];
-            const double v = ok ? diag[sidx] + w : -INFINITY;
-            acc.add(v);
-          }
+    const bool origin = active && (i == 0 && o == 0);
+    const bool anyOrigin = __any(origin);
+    // per-table token offsets and validity
+    const int tokM = (it * (P.nOut + 1) + ot) * LPG + q, tokI = it * LPG + q, tokO = ot * LPG + q;
+    const bool okM = active && i > 0 && o > 0, okI = active && i > 0, okO = active && o > 0;
+
+    // software pipeline over chunks: candidates of chunk c+1 are fetched while chunk c is evaluated
+    int cS[MS]; double cW[MS];
+    int nS[MS]; double nW[MS];
+    auto fetch = [&](int ch, int (&fs)[MS], double (&fw)[MS]) {
+      const int m0 = __builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS)]);
+      const int ns = m0 & 15;
+#pragma unroll
+      for (int k = 0; k < MS; ++k) {
+        if (k < ns) {
+          const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS) + 1 + k]);
+          const unsigned tb = sd >> 28;
+          const int off = (int)(sd & 0x0FFFFFFFu);
+          const int idx = off + (tb == 0 ? tokM : (tb == 1 ? tokI : (tb == 2 ? tokO : q)));
+          fs[k] = gsrc[idx]; fw[k] = gw[idx];
+        } else { fs[k] = S; fw[k] = -INFINITY; }
+      }
+    };
+    fetch(0, cS, cW);
+    double accM = -INFINITY; float accS = 0.0f;
+    for (int ch = 0; ch < P.nChunks; ++ch) {
+      const int m0 = __builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS)]);
+      const int ns = m0 & 15, round = m0 >> 8;
+      const bool first = (m0 >> 4) & 1, last = (m0 >> 5) & 1, sync = (m0 >> 6) & 1;
+      if (ch + 1 < P.nChunks) fetch(ch + 1, nS, nW);
+      const int d = ldsDest[round * LPG + q];
+      // pass 1: candidates and their maximum
+      double v[MS];
+      double mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < MS; ++k) {
+        if (k < ns) {
+          const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS) + 1 + k]);
+          const unsigned tb = sd >> 28;
+          const double *vec = tb == 0 ? diag : (tb == 1 ? left : (tb == 2 ? down : cur));
+          const bool ok = tb == 0 ? okM : (tb == 1 ? okI : (tb == 2 ? okO : active));
+          const double x = vec[cS[k]];
+          v[k] = ok ? x + cW[k] : -INFINITY;
+          mx = dmax(mx, v[k]);
+        } else v[k] = -INFINITY;
+      }
+      if (anyOrigin && first && origin && d == A.startNode) {   // the seed cell(0,0,start) = 0 (src/forward.defs.h:36)
+        accM = 0.0; accS = 1.0f;
+      } else if (first) { accM = -INFINITY; accS = 0.0f; }
+      if (MODE == MB_VITERBI) {
+        accM = dmax(accM, mx);
+      } else {
+        // pass 2: sum of exp(candidate - max) in fp32; a lone candidate gives exactly 1.0 -> log 0 -> exact result
+        const double newM = dmax(accM, mx);
+        const double gM = (newM == -INFINITY) ? 0.0 : newM;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MS; ++k)
+          if (k < ns) s += __builtin_amdgcn_exp2f((float)(v[k] - gM) * MED_L2E);
+        if (!(first && !anyOrigin)) s += accS * __builtin_amdgcn_exp2f((float)(accM - gM) * MED_L2E);
+        accS = s; accM = newM;
+      }
+      if (last) {
+        double res;
+        if (MODE == MB_VITERBI) res = accM;
+        else res = ((accM == -INFINITY) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
+        if (active && d >= 0) cur[d] = res;
+        if (sync) {  // wave-local: the next round reads what other lanes of this wave just wrote
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
       }
-      {  // input-only: (i-1,o)
-        const int ns = P.tab[1].nslots[r];
-        if (ns) {
-          const bool ok = active && i > 0;
-          const int base = P.tab[1].base[r] + (it * ns) * LPG + q;
-          for (int k = 0; k < ns; ++k) {
-            const int sidx = P.tab[1].src[base + k * LPG];
-            const double w = P.tab[1].w[base + k * LPG];
-            const double v = ok ? left[sidx] + w : -INFINITY;
-            acc.add(v);
-          }
-        }
-      }
-      {  // output-only: (i,o-1)
-        const int ns = P.tab[2].nslots[r];
-        if (ns) {
-          const bool ok = active && o > 0;
-          const int base = P.tab[2].base[r] + (ot * ns) * LPG + q;
-          for (int k = 0; k < ns; ++k) {
-            const int sidx = P.tab[2].src[base + k * LPG];
-            const double w = P.tab[2].w[base + k * LPG];
-            const double v = ok ? down[sidx] + w : -INFINITY;
-            acc.add(v);
-          }
-        }
-      }
-      {  // silent: same supercell, lower levels
-        const int ns = P.tab[3].nslots[r];
-        if (ns) {
-          const int base = P.tab[3].base[r] + q;
-          for (int k = 0; k < ns; ++k) {
-            const int sidx = P.tab[3].src[base + k * LPG];
-            const double w = P.tab[3].w[base + k * LPG];
-            const double v = active ? cur[sidx] + w : -INFINITY;
-            acc.add(v);
-          }
-        }
-      }
-      if (active && d >= 0) cur[d] = acc.result();
-      if (P.sync[r]) {  // wave-local: the next round reads what other lanes of this wave just wrote
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+#pragma unroll
+      for (int k = 0; k < MS; ++k) { cS[k] = nS[k]; cW[k] = nW[k]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -245,8 +258,9 @@ struct Cand { uint16_t src; uint32_t eid; };
 
 static void build_program(const mb_machine *m, bool backward, int G, MedProgram &P) {
   const int S = m->S, LPG = 64 / G, nIn = m->nIn, nOut = m->nOut;
+  constexpr int MS = MED_MAXSLOT;
   P.G = G; P.LPG = LPG; P.backward = backward;
-  P.Spad = (S + 1) & ~1;
+  P.Spad = (S + 2) & ~1;   // >= S+1: entry [S] of every LDS vector is a -inf sentinel read by padding slots
   P.NS = m->hasMatch ? 3 : 2;
   const std::vector<int> &lev = backward ? m->levB : m->levF;
   const std::vector<int> &off = backward ? m->outOff : m->inOff;
@@ -270,21 +284,25 @@ static void build_program(const mb_machine *m, bool backward, int G, MedProgram 
     }
   };
   const int ntok[4] = {(nIn + 1) * (nOut + 1), nIn + 1, nOut + 1, 1};
-  // rounds: per level, states sorted by silent degree (descending) so that a round's slot count is tight
+  // rounds: per level, states sorted by candidate count (descending) so that a round's slot count is tight
   std::vector<Cand> tmp;
   std::vector<std::vector<int>> rounds;
   std::vector<unsigned char> sync;
+  std::vector<std::array<int, 4>> degOf(S);
+  for (int s = 0; s < S; ++s)
+    for (int T = 0; T < 4; ++T) {
+      int mx = 0;
+      for (int tok = 0; tok < ntok[T]; ++tok) { cands(s, T, tok, tmp); mx = std::max(mx, (int)tmp.size()); }
+      degOf[s][T] = mx;
+    }
   for (int l = 0; l < nLev; ++l) {
     std::vector<int> st;
     for (int s = 0; s < S; ++s) if (lev[s] == l) st.push_back(s);
-    std::vector<int> deg(S, 0);
-    for (int s : st) {
-      cands(s, 3, 0, tmp); deg[s] = (int)tmp.size() * 1000;
-      int mx = 0;
-      for (int T = 0; T < 3; ++T) for (int tok = 0; tok < ntok[T]; ++tok) { cands(s, T, tok, tmp); mx = std::max(mx, (int)tmp.size()); }
-      deg[s] += mx;
-    }
-    std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return deg[x] > deg[y]; });
+    auto tot = [&](int s) { return degOf[s][0] + degOf[s][1] + degOf[s][2] + degOf[s][3]; };
+    std::stable_sort(st.begin(), st.end(), [&](int x, int y) {
+      if (tot(x) != tot(y)) return tot(x) > tot(y);
+      return degOf[x] > degOf[y];
+    });
     for (size_t k = 0; k < st.size(); k += LPG) {
       rounds.emplace_back(st.begin() + k, st.begin() + std::min(st.size(), k + LPG));
       sync.push_back(0);
@@ -293,29 +311,41 @@ static void build_program(const mb_machine *m, bool backward, int G, MedProgram 
   }
   if (!sync.empty()) sync.back() = 0;
   const int R = (int)rounds.size();
-  P.R = R; P.sync = sync;
+  P.R = R;
   P.dest.assign((size_t)R * LPG, -1);
   for (int r = 0; r < R; ++r) for (size_t k = 0; k < rounds[r].size(); ++k) P.dest[(size_t)r * LPG + k] = (short)rounds[r][k];
-  for (int T = 0; T < 4; ++T) {
-    P.nslots[T].assign(R, 0); P.base[T].assign(R, 0);
-    P.src[T].clear(); P.eid[T].clear();
-    for (int r = 0; r < R; ++r) {
+  P.meta.clear(); P.src.clear(); P.eid.clear();
+  for (int r = 0; r < R; ++r) {
+    // unified slot list of the round: (table, j)
+    std::vector<std::pair<int, int>> slots;
+    for (int T = 0; T < 4; ++T) {
       int ns = 0;
-      for (int s : rounds[r]) for (int tok = 0; tok < ntok[T]; ++tok) { cands(s, T, tok, tmp); ns = std::max(ns, (int)tmp.size()); }
-      P.nslots[T][r] = ns; P.base[T][r] = (int)P.src[T].size();
-      if (!ns) continue;
-      const size_t sz = (size_t)ntok[T] * ns * LPG, b0 = P.src[T].size();
-      P.src[T].resize(b0 + sz, 0); P.eid[T].resize(b0 + sz, 0xFFFFFFFFu);
-      for (size_t k = 0; k < rounds[r].size(); ++k)
-        for (int tok = 0; tok < ntok[T]; ++tok) {
-          cands(rounds[r][k], T, tok, tmp);
-          for (size_t j = 0; j < tmp.size(); ++j) {
-            const size_t idx = b0 + ((size_t)tok * ns + j) * LPG + k;
-            P.src[T][idx] = tmp[j].src; P.eid[T][idx] = tmp[j].eid;
+      for (int s : rounds[r]) ns = std::max(ns, degOf[s][T]);
+      for (int j = 0; j < ns; ++j) slots.push_back({T, j});
+    }
+    const int nch = std::max<int>(1, ((int)slots.size() + MS - 1) / MS);
+    for (int chn = 0; chn < nch; ++chn) {
+      const int k0 = chn * MS, k1 = std::min<int>((int)slots.size(), k0 + MS);
+      const size_t mbase = P.meta.size();
+      P.meta.resize(mbase + 1 + MS, 0);
+      P.meta[mbase] = (k1 - k0) | ((chn == 0) << 4) | ((chn == nch - 1) << 5) | ((chn == nch - 1 && sync[r]) << 6) | (r << 8);
+      for (int k = k0; k < k1; ++k) {
+        const int T = slots[k].first, j = slots[k].second;
+        const size_t b0 = P.src.size();
+        P.meta[mbase + 1 + (k - k0)] = (int)((unsigned)b0 | ((unsigned)T << 28));
+        P.src.resize(b0 + (size_t)ntok[T] * LPG, (uint16_t)S); P.eid.resize(b0 + (size_t)ntok[T] * LPG, 0xFFFFFFFFu);
+        for (size_t lane = 0; lane < rounds[r].size(); ++lane)
+          for (int tok = 0; tok < ntok[T]; ++tok) {
+            cands(rounds[r][lane], T, tok, tmp);
+            if (j < (int)tmp.size()) {
+              P.src[b0 + (size_t)tok * LPG + lane] = tmp[j].src;
+              P.eid[b0 + (size_t)tok * LPG + lane] = tmp[j].eid;
+            }
           }
-        }
+      }
     }
   }
+  P.nChunks = (int)(P.meta.size() / (1 + MS));
 }
 
 template <class T>
@@ -327,43 +357,37 @@ static bool up(T *&d, const std::vector<T> &h) {
 }
 
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
-  for (int T = 0; T < 4; ++T) {
-    std::vector<double> w(P.eid[T].size());
-    for (size_t k = 0; k < w.size(); ++k) w[k] = P.eid[T][k] == 0xFFFFFFFFu ? -INFINITY : m->logW[P.eid[T][k]];
-    if (!up(P.d_w[T], w)) return false;
-    P.dev.tab[T].w = P.d_w[T];
-  }
+  std::vector<double> w(P.eid.size());
+  for (size_t k = 0; k < w.size(); ++k) w[k] = P.eid[k] == 0xFFFFFFFFu ? -INFINITY : m->logW[P.eid[k]];
+  if (!up(P.d_w, w)) return false;
+  P.dev.w = P.d_w;
   return true;
 }
 
 bool medium_build(const mb_machine *m, bool backward, int G, MedProgram &P) {
   build_program(m, backward, G, P);
-  if (!up(P.d_dest, P.dest) || !up(P.d_sync, P.sync)) return false;
-  for (int T = 0; T < 4; ++T)
-    if (!up(P.d_src[T], P.src[T]) || !up(P.d_base[T], P.base[T]) || !up(P.d_nslots[T], P.nslots[T])) return false;
+  if (P.src.size() >= (1u << 28)) { set_error("machine too large for the tiled kernel family"); return false; }
+  if (!up(P.d_meta, P.meta) || !up(P.d_dest, P.dest) || !up(P.d_src, P.src)) return false;
   MedProgDev &d = P.dev;
-  d.S = m->S; d.Spad = P.Spad; d.R = P.R; d.LPG = P.LPG; d.G = G; d.NS = P.NS;
+  d.S = m->S; d.Spad = P.Spad; d.R = P.R; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
   d.nIn = m->nIn; d.nOut = m->nOut;
   d.startNode = backward ? m->S - 1 : 0; d.endNode = backward ? 0 : m->S - 1;
-  d.dest = P.d_dest; d.sync = P.d_sync;
-  for (int T = 0; T < 4; ++T) { d.tab[T].src = P.d_src[T]; d.tab[T].base = P.d_base[T]; d.tab[T].nslots = P.d_nslots[T]; }
+  d.meta = P.d_meta; d.dest = P.d_dest; d.src = P.d_src;
   return medium_refresh_weights(m, P);
 }
 
 void medium_free(MedProgram &P) {
-  void *ptrs[] = {P.d_dest, P.d_sync};
+  void *ptrs[] = {P.d_meta, P.d_dest, P.d_src, P.d_w};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  for (int T = 0; T < 4; ++T) {
-    void *q[] = {P.d_src[T], P.d_w[T], P.d_base[T], P.d_nslots[T]};
-    for (void *p : q) if (p) (void)hipFree(p);
-  }
   P = MedProgram();
 }
 
 // Geometry: columns per strip limited by the 160 KB LDS of a CU.
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   const size_t perCol = (size_t)P.NS * P.Spad * sizeof(double);
-  const size_t budget = 160 * 1024 - 1024;
+  const size_t progBytes = (size_t)P.nChunks * (1 + MED_MAXSLOT) * sizeof(int) + (size_t)P.R * P.LPG * sizeof(short) + 64;
+  if (progBytes > 48 * 1024) return false;
+  const size_t budget = 160 * 1024 - 512 - progBytes;
   long long maxCols = (long long)(budget / perCol) - 1;   // one extra column for the halo
   if (maxCols < P.G) return false;
   int waves = (int)std::min<long long>(maxCols / P.G, 16);
@@ -371,7 +395,7 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   while (waves < 16 && (long long)waves * 64 * 4 < m->S) ++waves;
   if ((long long)waves * 64 * 4 < m->S || (long long)waves * P.G > maxCols) return false;
   geo.waves = waves; geo.C = waves * P.G;
-  geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);
+  geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double) + progBytes;
   return true;
 }
 
