@@ -135,8 +135,10 @@ static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_ou
 struct FastState {
   bool tried = false, mediumOk = false;
   int G = 0;
-  MedProgram fwd, bwd;
-  MedGeom geoF, geoB;
+  // exact (leveled) programs: Viterbi and Forward with a custom start state; "sum" programs: Forward / Backward,
+  // silent closure when it stays small, otherwise the exact program of that direction
+  MedProgram fwdExact, fwdSum, bwdSum;
+  MedGeom geoFE, geoFS, geoBS;
 };
 
 static int env_int(const char *name, int dflt) {
@@ -155,8 +157,23 @@ static FastState *fast_state(mb_machine *m) {
       int G = env_int("MB_MEDIUM_G", 0);
       if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 384 ? 2 : 4);
       f->G = G;
-      f->mediumOk = medium_build(m, false, G, f->fwd) && medium_build(m, true, G, f->bwd) &&
-                    medium_geometry(m, f->fwd, f->geoF) && medium_geometry(m, f->bwd, f->geoB);
+      long long nSilent = 0;
+      for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
+      const bool wantClosure = env_int("MB_MEDIUM_CLOSURE", 1) != 0;
+      bool ok = medium_build(m, false, false, G, f->fwdExact) && medium_geometry(m, f->fwdExact, f->geoFE);
+      if (ok) {
+        bool clos = wantClosure;
+        ok = medium_build(m, false, clos, G, f->fwdSum);
+        if (ok && clos && f->fwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, false, false, G, f->fwdSum); }
+        ok = ok && medium_geometry(m, f->fwdSum, f->geoFS);
+      }
+      if (ok) {
+        bool clos = wantClosure;
+        ok = medium_build(m, true, clos, G, f->bwdSum);
+        if (ok && clos && f->bwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, true, false, G, f->bwdSum); }
+        ok = ok && medium_geometry(m, f->bwdSum, f->geoBS);
+      }
+      f->mediumOk = ok;
     }
   }
   return f;
@@ -174,15 +191,12 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
                       const int *d_out, double *pool, int startState) {
   if (use_medium(m)) {
     FastState *f = fast_state(m);
-    const bool bw = mode == MB_BACKWARD;
-    MedProgram &P = bw ? f->bwd : f->fwd;
-    const int saved = P.dev.startNode;
-    if (mode == MB_FORWARD) P.dev.startNode = startState;
+    const bool exactFwd = mode == MB_VITERBI || (mode == MB_FORWARD && startState != 0);
+    MedProgram &P = mode == MB_BACKWARD ? f->bwdSum : (exactFwd ? f->fwdExact : f->fwdSum);
+    const MedGeom &geo = mode == MB_BACKWARD ? f->geoBS : (exactFwd ? f->geoFE : f->geoFS);
     g_last_kernel = mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>";
-    const int rc = medium_fill_materialised(m, P, bw ? f->geoB : f->geoF, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, d_desc, hp,
-                                            d_in, d_out, pool, g_stream);
-    P.dev.startNode = saved;
-    return rc;
+    return medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
+                                    (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream);
   }
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
   return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream);
@@ -241,7 +255,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
   if (!upload_weights(m)) return 1;
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
-    if (f->mediumOk && !(medium_refresh_weights(m, f->fwd) && medium_refresh_weights(m, f->bwd))) return 1;
+    if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
   }
   return 0;
 }
@@ -250,7 +264,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (!m) return;
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
-    medium_free(f->fwd); medium_free(f->bwd);
+    medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum);
     delete f;
   }
   free_machine_device(m);
@@ -338,7 +352,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
       g_last_kernel = "k_medium_tile<0>";
       tm.start();
-      rc = medium_forward_rolling(m, f->fwd, f->geoF, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
+      rc = medium_forward_rolling(m, f->fwdSum, f->geoFS, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);

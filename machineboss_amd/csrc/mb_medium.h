@@ -6,48 +6,65 @@
 
 namespace mb {
 
-constexpr int MED_MAXSLOT = 8;   // candidate slots evaluated together (two-pass max / sum-exp in registers)
+constexpr int MED_MAXSLOT = 4;      // candidate slots evaluated together (two-pass max / sum-exp in registers)
+constexpr int MED_DESC_WORDS = 16;  // descriptor words per chunk (64 B, fetched with scalar loads)
+
+// One candidate of one lane: 16 bytes, fetched with a single global_load_dwordx4.
+struct alignas(16) MedRec {
+  double w;          // log-weight (padding: -inf)
+  uint32_t srcOff;   // byte offset of the source value inside an LDS state vector (padding: the -inf sentinel)
+  uint32_t dstOff;   // slot 0 of a chunk only: byte offset of the state this lane finalises, 0xFFFFFFFF = idle lane
+};
 
 // The compiled "program" of a machine for one sweep direction.
-//   round  = up to LPG states of one silent level, one state per lane of a lane group;
-//   slot   = one candidate (source state, log-weight) per lane; slots of a round are grouped by table
-//            (0 match -> (i-1,o-1), 1 input-only -> (i-1,o), 2 output-only -> (i,o-1), 3 silent -> (i,o));
+//   round  = up to LPG states, one per lane of a lane group, that may be finalised together;
+//   slot   = one candidate (source value, log-weight) per lane; the vector a slot reads is wave-uniform:
+//            0 diag (i-1,o-1), 1 left (i-1,o), 2 down (i,o-1), 3 cur (same supercell, earlier rounds);
 //   chunk  = up to MED_MAXSLOT slots of one round, the unit the kernel software-pipelines.
-// meta[chunk*(1+MED_MAXSLOT)]: word 0 = ns | first<<4 | last<<5 | sync<<6 | round<<8;
-//                              word 1+k = slot offset (28 bits) | table<<28.
-// slot arrays: src/w[offset + token*LPG + laneInGroup], token = table-specific (pair index, inTok, outTok, 0).
+// desc[chunk*MED_DESC_WORDS]: word 0 = ns | first<<4 | last<<5 | sync<<6 | nsNext<<8 (15 = none) | single<<12;
+//                             words 1+3k.. = {offset, mulI, mulO | vector<<24} of slot k.
+// record index of (slot k, lane) = offset + inTok*mulI + outTok*mulO + laneInGroup.
+//
+// Two program kinds:
+//   EXACT   : silent transitions level by level, one candidate per edge in the reference's order -> every candidate
+//             is the single rounded add cell+logW of the reference, Viterbi is bit-exact.
+//   CLOSURE : (sum semiring only) the silent sub-graph is replaced by its transitive closure over the "base" states
+//             (states fed by emitting edges, plus the start state), so a supercell needs two stages instead of one per
+//             silent level: v = W* e  with  e = emit-only parts (stage 1)  and  W* = sum over silent paths (stage 2).
 struct MedProgDev {
-  int S, Spad, R, LPG, G, NS, nChunks;
+  int S, Spad, LPG, G, NS, nChunks;
   int nIn, nOut, startNode, endNode;
-  const int *meta;
-  const short *dest;        // [R*LPG] state finalised by (round, laneInGroup), -1 = idle
-  const uint16_t *src;      // candidate source state (padding: S, the -inf sentinel)
-  const double *w;          // candidate log-weight   (padding: -inf)
+  unsigned seedOff;         // byte offset of the value that receives the seed 0 at the origin cell
+  const int *desc;
+  const MedRec *rec;
 };
 
 struct MedProgram {
-  int G = 0, LPG = 0, R = 0, NS = 0, Spad = 0, nChunks = 0;
-  bool backward = false;
-  std::vector<int> meta;
-  std::vector<short> dest;
-  std::vector<uint16_t> src;
-  std::vector<uint32_t> eid;   // slot entry -> global edge id (0xFFFFFFFF = padding), to refresh weights per EM iteration
-  int *d_meta = nullptr;
-  short *d_dest = nullptr;
-  uint16_t *d_src = nullptr;
-  double *d_w = nullptr;
+  int G = 0, LPG = 0, NS = 0, Spad = 0, nChunks = 0, nRounds = 0;
+  bool backward = false, closure = false;
+  std::vector<int> desc;
+  std::vector<MedRec> rec;
+  std::vector<int> wref;            // per record: >= 0 global edge id, -1 padding (-inf), <= -2 closure pair -2-id
+  // closure structure (recomputed numerically whenever the weights change)
+  std::vector<std::vector<std::pair<int, uint32_t>>> silPred;   // node -> (predecessor node, edge id)
+  std::vector<char> isBase;
+  std::vector<std::vector<int>> closBase;                       // node -> sorted base ancestors
+  std::vector<std::vector<int>> closPair;                       // node -> pair id per ancestor (parallel to closBase)
+  int nPairs = 0;
+  int *d_desc = nullptr;
+  MedRec *d_rec = nullptr;
   MedProgDev dev{};
 };
 
 struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
 
-bool medium_build(const mb_machine *m, bool backward, int G, MedProgram &P);
+bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_free(MedProgram &P);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
-int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, const PairDesc *d_pairs,
-                             const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_pool,
-                             hipStream_t st);
+int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
+                             const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
+                             double *d_pool, hipStream_t st);
 int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st);

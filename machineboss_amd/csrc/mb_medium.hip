@@ -45,17 +45,122 @@ struct MedTileArgs {
   double *colHalo;            // rolling mode: per pair two [outLen+1][S] column buffers (ping-pong by strip parity)
   const long long *haloBase;  // rolling mode: per pair offset (in doubles) of its two buffers
   double *loglike;            // rolling mode: loglike[pair]
-  int C, TS, launch, rev, materialise, startNode;
+  int C, TS, launch, rev, materialise;
 };
 
 #define MED_L2E 1.44269504088896f
 #define MED_LN2 0.693147180559945f
+constexpr int MS = MED_MAXSLOT;
+constexpr int DW = MED_DESC_WORDS;
+
+typedef const __attribute__((address_space(4))) int *cdesc_t;          // descriptors: constant address space -> s_load
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef const __attribute__((address_space(1))) u32x4 *grec_t;         // candidate records: global_load_dwordx4
+
+struct Rec { double w; unsigned srcOff, dstOff; };
+
+__device__ __forceinline__ Rec med_load(grec_t g, int idx) {
+  const u32x4 r = g[idx];
+  Rec o;
+  o.w = __hiloint2double((int)r.y, (int)r.x);
+  o.srcOff = r.z; o.dstOff = r.w;
+  return o;
+}
+
+// record index of slot k for this lane: offset + inTok*mulI + outTok*mulO + laneInGroup (24-bit multiplies: full rate)
+__device__ __forceinline__ int med_idx(cdesc_t dp, int k, int it, int ot, int q) {
+  return (int)__umul24(it, dp[2 + 3 * k]) + (int)__umul24(ot, dp[3 + 3 * k] & 0xFFFFFF) + dp[1 + 3 * k] + q;
+}
+
+template <int N>
+__device__ __forceinline__ void med_fetch(cdesc_t dp, grec_t g, int it, int ot, int q, Rec (&R)[MS]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) R[k] = med_load(g, med_idx(dp, k, it, ot, q));
+}
+
+// LDS byte offset of the vector a slot reads, relative to the lane's own column: 0 diag, 1 left, 2 down, 3 cur.
+__device__ __forceinline__ int med_vofs(int vsel, int sCur, int sPrev, int sPrev2, int colStride) {
+  const int slotOff = vsel == 3 ? sCur : (vsel == 0 ? sPrev2 : sPrev);
+  return slotOff - (vsel < 2 ? colStride : 0);
+}
+
+__device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(const double *)(ldsb + off); }
+
+// pass 1 of a chunk: N candidates cell+logW (fp64) and their maximum
+template <int N>
+__device__ __forceinline__ void med_cands(cdesc_t dp, const char *ldsb, int myColBase, int sCur, int sPrev, int sPrev2,
+                                          int colStride, const Rec (&R)[MS], double (&v)[MS], double &mx) {
+  double x[N > 0 ? N : 1];
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    x[k] = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3 + 3 * k] >> 24, sCur, sPrev, sPrev2, colStride) + (int)R[k].srcOff);
+#pragma unroll
+  for (int k = 0; k < N; ++k) { v[k] = x[k] + R[k].w; mx = dmax(mx, v[k]); }
+}
+
+template <int N>
+__device__ __forceinline__ float med_sumexp(const double (&v)[MS], double gM) {
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) s += __builtin_amdgcn_exp2f((float)(v[k] - gM) * MED_L2E);
+  return s;
+}
+
+static_assert(MED_MAXSLOT == 4, "MED_SWITCH enumerates the slot counts 1..MED_MAXSLOT");
+#define MED_SWITCH(n, CALL)                                                                     \
+  switch (n) {                                                                                  \
+    case 1: { CALL(1); } break; case 2: { CALL(2); } break; case 3: { CALL(3); } break;         \
+    default: { CALL(4); } break;                                                                \
+  }
+
+__device__ __forceinline__ void med_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- slow path: one supercell evaluated with generic loops (only the origin supercell of a pair uses it) ----------
+template <int MODE>
+__device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
+                                                int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
+                                                unsigned seedOff, bool origin, bool lanesOn) {
+  double accM = -INFINITY; float accS = 0.0f;
+  for (int ch = 0; ch < nChunks; ++ch) {
+    cdesc_t dp = desc + ch * DW;
+    const int hdr = dp[0];
+    const int ns = hdr & 15;
+    const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1, sync = (hdr >> 6) & 1;
+    unsigned dstOff = 0xFFFFFFFFu;
+    for (int k = 0; k < ns; ++k) {
+      const Rec r = med_load(grec, med_idx(dp, k, it, ot, q));
+      if (k == 0) {
+        dstOff = r.dstOff;
+        if (first) {
+          const bool seed = origin && dstOff == seedOff;   // cell(0,0,start) = 0 (src/forward.defs.h:36, viterbi.cpp:30)
+          accM = seed ? 0.0 : -INFINITY; accS = seed ? 1.0f : 0.0f;
+        }
+      }
+      const double v = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3 + 3 * k] >> 24, sCur, sPrev, sPrev2, colStride) + (int)r.srcOff) + r.w;
+      if (MODE == MB_VITERBI) accM = dmax(accM, v);
+      else {
+        const double nm = dmax(accM, v), gM = (nm == -INFINITY) ? 0.0 : nm;
+        accS = accS * __builtin_amdgcn_exp2f((float)(accM - gM) * MED_L2E) + __builtin_amdgcn_exp2f((float)(v - gM) * MED_L2E);
+        accM = nm;
+      }
+    }
+    if (last) {
+      const double res = (MODE == MB_VITERBI) ? accM
+                                               : ((accM == -INFINITY) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
+      if (lanesOn && (int)dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)dstOff)) = res;
+    }
+    if (sync) med_wave_sync();
+  }
+}
 
 template <int MODE, int G>
 __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs A) {
   extern __shared__ double lds[];
   constexpr int LPG = 64 / G;
-  constexpr int MS = MED_MAXSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   const int S = P.S, Spad = P.Spad, NS = P.NS, C = A.C;
@@ -90,14 +195,11 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
     return cells + (ro * I + ri) * S;
   };
   auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
-  int *ldsMeta = (int *)(lds + (long long)NS * (C + 1) * Spad);
-  short *ldsDest = (short *)(ldsMeta + P.nChunks * (1 + MS));
 
-  // ---- program metadata into LDS --------------------------------------------------------------------------------
-  for (int j = tid; j < P.nChunks * (1 + MS); j += blockDim.x) ldsMeta[j] = P.meta[j];
-  for (int j = tid; j < P.R * LPG; j += blockDim.x) ldsDest[j] = P.dest[j];
-  // sentinel: padding candidates (source index S, weight -inf) must read -inf, never stale LDS (NaN + -inf = NaN)
-  for (int j = tid; j < NS * (C + 1); j += blockDim.x) lds[(long long)j * Spad + S] = -INFINITY;
+  // ---- LDS init: every vector starts as -inf, so that neighbours that do not exist (i = 0, o = 0), the sentinel
+  //      entry [S] read by padding candidates, and not-yet-active columns all read -inf without any predicate ----
+  for (int j = tid; j < NS * (C + 1) * Spad; j += blockDim.x) lds[j] = -INFINITY;
+  __syncthreads();
   // ---- preload the ring state of steps t0-1 (and t0-2 when match edges exist) --------------------------------
   for (int dt = 1; dt < NS; ++dt) {
     const int tp = t0 - dt;
@@ -115,10 +217,13 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   }
   __syncthreads();
 
-  const uint16_t *__restrict__ gsrc = P.src;
-  const double *__restrict__ gw = P.w;
+  cdesc_t desc = (cdesc_t)P.desc;
+  grec_t grec = (grec_t)P.rec;
+  const int nChunks = P.nChunks;
+  const char *ldsb = (const char *)lds;
+  const int colStride = Spad * 8, slotStride = (C + 1) * colStride;
+  const int myColBase = (c + 1) * colStride;
   int slotCur = t0 % NS;
-  // output token of the first step
   int otNext = 0;
   {
     const int o = t0 - c;
@@ -133,6 +238,7 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
       otNext = (colValid && on > 0 && on <= outLen) ? (rev ? out[outLen - on] : out[on - 1]) : 0;
     }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
+    const int sCur = slotCur * slotStride, sPrev = slotPrev * slotStride, sPrev2 = slotPrev2 * slotStride;
     // halo supercell (i0-1, t+1) for the next step, fetched cooperatively by the whole workgroup
     double hv[4];
     const bool wantHalo = (i0 > 0) && (t + 1 <= outLen);
@@ -144,88 +250,73 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
         hv[k] = (j < S) ? hs[j] : 0.0;
       }
     }
-    double *cur = ring(slotCur, c + 1);
-    const double *down = ring(slotPrev, c + 1), *left = ring(slotPrev, c), *diag = ring(slotPrev2, c);
-    const bool origin = active && (i == 0 && o == 0);
-    const bool anyOrigin = __any(origin);
-    // per-table token offsets and validity
-    const int tokM = (it * (P.nOut + 1) + ot) * LPG + q, tokI = it * LPG + q, tokO = ot * LPG + q;
-    const bool okM = active && i > 0 && o > 0, okI = active && i > 0, okO = active && o > 0;
-
-    // software pipeline over chunks: candidates of chunk c+1 are fetched while chunk c is evaluated
-    int cS[MS]; double cW[MS];
-    int nS[MS]; double nW[MS];
-    auto fetch = [&](int ch, int (&fs)[MS], double (&fw)[MS]) {
-      const int m0 = __builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS)]);
-      const int ns = m0 & 15;
-#pragma unroll
-      for (int k = 0; k < MS; ++k) {
-        if (k < ns) {
-          const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS) + 1 + k]);
-          const unsigned tb = sd >> 28;
-          const int off = (int)(sd & 0x0FFFFFFFu);
-          const int idx = off + (tb == 0 ? tokM : (tb == 1 ? tokI : (tb == 2 ? tokO : q)));
-          fs[k] = gsrc[idx]; fw[k] = gw[idx];
-        } else { fs[k] = S; fw[k] = -INFINITY; }
-      }
-    };
-    fetch(0, cS, cW);
-    double accM = -INFINITY; float accS = 0.0f;
-    for (int ch = 0; ch < P.nChunks; ++ch) {
-      const int m0 = __builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS)]);
-      const int ns = m0 & 15, round = m0 >> 8;
-      const bool first = (m0 >> 4) & 1, last = (m0 >> 5) & 1, sync = (m0 >> 6) & 1;
-      if (ch + 1 < P.nChunks) fetch(ch + 1, nS, nW);
-      const int d = ldsDest[round * LPG + q];
-      // pass 1: candidates and their maximum
-      double v[MS];
-      double mx = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < MS; ++k) {
-        if (k < ns) {
-          const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane(ldsMeta[ch * (1 + MS) + 1 + k]);
-          const unsigned tb = sd >> 28;
-          const double *vec = tb == 0 ? diag : (tb == 1 ? left : (tb == 2 ? down : cur));
-          const bool ok = tb == 0 ? okM : (tb == 1 ? okI : (tb == 2 ? okO : active));
-          const double x = vec[cS[k]];
-          v[k] = ok ? x + cW[k] : -INFINITY;
-          mx = dmax(mx, v[k]);
-        } else v[k] = -INFINITY;
-      }
-      if (anyOrigin && first && origin && d == A.startNode) {   // the seed cell(0,0,start) = 0 (src/forward.defs.h:36)
-        accM = 0.0; accS = 1.0f;
-      } else if (first) { accM = -INFINITY; accS = 0.0f; }
-      if (MODE == MB_VITERBI) {
-        accM = dmax(accM, mx);
-      } else {
-        // pass 2: sum of exp(candidate - max) in fp32; a lone candidate gives exactly 1.0 -> log 0 -> exact result
-        const double newM = dmax(accM, mx);
-        const double gM = (newM == -INFINITY) ? 0.0 : newM;
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < MS; ++k)
-          if (k < ns) s += __builtin_amdgcn_exp2f((float)(v[k] - gM) * MED_L2E);
-        if (!(first && !anyOrigin)) s += accS * __builtin_amdgcn_exp2f((float)(accM - gM) * MED_L2E);
-        accS = s; accM = newM;
-      }
-      if (last) {
-        double res;
-        if (MODE == MB_VITERBI) res = accM;
-        else res = ((accM == -INFINITY) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
-        if (active && d >= 0) cur[d] = res;
-        if (sync) {  // wave-local: the next round reads what other lanes of this wave just wrote
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t == 0 && a == 0) {
+      // the origin supercell (0,0) is the only active one at step 0 of strip 0: generic slow path with the seed
+      if (wv == 0) med_slow_supercell<MODE>(desc, grec, nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
+                                            P.seedOff, active && i == 0 && o == 0, active);
+    } else {
+      // ---- fast path: software pipeline over chunks; records of chunk ch+1 are fetched while ch is evaluated -----
+      Rec RA[MS], RB[MS];
+      double accM = -INFINITY; float accS = 0.0f;
+      auto body = [&](int ch, Rec (&CUR)[MS], Rec (&NXT)[MS]) __attribute__((always_inline)) {
+        cdesc_t dp = desc + ch * DW;
+        const int hdr = dp[0];
+        const int ns = hdr & 15, nsNext = (hdr >> 8) & 15;
+        if (nsNext != 15) {   // 15 marks the last chunk
+          cdesc_t dn = dp + DW;
+#define CALL(N) med_fetch<N>(dn, grec, it, ot, q, NXT)
+          MED_SWITCH(nsNext, CALL)
+#undef CALL
         }
+        if (hdr & (1 << 12)) {
+          // every lane of this round has at most one candidate: the cell is exactly cand = source + logW
+          const double res = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride) + (int)CUR[0].srcOff) + CUR[0].w;
+          if (active && (int)CUR[0].dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)CUR[0].dstOff)) = res;
+        } else {
+          const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1;
+          double v[MS];
+          double mx = -INFINITY;
+#define CALL(N) med_cands<N>(dp, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, CUR, v, mx)
+          MED_SWITCH(ns, CALL)
+#undef CALL
+          if (first) { accM = -INFINITY; accS = 0.0f; }
+          if (MODE == MB_VITERBI) {
+            accM = dmax(accM, mx);
+          } else {
+            // pass 2: sum of exp(candidate - max) in fp32
+            const double newM = dmax(accM, mx);
+            const double gM = (newM == -INFINITY) ? 0.0 : newM;
+            float s = 0.0f;
+#define CALL(N) s = med_sumexp<N>(v, gM)
+            MED_SWITCH(ns, CALL)
+#undef CALL
+            if (!first) s += accS * __builtin_amdgcn_exp2f((float)(accM - gM) * MED_L2E);
+            accS = s; accM = newM;
+          }
+          if (last) {
+            double res;
+            if (MODE == MB_VITERBI) res = accM;
+            else res = ((accM == -INFINITY) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
+            if (active && (int)CUR[0].dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)CUR[0].dstOff)) = res;
+          }
+        }
+        if (hdr & (1 << 6)) med_wave_sync();   // the next round reads what other lanes of this wave just wrote
+      };
+      {
+        const int n0 = desc[0] & 15;
+#define CALL(N) med_fetch<N>(desc, grec, it, ot, q, RA)
+        MED_SWITCH(n0, CALL)
+#undef CALL
       }
-#pragma unroll
-      for (int k = 0; k < MS; ++k) { cS[k] = nS[k]; cW[k] = nW[k]; }
+      for (int ch = 0; ch < nChunks; ch += 2) {
+        body(ch, RA, RB);
+        if (ch + 1 >= nChunks) break;
+        body(ch + 1, RB, RA);
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    med_wave_sync();
     // ---- copy the finished supercell out ----------------------------------------------------------------------
+    const double *cur = (const double *)(ldsb + (myColBase + sCur));
     if (active) {
       if (A.materialise) {
         double *dstp = cellPtr(i, o);
@@ -254,98 +345,184 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
 // ------------------------------------------------------------------------------------------------------------
 // host side: program compiler
 // ------------------------------------------------------------------------------------------------------------
-struct Cand { uint16_t src; uint32_t eid; };
+struct Cand { int src; int wref; };   // src: index into the LDS state vector; wref: see MedProgram::wref
 
-static void build_program(const mb_machine *m, bool backward, int G, MedProgram &P) {
+static double host_lse(double a, double b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const double mx = a > b ? a : b, mn = a > b ? b : a;
+  return mx + log1p(exp(mn - mx));
+}
+
+static void build_program(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P) {
   const int S = m->S, LPG = 64 / G, nIn = m->nIn, nOut = m->nOut;
-  constexpr int MS = MED_MAXSLOT;
-  P.G = G; P.LPG = LPG; P.backward = backward;
-  P.Spad = (S + 2) & ~1;   // >= S+1: entry [S] of every LDS vector is a -inf sentinel read by padding slots
+  P = MedProgram();
+  P.G = G; P.LPG = LPG; P.backward = backward; P.closure = closure;
   P.NS = m->hasMatch ? 3 : 2;
   const std::vector<int> &lev = backward ? m->levB : m->levF;
   const std::vector<int> &off = backward ? m->outOff : m->inOff;
   const std::vector<uint32_t> &perm = backward ? m->outPerm : m->inPerm;
   const int nLev = backward ? m->nLevB : m->nLevF;
-  auto other = [&](uint32_t e) { return backward ? m->dst[e] : m->src[e]; };
+  const int startNode = backward ? S - 1 : 0;
+  auto other = [&](uint32_t e) { return (int)(backward ? m->dst[e] : m->src[e]); };
   auto row = [&](int st, int it, int ot) { return ((long long)st * (nIn + 1) + it) * (nOut + 1) + ot; };
-  // candidate list of (state, table, token) in the reference's iteration order
-  auto cands = [&](int st, int T, int tok, std::vector<Cand> &out) {
+  const int ntok[3] = {(nIn + 1) * (nOut + 1), nIn + 1, nOut + 1};
+  // emitting candidates of (node, table, token) in the reference's iteration order
+  auto emitCands = [&](int st, int T, int tok, std::vector<Cand> &out) {
     out.clear();
     int it = 0, ot = 0;
     if (T == 0) { it = tok / (nOut + 1); ot = tok % (nOut + 1); if (!it || !ot) return; }
     else if (T == 1) { it = tok; if (!it) return; }
-    else if (T == 2) { ot = tok; if (!ot) return; }
+    else { ot = tok; if (!ot) return; }
     const long long rw = row(st, it, ot);
-    for (int a = off[rw]; a < off[rw + 1]; ++a) {
-      const uint32_t e = perm[a];
-      const uint32_t o = other(e);
-      if (T == 3 && (backward ? o <= (uint32_t)st : o >= (uint32_t)st)) continue;  // silent self-loop on state 0
-      out.push_back({(uint16_t)o, e});
-    }
+    for (int a = off[rw]; a < off[rw + 1]; ++a) out.push_back({other(perm[a]), (int)perm[a]});
   };
-  const int ntok[4] = {(nIn + 1) * (nOut + 1), nIn + 1, nOut + 1, 1};
-  // rounds: per level, states sorted by candidate count (descending) so that a round's slot count is tight
+  // silent predecessors (a silent self-loop on state 0 never contributes to a fill, see mb_machine.cpp)
+  P.silPred.assign(S, {});
+  for (int st = 0; st < S; ++st) {
+    const long long rw = row(st, 0, 0);
+    for (int a = off[rw]; a < off[rw + 1]; ++a) {
+      const int o = other(perm[a]);
+      if (backward ? o <= st : o >= st) continue;
+      P.silPred[st].push_back({o, perm[a]});
+    }
+  }
+  std::vector<std::array<int, 3>> emitDeg(S);
   std::vector<Cand> tmp;
+  for (int s = 0; s < S; ++s)
+    for (int T = 0; T < 3; ++T) {
+      int mx = 0;
+      for (int tok = 0; tok < ntok[T]; ++tok) { emitCands(s, T, tok, tmp); mx = std::max(mx, (int)tmp.size()); }
+      emitDeg[s][T] = mx;
+    }
+
+  // ---- nodes of the program: (destination index in the LDS vector, emit candidates of which state, "cur" candidates)
+  struct Node { int dst; int emitOf; std::vector<Cand> cur; int stage; };
+  std::vector<Node> nodes;
+  int nExtra = 0;
+  if (!closure) {
+    for (int s = 0; s < S; ++s) {
+      Node n{s, s, {}, lev[s]};
+      for (auto &pe : P.silPred[s]) n.cur.push_back({pe.first, (int)pe.second});
+      nodes.push_back(n);
+    }
+  } else {
+    // base states: fed by emitting edges, or the start node (which carries the seed)
+    P.isBase.assign(S, 0);
+    for (int s = 0; s < S; ++s) P.isBase[s] = (emitDeg[s][0] || emitDeg[s][1] || emitDeg[s][2] || s == startNode) ? 1 : 0;
+    // closure structure: base ancestors through silent paths, in topological order
+    P.closBase.assign(S, {}); P.closPair.assign(S, {});
+    std::vector<int> order(S);
+    std::iota(order.begin(), order.end(), 0);
+    if (backward) std::reverse(order.begin(), order.end());
+    for (int d : order) {
+      std::vector<int> anc;
+      for (auto &pe : P.silPred[d]) {
+        const int sp = pe.first;
+        if (P.isBase[sp]) anc.push_back(sp);
+        anc.insert(anc.end(), P.closBase[sp].begin(), P.closBase[sp].end());
+      }
+      std::sort(anc.begin(), anc.end());
+      anc.erase(std::unique(anc.begin(), anc.end()), anc.end());
+      P.closBase[d] = anc;
+      for (size_t k = 0; k < anc.size(); ++k) P.closPair[d].push_back(P.nPairs++);
+    }
+    // e-slots: a base state that also has silent predecessors keeps its emit-only part in an extra vector entry
+    std::vector<int> eslot(S, -1);
+    for (int s = 0; s < S; ++s)
+      if (P.isBase[s] && !P.silPred[s].empty()) eslot[s] = S + 1 + nExtra++;
+    auto baseIdx = [&](int b) { return eslot[b] >= 0 ? eslot[b] : b; };
+    for (int s = 0; s < S; ++s) {
+      if (P.isBase[s] || P.silPred[s].empty()) nodes.push_back(Node{baseIdx(s), s, {}, 0});   // stage 1 (also dead states)
+      if (!P.silPred[s].empty()) {
+        Node n{s, -1, {}, 1};
+        if (P.isBase[s]) n.cur.push_back({eslot[s], -2 - P.nPairs});   // own emit part, weight 0 (a constant "pair")
+        for (size_t k = 0; k < P.closBase[s].size(); ++k) n.cur.push_back({baseIdx(P.closBase[s][k]), -2 - P.closPair[s][k]});
+        nodes.push_back(n);
+      }
+    }
+  }
+  P.Spad = (S + 1 + nExtra + 1) & ~1;   // [S] = -inf sentinel, then the e-slots; even length
+  const int nStages = closure ? 2 : nLev;
+
+  // ---- rounds: per stage, nodes sorted so that a round is homogeneous in (tables used, candidate count) ----------
+  auto sig = [&](const Node &n) {
+    std::array<int, 4> d{0, 0, 0, (int)n.cur.size()};
+    if (n.emitOf >= 0) for (int T = 0; T < 3; ++T) d[T] = emitDeg[n.emitOf][T];
+    return d;
+  };
   std::vector<std::vector<int>> rounds;
   std::vector<unsigned char> sync;
-  std::vector<std::array<int, 4>> degOf(S);
-  for (int s = 0; s < S; ++s)
-    for (int T = 0; T < 4; ++T) {
-      int mx = 0;
-      for (int tok = 0; tok < ntok[T]; ++tok) { cands(s, T, tok, tmp); mx = std::max(mx, (int)tmp.size()); }
-      degOf[s][T] = mx;
-    }
-  for (int l = 0; l < nLev; ++l) {
-    std::vector<int> st;
-    for (int s = 0; s < S; ++s) if (lev[s] == l) st.push_back(s);
-    auto tot = [&](int s) { return degOf[s][0] + degOf[s][1] + degOf[s][2] + degOf[s][3]; };
-    std::stable_sort(st.begin(), st.end(), [&](int x, int y) {
-      if (tot(x) != tot(y)) return tot(x) > tot(y);
-      return degOf[x] > degOf[y];
+  for (int st = 0; st < nStages; ++st) {
+    std::vector<int> ids;
+    for (int k = 0; k < (int)nodes.size(); ++k) if (nodes[k].stage == st) ids.push_back(k);
+    std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) {
+      const auto dx = sig(nodes[x]), dy = sig(nodes[y]);
+      const int tx = dx[0] + dx[1] + dx[2] + dx[3], ty = dy[0] + dy[1] + dy[2] + dy[3];
+      if (tx != ty) return tx > ty;
+      return dx > dy;
     });
-    for (size_t k = 0; k < st.size(); k += LPG) {
-      rounds.emplace_back(st.begin() + k, st.begin() + std::min(st.size(), k + LPG));
+    for (size_t k = 0; k < ids.size(); k += LPG) {
+      rounds.emplace_back(ids.begin() + k, ids.begin() + std::min(ids.size(), k + LPG));
       sync.push_back(0);
     }
     if (!sync.empty()) sync.back() = 1;
   }
   if (!sync.empty()) sync.back() = 0;
-  const int R = (int)rounds.size();
-  P.R = R;
-  P.dest.assign((size_t)R * LPG, -1);
-  for (int r = 0; r < R; ++r) for (size_t k = 0; k < rounds[r].size(); ++k) P.dest[(size_t)r * LPG + k] = (short)rounds[r][k];
-  P.meta.clear(); P.src.clear(); P.eid.clear();
-  for (int r = 0; r < R; ++r) {
-    // unified slot list of the round: (table, j)
-    std::vector<std::pair<int, int>> slots;
+  P.nRounds = (int)rounds.size();
+
+  // ---- descriptors and records -------------------------------------------------------------------------------------
+  const int mulI[4] = {LPG * (nOut + 1), LPG, 0, 0}, mulO[4] = {LPG, 0, LPG, 0};
+  const int ntokT[4] = {ntok[0], ntok[1], ntok[2], 1};
+  const MedRec padRec{-INFINITY, (uint32_t)S * 8u, 0xFFFFFFFFu};
+  auto candsOf = [&](const Node &n, int T, int tok, std::vector<Cand> &out) {
+    if (T == 3) { out = n.cur; return; }
+    out.clear();
+    if (n.emitOf >= 0) emitCands(n.emitOf, T, tok, out);
+  };
+  for (int r = 0; r < P.nRounds; ++r) {
+    std::vector<std::pair<int, int>> slots;   // (table, j)
+    bool single = true;
+    for (int id : rounds[r]) { const auto d = sig(nodes[id]); if (d[0] + d[1] + d[2] + d[3] > 1) single = false; }
     for (int T = 0; T < 4; ++T) {
       int ns = 0;
-      for (int s : rounds[r]) ns = std::max(ns, degOf[s][T]);
+      for (int id : rounds[r]) ns = std::max(ns, sig(nodes[id])[T]);
       for (int j = 0; j < ns; ++j) slots.push_back({T, j});
     }
-    const int nch = std::max<int>(1, ((int)slots.size() + MS - 1) / MS);
+    if (slots.empty()) slots.push_back({3, 0});   // a round of dead states still writes -inf through one padded slot
+    if (slots.size() != 1) single = false;
+    const int nch = ((int)slots.size() + MS - 1) / MS;
     for (int chn = 0; chn < nch; ++chn) {
       const int k0 = chn * MS, k1 = std::min<int>((int)slots.size(), k0 + MS);
-      const size_t mbase = P.meta.size();
-      P.meta.resize(mbase + 1 + MS, 0);
-      P.meta[mbase] = (k1 - k0) | ((chn == 0) << 4) | ((chn == nch - 1) << 5) | ((chn == nch - 1 && sync[r]) << 6) | (r << 8);
+      const size_t db = P.desc.size();
+      P.desc.resize(db + DW, 0);
+      P.desc[db] = (k1 - k0) | ((chn == 0) << 4) | ((chn == nch - 1) << 5) | ((chn == nch - 1 && sync[r]) << 6) | (15 << 8) | (single << 12);
+      if (db) P.desc[db - DW] = (P.desc[db - DW] & ~(15 << 8)) | ((k1 - k0) << 8);   // nsNext of the previous chunk
       for (int k = k0; k < k1; ++k) {
         const int T = slots[k].first, j = slots[k].second;
-        const size_t b0 = P.src.size();
-        P.meta[mbase + 1 + (k - k0)] = (int)((unsigned)b0 | ((unsigned)T << 28));
-        P.src.resize(b0 + (size_t)ntok[T] * LPG, (uint16_t)S); P.eid.resize(b0 + (size_t)ntok[T] * LPG, 0xFFFFFFFFu);
-        for (size_t lane = 0; lane < rounds[r].size(); ++lane)
-          for (int tok = 0; tok < ntok[T]; ++tok) {
-            cands(rounds[r][lane], T, tok, tmp);
-            if (j < (int)tmp.size()) {
-              P.src[b0 + (size_t)tok * LPG + lane] = tmp[j].src;
-              P.eid[b0 + (size_t)tok * LPG + lane] = tmp[j].eid;
-            }
+        const size_t b0 = P.rec.size();
+        P.desc[db + 1 + 3 * (k - k0)] = (int)b0;
+        P.desc[db + 2 + 3 * (k - k0)] = mulI[T];
+        P.desc[db + 3 + 3 * (k - k0)] = mulO[T] | (T << 24);
+        P.rec.resize(b0 + (size_t)ntokT[T] * LPG, padRec);
+        P.wref.resize(b0 + (size_t)ntokT[T] * LPG, -1);
+        for (size_t ln = 0; ln < rounds[r].size(); ++ln) {
+          const Node &n = nodes[rounds[r][ln]];
+          for (int tok = 0; tok < ntokT[T]; ++tok) {
+            const size_t idx = b0 + (size_t)tok * LPG + ln;
+            if (k == k0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u;
+            candsOf(n, T, tok, tmp);
+            if (j < (int)tmp.size()) { P.rec[idx].srcOff = (uint32_t)tmp[j].src * 8u; P.wref[idx] = tmp[j].wref; }
           }
+        }
       }
     }
   }
-  P.nChunks = (int)(P.meta.size() / (1 + MS));
+  P.nChunks = (int)(P.desc.size() / DW);
+  // where the seed goes: the stage-1 destination of the start node
+  P.dev.seedOff = 0;
+  for (const Node &n : nodes)
+    if (n.emitOf == startNode && n.stage == (closure ? 0 : lev[startNode])) P.dev.seedOff = (unsigned)n.dst * 8u;
 }
 
 template <class T>
@@ -356,28 +533,54 @@ static bool up(T *&d, const std::vector<T> &h) {
   return true;
 }
 
+// (Re)evaluate every record's log-weight: plain edges take logW[edge]; closure pairs take the log-sum over all silent
+// paths from the base state to the node (recurrence over the silent DAG in topological order).
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
-  std::vector<double> w(P.eid.size());
-  for (size_t k = 0; k < w.size(); ++k) w[k] = P.eid[k] == 0xFFFFFFFFu ? -INFINITY : m->logW[P.eid[k]];
-  if (!up(P.d_w, w)) return false;
-  P.dev.w = P.d_w;
+  std::vector<double> pairW(P.nPairs + 1, -INFINITY);
+  pairW[P.nPairs] = 0.0;   // the constant "own emit part" pair
+  if (P.closure) {
+    const int S = m->S;
+    std::vector<int> order(S);
+    std::iota(order.begin(), order.end(), 0);
+    if (P.backward) std::reverse(order.begin(), order.end());
+    for (int d : order) {
+      const std::vector<int> &anc = P.closBase[d];
+      for (auto &pe : P.silPred[d]) {
+        const int sp = pe.first;
+        const double w = m->logW[pe.second];
+        auto addTo = [&](int b, double x) {
+          const size_t k = std::lower_bound(anc.begin(), anc.end(), b) - anc.begin();
+          double &t = pairW[P.closPair[d][k]];
+          t = host_lse(t, x);
+        };
+        if (P.isBase[sp]) addTo(sp, w);
+        for (size_t k = 0; k < P.closBase[sp].size(); ++k) addTo(P.closBase[sp][k], pairW[P.closPair[sp][k]] + w);
+      }
+    }
+  }
+  for (size_t k = 0; k < P.rec.size(); ++k) {
+    const int r = P.wref[k];
+    P.rec[k].w = r >= 0 ? m->logW[r] : (r == -1 ? -INFINITY : pairW[-2 - r]);
+  }
+  if (!up(P.d_rec, P.rec)) return false;
+  P.dev.rec = P.d_rec;
   return true;
 }
 
-bool medium_build(const mb_machine *m, bool backward, int G, MedProgram &P) {
-  build_program(m, backward, G, P);
-  if (P.src.size() >= (1u << 28)) { set_error("machine too large for the tiled kernel family"); return false; }
-  if (!up(P.d_meta, P.meta) || !up(P.d_dest, P.dest) || !up(P.d_src, P.src)) return false;
+bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P) {
+  build_program(m, backward, closure, G, P);
+  if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 24)) { set_error("machine too large for the tiled kernel family"); return false; }
+  if (!up(P.d_desc, P.desc)) return false;
   MedProgDev &d = P.dev;
-  d.S = m->S; d.Spad = P.Spad; d.R = P.R; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
+  d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
   d.nIn = m->nIn; d.nOut = m->nOut;
   d.startNode = backward ? m->S - 1 : 0; d.endNode = backward ? 0 : m->S - 1;
-  d.meta = P.d_meta; d.dest = P.d_dest; d.src = P.d_src;
+  d.desc = P.d_desc;
   return medium_refresh_weights(m, P);
 }
 
 void medium_free(MedProgram &P) {
-  void *ptrs[] = {P.d_meta, P.d_dest, P.d_src, P.d_w};
+  void *ptrs[] = {P.d_desc, P.d_rec};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   P = MedProgram();
 }
@@ -385,9 +588,8 @@ void medium_free(MedProgram &P) {
 // Geometry: columns per strip limited by the 160 KB LDS of a CU.
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   const size_t perCol = (size_t)P.NS * P.Spad * sizeof(double);
-  const size_t progBytes = (size_t)P.nChunks * (1 + MED_MAXSLOT) * sizeof(int) + (size_t)P.R * P.LPG * sizeof(short) + 64;
-  if (progBytes > 48 * 1024) return false;
-  const size_t budget = 160 * 1024 - 512 - progBytes;
+  const size_t progBytes = 0;
+  const size_t budget = 160 * 1024 - 512;
   long long maxCols = (long long)(budget / perCol) - 1;   // one extra column for the halo
   if (maxCols < P.G) return false;
   int waves = (int)std::min<long long>(maxCols / P.G, 16);
@@ -419,9 +621,9 @@ static void set_lds_attr() {
 }
 
 // Materialised fill of a chunk of pairs: wavefront of parallelogram tiles, launch index = 2*strip + block.
-int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, const PairDesc *d_pairs,
-                             const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_pool,
-                             hipStream_t st) {
+int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
+                             const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
+                             double *d_pool, hipStream_t st) {
   if (pairs.empty()) return 0;
   set_lds_attr();
   int maxIn = 0, maxOut = 0;
@@ -437,12 +639,14 @@ int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const Med
   const int NB = (T + TS - 1) / TS;
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
-  A.loglike = nullptr; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1; A.startNode = P.dev.startNode;
+  A.loglike = nullptr; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
+  MedProgDev dev = P.dev;
+  if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
   const dim3 grid(NA, (unsigned)pairs.size()), block(geo.waves * 64);
   for (int launch = 0; launch <= 2 * (NA - 1) + (NB - 1); ++launch) {
     A.launch = launch;
-    if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
-    else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
+    if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, st, dev, A);
+    else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
   return hip_ok(hipGetLastError(), "medium tile launch") ? 0 : 1;
 }
@@ -458,7 +662,7 @@ int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGe
   const int C = geo.C, NA = (maxIn + C) / C;
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
-  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.startNode = P.dev.startNode;
+  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0;
   const dim3 grid(1, (unsigned)pairs.size()), block(geo.waves * 64);
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
