@@ -7,7 +7,7 @@
 namespace mb {
 
 constexpr int MED_MAXSLOT = 4;      // candidate slots evaluated together (two-pass max / sum-exp in registers)
-constexpr int MED_DESC_WORDS = 16;  // descriptor words per chunk (64 B, fetched with scalar loads)
+constexpr int MED_DESC_WORDS = 8;   // descriptor words per chunk (32 B, fetched with scalar loads)
 
 // One candidate of one lane: 16 bytes, fetched with a single global_load_dwordx4.
 struct alignas(16) MedRec {
@@ -20,10 +20,10 @@ struct alignas(16) MedRec {
 //   round  = up to LPG states, one per lane of a lane group, that may be finalised together;
 //   slot   = one candidate (source value, log-weight) per lane; the vector a slot reads is wave-uniform:
 //            0 diag (i-1,o-1), 1 left (i-1,o), 2 down (i,o-1), 3 cur (same supercell, earlier rounds);
-//   chunk  = up to MED_MAXSLOT slots of one round, the unit the kernel software-pipelines.
+//   chunk  = up to MED_MAXSLOT slots of one round that read the same vector, the unit the kernel software-pipelines.
 // desc[chunk*MED_DESC_WORDS]: word 0 = ns | first<<4 | last<<5 | sync<<6 | nsNext<<8 (15 = none) | single<<12;
-//                             words 1+3k.. = {offset, mulI, mulO | vector<<24} of slot k.
-// record index of (slot k, lane) = offset + inTok*mulI + outTok*mulO + laneInGroup.
+//                             words 1..4 = offset, mulI, mulO | vector<<24, stride between the chunk's slots.
+// record index of (slot k, lane) = offset + inTok*mulI + outTok*mulO + laneInGroup + k*stride.
 //
 // Two program kinds:
 //   EXACT   : silent transitions level by level, one candidate per edge in the reference's order -> every candidate

@@ -67,18 +67,20 @@ __device__ __forceinline__ Rec med_load(grec_t g, int idx) {
   return o;
 }
 
-// record index of slot k for this lane: offset + inTok*mulI + outTok*mulO + laneInGroup (24-bit multiplies: full rate)
-__device__ __forceinline__ int med_idx(cdesc_t dp, int k, int it, int ot, int q) {
-  return (int)__umul24(it, dp[2 + 3 * k]) + (int)__umul24(ot, dp[3 + 3 * k] & 0xFFFFFF) + dp[1 + 3 * k] + q;
+// first record of a chunk for this lane: offset + inTok*mulI + outTok*mulO + laneInGroup (24-bit multiplies: full
+// rate); slot k of the chunk follows at k*stride.  All slots of a chunk belong to one table, hence read one vector.
+__device__ __forceinline__ int med_idx0(cdesc_t dp, int it, int ot, int q) {
+  return (int)__umul24(it, dp[2]) + (int)__umul24(ot, dp[3] & 0xFFFFFF) + dp[1] + q;
 }
 
 template <int N>
 __device__ __forceinline__ void med_fetch(cdesc_t dp, grec_t g, int it, int ot, int q, Rec (&R)[MS]) {
+  const int i0 = med_idx0(dp, it, ot, q), stride = dp[4];
 #pragma unroll
-  for (int k = 0; k < N; ++k) R[k] = med_load(g, med_idx(dp, k, it, ot, q));
+  for (int k = 0; k < N; ++k) R[k] = med_load(g, i0 + k * stride);
 }
 
-// LDS byte offset of the vector a slot reads, relative to the lane's own column: 0 diag, 1 left, 2 down, 3 cur.
+// LDS byte offset of the vector a chunk reads, relative to the lane's own column: 0 diag, 1 left, 2 down, 3 cur.
 __device__ __forceinline__ int med_vofs(int vsel, int sCur, int sPrev, int sPrev2, int colStride) {
   const int slotOff = vsel == 3 ? sCur : (vsel == 0 ? sPrev2 : sPrev);
   return slotOff - (vsel < 2 ? colStride : 0);
@@ -88,12 +90,10 @@ __device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(
 
 // pass 1 of a chunk: N candidates cell+logW (fp64) and their maximum
 template <int N>
-__device__ __forceinline__ void med_cands(cdesc_t dp, const char *ldsb, int myColBase, int sCur, int sPrev, int sPrev2,
-                                          int colStride, const Rec (&R)[MS], double (&v)[MS], double &mx) {
+__device__ __forceinline__ void med_cands(const char *ldsb, int vecBase, const Rec (&R)[MS], double (&v)[MS], double &mx) {
   double x[N > 0 ? N : 1];
 #pragma unroll
-  for (int k = 0; k < N; ++k)
-    x[k] = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3 + 3 * k] >> 24, sCur, sPrev, sPrev2, colStride) + (int)R[k].srcOff);
+  for (int k = 0; k < N; ++k) x[k] = med_lds(ldsb, vecBase + (int)R[k].srcOff);
 #pragma unroll
   for (int k = 0; k < N; ++k) { v[k] = x[k] + R[k].w; mx = dmax(mx, v[k]); }
 }
@@ -131,8 +131,9 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
     const int ns = hdr & 15;
     const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1, sync = (hdr >> 6) & 1;
     unsigned dstOff = 0xFFFFFFFFu;
+    const int vecBase = myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride);
     for (int k = 0; k < ns; ++k) {
-      const Rec r = med_load(grec, med_idx(dp, k, it, ot, q));
+      const Rec r = med_load(grec, med_idx0(dp, it, ot, q) + k * dp[4]);
       if (k == 0) {
         dstOff = r.dstOff;
         if (first) {
@@ -140,7 +141,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
           accM = seed ? 0.0 : -INFINITY; accS = seed ? 1.0f : 0.0f;
         }
       }
-      const double v = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3 + 3 * k] >> 24, sCur, sPrev, sPrev2, colStride) + (int)r.srcOff) + r.w;
+      const double v = med_lds(ldsb, vecBase + (int)r.srcOff) + r.w;
       if (MODE == MB_VITERBI) accM = dmax(accM, v);
       else {
         const double nm = dmax(accM, v), gM = (nm == -INFINITY) ? 0.0 : nm;
@@ -268,15 +269,16 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
           MED_SWITCH(nsNext, CALL)
 #undef CALL
         }
+        const int vecBase = myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride);
         if (hdr & (1 << 12)) {
           // every lane of this round has at most one candidate: the cell is exactly cand = source + logW
-          const double res = med_lds(ldsb, myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride) + (int)CUR[0].srcOff) + CUR[0].w;
+          const double res = med_lds(ldsb, vecBase + (int)CUR[0].srcOff) + CUR[0].w;
           if (active && (int)CUR[0].dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)CUR[0].dstOff)) = res;
         } else {
           const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1;
           double v[MS];
           double mx = -INFINITY;
-#define CALL(N) med_cands<N>(dp, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, CUR, v, mx)
+#define CALL(N) med_cands<N>(ldsb, vecBase, CUR, v, mx)
           MED_SWITCH(ns, CALL)
 #undef CALL
           if (first) { accM = -INFINITY; accS = 0.0f; }
@@ -481,37 +483,43 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
     if (n.emitOf >= 0) emitCands(n.emitOf, T, tok, out);
   };
   for (int r = 0; r < P.nRounds; ++r) {
-    std::vector<std::pair<int, int>> slots;   // (table, j)
-    bool single = true;
-    for (int id : rounds[r]) { const auto d = sig(nodes[id]); if (d[0] + d[1] + d[2] + d[3] > 1) single = false; }
+    // slots of the round, table by table; a chunk holds up to MS slots of ONE table (so it reads one LDS vector)
+    int nsT[4], total = 0;
     for (int T = 0; T < 4; ++T) {
-      int ns = 0;
-      for (int id : rounds[r]) ns = std::max(ns, sig(nodes[id])[T]);
-      for (int j = 0; j < ns; ++j) slots.push_back({T, j});
+      nsT[T] = 0;
+      for (int id : rounds[r]) nsT[T] = std::max(nsT[T], sig(nodes[id])[T]);
+      total += nsT[T];
     }
-    if (slots.empty()) slots.push_back({3, 0});   // a round of dead states still writes -inf through one padded slot
-    if (slots.size() != 1) single = false;
-    const int nch = ((int)slots.size() + MS - 1) / MS;
-    for (int chn = 0; chn < nch; ++chn) {
-      const int k0 = chn * MS, k1 = std::min<int>((int)slots.size(), k0 + MS);
+    bool single = (total == 1);
+    for (int id : rounds[r]) { const auto d = sig(nodes[id]); if (d[0] + d[1] + d[2] + d[3] > 1) single = false; }
+    if (total == 0) { nsT[3] = 1; total = 1; single = true; }   // a round of dead states still writes -inf through one padded slot
+    struct Ch { int T, j0, n; };
+    std::vector<Ch> chs;
+    for (int T = 0; T < 4; ++T)
+      for (int j0 = 0; j0 < nsT[T]; j0 += MS) chs.push_back({T, j0, std::min(MS, nsT[T] - j0)});
+    for (size_t ci = 0; ci < chs.size(); ++ci) {
+      const Ch &c = chs[ci];
+      const bool firstC = ci == 0, lastC = ci + 1 == chs.size();
       const size_t db = P.desc.size();
       P.desc.resize(db + DW, 0);
-      P.desc[db] = (k1 - k0) | ((chn == 0) << 4) | ((chn == nch - 1) << 5) | ((chn == nch - 1 && sync[r]) << 6) | (15 << 8) | (single << 12);
-      if (db) P.desc[db - DW] = (P.desc[db - DW] & ~(15 << 8)) | ((k1 - k0) << 8);   // nsNext of the previous chunk
-      for (int k = k0; k < k1; ++k) {
-        const int T = slots[k].first, j = slots[k].second;
-        const size_t b0 = P.rec.size();
-        P.desc[db + 1 + 3 * (k - k0)] = (int)b0;
-        P.desc[db + 2 + 3 * (k - k0)] = mulI[T];
-        P.desc[db + 3 + 3 * (k - k0)] = mulO[T] | (T << 24);
-        P.rec.resize(b0 + (size_t)ntokT[T] * LPG, padRec);
-        P.wref.resize(b0 + (size_t)ntokT[T] * LPG, -1);
-        for (size_t ln = 0; ln < rounds[r].size(); ++ln) {
-          const Node &n = nodes[rounds[r][ln]];
-          for (int tok = 0; tok < ntokT[T]; ++tok) {
-            const size_t idx = b0 + (size_t)tok * LPG + ln;
-            if (k == k0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u;
-            candsOf(n, T, tok, tmp);
+      P.desc[db] = c.n | (firstC << 4) | (lastC << 5) | ((lastC && sync[r]) << 6) | (15 << 8) | (single << 12);
+      if (db) P.desc[db - DW] = (P.desc[db - DW] & ~(15 << 8)) | (c.n << 8);   // nsNext of the previous chunk
+      const size_t b0 = P.rec.size();
+      const int stride = ntokT[c.T] * LPG;
+      P.desc[db + 1] = (int)b0;
+      P.desc[db + 2] = mulI[c.T];
+      P.desc[db + 3] = mulO[c.T] | (c.T << 24);
+      P.desc[db + 4] = stride;
+      P.rec.resize(b0 + (size_t)c.n * stride, padRec);
+      P.wref.resize(b0 + (size_t)c.n * stride, -1);
+      for (size_t ln = 0; ln < rounds[r].size(); ++ln) {
+        const Node &n = nodes[rounds[r][ln]];
+        for (int tok = 0; tok < ntokT[c.T]; ++tok) {
+          candsOf(n, c.T, tok, tmp);
+          for (int k = 0; k < c.n; ++k) {
+            const size_t idx = b0 + (size_t)k * stride + (size_t)tok * LPG + ln;
+            if (k == 0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u;
+            const int j = c.j0 + k;
             if (j < (int)tmp.size()) { P.rec[idx].srcOff = (uint32_t)tmp[j].src * 8u; P.wref[idx] = tmp[j].wref; }
           }
         }
