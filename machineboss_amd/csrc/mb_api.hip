@@ -357,6 +357,20 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
     if (d_hb) (void)hipFree(d_hb);
+  } else if (mode == MB_FORWARD && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1)) {
+    // ForwardMatrix semantics with only logLike() kept: continuous pipeline over recycled matrix slots
+    FastState *f = fast_state(m);
+    const size_t budget = budget_bytes();
+    const long long want = std::min<long long>(b->totalCells, (long long)(budget / 8));
+    double *pool = (double *)ws_get(0, (size_t)std::max<long long>(want, b->maxPairCells) * sizeof(double));
+    if (!pool) rc = 1;
+    else if ((long long)(g_ws[0].bytes / 8) < b->maxPairCells) { set_error("a single DP matrix exceeds the device memory budget"); rc = 1; }
+    else {
+      g_last_kernel = "k_medium_tile<0>";
+      tm.start();
+      rc = medium_forward_pipelined(m, f->fwdSum, f->geoFS, b->pairs, b->d_in, b->d_out, pool, (long long)(g_ws[0].bytes / 8), d_ll, g_stream);
+      g_last_ms += tm.stop();
+    }
   } else {
     std::vector<Chunk> chunks;
     if (!plan_chunks(b, 1, chunks)) { (void)hipFree(d_ll); return 1; }

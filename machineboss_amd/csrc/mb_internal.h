@@ -36,6 +36,8 @@ struct PairDesc {
   long long inBase, outBase;   // offsets into the batch token arrays
   int inLen, outLen;
   long long cellBase;          // offset (in doubles) of this pair's matrix inside a matrix pool
+  int launch0;                 // tiled kernels: index of the launch in which this pair's first tile runs
+  int pad;
 };
 
 }  // namespace mb

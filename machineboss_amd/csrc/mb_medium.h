@@ -65,6 +65,9 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st);
+int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs,
+                             const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,
+                             hipStream_t st);
 int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st);

@@ -44,8 +44,8 @@ struct MedTileArgs {
   double *pool;               // materialised matrices, reference layout; nullptr in rolling mode
   double *colHalo;            // rolling mode: per pair two [outLen+1][S] column buffers (ping-pong by strip parity)
   const long long *haloBase;  // rolling mode: per pair offset (in doubles) of its two buffers
-  double *loglike;            // rolling mode: loglike[pair]
-  int C, TS, launch, rev, materialise;
+  double *loglike;            // loglike[pairBase + blockIdx.y], written when the end cell is finalised (may be null)
+  int C, TS, launch, rev, materialise, pairBase;
 };
 
 #define MED_L2E 1.44269504088896f
@@ -113,6 +113,14 @@ static_assert(MED_MAXSLOT == 4, "MED_SWITCH enumerates the slot counts 1..MED_MA
     default: { CALL(4); } break;                                                                \
   }
 
+// workgroup barrier that orders LDS traffic only: global stores of finished supercells stay in flight across it
+// (nothing in this launch reads them back), unlike __syncthreads() which drains vmcnt to zero every step.
+__device__ __forceinline__ void med_block_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ void med_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -165,12 +173,13 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   const int S = P.S, Spad = P.Spad, NS = P.NS, C = A.C;
-  const PairDesc pd = A.pairs[blockIdx.y];
+  const int pairIdx = A.pairBase + blockIdx.y;
+  const PairDesc pd = A.pairs[pairIdx];
   const int inLen = pd.inLen, outLen = pd.outLen;
   const long long I = inLen + 1;
   // which tile
   int a, b;
-  if (A.materialise) { a = blockIdx.x; b = A.launch - 2 * a; } else { a = A.launch; b = 0; }
+  if (A.materialise) { a = blockIdx.x; b = A.launch - pd.launch0 - 2 * a; } else { a = A.launch; b = 0; }
   const int NA = (inLen + C) / C;               // ceil((inLen+1)/C)
   const int T = outLen + C;                     // steps of one strip sweep: (outLen+1) + (C-1)
   if (a >= NA || b < 0 || (long long)b * A.TS >= T) return;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   double *cells = A.materialise ? A.pool + pd.cellBase : nullptr;
   double *haloIn = nullptr, *haloOut = nullptr;
   if (!A.materialise) {
-    double *hb = A.colHalo + A.haloBase[blockIdx.y];
+    double *hb = A.colHalo + A.haloBase[pairIdx];
     const long long hsz = (long long)(outLen + 1) * S;
     haloIn = hb + ((a + 1) & 1) * hsz;   // written by strip a-1
     haloOut = hb + (a & 1) * hsz;
@@ -317,20 +326,7 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
       }
     }
     med_wave_sync();
-    // ---- copy the finished supercell out ----------------------------------------------------------------------
-    const double *cur = (const double *)(ldsb + (myColBase + sCur));
-    if (active) {
-      if (A.materialise) {
-        double *dstp = cellPtr(i, o);
-        for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
-      } else {
-        if (c == C - 1) {
-          double *dstp = haloOut + (long long)o * S;
-          for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
-        }
-        if (i == inLen && o == outLen && q == 0) A.loglike[blockIdx.y] = cur[P.endNode];
-      }
-    }
+    // ---- halo for the next step into LDS first (its load is older than the stores below: no wait on stores) --------
     if (wantHalo) {
       double *hd = ring(slotCur, 0);
 #pragma unroll
@@ -339,7 +335,19 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
         if (j < S) hd[j] = hv[k];
       }
     }
-    __syncthreads();
+    // ---- copy the finished supercell out ----------------------------------------------------------------------
+    const double *cur = (const double *)(ldsb + (myColBase + sCur));
+    if (active) {
+      if (A.materialise) {
+        double *dstp = cellPtr(i, o);
+        for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
+      } else if (c == C - 1) {
+        double *dstp = haloOut + (long long)o * S;
+        for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
+      }
+      if (i == inLen && o == outLen && q == 0 && A.loglike) A.loglike[pairIdx] = cur[P.endNode];
+    }
+    med_block_sync();
     slotCur = (slotCur + 1) % NS;
   }
 }
@@ -647,7 +655,7 @@ int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const Med
   const int NB = (T + TS - 1) / TS;
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
-  A.loglike = nullptr; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
+  A.loglike = nullptr; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1; A.pairBase = 0;
   MedProgDev dev = P.dev;
   if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
   const dim3 grid(NA, (unsigned)pairs.size()), block(geo.waves * 64);
@@ -657,6 +665,87 @@ int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const Med
     else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
   return hip_ok(hipGetLastError(), "medium tile launch") ? 0 : 1;
+}
+
+// Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):
+// a continuous pipeline.  Pair p starts at launch launch0[p]; a new pair is admitted as soon as the wavefront has
+// room for its strips (target: one resident workgroup per CU) and a matrix slot is free, so the chip stays full
+// across pair boundaries instead of draining at every sub-batch.  Matrix slots are recycled in stream order.
+int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairsIn,
+                             const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,
+                             hipStream_t st) {
+  const long long n = (long long)pairsIn.size();
+  if (n == 0) return 0;
+  set_lds_attr();
+  const int C = geo.C, S = m->S;
+  long long slotCells = 0;
+  int maxNA = 1;
+  for (const PairDesc &pd : pairsIn) {
+    slotCells = std::max(slotCells, (long long)(pd.inLen + 1) * (pd.outLen + 1) * S);
+    maxNA = std::max(maxNA, (pd.inLen + C) / C);
+  }
+  const long long nSlots = std::min<long long>(poolCells / std::max<long long>(slotCells, 1), n);
+  if (nSlots < 1) { set_error("a single DP matrix exceeds the device memory budget"); return 1; }
+  const int TS = std::max(C, 64);
+  const int target = 256;   // resident workgroups: one per CU (the LDS ring takes most of a CU's 160 KB)
+  // admission simulation
+  std::vector<PairDesc> pairs = pairsIn;
+  std::vector<int> life(n), NAp(n), NBp(n);
+  for (long long p = 0; p < n; ++p) {
+    NAp[p] = (pairs[p].inLen + C) / C;
+    NBp[p] = (pairs[p].outLen + C + TS - 1) / TS;
+    life[p] = 2 * (NAp[p] - 1) + NBp[p];
+  }
+  // tiles of a pair that run k launches after its first one (a trapezoid: +1 strip every 2 launches, plateau, drain)
+  auto profile = [&](long long p, int k) {
+    int cnt = 0;
+    for (int a = 0; a < NAp[p]; ++a) { const int b = k - 2 * a; if (b >= 0 && b < NBp[p]) ++cnt; }
+    return cnt;
+  };
+  std::vector<int> load;                           // committed tiles per future launch
+  std::vector<long long> slotFreeAt(nSlots, 0);    // launch index from which the slot may be reused
+  long long next = 0, firstAlive = 0;
+  int launch = 0;
+  std::vector<std::pair<long long, long long>> windows;   // per launch: [firstAlive, next)
+  while (firstAlive < n) {
+    // admit the next pair as soon as a matrix slot is free and no launch of its life would exceed the target
+    while (next < n) {
+      long long slot = -1;
+      for (long long k = 0; k < nSlots; ++k) if (slotFreeAt[k] <= launch) { slot = k; break; }
+      if (slot < 0) break;
+      if ((int)load.size() < launch + life[next]) load.resize(launch + life[next], 0);
+      bool fits = true;
+      if (next > firstAlive)   // an empty pipeline always admits
+        for (int k = 0; k < life[next] && fits; ++k) fits = load[launch + k] + profile(next, k) <= target;
+      if (!fits) break;
+      for (int k = 0; k < life[next]; ++k) load[launch + k] += profile(next, k);
+      pairs[next].launch0 = launch;
+      pairs[next].cellBase = slot * slotCells;
+      slotFreeAt[slot] = launch + life[next];
+      ++next;
+    }
+    while (firstAlive < next && pairs[firstAlive].launch0 + life[firstAlive] <= launch) ++firstAlive;
+    if (firstAlive >= n) break;
+    windows.push_back({firstAlive, next});
+    ++launch;
+  }
+  PairDesc *d_pairs = nullptr;
+  if (!hip_ok(hipMalloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
+  if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { (void)hipFree(d_pairs); return 1; }
+  MedTileArgs A{};
+  A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
+  A.loglike = d_loglike; A.C = C; A.TS = TS; A.rev = 0; A.materialise = 1;
+  const dim3 block(geo.waves * 64);
+  for (size_t l = 0; l < windows.size(); ++l) {
+    const long long p0 = windows[l].first, p1 = windows[l].second;
+    if (p1 <= p0) continue;
+    A.launch = (int)l; A.pairBase = (int)p0;
+    const dim3 grid(maxNA, (unsigned)(p1 - p0));
+    launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
+  }
+  const bool ok = hip_ok(hipGetLastError(), "medium pipelined launch") && hip_ok(hipStreamSynchronize(st), "medium pipelined kernels");
+  (void)hipFree(d_pairs);
+  return ok ? 0 : 1;
 }
 
 // Rolling (log-likelihood only) Forward: one workgroup per pair per launch, strips in sequence.
@@ -670,7 +759,7 @@ int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGe
   const int C = geo.C, NA = (maxIn + C) / C;
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
-  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0;
+  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.pairBase = 0;
   const dim3 grid(1, (unsigned)pairs.size()), block(geo.waves * 64);
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
