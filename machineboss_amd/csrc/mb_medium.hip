@@ -45,7 +45,8 @@ struct MedTileArgs {
   double *colHalo;            // rolling mode: per pair two [outLen+1][S] column buffers (ping-pong by strip parity)
   const long long *haloBase;  // rolling mode: per pair offset (in doubles) of its two buffers
   double *loglike;            // loglike[pairBase + blockIdx.y], written when the end cell is finalised (may be null)
-  int C, TS, launch, rev, materialise, pairBase;
+  const int2 *tiles;          // materialised mode: (pair, strip) of workgroup tileBase + blockIdx.x
+  int C, TS, launch, rev, materialise, tileBase, debugNoStore;
 };
 
 #define MED_L2E 1.44269504088896f
@@ -173,13 +174,16 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   const int S = P.S, Spad = P.Spad, NS = P.NS, C = A.C;
-  const int pairIdx = A.pairBase + blockIdx.y;
+  // which tile.  Materialised launches enumerate exactly the live tiles in a 1-D grid: consecutive workgroup ids are
+  // dealt round-robin to the 8 XCDs, so a dense list keeps every XCD at <= 32 resident workgroups (a 2-D grid with
+  // early-exit holes put 33+ live tiles on some XCD and doubled the launch time).
+  int pairIdx, a;
+  if (A.materialise) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y; }
+  else { pairIdx = blockIdx.x; a = A.launch; }
   const PairDesc pd = A.pairs[pairIdx];
   const int inLen = pd.inLen, outLen = pd.outLen;
   const long long I = inLen + 1;
-  // which tile
-  int a, b;
-  if (A.materialise) { a = blockIdx.x; b = A.launch - pd.launch0 - 2 * a; } else { a = A.launch; b = 0; }
+  const int b = A.materialise ? A.launch - pd.launch0 - 2 * a : 0;
   const int NA = (inLen + C) / C;               // ceil((inLen+1)/C)
   const int T = outLen + C;                     // steps of one strip sweep: (outLen+1) + (C-1)
   if (a >= NA || b < 0 || (long long)b * A.TS >= T) return;
@@ -340,7 +344,8 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
     if (active) {
       if (A.materialise) {
         double *dstp = cellPtr(i, o);
-        for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
+        if (!A.debugNoStore || c == C - 1)
+          for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
       } else if (c == C - 1) {
         double *dstp = haloOut + (long long)o * S;
         for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
@@ -636,35 +641,74 @@ static void set_lds_attr() {
   g_attr_set = true;
 }
 
-// Materialised fill of a chunk of pairs: wavefront of parallelogram tiles, launch index = 2*strip + block.
-int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
-                             const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
-                             double *d_pool, hipStream_t st) {
-  if (pairs.empty()) return 0;
-  set_lds_attr();
-  int maxIn = 0, maxOut = 0;
-  for (const PairDesc &pd : pairs) { maxIn = std::max(maxIn, pd.inLen); maxOut = std::max(maxOut, pd.outLen); }
+// Launch the wavefront of parallelogram tiles of a set of pairs whose first launches (PairDesc::launch0) are given:
+// tile (pair, strip a, block b) runs in launch launch0 + 2a + b.  Builds the dense per-launch tile lists.
+static int launch_wavefront(const MedProgram &P, const MedProgDev &dev, const MedGeom &geo, int mode, int TS,
+                            const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
+                            double *d_pool, double *d_loglike, hipStream_t st) {
   const int C = geo.C;
-  const int NA = (maxIn + C) / C;
-  const int T = maxOut + C;
-  // tile length: enough blocks that ~2 workgroups per CU are in flight on the widest wavefront, but >= C steps
-  // (dependency (a-1,b+1) needs TS >= C) and >= 64 steps to amortise the preload.
-  long long wantBlocks = std::max<long long>(1, (512 + (long long)pairs.size() - 1) / (long long)pairs.size());
-  int TS = (int)std::max<long long>(std::max(C, 64), (T + 2 * wantBlocks - 1) / (2 * wantBlocks));
-  if (NA == 1) TS = T;  // a single strip has no wavefront to exploit
-  const int NB = (T + TS - 1) / TS;
+  const long long n = (long long)pairs.size();
+  int nLaunch = 0;
+  for (const PairDesc &pd : pairs) {
+    const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
+    nLaunch = std::max(nLaunch, pd.launch0 + 2 * (NA - 1) + NB);
+  }
+  std::vector<int> cnt(nLaunch + 1, 0);
+  for (const PairDesc &pd : pairs) {
+    const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
+    for (int a = 0; a < NA; ++a) { cnt[pd.launch0 + 2 * a] += 1; cnt[pd.launch0 + 2 * a + NB] -= 1; }
+  }
+  std::vector<long long> off(nLaunch + 1, 0);
+  { long long run = 0, tot = 0; for (int l = 0; l < nLaunch; ++l) { run += cnt[l]; off[l] = tot; tot += run; cnt[l] = (int)run; } off[nLaunch] = tot; }
+  std::vector<int2> tiles((size_t)off[nLaunch]);
+  {
+    std::vector<long long> fill(off.begin(), off.end() - 1);
+    for (long long p = 0; p < n; ++p) {
+      const PairDesc &pd = pairs[p];
+      const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
+      for (int a = 0; a < NA; ++a)
+        for (int b = 0; b < NB; ++b) tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a);
+    }
+  }
+  int2 *d_tiles = nullptr;
+  if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
+  if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
-  A.loglike = nullptr; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1; A.pairBase = 0;
-  MedProgDev dev = P.dev;
-  if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
-  const dim3 grid(NA, (unsigned)pairs.size()), block(geo.waves * 64);
-  for (int launch = 0; launch <= 2 * (NA - 1) + (NB - 1); ++launch) {
-    A.launch = launch;
+  A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
+  { const char *e = getenv("MB_DEBUG_NOSTORE"); A.debugNoStore = (e && *e == '1') ? 1 : 0; }
+  const dim3 block(geo.waves * 64);
+  for (int l = 0; l < nLaunch; ++l) {
+    if (cnt[l] <= 0) continue;
+    A.launch = l; A.tileBase = (int)off[l];
+    const dim3 grid((unsigned)cnt[l]);
     if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, st, dev, A);
     else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
-  return hip_ok(hipGetLastError(), "medium tile launch") ? 0 : 1;
+  const bool ok = hip_ok(hipGetLastError(), "medium tile launch") && hip_ok(hipStreamSynchronize(st), "medium tile kernels");
+  (void)hipFree(d_tiles);
+  return ok ? 0 : 1;
+}
+
+static int tile_steps(int C, size_t nPairs, int maxOut) {
+  int TS = std::max(C, 64);
+  const char *e = getenv("MB_MEDIUM_TS");
+  if (e && atoi(e) >= C) TS = atoi(e);
+  (void)nPairs; (void)maxOut;
+  return TS;
+}
+
+// Materialised fill of a chunk of pairs whose matrices are all kept (Viterbi, Backward, counts, mb_fill).
+int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
+                             const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out,
+                             double *d_pool, hipStream_t st) {
+  if (pairsIn.empty()) return 0;
+  set_lds_attr();
+  std::vector<PairDesc> pairs = pairsIn;
+  for (PairDesc &pd : pairs) pd.launch0 = 0;
+  MedProgDev dev = P.dev;
+  if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
+  return launch_wavefront(P, dev, geo, mode, tile_steps(geo.C, pairs.size(), 0), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
 }
 
 // Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):
@@ -679,16 +723,11 @@ int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const Med
   set_lds_attr();
   const int C = geo.C, S = m->S;
   long long slotCells = 0;
-  int maxNA = 1;
-  for (const PairDesc &pd : pairsIn) {
-    slotCells = std::max(slotCells, (long long)(pd.inLen + 1) * (pd.outLen + 1) * S);
-    maxNA = std::max(maxNA, (pd.inLen + C) / C);
-  }
+  for (const PairDesc &pd : pairsIn) slotCells = std::max(slotCells, (long long)(pd.inLen + 1) * (pd.outLen + 1) * S);
   const long long nSlots = std::min<long long>(poolCells / std::max<long long>(slotCells, 1), n);
   if (nSlots < 1) { set_error("a single DP matrix exceeds the device memory budget"); return 1; }
-  const int TS = std::max(C, 64);
+  const int TS = tile_steps(C, (size_t)n, 0);
   const int target = 256;   // resident workgroups: one per CU (the LDS ring takes most of a CU's 160 KB)
-  // admission simulation
   std::vector<PairDesc> pairs = pairsIn;
   std::vector<int> life(n), NAp(n), NBp(n);
   for (long long p = 0; p < n; ++p) {
@@ -706,7 +745,6 @@ int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const Med
   std::vector<long long> slotFreeAt(nSlots, 0);    // launch index from which the slot may be reused
   long long next = 0, firstAlive = 0;
   int launch = 0;
-  std::vector<std::pair<long long, long long>> windows;   // per launch: [firstAlive, next)
   while (firstAlive < n) {
     // admit the next pair as soon as a matrix slot is free and no launch of its life would exceed the target
     while (next < n) {
@@ -725,27 +763,14 @@ int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const Med
       ++next;
     }
     while (firstAlive < next && pairs[firstAlive].launch0 + life[firstAlive] <= launch) ++firstAlive;
-    if (firstAlive >= n) break;
-    windows.push_back({firstAlive, next});
     ++launch;
   }
   PairDesc *d_pairs = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
   if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { (void)hipFree(d_pairs); return 1; }
-  MedTileArgs A{};
-  A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
-  A.loglike = d_loglike; A.C = C; A.TS = TS; A.rev = 0; A.materialise = 1;
-  const dim3 block(geo.waves * 64);
-  for (size_t l = 0; l < windows.size(); ++l) {
-    const long long p0 = windows[l].first, p1 = windows[l].second;
-    if (p1 <= p0) continue;
-    A.launch = (int)l; A.pairBase = (int)p0;
-    const dim3 grid(maxNA, (unsigned)(p1 - p0));
-    launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
-  }
-  const bool ok = hip_ok(hipGetLastError(), "medium pipelined launch") && hip_ok(hipStreamSynchronize(st), "medium pipelined kernels");
+  const int rc = launch_wavefront(P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st);
   (void)hipFree(d_pairs);
-  return ok ? 0 : 1;
+  return rc;
 }
 
 // Rolling (log-likelihood only) Forward: one workgroup per pair per launch, strips in sequence.
@@ -759,8 +784,8 @@ int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGe
   const int C = geo.C, NA = (maxIn + C) / C;
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
-  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.pairBase = 0;
-  const dim3 grid(1, (unsigned)pairs.size()), block(geo.waves * 64);
+  A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.tiles = nullptr; A.tileBase = 0;
+  const dim3 grid((unsigned)pairs.size()), block(geo.waves * 64);
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
     launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
