@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % s)
-    subprocess.check_call([_hipcc(), "-shared", "-o", LIB] + objs + ["--offload-arch=gfx950"])
+    subprocess.check_call([_hipcc(), "-shared", "-o", LIB] + objs + ["--offload-arch=gfx950", "-lhiprtc"])
     return LIB
 
 

@@ -35,8 +35,21 @@ struct MedProgDev {
   int S, Spad, LPG, G, NS, nChunks;
   int nIn, nOut, startNode, endNode;
   unsigned seedOff;         // byte offset of the value that receives the seed 0 at the origin cell
+  int ldsImageRecs;         // run-time specialised kernel: number of token-independent records kept in LDS
   const int *desc;
   const MedRec *rec;
+  const MedRec *ldsImage;   // those records, in the order the specialised kernel addresses them
+};
+
+// structure of the program, kept for the run-time code generator (mb_medium_jit.cpp)
+struct MedSlotInfo { int T; long long recBase; };          // table (= vector it reads, = token kind), first record
+struct MedRoundInfo { std::vector<MedSlotInfo> slots; bool sync = false, single = false; };
+
+struct MedJit {                 // one specialised kernel (per program and semiring)
+  bool tried = false;
+  void *module = nullptr, *func = nullptr;
+  size_t ldsBytes = 0;
+  bool recsInLds = false;
 };
 
 struct MedProgram {
@@ -51,9 +64,12 @@ struct MedProgram {
   std::vector<std::vector<int>> closBase;                       // node -> sorted base ancestors
   std::vector<std::vector<int>> closPair;                       // node -> pair id per ancestor (parallel to closBase)
   int nPairs = 0;
+  std::vector<MedRoundInfo> roundInfo;
+  std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (token-independent slots)
   int *d_desc = nullptr;
-  MedRec *d_rec = nullptr;
+  MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
+  MedJit jit[2];                        // [MB_FORWARD (sum)], [MB_VITERBI (max)]
 };
 
 struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
@@ -62,13 +78,16 @@ bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedPr
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_free(MedProgram &P);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
-int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
+int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st);
-int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs,
+// run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode);
+void medium_jit_free(MedProgram &P);
+int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs,
                              const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,
                              hipStream_t st);
-int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st);
 

@@ -506,6 +506,9 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
     bool single = (total == 1);
     for (int id : rounds[r]) { const auto d = sig(nodes[id]); if (d[0] + d[1] + d[2] + d[3] > 1) single = false; }
     if (total == 0) { nsT[3] = 1; total = 1; single = true; }   // a round of dead states still writes -inf through one padded slot
+    P.roundInfo.emplace_back();
+    P.roundInfo.back().sync = sync[r] != 0;
+    P.roundInfo.back().single = single;
     struct Ch { int T, j0, n; };
     std::vector<Ch> chs;
     for (int T = 0; T < 4; ++T)
@@ -525,6 +528,10 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
       P.desc[db + 4] = stride;
       P.rec.resize(b0 + (size_t)c.n * stride, padRec);
       P.wref.resize(b0 + (size_t)c.n * stride, -1);
+      for (int k = 0; k < c.n; ++k) {
+        P.roundInfo.back().slots.push_back({c.T, (long long)b0 + (long long)k * stride});
+        if (c.T == 3) for (int ln = 0; ln < LPG; ++ln) P.ldsImageIdx.push_back((long long)b0 + (long long)k * stride + ln);
+      }
       for (size_t ln = 0; ln < rounds[r].size(); ++ln) {
         const Node &n = nodes[rounds[r][ln]];
         for (int tok = 0; tok < ntokT[c.T]; ++tok) {
@@ -585,6 +592,10 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
   }
   if (!up(P.d_rec, P.rec)) return false;
   P.dev.rec = P.d_rec;
+  std::vector<MedRec> img(P.ldsImageIdx.size());
+  for (size_t k = 0; k < img.size(); ++k) img[k] = P.rec[P.ldsImageIdx[k]];
+  if (!up(P.d_ldsImage, img)) return false;
+  P.dev.ldsImage = P.d_ldsImage;
   return true;
 }
 
@@ -601,7 +612,8 @@ bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedPr
 }
 
 void medium_free(MedProgram &P) {
-  void *ptrs[] = {P.d_desc, P.d_rec};
+  medium_jit_free(P);
+  void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   P = MedProgram();
 }
@@ -620,6 +632,14 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   geo.waves = waves; geo.C = waves * P.G;
   geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double) + progBytes;
   return true;
+}
+
+static bool launch_jit(const MedJit &J, dim3 grid, dim3 block, hipStream_t st, const MedProgDev &P, const MedTileArgs &A) {
+  if (!J.func) return false;
+  MedProgDev p = P; MedTileArgs a = A;
+  if (!J.recsInLds) p.ldsImageRecs = 0;
+  void *args[] = {&p, &a};
+  return hipModuleLaunchKernel((hipFunction_t)J.func, grid.x, grid.y, grid.z, block.x, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
 }
 
 template <int MODE>
@@ -643,7 +663,7 @@ static void set_lds_attr() {
 
 // Launch the wavefront of parallelogram tiles of a set of pairs whose first launches (PairDesc::launch0) are given:
 // tile (pair, strip a, block b) runs in launch launch0 + 2a + b.  Builds the dense per-launch tile lists.
-static int launch_wavefront(const MedProgram &P, const MedProgDev &dev, const MedGeom &geo, int mode, int TS,
+static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev &devIn, const MedGeom &geo, int mode, int TS,
                             const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
                             double *d_pool, double *d_loglike, hipStream_t st) {
   const int C = geo.C;
@@ -673,6 +693,9 @@ static int launch_wavefront(const MedProgram &P, const MedProgDev &dev, const Me
   int2 *d_tiles = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
+  const MedJit *J = medium_jit_get(m, P, geo, mode) ? &P.jit[mode == MB_VITERBI ? 1 : 0] : nullptr;
+  MedProgDev dev = devIn;
+  dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
@@ -682,6 +705,7 @@ static int launch_wavefront(const MedProgram &P, const MedProgDev &dev, const Me
     if (cnt[l] <= 0) continue;
     A.launch = l; A.tileBase = (int)off[l];
     const dim3 grid((unsigned)cnt[l]);
+    if (J && launch_jit(*J, grid, block, st, dev, A)) continue;
     if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, st, dev, A);
     else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
@@ -699,7 +723,7 @@ static int tile_steps(int C, size_t nPairs, int maxOut) {
 }
 
 // Materialised fill of a chunk of pairs whose matrices are all kept (Viterbi, Backward, counts, mb_fill).
-int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int startNode,
+int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st) {
   if (pairsIn.empty()) return 0;
@@ -708,14 +732,14 @@ int medium_fill_materialised(const mb_machine *m, const MedProgram &P, const Med
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   MedProgDev dev = P.dev;
   if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
-  return launch_wavefront(P, dev, geo, mode, tile_steps(geo.C, pairs.size(), 0), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
+  return launch_wavefront(m, P, dev, geo, mode, tile_steps(geo.C, pairs.size(), 0), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
 }
 
 // Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):
 // a continuous pipeline.  Pair p starts at launch launch0[p]; a new pair is admitted as soon as the wavefront has
 // room for its strips (target: one resident workgroup per CU) and a matrix slot is free, so the chip stays full
 // across pair boundaries instead of draining at every sub-batch.  Matrix slots are recycled in stream order.
-int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairsIn,
+int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairsIn,
                              const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,
                              hipStream_t st) {
   const long long n = (long long)pairsIn.size();
@@ -768,13 +792,13 @@ int medium_forward_pipelined(const mb_machine *m, const MedProgram &P, const Med
   PairDesc *d_pairs = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
   if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { (void)hipFree(d_pairs); return 1; }
-  const int rc = launch_wavefront(P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st);
+  const int rc = launch_wavefront(m, P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st);
   (void)hipFree(d_pairs);
   return rc;
 }
 
 // Rolling (log-likelihood only) Forward: one workgroup per pair per launch, strips in sequence.
-int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st) {
   if (pairs.empty()) return 0;
@@ -786,9 +810,13 @@ int medium_forward_rolling(const mb_machine *m, const MedProgram &P, const MedGe
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
   A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.tiles = nullptr; A.tileBase = 0;
   const dim3 grid((unsigned)pairs.size()), block(geo.waves * 64);
+  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD) ? &P.jit[0] : nullptr;
+  MedProgDev dev = P.dev;
+  dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
-    launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, P.dev, A);
+    if (J && launch_jit(*J, grid, block, st, dev, A)) continue;
+    launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
   return hip_ok(hipGetLastError(), "medium rolling launch") ? 0 : 1;
 }

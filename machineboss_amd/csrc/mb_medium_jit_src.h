@@ -1,0 +1,242 @@
+// mb_medium_jit_src.h -- source skeleton of the run-time specialised "lanes = states" tile kernel.
+//
+// The ahead-of-time kernel in mb_medium.hip interprets a compiled program (descriptors + switch on slot counts); its
+// instruction stream is dominated by that interpretation.  Here the same program is unrolled at run time into
+// straight-line HIP for ONE machine and compiled with hiprtc for gfx950: slot counts, record offsets, which LDS vector a
+// candidate reads, the state count and the strip geometry are all literals, token-independent candidate records live in
+// LDS, and the compiler schedules every load of a step ahead of its use.  Semantics are identical to k_medium_tile
+// (tests run both and compare); if hiprtc is unavailable the engine silently keeps the ahead-of-time kernel.
+//
+// Markers replaced by the generator (mb_medium_jit.cpp):  /*@DEFS@*/  /*@BODY@*/
+#pragma once
+
+namespace mb {
+static const char *kMedJitSkeleton = R"MBJIT(
+/*@DEFS@*/
+#define NEG_INF (-__builtin_inf())
+#define MED_L2E 1.44269504088896f
+#define MED_LN2 0.693147180559945f
+struct PairDesc { long long inBase, outBase; int inLen, outLen; long long cellBase; int launch0; int pad; };
+struct MedRec { double w; unsigned srcOff; unsigned dstOff; };
+struct MedProgDev {
+  int S, Spad, LPG, G, NS, nChunks;
+  int nIn, nOut, startNode, endNode;
+  unsigned seedOff;
+  int ldsImageRecs;
+  const int *desc;
+  const MedRec *rec;
+  const MedRec *ldsImage;
+};
+struct MedTileArgs {
+  const PairDesc *pairs;
+  const int *inTok, *outTok;
+  double *pool;
+  double *colHalo;
+  const long long *haloBase;
+  double *loglike;
+  const int2 *tiles;
+  int C, TS, launch, rev, materialise, tileBase, debugNoStore;
+};
+typedef const __attribute__((address_space(4))) int *cdesc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef const __attribute__((address_space(1))) u32x4 *grec_t;
+typedef const __attribute__((address_space(1))) char *gbytes_t;
+struct Rec { double w; unsigned srcOff, dstOff; };
+
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ Rec mk_rec(u32x4 r) {
+  Rec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.srcOff = r.z; o.dstOff = r.w; return o;
+}
+__device__ __forceinline__ Rec ld_g(gbytes_t base, unsigned off) { return mk_rec(*(grec_t)(base + off)); }
+__device__ __forceinline__ Rec ld_l(const char *base, unsigned off) { return mk_rec(*(const u32x4 *)(base + off)); }
+__device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(const double *)(ldsb + off); }
+__device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((float)d * MED_L2E); }
+__device__ __forceinline__ void med_block_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void med_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int med_vofs(int vsel, int sCur, int sPrev, int sPrev2, int colStride) {
+  const int slotOff = vsel == 3 ? sCur : (vsel == 0 ? sPrev2 : sPrev);
+  return slotOff - (vsel < 2 ? colStride : 0);
+}
+
+// generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
+__device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
+                                                int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
+                                                unsigned seedOff, bool origin, bool lanesOn) {
+  double accM = NEG_INF; float accS = 0.0f;
+  for (int ch = 0; ch < nChunks; ++ch) {
+    cdesc_t dp = desc + ch * 8;
+    const int hdr = dp[0];
+    const int ns = hdr & 15;
+    const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1, sync = (hdr >> 6) & 1;
+    unsigned dstOff = 0xFFFFFFFFu;
+    const int vecBase = myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride);
+    const int idx0 = (int)__umul24(it, dp[2]) + (int)__umul24(ot, dp[3] & 0xFFFFFF) + dp[1] + q;
+    for (int k = 0; k < ns; ++k) {
+      const Rec r = mk_rec(grec[idx0 + k * dp[4]]);
+      if (k == 0) {
+        dstOff = r.dstOff;
+        if (first) {
+          const bool seed = origin && dstOff == seedOff;
+          accM = seed ? 0.0 : NEG_INF; accS = seed ? 1.0f : 0.0f;
+        }
+      }
+      const double v = med_lds(ldsb, vecBase + (int)r.srcOff) + r.w;
+      if (JMODE == 1) accM = dmax(accM, v);
+      else {
+        const double nm = dmax(accM, v), gM = (nm == NEG_INF) ? 0.0 : nm;
+        accS = accS * ex2(accM - gM) + ex2(v - gM);
+        accM = nm;
+      }
+    }
+    if (last) {
+      const double res = (JMODE == 1) ? accM : ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
+      if (lanesOn && (int)dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)dstOff)) = res;
+    }
+    if (sync) med_wave_sync();
+  }
+}
+
+extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDev P, MedTileArgs A) {
+  extern __shared__ double lds[];
+  constexpr int LPG = 64 / JG, S = JS, Spad = JSPAD, NS = JNS, C = JC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane / LPG, q = lane - g * LPG;
+  int pairIdx, a;
+  if (A.materialise) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y; }
+  else { pairIdx = blockIdx.x; a = A.launch; }
+  const PairDesc pd = A.pairs[pairIdx];
+  const int inLen = pd.inLen, outLen = pd.outLen;
+  const long long I = inLen + 1;
+  const int b = A.materialise ? A.launch - pd.launch0 - 2 * a : 0;
+  const int NA = (inLen + C) / C;
+  const int T = outLen + C;
+  if (a >= NA || b < 0 || (long long)b * A.TS >= T) return;
+  const int t0 = b * A.TS, t1 = min(t0 + A.TS, T);
+  const int i0 = a * C;
+  const int c = wv * JG + g;
+  const int i = i0 + c;
+  const bool colValid = (c < C) && (i <= inLen);
+  const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
+  const int rev = A.rev;
+  const int it = (colValid && i > 0) ? (rev ? in[inLen - i] : in[i - 1]) : 0;
+  double *cells = A.materialise ? A.pool + pd.cellBase : nullptr;
+  double *haloIn = nullptr, *haloOut = nullptr;
+  if (!A.materialise) {
+    double *hb = A.colHalo + A.haloBase[pairIdx];
+    const long long hsz = (long long)(outLen + 1) * S;
+    haloIn = hb + ((a + 1) & 1) * hsz;
+    haloOut = hb + (a & 1) * hsz;
+  }
+  auto cellPtr = [&](int ci, int co) -> double * {
+    const long long ri = rev ? inLen - ci : ci, ro = rev ? outLen - co : co;
+    return cells + (ro * I + ri) * S;
+  };
+  auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
+  char *ldsRec = (char *)(lds + (long long)NS * (C + 1) * Spad);
+
+  for (int j = tid; j < NS * (C + 1) * Spad; j += JWAVES * 64) lds[j] = NEG_INF;
+  {  // token-independent candidate records -> LDS (16 B each)
+    const u32x4 *img = (const u32x4 *)P.ldsImage;
+    u32x4 *dst = (u32x4 *)ldsRec;
+    for (int j = tid; j < JLDSRECS; j += JWAVES * 64) dst[j] = img[j];
+  }
+  __syncthreads();
+  for (int dt = 1; dt < NS; ++dt) {
+    const int tp = t0 - dt;
+    const int slot = ((tp % NS) + NS) % NS;
+    for (int col = 0; col <= C; ++col) {
+      const int cc = col - 1, ci = i0 + cc, co = tp - cc;
+      if (ci < 0 || ci > inLen || co < 0 || co > outLen) continue;
+      const double *src = nullptr;
+      if (A.materialise) src = cellPtr(ci, co);
+      else if (cc == -1) src = haloIn + (long long)co * S;
+      if (!src) continue;
+      double *dstp = ring(slot, col);
+      for (int j = tid; j < S; j += JWAVES * 64) dstp[j] = src[j];
+    }
+  }
+  __syncthreads();
+
+  cdesc_t desc = (cdesc_t)P.desc;
+  grec_t grec = (grec_t)P.rec;
+  gbytes_t grb = (gbytes_t)P.rec;
+  const char *ldsb = (const char *)lds;
+  constexpr int colStride = Spad * 8, slotStride = (C + 1) * colStride;
+  const int myColBase = (c + 1) * colStride;
+  const unsigned q16 = (unsigned)q * 16u;
+  const unsigned itOff16 = (unsigned)(it * LPG + q) * 16u;
+  int slotCur = t0 % NS;
+  int otNext = 0;
+  {
+    const int o = t0 - c;
+    if (colValid && o > 0 && o <= outLen) otNext = rev ? out[outLen - o] : out[o - 1];
+  }
+  for (int t = t0; t < t1; ++t) {
+    const int o = t - c;
+    const bool active = colValid && o >= 0 && o <= outLen;
+    const int ot = otNext;
+    {
+      const int on = o + 1;
+      otNext = (colValid && on > 0 && on <= outLen) ? (rev ? out[outLen - on] : out[on - 1]) : 0;
+    }
+    const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
+    const int sCur = slotCur * slotStride, sPrev = slotPrev * slotStride, sPrev2 = slotPrev2 * slotStride;
+    double hv[JHALO];
+    const bool wantHalo = (i0 > 0) && (t + 1 <= outLen);
+    if (wantHalo) {
+      const double *hs = A.materialise ? cellPtr(i0 - 1, t + 1) : haloIn + (long long)(t + 1) * S;
+#pragma unroll
+      for (int k = 0; k < JHALO; ++k) {
+        const int j = tid + k * JWAVES * 64;
+        hv[k] = (j < S) ? hs[j] : 0.0;
+      }
+    }
+    if (t == 0 && a == 0) {
+      if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
+                                      P.seedOff, active && i == 0 && o == 0, active);
+    } else {
+      // LDS byte addresses of the four vectors this lane's column reads / writes
+      const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
+      const unsigned otOff16 = (unsigned)(ot * LPG + q) * 16u;
+      const unsigned tokM16 = (unsigned)((it * (JNOUT + 1) + ot) * LPG + q) * 16u;
+      (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
+/*@BODY@*/
+    }
+    med_wave_sync();
+    if (wantHalo) {
+      double *hd = ring(slotCur, 0);
+#pragma unroll
+      for (int k = 0; k < JHALO; ++k) {
+        const int j = tid + k * JWAVES * 64;
+        if (j < S) hd[j] = hv[k];
+      }
+    }
+    const double *cur = (const double *)(ldsb + (myColBase + sCur));
+    if (active) {
+      if (A.materialise) {
+        double *dstp = cellPtr(i, o);
+        if (!A.debugNoStore || c == C - 1) {
+#pragma unroll
+          for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }
+        }
+      } else if (c == C - 1) {
+        double *dstp = haloOut + (long long)o * S;
+#pragma unroll
+        for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }
+      }
+      if (i == inLen && o == outLen && q == 0 && A.loglike) A.loglike[pairIdx] = cur[JENDNODE];
+    }
+    med_block_sync();
+    slotCur = (slotCur + 1) % NS;
+  }
+}
+)MBJIT";
+}  // namespace mb
