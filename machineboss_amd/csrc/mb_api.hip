@@ -155,7 +155,7 @@ static FastState *fast_state(mb_machine *m) {
     // generic family until the lanes = supercells family exists.
     if (m->S > 16 && m->S <= 4096) {
       int G = env_int("MB_MEDIUM_G", 0);
-      if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 384 ? 2 : 4);
+      if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 128 ? 2 : (m->S >= 48 ? 4 : 8));   // measured on psw2dna (271 states): G=2 > 4 > 1
       f->G = G;
       long long nSilent = 0;
       for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
@@ -194,9 +194,10 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     const bool exactFwd = mode == MB_VITERBI || (mode == MB_FORWARD && startState != 0);
     MedProgram &P = mode == MB_BACKWARD ? f->bwdSum : (exactFwd ? f->fwdExact : f->fwdSum);
     const MedGeom &geo = mode == MB_BACKWARD ? f->geoBS : (exactFwd ? f->geoFE : f->geoFS);
-    g_last_kernel = mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>";
-    return medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
-                                    (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream);
+    const int rc = medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
+                                            (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream);
+    g_last_kernel = P.jit[mode == MB_VITERBI ? 1 : 0].func ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
+    return rc;
   }
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
   return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream);
@@ -350,9 +351,9 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!(d_halo = (double *)ws_get(2, std::max<long long>(tot, 1) * sizeof(double)))) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&d_hb, b->nPairs * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
-      g_last_kernel = "k_medium_tile<0>";
       tm.start();
       rc = medium_forward_rolling(m, f->fwdSum, f->geoFS, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
+      g_last_kernel = f->fwdSum.jit[0].func ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
@@ -366,9 +367,9 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     if (!pool) rc = 1;
     else if ((long long)(g_ws[0].bytes / 8) < b->maxPairCells) { set_error("a single DP matrix exceeds the device memory budget"); rc = 1; }
     else {
-      g_last_kernel = "k_medium_tile<0>";
       tm.start();
       rc = medium_forward_pipelined(m, f->fwdSum, f->geoFS, b->pairs, b->d_in, b->d_out, pool, (long long)(g_ws[0].bytes / 8), d_ll, g_stream);
+      g_last_kernel = f->fwdSum.jit[0].func ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
     }
   } else {

@@ -3,6 +3,7 @@
 // straight-line HIP; everything structural becomes a literal.
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <sstream>
 #include <string>
@@ -28,31 +29,55 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
   for (size_t r = 0; r < P.roundInfo.size(); ++r) {
     const MedRoundInfo &ri = P.roundInfo[r];
     const int n = (int)ri.slots.size();
-    body << "      {  // round " << r << "\n";
-    for (int k = 0; k < n; ++k) {
+    body << "      {  // round " << r << ": " << n << " candidate slot(s)\n";
+    auto loadRec = [&](int k, const std::string &name) {
       const MedSlotInfo &sl = ri.slots[k];
-      if (sl.T == 3 && recsInLds) {
-        body << "        const Rec r" << k << " = ld_l(ldsRec, " << ldsOff * 16 << "u + q16);\n";
-      } else {
-        body << "        const Rec r" << k << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
-      }
+      if (sl.T == 3 && recsInLds) body << "        const Rec " << name << " = ld_l(ldsRec, " << ldsOff * 16 << "u + q16);\n";
+      else body << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
       if (sl.T == 3) ldsOff += P.LPG;
-    }
-    for (int k = 0; k < n; ++k)
-      body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)r" << k << ".srcOff) + r" << k << ".w;\n";
-    if (n == 1) {
-      body << "        const double res = v0;\n";
-    } else {
-      body << "        double mx = dmax(v0, v1);\n";
-      for (int k = 2; k < n; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
-      if (mode == MB_VITERBI) body << "        const double res = mx;\n";
-      else {
-        body << "        const double gM = (mx == NEG_INF) ? 0.0 : mx;\n        float sm = ex2(v0 - gM)";
-        for (int k = 1; k < n; ++k) body << " + ex2(v" << k << " - gM)";
-        body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
+    };
+    if (n <= JIT_MAX_CANDS) {
+      for (int k = 0; k < n; ++k) loadRec(k, "r" + std::to_string(k));
+      for (int k = 0; k < n; ++k)
+        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)r" << k << ".srcOff) + r" << k << ".w;\n";
+      if (n == 1) {
+        body << "        const double res = v0;\n";
+      } else {
+        body << "        double mx = dmax(v0, v1);\n";
+        for (int k = 2; k < n; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
+        if (mode == MB_VITERBI) body << "        const double res = mx;\n";
+        else {
+          body << "        const double gM = (mx == NEG_INF) ? 0.0 : mx;\n        const float sm = ex2(v0 - gM)";
+          for (int k = 1; k < n; ++k) body << " + ex2(v" << k << " - gM)";
+          body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
+        }
       }
+      body << "        if (active && (int)r0.dstOff >= 0) *(double *)(ldsb + (aCur + (int)r0.dstOff)) = res;\n";
+    } else {
+      // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
+      body << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
+      for (int k0 = 0; k0 < n; k0 += JIT_MAX_CANDS) {
+        const int k1 = std::min(n, k0 + JIT_MAX_CANDS);
+        body << "        {\n";
+        for (int k = k0; k < k1; ++k) loadRec(k, "r" + std::to_string(k));
+        if (k0 == 0) body << "        dstOff = r0.dstOff;\n";
+        for (int k = k0; k < k1; ++k)
+          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)r" << k << ".srcOff) + r" << k << ".w;\n";
+        body << "        double mx = v" << k0 << ";\n";
+        for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
+        if (mode == MB_VITERBI) body << "        accM = dmax(accM, mx);\n";
+        else {
+          body << "        const double nm = dmax(accM, mx), gM = (nm == NEG_INF) ? 0.0 : nm;\n        accS = accS * ex2(accM - gM)";
+          for (int k = k0; k < k1; ++k) body << " + ex2(v" << k << " - gM)";
+          body << ";\n        accM = nm;\n";
+        }
+        body << "        }\n";
+      }
+      if (mode == MB_VITERBI) body << "        const double res = accM;\n";
+      else body << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
+      body << "        if (active && (int)dstOff >= 0) *(double *)(ldsb + (aCur + (int)dstOff)) = res;\n";
     }
-    body << "        if (active && (int)r0.dstOff >= 0) *(double *)(ldsb + (aCur + (int)r0.dstOff)) = res;\n      }\n";
+    body << "      }\n";
     if (ri.sync) body << "      med_wave_sync();\n";
   }
   std::string src = kMedJitSkeleton;
@@ -71,8 +96,12 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
   J.tried = true;
   const char *e = getenv("MB_MEDIUM_JIT");
   if (e && *e == '0') return false;
-  for (const MedRoundInfo &ri : P.roundInfo)
-    if ((int)ri.slots.size() > JIT_MAX_CANDS || ri.slots.empty()) return false;
+  long long totalSlots = 0;
+  for (const MedRoundInfo &ri : P.roundInfo) {
+    if (ri.slots.empty()) return false;
+    totalSlots += (long long)ri.slots.size();
+  }
+  if (totalSlots > 20000) return false;
   if (P.roundInfo.size() > 4096) return false;   // keep the generated code within reach of the instruction cache
   // token-independent records go to LDS when they fit next to the ring
   const size_t ring = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);

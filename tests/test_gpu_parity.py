@@ -231,8 +231,10 @@ def test_survey_anchors_gpu(capi, machines, idx):
 
 
 # ---- tiled "lanes = states" family (mb_medium.hip) ---------------------------------------------------------------
-def _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch):
+def _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch, jit=0):
+    """jit=0: the ahead-of-time interpreter kernel k_medium_tile; jit=1: the hiprtc-specialised k_medium_jit."""
     monkeypatch.setenv("MB_MEDIUM_G", str(G))
+    monkeypatch.setenv("MB_MEDIUM_JIT", str(jit))
     om = oracle_mod.OracleMachine(em)
     capi.set_kernel(capi.KERNEL_MEDIUM)
     try:
@@ -240,7 +242,7 @@ def _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch):
         V = dm.fill(capi.MB_VITERBI, x, y)
         F = dm.fill(capi.MB_FORWARD, x, y)
         B = dm.fill(capi.MB_BACKWARD, x, y)
-        assert "medium" in capi.last_kernel_name()
+        assert ("k_medium_jit" if jit else "k_medium_tile") in capi.last_kernel_name()
         b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
         llr = b.forward(capi.MB_ROLLING)[0]
     finally:
@@ -262,6 +264,14 @@ def test_medium_psw2dna(capi, oracle_mod, machines, monkeypatch, G, shape):
     _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch)
 
 
+@pytest.mark.parametrize("G,shape", [(2, (70, 300)), (2, (0, 33)), (4, (41, 0)), (1, (130, 17))])
+def test_medium_psw2dna_jit(capi, oracle_mod, machines, monkeypatch, G, shape):
+    """The same checks through the run-time specialised kernel (hiprtc)."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    x, y = synth_tokens(11, shape[0], shape[1], em.nInTok, em.nOutTok)
+    _medium_case(capi, oracle_mod, em, x, y, G, monkeypatch, jit=1)
+
+
 @pytest.mark.parametrize("G", [1, 4])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_medium_random_machines(capi, oracle_mod, monkeypatch, G, seed):
@@ -271,7 +281,7 @@ def test_medium_random_machines(capi, oracle_mod, monkeypatch, G, seed):
     em = random_machine(S, 3, 4, seed, allow_inf=(seed == 2))
     rng = np.random.RandomState(seed)
     for il, ol in [(25, 31), (0, 9), (60, 45)]:
-        _medium_case(capi, oracle_mod, em, random_seq(rng, il, 3), random_seq(rng, ol, 4), G, monkeypatch)
+        _medium_case(capi, oracle_mod, em, random_seq(rng, il, 3), random_seq(rng, ol, 4), G, monkeypatch, jit=(seed + G) % 2)
 
 
 def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
@@ -282,7 +292,7 @@ def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
     pairs = [synth_tokens(40 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(12, 50), (40, 90), (3, 7)])]
     b = capi.DeviceBatch.from_pairs(dm, pairs)
     vll, off, edges = b.viterbi()
-    assert "medium" in capi.last_kernel_name()
+    assert "k_medium" in capi.last_kernel_name()
     for k, (x, y) in enumerate(pairs):
         V = om.viterbi(x, y)
         assert vll[k] == V[-1, -1, -1] and np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, V))
