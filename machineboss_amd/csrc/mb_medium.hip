@@ -471,14 +471,29 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
   for (int st = 0; st < nStages; ++st) {
     std::vector<int> ids;
     for (int k = 0; k < (int)nodes.size(); ++k) if (nodes[k].stage == st) ids.push_back(k);
-    std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) {
-      const auto dx = sig(nodes[x]), dy = sig(nodes[y]);
-      const int tx = dx[0] + dx[1] + dx[2] + dx[3], ty = dy[0] + dy[1] + dy[2] + dy[3];
-      if (tx != ty) return tx > ty;
-      return dx > dy;
-    });
-    for (size_t k = 0; k < ids.size(); k += LPG) {
-      rounds.emplace_back(ids.begin() + k, ids.begin() + std::min(ids.size(), k + LPG));
+    // order by candidate signature, then cut the ordered list into rounds of <= LPG nodes by dynamic programming:
+    // a round costs a fixed overhead plus, per table, as many slots as its most demanding node (padding is work).
+    std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) { return sig(nodes[x]) > sig(nodes[y]); });
+    const int nIds = (int)ids.size();
+    const double roundCost = 6.0, slotCost = 9.0, singleCost = 3.0;
+    std::vector<double> best(nIds + 1, 1e300);
+    std::vector<int> cut(nIds + 1, 0);
+    best[0] = 0.0;
+    for (int e = 1; e <= nIds; ++e) {
+      std::array<int, 4> mxs{0, 0, 0, 0};
+      for (int b = e - 1; b >= 0 && e - b <= LPG; --b) {
+        const auto d = sig(nodes[ids[b]]);
+        for (int T = 0; T < 4; ++T) mxs[T] = std::max(mxs[T], d[T]);
+        const int tot = mxs[0] + mxs[1] + mxs[2] + mxs[3];
+        const double c = best[b] + roundCost + (tot <= 1 ? singleCost : tot * slotCost);
+        if (c < best[e]) { best[e] = c; cut[e] = b; }
+      }
+    }
+    std::vector<std::pair<int, int>> segs;
+    for (int e = nIds; e > 0; e = cut[e]) segs.push_back({cut[e], e});
+    std::reverse(segs.begin(), segs.end());
+    for (auto &sg : segs) {
+      rounds.emplace_back(ids.begin() + sg.first, ids.begin() + sg.second);
       sync.push_back(0);
     }
     if (!sync.empty()) sync.back() = 1;
