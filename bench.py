@@ -86,10 +86,12 @@ def main():
         ll = batch.forward(flags)
     sync()
     dev_ms = 0.0
+    launches = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ll = batch.forward(flags)
         dev_ms += capi.last_device_ms()
+        launches += capi.last_launch_count()
     sync()
     dt = time.perf_counter() - t0
     kernel = capi.last_kernel_name()
@@ -129,7 +131,16 @@ def main():
                          % (len(x), len(y), args.preset, d2)}
 
     if rank == 0:
+        # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the
+        # library stream around the launch sequence; launches are back to back, gaps < 1 us in the rocprof trace)
         ach = BYTES_PER_CELL * cells_rank * args.steps / (dev_ms / 1e3) / 1e9 if (dev_ms > 0 and flags == capi.MB_MATERIALISE) else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/), valid for the default workload only
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
+            if pmc["kernel"] == kernel and pmc["cells_per_step"] == cells_rank and flags == capi.MB_MATERIALISE:
+                traffic = round(pmc["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         out = {
             "metric": "Giga DP-cells/sec (Forward) on composed protpsw machine",
             "value": round(value, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,8 +151,11 @@ def main():
                        "parallelism": "pairs sharded over %d GPU(s), no data-path collective" % world,
                        "cells_per_gpu_per_step": int(cells_rank)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL if flags == capi.MB_MATERIALISE else 0,
+                         "algorithmic_bytes_per_launch": round(BYTES_PER_CELL * cells_rank * args.steps / max(launches, 1)) if flags == capi.MB_MATERIALISE else 0,
+                         "launches_per_step": launches // max(args.steps, 1),
+                         "avg_launch_us": round(dev_ms * 1e3 / max(launches, 1), 2),
                          "device_ms_per_step": round(dev_ms / args.steps, 3)},
             "cpu_baseline": cpu,
             "loglike_checksum": float(np.sum(ll)),

@@ -47,6 +47,7 @@ int mb_set_device(int device);    /* one process drives one GPU (rank-local devi
 const char *mb_last_error(void);  /* thread-local message of the last failing call                             */
 double mb_last_device_ms(void);   /* device time (HIP events on the library's stream) of the last batch call   */
 const char *mb_last_kernel_name(void); /* name of the dominant kernel of the last batch call (for profiles)     */
+int64_t mb_last_launch_count(void);    /* launches of that kernel in the last batch call                            */
 
 /* ---- machine ----------------------------------------------------------------------------------------------
  * Replaces the per-state incoming/outgoing maps built by EvaluatedMachine::init (src/eval.cpp:40-70).

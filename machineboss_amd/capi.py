@@ -19,7 +19,7 @@ MB_MATERIALISE, MB_ROLLING = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SMALL, KERNEL_MEDIUM = 0, 1, 2, 3
 
 EXPORTS = [
-    "mb_device_count", "mb_set_device", "mb_last_error", "mb_last_device_ms", "mb_last_kernel_name",
+    "mb_device_count", "mb_set_device", "mb_last_error", "mb_last_device_ms", "mb_last_kernel_name", "mb_last_launch_count",
     "mb_machine_create", "mb_machine_set_weights", "mb_machine_destroy", "mb_machine_n_states", "mb_machine_n_trans",
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
@@ -49,6 +49,7 @@ def load():
     L.mb_last_error.restype = C.c_char_p
     L.mb_last_device_ms.restype = C.c_double
     L.mb_last_kernel_name.restype = C.c_char_p
+    L.mb_last_launch_count.restype = C.c_int64
     L.mb_machine_create.restype = vp
     L.mb_machine_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp]
     L.mb_machine_set_weights.argtypes = [vp, dp]
@@ -107,6 +108,10 @@ def release_workspace():
 
 def last_device_ms() -> float:
     return load().mb_last_device_ms()
+
+
+def last_launch_count() -> int:
+    return load().mb_last_launch_count()
 
 
 def last_kernel_name() -> str:

@@ -16,6 +16,7 @@ namespace mb {
 thread_local std::string g_err;
 thread_local double g_last_ms = 0.0;
 thread_local const char *g_last_kernel = "";
+thread_local long long g_last_launches = 0;
 hipStream_t g_stream = nullptr;
 int g_kernel_choice = 0;
 size_t g_mem_budget = 0;
@@ -223,6 +224,7 @@ int mb_set_device(int device) {
 const char *mb_last_error(void) { return g_err.c_str(); }
 double mb_last_device_ms(void) { return g_last_ms; }
 const char *mb_last_kernel_name(void) { return g_last_kernel; }
+int64_t mb_last_launch_count(void) { return g_last_launches; }
 
 int mb_set_kernel(int which) {
   if (which < 0 || which > 3) { set_error("mb_set_kernel: unknown kernel family"); return 1; }
@@ -332,7 +334,7 @@ int64_t mb_batch_cells(const mb_batch *b) { return b ? b->totalCells : 0; }
 
 // ---- Forward ------------------------------------------------------------------------------------------------
 static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
-  g_last_ms = 0.0;
+  g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   mb_machine *m = b->m;
@@ -409,7 +411,7 @@ int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen
 
 int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
   if (!b || !loglike) { set_error("null argument"); return 1; }
-  g_last_ms = 0.0;
+  g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
   if (pathOff) pathOff[0] = 0;
@@ -473,7 +475,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
 // ---- Forward-Backward counts --------------------------------------------------------------------------------
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
   if (!b || !counts) { set_error("null argument"); return 1; }
-  g_last_ms = 0.0;
+  g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   const long long nT = b->m->nTrans;

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
 int launch_generic_fill(const mb_machine *m, int mode, const PairDesc *d_pairs, long long nPairs, const int *d_in,
                         const int *d_out, double *d_pool, int startState, hipStream_t st) {
   if (nPairs == 0) return 0;
+  ++g_last_launches;
   const dim3 grid((unsigned)nPairs), block(m->S * 64 >= 1024 ? 1024 : 256);
   if (mode == MB_FORWARD)
     hipLaunchKernelGGL(k_generic_fill_fwd<MB_FORWARD>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, startState);

@@ -83,6 +83,7 @@ namespace mb {
 void set_error(const std::string &msg);
 bool hip_ok(hipError_t e, const char *what);
 extern hipStream_t g_stream;
+extern thread_local long long g_last_launches;   // kernel launches of the dominant kernel in the last batch call
 extern int g_kernel_choice;
 extern size_t g_mem_budget;
 #define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)

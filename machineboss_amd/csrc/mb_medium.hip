@@ -718,6 +718,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
     if (cnt[l] <= 0) continue;
+    ++g_last_launches;
     A.launch = l; A.tileBase = (int)off[l];
     const dim3 grid((unsigned)cnt[l]);
     if (J && launch_jit(*J, grid, block, st, dev, A)) continue;
@@ -830,6 +831,7 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
   dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
+    ++g_last_launches;
     if (J && launch_jit(*J, grid, block, st, dev, A)) continue;
     launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }

@@ -1,0 +1,22 @@
+// Exercises the C++ shim (machineboss_amd/cxx/mb_dp.hpp) on the reference's bitnoise golden case
+// (t/machine/bitnoise.json, t/io/params.json p=0.99 q=0.01, t/io/tiny.json: input 001, output 101).
+#include <cstdio>
+#include <cmath>
+#include "mb_dp.hpp"
+using namespace MachineBossHIP;
+int main() {
+  FlatMachine m; m.nStates = 1; m.nInTok = 2; m.nOutTok = 2;
+  const double p = std::log(0.99), q = std::log(0.01);
+  m.addTransition(0, 0, 1, 1, p); m.addTransition(0, 0, 1, 2, q); m.addTransition(0, 0, 2, 2, p); m.addTransition(0, 0, 2, 1, q);
+  m.finish();
+  TokSeqPair sp{{1, 1, 2}, {2, 1, 2}};
+  ForwardMatrix fwd(m, sp); BackwardMatrix bwd(m, sp); ViterbiMatrix vit(m, sp); RollingOutputForwardMatrix roll(m, sp);
+  MachineCounts mc(m, {sp});
+  std::printf("fwd %.5g back %.5g vit %.5g roll %.5g path %zu counts %g %g %g %g ll %.5g\n", fwd.logLike(), bwd.logLike(), vit.logLike(),
+              roll.logLike(), vit.path().size(), mc.count[0][0], mc.count[0][1], mc.count[0][2], mc.count[0][3], mc.loglike);
+  const bool ok = std::fabs(fwd.logLike() + 4.6253) < 1e-4 && std::fabs(bwd.logLike() + 4.6253) < 1e-4 && vit.path().size() == 3 &&
+                  std::fabs(mc.count[0][0] - 1) < 1e-9 && std::fabs(mc.count[0][3]) < 1e-12 && std::fabs(fwd.cell(1, 1, 0) + 4.6052) < 1e-4 &&
+                  std::isinf(fwd.cell(0, 1, 0));
+  std::printf(ok ? "FACADE OK\n" : "FACADE MISMATCH\n");
+  return ok ? 0 : 1;
+}

@@ -1,0 +1,81 @@
+"""CPU tests of the multi-GPU plumbing (world_size 2, gloo): sharding is a partition, and the one exchange step of the
+path -- the all-reduce of E-step sufficient statistics (MachineCounts::operator+=, src/counts.cpp:66-71) -- gives every
+rank the serial result.  The per-rank E-step here is the oracle (no GPU in this container); on GPUs the same
+allreduce_counts() runs over RCCL (backend "nccl")."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_path
+from machineboss_amd.shard import allreduce_counts, lpt_assign, shard_range
+
+
+def test_shard_range_is_partition():
+    for n in (0, 1, 7, 256, 1000):
+        for w in (1, 2, 3, 8):
+            got = []
+            for r in range(w):
+                f, c = shard_range(n, w, r)
+                got += list(range(f, f + c))
+            assert got == list(range(n))
+
+
+def test_lpt_assign_balances_ragged_batches():
+    rng = np.random.RandomState(0)
+    cells = rng.randint(1, 1000, size=200) ** 2
+    parts = lpt_assign(cells, 8)
+    assert sorted(k for p in parts for k in p) == list(range(200))
+    loads = [sum(int(cells[k]) for k in p) for p in parts]
+    assert max(loads) <= 1.05 * (sum(loads) / 8)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.seqgen import synth_tokens
+    from oracle import oracle
+    m = Machine.fromFile(golden_path("preset", "dnapsw.json"))
+    em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    om = oracle.OracleMachine(em)
+    nPairs = 7
+    first, count = shard_range(nPairs, world, rank)
+    counts = np.zeros(em.nTransitions); ll = 0.0
+    for k in range(first, first + count):
+        x, y = synth_tokens(3000 + k, 20 + k, 25, em.nInTok, em.nOutTok)
+        ll += om.counts_add(x, y, counts)
+    counts, ll = allreduce_counts(counts, ll, "cpu")
+    q.put((rank, counts.copy(), ll))
+    dist.destroy_process_group()
+
+
+def test_counts_allreduce_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    # serial reference
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.seqgen import synth_tokens
+    from oracle import oracle
+    em = EvaluatedMachine.fromMachine(Machine.fromFile(golden_path("preset", "dnapsw.json")), None, useDefaults=True)
+    om = oracle.OracleMachine(em)
+    ref = np.zeros(em.nTransitions); ref_ll = 0.0
+    for k in range(7):
+        x, y = synth_tokens(3000 + k, 20 + k, 25, em.nInTok, em.nOutTok)
+        ref_ll += om.counts_add(x, y, ref)
+    for rank, counts, ll in res:
+        assert np.allclose(counts, ref, rtol=1e-12, atol=1e-14) and abs(ll - ref_ll) <= 1e-12 * abs(ref_ll)

@@ -6,6 +6,7 @@ with the reference's table mode to REL_TABLE (the north-star tolerance is 1e-4 r
 posterior counts agree to COUNT_TOL (summation order differs: fp64 atomics).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -319,3 +320,17 @@ def test_medium_vs_generic_large(capi, machines):
         capi.set_kernel(capi.KERNEL_AUTO)
     assert np.array_equal(vm, vg) and np.all(vm == vm[0])
     assert close(llm, llg, FAST_REL, FAST_ABS) and close(llr, llg, FAST_REL, FAST_ABS) and np.all(llm == llm[0])
+
+
+def test_cxx_facade(capi, tmp_path):
+    """The C++ shim with the reference's class names (machineboss_amd/cxx/mb_dp.hpp) over the C-ABI, on the
+    reference's bitnoise golden case (t/expect/{fwd,back,fwdback}-bitnoise-params-tiny.json)."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "test_facade")
+    libdir = os.path.join(ROOT, "machineboss_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"),
+                           os.path.join(ROOT, "tests", "cxx", "test_facade.cpp"), "-o", exe, "-L", libdir, "-lmbhip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "FACADE OK" in out.stdout, out.stdout + out.stderr
