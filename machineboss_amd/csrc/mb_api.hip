@@ -152,9 +152,8 @@ static FastState *fast_state(mb_machine *m) {
   FastState *f = (FastState *)m->fast;
   if (!f->tried) {
     f->tried = true;
-    // lanes = states pays once a supercell has clearly more states than a lane group; tiny machines stay on the
-    // generic family until the lanes = supercells family exists.
-    if (m->S > 16 && m->S <= 4096) {
+    // tiny machines run with 8 columns per wavefront (8 lanes per supercell); 1-state machines stay generic
+    if (m->S >= env_int("MB_MEDIUM_MIN_STATES", 2) && m->S <= 4096) {
       int G = env_int("MB_MEDIUM_G", 0);
       if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 128 ? 2 : (m->S >= 48 ? 4 : 8));   // measured on psw2dna (271 states): G=2 > 4 > 1
       f->G = G;

@@ -91,7 +91,9 @@ def test_forward_start_state(capi, oracle_mod, machines):
     """ForwardMatrix 4-argument constructor: caller-chosen start state (src/forward.defs.h:16-21,36)."""
     m, em, i, o = setup_case(machines, CASES[2])
     F = capi.DeviceMachine(em).fill(capi.MB_FORWARD, i, o, startState=2)
-    assert close(F, oracle_mod.OracleMachine(em).forward(i, o, oracle_mod.SUM_EXACT, startState=2), REL_EXACT)
+    fast = "generic" not in capi.last_kernel_name()
+    assert close(F, oracle_mod.OracleMachine(em).forward(i, o, oracle_mod.SUM_EXACT, startState=2),
+                 FAST_REL if fast else REL_EXACT, FAST_ABS if fast else 0.0)
 
 
 def test_reference_goldens_through_gpu(capi, machines):
@@ -181,7 +183,9 @@ def test_set_weights(capi, oracle_mod, machines):
     dm.set_weights(lw)
     om = oracle_mod.OracleMachine(em.withLogWeights(lw))
     assert np.array_equal(dm.fill(capi.MB_VITERBI, x, y), om.viterbi(x, y))
-    assert close(dm.fill(capi.MB_FORWARD, x, y), om.forward(x, y, oracle_mod.SUM_EXACT), REL_EXACT)
+    F = dm.fill(capi.MB_FORWARD, x, y)
+    fast = "generic" not in capi.last_kernel_name()
+    assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL if fast else REL_EXACT, FAST_ABS if fast else 0.0)
 
 
 def test_errors(capi, machines):
@@ -226,7 +230,7 @@ def test_survey_anchors_gpu(capi, machines, idx):
     ll = b.forward()[0]
     assert abs(ll - a["forward"]) <= 1e-4 * abs(a["forward"])
     if a["forward_exact"] is not None:
-        assert abs(ll - a["forward_exact"]) <= 1e-5   # device direct-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
+        assert abs(ll - a["forward_exact"]) <= 2e-7 * abs(a["forward_exact"])   # fp32 correction terms accumulate along the lattice; device direct-logsumexp == the reference's -DLOG_SUM_EXP_SLOW build
     vll, off, edges = b.viterbi()
     assert float("%.10g" % vll[0]) == a["viterbi"] and off[1] == a["pathLen"]
 
