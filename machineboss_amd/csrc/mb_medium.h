@@ -13,7 +13,7 @@ constexpr int MED_DESC_WORDS = 8;   // descriptor words per chunk (32 B, fetched
 struct alignas(16) MedRec {
   double w;          // log-weight (padding: -inf)
   uint32_t srcOff;   // byte offset of the source value inside an LDS state vector (padding: the -inf sentinel)
-  uint32_t dstOff;   // slot 0 of a chunk only: byte offset of the state this lane finalises, 0xFFFFFFFF = idle lane
+  uint32_t dstOff;   // slot 0 of a chunk only: byte offset of the state this lane finalises (idle lane: the dummy entry)
 };
 
 // The compiled "program" of a machine for one sweep direction.
@@ -64,6 +64,7 @@ struct MedProgram {
   std::vector<std::vector<int>> closBase;                       // node -> sorted base ancestors
   std::vector<std::vector<int>> closPair;                       // node -> pair id per ancestor (parallel to closBase)
   int nPairs = 0;
+  uint32_t dummyOff = 0;            // byte offset of the write-only dummy entry of an LDS state vector
   std::vector<MedRoundInfo> roundInfo;
   std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (token-independent slots)
   int *d_desc = nullptr;

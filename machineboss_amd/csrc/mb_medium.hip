@@ -457,7 +457,8 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
       }
     }
   }
-  P.Spad = (S + 1 + nExtra + 1) & ~1;   // [S] = -inf sentinel, then the e-slots; even length
+  P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;   // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to; even
+  P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
   const int nStages = closure ? 2 : nLev;
 
   // ---- rounds: per stage, nodes sorted so that a round is homogeneous in (tables used, candidate count) ----------
@@ -504,7 +505,7 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
   // ---- descriptors and records -------------------------------------------------------------------------------------
   const int mulI[4] = {LPG * (nOut + 1), LPG, 0, 0}, mulO[4] = {LPG, 0, LPG, 0};
   const int ntokT[4] = {ntok[0], ntok[1], ntok[2], 1};
-  const MedRec padRec{-INFINITY, (uint32_t)S * 8u, 0xFFFFFFFFu};
+  const MedRec padRec{-INFINITY, (uint32_t)S * 8u, (uint32_t)(S + 1 + nExtra) * 8u};   // idle lanes store into the dummy entry
   auto candsOf = [&](const Node &n, int T, int tok, std::vector<Cand> &out) {
     if (T == 3) { out = n.cur; return; }
     out.clear();

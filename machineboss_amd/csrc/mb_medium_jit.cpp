@@ -22,7 +22,7 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : 0)
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (recsInLds ? (long long)P.ldsImageIdx.size() : 0ll)
-       << "\n#define JHALO " << (S + geo.waves * 64 - 1) / (geo.waves * 64) << "\n";
+       << "\n#define JDUMMYOFF " << P.dummyOff << "\n#define JHALO " << (S + geo.waves * 64 - 1) / (geo.waves * 64) << "\n";
   static const char *vec[4] = {"aDiag", "aLeft", "aDown", "aCur"};
   static const char *tok[4] = {"tokM16", "itOff16", "otOff16", "q16"};
   long long ldsOff = 0;   // running record offset inside the LDS image (same order as MedProgram::ldsImageIdx)
@@ -52,7 +52,7 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
           body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
         }
       }
-      body << "        if (active && (int)r0.dstOff >= 0) *(double *)(ldsb + (aCur + (int)r0.dstOff)) = res;\n";
+      body << "        *(double *)(ldsb + (aCur + (int)(active ? r0.dstOff : (unsigned)JDUMMYOFF))) = res;\n";
     } else {
       // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
       body << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
@@ -75,7 +75,7 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
       }
       if (mode == MB_VITERBI) body << "        const double res = accM;\n";
       else body << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
-      body << "        if (active && (int)dstOff >= 0) *(double *)(ldsb + (aCur + (int)dstOff)) = res;\n";
+      body << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = res;\n";
     }
     body << "      }\n";
     if (ri.sync) body << "      med_wave_sync();\n";

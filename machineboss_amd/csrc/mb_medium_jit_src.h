@@ -43,7 +43,7 @@ typedef const __attribute__((address_space(1))) u32x4 *grec_t;
 typedef const __attribute__((address_space(1))) char *gbytes_t;
 struct Rec { double w; unsigned srcOff, dstOff; };
 
-__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64; operands are never NaN
 __device__ __forceinline__ Rec mk_rec(u32x4 r) {
   Rec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.srcOff = r.z; o.dstOff = r.w; return o;
 }
