@@ -24,7 +24,7 @@ EXPORTS = [
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
-    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace",
+    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source",
 ]
 
 _lib = None
@@ -73,6 +73,8 @@ def load():
     L.mb_counts_batch.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p, dp, dp, dp]
     L.mb_set_kernel.argtypes = [C.c_int]
     L.mb_set_memory_budget.argtypes = [C.c_size_t]
+    L.mb_debug_jit_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     _lib = L
     return L
 
@@ -116,6 +118,16 @@ def last_launch_count() -> int:
 
 def last_kernel_name() -> str:
     return load().mb_last_kernel_name().decode()
+
+
+def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: bool = True, G: int = 2):
+    """Write the HIP source of the run-time specialised tile kernel for this machine (host only, no GPU needed)."""
+    a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+         np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+         np.ascontiguousarray(em.logWeight, np.float64)]
+    _check(load().mb_debug_jit_source(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                      _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
+                                      mode, int(backward), int(closure), G, path.encode()))
 
 
 class DeviceMachine:

@@ -160,18 +160,16 @@ static FastState *fast_state(mb_machine *m) {
       long long nSilent = 0;
       for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
       const bool wantClosure = env_int("MB_MEDIUM_CLOSURE", 1) != 0;
-      bool ok = medium_build(m, false, false, G, f->fwdExact) && medium_geometry(m, f->fwdExact, f->geoFE);
+      bool ok = medium_build(m, false, false, G, f->fwdExact, f->geoFE);
       if (ok) {
         bool clos = wantClosure;
-        ok = medium_build(m, false, clos, G, f->fwdSum);
-        if (ok && clos && f->fwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, false, false, G, f->fwdSum); }
-        ok = ok && medium_geometry(m, f->fwdSum, f->geoFS);
+        ok = medium_build(m, false, clos, G, f->fwdSum, f->geoFS);
+        if (ok && clos && f->fwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, false, false, G, f->fwdSum, f->geoFS); }
       }
       if (ok) {
         bool clos = wantClosure;
-        ok = medium_build(m, true, clos, G, f->bwdSum);
-        if (ok && clos && f->bwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, true, false, G, f->bwdSum); }
-        ok = ok && medium_geometry(m, f->bwdSum, f->geoBS);
+        ok = medium_build(m, true, clos, G, f->bwdSum, f->geoBS);
+        if (ok && clos && f->bwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, true, false, G, f->bwdSum, f->geoBS); }
       }
       f->mediumOk = ok;
     }
@@ -544,6 +542,31 @@ int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
   mb_batch_destroy(b);
   return rc;
+}
+
+// ---- introspection: generated source of the run-time specialised tile kernel (host only, no device needed) ------
+int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                        const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int closure,
+                        int G, const char *path) {
+  if (nStates <= 0 || nTrans < 0 || !path) { set_error("mb_debug_jit_source: bad argument"); return 1; }
+  if (G != 1 && G != 2 && G != 4 && G != 8) { set_error("mb_debug_jit_source: G must be 1, 2, 4 or 8"); return 1; }
+  mb_machine m;
+  m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
+  m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);
+  m.inTok.assign(inTok, inTok + nTrans); m.outTok.assign(outTok, outTok + nTrans);
+  m.logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  MedProgram P; MedGeom geo;
+  if (!medium_build_host(&m, backward != 0, closure != 0, G, P, geo)) return 1;
+  const std::string code = medium_jit_source(&m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD);
+  FILE *f = fopen(path, "w");
+  if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
+  fprintf(f, "// G=%d C=%d waves=%d ldsBytes=%zu ldsRecs=%zu rounds=%zu\n", G, geo.C, geo.waves, medium_jit_lds_bytes(P, geo),
+          P.ldsImageIdx.size(), P.roundInfo.size());
+  fputs(code.c_str(), f);
+  fclose(f);
+  return 0;
 }
 
 // ---- host-buffer convenience wrappers -------------------------------------------------------------------------

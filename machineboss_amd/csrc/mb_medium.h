@@ -42,14 +42,17 @@ struct MedProgDev {
 };
 
 // structure of the program, kept for the run-time code generator (mb_medium_jit.cpp)
-struct MedSlotInfo { int T; long long recBase; };          // table (= vector it reads, = token kind), first record
+// placement of a slot's records in the run-time specialised kernel (mb_medium_jit.cpp, medium_jit_plan):
+//   REG    loop-invariant per lane (token-independent, or dependent on the column's input token only): loaded once
+//          into VGPRs before the sweep;   LDS  copied into the LDS image next to the ring;   GLOBAL  fetched per step.
+enum { MED_PLACE_GLOBAL = 0, MED_PLACE_LDS = 1, MED_PLACE_REG = 2 };
+struct MedSlotInfo { int T; long long recBase; int place = MED_PLACE_GLOBAL; long long ldsOff = 0; };   // table (= vector it reads, = token kind), first record, placement, record offset in the LDS image
 struct MedRoundInfo { std::vector<MedSlotInfo> slots; bool sync = false, single = false; };
 
 struct MedJit {                 // one specialised kernel (per program and semiring)
   bool tried = false;
   void *module = nullptr, *func = nullptr;
   size_t ldsBytes = 0;
-  bool recsInLds = false;
 };
 
 struct MedProgram {
@@ -66,7 +69,9 @@ struct MedProgram {
   int nPairs = 0;
   uint32_t dummyOff = 0;            // byte offset of the write-only dummy entry of an LDS state vector
   std::vector<MedRoundInfo> roundInfo;
-  std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (token-independent slots)
+  std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (slots placed in LDS by medium_jit_plan)
+  int regBudget = -1;                   // VGPRs medium_jit_plan may spend on loop-invariant records (-1: default)
+  int tokWindow = 64;                   // steps per output-token window kept in LDS by the specialised kernel
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
@@ -75,8 +80,15 @@ struct MedProgram {
 
 struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
 
-bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P);
+// host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
+bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
+bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
+void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
+void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);
+long long medium_jit_spill_count(const std::string &codeObject);
+size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo);
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode);
 void medium_free(MedProgram &P);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,

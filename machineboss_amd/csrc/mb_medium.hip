@@ -546,7 +546,6 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
       P.wref.resize(b0 + (size_t)c.n * stride, -1);
       for (int k = 0; k < c.n; ++k) {
         P.roundInfo.back().slots.push_back({c.T, (long long)b0 + (long long)k * stride});
-        if (c.T == 3) for (int ln = 0; ln < LPG; ++ln) P.ldsImageIdx.push_back((long long)b0 + (long long)k * stride + ln);
       }
       for (size_t ln = 0; ln < rounds[r].size(); ++ln) {
         const Node &n = nodes[rounds[r][ln]];
@@ -578,8 +577,8 @@ static bool up(T *&d, const std::vector<T> &h) {
 }
 
 // (Re)evaluate every record's log-weight: plain edges take logW[edge]; closure pairs take the log-sum over all silent
-// paths from the base state to the node (recurrence over the silent DAG in topological order).
-bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
+// paths from the base state to the node (recurrence over the silent DAG in topological order).  Host only.
+void medium_eval_weights(const mb_machine *m, MedProgram &P) {
   std::vector<double> pairW(P.nPairs + 1, -INFINITY);
   pairW[P.nPairs] = 0.0;   // the constant "own emit part" pair
   if (P.closure) {
@@ -606,6 +605,10 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
     const int r = P.wref[k];
     P.rec[k].w = r >= 0 ? m->logW[r] : (r == -1 ? -INFINITY : pairW[-2 - r]);
   }
+}
+
+bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
+  medium_eval_weights(m, P);
   if (!up(P.d_rec, P.rec)) return false;
   P.dev.rec = P.d_rec;
   std::vector<MedRec> img(P.ldsImageIdx.size());
@@ -615,15 +618,23 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
   return true;
 }
 
-bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P) {
+bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo) {
   build_program(m, backward, closure, G, P);
   if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 24)) { set_error("machine too large for the tiled kernel family"); return false; }
-  if (!up(P.d_desc, P.desc)) return false;
   MedProgDev &d = P.dev;
   d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
   d.nIn = m->nIn; d.nOut = m->nOut;
   d.startNode = backward ? m->S - 1 : 0; d.endNode = backward ? 0 : m->S - 1;
-  d.desc = P.d_desc;
+  if (!medium_geometry(m, P, geo)) { set_error("machine does not fit the tiled kernel family's LDS ring"); return false; }
+  medium_jit_plan(m, P, geo);
+  medium_eval_weights(m, P);
+  return true;
+}
+
+bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo) {
+  if (!medium_build_host(m, backward, closure, G, P, geo)) return false;
+  if (!up(P.d_desc, P.desc)) return false;
+  P.dev.desc = P.d_desc;
   return medium_refresh_weights(m, P);
 }
 
@@ -653,7 +664,6 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
 static bool launch_jit(const MedJit &J, dim3 grid, dim3 block, hipStream_t st, const MedProgDev &P, const MedTileArgs &A) {
   if (!J.func) return false;
   MedProgDev p = P; MedTileArgs a = A;
-  if (!J.recsInLds) p.ldsImageRecs = 0;
   void *args[] = {&p, &a};
   return hipModuleLaunchKernel((hipFunction_t)J.func, grid.x, grid.y, grid.z, block.x, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
 }

@@ -1,6 +1,15 @@
 // mb_medium_jit.cpp -- run-time specialisation of the "lanes = states" tile kernel with hiprtc (see
 // mb_medium_jit_src.h for the rationale).  The generator unrolls the compiled program of ONE machine into
-// straight-line HIP; everything structural becomes a literal.
+// straight-line HIP; everything structural becomes a literal, and every candidate record gets a PLACEMENT:
+//
+//   REG     records that do not change along the sweep of a column -- token-independent ones (silent closure) and the
+//           ones selected by the column's INPUT token only -- are loaded once into VGPRs before the step loop;
+//   LDS     records selected by the output token (and whatever token-independent ones exceed the VGPR budget) are
+//           copied into LDS next to the ring at the start of a tile;
+//   GLOBAL  what fits neither (large match tables) is fetched per step with global_load_dwordx4 as before.
+//
+// With REG + LDS placement the step loop issues no vector-memory LOAD other than the halo supercell, so nothing in
+// a step waits (through the in-order vmcnt counter of gfx9) for the previous step's global stores to be acknowledged.
 #include <hip/hiprtc.h>
 
 #include <algorithm>
@@ -13,33 +22,124 @@
 
 namespace mb {
 
-static constexpr int JIT_MAX_CANDS = 12;   // candidates evaluated in one straight-line round body
+static int env_int_early(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static const int JIT_MAX_CANDS = std::max(2, env_int_early("MB_JIT_MAXCANDS", 12));   // candidates evaluated in one straight-line round body
 
-static std::string generate_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool recsInLds) {
-  std::ostringstream defs, body;
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) { return (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double); }
+static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }
+
+size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo) {
+  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo);
+}
+
+// Decide where every slot's records live (see the file header).  Deterministic in (program, geometry).
+void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
+  if (P.regBudget < 0) {
+    // VGPRs left for loop-invariant records: a wavefront of a W-wave workgroup may use 512 / ceil(W / 4) registers and
+    // the specialised kernel needs ~90 of them for everything else; medium_jit_get lowers this if the compiler spills
+    const int perWave = std::min(512 / ((geo.waves + 3) / 4), 256);
+    P.regBudget = env_int("MB_JIT_REGBUDGET", std::max(0, perWave - 84));
+  }
+  P.ldsImageIdx.clear();
+  P.tokWindow = 64;
+  const int LPG = P.LPG;
+  const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
+  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo);
+  int regFree = P.regBudget;                               // VGPRs for loop-invariant records (3 per record, +1 per round)
+  if (P.Spad * 8 >= (1 << 16)) regFree = 0;
+  for (MedRoundInfo &ri : P.roundInfo) for (MedSlotInfo &sl : ri.slots) { sl.place = MED_PLACE_GLOBAL; sl.ldsOff = 0; }
+  auto toLds = [&](MedSlotInfo &sl) {
+    const long long n = ntokT[sl.T] * LPG;
+    if (n * 16 > ldsFree) return false;
+    sl.place = MED_PLACE_LDS; sl.ldsOff = (long long)P.ldsImageIdx.size();
+    for (long long k = 0; k < n; ++k) P.ldsImageIdx.push_back(sl.recBase + k);
+    ldsFree -= n * 16;
+    return true;
+  };
+  auto toReg = [&](MedRoundInfo &ri, size_t k) {
+    const int cost = 3 + (k == 0 ? 1 : 0);
+    if (cost > regFree) return false;
+    ri.slots[k].place = MED_PLACE_REG; regFree -= cost;
+    return true;
+  };
+  if (env_int("MB_JIT_PLACE", 1) == 0) {   // legacy placement: token-independent records in LDS, everything else global
+    for (MedRoundInfo &ri : P.roundInfo) for (MedSlotInfo &sl : ri.slots) if (sl.T == 3) toLds(sl);
+    return;
+  }
+  // pass 1: input-token records -> VGPRs (they would otherwise be per-step global loads); output-token records -> LDS
+  for (MedRoundInfo &ri : P.roundInfo)
+    for (size_t k = 0; k < ri.slots.size(); ++k) {
+      if (ri.slots[k].T == 1) toReg(ri, k);
+      else if (ri.slots[k].T == 2) toLds(ri.slots[k]);
+    }
+  // pass 2: token-independent records -> VGPRs while the budget lasts, then LDS
+  for (MedRoundInfo &ri : P.roundInfo)
+    for (size_t k = 0; k < ri.slots.size(); ++k)
+      if (ri.slots[k].T == 3 && !toReg(ri, k)) toLds(ri.slots[k]);
+  // pass 3: leftovers (input-token records beyond the VGPR budget, match tables) -> LDS if they still fit
+  for (MedRoundInfo &ri : P.roundInfo)
+    for (MedSlotInfo &sl : ri.slots)
+      if (sl.place == MED_PLACE_GLOBAL) toLds(sl);
+}
+
+// Spilled VGPRs of the (single) kernel in a code object: the value behind ".vgpr_spill_count" in the msgpack metadata
+// note (a positive fixint, or 0xcc/0xcd/0xce + big-endian uint8/16/32).  -1 if the key is missing.
+long long medium_jit_spill_count(const std::string &code) {
+  static const char key[] = ".vgpr_spill_count";
+  const size_t p = code.find(key);
+  if (p == std::string::npos || p + sizeof(key) - 1 >= code.size()) return -1;
+  const unsigned char *q = (const unsigned char *)code.data() + p + sizeof(key) - 1;
+  const size_t left = code.size() - (p + sizeof(key) - 1);
+  if (q[0] <= 0x7f) return q[0];
+  if (q[0] == 0xcc && left >= 2) return q[1];
+  if (q[0] == 0xcd && left >= 3) return ((long long)q[1] << 8) | q[2];
+  if (q[0] == 0xce && left >= 5) return ((long long)q[1] << 24) | ((long long)q[2] << 16) | ((long long)q[3] << 8) | q[4];
+  return -1;
+}
+
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode) {
+  std::ostringstream defs, pre, body;
   const int S = m->S;
+  const int threads = geo.waves * 64;
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : 0)
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
-       << "\n#define JLDSRECS " << (recsInLds ? (long long)P.ldsImageIdx.size() : 0ll)
-       << "\n#define JDUMMYOFF " << P.dummyOff << "\n#define JHALO " << (S + geo.waves * 64 - 1) / (geo.waves * 64) << "\n";
+       << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
+       << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
+       << "\n#define JDUMMYOFF " << P.dummyOff << "\n#define JHALO " << (S + threads - 1) / threads << "\n";
   static const char *vec[4] = {"aDiag", "aLeft", "aDown", "aCur"};
   static const char *tok[4] = {"tokM16", "itOff16", "otOff16", "q16"};
-  long long ldsOff = 0;   // running record offset inside the LDS image (same order as MedProgram::ldsImageIdx)
   for (size_t r = 0; r < P.roundInfo.size(); ++r) {
     const MedRoundInfo &ri = P.roundInfo[r];
     const int n = (int)ri.slots.size();
     body << "      {  // round " << r << ": " << n << " candidate slot(s)\n";
-    auto loadRec = [&](int k, const std::string &name) {
+    // name of the record of slot k; emits its load (loop-invariant ones go to the prologue)
+    auto rec = [&](int k) {
       const MedSlotInfo &sl = ri.slots[k];
-      if (sl.T == 3 && recsInLds) body << "        const Rec " << name << " = ld_l(ldsRec, " << ldsOff * 16 << "u + q16);\n";
-      else body << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
-      if (sl.T == 3) ldsOff += P.LPG;
+      const std::string name = "r" + std::to_string(r) + "_" + std::to_string(k);
+      if (sl.place == MED_PLACE_REG)
+        pre << "  const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ");\n";
+      else if (sl.place == MED_PLACE_LDS)
+        body << "        const Rec " << name << " = ld_l(ldsRec, " << sl.ldsOff * 16 << "u + " << tok[sl.T] << ");\n";
+      else if ((long long)P.rec.size() * 16 < (1ll << 31))   // buffer load: lane offset in a VGPR, slot base in an SGPR -> no loop-invariant 64-bit address per slot
+        body << "        const Rec " << name << " = ld_b(recRsrc, " << tok[sl.T] << ", " << sl.recBase * 16 << ");\n";
+      else
+        body << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
+      return name;
     };
+    std::vector<std::string> nm(n);
     if (n <= JIT_MAX_CANDS) {
-      for (int k = 0; k < n; ++k) loadRec(k, "r" + std::to_string(k));
+      for (int k = 0; k < n; ++k) nm[k] = rec(k);
       for (int k = 0; k < n; ++k)
-        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)r" << k << ".srcOff) + r" << k << ".w;\n";
+        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)" << nm[k] << ".srcOff) + " << nm[k] << ".w;\n";
       if (n == 1) {
         body << "        const double res = v0;\n";
       } else {
@@ -52,17 +152,17 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
           body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
         }
       }
-      body << "        *(double *)(ldsb + (aCur + (int)(active ? r0.dstOff : (unsigned)JDUMMYOFF))) = res;\n";
+      body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = res;\n";
     } else {
       // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
       body << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
       for (int k0 = 0; k0 < n; k0 += JIT_MAX_CANDS) {
         const int k1 = std::min(n, k0 + JIT_MAX_CANDS);
         body << "        {\n";
-        for (int k = k0; k < k1; ++k) loadRec(k, "r" + std::to_string(k));
-        if (k0 == 0) body << "        dstOff = r0.dstOff;\n";
+        for (int k = k0; k < k1; ++k) nm[k] = rec(k);
+        if (k0 == 0) body << "        dstOff = " << nm[0] << ".dstOff;\n";
         for (int k = k0; k < k1; ++k)
-          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)r" << k << ".srcOff) + r" << k << ".w;\n";
+          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)" << nm[k] << ".srcOff) + " << nm[k] << ".w;\n";
         body << "        double mx = v" << k0 << ";\n";
         for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
         if (mode == MB_VITERBI) body << "        accM = dmax(accM, mx);\n";
@@ -86,6 +186,7 @@ static std::string generate_source(const mb_machine *m, const MedProgram &P, con
     if (p != std::string::npos) src.replace(p, mark.size(), with);
   };
   replace("/*@DEFS@*/", defs.str());
+  replace("/*@PRE@*/", pre.str());
   replace("/*@BODY@*/", body.str());
   return src;
 }
@@ -103,33 +204,44 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
   }
   if (totalSlots > 20000) return false;
   if (P.roundInfo.size() > 4096) return false;   // keep the generated code within reach of the instruction cache
-  // token-independent records go to LDS when they fit next to the ring
-  const size_t ring = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);
-  const size_t recBytes = P.ldsImageIdx.size() * sizeof(MedRec);
-  J.recsInLds = recBytes > 0 && ring + recBytes + 64 <= 160 * 1024;
-  J.ldsBytes = ring + (J.recsInLds ? recBytes : 0);
-  const std::string src = generate_source(m, P, geo, mode, J.recsInLds);
-  if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
-    if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : ".sum") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
-  }
-  hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "mb_medium_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
-  if (rc != HIPRTC_SUCCESS) {
-    size_t ls = 0;
-    hiprtcGetProgramLogSize(prog, &ls);
-    std::string log(ls, 0);
-    if (ls) hiprtcGetProgramLog(prog, &log[0]);
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
+  std::string code;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    J.ldsBytes = medium_jit_lds_bytes(P, geo);
+    if (J.ldsBytes > 160 * 1024) return false;
+    const std::string src = medium_jit_source(m, P, geo, mode);
+    if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
+      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : ".sum") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+    }
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "mb_medium_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+      size_t ls = 0;
+      hiprtcGetProgramLogSize(prog, &ls);
+      std::string log(ls, 0);
+      if (ls) hiprtcGetProgramLog(prog, &log[0]);
+      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
+      hiprtcDestroyProgram(&prog);
+      return false;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.assign(cs, 0);
+    hiprtcGetCode(prog, &code[0]);
     hiprtcDestroyProgram(&prog);
-    return false;
+    const long long spills = medium_jit_spill_count(code);
+    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : "sum", P.regBudget, spills);
+    if (spills <= 0 || P.regBudget == 0) break;
+    // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
+    // shared by both semirings of this program, so a kernel already built for the other one is dropped.
+    P.regBudget = std::max(0, P.regBudget - std::max(9, (int)spills / 2));
+    medium_jit_plan(m, P, geo);
+    if (!medium_refresh_weights(m, P)) return false;
+    MedJit &O = P.jit[mode == MB_VITERBI ? 0 : 1];
+    if (O.module) (void)hipModuleUnload((hipModule_t)O.module);
+    O = MedJit();
   }
-  size_t cs = 0;
-  hiprtcGetCodeSize(prog, &cs);
-  std::string code(cs, 0);
-  hiprtcGetCode(prog, &code[0]);
-  hiprtcDestroyProgram(&prog);
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;

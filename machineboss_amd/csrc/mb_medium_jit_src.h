@@ -3,11 +3,12 @@
 // The ahead-of-time kernel in mb_medium.hip interprets a compiled program (descriptors + switch on slot counts); its
 // instruction stream is dominated by that interpretation.  Here the same program is unrolled at run time into
 // straight-line HIP for ONE machine and compiled with hiprtc for gfx950: slot counts, record offsets, which LDS vector a
-// candidate reads, the state count and the strip geometry are all literals, token-independent candidate records live in
-// LDS, and the compiler schedules every load of a step ahead of its use.  Semantics are identical to k_medium_tile
+// candidate reads, the state count and the strip geometry are all literals; candidate records that do not change along a
+// column's sweep sit in VGPRs, output-token dependent ones and the sweep's output tokens in LDS (placement: see
+// mb_medium_jit.cpp), so a step issues no global load besides the halo supercell.  Semantics are identical to k_medium_tile
 // (tests run both and compare); if hiprtc is unavailable the engine silently keeps the ahead-of-time kernel.
 //
-// Markers replaced by the generator (mb_medium_jit.cpp):  /*@DEFS@*/  /*@BODY@*/
+// Markers replaced by the generator (mb_medium_jit.cpp):  /*@DEFS@*/  /*@PRE@*/  /*@BODY@*/
 #pragma once
 
 namespace mb {
@@ -48,6 +49,9 @@ __device__ __forceinline__ Rec mk_rec(u32x4 r) {
   Rec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.srcOff = r.z; o.dstOff = r.w; return o;
 }
 __device__ __forceinline__ Rec ld_g(gbytes_t base, unsigned off) { return mk_rec(*(grec_t)(base + off)); }
+__device__ __forceinline__ Rec ld_b(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  return mk_rec(__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0));
+}
 __device__ __forceinline__ Rec ld_l(const char *base, unsigned off) { return mk_rec(*(const u32x4 *)(base + off)); }
 __device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(const double *)(ldsb + off); }
 __device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((float)d * MED_L2E); }
@@ -106,7 +110,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
 
 extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDev P, MedTileArgs A) {
   extern __shared__ double lds[];
-  constexpr int LPG = 64 / JG, S = JS, Spad = JSPAD, NS = JNS, C = JC;
+  constexpr int LPG = 64 / JG, S = JS, Spad = JSPAD, NS = JNS, C = JC, W = JTOKW, NT = JWAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   int pairIdx, a;
@@ -141,12 +145,20 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   };
   auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
   char *ldsRec = (char *)(lds + (long long)NS * (C + 1) * Spad);
+  // output tokens of the sweep, kept in LDS one window of W steps at a time (double buffered): window k holds the
+  // tokens of o in [k*W - C + 1, k*W + W - 1]; the token of column c at step t sits at index (t % W) + (C - 1 - c).
+  int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
+  auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (rev ? out[outLen - o] : out[o - 1]) : 0; };
 
-  for (int j = tid; j < NS * (C + 1) * Spad; j += JWAVES * 64) lds[j] = NEG_INF;
-  {  // token-independent candidate records -> LDS (16 B each)
+  for (int j = tid; j < NS * (C + 1) * Spad; j += NT) lds[j] = NEG_INF;
+  {  // candidate records placed in LDS (16 B each)
     const u32x4 *img = (const u32x4 *)P.ldsImage;
     u32x4 *dst = (u32x4 *)ldsRec;
-    for (int j = tid; j < JLDSRECS; j += JWAVES * 64) dst[j] = img[j];
+    for (int j = tid; j < JLDSRECS; j += NT) dst[j] = img[j];
+  }
+  {
+    const int k0 = t0 / W;
+    for (int j = tid; j < W + C - 1; j += NT) tokWin[(k0 & 1) * (W + C) + j] = tokAt(k0 * W - C + 1 + j);
   }
   __syncthreads();
   for (int dt = 1; dt < NS; ++dt) {
@@ -160,7 +172,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       else if (cc == -1) src = haloIn + (long long)co * S;
       if (!src) continue;
       double *dstp = ring(slot, col);
-      for (int j = tid; j < S; j += JWAVES * 64) dstp[j] = src[j];
+      for (int j = tid; j < S; j += NT) dstp[j] = src[j];
     }
   }
   __syncthreads();
@@ -173,31 +185,38 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const int myColBase = (c + 1) * colStride;
   const unsigned q16 = (unsigned)q * 16u;
   const unsigned itOff16 = (unsigned)(it * LPG + q) * 16u;
+  const __amdgpu_buffer_rsrc_t recRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.rec, 0, 0x7fffffff, 0x00020000);
+  (void)q16; (void)itOff16; (void)grb; (void)recRsrc;
+  // ---- loop-invariant candidate records (placement REG): one load per sweep, kept in VGPRs --------------------------
+/*@PRE@*/
   int slotCur = t0 % NS;
-  int otNext = 0;
-  {
-    const int o = t0 - c;
-    if (colValid && o > 0 && o <= outLen) otNext = rev ? out[outLen - o] : out[o - 1];
-  }
   for (int t = t0; t < t1; ++t) {
     const int o = t - c;
     const bool active = colValid && o >= 0 && o <= outLen;
-    const int ot = otNext;
-    {
-      const int on = o + 1;
-      otNext = (colValid && on > 0 && on <= outLen) ? (rev ? out[outLen - on] : out[on - 1]) : 0;
+    const int kw = t / W, tw = t - kw * W;
+    const int ot = tokWin[(kw & 1) * (W + C) + tw + (C - 1 - c)];
+    // prefetch the next token window (registers now, LDS at the end of the step)
+    int tokPre[JTOKN];
+    const bool wantTok = (tw == 0 || t == t0) && (kw + 1) * W < t1;
+    if (wantTok) {
+#pragma unroll
+      for (int k = 0; k < JTOKN; ++k) {
+        const int j = tid + k * NT;
+        tokPre[k] = (j < W + C - 1) ? tokAt((kw + 1) * W - C + 1 + j) : 0;
+      }
     }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
     const int sCur = slotCur * slotStride, sPrev = slotPrev * slotStride, sPrev2 = slotPrev2 * slotStride;
+    // halo supercell (i0-1, t+1) for the next step.  The load is UNCONDITIONAL (clamped to a valid address when there
+    // is no halo): a conditionally initialised register would make the compiler wait for every outstanding memory
+    // operation -- the previous step's stores included -- before overwriting it.
     double hv[JHALO];
     const bool wantHalo = (i0 > 0) && (t + 1 <= outLen);
-    if (wantHalo) {
-      const double *hs = A.materialise ? cellPtr(i0 - 1, t + 1) : haloIn + (long long)(t + 1) * S;
+    {
+      const int hi = i0 > 0 ? i0 - 1 : 0, ho = min(t + 1, outLen);
+      const double *hs = A.materialise ? cellPtr(hi, ho) : haloIn + (long long)ho * S;
 #pragma unroll
-      for (int k = 0; k < JHALO; ++k) {
-        const int j = tid + k * JWAVES * 64;
-        hv[k] = (j < S) ? hs[j] : 0.0;
-      }
+      for (int k = 0; k < JHALO; ++k) hv[k] = hs[min(tid + k * NT, S - 1)];
     }
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
@@ -211,11 +230,20 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 /*@BODY@*/
     }
     med_wave_sync();
+    // everything loaded from global memory in this step is consumed here, BEFORE the step's global stores are issued:
+    // vmcnt counts loads and stores in order on gfx9, so a wait placed after the stores would wait for them too
+    if (wantTok) {
+#pragma unroll
+      for (int k = 0; k < JTOKN; ++k) {
+        const int j = tid + k * NT;
+        if (j < W + C - 1) tokWin[((kw + 1) & 1) * (W + C) + j] = tokPre[k];
+      }
+    }
     if (wantHalo) {
       double *hd = ring(slotCur, 0);
 #pragma unroll
       for (int k = 0; k < JHALO; ++k) {
-        const int j = tid + k * JWAVES * 64;
+        const int j = tid + k * NT;
         if (j < S) hd[j] = hv[k];
       }
     }
