@@ -127,7 +127,8 @@ int mb_set_memory_budget(size_t bytes);
 int mb_release_workspace(void);
 
 /* Writes the HIP source the run-time code generator produces for this machine (mode MB_FORWARD = sum semiring,
- * MB_VITERBI = max; backward/closure select the program; G = columns per wavefront, 1/2/4/8) to `path`.  Host only:
+ * MB_VITERBI = max, 3 = Forward fused with posterior counts; backward/closure select the program; G = columns per
+ * wavefront, 1/2/4/8) to `path`.  Host only:
  * works without a GPU, so the generated kernel can be inspected / cross-compiled offline. */
 int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                         const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,

@@ -140,6 +140,10 @@ struct FastState {
   // silent closure when it stays small, otherwise the exact program of that direction
   MedProgram fwdExact, fwdSum, bwdSum;
   MedGeom geoFE, geoFS, geoBS;
+  // Forward fill fused with posterior counts (run-time specialised kernel only)
+  bool countOk = false;
+  MedProgram fwdCnt;
+  MedGeom geoCnt;
 };
 
 static int env_int(const char *name, int dflt) {
@@ -172,6 +176,11 @@ static FastState *fast_state(mb_machine *m) {
         if (ok && clos && f->bwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, true, false, G, f->bwdSum, f->geoBS); }
       }
       f->mediumOk = ok;
+      if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
+        int Gc = env_int("MB_MEDIUM_COUNT_G", 0);
+        if (Gc != 1 && Gc != 2 && Gc != 4 && Gc != 8) Gc = G;
+        f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt);
+      }
     }
   }
   return f;
@@ -256,6 +265,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
+    if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
   }
   return 0;
 }
@@ -264,7 +274,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (!m) return;
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
-    medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum);
+    medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt);
     delete f;
   }
   free_machine_device(m);
@@ -497,9 +507,19 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
         maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
       tm.start();
       if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0))) break;
-      if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0))) break;
-      if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
-      if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
+      // fused path: the Forward sweep accumulates the counts while its anti-diagonals are still in LDS
+      int fused = -1;
+      if (use_medium(b->m) && fast_state(b->m)->countOk) {
+        FastState *f = fast_state(b->m);
+        fused = medium_counts_materialised(b->m, f->fwdCnt, f->geoCnt, d_desc, hp, b->d_in, b->d_out, fwd, bwd, d_counts, d_ll + c.p0, g_stream);
+        if (fused > 0) { rc = 1; break; }
+        if (fused == 0) g_last_kernel = "k_medium_jit";
+      }
+      if (fused < 0) {
+        if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0))) break;
+        if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
+        if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
+      }
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
     } while (0);
@@ -558,8 +578,10 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   std::string err;
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
   MedProgram P; MedGeom geo;
-  if (!medium_build_host(&m, backward != 0, closure != 0, G, P, geo)) return 1;
-  const std::string code = medium_jit_source(&m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD);
+  if (mode == MED_MODE_COUNT) {
+    if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
+  } else if (!medium_build_host(&m, backward != 0, closure != 0, G, P, geo)) return 1;
+  const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD));
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
   fprintf(f, "// G=%d C=%d waves=%d ldsBytes=%zu ldsRecs=%zu rounds=%zu\n", G, geo.C, geo.waves, medium_jit_lds_bytes(P, geo),

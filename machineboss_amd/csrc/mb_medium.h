@@ -8,6 +8,7 @@ namespace mb {
 
 constexpr int MED_MAXSLOT = 4;      // candidate slots evaluated together (two-pass max / sum-exp in registers)
 constexpr int MED_DESC_WORDS = 8;   // descriptor words per chunk (32 B, fetched with scalar loads)
+constexpr int MED_MODE_COUNT = 3;   // internal kernel mode: Forward fill (sum) fused with posterior transition counts
 
 // One candidate of one lane: 16 bytes, fetched with a single global_load_dwordx4.
 struct alignas(16) MedRec {
@@ -58,6 +59,9 @@ struct MedJit {                 // one specialised kernel (per program and semir
 struct MedProgram {
   int G = 0, LPG = 0, NS = 0, Spad = 0, nChunks = 0, nRounds = 0;
   bool backward = false, closure = false;
+  bool counting = false;            // Forward fill + posterior counts program: the upper 16 bits of a record's srcOff hold
+                                    // the byte offset of its transition's accumulator in the LDS count array
+  int accEntries = 0;               // counting: nTrans accumulators + LPG dummies (padding candidates, one per lane of a group)
   std::vector<int> desc;
   std::vector<MedRec> rec;
   std::vector<int> wref;            // per record: >= 0 global edge id, -1 padding (-inf), <= -2 closure pair -2-id
@@ -75,7 +79,7 @@ struct MedProgram {
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
-  MedJit jit[2];                        // [MB_FORWARD (sum)], [MB_VITERBI (max)]
+  MedJit jit[3];                        // [MB_FORWARD (sum)], [MB_VITERBI (max)], [MED_MODE_COUNT]
 };
 
 struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
@@ -83,6 +87,15 @@ struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
 bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
 bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
+// exact Forward program whose records also name their transition's count accumulator (see MedProgram::counting)
+bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
+bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
+// Forward fill of the chunk's matrices fused with MachineCounts accumulation (Backward matrices given); needs the
+// run-time specialised kernel: returns -1 (nothing launched) when it is unavailable, 0 ok, 1 error
+int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+                               const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_fwd,
+                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st);
+inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);

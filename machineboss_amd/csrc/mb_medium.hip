@@ -47,6 +47,8 @@ struct MedTileArgs {
   double *loglike;            // loglike[pairBase + blockIdx.y], written when the end cell is finalised (may be null)
   const int2 *tiles;          // materialised mode: (pair, strip) of workgroup tileBase + blockIdx.x
   int C, TS, launch, rev, materialise, tileBase, debugNoStore;
+  const double *poolB;        // count mode (specialised kernel only): Backward matrices, same layout and cellBase as pool
+  double *counts;             // count mode: [nTrans] posterior transition counts, accumulated with fp64 atomics
 };
 
 #define MED_L2E 1.44269504088896f
@@ -638,6 +640,33 @@ bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedPr
   return medium_refresh_weights(m, P);
 }
 
+// Count program = the exact Forward program (one candidate per transition) + the accumulator offset of each
+// candidate's transition packed into the upper half of srcOff.  Geometry leaves room for one Backward supercell per
+// column and the count array in LDS, and keeps the workgroup at 8 wavefronts (256 VGPRs each).
+bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
+  build_program(m, false, false, G, P);
+  P.counting = true; P.accEntries = (int)m->nTrans + P.LPG;   // + one dummy accumulator per lane of a group (padding candidates)
+  if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 16) || (m->nTrans + 64 + 2) * 8 >= (1 << 16)) return false;
+  MedProgDev &d = P.dev;
+  d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
+  d.nIn = m->nIn; d.nOut = m->nOut; d.startNode = 0; d.endNode = m->S - 1;
+  if (!medium_geometry(m, P, geo)) return false;
+  for (size_t k = 0; k < P.rec.size(); ++k) {
+    const long long e = P.wref[k] >= 0 ? P.wref[k] : m->nTrans + (long long)(k % P.LPG);   // padding candidates add 0 to their lane's dummy accumulator
+    P.rec[k].srcOff = (P.rec[k].srcOff & 0xFFFFu) | ((uint32_t)(e * 8) << 16);
+  }
+  medium_jit_plan(m, P, geo);
+  medium_eval_weights(m, P);
+  return true;
+}
+
+bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
+  if (!medium_build_count_host(m, G, P, geo)) return false;
+  if (!up(P.d_desc, P.desc)) return false;
+  P.dev.desc = P.d_desc;
+  return medium_refresh_weights(m, P);
+}
+
 void medium_free(MedProgram &P) {
   medium_jit_free(P);
   void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage};
@@ -647,14 +676,17 @@ void medium_free(MedProgram &P) {
 
 // Geometry: columns per strip limited by the 160 KB LDS of a CU.
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
-  const size_t perCol = (size_t)P.NS * P.Spad * sizeof(double);
+  // count programs keep one Backward supercell per column and the count array next to the ring
+  const size_t perCol = (size_t)(P.NS + (P.counting ? 1 : 0)) * P.Spad * sizeof(double);
   const size_t progBytes = 0;
-  const size_t budget = 160 * 1024 - 512;
+  const size_t fixed = 512 + (P.counting ? (size_t)(m->nTrans + 64 + 2) * sizeof(double) + 1024 : 0);
+  if (fixed + 2 * perCol > 160 * 1024) return false;
+  const size_t budget = 160 * 1024 - fixed;
   long long maxCols = (long long)(budget / perCol) - 1;   // one extra column for the halo
   if (maxCols < P.G) return false;
-  int waves = (int)std::min<long long>(maxCols / P.G, 16);
+  int waves = (int)std::min<long long>(maxCols / P.G, P.counting ? 8 : 16);
   // S must be covered by 4 halo registers per thread
-  while (waves < 16 && (long long)waves * 64 * 4 < m->S) ++waves;
+  while (waves < 16 && (long long)waves * 64 * 4 < m->S && (long long)(waves + 1) * P.G <= maxCols) ++waves;
   if ((long long)waves * 64 * 4 < m->S || (long long)waves * P.G > maxCols) return false;
   geo.waves = waves; geo.C = waves * P.G;
   geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double) + progBytes;
@@ -691,7 +723,8 @@ static void set_lds_attr() {
 // tile (pair, strip a, block b) runs in launch launch0 + 2a + b.  Builds the dense per-launch tile lists.
 static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev &devIn, const MedGeom &geo, int mode, int TS,
                             const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
-                            double *d_pool, double *d_loglike, hipStream_t st) {
+                            double *d_pool, double *d_loglike, hipStream_t st, const double *d_poolB = nullptr,
+                            double *d_counts = nullptr) {
   const int C = geo.C;
   const long long n = (long long)pairs.size();
   int nLaunch = 0;
@@ -719,12 +752,14 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   int2 *d_tiles = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
-  const MedJit *J = medium_jit_get(m, P, geo, mode) ? &P.jit[mode == MB_VITERBI ? 1 : 0] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, mode) ? &P.jit[medium_jit_index(mode)] : nullptr;
+  if (mode == MED_MODE_COUNT && !J) { (void)hipFree(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
+  A.poolB = d_poolB; A.counts = d_counts;
   { const char *e = getenv("MB_DEBUG_NOSTORE"); A.debugNoStore = (e && *e == '1') ? 1 : 0; }
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
@@ -760,6 +795,17 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
   MedProgDev dev = P.dev;
   if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
   return launch_wavefront(m, P, dev, geo, mode, tile_steps(geo.C, pairs.size(), 0), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
+}
+
+int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+                               const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out, double *d_fwd,
+                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st) {
+  if (pairsIn.empty()) return 0;
+  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT)) return -1;
+  std::vector<PairDesc> pairs = pairsIn;
+  for (PairDesc &pd : pairs) pd.launch0 = 0;
+  return launch_wavefront(m, P, P.dev, geo, MED_MODE_COUNT, tile_steps(geo.C, pairs.size(), 0), pairs, d_pairs, d_in, d_out, d_fwd,
+                          d_loglike, st, d_bwd, d_counts);
 }
 
 // Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):

@@ -36,8 +36,13 @@ static int env_int(const char *name, int dflt) {
 static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) { return (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double); }
 static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }
 
+// count programs: one Backward supercell per column + the count accumulators
+static size_t count_bytes(const MedProgram &P, const MedGeom &geo) {
+  return P.counting ? ((size_t)geo.C * P.Spad + (size_t)P.accEntries) * sizeof(double) : 0;
+}
+
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo) {
-  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo);
+  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo);
 }
 
 // Decide where every slot's records live (see the file header).  Deterministic in (program, geometry).
@@ -52,7 +57,7 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
   P.tokWindow = 64;
   const int LPG = P.LPG;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
-  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo);
+  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo);
   int regFree = P.regBudget;                               // VGPRs for loop-invariant records (3 per record, +1 per round)
   if (P.Spad * 8 >= (1 << 16)) regFree = 0;
   for (MedRoundInfo &ri : P.roundInfo) for (MedSlotInfo &sl : ri.slots) { sl.place = MED_PLACE_GLOBAL; sl.ldsOff = 0; }
@@ -108,9 +113,11 @@ long long medium_jit_spill_count(const std::string &code) {
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode) {
   std::ostringstream defs, pre, body;
   const int S = m->S;
+  const bool counting = mode == MED_MODE_COUNT;
   const int threads = geo.waves * 64;
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
-       << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : 0)
+       << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
+       << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
        << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
@@ -139,7 +146,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
     if (n <= JIT_MAX_CANDS) {
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
       for (int k = 0; k < n; ++k)
-        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)" << nm[k] << ".srcOff) + " << nm[k] << ".w;\n";
+        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
       if (n == 1) {
         body << "        const double res = v0;\n";
       } else {
@@ -153,6 +160,10 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         }
       }
       body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = res;\n";
+      if (counting) {   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
+        body << "        const double bl = active ? (med_lds(ldsb, aB + (int)" << nm[0] << ".dstOff) + negLL) : NEG_INF;\n";
+        for (int k = 0; k < n; ++k) body << "        cnt_add(ldsb, accBase + (" << nm[k] << ".srcOff >> 16), v" << k << " + bl);\n";
+      }
     } else {
       // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
       body << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
@@ -162,7 +173,11 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         for (int k = k0; k < k1; ++k) nm[k] = rec(k);
         if (k0 == 0) body << "        dstOff = " << nm[0] << ".dstOff;\n";
         for (int k = k0; k < k1; ++k)
-          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)" << nm[k] << ".srcOff) + " << nm[k] << ".w;\n";
+          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+        if (counting) {
+          body << "        const double bl = active ? (med_lds(ldsb, aB + (int)dstOff) + negLL) : NEG_INF;\n";
+          for (int k = k0; k < k1; ++k) body << "        cnt_add(ldsb, accBase + (" << nm[k] << ".srcOff >> 16), v" << k << " + bl);\n";
+        }
         body << "        double mx = v" << k0 << ";\n";
         for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
         if (mode == MB_VITERBI) body << "        accM = dmax(accM, mx);\n";
@@ -192,8 +207,9 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
 }
 
 bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode) {
-  MedJit &J = P.jit[mode == MB_VITERBI ? 1 : 0];
+  MedJit &J = P.jit[medium_jit_index(mode)];
   if (J.tried) return J.func != nullptr;
+  if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;
   const char *e = getenv("MB_MEDIUM_JIT");
   if (e && *e == '0') return false;
@@ -210,12 +226,12 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
     if (J.ldsBytes > 160 * 1024) return false;
     const std::string src = medium_jit_source(m, P, geo, mode);
     if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
-      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : ".sum") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : ".sum")) + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mb_medium_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
       size_t ls = 0;
       hiprtcGetProgramLogSize(prog, &ls);
@@ -231,16 +247,18 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
     hiprtcGetCode(prog, &code[0]);
     hiprtcDestroyProgram(&prog);
     const long long spills = medium_jit_spill_count(code);
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : "sum", P.regBudget, spills);
+    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : "sum"), P.regBudget, spills);
     if (spills <= 0 || P.regBudget == 0) break;
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.
     P.regBudget = std::max(0, P.regBudget - std::max(9, (int)spills / 2));
     medium_jit_plan(m, P, geo);
     if (!medium_refresh_weights(m, P)) return false;
-    MedJit &O = P.jit[mode == MB_VITERBI ? 0 : 1];
-    if (O.module) (void)hipModuleUnload((hipModule_t)O.module);
-    O = MedJit();
+    for (MedJit &O : P.jit) {
+      if (&O == &J) continue;
+      if (O.module) (void)hipModuleUnload((hipModule_t)O.module);
+      O = MedJit();
+    }
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;

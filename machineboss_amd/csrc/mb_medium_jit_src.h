@@ -37,7 +37,14 @@ struct MedTileArgs {
   double *loglike;
   const int2 *tiles;
   int C, TS, launch, rev, materialise, tileBase, debugNoStore;
+  const double *poolB;
+  double *counts;
 };
+#if JMODE == 2
+#define SRCOFF(x) ((int)((x) & 0xFFFFu))
+#else
+#define SRCOFF(x) ((int)(x))
+#endif
 typedef const __attribute__((address_space(4))) int *cdesc_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef const __attribute__((address_space(1))) u32x4 *grec_t;
@@ -55,6 +62,10 @@ __device__ __forceinline__ Rec ld_b(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, 
 __device__ __forceinline__ Rec ld_l(const char *base, unsigned off) { return mk_rec(*(const u32x4 *)(base + off)); }
 __device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(const double *)(ldsb + off); }
 __device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((float)d * MED_L2E); }
+// count mode: add exp(x) to the LDS accumulator at byte offset off (ds_add_f64; lanes of one column never collide)
+__device__ __forceinline__ void cnt_add(const char *ldsb, unsigned off, double x) {
+  (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)ex2(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void med_block_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
@@ -73,7 +84,7 @@ __device__ __forceinline__ int med_vofs(int vsel, int sCur, int sPrev, int sPrev
 // generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
 __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
                                                 int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
-                                                unsigned seedOff, bool origin, bool lanesOn) {
+                                                unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL) {
   double accM = NEG_INF; float accS = 0.0f;
   for (int ch = 0; ch < nChunks; ++ch) {
     cdesc_t dp = desc + ch * 8;
@@ -92,7 +103,13 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
           accM = seed ? 0.0 : NEG_INF; accS = seed ? 1.0f : 0.0f;
         }
       }
-      const double v = med_lds(ldsb, vecBase + (int)r.srcOff) + r.w;
+      const double v = med_lds(ldsb, vecBase + SRCOFF(r.srcOff)) + r.w;
+#if JMODE == 2
+      {  // every chunk's slot-0 record names the lane's destination state
+        const double bl = (lanesOn && (int)dstOff >= 0) ? (med_lds(ldsb, aB + (int)dstOff) + negLL) : NEG_INF;
+        cnt_add(ldsb, accBase + (r.srcOff >> 16), v + bl);
+      }
+#endif
       if (JMODE == 1) accM = dmax(accM, v);
       else {
         const double nm = dmax(accM, v), gM = (nm == NEG_INF) ? 0.0 : nm;
@@ -148,6 +165,16 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   // output tokens of the sweep, kept in LDS one window of W steps at a time (double buffered): window k holds the
   // tokens of o in [k*W - C + 1, k*W + W - 1]; the token of column c at step t sits at index (t % W) + (C - 1 - c).
   int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
+#if JMODE == 2
+  // count mode: the Backward supercell of every column (this step's) and the count accumulators of the workgroup
+  double *bvec = (double *)(tokWin + 2 * (W + C));
+  double *accL = bvec + (long long)C * Spad;
+  const double *cellsB = A.poolB + pd.cellBase;
+  auto cellPtrB = [&](int ci, int co) -> const double * { return cellsB + ((long long)co * I + ci) * S; };
+  const double bLL = cellsB[0];                                   // BackwardMatrix::logLike() = cell(0,0,start), src/backward.cpp:48-50,66
+  const double negLL = (bLL > NEG_INF) ? -bLL : NEG_INF;          // -inf likelihood: every term becomes exp(-inf) = 0
+  for (int j = tid; j < JNACC; j += NT) accL[j] = 0.0;
+#endif
   auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (rev ? out[outLen - o] : out[o - 1]) : 0; };
 
   for (int j = tid; j < NS * (C + 1) * Spad; j += NT) lds[j] = NEG_INF;
@@ -187,6 +214,20 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const unsigned itOff16 = (unsigned)(it * LPG + q) * 16u;
   const __amdgpu_buffer_rsrc_t recRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.rec, 0, 0x7fffffff, 0x00020000);
   (void)q16; (void)itOff16; (void)grb; (void)recRsrc;
+#if JMODE == 2
+  constexpr int JBV = (S + LPG - 1) / LPG;
+  const int aB = (int)((const char *)bvec - ldsb) + c * colStride;
+  const unsigned accBase = (unsigned)((const char *)accL - ldsb);
+  {  // Backward supercell of the first step
+    const int o0 = min(max(t0 - c, 0), outLen);
+    const double *bs = cellPtrB(min(i, inLen), o0);
+#pragma unroll
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = bs[j]; }
+  }
+#else
+  constexpr int aB = 0; constexpr unsigned accBase = 0; constexpr double negLL = 0.0;
+  (void)aB; (void)accBase; (void)negLL;
+#endif
   // ---- loop-invariant candidate records (placement REG): one load per sweep, kept in VGPRs --------------------------
 /*@PRE@*/
   int slotCur = t0 % NS;
@@ -218,9 +259,18 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #pragma unroll
       for (int k = 0; k < JHALO; ++k) hv[k] = hs[min(tid + k * NT, S - 1)];
     }
+#if JMODE == 2
+    // Backward supercell (i, o+1) of the next step: registers now, LDS after this step's counting (clamped, unconditional)
+    double bpre[JBV];
+    {
+      const double *bs = cellPtrB(min(i, inLen), min(max(o + 1, 0), outLen));
+#pragma unroll
+      for (int k = 0; k < JBV; ++k) bpre[k] = bs[min(k * LPG + q, S - 1)];
+    }
+#endif
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
-                                      P.seedOff, active && i == 0 && o == 0, active);
+                                      P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL);
     } else {
       // LDS byte addresses of the four vectors this lane's column reads / writes
       const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
@@ -239,6 +289,10 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
         if (j < W + C - 1) tokWin[((kw + 1) & 1) * (W + C) + j] = tokPre[k];
       }
     }
+#if JMODE == 2
+#pragma unroll
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = bpre[k]; }
+#endif
     if (wantHalo) {
       double *hd = ring(slotCur, 0);
 #pragma unroll
@@ -265,6 +319,13 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     med_block_sync();
     slotCur = (slotCur + 1) % NS;
   }
+#if JMODE == 2
+  // flush the workgroup's counts: one fp64 atomic per transition that was used in this tile
+  for (int e = tid; e < JNTRANS; e += NT) {
+    const double x = accL[e];
+    if (x != 0.0) (void)__hip_atomic_fetch_add(A.counts + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
 }
 )MBJIT";
 }  // namespace mb

@@ -1,6 +1,6 @@
 """Dump the run-time specialised kernel of a preset and cross-compile it to gfx950 ISA (no GPU needed).
 
-usage: python scripts/jit_dump.py <preset> [mode fwd|vit|bwd] [G] [outdir]
+usage: python scripts/jit_dump.py <preset> [mode fwd|vit|bwd|cnt] [G] [outdir]
 """
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,12 +12,12 @@ out = sys.argv[4] if len(sys.argv) > 4 else "/tmp/jit"
 os.makedirs(out, exist_ok=True)
 m = Machine.fromFile("tests/golden/preset/%s.json" % preset); em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
 src = os.path.join(out, "%s_%s_G%d.hip" % (preset, mode, G))
-capi.debug_jit_source(em, src, mode=capi.MB_VITERBI if mode == "vit" else capi.MB_FORWARD, backward=(mode == "bwd"),
+capi.debug_jit_source(em, src, mode={"vit": capi.MB_VITERBI, "cnt": 3}.get(mode, capi.MB_FORWARD), backward=(mode == "bwd"),
                       closure=(mode != "vit"), G=G)
 full = src.replace(".hip", "_full.hip")
 open(full, "w").write("#include <hip/hip_runtime.h>\n" + open(src).read())
 asm = src.replace(".hip", ".s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "--cuda-device-only",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics", "--cuda-device-only",
                        "-S", "-o", asm, full], stderr=subprocess.DEVNULL)
 print(open(src).readline().strip())
 for line in open(asm):
