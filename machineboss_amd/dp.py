@@ -49,8 +49,89 @@ class MachinePath:
     steps: List[tuple] = field(default_factory=list)   # (srcState, transIndex) per transition
 
 
+class Mt19937:
+    """std::mt19937(seed) as the reference uses it (``generator()`` -> 32-bit unsigned; src/util.h:102-106)."""
+
+    def __init__(self, seed: int = 5489):
+        self._rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+
+    def __call__(self) -> int:
+        return int(self._rs.randint(0, 2 ** 32, dtype=np.uint64))
+
+    @staticmethod
+    def max() -> int:
+        return 0xFFFFFFFF
+
+
+def random_double(rng) -> float:
+    """src/util.h:102-106."""
+    return rng() / (float(rng.max()) + 1.0)
+
+
+def random_index(weights: Sequence[float], rng) -> int:
+    """src/util.h:151-165."""
+    norm = 0.0
+    for w in weights:
+        if not w >= 0:
+            raise MachineError("Negative weights in random_index")
+        norm += w
+    if not norm > 0:
+        raise MachineError("Zero weights in random_index")
+    variate = random_double(rng) * norm
+    for n, w in enumerate(weights):
+        variate -= w
+        if variate <= 0:
+            return n
+    return len(weights)
+
+
+def selectMaxTrans(logWeights: Sequence[float]) -> int:
+    """DPMatrix::selectMaxTrans (src/dpmatrix.defs.h:171-174): index of the FIRST maximum (std::max_element)."""
+    best, bi = None, 0
+    for k, w in enumerate(logWeights):
+        if best is None or w > best:
+            best, bi = w, k
+    return bi
+
+
+def randomTransSelector(rng):
+    """DPMatrix::randomTransSelector (src/dpmatrix.defs.h:176-186)."""
+    return lambda logWeights: random_index([math.exp(lw) for lw in logWeights], rng)
+
+
+class _TransMaps:
+    """The reference's per-state ``incoming`` / ``outgoing`` maps (src/eval.h:59-70) rebuilt on the host from the flat
+    edge arrays: key (state, inTok, outTok) -> [(otherState, transIndex, logWeight)] in multimap order
+    (other state ascending, then insertion order = ascending transIndex, src/eval.cpp:60-61)."""
+
+    def __init__(self, em: EvaluatedMachine):
+        self.incoming: Dict[tuple, list] = {}
+        self.outgoing: Dict[tuple, list] = {}
+        for e in em.incomingOrder():
+            e = int(e)
+            self.incoming.setdefault((int(em.dst[e]), int(em.inTok[e]), int(em.outTok[e])), []).append(
+                (int(em.src[e]), int(em.transIndex[e]), float(em.logWeight[e])))
+        for e in em.outgoingOrder():
+            e = int(e)
+            self.outgoing.setdefault((int(em.src[e]), int(em.inTok[e]), int(em.outTok[e])), []).append(
+                (int(em.dst[e]), int(em.transIndex[e]), float(em.logWeight[e])))
+
+
+def _transMaps(em: EvaluatedMachine) -> _TransMaps:
+    tm = getattr(em, "_transMaps", None)
+    if tm is None:
+        tm = _TransMaps(em)
+        em._transMaps = tm
+    return tm
+
+
 class _DPMatrix:
-    """DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163): full matrix, cell() = -inf outside the lattice."""
+    """DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163): full matrix, cell() = -inf outside the lattice.
+
+    The fill runs on the GPU (mb_fill); the path functions below (traceBack / traceForward and their selectors and
+    terminators, src/dpmatrix.defs.h:61-186) walk the finished matrix on the host exactly as the reference does --
+    they visit O(path length x in-degree) cells and are only used by Machine::downsample / stochasticDownsample and
+    ForwardMatrix::samplePath.  The Viterbi path of a batch (the hot use) is traced on the device instead."""
     _mode = capi.MB_FORWARD
 
     def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, startState: int = 0):
@@ -75,6 +156,114 @@ class _DPMatrix:
     def cells(self) -> np.ndarray:
         return self._cells
 
+    # ---- DPMatrix::writeJson (src/dpmatrix.defs.h:39-53): every cell at setprecision(5), input position outermost ----
+    def writeJson(self) -> str:
+        import json as _json
+        rows = []
+        for i in range(self.inLen + 1):
+            for o in range(self.outLen + 1):
+                for s in range(self.nStates):
+                    v = self.cell(i, o, s)
+                    txt = ("%.5g" % v) if math.isfinite(v) else ("-inf" if v < 0 else "inf")
+                    rows.append('  { "inPos": %d, "outPos": %d, "state": %s, "logLike": %s }'
+                                % (i, o, _json.dumps(self.machine.stateNames[s], separators=(",", ":")), txt))
+        return ('{\n "input": "%s",\n "output": "%s",\n "cell": [\n' % (self.seqPair.inputName, self.seqPair.outputName)
+                + ",\n".join(rows) + "\n ]\n}\n")
+
+    # ---- DPMatrix::pathIterate (src/dpmatrix.h:111-119): candidates of one label group, in multimap order ----------
+    def _pathIterate(self, tmap: Dict[tuple, list], state: int, inTok: int, outTok: int, inPos: int, outPos: int,
+                     states: list, transIndex: list, loglike: list):
+        for other, ti, lw in tmap.get((state, inTok, outTok), ()):
+            states.append(other); transIndex.append(ti); loglike.append(self.cell(inPos, outPos, other) + lw)
+
+    # ---- traceBack (src/dpmatrix.defs.h:61-110) ------------------------------------------------------------------
+    def traceBackFrom(self, m: Machine, inPos: int, outPos: int, s: int, stopTrace, selectTrans=selectMaxTrans) -> None:
+        """The TraceTerminator overload: honours its position arguments; stopTrace(inPos,outPos,src,transIndex)->bool."""
+        if not (self.cell(inPos, outPos, s) > -math.inf):
+            raise MachineError("Can't do traceback: no finite-weight paths")
+        inc = _transMaps(self.machine).incoming
+        while inPos > 0 or outPos > 0 or s != 0:
+            loglike: list = []; source: list = []; tidx: list = []
+            inTok = int(self.input[inPos - 1]) if inPos else 0
+            outTok = int(self.output[outPos - 1]) if outPos else 0
+            if inPos and outPos:
+                self._pathIterate(inc, s, inTok, outTok, inPos - 1, outPos - 1, source, tidx, loglike)
+            if inPos:
+                self._pathIterate(inc, s, inTok, 0, inPos - 1, outPos, source, tidx, loglike)
+            if outPos:
+                self._pathIterate(inc, s, 0, outTok, inPos, outPos - 1, source, tidx, loglike)
+            self._pathIterate(inc, s, 0, 0, inPos, outPos, source, tidx, loglike)
+            if not loglike:   # the reference would index an empty vector here (undefined behaviour)
+                raise MachineError("Traceback reached a cell without incoming transitions")
+            best = selectTrans(loglike)
+            bestSource, bestTi = source[best], tidx[best]
+            bestTrans = m.state[bestSource].getTransition(bestTi)
+            if bestTrans.inp:
+                inPos -= 1
+            if bestTrans.out:
+                outPos -= 1
+            s = bestSource
+            if stopTrace(inPos, outPos, s, bestTi):
+                break
+
+    def traceBack(self, m: Machine, s: Optional[int] = None, selectTrans=selectMaxTrans) -> MachinePath:
+        """The MachinePath overloads.  Like the reference's 5-argument overload they always start at
+        (inLen, outLen) -- src/dpmatrix.defs.h:72-80 ignores its position arguments."""
+        path = MachinePath()
+
+        def stop(ip, op, src, ti):
+            path.trans.insert(0, m.state[src].getTransition(ti)); path.steps.insert(0, (src, ti))
+            return False
+        self.traceBackFrom(m, self.inLen, self.outLen, self.nStates - 1 if s is None else s, stop, selectTrans)
+        return path
+
+    # ---- traceForward (src/dpmatrix.defs.h:112-159) --------------------------------------------------------------
+    def traceForwardFrom(self, m: Machine, inPos: int, outPos: int, s: int, stopTrace, selectTrans=selectMaxTrans) -> None:
+        if not (self.cell(inPos, outPos, s) > -math.inf):
+            raise MachineError("Can't do traceforward: no finite-weight paths")
+        outg = _transMaps(self.machine).outgoing
+        while inPos < self.inLen or outPos < self.outLen or s != self.nStates - 1:
+            loglike: list = []; dest: list = []; tidx: list = []
+            endIn, endOut = inPos == self.inLen, outPos == self.outLen
+            inTok = 0 if endIn else int(self.input[inPos])
+            outTok = 0 if endOut else int(self.output[outPos])
+            if not endIn and not endOut:
+                self._pathIterate(outg, s, inTok, outTok, inPos + 1, outPos + 1, dest, tidx, loglike)
+            if not endIn:
+                self._pathIterate(outg, s, inTok, 0, inPos + 1, outPos, dest, tidx, loglike)
+            if not endOut:
+                self._pathIterate(outg, s, 0, outTok, inPos, outPos + 1, dest, tidx, loglike)
+            self._pathIterate(outg, s, 0, 0, inPos, outPos, dest, tidx, loglike)
+            if not loglike:
+                raise MachineError("Traceforward reached a cell without outgoing transitions")
+            best = selectTrans(loglike)
+            bestDest, bestTi = dest[best], tidx[best]
+            if stopTrace(inPos, outPos, s, bestTi):
+                break
+            bestTrans = m.state[s].getTransition(bestTi)
+            if bestTrans.dest != bestDest:
+                raise MachineError("Traceforward error")
+            if bestTrans.inp:
+                inPos += 1
+            if bestTrans.out:
+                outPos += 1
+            s = bestDest
+
+    def traceForward(self, m: Machine, inPos: Optional[int] = None, outPos: int = 0, s: int = 0,
+                     selectTrans=selectMaxTrans) -> MachinePath:
+        """MachinePath overloads, quirks kept: without a position this is ``traceBack(m,0,0,0,...)`` --
+        a traceback from state 0 (src/dpmatrix.defs.h:112-115); with one, the walk still starts at (inLen, outLen)
+        (:118-126)."""
+        if inPos is None:
+            return self.traceBack(m, 0, selectTrans)
+        path = MachinePath()
+
+        def stop(ip, op, src, ti):
+            path.trans.append(m.state[src].getTransition(ti)); path.steps.append((src, ti))
+            return False
+        self.traceForwardFrom(m, self.inLen, self.outLen, s, stop, selectTrans)
+        return path
+
 
 class ForwardMatrix(_DPMatrix):
     """src/forward.h:19-27."""
@@ -83,13 +272,85 @@ class ForwardMatrix(_DPMatrix):
     def logLike(self) -> float:
         return self.endCell()
 
+    def samplePath(self, m: Machine, rng, s: Optional[int] = None) -> MachinePath:
+        """Stochastic traceback with exp(candidate) weights (src/forward.cpp:17-23)."""
+        return self.traceBack(m, s, randomTransSelector(rng))
+
+
+@dataclass(order=True)
+class PostTrans:
+    """BackwardMatrix::PostTrans (src/backward.h:20-27): ordered by posterior weight."""
+    weight: float
+    inPos: int = field(compare=False)
+    outPos: int = field(compare=False)
+    src: int = field(compare=False)
+    transIndex: int = field(compare=False)
+
 
 class BackwardMatrix(_DPMatrix):
-    """src/backward.h:44-59 (fill + logLike; getCounts is served by MachineCounts on the device)."""
+    """src/backward.h:44-59.  MachineCounts runs the count sweep on the device for whole batches; the visitor forms
+    here (getCounts with a callback, postTransQueue, traceFrom) serve Machine::downsample and walk the two host
+    copies of the matrices like the reference (src/backward.cpp:52-108)."""
     _mode = capi.MB_BACKWARD
 
     def logLike(self) -> float:
         return self.startCell()
+
+    def getCounts(self, forward: "ForwardMatrix", visit) -> None:
+        """visit(src, transIndex, inPos, outPos, postProb) for every cell and outgoing edge, in the reference's order
+        (src/backward.cpp:62-87); ``visit`` may also be a MachineCounts, whose flat count vector is then updated."""
+        if isinstance(visit, MachineCounts):
+            mc = visit
+            off = self.machine.transOffset
+
+            def visit(s, ti, ip, op, pp):   # BackwardMatrix::transitionCounter
+                mc._flat[off[s] + ti] += pp
+        outg = _transMaps(self.machine).outgoing
+        ll = self.logLike()
+        for outPos in range(self.outLen, -1, -1):
+            endOut = outPos == self.outLen
+            outTok = 0 if endOut else int(self.output[outPos])
+            for inPos in range(self.inLen, -1, -1):
+                endIn = inPos == self.inLen
+                inTok = 0 if endIn else int(self.input[inPos])
+                for s in range(self.nStates - 1, -1, -1):
+                    logOdds = forward.cell(inPos, outPos, s) - ll
+                    groups = []
+                    if not endIn and not endOut:
+                        groups.append((inTok, outTok, inPos + 1, outPos + 1))
+                    if not endIn:
+                        groups.append((inTok, 0, inPos + 1, outPos))
+                    if not endOut:
+                        groups.append((0, outTok, inPos, outPos + 1))
+                    groups.append((0, 0, inPos, outPos))
+                    for it, ot, ip, op in groups:
+                        for dest, ti, lw in outg.get((s, it, ot), ()):
+                            visit(s, ti, ip, op, math.exp(logOdds + self.cell(ip, op, dest) + lw))
+
+    def postTransQueue(self, forward: "ForwardMatrix") -> List[PostTrans]:
+        """All posterior transition usages as a max-heap ordered list, largest weight first (src/backward.cpp:52-56).
+        Returned sorted descending; ``pop(0)`` is priority_queue::top()+pop()."""
+        q: List[PostTrans] = []
+        self.getCounts(forward, lambda s, ti, ip, op, pp: q.append(PostTrans(pp, ip, op, s, ti)))
+        q.sort(key=lambda pt: -pt.weight)
+        return q
+
+    def traceFrom(self, m: Machine, forward: "ForwardMatrix", inPos: int, outPos: int, state: int,
+                  transIndex: Optional[int] = None, stopTrace=None):
+        """src/backward.cpp:89-108.  With ``stopTrace`` it is the terminator overload (returns None); otherwise the
+        concatenated MachinePath through (state[, transIndex])."""
+        if stopTrace is not None:
+            if not stopTrace(inPos, outPos, state, transIndex):
+                forward.traceBackFrom(m, inPos, outPos, state, stopTrace)
+                mt = m.state[state].getTransition(transIndex)
+                self.traceForwardFrom(m, inPos + (1 if mt.inp else 0), outPos + (1 if mt.out else 0), mt.dest, stopTrace)
+            return None
+        path = forward.traceBack(m, state)            # MachinePath overloads: quirk Q2, see traceBack
+        if transIndex is not None:
+            path.trans.append(m.state[state].getTransition(transIndex)); path.steps.append((state, transIndex))
+        fwd = self.traceForward(m, inPos, outPos, state)
+        path.trans += fwd.trans; path.steps += fwd.steps
+        return path
 
 
 class ViterbiMatrix(_DPMatrix):

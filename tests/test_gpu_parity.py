@@ -338,3 +338,97 @@ def test_cxx_facade(capi, tmp_path):
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "FACADE OK" in out.stdout, out.stdout + out.stderr
+
+
+# ---- host-side path functions over device-filled matrices ------
+def _check_path(em, m, path, x, y, startState=0, endState=None):
+    """A MachinePath must be contiguous, start/end at the right states and spell both sequences."""
+    s = startState; ins = []; outs = []
+    for (src, ti), tr in zip(path.steps, path.trans):
+        assert src == s and m.state[src].getTransition(ti) is tr
+        if tr.inp: ins.append(tr.inp)
+        if tr.out: outs.append(tr.out)
+        s = tr.dest
+    assert s == (em.nStates - 1 if endState is None else endState)
+    assert list(em.inputTokenizer.tokenize(ins)) == list(x) and list(em.outputTokenizer.tokenize(outs)) == list(y)
+
+
+def test_write_json_matches_reference_text(capi, machines):
+    """DPMatrix::writeJson (src/dpmatrix.defs.h:39-53) reproduces the reference's golden matrix dumps byte for byte."""
+    from machineboss_amd.dp import ForwardMatrix, BackwardMatrix, SeqPair
+    m, em = machines("bitnoise", load_json("io", "params.json"))
+    sp = SeqPair.fromJson(load_json("io", "tiny.json"))
+    assert ForwardMatrix(em, sp).writeJson() == open(golden_path("expect", "fwd-bitnoise-params-tiny.json")).read()
+    assert BackwardMatrix(em, sp).writeJson() == open(golden_path("expect", "back-bitnoise-params-tiny.json")).read()
+
+
+@pytest.mark.parametrize("name,il,ol", [("dnapsw", 14, 11), ("bitstutter-noise", 4, 7), ("psw2dna", 4, 13)])
+def test_host_traceback_equals_device_traceback(capi, machines, name, il, ol):
+    """DPMatrix::traceBack with selectMaxTrans, walked on the host over the device-filled matrix, is the same path the
+    device traceback kernel returns (both follow src/dpmatrix.defs.h:82-110 incl. the first-maximum tie-break)."""
+    from machineboss_amd.dp import ViterbiMatrix, SeqPair
+    preset = name != "bitstutter-noise"
+    m, em = machines(name, None if preset else load_json("io", "params.json"), useDefaults=preset, preset=preset)
+    x, y = synth_tokens(9, il, ol, em.nInTok, em.nOutTok)
+    sp = SeqPair(em.inputTokenizer.detokenize(x), em.outputTokenizer.detokenize(y))
+    vit = ViterbiMatrix(em, sp)
+    dev, host = vit.path(m), vit.traceBack(m)
+    assert dev.steps == host.steps and len(host.steps) > 0
+    _check_path(em, m, host, x, y)
+
+
+def test_sample_path_and_trace_forward(capi, machines):
+    """ForwardMatrix::samplePath (src/forward.cpp:17-23) and traceForward over a Backward matrix (dpmatrix.defs.h:128-159):
+    valid paths, deterministic in the mt19937 seed, sampled in proportion to exp(candidate)."""
+    from machineboss_amd.dp import ForwardMatrix, BackwardMatrix, SeqPair, Mt19937, randomTransSelector
+    m, em = machines("bitstutter-noise", load_json("io", "params.json"))
+    sp = SeqPair(list("101"), list("10011"))
+    fwd, back = ForwardMatrix(em, sp), BackwardMatrix(em, sp)
+    x, y = fwd.input, fwd.output
+    paths = [fwd.samplePath(m, Mt19937(seed)) for seed in (1, 1, 2, 3, 4, 5)]
+    for p in paths:
+        _check_path(em, m, p, x, y)
+    assert paths[0].steps == paths[1].steps
+    # many alignments of similar weight under uniform parameters: different seeds must give different samples
+    md, emd = machines("dnapsw", None, useDefaults=True, preset=True)
+    xd, yd = synth_tokens(3, 8, 8, 4, 4)
+    fd = ForwardMatrix(emd, SeqPair(emd.inputTokenizer.detokenize(xd), emd.outputTokenizer.detokenize(yd)))
+    pd_ = [fd.samplePath(md, Mt19937(seed)) for seed in range(1, 9)]
+    for p in pd_:
+        _check_path(emd, md, p, xd, yd)
+    assert len({tuple(p.steps) for p in pd_}) > 1
+    # forward walk over the Backward matrix from the start cell (the TraceTerminator overload honours its position)
+    steps = []
+    back.traceForwardFrom(m, 0, 0, 0, lambda ip, op, s, ti: steps.append((s, ti)) or False)
+    from machineboss_amd.dp import MachinePath
+    p = MachinePath([m.state[s].getTransition(ti) for s, ti in steps], steps)
+    _check_path(em, m, p, x, y)
+
+
+def test_backward_visitors_match_device_counts(capi, machines):
+    """BackwardMatrix::getCounts visitor / postTransQueue / traceFrom (src/backward.cpp:52-108) on the host agree with
+    the device count sweep (MachineCounts)."""
+    from machineboss_amd.dp import ForwardMatrix, BackwardMatrix, MachineCounts, SeqPair
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    x, y = synth_tokens(21, 9, 12, em.nInTok, em.nOutTok)
+    sp = SeqPair(em.inputTokenizer.detokenize(x), em.outputTokenizer.detokenize(y))
+    fwd, back = ForwardMatrix(em, sp), BackwardMatrix(em, sp)
+    dev = MachineCounts(em, [sp])
+    host = MachineCounts(em)
+    back.getCounts(fwd, host)
+    assert close(host._flat, dev._flat, 1e-5, 1e-7)
+    q = back.postTransQueue(fwd)
+    assert all(q[k].weight >= q[k + 1].weight for k in range(len(q) - 1))
+    per_edge = np.zeros(em.nTransitions)
+    for pt in q:
+        per_edge[em.transOffset[pt.src] + pt.transIndex] += pt.weight
+    assert close(per_edge, host._flat, 1e-12, 1e-15)
+    # path through the most probable transition usage: terminator overload visits a contiguous start->end path
+    top = q[0]
+    seen = []
+    back.traceFrom(m, fwd, top.inPos, top.outPos, top.src, top.transIndex, lambda ip, op, s, ti: seen.append((ip, op, s, ti)) or False)
+    assert (top.inPos, top.outPos, top.src, top.transIndex) in seen
+    used = sorted(set((s, ti) for _, _, s, ti in seen))
+    emitted_in = sum(1 for s, ti in [(a[2], a[3]) for a in seen] if m.state[s].getTransition(ti).inp)
+    emitted_out = sum(1 for s, ti in [(a[2], a[3]) for a in seen] if m.state[s].getTransition(ti).out)
+    assert emitted_in == len(x) and emitted_out == len(y) and len(used) > 0
