@@ -159,7 +159,7 @@ static FastState *fast_state(mb_machine *m) {
     // tiny machines run with 8 columns per wavefront (8 lanes per supercell); 1-state machines stay generic
     if (m->S >= env_int("MB_MEDIUM_MIN_STATES", 2) && m->S <= 4096) {
       int G = env_int("MB_MEDIUM_G", 0);
-      if (G != 1 && G != 2 && G != 4 && G != 8) G = m->S >= 1024 ? 1 : (m->S >= 128 ? 2 : (m->S >= 48 ? 4 : 8));   // measured on psw2dna (271 states): G=2 > 4 > 1
+      if (!medium_valid_G(G)) G = medium_default_G(m->S);
       f->G = G;
       long long nSilent = 0;
       for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
@@ -178,7 +178,7 @@ static FastState *fast_state(mb_machine *m) {
       f->mediumOk = ok;
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
         int Gc = env_int("MB_MEDIUM_COUNT_G", 0);
-        if (Gc != 1 && Gc != 2 && Gc != 4 && Gc != 8) Gc = G;
+        if (!medium_valid_G(Gc)) Gc = env_int("MB_MEDIUM_G", 0) ? G : medium_default_count_G(m->S);
         f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt);
       }
     }
@@ -569,7 +569,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
                         const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int closure,
                         int G, const char *path) {
   if (nStates <= 0 || nTrans < 0 || !path) { set_error("mb_debug_jit_source: bad argument"); return 1; }
-  if (G != 1 && G != 2 && G != 4 && G != 8) { set_error("mb_debug_jit_source: G must be 1, 2, 4 or 8"); return 1; }
+  if (!medium_valid_G(G)) { set_error("mb_debug_jit_source: G must be a power of two in 1..64"); return 1; }
   mb_machine m;
   m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
   m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);

@@ -95,6 +95,13 @@ bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo)
 int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                                const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_fwd,
                                const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st);
+// G = columns (supercells) per wavefront, LPG = 64 / G lanes per supercell.  G = 64 is "one lane per supercell": the
+// mapping for machines with a handful of states (dnapsw, protpsw: 8 states).
+inline bool medium_valid_G(int G) { return G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
+inline int medium_default_G(int S) {   // measured with the specialised kernel: psw2dna (271 states) G=4 (8 wavefronts x 256 VGPRs) >= 2 > 1
+  return S >= 1024 ? 1 : (S >= 512 ? 2 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32)));   // dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
+}
+inline int medium_default_count_G(int S) { return S >= 24 ? medium_default_G(S) : 16; }   // LDS count atomics collide across the lanes of a wavefront that share a transition
 inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);

@@ -220,15 +220,14 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
   for (int dt = 1; dt < NS; ++dt) {
     const int tp = t0 - dt;
     const int slot = ((tp % NS) + NS) % NS;
-    for (int col = 0; col <= C; ++col) {
+    for (int idx = tid; idx < (C + 1) * S; idx += blockDim.x) {   // flat over (column, state)
+      const int col = idx / S, j = idx - col * S;
       const int cc = col - 1, ci = i0 + cc, co = tp - cc;
       if (ci < 0 || ci > inLen || co < 0 || co > outLen) continue;
       const double *src = nullptr;
       if (A.materialise) src = cellPtr(ci, co);
       else if (cc == -1) src = haloIn + (long long)co * S;
-      if (!src) continue;
-      double *dstp = ring(slot, col);
-      for (int j = tid; j < S; j += blockDim.x) dstp[j] = src[j];
+      if (src) ring(slot, col)[j] = src[j];
     }
   }
   __syncthreads();
@@ -459,7 +458,11 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
       }
     }
   }
-  P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;   // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to; even
+  // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to.  Even length keeps every column 16-byte
+  // aligned; with one or two lanes per supercell the lanes of a wavefront read DIFFERENT columns at the same state
+  // offset, and an odd length (stride of 2 x odd LDS banks) makes those reads conflict-free.
+  P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;
+  if (LPG <= 2) P.Spad |= 1;
   P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
   const int nStages = closure ? 2 : nLev;
 
@@ -706,7 +709,10 @@ static void launch_tile(int G, dim3 grid, dim3 block, size_t ldsBytes, hipStream
     case 1: hipLaunchKernelGGL((k_medium_tile<MODE, 1>), grid, block, ldsBytes, st, P, A); break;
     case 2: hipLaunchKernelGGL((k_medium_tile<MODE, 2>), grid, block, ldsBytes, st, P, A); break;
     case 4: hipLaunchKernelGGL((k_medium_tile<MODE, 4>), grid, block, ldsBytes, st, P, A); break;
-    default: hipLaunchKernelGGL((k_medium_tile<MODE, 8>), grid, block, ldsBytes, st, P, A); break;
+    case 8: hipLaunchKernelGGL((k_medium_tile<MODE, 8>), grid, block, ldsBytes, st, P, A); break;
+    case 16: hipLaunchKernelGGL((k_medium_tile<MODE, 16>), grid, block, ldsBytes, st, P, A); break;
+    case 32: hipLaunchKernelGGL((k_medium_tile<MODE, 32>), grid, block, ldsBytes, st, P, A); break;
+    default: hipLaunchKernelGGL((k_medium_tile<MODE, 64>), grid, block, ldsBytes, st, P, A); break;
   }
 }
 
@@ -714,7 +720,8 @@ static bool g_attr_set = false;
 static void set_lds_attr() {
   if (g_attr_set) return;
 #define SET(M, GG) (void)hipFuncSetAttribute((const void *)k_medium_tile<M, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  SET(0, 1); SET(0, 2); SET(0, 4); SET(0, 8); SET(1, 1); SET(1, 2); SET(1, 4); SET(1, 8);
+  SET(0, 1); SET(0, 2); SET(0, 4); SET(0, 8); SET(0, 16); SET(0, 32); SET(0, 64);
+  SET(1, 1); SET(1, 2); SET(1, 4); SET(1, 8); SET(1, 16); SET(1, 32); SET(1, 64);
 #undef SET
   g_attr_set = true;
 }

@@ -33,7 +33,9 @@ static int env_int(const char *name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) { return (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double); }
+static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) {   // rounded up to 16 bytes: the record image follows
+  return ((((size_t)P.NS * (geo.C + 1) * P.Spad + 1) & ~(size_t)1)) * sizeof(double);
+}
 static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }
 
 // count programs: one Backward supercell per column + the count accumulators
@@ -117,6 +119,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   const int threads = geo.waves * 64;
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
+       << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
        << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow

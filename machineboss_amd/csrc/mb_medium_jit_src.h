@@ -81,6 +81,24 @@ __device__ __forceinline__ int med_vofs(int vsel, int sCur, int sPrev, int sPrev
   return slotOff - (vsel < 2 ? colStride : 0);
 }
 
+// finished supercell: LDS -> global, the LPG lanes of the column side by side.  JSTORE2: 16 bytes per lane and store
+// (global_store_dwordx4; the destination is only 8-byte aligned when the state count is odd, which global memory allows)
+typedef double d2a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void med_copy_out(double *dstp, const double *cur, int q) {
+  constexpr int LPG = 64 / JG, S = JS;
+#if JSTORE2
+#pragma unroll
+  for (int j0 = 0; 2 * j0 < S; j0 += LPG) {
+    const int j = 2 * (j0 + q);
+    if (j + 1 < S) { d2a8 v; v.x = cur[j]; v.y = cur[j + 1]; *(d2a8 *)(dstp + j) = v; }
+    else if (j < S) dstp[j] = cur[j];
+  }
+#else
+#pragma unroll
+  for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }
+#endif
+}
+
 // generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
 __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
                                                 int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
@@ -161,7 +179,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     return cells + (ro * I + ri) * S;
   };
   auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
-  char *ldsRec = (char *)(lds + (long long)NS * (C + 1) * Spad);
+  char *ldsRec = (char *)(lds + (((long long)NS * (C + 1) * Spad + 1) & ~1ll));   // 16-byte aligned
   // output tokens of the sweep, kept in LDS one window of W steps at a time (double buffered): window k holds the
   // tokens of o in [k*W - C + 1, k*W + W - 1]; the token of column c at step t sits at index (t % W) + (C - 1 - c).
   int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
@@ -188,18 +206,19 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     for (int j = tid; j < W + C - 1; j += NT) tokWin[(k0 & 1) * (W + C) + j] = tokAt(k0 * W - C + 1 + j);
   }
   __syncthreads();
+  // ring state of steps t0-1 (and t0-2 when match edges exist); flat index over (column, state) so that machines with
+  // few states still use every thread
   for (int dt = 1; dt < NS; ++dt) {
     const int tp = t0 - dt;
     const int slot = ((tp % NS) + NS) % NS;
-    for (int col = 0; col <= C; ++col) {
+    for (int idx = tid; idx < (C + 1) * S; idx += NT) {
+      const int col = idx / S, j = idx - col * S;
       const int cc = col - 1, ci = i0 + cc, co = tp - cc;
       if (ci < 0 || ci > inLen || co < 0 || co > outLen) continue;
       const double *src = nullptr;
       if (A.materialise) src = cellPtr(ci, co);
       else if (cc == -1) src = haloIn + (long long)co * S;
-      if (!src) continue;
-      double *dstp = ring(slot, col);
-      for (int j = tid; j < S; j += NT) dstp[j] = src[j];
+      if (src) ring(slot, col)[j] = src[j];
     }
   }
   __syncthreads();
@@ -305,14 +324,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     if (active) {
       if (A.materialise) {
         double *dstp = cellPtr(i, o);
-        if (!A.debugNoStore || c == C - 1) {
-#pragma unroll
-          for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }
-        }
+        if (!A.debugNoStore || c == C - 1) med_copy_out(dstp, cur, q);
       } else if (c == C - 1) {
-        double *dstp = haloOut + (long long)o * S;
-#pragma unroll
-        for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }
+        med_copy_out(haloOut + (long long)o * S, cur, q);
       }
       if (i == inLen && o == outLen && q == 0 && A.loglike) A.loglike[pairIdx] = cur[JENDNODE];
     }
