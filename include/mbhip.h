@@ -16,8 +16,12 @@
  *    which EvaluatedMachine::init visits them (src/eval.cpp:47-69).  counts[] and Viterbi paths use these ids.
  *  - matrices use the reference's IdentityIndexMapper layout with a full envelope (src/dpmatrix.h:34-44,90-96):
  *        cell(inPos,outPos,state) = cells[((outPos*(inLen+1)) + inPos)*nStates + state]      (double)
- *  - only full envelopes are supported in this round (the reference ignores the Envelope argument of the
- *    3-argument DPMatrix constructor, src/dpmatrix.defs.h:16-17; path envelopes of aligned SeqPairs are "next").
+ *  - envelopes (src/seqpair.h:75-97) restrict the cells that exist: mb_batch_set_envelopes / mb_fill_env.  The matrix
+ *    handed back is still the full rectangle; cells outside the envelope hold -inf, which is what the reference's
+ *    const cell() accessor returns for them (src/dpmatrix.h:142-144).  Note the reference's 3-argument DPMatrix
+ *    constructor ignores its Envelope argument and uses Envelope(seqPair): the alignment's path envelope if the pair
+ *    carries an alignment, else the full one (src/dpmatrix.defs.h:16-17, src/seqpair.cpp:104-110) -- the host shims
+ *    (mb_dp.hpp, dp.py) reproduce that choice.
  */
 #ifndef MBHIP_H_INCLUDED
 #define MBHIP_H_INCLUDED
@@ -77,7 +81,12 @@ int mb_machine_edge_order(const mb_machine *m, int which, uint32_t *out);
 mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
                           const int32_t *outTok, const int64_t *outOff);
 void mb_batch_destroy(mb_batch *b);
-int64_t mb_batch_cells(const mb_batch *b); /* sum over pairs of (inLen+1)(outLen+1)nStates */
+int64_t mb_batch_cells(const mb_batch *b);
+/* Envelopes of the pairs (Envelope::inStart / inEnd, src/seqpair.h:75-97): pair p owns rows envOff[p]..envOff[p+1] of
+ * inStart[] / inEnd[] -- either outLen+1 rows (cell (x,y) exists <=> inStart[y] <= x < inEnd[y]) or none (full).
+ * Rejected like DPMatrix::alloc does (src/dpmatrix.defs.h:31-32): "Envelope/sequence mismatch", "Envelope is not
+ * connected".  Batches with a restricted envelope run on the generic kernel family. */
+int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *inStart, const int32_t *inEnd); /* sum over pairs of (inLen+1)(outLen+1)nStates */
 
 /* Forward log-likelihoods, loglike[nPairs] (-inf allowed).
  * MB_MATERIALISE = ForwardMatrix(eval, sp).logLike()             src/forward.defs.h:23-55, src/api.cpp:32-35
@@ -105,6 +114,10 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
  * cellsOut[(inLen+1)*(outLen+1)*nStates]. */
 int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
             int32_t startState, double *cellsOut);
+
+/* mb_fill with an envelope (envStart/envEnd: outLen+1 entries each, or both NULL for the full envelope). */
+int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
+                int32_t startState, const int32_t *envStart, const int32_t *envEnd, double *cellsOut);
 
 /* ---- convenience wrappers over host buffers (create batch, run, destroy) ----------------------------------
  * forwardLogLike / viterbiLogLike+viterbiAlign / forwardBackwardCounts of src/api.h:20-34.                   */

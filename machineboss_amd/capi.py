@@ -25,6 +25,7 @@ EXPORTS = [
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source",
+    "mb_batch_set_envelopes", "mb_fill_env",
 ]
 
 _lib = None
@@ -73,6 +74,8 @@ def load():
     L.mb_counts_batch.argtypes = [vp, C.c_int64, i32p, i64p, i32p, i64p, dp, dp, dp]
     L.mb_set_kernel.argtypes = [C.c_int]
     L.mb_set_memory_budget.argtypes = [C.c_size_t]
+    L.mb_batch_set_envelopes.argtypes = [vp, i64p, i32p, i32p]
+    L.mb_fill_env.argtypes = [vp, C.c_int, i32p, C.c_int64, i32p, C.c_int64, C.c_int32, i32p, i32p, dp]
     L.mb_debug_jit_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     _lib = L
@@ -165,11 +168,15 @@ class DeviceMachine:
         _check(load().mb_machine_edge_order(self.h, which, _p(o, C.c_uint32)))
         return o
 
-    def fill(self, mode: int, inp, out, startState: int = 0) -> np.ndarray:
-        """Full matrix [outLen+1][inLen+1][nStates] (DPMatrix cell storage, src/dpmatrix.h:90-96)."""
+    def fill(self, mode: int, inp, out, startState: int = 0, envStart=None, envEnd=None) -> np.ndarray:
+        """Full matrix [outLen+1][inLen+1][nStates] (DPMatrix cell storage, src/dpmatrix.h:90-96); with an envelope
+        (inStart[o], inEnd[o] per output position) the cells outside it are -inf."""
         i = np.ascontiguousarray(inp, np.int32); o = np.ascontiguousarray(out, np.int32)
         cells = np.empty((len(o) + 1, len(i) + 1, self.nStates), np.float64)
-        _check(load().mb_fill(self.h, mode, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), startState, _p(cells, C.c_double)))
+        es = None if envStart is None else np.ascontiguousarray(envStart, np.int32)
+        ee = None if envEnd is None else np.ascontiguousarray(envEnd, np.int32)
+        _check(load().mb_fill_env(self.h, mode, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), startState,
+                                  _p(es, C.c_int32), _p(ee, C.c_int32), _p(cells, C.c_double)))
         return cells
 
     def path_bound(self, inLen: int, outLen: int) -> int:
@@ -200,6 +207,19 @@ class DeviceBatch:
             inOff[k + 1] = inOff[k] + len(a); outOff[k + 1] = outOff[k] + len(b)
         cat = lambda xs: (np.concatenate([np.asarray(x, np.int32) for x in xs]) if len(xs) else np.zeros(0, np.int32)).astype(np.int32)
         return cls(dm, cat([a for a, _ in pairs]), inOff, cat([b for _, b in pairs]), outOff)
+
+    def set_envelopes(self, envs):
+        """envs: per pair either None (full) or (inStart, inEnd) arrays of outLen+1 entries (src/seqpair.h:75-97)."""
+        off = np.zeros(self.nPairs + 1, np.int64)
+        st, en = [], []
+        for k, e in enumerate(envs):
+            n = 0
+            if e is not None:
+                st.append(np.asarray(e[0], np.int32)); en.append(np.asarray(e[1], np.int32)); n = len(st[-1])
+            off[k + 1] = off[k] + n
+        cat = lambda xs: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(1, np.int32), np.int32)
+        a, b = cat(st), cat(en)
+        _check(load().mb_batch_set_envelopes(self.h, _p(off, C.c_int64), _p(a, C.c_int32), _p(b, C.c_int32)))
 
     def close(self):
         if getattr(self, "h", None):

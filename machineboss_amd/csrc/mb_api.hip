@@ -70,7 +70,9 @@ static size_t budget_bytes() {
 }
 
 // kernel launchers implemented in the kernel files
-int launch_generic_fill(const mb_machine *, int, const PairDesc *, long long, const int *, const int *, double *, int, hipStream_t);
+int launch_generic_fill(const mb_machine *, int, const PairDesc *, long long, const int *, const int *, double *, int, hipStream_t,
+                        const int *, const int *);
+int launch_fill_neg_inf(double *, long long, hipStream_t);
 int launch_gather_loglike(const PairDesc *, long long, const double *, int, int, double *, hipStream_t);
 int launch_generic_counts(const mb_machine *, const PairDesc *, long long, long long, const int *, const int *,
                           const double *, const double *, double *, hipStream_t);
@@ -195,8 +197,14 @@ static bool use_medium(mb_machine *m) {
 
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
-                      const int *d_out, double *pool, int startState) {
-  if (use_medium(m)) {
+                      const int *d_out, double *pool, int startState, const mb_batch *b) {
+  const bool env = b && b->hasEnv;   // envelopes: generic family only; cells outside keep the -inf written here
+  if (env) {
+    long long cells = 0;
+    for (const PairDesc &pd : hp) cells = std::max(cells, pd.cellBase + (long long)(pd.inLen + 1) * (pd.outLen + 1) * m->S);
+    if (launch_fill_neg_inf(pool, cells, g_stream)) return 1;
+  }
+  if (!env && use_medium(m)) {
     FastState *f = fast_state(m);
     const bool exactFwd = mode == MB_VITERBI || (mode == MB_FORWARD && startState != 0);
     MedProgram &P = mode == MB_BACKWARD ? f->bwdSum : (exactFwd ? f->fwdExact : f->fwdSum);
@@ -207,7 +215,8 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     return rc;
   }
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
-  return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream);
+  return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream,
+                             env ? b->d_envStart : nullptr, env ? b->d_envEnd : nullptr);
 }
 
 }  // namespace mb
@@ -305,7 +314,7 @@ mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, c
     const long long il = inOff[p + 1] - inOff[p], ol = outOff[p + 1] - outOff[p];
     if (il < 0 || ol < 0 || il > 0x3fffffff || ol > 0x3fffffff) { set_error("bad sequence offsets"); delete b; return nullptr; }
     pd.inBase = inOff[p] - inOff[0]; pd.outBase = outOff[p] - outOff[0];
-    pd.inLen = (int)il; pd.outLen = (int)ol; pd.cellBase = base;
+    pd.inLen = (int)il; pd.outLen = (int)ol; pd.cellBase = base; pd.envBase = -1;
     const long long c = (il + 1) * (ol + 1) * m->S;
     base += c;
     b->maxPairCells = std::max(b->maxPairCells, c);
@@ -334,10 +343,48 @@ void mb_batch_destroy(mb_batch *b) {
   if (b->d_in) (void)hipFree(b->d_in);
   if (b->d_out) (void)hipFree(b->d_out);
   if (b->d_pairs) (void)hipFree(b->d_pairs);
+  if (b->d_envStart) (void)hipFree(b->d_envStart);
+  if (b->d_envEnd) (void)hipFree(b->d_envEnd);
   delete b;
 }
 
 int64_t mb_batch_cells(const mb_batch *b) { return b ? b->totalCells : 0; }
+
+// Envelope::fits / connected as DPMatrix::alloc asserts them (src/dpmatrix.defs.h:31-32, src/seqpair.cpp:184-193)
+static bool env_overlapping(long long s1, long long e1, long long s2, long long e2) { return !(s1 >= e2 || s2 >= e1); }
+
+int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *inStart, const int32_t *inEnd) {
+  if (!b || !envOff) { set_error("null argument"); return 1; }
+  if (b->d_envStart) { (void)hipFree(b->d_envStart); b->d_envStart = nullptr; }
+  if (b->d_envEnd) { (void)hipFree(b->d_envEnd); b->d_envEnd = nullptr; }
+  b->hasEnv = false;
+  const long long total = envOff[b->nPairs] - envOff[0];
+  for (long long p = 0; p < b->nPairs; ++p) {
+    PairDesc &pd = b->pairs[p];
+    const long long rows = envOff[p + 1] - envOff[p];
+    pd.envBase = -1;
+    if (rows == 0) continue;   // full envelope
+    if (!inStart || !inEnd) { set_error("null argument"); return 1; }
+    if (rows != (long long)pd.outLen + 1) { set_error("Envelope/sequence mismatch"); return 1; }
+    const int32_t *st = inStart + envOff[p], *en = inEnd + envOff[p];
+    for (long long y = 0; y < rows; ++y)
+      if (st[y] < 0 || en[y] > pd.inLen + 1 || st[y] > en[y]) { set_error("Envelope/sequence mismatch"); return 1; }
+    bool conn = env_overlapping(st[0], en[0], 0, 1);
+    for (long long y = 1; conn && y < rows; ++y) conn = env_overlapping(st[y - 1], (long long)en[y - 1] + 1, st[y], en[y]);
+    conn = conn && env_overlapping(st[rows - 1], en[rows - 1], pd.inLen, (long long)pd.inLen + 1);
+    if (!conn) { set_error("Envelope is not connected"); return 1; }
+    pd.envBase = envOff[p] - envOff[0];
+    b->hasEnv = true;
+  }
+  if (b->hasEnv) {
+    MB_HIP(hipMalloc((void **)&b->d_envStart, std::max<long long>(total, 1) * sizeof(int)));
+    MB_HIP(hipMalloc((void **)&b->d_envEnd, std::max<long long>(total, 1) * sizeof(int)));
+    MB_HIP(hipMemcpy(b->d_envStart, inStart + envOff[0], total * sizeof(int), hipMemcpyHostToDevice));
+    MB_HIP(hipMemcpy(b->d_envEnd, inEnd + envOff[0], total * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (b->nPairs) MB_HIP(hipMemcpy(b->d_pairs, b->pairs.data(), b->nPairs * sizeof(PairDesc), hipMemcpyHostToDevice));
+  return 0;
+}
 
 // ---- Forward ------------------------------------------------------------------------------------------------
 static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
@@ -349,7 +396,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
   Timer tm;
-  if (mode == MB_FORWARD && (flags & MB_ROLLING) && use_medium(m)) {
+  if (mode == MB_FORWARD && (flags & MB_ROLLING) && !b->hasEnv && use_medium(m)) {
     // RollingOutputForwardMatrix: no matrix in HBM, only two halo columns per pair
     FastState *f = fast_state(m);
     std::vector<long long> hb(b->nPairs);
@@ -367,7 +414,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
     if (d_hb) (void)hipFree(d_hb);
-  } else if (mode == MB_FORWARD && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1)) {
+  } else if (mode == MB_FORWARD && !b->hasEnv && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1)) {
     // ForwardMatrix semantics with only logLike() kept: continuous pipeline over recycled matrix slots
     FastState *f = fast_state(m);
     const size_t budget = budget_bytes();
@@ -390,7 +437,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
       if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { (void)hipFree(d_desc); rc = 1; break; }
       tm.start();
-      rc = fill_chunk(m, mode, d_desc, hp, b->d_in, b->d_out, pool, 0);
+      rc = fill_chunk(m, mode, d_desc, hp, b->d_in, b->d_out, pool, 0, b);
       if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, m->S, 0, d_ll + c.p0, g_stream);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
@@ -441,7 +488,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
       if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       if (!hip_ok(hipMalloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       tm.start();
-      if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0))) break;
+      if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0, b))) break;
       if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
       if (wantPaths) {
         for (long long p = 0; p < np; ++p)
@@ -506,17 +553,17 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       for (long long p = c.p0; p < c.p1; ++p)
         maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
       tm.start();
-      if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0))) break;
+      if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;
       // fused path: the Forward sweep accumulates the counts while its anti-diagonals are still in LDS
       int fused = -1;
-      if (use_medium(b->m) && fast_state(b->m)->countOk) {
+      if (!b->hasEnv && use_medium(b->m) && fast_state(b->m)->countOk) {
         FastState *f = fast_state(b->m);
         fused = medium_counts_materialised(b->m, f->fwdCnt, f->geoCnt, d_desc, hp, b->d_in, b->d_out, fwd, bwd, d_counts, d_ll + c.p0, g_stream);
         if (fused > 0) { rc = 1; break; }
         if (fused == 0) g_last_kernel = "k_medium_jit";
       }
       if (fused < 0) {
-        if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0))) break;
+        if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0, b))) break;
         if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
         if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
       }
@@ -543,25 +590,34 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
 }
 
 // ---- single full matrix -------------------------------------------------------------------------------------
-int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
-            int32_t startState, double *cellsOut) {
+int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
+                int32_t startState, const int32_t *envStart, const int32_t *envEnd, double *cellsOut) {
   if (!m || !cellsOut) { set_error("null argument"); return 1; }
   if (mode < MB_FORWARD || mode > MB_BACKWARD) { set_error("mb_fill: unknown mode"); return 1; }
   if (startState < 0 || startState >= m->S) { set_error("mb_fill: start state out of range"); return 1; }
   const int64_t inOff[2] = {0, inLen}, outOff[2] = {0, outLen};
   mb_batch *b = mb_batch_create(m, 1, in, inOff, out, outOff);
   if (!b) return 1;
+  if (envStart && envEnd) {
+    const int64_t envOff[2] = {0, outLen + 1};
+    if (mb_batch_set_envelopes(b, envOff, envStart, envEnd)) { mb_batch_destroy(b); return 1; }
+  }
   const long long n = b->totalCells;
   double *pool = nullptr;
   int rc = 0;
   if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
   if (!rc && !(pool = (double *)ws_get(0, n * sizeof(double)))) rc = 1;
   if (!rc && env_int("MB_DEBUG_POISON", 0)) (void)hipMemsetAsync(pool, 0xFF, n * sizeof(double), g_stream);
-  if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0);
+  if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, b);
   if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
   mb_batch_destroy(b);
   return rc;
+}
+
+int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
+            int32_t startState, double *cellsOut) {
+  return mb_fill_env(m, mode, in, inLen, out, outLen, startState, nullptr, nullptr, cellsOut);
 }
 
 // ---- introspection: generated source of the run-time specialised tile kernel (host only, no device needed) ------

@@ -5,6 +5,8 @@
 // The matrix lives in HBM in the reference's layout (src/dpmatrix.h:90-96), so this family is also what backs
 // mb_fill(), Backward matrices, the posterior-count sweep and the Viterbi traceback for every machine size.
 // The fast families (mb_small.hip: lanes = supercells; mb_medium.hip: lanes = states) are checked against it.
+#include <algorithm>
+
 #include "mb_internal.h"
 #include "mb_device_math.h"
 
@@ -43,7 +45,8 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k_generic_fill_fwd(DevMachine m, const PairDesc *__restrict__ pairs,
                                                            const int *__restrict__ inTok,
                                                            const int *__restrict__ outTok,
-                                                           double *pool, int startState) {
+                                                           double *pool, int startState,
+                                                           const int *__restrict__ envStart, const int *__restrict__ envEnd) {
   const PairDesc pd = pairs[blockIdx.x];
   const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
   const long long I = inLen + 1;
@@ -59,6 +62,8 @@ __global__ __launch_bounds__(1024) void k_generic_fill_fwd(DevMachine m, const P
         const int k = idx / ns, j = idx - k * ns;
         const int i = iLo + k, o = diag - i;
         const int d = m.levFState[l0 + j];
+        // cells outside the envelope keep the -inf the pool was filled with (src/dpmatrix.defs.h:36, dpmatrix.h:142-144)
+        if (pd.envBase >= 0 && (i < envStart[pd.envBase + o] || i >= envEnd[pd.envBase + o])) continue;
         const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
         double *cur = cells + ((long long)o * I + i) * S;
         double acc = (i || o || d != startState) ? -INFINITY : 0.0;
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(1024) void k_generic_fill_fwd(DevMachine m, const P
 __global__ __launch_bounds__(1024) void k_generic_fill_bwd(DevMachine m, const PairDesc *__restrict__ pairs,
                                                            const int *__restrict__ inTok,
                                                            const int *__restrict__ outTok,
-                                                           double *pool) {
+                                                           double *pool,
+                                                           const int *__restrict__ envStart, const int *__restrict__ envEnd) {
   const PairDesc pd = pairs[blockIdx.x];
   const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
   const long long I = inLen + 1;
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(1024) void k_generic_fill_bwd(DevMachine m, const P
         const int k = idx / ns, j = idx - k * ns;
         const int i = iLo + k, o = diag - i;
         const int s = m.levBState[l0 + j];
+        if (pd.envBase >= 0 && (i < envStart[pd.envBase + o] || i >= envEnd[pd.envBase + o])) continue;
         const bool endIn = (i == inLen), endOut = (o == outLen);
         const int it = endIn ? 0 : in[i], ot = endOut ? 0 : out[o];
         double *cur = cells + ((long long)o * I + i) * S;
@@ -244,17 +251,28 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
 }
 
 // ---- launch helpers (host) -----------------------------------------------------------------------------------
+__global__ void k_fill_neg_inf(double *p, long long n) {
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) p[k] = -INFINITY;
+}
+
+int launch_fill_neg_inf(double *d_pool, long long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_fill_neg_inf, dim3((unsigned)std::min<long long>((n + 255) / 256, 65536)), dim3(256), 0, st, d_pool, n);
+  return hip_ok(hipGetLastError(), "fill launch") ? 0 : 1;
+}
+
 int launch_generic_fill(const mb_machine *m, int mode, const PairDesc *d_pairs, long long nPairs, const int *d_in,
-                        const int *d_out, double *d_pool, int startState, hipStream_t st) {
+                        const int *d_out, double *d_pool, int startState, hipStream_t st, const int *d_envStart,
+                        const int *d_envEnd) {
   if (nPairs == 0) return 0;
   ++g_last_launches;
   const dim3 grid((unsigned)nPairs), block(m->S * 64 >= 1024 ? 1024 : 256);
   if (mode == MB_FORWARD)
-    hipLaunchKernelGGL(k_generic_fill_fwd<MB_FORWARD>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, startState);
+    hipLaunchKernelGGL(k_generic_fill_fwd<MB_FORWARD>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, startState, d_envStart, d_envEnd);
   else if (mode == MB_VITERBI)
-    hipLaunchKernelGGL(k_generic_fill_fwd<MB_VITERBI>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, 0);
+    hipLaunchKernelGGL(k_generic_fill_fwd<MB_VITERBI>, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, 0, d_envStart, d_envEnd);
   else
-    hipLaunchKernelGGL(k_generic_fill_bwd, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool);
+    hipLaunchKernelGGL(k_generic_fill_bwd, grid, block, 0, st, m->dev, d_pairs, d_in, d_out, d_pool, d_envStart, d_envEnd);
   return hip_ok(hipGetLastError(), "generic fill launch") ? 0 : 1;
 }
 

@@ -38,6 +38,7 @@ struct PairDesc {
   long long cellBase;          // offset (in doubles) of this pair's matrix inside a matrix pool
   int launch0;                 // tiled kernels: index of the launch in which this pair's first tile runs
   int pad;
+  long long envBase;           // offset of this pair's envelope rows in the batch's inStart/inEnd arrays, -1 = full envelope
 };
 
 }  // namespace mb
@@ -77,6 +78,9 @@ struct mb_batch {
   int *d_in = nullptr, *d_out = nullptr;
   mb::PairDesc *d_pairs = nullptr;
   long long nInTokTotal = 0, nOutTokTotal = 0;
+  // envelopes (src/seqpair.h:75-97): cell (x,y) of pair p exists <=> envStart[envBase+y] <= x < envEnd[envBase+y]
+  bool hasEnv = false;
+  int *d_envStart = nullptr, *d_envEnd = nullptr;
 };
 
 namespace mb {

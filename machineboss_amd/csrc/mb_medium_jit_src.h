@@ -17,7 +17,7 @@ static const char *kMedJitSkeleton = R"MBJIT(
 #define NEG_INF (-__builtin_inf())
 #define MED_L2E 1.44269504088896f
 #define MED_LN2 0.693147180559945f
-struct PairDesc { long long inBase, outBase; int inLen, outLen; long long cellBase; int launch0; int pad; };
+struct PairDesc { long long inBase, outBase; int inLen, outLen; long long cellBase; int launch0; int pad; long long envBase; };
 struct MedRec { double w; unsigned srcOff; unsigned dstOff; };
 struct MedProgDev {
   int S, Spad, LPG, G, NS, nChunks;

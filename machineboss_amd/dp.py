@@ -18,20 +18,7 @@ import numpy as np
 from . import capi
 from .evalmachine import EvaluatedMachine
 from .machine import Machine, MachineError, MachineTransition, evalWeight
-
-
-@dataclass
-class SeqPair:
-    """src/seqpair.h:56-73 (names + symbol sequences; alignments/envelopes are not on this path yet)."""
-    input: List[str]
-    output: List[str]
-    inputName: str = "input"
-    outputName: str = "output"
-
-    @classmethod
-    def fromJson(cls, j: dict) -> "SeqPair":
-        return cls(list(j["input"]["sequence"]), list(j["output"]["sequence"]),
-                   j["input"].get("name", "input"), j["output"].get("name", "output"))
+from .seqpair import Envelope, SeqPair
 
 
 def _device_machine(em: EvaluatedMachine) -> capi.DeviceMachine:
@@ -134,13 +121,21 @@ class _DPMatrix:
     ForwardMatrix::samplePath.  The Viterbi path of a batch (the hot use) is traced on the device instead."""
     _mode = capi.MB_FORWARD
 
-    def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, startState: int = 0):
+    def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None, startState: int = 0):
         self.machine, self.seqPair = machine, seqPair
         self.input = machine.inputTokenizer.tokenize(seqPair.input)     # raises like Tokenizer::tokenize
         self.output = machine.outputTokenizer.tokenize(seqPair.output)
         self.inLen, self.outLen, self.nStates = len(self.input), len(self.output), machine.nStates
+        # Quirk Q1: the reference's constructors initialise their IndexMapper from the SeqPair, not from the Envelope
+        # argument (src/dpmatrix.defs.h:16-17): the envelope is ALWAYS Envelope(seqPair) -- the alignment's path
+        # envelope when the pair carries one, else full (src/seqpair.cpp:104-110).  `envelope` is accepted and ignored.
+        self.env = Envelope(seqPair)
+        if not self.env.connected():                                     # DPMatrix::alloc, src/dpmatrix.defs.h:31-32
+            raise MachineError("Envelope is not connected:\n%s\n" % self.env.writeJson())
         self._dm = _device_machine(machine)
-        self._cells = self._dm.fill(self._mode, self.input, self.output, startState)  # [o][i][s]
+        full = self.env.isFull()
+        self._cells = self._dm.fill(self._mode, self.input, self.output, startState,
+                                    None if full else self.env.inStart, None if full else self.env.inEnd)  # [o][i][s]
 
     def cell(self, inPos: int, outPos: int, state: int) -> float:
         if 0 <= outPos <= self.outLen and 0 <= inPos <= self.inLen:
@@ -310,7 +305,7 @@ class BackwardMatrix(_DPMatrix):
         for outPos in range(self.outLen, -1, -1):
             endOut = outPos == self.outLen
             outTok = 0 if endOut else int(self.output[outPos])
-            for inPos in range(self.inLen, -1, -1):
+            for inPos in range(self.env.inEnd[outPos] - 1, self.env.inStart[outPos] - 1, -1):
                 endIn = inPos == self.inLen
                 inTok = 0 if endIn else int(self.input[inPos])
                 for s in range(self.nStates - 1, -1, -1):
@@ -357,8 +352,8 @@ class ViterbiMatrix(_DPMatrix):
     """src/viterbi.h:9-18."""
     _mode = capi.MB_VITERBI
 
-    def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair):
-        super().__init__(machine, seqPair, 0)
+    def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None):
+        super().__init__(machine, seqPair, envelope, 0)
 
     def logLike(self) -> float:
         return self.endCell()
@@ -421,11 +416,19 @@ class MachineCounts:
     def add(self, seqPair: SeqPair) -> float:
         return self.addBatch([seqPair])[0]
 
-    def addBatch(self, seqPairs: Sequence[SeqPair]) -> List[float]:
+    def addBatch(self, seqPairs: Sequence[SeqPair], envelopes: Optional[Sequence[Envelope]] = None) -> List[float]:
+        """MachineCounts::add over a list (src/counts.cpp:37-64).  Quirk Q1: whatever envelope the caller passes, the
+        matrices use Envelope(seqPair) -- the path envelope of an aligned pair, else the full one."""
         dm = _device_machine(self.machine)
         toks = [(self.machine.inputTokenizer.tokenize(sp.input), self.machine.outputTokenizer.tokenize(sp.output))
                 for sp in seqPairs]
         b = capi.DeviceBatch.from_pairs(dm, toks)
+        envs = [Envelope(sp) for sp in seqPairs]
+        for e in envs:
+            if not e.connected():
+                raise MachineError("Envelope is not connected:\n%s\n" % e.writeJson())
+        if any(not e.isFull() for e in envs):
+            b.set_envelopes([None if e.isFull() else (e.inStart, e.inEnd) for e in envs])
         _, s, ll = b.counts(self._flat)
         b.close()
         self.loglike += s

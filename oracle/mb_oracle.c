@@ -154,6 +154,15 @@ void mbo_outgoing_order(const mbo_machine *m, uint32_t *out) { memcpy(out, m->ou
 
 enum { MBO_SUM_TABLE = 0, MBO_SUM_EXACT = 1, MBO_MAX = 2 };
 
+/* Envelope (src/seqpair.h:75-97): (x,y) is inside <=> inStart[y] <= x < inEnd[y].  NULL = full envelope.  The fills
+ * below visit only the cells inside (src/forward.defs.h:29, viterbi.cpp:23, backward.cpp:25); every other cell keeps the
+ * -inf that alloc() stored (src/dpmatrix.defs.h:36), which is also what the const cell() accessor returns for a
+ * position outside the envelope (src/dpmatrix.h:142-144).  The matrix here is always the FULL rectangle. */
+static const long *env_start = NULL, *env_end = NULL;
+void mbo_set_envelope(const long *inStart, const long *inEnd) { env_start = inStart; env_end = inEnd; }
+#define ENV_LO(o) (env_start ? env_start[o] : 0)
+#define ENV_HI(o, inLen) (env_end ? env_end[o] : (inLen) + 1)
+
 static inline double reduce2(int mode, double a, double b) {
   if (mode == MBO_MAX) return a > b ? a : (b > a ? b : a); /* std::max(a,b): returns a unless a<b (src/dpmatrix.h:122) */
   return mode == MBO_SUM_EXACT ? lse_exact2(a, b) : lse_table2(a, b);
@@ -184,12 +193,12 @@ static inline double acc_out(const mbo_machine *m, int mode, double ll, int s, i
 void mbo_fill_forward(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen,
                       int mode, int startState, double *cells) {
   const long I = inLen + 1; const int S = m->nStates;
+  for (long x = 0; x < I * (outLen + 1) * S; ++x) cells[x] = NEG_INF; /* alloc() fills with -inf (src/dpmatrix.defs.h:36) */
   for (long o = 0; o <= outLen; ++o) {
     const int ot = o ? out[o - 1] : 0;
-    for (long i = 0; i <= inLen; ++i) {
+    for (long i = ENV_LO(o); i < ENV_HI(o, inLen); ++i) {
       const int it = i ? in[i - 1] : 0;
       double *cur = &CELL(cells, I, S, i, o, 0);
-      for (int d = 0; d < S; ++d) cur[d] = NEG_INF; /* alloc() fills with -inf (src/dpmatrix.defs.h:36) */
       for (int d = 0; d < S; ++d) {
         double ll = (i || o || d != startState) ? NEG_INF : 0;
         if (i && o) ll = acc_in(m, mode, ll, d, it, ot, &CELL(cells, I, S, i - 1, o - 1, 0));
@@ -242,7 +251,7 @@ void mbo_fill_backward(const mbo_machine *m, const int32_t *in, long inLen, cons
   for (long o = outLen; o >= 0; --o) {
     const int endOfOutput = (o == outLen);
     const int ot = endOfOutput ? 0 : out[o];
-    for (long i = inLen; i >= 0; --i) {
+    for (long i = ENV_HI(o, inLen) - 1; i >= ENV_LO(o); --i) {
       const int endOfInput = (i == inLen);
       const int it = endOfInput ? 0 : in[i];
       double *cur = &CELL(cells, I, S, i, o, 0);
@@ -278,7 +287,7 @@ void mbo_get_counts(const mbo_machine *m, const int32_t *in, long inLen, const i
   for (long o = outLen; o >= 0; --o) {
     const int endOfOutput = (o == outLen);
     const int ot = endOfOutput ? 0 : out[o];
-    for (long i = inLen; i >= 0; --i) {
+    for (long i = ENV_HI(o, inLen) - 1; i >= ENV_LO(o); --i) {
       const int endOfInput = (i == inLen);
       const int it = endOfInput ? 0 : in[i];
       for (int s = S - 1; s >= 0; --s) {

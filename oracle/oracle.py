@@ -47,6 +47,8 @@ def lib():
         L.mbo_counts_add.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, C.c_int, dp]
         L.mbo_traceback.restype = C.c_long
         L.mbo_traceback.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, u32p, C.c_long]
+        L.mbo_set_envelope.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.mbo_set_envelope.restype = None
         L.mbo_init()
         _LIB = L
     return _LIB
@@ -54,6 +56,22 @@ def lib():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+class envelope:
+    """Context manager: fills inside the block use the given envelope (inStart[o], inEnd[o]); None = full."""
+
+    def __init__(self, inStart=None, inEnd=None):
+        self.a = None if inStart is None else np.ascontiguousarray(inStart, np.int64)
+        self.b = None if inEnd is None else np.ascontiguousarray(inEnd, np.int64)
+
+    def __enter__(self):
+        if self.a is not None:
+            lib().mbo_set_envelope(_p(self.a, C.c_long), _p(self.b, C.c_long))
+        return self
+
+    def __exit__(self, *exc):
+        lib().mbo_set_envelope(None, None)
 
 
 class OracleMachine:

@@ -432,3 +432,63 @@ def test_backward_visitors_match_device_counts(capi, machines):
     emitted_in = sum(1 for s, ti in [(a[2], a[3]) for a in seen] if m.state[s].getTransition(ti).inp)
     emitted_out = sum(1 for s, ti in [(a[2], a[3]) for a in seen] if m.state[s].getTransition(ti).out)
     assert emitted_in == len(x) and emitted_out == len(y) and len(used) > 0
+
+
+# ---- envelopes (src/seqpair.h:75-97; DPMatrix fills visit only the cells inside, dpmatrix.h:142-144 reads -inf outside) ----
+@pytest.mark.parametrize("name,il,ol,width", [("dnapsw", 14, 17, 2), ("bitstutter-noise", 4, 6, 1), ("psw2dna", 3, 11, 1)])
+def test_envelope_fills_match_oracle(capi, oracle_mod, machines, name, il, ol, width):
+    """Forward / Viterbi / Backward / counts under a path-area envelope: device (generic family) vs oracle."""
+    from machineboss_amd.seqpair import Envelope
+    preset = name != "bitstutter-noise"
+    m, em = machines(name, None if preset else load_json("io", "params.json"), useDefaults=preset, preset=preset)
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    x, y = synth_tokens(31, il, ol, em.nInTok, em.nOutTok)
+    # an alignment that matches min(il, ol) symbols diagonally, then gaps -> its path-area envelope of the given width
+    k = min(il, ol)
+    cols = [("a", "b")] * k + [("a", "")] * (il - k) + [("", "b")] * (ol - k)
+    env = Envelope.pathAreaEnvelope(cols, width)
+    assert env.connected() and not env.isFull()
+    with oracle_mod.envelope(env.inStart, env.inEnd):
+        Vr = om.viterbi(x, y); Fr = om.forward(x, y, oracle_mod.SUM_EXACT); Br = om.backward(x, y, oracle_mod.SUM_EXACT)
+        cr = np.zeros(em.nTransitions); llr = om.counts_add(x, y, cr, oracle_mod.SUM_EXACT)
+        path_r = om.traceback(x, y, Vr) if Vr[-1, -1, -1] > -math.inf else None
+    V = dm.fill(capi.MB_VITERBI, x, y, 0, env.inStart, env.inEnd)
+    F = dm.fill(capi.MB_FORWARD, x, y, 0, env.inStart, env.inEnd)
+    B = dm.fill(capi.MB_BACKWARD, x, y, 0, env.inStart, env.inEnd)
+    assert "generic" in capi.last_kernel_name()
+    assert np.array_equal(V, Vr) and close(F, Fr, REL_EXACT) and close(B, Br, REL_EXACT)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y), (x, y)])
+    b.set_envelopes([(env.inStart, env.inEnd), None])          # second pair keeps the full envelope
+    ll = b.forward(capi.MB_ROLLING)
+    assert close(ll[0], Fr[-1, -1, -1], 1e-10) and close(ll[1], om.loglike(x, y, oracle_mod.SUM_EXACT), 1e-10)
+    vll, off, edges = b.viterbi()
+    assert vll[0] == Vr[-1, -1, -1]
+    if path_r is not None:
+        assert np.array_equal(edges[off[0]:off[1]], path_r)
+    counts, s, cll = b.counts()
+    cf = np.zeros(em.nTransitions); llf = om.counts_add(x, y, cf, oracle_mod.SUM_EXACT)
+    assert close(counts, cr + cf, COUNT_TOL, 1e-12) and close(s, llr + llf, 1e-10)
+    # errors of DPMatrix::alloc (src/dpmatrix.defs.h:31-32)
+    with pytest.raises(capi.MbError, match="mismatch"):
+        b.set_envelopes([(env.inStart[:-1], env.inEnd[:-1]), None])
+    gap = list(env.inStart); gap[1] = env.inEnd[0] + 2
+    if gap[1] < il:
+        with pytest.raises(capi.MbError, match="not connected|mismatch"):
+            b.set_envelopes([(gap, [max(a + 1, e) for a, e in zip(gap, env.inEnd)]), None])
+
+
+def test_path_envelope_through_dp_classes(capi, machines):
+    """Quirk Q1: an aligned SeqPair is filled under its alignment's PATH envelope (src/dpmatrix.defs.h:16-17,
+    seqpair.cpp:104-110), so MachineCounts over t/io/pathlist.json counts exactly the aligned transitions."""
+    from machineboss_amd.dp import ForwardMatrix, MachineCounts
+    from machineboss_amd.seqpair import seqPairListFromJson
+    p = load_json("io", "params.json")
+    m, em = machines("bitnoise", p)
+    aligned = seqPairListFromJson(load_json("io", "pathlist.json"))
+    plain = seqPairListFromJson(load_json("io", "seqpairlist.json"))
+    fa, fp = ForwardMatrix(em, aligned[0]), ForwardMatrix(em, plain[0])
+    assert not fa.env.isFull() and fp.env.isFull() and fa.logLike() <= fp.logLike() and fa.cell(0, 1, 0) == -math.inf
+    mc = MachineCounts(em, aligned)
+    # 3 + 2 aligned columns, each a match transition of the single state; nothing else is reachable in the envelope
+    assert abs(sum(sum(r) for r in mc.count) - 5.0) < 1e-9
