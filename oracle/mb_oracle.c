@@ -6,10 +6,15 @@
  *
  * Parity pinning: the reference C++ path cannot be compiled in this image (src/logsumexp.h:5-6 and
  * src/eval.cpp:1 include GSL, which is absent, and stand-in headers are not allowed), so this
- * restatement is pinned against the reference's own golden vectors instead (tests/golden/, copied
- * data files of /root/reference/t/: fwd/back/fwdback-bitnoise-params-tiny, align-stutter-noise-difflen,
- * 101-bitnoise-001, 101-bitstutternoise-{fwd,vit}-0011, counts.json) and against values produced here
- * by the reference's JS CPU tier (js/webgpu/cpu/*.mjs, see tests/golden/make_js_goldens.mjs).
+ * restatement is pinned against
+ *   - the reference's own golden vectors (tests/golden/{expect,io,machine}: copied DATA files of
+ *     /root/reference/t/: fwd/back/fwdback-bitnoise-params-tiny, align-stutter-noise-difflen, 101-bitnoise-001,
+ *     101-bitstutternoise-{fwd,vit}-0011, counts.json, the *_env.json envelopes),
+ *   - benchmark-scale outputs of the real C++ reference recorded in SURVEY.md section 6 (tests/golden/survey_anchors.json),
+ *   - outputs of the reference's second implementation of this path, its JavaScript CPU tier
+ *     (js/webgpu/cpu/{forward,backward,viterbi}-2d.mjs), produced by RUNNING that code in the dev container with node:
+ *     tests/golden/make_js_cases.py + make_js_goldens.mjs -> tests/golden/js/goldens.json (every Forward and Backward
+ *     cell of five machines to 1e-10, Viterbi scores bit for bit; tests/test_oracle_golden.py).
  *
  * Each function cites the reference lines it restates (paths relative to /root/reference/).
  * Cell layout follows IdentityIndexMapper with a full envelope (src/dpmatrix.h:34-44,90-96):

@@ -492,3 +492,27 @@ def test_path_envelope_through_dp_classes(capi, machines):
     mc = MachineCounts(em, aligned)
     # 3 + 2 aligned columns, each a match transition of the single state; nothing else is reachable in the envelope
     assert abs(sum(sum(r) for r in mc.count) - 5.0) < 1e-9
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_reference_js_tier_goldens_through_gpu(capi, idx):
+    """Outputs of the reference's own JavaScript CPU implementation (tests/golden/js/, generated by running
+    js/webgpu/cpu/*-2d.mjs with node in the dev container): Viterbi score bit for bit, Forward / Backward log-likelihood
+    within 1e-4 relative (observed ~1e-9) through the HIP path."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    cases = {c["name"]: c for c in load_json("js", "cases.json")}
+    gold = load_json("js", "goldens.json")[idx]
+    case = cases[gold["name"]]
+    m = Machine.fromFile(golden_path(*case["machine"].split("/")))
+    defs = m.getParamDefs(True); defs.update(case["params"])
+    em = EvaluatedMachine.fromMachine(m, defs)
+    dm = capi.DeviceMachine(em)
+    x = np.array(case["input"], np.int32); y = np.array(case["output"], np.int32)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+    for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
+        ll = b.forward(flags)[0]
+        assert abs(ll - float(gold["forward"])) <= 1e-4 * abs(float(gold["forward"])) and abs(ll - float(gold["forward"])) < 1e-6
+    assert b.viterbi(paths=False)[0][0] == float(gold["viterbi"])
+    B = dm.fill(capi.MB_BACKWARD, x, y)
+    assert abs(B[0, 0, 0] - float(gold["backward"])) < 1e-6

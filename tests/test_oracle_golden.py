@@ -178,3 +178,45 @@ def test_empty_sequences(oracle_mod, machines):
     assert abs(om.loglike(i, o) - 6 * math.log(.5)) < 1e-12
     B = om.backward(i, o)
     assert abs(B[0, 0, 0] - 6 * math.log(.5)) < 1e-12
+
+
+# ---- outputs of the reference's own JavaScript CPU tier, run in the dev container (tests/golden/make_js_goldens.mjs) ----
+def _js_cases():
+    cases = {c["name"]: c for c in load_json("js", "cases.json")}
+    return [(cases[g["name"]], g) for g in load_json("js", "goldens.json")]
+
+
+def _num(v):
+    return -math.inf if v == "-inf" else (math.inf if v == "inf" else float(v))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_oracle_matches_reference_js_tier(oracle_mod, idx):
+    """The reference ships a second, independent implementation of this DP path (js/webgpu/cpu/*-2d.mjs: Float64, exact
+    logsumexp, dense transition tensor).  Its outputs on five machines -- generated by running THAT code here with node --
+    pin the oracle: Forward/Backward log-likelihoods and every cell to 1e-10 relative, Viterbi scores bit for bit."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    case, gold = _js_cases()[idx]
+    m = Machine.fromFile(golden_path(*case["machine"].split("/")))
+    defs = m.getParamDefs(True); defs.update(case["params"])
+    em = EvaluatedMachine.fromMachine(m, defs)
+    om = oracle_mod.OracleMachine(em)
+    x = np.array(case["input"], np.int32); y = np.array(case["output"], np.int32)
+    F = om.forward(x, y, oracle_mod.SUM_EXACT); B = om.backward(x, y, oracle_mod.SUM_EXACT); V = om.viterbi(x, y)
+    rel = lambda a, b: abs(a - b) <= 1e-10 * max(1.0, abs(b))
+    assert rel(F[-1, -1, -1], _num(gold["forward"])) and rel(B[0, 0, 0], _num(gold["backward"]))
+    assert V[-1, -1, -1] == _num(gold["viterbi"])
+    assert rel(om.loglike(x, y, oracle_mod.SUM_TABLE), _num(gold["forward"])) or abs(om.loglike(x, y) - _num(gold["forward"])) < 1e-4
+    S = em.nStates; Lo = len(y)
+
+    def cell(M, k):   # JS layout [(i*(Lo+1)+o)*S+s] -> ours [o][i][s]
+        s = k % S; io = k // S; return M[io % (Lo + 1), io // (Lo + 1), s]
+    if "forwardCells" in gold:
+        pairs = [(k, _num(f), _num(b)) for k, (f, b) in enumerate(zip(gold["forwardCells"], gold["backwardCells"]))]
+    else:
+        pairs = [(k, _num(f), _num(b)) for k, f, b in gold["sample"]]
+    assert len(pairs) > 10
+    for k, f, b in pairs:
+        for got, ref in ((cell(F, k), f), (cell(B, k), b)):
+            assert (got == ref) if not math.isfinite(ref) else rel(got, ref), (k, got, ref)
