@@ -516,3 +516,62 @@ def test_reference_js_tier_goldens_through_gpu(capi, idx):
     assert b.viterbi(paths=False)[0][0] == float(gold["viterbi"])
     B = dm.fill(capi.MB_BACKWARD, x, y)
     assert abs(B[0, 0, 0] - float(gold["backward"])) < 1e-6
+
+
+# ---- M-step and Baum-Welch (src/counts.cpp:117-295, src/fitter.cpp) around the device count sweep -------------------------
+def _round4(d):
+    return {k: float("%.4g" % v) for k, v in d.items()}
+
+
+def test_mstep_reference_golden(capi, machines):
+    """t/src/testmaximize.cpp on bitnoise (Makefile:502): counts -> MachineObjective::optimize == {"p":0.6667,"q":0.3333}."""
+    from machineboss_amd.dp import MachineCounts
+    from machineboss_amd.fitter import MachineObjective
+    from machineboss_amd.machine import Constraints
+    from machineboss_amd.seqpair import SeqPair
+    params = load_json("io", "params.json")
+    m, em = machines("bitnoise", params)
+    counts = MachineCounts(em, [SeqPair.fromJson(load_json("io", "tiny.json"))])
+    cons = Constraints.fromJson(load_json("io", "pqcons.json"))
+    obj = MachineObjective(m, counts, cons, {})
+    opt = obj.optimize(params)
+    assert _round4(opt) == load_json("expect", "max-bitnoise-params-tiny.json")
+    # the general path (the reference's transformed parameterisation minimised with BFGS) reaches the same optimum
+    obj._closed_form = lambda seed: None
+    assert _round4(obj.optimize(params)) == load_json("expect", "max-bitnoise-params-tiny.json")
+
+
+@pytest.mark.parametrize("data", ["seqpairlist.json", "pathlist.json"])
+def test_fit_reference_golden(capi, machines, data):
+    """`boss t/machine/bitnoise.json -N t/io/pqcons.json -D <data> -T` (Makefile:505-507): plain pairs and aligned pairs
+    (path envelopes) both fit to {"p":0.4,"q":0.6}."""
+    from machineboss_amd.fitter import MachineFitter
+    from machineboss_amd.machine import Constraints, Machine
+    from machineboss_amd.seqpair import seqPairListFromJson
+    m = Machine.fromFile(golden_path("machine", "bitnoise.json"))
+    fitter = MachineFitter(m, Constraints.fromJson(load_json("io", "pqcons.json")))
+    fit = fitter.fit(seqPairListFromJson(load_json("io", data)))
+    assert _round4(fit) == load_json("expect", "fit-bitnoise-seqpairlist.json")
+    assert len(fitter.log) >= 2 and all(b >= a - 1e-9 for a, b in zip(fitter.log, fitter.log[1:]))   # EM never decreases the likelihood
+
+
+def test_fit_protpsw_recovers_likelihood(capi, machines):
+    """EM on protpsw (BASELINE config 3 in miniature): the likelihood rises monotonically and the fitted parameters
+    stay normalised; weights are reloaded with mb_machine_set_weights between iterations."""
+    from machineboss_amd.fitter import MachineFitter
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.seqpair import SeqPair
+    m = Machine.fromFile(golden_path("preset", "protpsw.json"))
+    em0 = machines("protpsw", None, useDefaults=True, preset=True)[1]
+    rng = np.random.RandomState(5)
+    pairs = []
+    for k in range(6):
+        x = rng.randint(1, 21, size=12)
+        y = x.copy(); y[rng.randint(0, 12, size=3)] = rng.randint(1, 21, size=3)    # a noisy copy: substitutions only
+        pairs.append(SeqPair(em0.inputTokenizer.detokenize(x), em0.outputTokenizer.detokenize(y)))
+    fitter = MachineFitter(m)
+    fit = fitter.fit(pairs)
+    assert len(fitter.log) >= 3 and all(b >= a - 1e-7 for a, b in zip(fitter.log, fitter.log[1:]))
+    for g in m.cons.norm:
+        assert abs(sum(fit[p] for p in g) - 1.0) < 1e-9
+    assert fitter.log[-1] > fitter.log[0] + 1.0
