@@ -1,0 +1,295 @@
+"""`boss`-compatible command line for the inference surface, backed by the HIP engine.
+
+    python -m machineboss_amd.boss MACHINE.json [--preset NAME] [-P params.json] [-F funcs.json] [-N constraints.json]
+           [-D seqpairs.json] [--input-chars S] [--output-chars S] [--input-fasta F] [--output-fasta F]
+           [--input-json F] [--output-json F] [--use-defaults] [-L] [-V] [-A] [-C] [-T] [-R width]
+
+Restates the data-handling and inference section of /root/reference/target/boss.cpp:716-847 -- how sequences are
+collected into pairs, how parameters are assembled, and the exact output text of --loglike / --viterbi / --align /
+--counts / --train -- around the batched GPU calls.  The real `boss` needs Boost and cannot run on the GPU box; the
+machine-expression language of its command line (compose, concatenate, ...: machine algebra, out of scope) is not
+here: the machine is ONE JSON transducer file or ONE preset.
+
+Numbers print like C++ `ostream << double` (6 significant digits, target/boss.cpp:794-807 via src/jsonio.h:14-22),
+parameters with 15 (src/weight.cpp:483).  Work is batched: all pairs go through one device call per mode; with
+torch.distributed initialised (torchrun) the pairs are sharded over ranks, --train/--counts all-reduce their counts
+(RCCL) and rank 0 prints.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+from typing import Any, Dict, List, Optional, Tuple
+
+from .evalmachine import EvaluatedMachine
+from .machine import Constraints, Machine, MachineError
+from .seqpair import SeqPair, seqPairListFromJson
+
+PRESET_DIRS = [os.environ.get("MB_PRESET_DIR", ""), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                  "tests", "golden", "preset")]
+
+
+def fmt(x: float) -> str:
+    """toInfinitySafeString (src/jsonio.h:14-22): `out << x` = %g with 6 significant digits."""
+    if x == math.inf:
+        return '"Infinity"'
+    if x == -math.inf:
+        return '"-Infinity"'
+    return "%g" % x
+
+
+def fmtParam(x: Any) -> str:
+    """WeightAlgebra::toJsonStream for constants (src/weight.cpp:471-484): 0, 1, ints, doubles at 15 digits."""
+    if isinstance(x, bool):
+        return "1" if x else "0"
+    if isinstance(x, (int, float)):
+        if x == 0:
+            return "0"
+        if x == 1:
+            return "1"
+        if isinstance(x, int):
+            return str(x)
+        return "%.15g" % x
+    return json.dumps(x, separators=(",", ":"))
+
+
+def escaped(s: str) -> str:
+    return json.dumps(s)[1:-1]
+
+
+def readFasta(path: str) -> List[Tuple[str, str]]:
+    out: List[Tuple[str, str]] = []
+    name, seq = None, []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(seq)))
+                name, seq = line[1:].split()[0] if len(line) > 1 else "", []
+            elif line and name is not None:
+                seq.append(line)
+    if name is not None:
+        out.append((name, "".join(seq)))
+    return out
+
+
+def seqPairJson(sp: SeqPair) -> str:
+    """SeqPair::writeJson (src/seqpair.cpp:40-58)."""
+    named = lambda n, s: '{"name":"%s","sequence":[%s]}' % (n, ",".join('"%s"' % x for x in s))
+    out = '{"input":' + named(sp.inputName, sp.input) + ',"output":' + named(sp.outputName, sp.output)
+    if sp.alignment:
+        out += ',"alignment":[' + ",".join('["%s","%s"]' % (escaped(a), escaped(b)) for a, b in sp.alignment) + "]"
+    if sp.metadata is not None:
+        out += ',"meta":' + json.dumps(sp.metadata, separators=(",", ":"), sort_keys=True)
+    return out + "}"
+
+
+def pathJson(m: Machine, path) -> dict:
+    """MachinePath::writeJson (src/machine.cpp:1982-2000) as the JSON object stored under meta.path."""
+    j: Dict[str, Any] = {"start": m.startState()}
+    if m.state[m.startState()].name is not None:
+        j["id"] = m.state[m.startState()].name
+    trans = []
+    for t in path.trans:
+        tj: Dict[str, Any] = {"to": t.dest}
+        if m.state[t.dest].name is not None:
+            tj["id"] = m.state[t.dest].name
+        if t.inp:
+            tj["in"] = t.inp
+        if t.out:
+            tj["out"] = t.out
+        trans.append(tj)
+    j["trans"] = trans
+    return j
+
+
+def seqPairFromPath(m: Machine, path, inputName: str, outputName: str) -> SeqPair:
+    """SeqPair::seqPairFromPath (src/seqpair.cpp:60-89)."""
+    ali = [(t.inp, t.out) for t in path.trans if t.inp or t.out]
+    return SeqPair([a for a, _ in ali if a], [b for _, b in ali if b], inputName, outputName, ali, {"path": pathJson(m, path)})
+
+
+def buildParser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="boss", description=__doc__.split("\n\n")[0])
+    ap.add_argument("machine", nargs="*", help="transducer JSON file")
+    ap.add_argument("--preset", help="preset name (dnapsw, protpsw, psw2dna, translate)")
+    ap.add_argument("-P", "--params", action="append", default=[])
+    ap.add_argument("-F", "--functions", action="append", default=[])
+    ap.add_argument("-N", "--constraints", action="append", default=[])
+    ap.add_argument("-D", "--data", action="append", default=[])
+    ap.add_argument("--use-defaults", action="store_true")
+    ap.add_argument("--input-chars"); ap.add_argument("--output-chars")
+    ap.add_argument("--input-fasta"); ap.add_argument("--output-fasta")
+    ap.add_argument("--input-json"); ap.add_argument("--output-json")
+    ap.add_argument("-L", "--loglike", action="store_true")
+    ap.add_argument("-V", "--viterbi", action="store_true")
+    ap.add_argument("-A", "--align", action="store_true")
+    ap.add_argument("-C", "--counts", action="store_true")
+    ap.add_argument("-T", "--train", action="store_true")
+    ap.add_argument("-R", "--wiggle-room", type=int)
+    return ap
+
+
+def loadMachine(args) -> Machine:
+    if args.preset:
+        if args.machine:
+            raise MachineError("machine algebra (several machines on one command line) is outside the DP path: give one machine")
+        for d in PRESET_DIRS:
+            p = os.path.join(d, args.preset + ".json")
+            if d and os.path.exists(p):
+                return Machine.fromFile(p)
+        raise MachineError("Unknown preset %s" % args.preset)
+    if len(args.machine) != 1:
+        raise MachineError("give exactly one transducer JSON file (machine algebra is outside the DP path)")
+    return Machine.fromFile(args.machine[0])
+
+
+def collectData(args, machine: Machine, inferenceRequested: bool) -> List[SeqPair]:
+    """target/boss.cpp:716-773."""
+    data: List[SeqPair] = []
+    for f in args.data:
+        data += seqPairListFromJson(json.load(open(f)))
+    inSeqs: List[Tuple[str, List[str]]] = []
+    outSeqs: List[Tuple[str, List[str]]] = []
+    if args.input_fasta:
+        inSeqs += [(n, list(s)) for n, s in readFasta(args.input_fasta)]
+    if args.input_chars is not None:
+        inSeqs.append((args.input_chars, list(args.input_chars)))
+    if args.output_fasta:
+        outSeqs += [(n, list(s)) for n, s in readFasta(args.output_fasta)]
+    if args.output_chars is not None:
+        outSeqs.append((args.output_chars, list(args.output_chars)))
+    if args.input_json:
+        j = json.load(open(args.input_json)); inSeqs.append((j.get("name", ""), list(j["sequence"])))
+    if args.output_json:
+        j = json.load(open(args.output_json)); outSeqs.append((j.get("name", ""), list(j["sequence"])))
+    inputEmpty, outputEmpty = not machine.inputAlphabet(), not machine.outputAlphabet()
+    if not inSeqs and inputEmpty and ((outputEmpty and inferenceRequested) or outSeqs):
+        inSeqs.append(("", []))
+    if not outSeqs and inSeqs and outputEmpty:
+        outSeqs.append(("", []))
+    for iname, iseq in inSeqs:
+        for oname, oseq in outSeqs:
+            data.append(SeqPair(iseq, oseq, iname, oname))
+    if inferenceRequested and not data and inputEmpty and outputEmpty:
+        data.append(SeqPair([], [], "", ""))
+    return data
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+def _gather_in_order(local: List[Any], n: int, rank: int, world: int) -> List[Any]:
+    """Results of round-robin sharded pairs back in input order on every rank (no data-path collective: host gather)."""
+    dist = _dist()
+    if dist is None or world == 1:
+        return local
+    parts: List[Any] = [None] * world
+    dist.all_gather_object(parts, local)
+    out: List[Any] = [None] * n
+    for r in range(world):
+        for k, v in zip(range(r, n, world), parts[r]):
+            out[k] = v
+    return out
+
+
+def run(argv: Optional[List[str]] = None, out=None) -> int:
+    out = out or sys.stdout
+    args = buildParser().parse_args(argv)
+    machine = loadMachine(args)
+    inference = args.loglike or args.viterbi or args.align or args.counts or args.train
+    data = collectData(args, machine, inference)
+    gotData = bool(data)
+    noIO = not machine.inputAlphabet() and not machine.outputAlphabet()
+    if gotData and not inference:
+        raise MachineError("No point in specifying input/output data without --train, --loglike, --counts, --align")
+    funcs: Dict[str, Any] = {}
+    for f in args.functions:
+        funcs.update(json.load(open(f)))
+    seed: Dict[str, Any] = {}
+    for f in args.params:
+        seed.update(json.load(open(f)))
+    constraints = Constraints()
+    for f in args.constraints:
+        c = Constraints.fromJson(json.load(open(f)))
+        constraints = Constraints(constraints.prob + c.prob, constraints.norm + c.norm, constraints.rate + c.rate)
+
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    mine = data[rank::world]                         # pairs are independent units: round-robin shard
+    emit = (lambda s: out.write(s)) if rank == 0 else (lambda s: None)
+
+    from . import dp
+    if args.train:
+        from .fitter import MachineFitter, combineConstraints
+        from .shard import allreduce_counts
+        if not ((args.constraints or not machine.cons.empty()) and (gotData or noIO)):
+            raise MachineError("To fit parameters, please specify a constraints file and (for machines with input/output) a data file")
+        fitter = MachineFitter(machine, constraints, funcs)
+        sd = combineConstraints(machine.cons, constraints).defaultParams(); sd.update(seed)
+        fitter.seed = sd
+        reduce = None
+        if world > 1:
+            import torch
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            reduce = lambda counts, ll: allreduce_counts(counts, ll, dev)
+        params = fitter.fit(mine, args.wiggle_room, reduce)
+        emit("{" + ",".join('"%s":%s' % (escaped(k), fmtParam(params[k])) for k in sorted(params)) + "}\n")
+    else:
+        params = dict(funcs); params.update(seed)
+        for k, v in machine.getParamDefs(args.use_defaults).items():
+            params.setdefault(k, v)
+
+    if args.loglike:
+        ev = EvaluatedMachine.fromMachine(machine, params)
+        ll = _gather_in_order(dp.forwardLogLikeBatch(ev, mine, rolling=True), len(data), rank, world)
+        emit("[" + ",\n ".join('["%s","%s",%s]' % (escaped(sp.inputName), escaped(sp.outputName), fmt(x))
+                                for sp, x in zip(data, ll)) + "]\n")
+
+    if args.counts:
+        ev = EvaluatedMachine.fromMachine(machine, params)
+        counts = dp.MachineCounts(ev, mine)
+        if world > 1:
+            import torch
+            from .shard import allreduce_counts
+            _, counts.loglike = allreduce_counts(counts._flat, counts.loglike, "cuda" if torch.cuda.is_available() else "cpu")
+        pc = counts.paramCounts(machine, params)
+        emit("{" + ",".join('"%s":%s' % (escaped(k), "%g" % pc[k]) for k in sorted(pc)) + "}\n")
+
+    if args.align or args.viterbi:
+        if not gotData:
+            raise MachineError("To align sequences, please specify a data file")
+        ev = EvaluatedMachine.fromMachine(machine, params)
+        res = dp.viterbiBatch(ev, machine, mine)
+        res = _gather_in_order(res, len(data), rank, world)
+        if args.viterbi:
+            emit("[" + ",\n ".join('["%s","%s",%s]' % (escaped(sp.inputName), escaped(sp.outputName), fmt(v))
+                                    for sp, (v, _) in zip(data, res)) + "]\n")
+        if args.align:
+            aligned = [seqPairFromPath(machine, p, sp.inputName, sp.outputName) for sp, (v, p) in zip(data, res) if p is not None]
+            emit("[" + ",\n ".join(seqPairJson(sp) for sp in aligned) + "]\n")
+    return 0
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    try:
+        return run(argv)
+    except (MachineError, OSError, KeyError, ValueError) as e:   # main() of the reference prints what() and fails (boss.cpp:923-926)
+        sys.stderr.write(str(e) + "\n")
+        return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -395,6 +395,30 @@ def forwardLogLikeBatch(machine: EvaluatedMachine, pairs: Sequence[SeqPair], rol
     return out
 
 
+def viterbiBatch(machine: EvaluatedMachine, m: Machine, pairs: Sequence[SeqPair]) -> List[tuple]:
+    """The `--viterbi/--align` loop of target/boss.cpp:822-848 as one device call: per pair (logLike, MachinePath or
+    None); pairs that cannot be tokenised score -inf, and a -inf score has no path."""
+    dm = _device_machine(machine)
+    ok = [machine.canTokenize(sp.input, sp.output) for sp in pairs]
+    toks = [(machine.inputTokenizer.tokenize(sp.input), machine.outputTokenizer.tokenize(sp.output))
+            for sp, k in zip(pairs, ok) if k]
+    out: List[tuple] = [(-math.inf, None)] * len(pairs)
+    if toks:
+        b = capi.DeviceBatch.from_pairs(dm, toks)
+        envs = [Envelope(sp) for sp, k in zip(pairs, ok) if k]      # quirk Q1: aligned pairs use their path envelope
+        if any(not e.isFull() for e in envs):
+            b.set_envelopes([None if e.isFull() else (e.inStart, e.inEnd) for e in envs])
+        ll, off, edges = b.viterbi(paths=True)
+        b.close()
+        j = 0
+        for k, good in enumerate(ok):
+            if good:
+                v = float(ll[j])
+                out[k] = (v, edgesToPath(machine, m, edges[off[j]:off[j + 1]]) if v > -math.inf else None)
+                j += 1
+    return out
+
+
 class MachineCounts:
     """src/counts.h:11-25: E-step sufficient statistics, count[state][transIndex] and loglike."""
 

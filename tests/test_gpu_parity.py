@@ -5,6 +5,7 @@ candidate); Forward/Backward cells and log-likelihoods agree with the oracle's e
 with the reference's table mode to REL_TABLE (the north-star tolerance is 1e-4 relative; both bars are far tighter);
 posterior counts agree to COUNT_TOL (summation order differs: fp64 atomics).
 """
+import json
 import math
 import os
 
@@ -575,3 +576,47 @@ def test_fit_protpsw_recovers_likelihood(capi, machines):
     for g in m.cons.norm:
         assert abs(sum(fit[p] for p in g) - 1.0) < 1e-9
     assert fitter.log[-1] > fitter.log[0] + 1.0
+
+
+# ---- boss-compatible command line (target/boss.cpp:716-847) around the batched device calls --------------------------------
+def _boss(argv):
+    import io
+    from machineboss_amd import boss
+    buf = io.StringIO()
+    assert boss.run(argv, out=buf) == 0
+    return buf.getvalue()
+
+
+def test_boss_cli_reference_outputs(capi):
+    """CLI-level expectations of the reference (Makefile:493-531,567-572): -L / -V text, --align JSON incl. meta.path,
+    --counts parameter counts, --train fits."""
+    mach = lambda n: golden_path("machine", n + ".json")
+    io_ = lambda n: golden_path("io", n + ".json")
+    exp = lambda n: open(golden_path("expect", n + ".json")).read()
+    # test-101-bitnoise-001: boss bitnoise -P params --input-chars 101 --output-chars 001 -L
+    got = json.loads(_boss([mach("bitnoise"), "-P", io_("params"), "--input-chars", "101", "--output-chars", "001", "-L"]))
+    assert got[0][:2] == ["101", "001"] and float("%.4g" % got[0][2]) == json.loads(exp("101-bitnoise-001"))[0][0]   # expectation is name-stripped, 4 digits
+    got = json.loads(_boss([mach("bitstutter-noise"), "-P", io_("params"), "--input-chars", "101", "--output-chars", "0011", "-V"]))
+    assert got[0][:2] == ["101", "0011"] and float("%.3g" % got[0][2]) == json.loads(exp("101-bitstutternoise-vit-0011"))[0][0]
+    got = json.loads(_boss([mach("bitstutter-noise"), "-P", io_("params"), "--input-chars", "101", "--output-chars", "0011", "-L"]))
+    assert float("%.3g" % got[0][2]) == json.loads(exp("101-bitstutternoise-fwd-0011"))[0][0]
+    # test-align-stutter-noise: --align prints the SeqPairList with alignment and meta.path, byte for byte
+    got = _boss([mach("bitstutter-noise"), "-P", io_("params"), "-D", io_("difflen"), "-A"])
+    assert got == exp("align-stutter-noise-difflen")
+    # test-counts: -C prints parameter counts {"p":2,"q":1}
+    got = _boss([mach("bitnoise"), "-P", io_("params"), "--input-chars", "101", "--output-chars", "001", "-C"])
+    assert json.loads(got) == json.loads(exp("counts"))
+    # test-fit-bitnoise-seqpairlist: -T prints the fitted parameters
+    got = json.loads(_boss([mach("bitnoise"), "-N", io_("pqcons"), "-D", io_("seqpairlist"), "-T"]))
+    assert {k: float("%.4g" % v) for k, v in got.items()} == json.loads(exp("fit-bitnoise-seqpairlist"))
+    # a pair the machine cannot tokenise prints "-Infinity" (target/boss.cpp:797-805)
+    got = _boss([mach("bitnoise"), "-P", io_("params"), "--input-chars", "10x", "--output-chars", "001", "-L"])
+    assert '"-Infinity"' in got
+    # presets and --use-defaults: the SURVEY anchor value of protpsw 50x50 is reproduced to the 6 digits boss prints
+    a = load_json("survey_anchors.json")["anchors"][0]
+    m = __import__("machineboss_amd.machine", fromlist=["Machine"]).Machine.fromFile(golden_path("preset", "protpsw.json"))
+    em = __import__("machineboss_amd.evalmachine", fromlist=["EvaluatedMachine"]).EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    x, y = synth_tokens(a["seed"], a["inLen"], a["outLen"], em.nInTok, em.nOutTok)
+    got = json.loads(_boss(["--preset", "protpsw", "--use-defaults", "--input-chars", "".join(em.inputTokenizer.detokenize(x)),
+                            "--output-chars", "".join(em.outputTokenizer.detokenize(y)), "-L"]))
+    assert got[0][2] == float("%.6g" % a["forward"])
