@@ -120,6 +120,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
        << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
+       << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0)
        << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow

@@ -93,6 +93,9 @@ __device__ __forceinline__ void med_copy_out(double *dstp, const double *cur, in
     if (j + 1 < S) { d2a8 v; v.x = cur[j]; v.y = cur[j + 1]; *(d2a8 *)(dstp + j) = v; }
     else if (j < S) dstp[j] = cur[j];
   }
+#elif JSTORENT
+#pragma unroll
+  for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) __builtin_nontemporal_store(cur[j], dstp + j); }
 #else
 #pragma unroll
   for (int j0 = 0; j0 < S; j0 += LPG) { const int j = j0 + q; if (j < S) dstp[j] = cur[j]; }

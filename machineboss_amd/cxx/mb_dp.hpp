@@ -76,21 +76,72 @@ struct TokSeqPair {                       // a tokenised SeqPair (Tokenizer::tok
 
 struct PathStep { StateIndex src; size_t transIndex; };   // MachinePath as (state, index into its transition list)
 
+// Envelope (src/seqpair.h:75-97): cell (x,y) exists <=> inStart[y] <= x < inEnd[y].  An alignment column is
+// (gotInput, gotOutput); initPath / initPathArea restate src/seqpair.cpp:134-182.
+struct Envelope {
+  typedef std::pair<bool, bool> AlignCol;
+  long inLen = 0, outLen = 0;
+  std::vector<int32_t> inStart{0}, inEnd{1};
+  void clear() { inLen = outLen = 0; inStart.assign(1, 0); inEnd.assign(1, 1); }
+  void initFull(long il, long ol) { inLen = il; outLen = ol; inStart.assign(ol + 1, 0); inEnd.assign(ol + 1, (int32_t)il + 1); }
+  void initPath(const std::vector<AlignCol> &cols) {
+    clear();
+    for (const AlignCol &c : cols) {
+      if (!c.first && c.second) { inStart.push_back(inEnd.back() - 1); inEnd.push_back(inEnd.back()); ++outLen; }
+      else if (c.first && !c.second) { ++inEnd.back(); ++inLen; }
+      else if (c.first && c.second) { inStart.push_back(inEnd.back()); inEnd.push_back(inEnd.back() + 1); ++inLen; ++outLen; }
+    }
+  }
+  void initPathArea(const std::vector<AlignCol> &cols, size_t width) {
+    clear();
+    std::vector<int32_t> match; std::vector<size_t> nBefore(1, 0);
+    for (const AlignCol &c : cols) {
+      if (c.first && c.second) match.push_back((int32_t)inLen);
+      if (c.first) ++inLen;
+      if (c.second) { ++outLen; nBefore.push_back(match.size()); }
+    }
+    inStart.clear(); inEnd.clear();
+    for (long j = 0; j <= outLen; ++j) {
+      int32_t iStart = 0, iEnd = (int32_t)inLen + 1;
+      if (nBefore[j] > width) iStart = match[nBefore[j] - width - 1] + 1;
+      if (match.size() - nBefore[j] > width) iEnd = match[nBefore[j] + width] + 1;
+      inStart.push_back(iStart); inEnd.push_back(iEnd);
+    }
+  }
+  bool contains(long x, long y) const { return y >= 0 && y <= outLen && x >= inStart[y] && x < inEnd[y]; }
+  bool fits(const TokSeqPair &sp) const { return inLen == (long)sp.input.size() && outLen == (long)sp.output.size(); }
+  bool isFull() const {
+    for (long y = 0; y <= outLen; ++y) if (inStart[y] != 0 || inEnd[y] != inLen + 1) return false;
+    return true;
+  }
+  std::vector<long long> offsets() const {     // src/seqpair.cpp:195-204
+    std::vector<long long> r(1, 0);
+    for (long y = 0; y <= outLen; ++y) r.push_back(r.back() + inEnd[y] - inStart[y]);
+    return r;
+  }
+};
+
 // DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163)
 class DPMatrix {
 protected:
   std::vector<double> cellStorage;
   void fill(int mode, int startState) {
     cellStorage.resize((size_t)(inLen + 1) * (outLen + 1) * nStates);
-    check(mb_fill(machine.device(), mode, seqPair.input.data(), inLen, seqPair.output.data(), outLen, startState, cellStorage.data()));
+    if (!env.fits(seqPair)) throw std::runtime_error("Envelope/sequence mismatch");      // DPMatrix::alloc, src/dpmatrix.defs.h:31
+    const bool full = env.isFull();
+    check(mb_fill_env(machine.device(), mode, seqPair.input.data(), inLen, seqPair.output.data(), outLen, startState,
+                      full ? nullptr : env.inStart.data(), full ? nullptr : env.inEnd.data(), cellStorage.data()));
   }
 public:
   const FlatMachine &machine;
   const TokSeqPair &seqPair;
   const long inLen, outLen;
   const StateIndex nStates;
+  Envelope env;     // the caller's glue passes Envelope(seqPair): path envelope of an aligned pair, else full (quirk Q1)
   DPMatrix(const FlatMachine &m, const TokSeqPair &sp)
-      : machine(m), seqPair(sp), inLen((long)sp.input.size()), outLen((long)sp.output.size()), nStates(m.nStates) {}
+      : machine(m), seqPair(sp), inLen((long)sp.input.size()), outLen((long)sp.output.size()), nStates(m.nStates) { env.initFull(inLen, outLen); }
+  DPMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e)
+      : machine(m), seqPair(sp), inLen((long)sp.input.size()), outLen((long)sp.output.size()), nStates(m.nStates), env(e) {}
   double cell(long inPos, long outPos, StateIndex state) const {
     if (inPos < 0 || inPos > inLen || outPos < 0 || outPos > outLen) return -std::numeric_limits<double>::infinity();
     return cellStorage[((size_t)outPos * (inLen + 1) + inPos) * nStates + state];
@@ -102,18 +153,21 @@ public:
 class ForwardMatrix : public DPMatrix {      // src/forward.h:19-27
 public:
   ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, StateIndex startState = 0) : DPMatrix(m, sp) { fill(MB_FORWARD, (int)startState); }
+  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e, StateIndex startState = 0) : DPMatrix(m, sp, e) { fill(MB_FORWARD, (int)startState); }
   double logLike() const { return endCell(); }
 };
 
 class BackwardMatrix : public DPMatrix {     // src/backward.h:44-59
 public:
   BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp) : DPMatrix(m, sp) { fill(MB_BACKWARD, 0); }
+  BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : DPMatrix(m, sp, e) { fill(MB_BACKWARD, 0); }
   double logLike() const { return startCell(); }
 };
 
 class ViterbiMatrix : public DPMatrix {      // src/viterbi.h:9-18
 public:
   ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp) : DPMatrix(m, sp) { fill(MB_VITERBI, 0); }
+  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : DPMatrix(m, sp, e) { fill(MB_VITERBI, 0); }
   double logLike() const { return endCell(); }
   std::vector<PathStep> path() const {       // traceBack (src/dpmatrix.defs.h:61-110), run on the device
     if (!(endCell() > -std::numeric_limits<double>::infinity())) throw std::runtime_error("Can't do traceback: no finite-weight paths");
@@ -152,7 +206,8 @@ struct MachineCounts {
     count.assign(m.nStates, {});
     for (int s = 0; s < m.nStates; ++s) count[s].assign(m.transOffset[s + 1] - m.transOffset[s], 0.0);
   }
-  std::vector<double> add(const FlatMachine &m, const std::vector<TokSeqPair> &pairs) {
+  // envelopes: empty = all full; otherwise one per pair (MachineCounts(eval, seqPairList, envelopes), src/counts.cpp:37-43)
+  std::vector<double> add(const FlatMachine &m, const std::vector<TokSeqPair> &pairs, const std::vector<Envelope> &envelopes = {}) {
     std::vector<InputToken> in; std::vector<OutputToken> out;
     std::vector<int64_t> inOff(1, 0), outOff(1, 0);
     for (const TokSeqPair &sp : pairs) {
@@ -161,7 +216,23 @@ struct MachineCounts {
     }
     std::vector<double> flat(m.nTransitions(), 0.0), ll(pairs.size(), 0.0);
     double s = 0;
-    check(mb_counts_batch(m.device(), (int64_t)pairs.size(), in.data(), inOff.data(), out.data(), outOff.data(), flat.data(), &s, ll.data()));
+    mb_batch *b = mb_batch_create(m.device(), (int64_t)pairs.size(), in.data(), inOff.data(), out.data(), outOff.data());
+    if (!b) throw std::runtime_error(mb_last_error());
+    int rc = 0;
+    if (!envelopes.empty()) {
+      if (envelopes.size() != pairs.size()) { mb_batch_destroy(b); throw std::runtime_error("Envelope/training set mismatch"); }
+      std::vector<int64_t> envOff(1, 0); std::vector<int32_t> st(1, 0), en(1, 0);
+      st.clear(); en.clear();
+      for (const Envelope &e : envelopes) {
+        if (!e.isFull()) { st.insert(st.end(), e.inStart.begin(), e.inStart.end()); en.insert(en.end(), e.inEnd.begin(), e.inEnd.end()); }
+        envOff.push_back((int64_t)st.size());
+      }
+      if (st.empty()) { st.push_back(0); en.push_back(0); }
+      rc = mb_batch_set_envelopes(b, envOff.data(), st.data(), en.data());
+    }
+    if (!rc) rc = mb_batch_counts(b, flat.data(), &s, ll.data());
+    mb_batch_destroy(b);
+    check(rc);
     for (size_t e = 0; e < flat.size(); ++e) count[m.src[e]][m.transIndex[e]] += flat[e];
     loglike += s;
     return ll;

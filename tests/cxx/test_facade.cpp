@@ -17,6 +17,16 @@ int main() {
   const bool ok = std::fabs(fwd.logLike() + 4.6253) < 1e-4 && std::fabs(bwd.logLike() + 4.6253) < 1e-4 && vit.path().size() == 3 &&
                   std::fabs(mc.count[0][0] - 1) < 1e-9 && std::fabs(mc.count[0][3]) < 1e-12 && std::fabs(fwd.cell(1, 1, 0) + 4.6052) < 1e-4 &&
                   std::isinf(fwd.cell(0, 1, 0));
-  std::printf(ok ? "FACADE OK\n" : "FACADE MISMATCH\n");
-  return ok ? 0 : 1;
+  // path envelope of the alignment 0/1 0/0 1/1 (t/io/tinypath.json -> t/expect/tinypath_path_env.json [[0,1],[1,2],[2,3],[3,4]])
+  Envelope env; env.initPath({{true, true}, {true, true}, {true, true}});
+  const bool envOk = env.inStart == std::vector<int32_t>({0, 1, 2, 3}) && env.inEnd == std::vector<int32_t>({1, 2, 3, 4}) && env.fits(sp) && !env.isFull();
+  ForwardMatrix fenv(m, sp, env);
+  MachineCounts mce(m); mce.add(m, {sp}, {env});
+  const bool envDp = std::fabs(fenv.logLike() + 4.6253) < 1e-4 && std::isinf(fenv.cell(1, 0, 0)) && std::fabs(mce.count[0][0] + mce.count[0][1] + mce.count[0][2] + mce.count[0][3] - 3) < 1e-9;
+  Envelope area; area.initPathArea({{true, true}, {true, true}, {true, true}}, 1);
+  const bool areaOk = area.inStart == std::vector<int32_t>({0, 0, 1, 2}) && area.inEnd == std::vector<int32_t>({2, 3, 4, 4});
+  std::printf("env %d %d %d\n", (int)envOk, (int)envDp, (int)areaOk);
+  const bool all = ok && envOk && envDp && areaOk;
+  std::printf(all ? "FACADE OK\n" : "FACADE MISMATCH\n");
+  return all ? 0 : 1;
 }

@@ -79,3 +79,30 @@ def test_counts_allreduce_world2():
         ref_ll += om.counts_add(x, y, ref)
     for rank, counts, ll in res:
         assert np.allclose(counts, ref, rtol=1e-12, atol=1e-14) and abs(ll - ref_ll) <= 1e-12 * abs(ref_ll)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from machineboss_amd.boss import _gather_in_order
+    n = 7
+    mine = ["pair%d" % k for k in range(rank, n, world)]      # the CLI's round-robin shard (boss.py: data[rank::world])
+    q.put((rank, _gather_in_order(mine, n, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_cli_results_gathered_in_input_order_world2():
+    """`boss --loglike/--viterbi/--align` on N ranks: pairs are dealt round-robin, results come back in input order
+    (no data-path collective; a host-side object gather)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, got in res:
+        assert got == ["pair%d" % k for k in range(7)]
