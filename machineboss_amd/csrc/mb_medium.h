@@ -74,6 +74,7 @@ struct MedProgram {
   uint32_t dummyOff = 0;            // byte offset of the write-only dummy entry of an LDS state vector
   std::vector<MedRoundInfo> roundInfo;
   std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (slots placed in LDS by medium_jit_plan)
+  int regUsed = 0;                      // what the last plan spent of it
   int regBudget = -1;                   // VGPRs medium_jit_plan may spend on loop-invariant records (-1: default)
   int tokWindow = 64;                   // steps per output-token window kept in LDS by the specialised kernel
   int *d_desc = nullptr;

@@ -72,7 +72,7 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
     return true;
   };
   auto toReg = [&](MedRoundInfo &ri, size_t k) {
-    const int cost = 3 + (k == 0 ? 1 : 0);
+    const int cost = 3 + (k == 0 ? 1 : 0) + (P.counting ? 1 : 0);   // count programs: + one fp32 usage accumulator per record
     if (cost > regFree) return false;
     ri.slots[k].place = MED_PLACE_REG; regFree -= cost;
     return true;
@@ -91,6 +91,7 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
   for (MedRoundInfo &ri : P.roundInfo)
     for (size_t k = 0; k < ri.slots.size(); ++k)
       if (ri.slots[k].T == 3 && !toReg(ri, k)) toLds(ri.slots[k]);
+  P.regUsed = P.regBudget - regFree;
   // pass 3: leftovers (input-token records beyond the VGPR budget, match tables) -> LDS if they still fit
   for (MedRoundInfo &ri : P.roundInfo)
     for (MedSlotInfo &sl : ri.slots)
@@ -113,7 +114,7 @@ long long medium_jit_spill_count(const std::string &code) {
 }
 
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode) {
-  std::ostringstream defs, pre, body;
+  std::ostringstream defs, pre, body, post;
   const int S = m->S;
   const bool counting = mode == MED_MODE_COUNT;
   const int threads = geo.waves * 64;
@@ -146,6 +147,17 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         body << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
       return name;
     };
+    // count mode: usage term exp(v + bl) of candidate k.  A record that sits in VGPRs names the same transition for the
+    // whole sweep, so its usage is summed in a register (fp32, at most one tile of steps) and reaches the workgroup's
+    // LDS accumulator once, after the step loop; the others add to LDS per step (ds_add_f64).
+    auto countTerm = [&](const MedSlotInfo &sl, const std::string &name, int k) {
+      if (sl.place == MED_PLACE_REG) {
+        pre << "  float acc_" << name << " = 0.0f;\n";
+        body << "        acc_" << name << " += ex2(v" << k << " + bl);\n";
+        post << "  cnt_flush(ldsb, accBase + (" << name << ".srcOff >> 16), acc_" << name << ");\n";
+      } else
+        body << "        cnt_add(ldsb, accBase + (" << name << ".srcOff >> 16), v" << k << " + bl);\n";
+    };
     std::vector<std::string> nm(n);
     if (n <= JIT_MAX_CANDS) {
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
@@ -165,8 +177,8 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       }
       body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = res;\n";
       if (counting) {   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
-        body << "        const double bl = active ? (med_lds(ldsb, aB + (int)" << nm[0] << ".dstOff) + negLL) : NEG_INF;\n";
-        for (int k = 0; k < n; ++k) body << "        cnt_add(ldsb, accBase + (" << nm[k] << ".srcOff >> 16), v" << k << " + bl);\n";
+        body << "        const double bl = med_lds(ldsb, aB + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
+        for (int k = 0; k < n; ++k) countTerm(ri.slots[k], nm[k], k);
       }
     } else {
       // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
@@ -179,8 +191,8 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         for (int k = k0; k < k1; ++k)
           body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
         if (counting) {
-          body << "        const double bl = active ? (med_lds(ldsb, aB + (int)dstOff) + negLL) : NEG_INF;\n";
-          for (int k = k0; k < k1; ++k) body << "        cnt_add(ldsb, accBase + (" << nm[k] << ".srcOff >> 16), v" << k << " + bl);\n";
+          body << "        const double bl = med_lds(ldsb, aB + (int)(active ? dstOff : (unsigned)JDUMMYOFF)) + negLL;\n";
+          for (int k = k0; k < k1; ++k) countTerm(ri.slots[k], nm[k], k);
         }
         body << "        double mx = v" << k0 << ";\n";
         for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
@@ -207,6 +219,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   replace("/*@DEFS@*/", defs.str());
   replace("/*@PRE@*/", pre.str());
   replace("/*@BODY@*/", body.str());
+  replace("/*@POST@*/", post.str());
   return src;
 }
 
@@ -255,7 +268,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
     if (spills <= 0 || P.regBudget == 0) break;
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.
-    P.regBudget = std::max(0, P.regBudget - std::max(9, (int)spills / 2));
+    P.regBudget = std::max(0, std::min(P.regBudget, P.regUsed) - std::max(9, (int)spills + 3));   // cut from what the plan really spent
     medium_jit_plan(m, P, geo);
     if (!medium_refresh_weights(m, P)) return false;
     for (MedJit &O : P.jit) {

@@ -8,7 +8,7 @@
 // mb_medium_jit.cpp), so a step issues no global load besides the halo supercell.  Semantics are identical to k_medium_tile
 // (tests run both and compare); if hiprtc is unavailable the engine silently keeps the ahead-of-time kernel.
 //
-// Markers replaced by the generator (mb_medium_jit.cpp):  /*@DEFS@*/  /*@PRE@*/  /*@BODY@*/
+// Markers replaced by the generator (mb_medium_jit.cpp):  /*@DEFS@*/  /*@PRE@*/  /*@BODY@*/  /*@POST@*/
 #pragma once
 
 namespace mb {
@@ -65,6 +65,9 @@ __device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((
 // count mode: add exp(x) to the LDS accumulator at byte offset off (ds_add_f64; lanes of one column never collide)
 __device__ __forceinline__ void cnt_add(const char *ldsb, unsigned off, double x) {
   (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)ex2(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void cnt_flush(const char *ldsb, unsigned off, float acc) {
+  (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void med_block_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -240,6 +243,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   constexpr int JBV = (S + LPG - 1) / LPG;
   const int aB = (int)((const char *)bvec - ldsb) + c * colStride;
   const unsigned accBase = (unsigned)((const char *)accL - ldsb);
+  if (q == 0) bvec[c * Spad + JDUMMYOFF / 8] = NEG_INF;   // read by inactive columns: their terms become exp(-inf) = 0
   {  // Backward supercell of the first step
     const int o0 = min(max(t0 - c, 0), outLen);
     const double *bs = cellPtrB(min(i, inLen), o0);
@@ -337,6 +341,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     slotCur = (slotCur + 1) % NS;
   }
 #if JMODE == 2
+  // usage summed in registers over the tile's steps (records held in VGPRs) -> the workgroup's LDS accumulators
+/*@POST@*/
+  __syncthreads();
   // flush the workgroup's counts: one fp64 atomic per transition that was used in this tile
   for (int e = tid; e < JNTRANS; e += NT) {
     const double x = accL[e];
