@@ -620,3 +620,53 @@ def test_boss_cli_reference_outputs(capi):
     got = json.loads(_boss(["--preset", "protpsw", "--use-defaults", "--input-chars", "".join(em.inputTokenizer.detokenize(x)),
                             "--output-chars", "".join(em.outputTokenizer.detokenize(y)), "-L"]))
     assert got[0][2] == float("%.6g" % a["forward"])
+
+
+# ---- BASELINE.json configurations at FULL size: size-independent properties (the oracle would need hours) -----------------
+def _count_invariants(em, counts, nPairs, inLen, outLen):
+    """Expected usage of input-consuming transitions sums to the number of input symbols (likewise output): every
+    path of a pair reads each symbol exactly once."""
+    cin = counts[np.asarray(em.inTok) != 0].sum(); cout = counts[np.asarray(em.outTok) != 0].sum()
+    # posterior = exp(F + w + B - logLike): the fp32 correction terms of the tiled fills leave ~1e-6 absolute error in
+    # F + B - logLike after a few thousand steps, i.e. ~1e-6..5e-6 relative in every count (measured 2e-6 at 1 kb x 1 kb)
+    tol = 2e-5
+    return abs(cin - nPairs * inLen) <= tol * nPairs * inLen and abs(cout - nPairs * outLen) <= tol * nPairs * outLen
+
+
+@pytest.mark.parametrize("preset,config,nPairs,il,ol", [("dnapsw", 2, 1024, 1000, 1000), ("protpsw", 3, 1024, 400, 400),
+                                                       ("psw2dna", 4, 16, 487, 10000)])
+def test_baseline_configs_full_size_properties(capi, machines, preset, config, nPairs, il, ol):
+    """configs[1] (dnapsw, 1024 x 1 kb), configs[2] per GPU (protpsw, 1024 x 400 aa) and configs[3] (psw2dna, 10 kb DNA):
+    rolling == materialised Forward; Viterbi <= Forward; duplicated pairs give identical results; the Viterbi path
+    re-scores to the Viterbi log-likelihood and spells both sequences; counts obey the symbol-count invariant and the
+    summed Forward log-likelihood equals the Forward pass's."""
+    m, em = machines(preset, None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    inTok, inOff, outTok, outOff = synth_batch(config, nPairs, il, ol, em.nInTok, em.nOutTok)
+    # make pair 1 a copy of pair 0: identical inputs must give bit-identical outputs wherever they run
+    inTok[inOff[1]:inOff[2]] = inTok[inOff[0]:inOff[1]]; outTok[outOff[1]:outOff[2]] = outTok[outOff[0]:outOff[1]]
+    b = capi.DeviceBatch(dm, inTok, inOff, outTok, outOff)
+    assert b.cells() == nPairs * (il + 1) * (ol + 1) * em.nStates
+    llm = b.forward(capi.MB_MATERIALISE); llr = b.forward(capi.MB_ROLLING)
+    assert "k_medium_jit" in capi.last_kernel_name()
+    assert np.all(np.isfinite(llm)) and close(llr, llm, 1e-12) and llm[0] == llm[1] and llr[0] == llr[1]
+    npv = min(nPairs, 64)    # tracebacks of a sub-batch (the fill of all pairs is checked through the log-likelihoods)
+    bv = capi.DeviceBatch(dm, inTok[:inOff[npv]], inOff[:npv + 1], outTok[:outOff[npv]], outOff[:npv + 1])
+    vll, off, edges = bv.viterbi()
+    assert np.all(vll <= llm[:npv] + 1e-9) and vll[0] == vll[1]
+    lw = np.asarray(em.logWeight)
+    for k in (0, 1, npv - 1):
+        e = edges[off[k]:off[k + 1]]
+        # path is contiguous start -> end, spells the pair, and its weight IS the Viterbi score (summed in path order)
+        assert em.src[e[0]] == 0 and em.dst[e[-1]] == em.nStates - 1 and np.array_equal(em.dst[e[:-1]], em.src[e[1:]])
+        assert np.array_equal(em.inTok[e][em.inTok[e] != 0], inTok[inOff[k]:inOff[k + 1]])
+        assert np.array_equal(em.outTok[e][em.outTok[e] != 0], outTok[outOff[k]:outOff[k + 1]])
+        acc = 0.0
+        for w in lw[e]:
+            acc += w
+        assert abs(acc - vll[k]) <= 1e-9 * abs(vll[k])
+    nc = min(nPairs, 256 if preset != "psw2dna" else 4)
+    bc = capi.DeviceBatch(dm, inTok[:inOff[nc]], inOff[:nc + 1], outTok[:outOff[nc]], outOff[:nc + 1])
+    counts, s, cll = bc.counts()
+    assert _count_invariants(em, counts, nc, il, ol)
+    assert close(cll, llm[:nc], 1e-8) and abs(s - cll.sum()) <= 1e-9 * abs(s)
