@@ -7,8 +7,9 @@
 Restates the data-handling and inference section of /root/reference/target/boss.cpp:716-847 -- how sequences are
 collected into pairs, how parameters are assembled, and the exact output text of --loglike / --viterbi / --align /
 --counts / --train -- around the batched GPU calls.  The real `boss` needs Boost and cannot run on the GPU box; the
-machine-expression language of its command line (compose, concatenate, ...: machine algebra, out of scope) is not
-here: the machine is ONE JSON transducer file or ONE preset.
+machine-expression language of its command line is reduced to what assembles the benchmark machines: several
+transducer files / presets on one command line are COMPOSED (algebra.py = Machine::compose); the other operators
+(concatenate, union, Kleene closures, ...) are not here.
 
 Numbers print like C++ `ostream << double` (6 significant digits, target/boss.cpp:794-807 via src/jsonio.h:14-22),
 parameters with 15 (src/weight.cpp:483).  Work is batched: all pairs go through one device call per mode; with
@@ -116,7 +117,7 @@ def seqPairFromPath(m: Machine, path, inputName: str, outputName: str) -> SeqPai
 def buildParser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="boss", description=__doc__.split("\n\n")[0])
     ap.add_argument("machine", nargs="*", help="transducer JSON file")
-    ap.add_argument("--preset", help="preset name (dnapsw, protpsw, psw2dna, translate)")
+    ap.add_argument("--preset", action="append", default=[], help="preset name (dnapsw, protpsw, psw2dna, translate); repeatable")
     ap.add_argument("-P", "--params", action="append", default=[])
     ap.add_argument("-F", "--functions", action="append", default=[])
     ap.add_argument("-N", "--constraints", action="append", default=[])
@@ -134,18 +135,22 @@ def buildParser() -> argparse.ArgumentParser:
     return ap
 
 
+def loadPreset(name: str) -> Machine:
+    for d in PRESET_DIRS:
+        p = os.path.join(d, name + ".json")
+        if d and os.path.exists(p):
+            return Machine.fromFile(p)
+    raise MachineError("Unknown preset %s" % name)
+
+
 def loadMachine(args) -> Machine:
-    if args.preset:
-        if args.machine:
-            raise MachineError("machine algebra (several machines on one command line) is outside the DP path: give one machine")
-        for d in PRESET_DIRS:
-            p = os.path.join(d, args.preset + ".json")
-            if d and os.path.exists(p):
-                return Machine.fromFile(p)
-        raise MachineError("Unknown preset %s" % args.preset)
-    if len(args.machine) != 1:
-        raise MachineError("give exactly one transducer JSON file (machine algebra is outside the DP path)")
-    return Machine.fromFile(args.machine[0])
+    """Several machines on one command line are composed, right to left (target/boss.cpp:268-276, 628-634); presets come
+    first, in the order given."""
+    from .algebra import composeAll
+    machines = [loadPreset(n) for n in args.preset] + [Machine.fromFile(f) for f in args.machine]
+    if not machines:
+        raise MachineError("Please specify a transducer")
+    return composeAll(machines)
 
 
 def collectData(args, machine: Machine, inferenceRequested: bool) -> List[SeqPair]:

@@ -1,0 +1,89 @@
+"""CPU tests of transducer composition (machineboss_amd/algebra.py) against the reference's expected machines
+(Makefile:247-270 COMPOSE_TESTS: `boss A.json B.json` prints the composition) and its probe numbers."""
+import json
+
+import pytest
+
+from conftest import golden_path, load_json
+from machineboss_amd import algebra as A
+from machineboss_amd.evalmachine import EvaluatedMachine
+from machineboss_amd.machine import Constraints, Machine, MachineError
+
+
+def _norm(j):
+    """An expected machine file, normalised like algebra.machineToJson (state numbers, default weights dropped)."""
+    out = {"state": []}
+    for n, s in enumerate(j["state"]):
+        sj = {"n": n}
+        if "id" in s:
+            sj["id"] = s["id"]
+        tr = []
+        for t in s.get("trans", []):
+            tj = {"to": t["to"]}
+            if t.get("in"): tj["in"] = t["in"]
+            if t.get("out"): tj["out"] = t["out"]
+            if "weight" in t and not A.wIsOne(t["weight"]): tj["weight"] = A.weightToJson(A._canon(t["weight"]))
+            tr.append(tj)
+        if tr:
+            sj["trans"] = tr
+        out["state"].append(sj)
+    for k in ("defs", "cons"):
+        if k in j:
+            out[k] = j[k]
+    return out
+
+
+M = lambda n: Machine.fromFile(golden_path("machine", n + ".json"))
+P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+
+
+@pytest.mark.parametrize("a,b,expect,showParams", [
+    ("bitecho", "bitecho", "bitecho-bitecho", False), ("bitecho", "bitstutter", "bitecho-bitstutter", False),
+    ("bitstutter", "bitstutter", "bitstutter-bitstutter", False), ("bitnoise", "bitnoise", "bitnoise-bitnoise", True),
+    ("unitindel", "unitindel", "unitindel-unitindel", True)])
+def test_compose_reference_goldens(a, b, expect, showParams):
+    """State order (advanceSort, incl. the null-padding retry), state names, symbolic weights (sums of products with the
+    reference's simplifications) and merged defs/cons are exactly the reference's."""
+    got = A.machineToJson(A.compose(M(a), M(b)), showParams)
+    assert got == _norm(load_json("expect", expect + ".json"))
+
+
+def test_compose_matches_shipped_composition():
+    """t/machine/bitstutter-noise.json is bitstutter composed with bitnoise (test-align-stutter-noise, Makefile:515)."""
+    assert A.machineToJson(A.compose(M("bitstutter"), M("bitnoise"))) == A.machineToJson(M("bitstutter-noise"))
+
+
+def test_compose_presets_probe_numbers():
+    """protpsw.translate = 177 states / 1502 transitions / 5 silent levels; the literal three-way
+    composition aborts on shared parameter names; with dnapsw's constraints cleared it has 482 states / 3095 transitions."""
+    pt = A.compose(P("protpsw"), P("translate"))
+    em = EvaluatedMachine.fromMachine(pt, None, useDefaults=True)
+    assert (em.nStates, em.nTransitions, int(em.silentLevels().max()) + 1) == (177, 1502, 5)
+    with pytest.raises(MachineError, match="Inconsistent constraints for eqmA"):
+        A.compose(pt, P("dnapsw"))
+    d = P("dnapsw"); d.cons = Constraints()
+    ptd = A.compose(pt, d)
+    assert (len(ptd.state), ptd.nTransitions()) == (482, 3095) and ptd.isAdvancingMachine()
+    assert A.composeAll([P("protpsw"), P("translate")]).nTransitions() == 1502
+
+
+def test_weight_algebra_simplifications():
+    """src/weight.cpp:137-182."""
+    assert A.wMultiply(1, "p") == "p" and A.wMultiply("p", 1.0) == "p" and A.wMultiply(0, "p") == 0
+    assert A.wMultiply(2, 3) == 6 and A.wMultiply(0.5, 4) == 2.0 and A.wMultiply("p", "q") == {"*": ["p", "q"]}
+    assert A.wAdd(0, "p") == "p" and A.wAdd(1, 2) == 3 and A.wAdd("p", {"-": [0, "q"]}) == {"-": ["p", "q"]}
+    assert A.weightToJson(A.wGeometricSum("p")) == {"geomsum": "p"} and A.weightToJson(A.wNegate("p")) == {"not": "p"}
+    assert A._canon({"not": "p"}) == {"-": [1, "p"]}
+
+
+def test_silent_cycle_summation():
+    """advancingMachine (src/machine.cpp:1177-1230): a silent back-transition is summed out as a geometric series."""
+    m = Machine.fromJson({"state": [{"id": "a", "trans": [{"to": "b"}]},
+                                     {"id": "b", "trans": [{"to": "a", "weight": "r"}, {"to": "c", "out": "x", "weight": "s"}]},
+                                     {"id": "c"}]})
+    assert not m.isAdvancingMachine()
+    am = A.advancingMachine(m)
+    assert am.isAdvancingMachine() and len(am.state) == 3
+    # state b: b -> a -> b is a silent self-loop of weight r: exits are scaled by 1/(1-r)
+    w = [t.weight for t in am.state[1].trans if t.out == "x"][0]
+    assert A.weightToJson(A._canon(w)) == {"*": [{"geomsum": "r"}, "s"]}

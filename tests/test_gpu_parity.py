@@ -670,3 +670,34 @@ def test_baseline_configs_full_size_properties(capi, machines, preset, config, n
     counts, s, cll = bc.counts()
     assert _count_invariants(em, counts, nc, il, ol)
     assert close(cll, llm[:nc], 1e-8) and abs(s - cll.sum()) <= 1e-9 * abs(s)
+
+
+# ---- machines assembled by composition (algebra.py = Machine::compose) through the DP engine -------------------------------
+def test_composed_machines_through_gpu(capi, oracle_mod):
+    """protpsw . translate (177 states, composed here) and the cons-stripped three-way protpsw . translate . dnapsw
+    (482 states, BASELINE config 4b): Viterbi bit-exact, Forward/Backward within the tiled tolerance, tracebacks and
+    counts vs the oracle -- and the reference's `boss bitstutter.json bitnoise.json ... -A` CLI golden."""
+    from machineboss_amd import algebra as A
+    from machineboss_amd.machine import Constraints, Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    pt = A.compose(P("protpsw"), P("translate"))
+    d = P("dnapsw"); d.cons = Constraints()
+    for mach, il, ol in ((pt, 7, 33), (A.compose(pt, d), 5, 18)):
+        em = EvaluatedMachine.fromMachine(mach, None, useDefaults=True)
+        om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+        x, y = synth_tokens(12, il, ol, em.nInTok, 3)      # DNA over {A,C,G}: no stop codons, which translate cannot emit
+        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+        assert "k_medium" in capi.last_kernel_name() and V[-1, -1, -1] > -math.inf
+        assert np.array_equal(V, om.viterbi(x, y))
+        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        assert close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+        vll, off, edges = b.viterbi()
+        assert np.array_equal(edges, om.traceback(x, y, om.viterbi(x, y)))
+        counts, s, _ = b.counts()
+        ref = np.zeros(em.nTransitions); om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+        assert close(counts, ref, 1e-5, 1e-7)
+    got = _boss([golden_path("machine", "bitstutter.json"), golden_path("machine", "bitnoise.json"), "-P", golden_path("io", "params.json"),
+                 "-D", golden_path("io", "difflen.json"), "-A"])
+    assert got == open(golden_path("expect", "align-stutter-noise-difflen.json")).read()
