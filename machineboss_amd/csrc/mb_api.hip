@@ -166,16 +166,35 @@ static FastState *fast_state(mb_machine *m) {
       long long nSilent = 0;
       for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
       const bool wantClosure = env_int("MB_MEDIUM_CLOSURE", 1) != 0;
+      // the silent closure trades levels (one wave-level LDS round trip each) for candidates; on machines whose silent
+      // sub-graph is deep AND dense (protpsw.translate.dnapsw: 22 levels, 551 silent edges -> 832 closure slots against
+      // 91) the levelled program is cheaper.  Cost model: candidate slots + 6 per synchronisation point.
+      auto cost = [](const MedProgram &P) {
+        long long c = 0;
+        for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + (ri.sync ? 6 : 0);
+        return c;
+      };
       bool ok = medium_build(m, false, false, G, f->fwdExact, f->geoFE);
       if (ok) {
         bool clos = wantClosure;
         ok = medium_build(m, false, clos, G, f->fwdSum, f->geoFS);
-        if (ok && clos && f->fwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, false, false, G, f->fwdSum, f->geoFS); }
+        if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] forward program cost: closure %lld (pairs %d), levelled %lld\n", cost(f->fwdSum), f->fwdSum.nPairs, cost(f->fwdExact));
+        if (ok && clos && (f->fwdSum.nPairs > 4 * nSilent + m->S || cost(f->fwdSum) > cost(f->fwdExact))) {
+          medium_free(f->fwdSum);
+          ok = medium_build(m, false, false, G, f->fwdSum, f->geoFS);
+        }
       }
       if (ok) {
         bool clos = wantClosure;
         ok = medium_build(m, true, clos, G, f->bwdSum, f->geoBS);
-        if (ok && clos && f->bwdSum.nPairs > 4 * nSilent + m->S) { clos = false; ok = medium_build(m, true, false, G, f->bwdSum, f->geoBS); }
+        if (ok && clos) {
+          MedProgram ex; MedGeom gex;
+          const bool okx = medium_build_host(m, true, false, G, ex, gex);
+          if (f->bwdSum.nPairs > 4 * nSilent + m->S || (okx && cost(f->bwdSum) > cost(ex))) {
+            medium_free(f->bwdSum);
+            ok = medium_build(m, true, false, G, f->bwdSum, f->geoBS);
+          }
+        }
       }
       f->mediumOk = ok;
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {

@@ -100,7 +100,8 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
 // mapping for machines with a handful of states (dnapsw, protpsw: 8 states).
 inline bool medium_valid_G(int G) { return G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
 inline int medium_default_G(int S) {   // measured with the specialised kernel: psw2dna (271 states) G=4 (8 wavefronts x 256 VGPRs) >= 2 > 1
-  return S >= 1024 ? 1 : (S >= 512 ? 2 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32)));   // dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
+  // protpsw.translate.dnapsw (482 states, 22 silent levels): G=1 (171 G cells/s) > 2 (157) > 4 (141); dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
+  return S >= 384 ? 1 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32));
 }
 inline int medium_default_count_G(int S) { return S >= 24 ? medium_default_G(S) : 16; }   // LDS count atomics collide across the lanes of a wavefront that share a transition
 inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
