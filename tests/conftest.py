@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# MB_ROLLING: the library sends small batches of a rolling Forward through the tile pipeline (faster when there are fewer
+# pairs than CUs).  The tests want the rolling kernel itself, so the threshold is switched off here; one test
+# (test_rolling_small_batch_uses_pipeline) restores it.
+os.environ.setdefault("MB_ROLLING_MIN_PAIRS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -701,3 +701,17 @@ def test_composed_machines_through_gpu(capi, oracle_mod):
     got = _boss([golden_path("machine", "bitstutter.json"), golden_path("machine", "bitnoise.json"), "-P", golden_path("io", "params.json"),
                  "-D", golden_path("io", "difflen.json"), "-A"])
     assert got == open(golden_path("expect", "align-stutter-noise-difflen.json")).read()
+
+
+def test_rolling_small_batch_uses_pipeline(capi, oracle_mod, machines, monkeypatch):
+    """Fewer pairs than CUs: MB_ROLLING is served by the tile pipeline (same log-likelihoods, only they are kept)."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    pairs = [synth_tokens(60 + k, 20 + k, 70, em.nInTok, em.nOutTok) for k in range(3)]
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    ref = b.forward(capi.MB_ROLLING); n0 = capi.last_launch_count()
+    monkeypatch.setenv("MB_ROLLING_MIN_PAIRS", "192")
+    got = b.forward(capi.MB_ROLLING); n1 = capi.last_launch_count()
+    assert n1 != n0 and close(got, ref, 1e-12)
+    om = oracle_mod.OracleMachine(em)
+    assert close(got, [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs], FAST_REL, FAST_ABS)
