@@ -149,8 +149,11 @@ class DeviceMachine:
         self.nStates, self.nTrans = em.nStates, em.nTransitions
 
     def close(self):
-        if getattr(self, "h", None):
-            load().mb_machine_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:   # at interpreter shutdown the module globals may be gone
+            try:
+                _lib.mb_machine_destroy(self.h)
+            except Exception:
+                pass
             self.h = None
 
     __del__ = close
@@ -222,8 +225,11 @@ class DeviceBatch:
         _check(load().mb_batch_set_envelopes(self.h, _p(off, C.c_int64), _p(a, C.c_int32), _p(b, C.c_int32)))
 
     def close(self):
-        if getattr(self, "h", None):
-            load().mb_batch_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            try:
+                _lib.mb_batch_destroy(self.h)
+            except Exception:
+                pass
             self.h = None
 
     __del__ = close

@@ -440,19 +440,30 @@ class MachineCounts:
     def add(self, seqPair: SeqPair) -> float:
         return self.addBatch([seqPair])[0]
 
-    def addBatch(self, seqPairs: Sequence[SeqPair], envelopes: Optional[Sequence[Envelope]] = None) -> List[float]:
-        """MachineCounts::add over a list (src/counts.cpp:37-64).  Quirk Q1: whatever envelope the caller passes, the
-        matrices use Envelope(seqPair) -- the path envelope of an aligned pair, else the full one."""
-        dm = _device_machine(self.machine)
-        toks = [(self.machine.inputTokenizer.tokenize(sp.input), self.machine.outputTokenizer.tokenize(sp.output))
-                for sp in seqPairs]
+    @staticmethod
+    def deviceBatch(machine: EvaluatedMachine, seqPairs: Sequence[SeqPair]) -> "capi.DeviceBatch":
+        """Tokenise a SeqPairList once and park it in HBM (with the envelopes of its aligned pairs): Baum-Welch reuses
+        the same batch in every iteration, only the machine's weights change."""
+        dm = _device_machine(machine)
+        toks = [(machine.inputTokenizer.tokenize(sp.input), machine.outputTokenizer.tokenize(sp.output)) for sp in seqPairs]
         b = capi.DeviceBatch.from_pairs(dm, toks)
-        envs = [Envelope(sp) for sp in seqPairs]
+        envs = [Envelope(sp) for sp in seqPairs]      # quirk Q1: always Envelope(seqPair), whatever the caller passes
         for e in envs:
             if not e.connected():
                 raise MachineError("Envelope is not connected:\n%s\n" % e.writeJson())
         if any(not e.isFull() for e in envs):
             b.set_envelopes([None if e.isFull() else (e.inStart, e.inEnd) for e in envs])
+        return b
+
+    def addDeviceBatch(self, b: "capi.DeviceBatch") -> List[float]:
+        _, s, ll = b.counts(self._flat)
+        self.loglike += s
+        return [float(x) for x in ll]
+
+    def addBatch(self, seqPairs: Sequence[SeqPair], envelopes: Optional[Sequence[Envelope]] = None) -> List[float]:
+        """MachineCounts::add over a list (src/counts.cpp:37-64).  Quirk Q1: whatever envelope the caller passes, the
+        matrices use Envelope(seqPair) -- the path envelope of an aligned pair, else the full one."""
+        b = self.deviceBatch(self.machine, seqPairs)
         _, s, ll = b.counts(self._flat)
         b.close()
         self.loglike += s

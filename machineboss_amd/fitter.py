@@ -222,6 +222,7 @@ class MachineFitter:
         self.log = []
         it = 0
         dm = None
+        batch = None
         while True:
             allParams = dict(self.machine.funcs); allParams.update(self.constants); allParams.update(params)
             ev = EvaluatedMachine.fromMachine(self.machine, allParams)
@@ -229,11 +230,12 @@ class MachineFitter:
             # (mb_machine_set_weights) -- the reference rebuilds its EvaluatedMachine every iteration (src/fitter.cpp:28-29)
             if dm is None:
                 dm = _device_machine(ev)
+                batch = MachineCounts.deviceBatch(ev, trainingSet)      # tokenised once, resident in HBM for all iterations
             else:
                 dm.set_weights(ev.logWeight)
                 ev._device = dm
             counts = MachineCounts(ev)
-            counts.addBatch(trainingSet, envelopes)
+            counts.addDeviceBatch(batch)
             if reduce is not None:
                 _, ll = reduce(counts._flat, counts.loglike)
                 counts.loglike = ll

@@ -715,3 +715,28 @@ def test_rolling_small_batch_uses_pipeline(capi, oracle_mod, machines, monkeypat
     assert n1 != n0 and close(got, ref, 1e-12)
     om = oracle_mod.OracleMachine(em)
     assert close(got, [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs], FAST_REL, FAST_ABS)
+
+
+def test_memory_budget_chunking(capi, machines):
+    """A batch whose matrices exceed the device-memory budget is processed in sub-batches / recycled matrix slots with
+    identical results; a single matrix that cannot fit is refused with the library's message."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    pairs = [synth_tokens(300 + k, 30 + (k % 5), 200 + 7 * k, em.nInTok, em.nOutTok) for k in range(12)]
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    ref_ll = b.forward(capi.MB_MATERIALISE); ref_v = b.viterbi(); ref_c = b.counts()
+    one = max((len(x) + 1) * (len(y) + 1) * em.nStates * 8 for x, y in pairs)
+    try:
+        capi.release_workspace()
+        capi.set_memory_budget(int(2.5 * one))           # two matrices at most: Forward recycles slots, counts runs pair by pair
+        assert np.array_equal(b.forward(capi.MB_MATERIALISE), ref_ll)
+        v = b.viterbi()
+        assert np.array_equal(v[0], ref_v[0]) and np.array_equal(v[1], ref_v[1]) and np.array_equal(v[2], ref_v[2])
+        c = b.counts()
+        assert close(c[0], ref_c[0], 1e-12, 1e-15) and np.array_equal(c[2], ref_c[2])
+        capi.set_memory_budget(one // 2)
+        with pytest.raises(capi.MbError, match="exceeds the device memory budget"):
+            b.viterbi()
+    finally:
+        capi.set_memory_budget(0)
+        capi.release_workspace()
