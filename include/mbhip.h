@@ -140,7 +140,8 @@ int mb_set_memory_budget(size_t bytes);
 int mb_release_workspace(void);
 
 /* Writes the HIP source the run-time code generator produces for this machine (mode MB_FORWARD = sum semiring,
- * MB_VITERBI = max, 3 = Forward fused with posterior counts; backward/closure select the program; G = columns per
+ * MB_VITERBI = max, 3 = Forward fused with posterior counts; backward and closure (0 = levelled, K >= 1 = silent closure in
+ * K stages) select the program; G = columns per
  * wavefront, 1/2/4/8) to `path`.  Host only:
  * works without a GPU, so the generated kernel can be inspected / cross-compiled offline. */
 int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,

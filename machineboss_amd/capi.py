@@ -123,8 +123,9 @@ def last_kernel_name() -> str:
     return load().mb_last_kernel_name().decode()
 
 
-def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: bool = True, G: int = 2):
-    """Write the HIP source of the run-time specialised tile kernel for this machine (host only, no GPU needed)."""
+def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: int = 1, G: int = 2):
+    """Write the HIP source of the run-time specialised tile kernel for this machine (host only, no GPU needed).
+    closure: 0 = levelled program, K >= 1 = silent closure in K stages."""
     a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
          np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
          np.ascontiguousarray(em.logWeight, np.float64)]

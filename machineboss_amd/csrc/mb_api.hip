@@ -166,36 +166,35 @@ static FastState *fast_state(mb_machine *m) {
       long long nSilent = 0;
       for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
       const bool wantClosure = env_int("MB_MEDIUM_CLOSURE", 1) != 0;
-      // the silent closure trades levels (one wave-level LDS round trip each) for candidates; on machines whose silent
-      // sub-graph is deep AND dense (protpsw.translate.dnapsw: 22 levels, 551 silent edges -> 832 closure slots against
-      // 91) the levelled program is cheaper.  Cost model: candidate slots + 6 per synchronisation point.
+      // The silent closure trades synchronisation points (one wave-level LDS round trip per silent level) for
+      // candidates.  Closing ALL levels at once is right for psw2dna (10 levels, 146 silent edges -> 360 pairs), but on
+      // machines whose silent sub-graph is deep and dense (protpsw.translate.dnapsw: 22 levels, 551 silent edges ->
+      // 12 162 pairs) neither extreme is: the levels are closed in K groups, K chosen by a cost model
+      // (candidate slots + 6 per synchronisation point), K = 0 meaning the levelled program.
       auto cost = [](const MedProgram &P) {
         long long c = 0;
         for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + (ri.sync ? 6 : 0);
         return c;
       };
-      bool ok = medium_build(m, false, false, G, f->fwdExact, f->geoFE);
-      if (ok) {
-        bool clos = wantClosure;
-        ok = medium_build(m, false, clos, G, f->fwdSum, f->geoFS);
-        if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] forward program cost: closure %lld (pairs %d), levelled %lld\n", cost(f->fwdSum), f->fwdSum.nPairs, cost(f->fwdExact));
-        if (ok && clos && (f->fwdSum.nPairs > 4 * nSilent + m->S || cost(f->fwdSum) > cost(f->fwdExact))) {
-          medium_free(f->fwdSum);
-          ok = medium_build(m, false, false, G, f->fwdSum, f->geoFS);
+      auto choose = [&](bool backward) {
+        int bestK = 0; long long best = -1;
+        const int forced = env_int("MB_MEDIUM_CLOSURE_STAGES", -1);
+        if (forced >= 0) return forced;
+        if (!wantClosure) return 0;
+        const int nLev = backward ? m->nLevB : m->nLevF;
+        for (int K = 0; K <= std::min(std::max(nLev - 1, 1), 12); ++K) {
+          MedProgram P; MedGeom g;
+          if (!medium_build_host(m, backward, K, G, P, g)) continue;
+          if (K && P.nPairs > 16 * nSilent + 4 * m->S) continue;      // record tables would not stay cache-resident
+          const long long c = cost(P);
+          if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] %s program, closure stages %d: cost %lld (pairs %d)\n", backward ? "backward" : "forward", K, c, P.nPairs);
+          if (best < 0 || c < best) { best = c; bestK = K; }
         }
-      }
-      if (ok) {
-        bool clos = wantClosure;
-        ok = medium_build(m, true, clos, G, f->bwdSum, f->geoBS);
-        if (ok && clos) {
-          MedProgram ex; MedGeom gex;
-          const bool okx = medium_build_host(m, true, false, G, ex, gex);
-          if (f->bwdSum.nPairs > 4 * nSilent + m->S || (okx && cost(f->bwdSum) > cost(ex))) {
-            medium_free(f->bwdSum);
-            ok = medium_build(m, true, false, G, f->bwdSum, f->geoBS);
-          }
-        }
-      }
+        return bestK;
+      };
+      bool ok = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
+      if (ok) ok = medium_build(m, false, choose(false), G, f->fwdSum, f->geoFS);
+      if (ok) ok = medium_build(m, true, choose(true), G, f->bwdSum, f->geoBS);
       f->mediumOk = ok;
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
         int Gc = env_int("MB_MEDIUM_COUNT_G", 0);
@@ -660,7 +659,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   MedProgram P; MedGeom geo;
   if (mode == MED_MODE_COUNT) {
     if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
-  } else if (!medium_build_host(&m, backward != 0, closure != 0, G, P, geo)) return 1;
+  } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
   const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD));
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }

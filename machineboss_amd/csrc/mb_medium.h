@@ -68,6 +68,7 @@ struct MedProgram {
   // closure structure (recomputed numerically whenever the weights change)
   std::vector<std::vector<std::pair<int, uint32_t>>> silPred;   // node -> (predecessor node, edge id)
   std::vector<char> isBase;
+  std::vector<int> stageOf;                                     // closure programs: stage that finalises the state (0 = emit-only)
   std::vector<std::vector<int>> closBase;                       // node -> sorted base ancestors
   std::vector<std::vector<int>> closPair;                       // node -> pair id per ancestor (parallel to closBase)
   int nPairs = 0;
@@ -86,8 +87,8 @@ struct MedProgram {
 struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
 
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
-bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
-bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo);
+bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
+bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);
 // exact Forward program whose records also name their transition's count accumulator (see MedProgram::counting)
 bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
 bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
@@ -100,8 +101,9 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
 // mapping for machines with a handful of states (dnapsw, protpsw: 8 states).
 inline bool medium_valid_G(int G) { return G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
 inline int medium_default_G(int S) {   // measured with the specialised kernel: psw2dna (271 states) G=4 (8 wavefronts x 256 VGPRs) >= 2 > 1
-  // protpsw.translate.dnapsw (482 states, 22 silent levels): G=1 (171 G cells/s) > 2 (157) > 4 (141); dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
-  return S >= 384 ? 1 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32));
+  // protpsw.translate.dnapsw (482 states, 22 silent levels, records kept in LDS): G=2 (264 G cells/s) > 4 (192) > 1 (167);
+  // psw2dna (271 states): 4 >= 2 > 1; dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
+  return S >= 1024 ? 1 : (S >= 384 ? 2 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32)));
 }
 inline int medium_default_count_G(int S) { return S >= 24 ? medium_default_G(S) : 16; }   // LDS count atomics collide across the lanes of a wavefront that share a transition
 inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
@@ -113,6 +115,7 @@ size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo);
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode);
 void medium_free(MedProgram &P);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
+void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st);

@@ -370,10 +370,13 @@ static double host_lse(double a, double b) {
   return mx + log1p(exp(mn - mx));
 }
 
-static void build_program(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P) {
+// closure = 0: levelled (exact) program; K >= 1: silent closure in K stages -- the silent levels 1..nLev-1 are cut into K
+// consecutive groups, every group is closed transitively over (a) the states finalised by earlier groups and (b) the
+// emit-only parts of its own emit-fed states, and costs ONE synchronisation point.  K = 1 is the full closure.
+static void build_program(const mb_machine *m, bool backward, int closure, int G, MedProgram &P) {
   const int S = m->S, LPG = 64 / G, nIn = m->nIn, nOut = m->nOut;
   P = MedProgram();
-  P.G = G; P.LPG = LPG; P.backward = backward; P.closure = closure;
+  P.G = G; P.LPG = LPG; P.backward = backward; P.closure = closure != 0;
   P.NS = m->hasMatch ? 3 : 2;
   const std::vector<int> &lev = backward ? m->levB : m->levF;
   const std::vector<int> &off = backward ? m->outOff : m->inOff;
@@ -415,7 +418,7 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
   // ---- nodes of the program: (destination index in the LDS vector, emit candidates of which state, "cur" candidates)
   struct Node { int dst; int emitOf; std::vector<Cand> cur; int stage; };
   std::vector<Node> nodes;
-  int nExtra = 0;
+  int nExtra = 0, nClosureStages = 1;
   if (!closure) {
     for (int s = 0; s < S; ++s) {
       Node n{s, s, {}, lev[s]};
@@ -426,7 +429,15 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
     // base states: fed by emitting edges, or the start node (which carries the seed)
     P.isBase.assign(S, 0);
     for (int s = 0; s < S; ++s) P.isBase[s] = (emitDeg[s][0] || emitDeg[s][1] || emitDeg[s][2] || s == startNode) ? 1 : 0;
-    // closure structure: base ancestors through silent paths, in topological order
+    // stage of a state: 0 = no silent predecessor (its value is its emit part), else the group of its silent level
+    const int K = std::max(1, std::min(closure, std::max(1, nLev - 1)));
+    P.stageOf.assign(S, 0);
+    for (int s = 0; s < S; ++s)
+      if (lev[s] > 0) P.stageOf[s] = 1 + (int)(((long long)(lev[s] - 1) * K) / std::max(1, nLev - 1));
+    const std::vector<int> &stg = P.stageOf;
+    // closure structure: ancestors through silent paths whose intermediate states lie in the node's own stage, in
+    // topological order.  An ancestor is either final already (earlier stage) or an emit-fed state of the same stage
+    // (then its emit-only part is the source).
     P.closBase.assign(S, {}); P.closPair.assign(S, {});
     std::vector<int> order(S);
     std::iota(order.begin(), order.end(), 0);
@@ -435,6 +446,7 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
       std::vector<int> anc;
       for (auto &pe : P.silPred[d]) {
         const int sp = pe.first;
+        if (stg[sp] < stg[d]) { anc.push_back(sp); continue; }
         if (P.isBase[sp]) anc.push_back(sp);
         anc.insert(anc.end(), P.closBase[sp].begin(), P.closBase[sp].end());
       }
@@ -447,16 +459,17 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
     std::vector<int> eslot(S, -1);
     for (int s = 0; s < S; ++s)
       if (P.isBase[s] && !P.silPred[s].empty()) eslot[s] = S + 1 + nExtra++;
-    auto baseIdx = [&](int b) { return eslot[b] >= 0 ? eslot[b] : b; };
+    auto srcIdx = [&](int b, int d) { return (stg[b] < stg[d] || eslot[b] < 0) ? b : eslot[b]; };
     for (int s = 0; s < S; ++s) {
-      if (P.isBase[s] || P.silPred[s].empty()) nodes.push_back(Node{baseIdx(s), s, {}, 0});   // stage 1 (also dead states)
+      if (P.isBase[s] || P.silPred[s].empty()) nodes.push_back(Node{eslot[s] >= 0 ? eslot[s] : s, s, {}, 0});   // stage 0 (also dead states)
       if (!P.silPred[s].empty()) {
-        Node n{s, -1, {}, 1};
+        Node n{s, -1, {}, stg[s]};
         if (P.isBase[s]) n.cur.push_back({eslot[s], -2 - P.nPairs});   // own emit part, weight 0 (a constant "pair")
-        for (size_t k = 0; k < P.closBase[s].size(); ++k) n.cur.push_back({baseIdx(P.closBase[s][k]), -2 - P.closPair[s][k]});
+        for (size_t k = 0; k < P.closBase[s].size(); ++k) n.cur.push_back({srcIdx(P.closBase[s][k], s), -2 - P.closPair[s][k]});
         nodes.push_back(n);
       }
     }
+    nClosureStages = K;
   }
   // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to.  Even length keeps every column 16-byte
   // aligned; with one or two lanes per supercell the lanes of a wavefront read DIFFERENT columns at the same state
@@ -464,7 +477,7 @@ static void build_program(const mb_machine *m, bool backward, bool closure, int 
   P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;
   if (LPG <= 2) P.Spad |= 1;
   P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
-  const int nStages = closure ? 2 : nLev;
+  const int nStages = closure ? 1 + nClosureStages : nLev;
 
   // ---- rounds: per stage, nodes sorted so that a round is homogeneous in (tables used, candidate count) ----------
   auto sig = [&](const Node &n) {
@@ -601,6 +614,7 @@ void medium_eval_weights(const mb_machine *m, MedProgram &P) {
           double &t = pairW[P.closPair[d][k]];
           t = host_lse(t, x);
         };
+        if (P.stageOf[sp] < P.stageOf[d]) { addTo(sp, w); continue; }   // final already: paths through it belong to its own value
         if (P.isBase[sp]) addTo(sp, w);
         for (size_t k = 0; k < P.closBase[sp].size(); ++k) addTo(P.closBase[sp][k], pairW[P.closPair[sp][k]] + w);
       }
@@ -623,7 +637,7 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
   return true;
 }
 
-bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo) {
+bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo) {
   build_program(m, backward, closure, G, P);
   if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 24)) { set_error("machine too large for the tiled kernel family"); return false; }
   MedProgDev &d = P.dev;
@@ -631,12 +645,37 @@ bool medium_build_host(const mb_machine *m, bool backward, bool closure, int G, 
   d.nIn = m->nIn; d.nOut = m->nOut;
   d.startNode = backward ? m->S - 1 : 0; d.endNode = backward ? 0 : m->S - 1;
   if (!medium_geometry(m, P, geo)) { set_error("machine does not fit the tiled kernel family's LDS ring"); return false; }
+  medium_fit_records(m, P, geo);
   medium_jit_plan(m, P, geo);
   medium_eval_weights(m, P);
   return true;
 }
 
-bool medium_build(const mb_machine *m, bool backward, bool closure, int G, MedProgram &P, MedGeom &geo) {
+// The geometry above takes as many columns as the LDS ring allows.  On machines with many candidate slots that leaves no
+// LDS for the candidate records, which then stream from L2 on every step (protpsw.translate.dnapsw: 42 KB per wave-step,
+// 670 KB per step and CU -- the L1 fill rate, not HBM, bounded the kernel).  Give columns up -- down to half -- until
+// the records that cannot sit in VGPRs fit next to the ring.
+void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
+  const char *e = getenv("MB_MEDIUM_MAXWAVES");
+  if (e && atoi(e) > 0 && atoi(e) < geo.waves) { geo.waves = atoi(e); geo.C = geo.waves * P.G; }
+  if (getenv("MB_MEDIUM_FIT_RECORDS") && atoi(getenv("MB_MEDIUM_FIT_RECORDS")) == 0) return;
+  const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
+  long long slotsT[4] = {0, 0, 0, 0};
+  for (const MedRoundInfo &ri : P.roundInfo) for (const MedSlotInfo &sl : ri.slots) ++slotsT[sl.T];
+  const int minWaves = std::max(1, (geo.waves + 1) / 2);
+  while (true) {
+    const int regBudget = std::max(0, std::min(512 / ((geo.waves + 3) / 4), 256) - 84);
+    const long long perRec = P.counting ? 5 : 4;
+    const long long inReg = std::max<long long>(0, regBudget / perRec - slotsT[1]);      // token-independent records the VGPRs can hold
+    const long long need = (slotsT[2] * ntokT[2] + std::max<long long>(0, slotsT[3] - inReg)) * P.LPG * 16;
+    const long long ring = (long long)(P.NS + (P.counting ? 1 : 0)) * (geo.C + 1) * P.Spad * 8 + (P.counting ? (long long)(m->nTrans + 66) * 8 : 0);
+    if (ring + need + 2048 <= 160 * 1024 || geo.waves <= minWaves) break;
+    --geo.waves; geo.C = geo.waves * P.G;
+  }
+  geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);
+}
+
+bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo) {
   if (!medium_build_host(m, backward, closure, G, P, geo)) return false;
   if (!up(P.d_desc, P.desc)) return false;
   P.dev.desc = P.d_desc;
@@ -654,6 +693,7 @@ bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom 
   d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
   d.nIn = m->nIn; d.nOut = m->nOut; d.startNode = 0; d.endNode = m->S - 1;
   if (!medium_geometry(m, P, geo)) return false;
+  medium_fit_records(m, P, geo);
   for (size_t k = 0; k < P.rec.size(); ++k) {
     const long long e = P.wref[k] >= 0 ? P.wref[k] : m->nTrans + (long long)(k % P.LPG);   // padding candidates add 0 to their lane's dummy accumulator
     P.rec[k].srcOff = (P.rec[k].srcOff & 0xFFFFu) | ((uint32_t)(e * 8) << 16);
