@@ -141,11 +141,13 @@ def main():
         # independent, and ctypes releases the GIL during the call.  Sample sized for ~10-20 s of wall time.
         cores = host_cores()
         # calibrate: a container may show more CPUs than it is allowed to run; use as many threads as actually scale
-        probe = [synth_tokens(3000 + k, args.inlen, 60, em.nInTok, em.nOutTok) for k in range(cores)]
+        probe = [synth_tokens(3000 + k, args.inlen, 150, em.nInTok, em.nOutTok) for k in range(cores)]
         om.loglike(*probe[0])
-        tp = time.perf_counter(); om.loglike(*probe[0]); p1 = time.perf_counter() - tp
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            tp = time.perf_counter(); list(ex.map(lambda xy: om.loglike(*xy), probe)); pn = time.perf_counter() - tp
+        p1, pn = 1e9, 1e9
+        for _ in range(2):      # best of two: the probe is short and the host is shared
+            tp = time.perf_counter(); om.loglike(*probe[0]); p1 = min(p1, time.perf_counter() - tp)
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                tp = time.perf_counter(); list(ex.map(lambda xy: om.loglike(*xy), probe)); pn = min(pn, time.perf_counter() - tp)
         cores = max(1, min(cores, int(round(cores * p1 / pn))))
         sample_out = min(args.outlen, 1500)
         samples = [synth_tokens(4000 + k, args.inlen, sample_out, em.nInTok, em.nOutTok) for k in range(cores)]
@@ -170,7 +172,8 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (profiles/), valid for the default workload only
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
             if pmc["kernel"] == kernel and pmc["cells_per_step"] == cells_rank and flags == capi.MB_MATERIALISE:
-                traffic = round(pmc["hbm_bytes_per_launch"])
+                # measured HBM bytes per cell x the cells of one launch (the launch count depends on the tile length)
+                traffic = round(pmc["hbm_bytes_per_cell"] * cells_rank * args.steps / max(launches, 1))
         except Exception:
             pass
         out = {
