@@ -229,7 +229,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     const MedGeom &geo = mode == MB_BACKWARD ? f->geoBS : (exactFwd ? f->geoFE : f->geoFS);
     const int rc = medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
                                             (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream);
-    g_last_kernel = P.jit[mode == MB_VITERBI ? 1 : 0].func ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
+    g_last_kernel = medium_jit_ready(P, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, true) ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
     return rc;
   }
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
@@ -432,12 +432,14 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
       tm.start();
       rc = medium_forward_rolling(m, f->fwdSum, f->geoFS, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
-      g_last_kernel = f->fwdSum.jit[0].func ? "k_medium_jit" : "k_medium_tile<0>";
+      g_last_kernel = medium_jit_ready(f->fwdSum, MB_FORWARD, false) ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
     if (d_hb) (void)hipFree(d_hb);
-  } else if (mode == MB_FORWARD && !b->hasEnv && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1)) {
+  } else if (mode == MB_FORWARD && !b->hasEnv && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1) &&
+             (size_t)b->totalCells * 8 > budget_bytes()) {
+    // the matrices of the batch do not fit the device-memory budget together:
     // ForwardMatrix semantics with only logLike() kept: continuous pipeline over recycled matrix slots
     FastState *f = fast_state(m);
     const size_t budget = budget_bytes();
@@ -448,7 +450,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     else {
       tm.start();
       rc = medium_forward_pipelined(m, f->fwdSum, f->geoFS, b->pairs, b->d_in, b->d_out, pool, (long long)(g_ws[0].bytes / 8), d_ll, g_stream);
-      g_last_kernel = f->fwdSum.jit[0].func ? "k_medium_jit" : "k_medium_tile<0>";
+      g_last_kernel = medium_jit_ready(f->fwdSum, MB_FORWARD, true) ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
     }
   } else {
@@ -660,7 +662,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   if (mode == MED_MODE_COUNT) {
     if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
-  const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD));
+  const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD), true);
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
   fprintf(f, "// G=%d C=%d waves=%d ldsBytes=%zu ldsRecs=%zu rounds=%zu\n", G, geo.C, geo.waves, medium_jit_lds_bytes(P, geo),

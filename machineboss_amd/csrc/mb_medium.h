@@ -81,10 +81,13 @@ struct MedProgram {
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
-  MedJit jit[3];                        // [MB_FORWARD (sum)], [MB_VITERBI (max)], [MED_MODE_COUNT]
+  MedJit jit[6];                        // [2 * medium_jit_index(mode) + materialise]: sum / max / count, rolling / materialised
 };
 
-struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; };
+// haloSteps > 0: the materialised kernel loads the halo supercells of a whole tile (at most haloSteps steps) into LDS in
+// its prologue, so its step loop issues NO vector-memory load (machines with few states, where a step is shorter than
+// the time the previous step's stores need to be acknowledged)
+struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; };
 
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
 bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
@@ -112,7 +115,7 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);
 long long medium_jit_spill_count(const std::string &codeObject);
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo);
-std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode);
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool materialise);
 void medium_free(MedProgram &P);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo);
@@ -120,7 +123,9 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st);
 // run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode);
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise);
+inline int medium_jit_slot(int mode, bool materialise) { return 2 * medium_jit_index(mode) + (materialise ? 1 : 0); }
+inline bool medium_jit_ready(const MedProgram &P, int mode, bool materialise) { return P.jit[medium_jit_slot(mode, materialise)].func != nullptr; }
 void medium_jit_free(MedProgram &P);
 int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs,
                              const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,

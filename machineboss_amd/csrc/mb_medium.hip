@@ -655,6 +655,11 @@ bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, M
 // LDS for the candidate records, which then stream from L2 on every step (protpsw.translate.dnapsw: 42 KB per wave-step,
 // 670 KB per step and CU -- the L1 fill rate, not HBM, bounded the kernel).  Give columns up -- down to half -- until
 // the records that cannot sit in VGPRs fit next to the ring.
+static int env_int_m(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   const char *e = getenv("MB_MEDIUM_MAXWAVES");
   if (e && atoi(e) > 0 && atoi(e) < geo.waves) { geo.waves = atoi(e); geo.C = geo.waves * P.G; }
@@ -663,15 +668,22 @@ void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) 
   long long slotsT[4] = {0, 0, 0, 0};
   for (const MedRoundInfo &ri : P.roundInfo) for (const MedSlotInfo &sl : ri.slots) ++slotsT[sl.T];
   const int minWaves = std::max(1, (geo.waves + 1) / 2);
+  // machines with a handful of states: a step is shorter than the acknowledgement of the previous step's stores, and on
+  // gfx9 any vector load waits for those (one in-order vmcnt) -- so the halo supercells of a whole tile are fetched in
+  // the tile's prologue instead (MedGeom::haloSteps), if 32 KB of LDS buy that
+  const bool wantHaloTile = env_int_m("MB_MEDIUM_HALO_TILE", 1) != 0 && !P.counting;
+  auto haloStepsFor = [&](int C) { const long long cap = std::max(C, 128); return (wantHaloTile && cap * m->S * 8 <= 32 * 1024) ? (int)cap : 0; };
   while (true) {
     const int regBudget = std::max(0, std::min(512 / ((geo.waves + 3) / 4), 256) - 84);
     const long long perRec = P.counting ? 5 : 4;
     const long long inReg = std::max<long long>(0, regBudget / perRec - slotsT[1]);      // token-independent records the VGPRs can hold
-    const long long need = (slotsT[2] * ntokT[2] + std::max<long long>(0, slotsT[3] - inReg)) * P.LPG * 16;
+    const long long need = (slotsT[2] * ntokT[2] + std::max<long long>(0, slotsT[3] - inReg)) * P.LPG * 16 + (long long)haloStepsFor(geo.C) * m->S * 8;
     const long long ring = (long long)(P.NS + (P.counting ? 1 : 0)) * (geo.C + 1) * P.Spad * 8 + (P.counting ? (long long)(m->nTrans + 66) * 8 : 0);
     if (ring + need + 2048 <= 160 * 1024 || geo.waves <= minWaves) break;
     --geo.waves; geo.C = geo.waves * P.G;
   }
+  geo.haloSteps = haloStepsFor(geo.C);
+  if (geo.haloSteps && (long long)P.NS * (geo.C + 1) * P.Spad * 8 + (long long)geo.haloSteps * m->S * 8 + 4096 > 160 * 1024) geo.haloSteps = 0;
   geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);
 }
 
@@ -727,7 +739,9 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   const size_t budget = 160 * 1024 - fixed;
   long long maxCols = (long long)(budget / perCol) - 1;   // one extra column for the halo
   if (maxCols < P.G) return false;
-  int waves = (int)std::min<long long>(maxCols / P.G, P.counting ? 8 : 16);
+  // one or two lanes per supercell (machines with a handful of states): a 512-column strip wastes half its steps on
+  // the skewed start/end of a 1 kb sweep; 8 wavefronts (256 columns) measured best on dnapsw / protpsw
+  int waves = (int)std::min<long long>(maxCols / P.G, (P.counting || P.LPG <= 2) ? 8 : 16);
   // S must be covered by 4 halo registers per thread
   while (waves < 16 && (long long)waves * 64 * 4 < m->S && (long long)(waves + 1) * P.G <= maxCols) ++waves;
   if ((long long)waves * 64 * 4 < m->S || (long long)waves * P.G > maxCols) return false;
@@ -799,7 +813,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   int2 *d_tiles = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
-  const MedJit *J = medium_jit_get(m, P, geo, mode) ? &P.jit[medium_jit_index(mode)] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true)] : nullptr;
   if (mode == MED_MODE_COUNT && !J) { (void)hipFree(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
@@ -856,7 +870,7 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
                                const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out, double *d_fwd,
                                const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st) {
   if (pairsIn.empty()) return 0;
-  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT)) return -1;
+  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, true)) return -1;
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   return launch_wavefront(m, P, P.dev, geo, MED_MODE_COUNT, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_fwd,
@@ -879,7 +893,10 @@ int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &
   const long long nSlots = std::min<long long>(poolCells / std::max<long long>(slotCells, 1), n);
   if (nSlots < 1) { set_error("a single DP matrix exceeds the device memory budget"); return 1; }
   const int TS = tile_steps(C, (size_t)n, max_out_len(pairsIn));
-  const int target = 256;   // resident workgroups: one per CU (the LDS ring takes most of a CU's 160 KB)
+  // resident workgroups the chip can hold: per CU as many as the LDS footprint and the 32-wavefront limit allow
+  const size_t ldsPerWg = std::max<size_t>(medium_jit_lds_bytes(P, geo), 1024);
+  const int wgPerCU = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((160 * 1024) / ldsPerWg, 32 / std::max(geo.waves, 1)), 8));
+  const int target = 256 * wgPerCU;
   std::vector<PairDesc> pairs = pairsIn;
   std::vector<int> life(n), NAp(n), NBp(n);
   for (long long p = 0; p < n; ++p) {
@@ -938,7 +955,7 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
   A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.tiles = nullptr; A.tileBase = 0;
   const dim3 grid((unsigned)pairs.size()), block(geo.waves * 64);
-  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD) ? &P.jit[0] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, false) ? &P.jit[medium_jit_slot(MB_FORWARD, false)] : nullptr;
   MedProgDev dev = P.dev;
   dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   for (int a = 0; a < NA; ++a) {

@@ -43,8 +43,10 @@ static size_t count_bytes(const MedProgram &P, const MedGeom &geo) {
   return P.counting ? ((size_t)geo.C * P.Spad + (size_t)P.accEntries) * sizeof(double) : 0;
 }
 
+static size_t halo_bytes(const MedProgram &P, const MedGeom &geo) { return (size_t)geo.haloSteps * P.dev.S * sizeof(double); }
+
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo) {
-  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo);
+  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo);
 }
 
 // Decide where every slot's records live (see the file header).  Deterministic in (program, geometry).
@@ -59,7 +61,7 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
   P.tokWindow = 64;
   const int LPG = P.LPG;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
-  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo);
+  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo) - (long long)halo_bytes(P, geo);
   int regFree = P.regBudget;                               // VGPRs for loop-invariant records (3 per record, +1 per round)
   if (P.Spad * 8 >= (1 << 16)) regFree = 0;
   for (MedRoundInfo &ri : P.roundInfo) for (MedSlotInfo &sl : ri.slots) { sl.place = MED_PLACE_GLOBAL; sl.ldsOff = 0; }
@@ -113,7 +115,7 @@ long long medium_jit_spill_count(const std::string &code) {
   return -1;
 }
 
-std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode) {
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
   std::ostringstream defs, pre, body, post;
   const int S = m->S;
   const bool counting = mode == MED_MODE_COUNT;
@@ -122,6 +124,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
        << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
        << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0)
+       << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
        << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
@@ -223,8 +226,8 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   return src;
 }
 
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode) {
-  MedJit &J = P.jit[medium_jit_index(mode)];
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
+  MedJit &J = P.jit[medium_jit_slot(mode, materialise)];
   if (J.tried) return J.func != nullptr;
   if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;
@@ -239,11 +242,11 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
   if (P.roundInfo.size() > 4096) return false;   // keep the generated code within reach of the instruction cache
   std::string code;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    J.ldsBytes = medium_jit_lds_bytes(P, geo);
+    J.ldsBytes = medium_jit_lds_bytes(P, geo) - (materialise ? 0 : halo_bytes(P, geo));   // the rolling kernel has no halo tile
     if (J.ldsBytes > 160 * 1024) return false;
-    const std::string src = medium_jit_source(m, P, geo, mode);
+    const std::string src = medium_jit_source(m, P, geo, mode, materialise);
     if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
-      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : ".sum")) + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : ".sum")) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mb_medium_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;

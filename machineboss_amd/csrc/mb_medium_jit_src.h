@@ -155,12 +155,12 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   int pairIdx, a;
-  if (A.materialise) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y; }
+  if (JMAT) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y; }
   else { pairIdx = blockIdx.x; a = A.launch; }
   const PairDesc pd = A.pairs[pairIdx];
   const int inLen = pd.inLen, outLen = pd.outLen;
   const long long I = inLen + 1;
-  const int b = A.materialise ? A.launch - pd.launch0 - 2 * a : 0;
+  const int b = JMAT ? A.launch - pd.launch0 - 2 * a : 0;
   const int NA = (inLen + C) / C;
   const int T = outLen + C;
   if (a >= NA || b < 0 || (long long)b * A.TS >= T) return;
@@ -172,9 +172,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
   const int rev = A.rev;
   const int it = (colValid && i > 0) ? (rev ? in[inLen - i] : in[i - 1]) : 0;
-  double *cells = A.materialise ? A.pool + pd.cellBase : nullptr;
+  double *cells = JMAT ? A.pool + pd.cellBase : nullptr;
   double *haloIn = nullptr, *haloOut = nullptr;
-  if (!A.materialise) {
+  if (!JMAT) {
     double *hb = A.colHalo + A.haloBase[pairIdx];
     const long long hsz = (long long)(outLen + 1) * S;
     haloIn = hb + ((a + 1) & 1) * hsz;
@@ -200,6 +200,19 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   for (int j = tid; j < JNACC; j += NT) accL[j] = 0.0;
 #endif
   auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (rev ? out[outLen - o] : out[o - 1]) : 0; };
+#if JHALOT > 0
+  // halo supercells (i0-1, t+1) of ALL the tile's steps, fetched here: the step loop then issues no vector-memory load
+#if JMODE == 2
+  double *haloBuf = accL + JNACC;
+#else
+  double *haloBuf = (double *)(tokWin + 2 * (W + C));
+#endif
+  if (i0 > 0)
+    for (int idx = tid; idx < (t1 - t0) * S; idx += NT) {
+      const int k = idx / S, j = idx - k * S, ho = t0 + k + 1;
+      if (ho <= outLen) haloBuf[idx] = cellPtr(i0 - 1, ho)[j];
+    }
+#endif
 
   for (int j = tid; j < NS * (C + 1) * Spad; j += NT) lds[j] = NEG_INF;
   {  // candidate records placed in LDS (16 B each)
@@ -222,7 +235,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       const int cc = col - 1, ci = i0 + cc, co = tp - cc;
       if (ci < 0 || ci > inLen || co < 0 || co > outLen) continue;
       const double *src = nullptr;
-      if (A.materialise) src = cellPtr(ci, co);
+      if (JMAT) src = cellPtr(ci, co);
       else if (cc == -1) src = haloIn + (long long)co * S;
       if (src) ring(slot, col)[j] = src[j];
     }
@@ -277,14 +290,16 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     // halo supercell (i0-1, t+1) for the next step.  The load is UNCONDITIONAL (clamped to a valid address when there
     // is no halo): a conditionally initialised register would make the compiler wait for every outstanding memory
     // operation -- the previous step's stores included -- before overwriting it.
-    double hv[JHALO];
     const bool wantHalo = (i0 > 0) && (t + 1 <= outLen);
+#if JHALOT == 0
+    double hv[JHALO];
     {
       const int hi = i0 > 0 ? i0 - 1 : 0, ho = min(t + 1, outLen);
-      const double *hs = A.materialise ? cellPtr(hi, ho) : haloIn + (long long)ho * S;
+      const double *hs = JMAT ? cellPtr(hi, ho) : haloIn + (long long)ho * S;
 #pragma unroll
       for (int k = 0; k < JHALO; ++k) hv[k] = hs[min(tid + k * NT, S - 1)];
     }
+#endif
 #if JMODE == 2
     // Backward supercell (i, o+1) of the next step: registers now, LDS after this step's counting (clamped, unconditional)
     double bpre[JBV];
@@ -324,12 +339,16 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #pragma unroll
       for (int k = 0; k < JHALO; ++k) {
         const int j = tid + k * NT;
+#if JHALOT > 0
+        if (j < S) hd[j] = haloBuf[(t - t0) * S + j];
+#else
         if (j < S) hd[j] = hv[k];
+#endif
       }
     }
     const double *cur = (const double *)(ldsb + (myColBase + sCur));
     if (active) {
-      if (A.materialise) {
+      if (JMAT) {
         double *dstp = cellPtr(i, o);
         if (!A.debugNoStore || c == C - 1) med_copy_out(dstp, cur, q);
       } else if (c == C - 1) {
