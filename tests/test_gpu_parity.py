@@ -740,3 +740,37 @@ def test_memory_budget_chunking(capi, machines):
     finally:
         capi.set_memory_budget(0)
         capi.release_workspace()
+
+
+def test_one_tape_machines(capi, oracle_mod):
+    """Generators (no input alphabet) and recognisers (no output alphabet): the lattice degenerates to one row / column;
+    silent chains and a 1-state machine included (BASELINE config 5 is a one-tape machine)."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    gen = Machine.fromJson({"state": [
+        {"id": "S", "trans": [{"to": "A"}, {"to": "B", "weight": 0.25}]},
+        {"id": "A", "trans": [{"to": "A", "out": "x", "weight": 0.5}, {"to": "B", "out": "y", "weight": 0.3}, {"to": "E", "weight": 0.2}]},
+        {"id": "B", "trans": [{"to": "A", "out": "y", "weight": 0.6}, {"to": "B", "out": "x", "weight": 0.1}, {"to": "E", "weight": 0.3}]},
+        {"id": "E"}]})
+    rec = Machine.fromJson({"state": [{"id": "S", "trans": [{"to": "S", "in": "a", "weight": 0.4}, {"to": "S", "in": "b", "weight": 0.1}]}]})
+    for mach, il, ol in ((gen, 0, 23), (rec, 17, 0), (gen, 0, 0)):
+        em = EvaluatedMachine.fromMachine(mach, {})
+        om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+        rng = np.random.RandomState(il + ol)
+        x = rng.randint(1, max(em.nInTok, 1) + 1, size=il).astype(np.int32) if em.nInTok else np.zeros(0, np.int32)
+        y = rng.randint(1, max(em.nOutTok, 1) + 1, size=ol).astype(np.int32) if em.nOutTok else np.zeros(0, np.int32)
+        for fam in (capi.KERNEL_GENERIC, capi.KERNEL_AUTO):
+            capi.set_kernel(fam)
+            try:
+                V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+                b = capi.DeviceBatch.from_pairs(dm, [(x, y)] * 3)
+                ll = b.forward(capi.MB_ROLLING); vll, off, edges = b.viterbi(); counts, s, _ = b.counts()
+            finally:
+                capi.set_kernel(capi.KERNEL_AUTO)
+            assert np.array_equal(V, om.viterbi(x, y))
+            assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+            assert close(ll, [F[-1, -1, -1]] * 3, 1e-9, 1e-12)
+            if V[-1, -1, -1] > -math.inf:
+                assert np.array_equal(edges[off[0]:off[1]], om.traceback(x, y, om.viterbi(x, y)))
+            ref = np.zeros(em.nTransitions); om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+            assert close(counts, 3 * ref, 1e-5, 1e-7)
