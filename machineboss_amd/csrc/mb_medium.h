@@ -9,6 +9,7 @@ namespace mb {
 constexpr int MED_MAXSLOT = 4;      // candidate slots evaluated together (two-pass max / sum-exp in registers)
 constexpr int MED_DESC_WORDS = 8;   // descriptor words per chunk (32 B, fetched with scalar loads)
 constexpr int MED_MODE_COUNT = 3;   // internal kernel mode: Forward fill (sum) fused with posterior transition counts
+constexpr int MED_GEOM_LEVELS = 5;  // strip widths a program is specialised for: its widest, halved 0..4 times
 
 // One candidate of one lane: 16 bytes, fetched with a single global_load_dwordx4.
 struct alignas(16) MedRec {
@@ -81,13 +82,15 @@ struct MedProgram {
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
-  MedJit jit[6];                        // [2 * medium_jit_index(mode) + materialise]: sum / max / count, rolling / materialised
+  // [2 * medium_jit_index(mode) + materialise][MedGeom::level]: sum / max / count, rolling / materialised, and the strip
+  // width (level h = the program's widest strip halved h times; narrow strips for short input sequences)
+  MedJit jit[6 * MED_GEOM_LEVELS];
 };
 
 // haloSteps > 0: the materialised kernel loads the halo supercells of a whole tile (at most haloSteps steps) into LDS in
 // its prologue, so its step loop issues NO vector-memory load (machines with few states, where a step is shorter than
 // the time the previous step's stores need to be acknowledged)
-struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; };
+struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; int level = 0; };
 
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
 bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
@@ -124,8 +127,13 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
                              double *d_pool, hipStream_t st);
 // run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
 bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise);
-inline int medium_jit_slot(int mode, bool materialise) { return 2 * medium_jit_index(mode) + (materialise ? 1 : 0); }
-inline bool medium_jit_ready(const MedProgram &P, int mode, bool materialise) { return P.jit[medium_jit_slot(mode, materialise)].func != nullptr; }
+inline int medium_jit_slot(int mode, bool materialise, int level) { return (2 * medium_jit_index(mode) + (materialise ? 1 : 0)) * MED_GEOM_LEVELS + level; }
+inline bool medium_jit_ready(const MedProgram &P, int mode, bool materialise) {
+  for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, materialise, h)].func) return true;
+  return false;
+}
+// strip width for a batch (narrower strips for short input sequences)
+MedGeom medium_pick_geometry(const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs, bool materialise);
 void medium_jit_free(MedProgram &P);
 int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs,
                              const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,

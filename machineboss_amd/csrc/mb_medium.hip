@@ -813,7 +813,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   int2 *d_tiles = nullptr;
   if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
-  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true)] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level)] : nullptr;
   if (mode == MED_MODE_COUNT && !J) { (void)hipFree(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
@@ -847,6 +847,27 @@ static int tile_steps(int C, size_t nPairs, int maxOut) {
   return TS;
 }
 
+MedGeom medium_pick_geometry(const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs, bool materialise) {
+  // Rule fitted to dnapsw (1 kb) and protpsw (400 aa) sweeps: a strip about an eighth of the longest input -- the last
+  // strip's padding and the skewed start/end of every sweep then cost ~10 % -- but never fewer than 4 wavefronts per
+  // workgroup for the materialised kernels (2 for the rolling one, which has no stores to hide).
+  MedGeom best = geo;
+  best.level = 0;
+  if (pairs.empty() || env_int_m("MB_MEDIUM_ADAPT_WIDTH", 1) == 0) return best;
+  int maxIn = 0;
+  for (const PairDesc &pd : pairs) maxIn = std::max(maxIn, pd.inLen);
+  const int minWaves = std::min(geo.waves, materialise ? 4 : 2);
+  int waves = geo.waves;
+  for (int h = 1; h < MED_GEOM_LEVELS; ++h) {
+    const int w2 = waves / 2;
+    if (w2 < minWaves || (long long)w2 * P.G * 8 < maxIn + 1) break;
+    waves = w2;
+    best.waves = waves; best.C = waves * P.G; best.level = h;
+  }
+  best.ldsBytes = (size_t)P.NS * (best.C + 1) * P.Spad * sizeof(double);
+  return best;
+}
+
 static int max_out_len(const std::vector<PairDesc> &pairs) {
   int mx = 0;
   for (const PairDesc &pd : pairs) mx = std::max(mx, pd.outLen);
@@ -854,10 +875,11 @@ static int max_out_len(const std::vector<PairDesc> &pairs) {
 }
 
 // Materialised fill of a chunk of pairs whose matrices are all kept (Viterbi, Backward, counts, mb_fill).
-int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,
+int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st) {
   if (pairsIn.empty()) return 0;
+  const MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
   set_lds_attr();
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
@@ -866,10 +888,11 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
   return launch_wavefront(m, P, dev, geo, mode, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
 }
 
-int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs,
                                const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out, double *d_fwd,
                                const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st) {
   if (pairsIn.empty()) return 0;
+  const MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
   if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, true)) return -1;
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
@@ -881,11 +904,12 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
 // a continuous pipeline.  Pair p starts at launch launch0[p]; a new pair is admitted as soon as the wavefront has
 // room for its strips (target: one resident workgroup per CU) and a matrix slot is free, so the chip stays full
 // across pair boundaries instead of draining at every sub-batch.  Matrix slots are recycled in stream order.
-int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairsIn,
+int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const std::vector<PairDesc> &pairsIn,
                              const int *d_in, const int *d_out, double *d_pool, long long poolCells, double *d_loglike,
                              hipStream_t st) {
   const long long n = (long long)pairsIn.size();
   if (n == 0) return 0;
+  const MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
   set_lds_attr();
   const int C = geo.C, S = m->S;
   long long slotCells = 0;
@@ -943,10 +967,11 @@ int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &
 }
 
 // Rolling (log-likelihood only) Forward: one workgroup per pair per launch, strips in sequence.
-int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
+int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs,
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st) {
   if (pairs.empty()) return 0;
+  const MedGeom geo = medium_pick_geometry(P, geoIn, pairs, false);
   set_lds_attr();
   int maxIn = 0, maxOut = 0;
   for (const PairDesc &pd : pairs) { maxIn = std::max(maxIn, pd.inLen); maxOut = std::max(maxOut, pd.outLen); }
@@ -955,7 +980,7 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
   A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.tiles = nullptr; A.tileBase = 0;
   const dim3 grid((unsigned)pairs.size()), block(geo.waves * 64);
-  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, false) ? &P.jit[medium_jit_slot(MB_FORWARD, false)] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, false) ? &P.jit[medium_jit_slot(MB_FORWARD, false, geo.level)] : nullptr;
   MedProgDev dev = P.dev;
   dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   for (int a = 0; a < NA; ++a) {

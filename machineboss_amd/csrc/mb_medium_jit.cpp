@@ -227,7 +227,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
 }
 
 bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
-  MedJit &J = P.jit[medium_jit_slot(mode, materialise)];
+  MedJit &J = P.jit[medium_jit_slot(mode, materialise, geo.level)];
   if (J.tried) return J.func != nullptr;
   if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;
