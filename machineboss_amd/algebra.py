@@ -201,6 +201,28 @@ def zeroMachine() -> Machine:
     m = Machine(); m.state += [MachineState(), MachineState()]; return m
 
 
+def generator(seq: List[str], name: str) -> Machine:
+    """Machine::generator (src/machine.cpp:1667-1675): emits exactly `seq`."""
+    m = Machine()
+    for pos in range(len(seq) + 1):
+        ms = MachineState(); ms.name = [name, pos]
+        if pos < len(seq):
+            ms.trans.append(MachineTransition(dest=pos + 1, inp="", out=seq[pos], weight=1))
+        m.state.append(ms)
+    return m
+
+
+def recognizer(seq: List[str], name: str) -> Machine:
+    """Machine::recognizer (src/machine.cpp:1677-1685): accepts exactly `seq`."""
+    m = Machine()
+    for pos in range(len(seq) + 1):
+        ms = MachineState(); ms.name = [name, pos]
+        if pos < len(seq):
+            ms.trans.append(MachineTransition(dest=pos + 1, inp=seq[pos], out="", weight=1))
+        m.state.append(ms)
+    return m
+
+
 def concatenate(left: Machine, right: Machine, leftTag: str = MachineCatLeftTag, rightTag: str = MachineCatRightTag) -> Machine:
     """src/machine.cpp:1748-1765."""
     if not left.state or not right.state:

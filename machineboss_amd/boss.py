@@ -118,6 +118,8 @@ def buildParser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="boss", description=__doc__.split("\n\n")[0])
     ap.add_argument("machine", nargs="*", help="transducer JSON file")
     ap.add_argument("--preset", action="append", default=[], help="preset name (dnapsw, protpsw, psw2dna, translate); repeatable")
+    ap.add_argument("--generate-chars", help="compose a generator of this sequence in front of the machine(s)")
+    ap.add_argument("--recognize-chars", help="compose a recogniser of this sequence behind the machine(s)")
     ap.add_argument("-P", "--params", action="append", default=[])
     ap.add_argument("-F", "--functions", action="append", default=[])
     ap.add_argument("-N", "--constraints", action="append", default=[])
@@ -146,8 +148,12 @@ def loadPreset(name: str) -> Machine:
 def loadMachine(args) -> Machine:
     """Several machines on one command line are composed, right to left (target/boss.cpp:268-276, 628-634); presets come
     first, in the order given."""
-    from .algebra import composeAll
+    from .algebra import composeAll, generator, recognizer
     machines = [loadPreset(n) for n in args.preset] + [Machine.fromFile(f) for f in args.machine]
+    if args.generate_chars is not None:       # leftmost: a generator of the sequence (target/boss.cpp:362-364)
+        machines.insert(0, generator(list(args.generate_chars), args.generate_chars))
+    if args.recognize_chars is not None:      # rightmost: a recogniser of the sequence (target/boss.cpp:384-386)
+        machines.append(recognizer(list(args.recognize_chars), args.recognize_chars))
     if not machines:
         raise MachineError("Please specify a transducer")
     return composeAll(machines)

@@ -475,19 +475,21 @@ class MachineCounts:
         return self
 
     def paramCounts(self, m: Machine, prob: Dict[str, Any]) -> Dict[str, float]:
-        """src/counts.cpp:88-106: sum over transitions of  count * (dw/dp) * p / w."""
+        """src/counts.cpp:88-106: sum over transitions of  count * (dw/dp) * p / w.  Like the reference, the parameters of
+        a weight are the names that appear IN it (WeightAlgebra::params / deriv are called with empty ParamDefs: function
+        definitions are not expanded), and values come from ``prob`` on top of the machine's own defs."""
         defs = dict(m.funcs); defs.update(prob)
         out: Dict[str, float] = {}
         e = 0
         for s, ms in enumerate(m.state):
             for t in ms.trans:
                 c = float(self._flat[e]); e += 1
-                params = _freeParams(t.weight, m.funcs)
+                params = _freeParams(t.weight, {})
                 if not params:
                     continue
                 w = evalWeight(t.weight, defs)
                 for p in sorted(params):
-                    d = _deriv(t.weight, defs, p)
+                    d = _deriv(t.weight, defs, p, expand=False)
                     out[p] = out.get(p, 0.0) + c * d * float(evalWeight(p, defs)) / w
         return out
 
@@ -506,35 +508,36 @@ def _freeParams(w: Any, funcs: Dict[str, Any]) -> set:
     return out
 
 
-def _deriv(w: Any, defs: Dict[str, Any], p: str) -> float:
+def _deriv(w: Any, defs: Dict[str, Any], p: str, expand: bool = True) -> float:
     """d eval(w) / d p, forward-mode over the JSON expression (the reference differentiates symbolically,
-    src/weight.cpp:302-380, then evaluates; the value is the same)."""
+    src/weight.cpp:302-380, then evaluates; the value is the same).  expand=False treats every other name as a constant
+    (WeightAlgebra::deriv with empty ParamDefs); values always come from ``defs``."""
     if w is None or isinstance(w, (bool, int, float)):
         return 0.0
     if isinstance(w, str):
         if w == p:
             return 1.0
         v = defs.get(w)
-        if v is None or isinstance(v, (int, float)):
+        if not expand or v is None or isinstance(v, (int, float)):
             return 0.0
         return _deriv(v, {k: x for k, x in defs.items() if k != w}, p)
     op, args = next(iter(w.items()))
     ev = lambda x: evalWeight(x, defs)
     if op == "log":
-        return _deriv(args, defs, p) / ev(args)
+        return _deriv(args, defs, p, expand) / ev(args)
     if op == "exp":
-        return _deriv(args, defs, p) * math.exp(ev(args))
+        return _deriv(args, defs, p, expand) * math.exp(ev(args))
     if op == "not":
-        return -_deriv(args, defs, p)
+        return -_deriv(args, defs, p, expand)
     if op == "geomsum":
-        return _deriv(args, defs, p) / (1.0 - ev(args)) ** 2
+        return _deriv(args, defs, p, expand) / (1.0 - ev(args)) ** 2
     a, b = args
     if op == "*":
-        return _deriv(a, defs, p) * ev(b) + ev(a) * _deriv(b, defs, p)
+        return _deriv(a, defs, p, expand) * ev(b) + ev(a) * _deriv(b, defs, p, expand)
     if op == "/":
-        return (_deriv(a, defs, p) * ev(b) - ev(a) * _deriv(b, defs, p)) / ev(b) ** 2
+        return (_deriv(a, defs, p, expand) * ev(b) - ev(a) * _deriv(b, defs, p, expand)) / ev(b) ** 2
     if op == "+":
-        return _deriv(a, defs, p) + _deriv(b, defs, p)
+        return _deriv(a, defs, p, expand) + _deriv(b, defs, p, expand)
     if op == "-":
-        return _deriv(a, defs, p) - _deriv(b, defs, p)
+        return _deriv(a, defs, p, expand) - _deriv(b, defs, p, expand)
     raise MachineError("Unknown opcode %s" % op)

@@ -606,6 +606,13 @@ def test_boss_cli_reference_outputs(capi):
     # test-counts: -C prints parameter counts {"p":2,"q":1}
     got = _boss([mach("bitnoise"), "-P", io_("params"), "--input-chars", "101", "--output-chars", "001", "-C"])
     assert json.loads(got) == json.loads(exp("counts"))
+    # test-counts (Makefile:518): the same counts from the composed-with-sequences form -- generator(101) . bitnoise .
+    # recognizer(001) is an all-silent machine whose only evidence is the empty pair
+    got = _boss(["--generate-chars", "101", mach("bitnoise"), "--recognize-chars", "001", "-P", io_("params"), "-N", io_("pqcons"), "-C"])
+    assert json.loads(got) == json.loads(exp("counts"))
+    # test-counts3 (Makefile:524): a generator with a counting parameter
+    got = _boss([mach("counter"), "--output-chars", "xxx", "-C"])
+    assert json.loads(got) == json.loads(exp("counter"))
     # test-fit-bitnoise-seqpairlist: -T prints the fitted parameters
     got = json.loads(_boss([mach("bitnoise"), "-N", io_("pqcons"), "-D", io_("seqpairlist"), "-T"]))
     assert {k: float("%.4g" % v) for k, v in got.items()} == json.loads(exp("fit-bitnoise-seqpairlist"))
