@@ -363,6 +363,11 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
 // ------------------------------------------------------------------------------------------------------------
 struct Cand { int src; int wref; };   // src: index into the LDS state vector; wref: see MedProgram::wref
 
+static int env_int_m(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 static double host_lse(double a, double b) {
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
@@ -373,7 +378,7 @@ static double host_lse(double a, double b) {
 // closure = 0: levelled (exact) program; K >= 1: silent closure in K stages -- the silent levels 1..nLev-1 are cut into K
 // consecutive groups, every group is closed transitively over (a) the states finalised by earlier groups and (b) the
 // emit-only parts of its own emit-fed states, and costs ONE synchronisation point.  K = 1 is the full closure.
-static void build_program(const mb_machine *m, bool backward, int closure, int G, MedProgram &P) {
+static void build_program(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, bool allowSplit = true) {
   const int S = m->S, LPG = 64 / G, nIn = m->nIn, nOut = m->nOut;
   P = MedProgram();
   P.G = G; P.LPG = LPG; P.backward = backward; P.closure = closure != 0;
@@ -416,7 +421,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
     }
 
   // ---- nodes of the program: (destination index in the LDS vector, emit candidates of which state, "cur" candidates)
-  struct Node { int dst; int emitOf; std::vector<Cand> cur; int stage; };
+  struct Node { int dst; int emitOf; std::vector<Cand> cur; int stage; int lo = 0, hi = 1 << 30; bool seed = false; };   // [lo,hi): window of the emit candidate lists
   std::vector<Node> nodes;
   int nExtra = 0, nClosureStages = 1;
   if (!closure) {
@@ -471,18 +476,85 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
     }
     nClosureStages = K;
   }
+  // ---- split high-degree nodes -------------------------------------------------------------------------------------------
+  // A state with dozens of emitting candidates for one token (psw2dna, Backward: three states fan out to 62 codon
+  // states) would make its whole round 60+ slots deep while one lane works.  Its candidate lists are cut into parts of
+  // `part`, each evaluated by its own lane into an extra vector entry (stage 0: emitting candidates read other cells
+  // only), and a combining node folds the partial results with weight 0 one stage later -- max of maxes and
+  // log-sum of log-sums are the same reductions, and for max the result is bit-identical.
+  bool anySplit = false, anySplitCur = false;
+  int extraStages = 0;
+  {
+    const int splitAt = allowSplit ? env_int_m("MB_MEDIUM_SPLIT_DEGREE", 12) : 0, part = 8;
+    const int seedStage = closure ? 0 : lev[startNode];
+    std::vector<Node> outNodes;
+    for (Node &n : nodes) {
+      if (n.emitOf == startNode && n.stage == seedStage) n.seed = true;
+      const int md = n.emitOf >= 0 ? std::max(emitDeg[n.emitOf][0], std::max(emitDeg[n.emitOf][1], emitDeg[n.emitOf][2])) : 0;
+      if (splitAt <= 0 || md <= splitAt) { outNodes.push_back(n); continue; }
+      anySplit = true;
+      Node comb = n;
+      comb.emitOf = -1; comb.stage = -1 - n.stage;      // marked: becomes n.stage + 1 below (and is never left in stage 0)
+      for (int lo = 0; lo < md; lo += part) {
+        Node pn{S + 1 + nExtra, n.emitOf, {}, 0};
+        pn.lo = lo; pn.hi = lo + part;
+        comb.cur.push_back({S + 1 + nExtra, -2 - P.nPairs});   // the constant-0 "pair"
+        ++nExtra;
+        outNodes.push_back(pn);
+      }
+      outNodes.push_back(comb);
+    }
+    if (anySplit) {
+      for (Node &n : outNodes) {
+        if (n.stage < 0) n.stage = -n.stage;            // combining node: old stage + 1
+        else if (n.stage > 0) n.stage += 1;             // everything that may depend on a combined value moves one stage on
+      }
+      nodes.swap(outNodes);
+    }
+    // the same for long lists of same-cell candidates (silent fan-in): the parts stay in the node's stage (they read
+    // values of earlier stages), the combining node opens a new stage right behind it
+    if (splitAt > 0) {
+      int maxStage = 0;
+      for (const Node &n : nodes) maxStage = std::max(maxStage, n.stage);
+      std::vector<int> shiftOf(maxStage + 2, 0);
+      for (int st = 0, shift = 0; st <= maxStage; ++st) {
+        shiftOf[st] = shift;
+        bool need = false;
+        for (const Node &n : nodes) if (n.stage == st && (int)n.cur.size() > splitAt) need = true;
+        if (need) ++shift;
+        shiftOf[st + 1] = shift;
+      }
+      std::vector<Node> out2;
+      for (Node &n : nodes) {
+        const int st = n.stage;
+        if ((int)n.cur.size() <= splitAt) { n.stage = st + shiftOf[st]; out2.push_back(n); continue; }
+        Node comb = n;
+        comb.cur.clear(); comb.stage = st + shiftOf[st] + 1;
+        for (size_t lo = 0; lo < n.cur.size(); lo += part) {
+          Node pn{S + 1 + nExtra, -1, {}, st + shiftOf[st]};
+          pn.cur.assign(n.cur.begin() + lo, n.cur.begin() + std::min(n.cur.size(), lo + part));
+          comb.cur.push_back({S + 1 + nExtra, -2 - P.nPairs});
+          ++nExtra;
+          out2.push_back(pn);
+        }
+        out2.push_back(comb);
+        anySplitCur = true;
+      }
+      if (anySplitCur) { nodes.swap(out2); extraStages = shiftOf[maxStage + 1]; }
+    }
+  }
   // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to.  Even length keeps every column 16-byte
   // aligned; with one or two lanes per supercell the lanes of a wavefront read DIFFERENT columns at the same state
   // offset, and an odd length (stride of 2 x odd LDS banks) makes those reads conflict-free.
   P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;
   if (LPG <= 2) P.Spad |= 1;
   P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
-  const int nStages = closure ? 1 + nClosureStages : nLev;
+  const int nStages = (closure ? 1 + nClosureStages : nLev) + (anySplit ? 1 : 0) + extraStages;
 
   // ---- rounds: per stage, nodes sorted so that a round is homogeneous in (tables used, candidate count) ----------
   auto sig = [&](const Node &n) {
     std::array<int, 4> d{0, 0, 0, (int)n.cur.size()};
-    if (n.emitOf >= 0) for (int T = 0; T < 3; ++T) d[T] = emitDeg[n.emitOf][T];
+    if (n.emitOf >= 0) for (int T = 0; T < 3; ++T) d[T] = std::max(0, std::min(emitDeg[n.emitOf][T], n.hi) - n.lo);
     return d;
   };
   std::vector<std::vector<int>> rounds;
@@ -527,7 +599,13 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   auto candsOf = [&](const Node &n, int T, int tok, std::vector<Cand> &out) {
     if (T == 3) { out = n.cur; return; }
     out.clear();
-    if (n.emitOf >= 0) emitCands(n.emitOf, T, tok, out);
+    if (n.emitOf >= 0) {
+      emitCands(n.emitOf, T, tok, out);
+      if (n.lo > 0 || n.hi < (int)out.size()) {      // this node's window of the candidate list
+        const int a = std::min<int>(n.lo, (int)out.size()), b = std::min<int>(n.hi, (int)out.size());
+        out = std::vector<Cand>(out.begin() + a, out.begin() + b);
+      }
+    }
   };
   for (int r = 0; r < P.nRounds; ++r) {
     // slots of the round, table by table; a chunk holds up to MS slots of ONE table (so it reads one LDS vector)
@@ -583,7 +661,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   // where the seed goes: the stage-1 destination of the start node
   P.dev.seedOff = 0;
   for (const Node &n : nodes)
-    if (n.emitOf == startNode && n.stage == (closure ? 0 : lev[startNode])) P.dev.seedOff = (unsigned)n.dst * 8u;
+    if (n.seed) P.dev.seedOff = (unsigned)n.dst * 8u;
 }
 
 template <class T>
@@ -655,11 +733,6 @@ bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, M
 // LDS for the candidate records, which then stream from L2 on every step (protpsw.translate.dnapsw: 42 KB per wave-step,
 // 670 KB per step and CU -- the L1 fill rate, not HBM, bounded the kernel).  Give columns up -- down to half -- until
 // the records that cannot sit in VGPRs fit next to the ring.
-static int env_int_m(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   const char *e = getenv("MB_MEDIUM_MAXWAVES");
   if (e && atoi(e) > 0 && atoi(e) < geo.waves) { geo.waves = atoi(e); geo.C = geo.waves * P.G; }
@@ -698,7 +771,7 @@ bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedPro
 // candidate's transition packed into the upper half of srcOff.  Geometry leaves room for one Backward supercell per
 // column and the count array in LDS, and keeps the workgroup at 8 wavefronts (256 VGPRs each).
 bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
-  build_program(m, false, false, G, P);
+  build_program(m, false, false, G, P, /*allowSplit=*/false);   // counting terms need every candidate beside its real destination
   P.counting = true; P.accEntries = (int)m->nTrans + P.LPG;   // + one dummy accumulator per lane of a group (padding candidates)
   if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 16) || (m->nTrans + 64 + 2) * 8 >= (1 << 16)) return false;
   MedProgDev &d = P.dev;
