@@ -45,9 +45,9 @@ static int ensure_init() {
 // Grow-only device workspaces, kept across calls so that steady-state batch calls do no hipMalloc/hipFree
 // (a 200 GB hipMalloc costs far more than the kernels it feeds).  Slot 0/1: matrix pools, 2: halo columns.
 struct Workspace { void *p = nullptr; size_t bytes = 0; };
-static Workspace g_ws[3];
+static Workspace g_ws[6];   // 0/1 matrix pools, 2 halo columns, 3/4/5 Viterbi path slots / lengths / edges
 
-static size_t cached_bytes() { return g_ws[0].bytes + g_ws[1].bytes + g_ws[2].bytes; }
+static size_t cached_bytes() { size_t t = 0; for (const Workspace &w : g_ws) t += w.bytes; return t; }
 
 static void *ws_get(int slot, size_t bytes) {
   Workspace &w = g_ws[slot];
@@ -518,9 +518,10 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
       if (wantPaths) {
         for (long long p = 0; p < np; ++p)
           slot[p + 1] = slot[p] + mb_viterbi_path_bound(b->m, b->pairs[c.p0 + p].inLen, b->pairs[c.p0 + p].outLen);
-        if (!hip_ok(hipMalloc((void **)&d_slot, (np + 1) * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
-        if (!hip_ok(hipMalloc((void **)&d_len, np * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
-        if (!hip_ok(hipMalloc((void **)&d_path, std::max<long long>(slot[np], 1) * sizeof(uint32_t)), "hipMalloc(paths)")) { rc = 1; break; }
+        // cached workspaces: a hipMalloc/hipFree pair per call costs more than the traceback kernel of a small batch
+        if (!(d_slot = (long long *)ws_get(3, (np + 1) * sizeof(long long)))) { rc = 1; break; }
+        if (!(d_len = (long long *)ws_get(4, np * sizeof(long long)))) { rc = 1; break; }
+        if (!(d_path = (uint32_t *)ws_get(5, std::max<long long>(slot[np], 1) * sizeof(uint32_t)))) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
         if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
       }
@@ -544,7 +545,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         }
       }
     } while (0);
-    void *ptrs[] = {d_desc, d_ll, d_slot, d_len, d_path};
+    void *ptrs[] = {d_desc, d_ll};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (rc) break;
   }

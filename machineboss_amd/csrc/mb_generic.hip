@@ -250,6 +250,93 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
   if (lane == 0) pathLen[p] = n;
 }
 
+// The same walk for machines whose incoming tables fit LDS (CSR offsets <= 8192 rows, <= 2048 transitions): four pairs
+// per workgroup (one wavefront each) share an LDS copy of the tables, so a path step costs ONE trip to HBM (the cells the
+// candidates point at) instead of three dependent ones (CSR offsets -> edges -> cells).  With few states per supercell
+// (S <= 16) the 3 x 3 block of supercells around the position -- every cell the NEXT step can read -- is touched one
+// step ahead, so that trip mostly ends in the XCD's L2.  Candidate order, tie-break and results are those of k_traceback.
+struct TbEdge { double w; uint32_t eid; uint16_t src; uint8_t hasIn, hasOut; };
+__global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairDesc *__restrict__ pairs, long long nPairs,
+                                                       long long nTrans, const int *__restrict__ inTok, const int *__restrict__ outTok,
+                                                       const double *__restrict__ pool, const long long *__restrict__ slotOff,
+                                                       uint32_t *__restrict__ pathBuf, long long *__restrict__ pathLen) {
+  extern __shared__ unsigned char tb_raw[];
+  const int nRows = m.S * m.K;
+  int *lOff = (int *)tb_raw;                                                   // [nRows + 1]
+  TbEdge *lEdge = (TbEdge *)(tb_raw + (((size_t)(nRows + 1) * 4 + 15) & ~(size_t)15));   // [nTrans]
+  for (int r = threadIdx.x; r <= nRows; r += blockDim.x) lOff[r] = m.inOff[r];
+  for (int a = threadIdx.x; a < nTrans; a += blockDim.x) {
+    const uint32_t eid = m.inEid[a];
+    TbEdge e; e.w = m.inW[a]; e.eid = eid; e.src = (uint16_t)m.inSrc[a]; e.hasIn = m.eInTok[eid] != 0; e.hasOut = m.eOutTok[eid] != 0;
+    lEdge[a] = e;
+  }
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= nPairs) return;
+  const PairDesc pd = pairs[p];
+  const int inLen = pd.inLen, outLen = pd.outLen, S = m.S;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  const double *cells = pool + pd.cellBase;
+  const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  int i = inLen, o = outLen, s = S - 1;
+  if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
+  long long n = 0;
+  const bool prefetch = 9 * S <= 128;
+  double pfA = 0.0, pfB = 0.0;
+  unsigned sink = 0;
+  while (i > 0 || o > 0 || s != 0) {
+    const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+    const double *cur = cells + ((long long)o * I + i) * S;
+    double best = -INFINITY; int bestIdx = 0x7fffffff; int bestA = -1;
+    int base = 0;
+    for (int grp = 0; grp < 4; ++grp) {
+      int kit, kot; const double *sc;
+      if (grp == 0) { if (!(i && o)) continue; kit = it; kot = ot; sc = cur - (I + 1) * S; }
+      else if (grp == 1) { if (!i) continue; kit = it; kot = 0; sc = cur - S; }
+      else if (grp == 2) { if (!o) continue; kit = 0; kot = ot; sc = cur - I * S; }
+      else { kit = 0; kot = 0; sc = cur; }
+      const int row = (s * (m.nIn + 1) + kit) * (m.nOut + 1) + kot;
+      const int a0 = lOff[row], a1 = lOff[row + 1];
+      for (int a = a0 + lane; a < a1; a += 64) {
+        const double v = sc[lEdge[a].src] + lEdge[a].w;
+        const int idx = base + (a - a0);
+        if (bestA < 0 || v > best || (v == best && idx < bestIdx)) { best = v; bestIdx = idx; bestA = a; }
+      }
+      base += a1 - a0;
+    }
+    if (prefetch) {
+      // touch the supercells (i-2..i, o-2..o): lane L reads double L of the 3 x 3 x S block (two passes), clamped
+      sink ^= (unsigned)__double2loint(pfA) ^ (unsigned)__double2loint(pfB);      // consumes LAST step's touches: no wait on this step's
+      const int per = 3 * S;
+      for (int k = 0; k < 2; ++k) {
+        const int e = lane + 64 * k;
+        const int r = min(e / per, 2), c = e - (e / per) * per;
+        const long long po = max(o - r, 0), pi0 = max(i - 2, 0);
+        const long long off = (po * I + pi0) * S + min(c, (int)((i - pi0 + 1) * S) - 1);
+        const double v = cells[off];
+        if (k == 0) pfA = v; else pfB = v;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bestIdx, off), oa = __shfl_xor(bestA, off);
+      const bool take = oa >= 0 && (bestA < 0 || ov > best || (ov == best && oi < bestIdx));
+      if (take) { best = ov; bestIdx = oi; bestA = oa; }
+    }
+    if (bestA < 0) { if (lane == 0) pathLen[p] = -3; return; }
+    if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
+    const TbEdge be = lEdge[bestA];
+    if (lane == 0) pathBuf[slot0 + cap - 1 - n] = be.eid;
+    ++n;
+    if (be.hasIn) --i;
+    if (be.hasOut) --o;
+    s = (int)be.src;
+  }
+  if (lane == 0) pathLen[p] = (sink == 0x9e3779b9u && n < 0) ? -4 : n;   // `sink` keeps the touches alive; never true
+}
+
 // ---- launch helpers (host) -----------------------------------------------------------------------------------
 __global__ void k_fill_neg_inf(double *p, long long n) {
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) p[k] = -INFINITY;
@@ -302,6 +389,15 @@ int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPa
                      const double *d_pool, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen,
                      hipStream_t st) {
   if (nPairs == 0) return 0;
+  const long long nRows = (long long)m->S * m->K;
+  const size_t ldsBytes = (((size_t)(nRows + 1) * 4 + 15) & ~(size_t)15) + (size_t)m->nTrans * sizeof(TbEdge);
+  static int useLds = -1;
+  if (useLds < 0) { const char *e = getenv("MB_TRACEBACK_LDS"); useLds = (e && *e == '0') ? 0 : 1; }
+  if (useLds && nRows <= 8192 && m->nTrans <= 2048 && m->S <= 65535 && ldsBytes <= 64 * 1024) {
+    hipLaunchKernelGGL(k_traceback_lds, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), ldsBytes, st, m->dev, d_pairs, nPairs,
+                       (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
+    return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
+  }
   hipLaunchKernelGGL(k_traceback, dim3((unsigned)nPairs), dim3(64), 0, st, m->dev, d_pairs, d_in, d_out, d_pool, d_slotOff,
                      d_pathBuf, d_pathLen);
   return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
