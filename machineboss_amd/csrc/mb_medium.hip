@@ -894,7 +894,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
   A.poolB = d_poolB; A.counts = d_counts;
-  { const char *e = getenv("MB_DEBUG_NOSTORE"); A.debugNoStore = (e && *e == '1') ? 1 : 0; }
+  { const char *e = getenv("MB_DEBUG_NOSTORE"); A.debugNoStore = e ? atoi(e) : 0; }   // timing experiments only: 1 = last column only, 2 = + every other column
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
     if (cnt[l] <= 0) continue;

@@ -350,7 +350,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     if (active) {
       if (JMAT) {
         double *dstp = cellPtr(i, o);
-        if (!A.debugNoStore || c == C - 1) med_copy_out(dstp, cur, q);
+        if (!A.debugNoStore || c == C - 1 || (A.debugNoStore == 2 && (c & 1) == 0)) med_copy_out(dstp, cur, q);
       } else if (c == C - 1) {
         med_copy_out(haloOut + (long long)o * S, cur, q);
       }
