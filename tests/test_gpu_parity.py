@@ -781,3 +781,34 @@ def test_one_tape_machines(capi, oracle_mod):
                 assert np.array_equal(edges[off[0]:off[1]], om.traceback(x, y, om.viterbi(x, y)))
             ref = np.zeros(em.nTransitions); om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
             assert close(counts, 3 * ref, 1e-5, 1e-7)
+
+
+@pytest.mark.parametrize("stages,split", [(0, 12), (1, 12), (2, 2), (3, 3), (5, 2), (9, 1)])
+def test_closure_stages_and_node_splitting(capi, oracle_mod, machines, monkeypatch, stages, split):
+    """Every shape of the program compiler -- levelled, full closure, K-stage closures, with nodes split into parts of
+    every granularity -- against the oracle: psw2dna (emitting and silent fan-out of 62) and random machines with match
+    edges, in both sweep directions; Viterbi stays bit-exact whatever the split."""
+    from randmachine import random_machine, random_seq
+    monkeypatch.setenv("MB_MEDIUM_CLOSURE_STAGES", str(stages))
+    monkeypatch.setenv("MB_MEDIUM_SPLIT_DEGREE", str(split))
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    rng = np.random.RandomState(stages * 7 + split)
+    cases = [(em, *synth_tokens(50 + stages, 37, 61, em.nInTok, em.nOutTok))]
+    for S, seed in ((29, 4), (75, 5)):
+        rm = random_machine(S, 3, 4, seed, allow_inf=(seed == 5))
+        cases.append((rm, random_seq(rng, 23, 3), random_seq(rng, 31, 4)))
+    for e, x, y in cases:
+        om = oracle_mod.OracleMachine(e); dm = capi.DeviceMachine(e)
+        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+        assert "k_medium" in capi.last_kernel_name()
+        assert np.array_equal(V, om.viterbi(x, y))
+        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        assert close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+        assert close(b.forward(capi.MB_ROLLING), [F[-1, -1, -1]], 1e-9, 1e-12)
+        counts, s, _ = b.counts()
+        if F[-1, -1, -1] > -math.inf:      # an unreachable pair counts nothing here (the reference would produce NaN)
+            ref = np.zeros(e.nTransitions); om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+            assert close(counts, ref, 1e-5, 1e-7)
+        else:
+            assert not counts.any()
