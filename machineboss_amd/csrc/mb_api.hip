@@ -10,6 +10,7 @@
 
 #include "mb_internal.h"
 #include "mb_medium.h"
+#include "mb_wide.h"
 
 namespace mb {
 
@@ -146,6 +147,8 @@ struct FastState {
   bool countOk = false;
   MedProgram fwdCnt;
   MedGeom geoCnt;
+  // large one-tape machines (mb_wide.hip): programs built on first use, rebuilt after a weight update
+  WideProgram wFwd, wBwd, wVit;
 };
 
 static int env_int(const char *name, int dflt) {
@@ -159,7 +162,7 @@ static FastState *fast_state(mb_machine *m) {
   if (!f->tried) {
     f->tried = true;
     // tiny machines run with 8 columns per wavefront (8 lanes per supercell); 1-state machines stay generic
-    if (m->S >= env_int("MB_MEDIUM_MIN_STATES", 2) && m->S <= 4096) {
+    if (m->S >= env_int("MB_MEDIUM_MIN_STATES", 2) && m->S <= 4096 && !wide_applicable(m)) {
       int G = env_int("MB_MEDIUM_G", 0);
       if (!medium_valid_G(G)) G = medium_default_G(m->S);
       f->G = G;
@@ -213,6 +216,15 @@ static bool use_medium(mb_machine *m) {
   return f->mediumOk;
 }
 
+// the one-tape family: program of a direction / semiring, (re)built from the current weights when needed
+static WideProgram *wide_program(mb_machine *m, int mode) {
+  if (g_kernel_choice == 1 || !wide_applicable(m)) return nullptr;
+  FastState *f = fast_state(m);
+  WideProgram &P = mode == MB_VITERBI ? f->wVit : (mode == MB_BACKWARD ? f->wBwd : f->wFwd);
+  if ((!P.ok || P.dirty) && !wide_build(m, mode == MB_BACKWARD, mode == MB_VITERBI, P)) return nullptr;
+  return &P;
+}
+
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
                       const int *d_out, double *pool, int startState, const mb_batch *b) {
@@ -221,6 +233,12 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     long long cells = 0;
     for (const PairDesc &pd : hp) cells = std::max(cells, pd.cellBase + (long long)(pd.inLen + 1) * (pd.outLen + 1) * m->S);
     if (launch_fill_neg_inf(pool, cells, g_stream)) return 1;
+  }
+  if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1) {
+    WideProgram *W = wide_program(m, mode);
+    if (!W) return 1;
+    g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : "k_wide_sweep<0>";
+    return wide_fill(m, *W, d_desc, (long long)hp.size(), d_out, pool, nullptr, g_stream);
   }
   if (!env && use_medium(m)) {
     FastState *f = fast_state(m);
@@ -293,6 +311,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
     FastState *f = (FastState *)m->fast;
     if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
     if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
+    f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = true;
   }
   return 0;
 }
@@ -302,6 +321,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt);
+    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit);
     delete f;
   }
   free_machine_device(m);
@@ -419,7 +439,19 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   // either way (psw2dna, 64 pairs: 229 vs 517 G cells/s).
   const bool fewPairs = b->nPairs < env_int("MB_ROLLING_MIN_PAIRS", 192) &&
                         (size_t)b->maxPairCells * 8 * 2 <= budget_bytes();
-  if (mode == MB_FORWARD && (flags & MB_ROLLING) && !fewPairs && !b->hasEnv && use_medium(m)) {
+  if (mode == MB_FORWARD && !b->hasEnv && wide_applicable(m) && g_kernel_choice != 1 &&
+      ((flags & MB_ROLLING) || (size_t)b->totalCells * 8 > budget_bytes())) {
+    // one-tape machine, log-likelihood only: the two live columns of every sequence stay in LDS, nothing goes to HBM
+    WideProgram *W = wide_program(m, MB_FORWARD);
+    if (!W) rc = 1;
+    else {
+      tm.start();
+      rc = wide_fill(m, *W, b->d_pairs, b->nPairs, b->d_out, nullptr, d_ll, g_stream);
+      g_last_kernel = "k_wide_sweep<0>";
+      g_last_ms += tm.stop();
+      if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;
+    }
+  } else if (mode == MB_FORWARD && (flags & MB_ROLLING) && !fewPairs && !b->hasEnv && use_medium(m)) {
     // RollingOutputForwardMatrix: no matrix in HBM, only two halo columns per pair
     FastState *f = fast_state(m);
     std::vector<long long> hb(b->nPairs);

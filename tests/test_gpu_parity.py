@@ -812,3 +812,73 @@ def test_closure_stages_and_node_splitting(capi, oracle_mod, machines, monkeypat
             assert close(counts, ref, 1e-5, 1e-7)
         else:
             assert not counts.any()
+
+
+def _profile_machine(nodes):
+    """fn3 profile truncated to `nodes` nodes . simple_introns . translate . dnapsw (BASELINE config 5, literal composition)."""
+    from machineboss_amd import algebra as A
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).truncated(nodes)
+    m = A.composeAll([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
+    return m, EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+
+
+@pytest.mark.parametrize("stages", [-1, 0, 1, 3, 40])
+def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
+    """BASELINE config 5 at test size: a 3-node profile composed with simple_introns . translate . dnapsw (600 states,
+    one tape) through the one-tape kernel family -- Forward / Backward matrices, rolling log-likelihood, bit-exact Viterbi
+    matrix and path, posterior counts -- for the levelled program and several closure groupings, LDS and L2 vectors."""
+    m, em = _profile_machine(3)
+    assert em.nInTok == 0 and em.nStates >= 256
+    if stages >= 0:
+        monkeypatch.setenv("MB_WIDE_CLOSURE_STAGES", str(stages))
+    if stages == 3:
+        monkeypatch.setenv("MB_WIDE_GLOBAL_VECTORS", "1")
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(11 + stages)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (41, 0, 1, 17)]
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    ll = b.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name().startswith("k_wide_sweep")
+    llm = b.forward(capi.MB_MATERIALISE); vll, off, edges = b.viterbi(); counts, s, _ = b.counts()
+    ref = np.zeros(em.nTransitions)
+    for k, y in enumerate(ys):
+        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+        Vo = om.viterbi(x, y)
+        assert np.array_equal(V, Vo)
+        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        assert close([ll[k], llm[k]], [F[-1, -1, -1]] * 2, 1e-9, 1e-12) and vll[k] == Vo[-1, -1, -1]
+        if Vo[-1, -1, -1] > -math.inf:
+            assert np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, Vo))
+        if F[-1, -1, -1] > -math.inf:
+            om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+    assert close(counts, ref, 1e-5, 1e-7)
+    # a weight update rebuilds the programs
+    lw = np.array(em.logWeight, dtype=np.float64) - 0.125
+    dm.set_weights(lw); om.set_weights(lw)
+    assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
+
+
+def test_one_tape_family_small_machines(capi, oracle_mod, monkeypatch):
+    """The one-tape family forced onto tiny generators (256-lane workgroups, single lanes per state)."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
+    gen = Machine.fromJson({"state": [
+        {"id": "S", "trans": [{"to": "A"}, {"to": "B", "weight": 0.25}]},
+        {"id": "A", "trans": [{"to": "A", "out": "x", "weight": 0.5}, {"to": "B", "out": "y", "weight": 0.3}, {"to": "E", "weight": 0.2}]},
+        {"id": "B", "trans": [{"to": "A", "out": "y", "weight": 0.6}, {"to": "B", "out": "x", "weight": 0.1}, {"to": "E", "weight": 0.3}]},
+        {"id": "E"}]})
+    em = EvaluatedMachine.fromMachine(gen, {})
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    x = np.zeros(0, np.int32)
+    for ol in (0, 1, 23):
+        y = np.random.RandomState(ol).randint(1, 3, size=ol).astype(np.int32)
+        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+        assert capi.last_kernel_name().startswith("k_wide_sweep")
+        assert np.array_equal(V, om.viterbi(x, y))
+        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
