@@ -18,19 +18,25 @@ struct alignas(16) WideRec {
 
 // A round: every lane group of one workgroup finalises one node (state or emit-only part).  Lane `l` of a group of g
 // lanes folds candidates l, l + g, l + 2g, ... of its node (depth slots), the group is reduced with shuffles, its first
-// lane stores.  Record of (slot j, lane) = rec[recBase + tok * tokStride + j * W + lane]; tokStride = 0 when no node of
-// the round has emitting candidates.  dst[dstBase + lane] = sel << 30 | log2(g) << 27 | index.
+// lane stores.  (Host-side planning structure; the kernel reads the linearised streams below.)
 struct WideRound {
   int recBase, tokStride, depth, dstBase;
   int maxG, sync, pad0, pad1;
 };
 
+// What the kernel reads: the slots of one column as a flat stream of [slot][lane] records, so that a lane's loads are
+// known ahead and kept WIDE_RING deep in flight across rounds, barriers and columns.  Segment A (the rounds up to the
+// last one with emitting candidates) exists once per output token, segment B (silent closure) is shared by all tokens.
+// WideRec::pad of slot j: bit 31 = the round ends with this slot, bit 30 = __syncthreads() after it (both uniform over
+// the lanes); in the last slot of a round, per lane: bit 29 = destination is an extra entry, bits 28..26 = log2 of the
+// lane-group size, bits 25..0 = destination index (all ones: this lane stores nothing).
+constexpr int WIDE_RING = 8;
 struct WideDev {
-  const WideRound *rounds;
-  const WideRec *recs;
-  const uint32_t *dsts;
-  int nRounds, S, NV, NX, W;
-  int resultIdx;     // state whose value in the last column is the log-likelihood
+  const WideRec *segA, *segB;
+  long long strideA;   // records per token table of segment A (= nA * W)
+  int nA, nB;          // slots; nA + nB is a multiple of WIDE_RING
+  int S, NV, NX, W;
+  int resultIdx;       // state whose value in the last column is the log-likelihood
   int backward;
 };
 
@@ -42,13 +48,13 @@ struct WideProgram {
   long long nPairs = 0;      // closure pairs
   long long slotsPerColumn = 0;
   int nSync = 0;
-  std::vector<WideRound> rounds;
+  std::vector<WideRound> rounds;     // planning tables (host only)
   std::vector<WideRec> recs;
   std::vector<uint32_t> dsts;
+  std::vector<WideRec> segA, segB;   // linearised streams
   int NV = 0, NX = 0;
-  WideRound *d_rounds = nullptr;
-  WideRec *d_recs = nullptr;
-  uint32_t *d_dsts = nullptr;
+  bool fastIdx = false;              // records carry 16-bit vector indices for both column parities
+  WideRec *d_segA = nullptr, *d_segB = nullptr;
   WideDev dev{};
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };

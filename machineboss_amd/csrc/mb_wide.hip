@@ -28,19 +28,50 @@
 namespace mb {
 
 static constexpr double W_NEG_BIG = -1e300;       // finite stand-in for -inf in the running maximum (avoids inf - inf)
-static constexpr uint32_t W_IDX_MASK = 0x07ffffffu;
-static constexpr uint32_t W_NO_DST = 0x07ffffffu;
+static constexpr uint32_t W_IDX_MASK = 0x03ffffffu;
+static constexpr uint32_t W_NO_DST = 0x03ffffffu;
 
 // ------------------------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------------------------
-template <int MODE, bool GV>
+// one candidate folded into a lane's running (max, sum of exp relative to max): exactly one of the two exponentials of
+// the usual online update is exp(0), so a single v_exp_f32 of -|v - m| serves both cases
+template <int MODE>
+__device__ __forceinline__ void wide_fold(double &m, float &s, double v, float sv) {
+  if (MODE == MB_VITERBI) { m = dmax(m, v); return; }
+  const float e = __expf(-fabsf((float)(v - m)));
+  const bool up = v > m;
+  s = __fmaf_rn(up ? s : sv, e, up ? sv : s);
+  m = __builtin_fmax(m, v);
+}
+
+// value of lane (l + H) of the same 16-lane row through the DPP crossbar (row_shl), H = 1, 2, 4, 8; lanes whose source
+// falls outside the row keep their own value (they are never the first lane of a group that still needs the step)
+template <int H>
+__device__ __forceinline__ int wide_row_down(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x100 + H, 0xf, 0xf, false); }
+
+// one step of the lane-group reduction: fold the partial result of lane l + H into lane l when both belong to one group
+template <int MODE, int H>
+__device__ __forceinline__ void wide_reduce_step(double &m, float &s, int g) {
+  double mo; float so;
+  if (H >= 16) { mo = __shfl_down(m, H, 64); so = __shfl_down(s, H, 64); }
+  else {
+    mo = __hiloint2double(wide_row_down<H>(__double2hiint(m)), wide_row_down<H>(__double2loint(m)));
+    so = __int_as_float(wide_row_down<H>(__float_as_int(s)));
+  }
+  if (H >= g) { mo = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG; so = 0.0f; }
+  wide_fold<MODE>(m, s, mo, so);
+}
+
+// FAST: all vector entries of a workgroup are addressable with 16 bits, and a record carries the source index for both
+// parities of the column (the two state vectors swap roles every column): src = index(even column) | index(odd) << 16.
+template <int MODE, bool GV, bool FAST>
 __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                      double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
   extern __shared__ double wlds[];
   const PairDesc pd = pairs[blockIdx.x];
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
-  const int outLen = pd.outLen;
+  const int outLen = pd.outLen, nA = P.nA, n = P.nA + P.nB;
   double *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wlds;
   for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
   __syncthreads();
@@ -50,47 +81,62 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
   const int extraOff = 2 * NV;
   const int *out = outTok + pd.outBase;
   double *cells = pool ? pool + pd.cellBase : nullptr;
+  auto tokOf = [&](int c) -> int {                  // output token the column c of the sweep consumes
+    if (c > outLen) return 0;
+    const int o = P.backward ? outLen - c : c;
+    return P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0);
+  };
+  // the record stream: a wave-uniform cursor (segment A of this column's token, then segment B, then segment A of the
+  // next column's token, ...) runs WIDE_RING slots ahead of the slot being folded; slot j sits in q[j % WIDE_RING]
+  const WideRec *cursor = P.segA + (size_t)tokOf(0) * P.strideA;
+  int jn = 0, cc = 0, tokAhead = tokOf(1);          // slot and column of the cursor, token of the column after it
+  WideRec q[WIDE_RING];
+  auto fetch = [&](WideRec &dst) {
+    dst = cursor[tid];
+    cursor += W; ++jn;
+    if (jn == nA) cursor = P.segB;
+    if (jn == n) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
+  };
+#pragma unroll
+  for (int k = 0; k < WIDE_RING; ++k) fetch(q[k]);
   for (int c = 0; c <= outLen; ++c) {
     const int o = P.backward ? outLen - c : c;
-    const int tok = P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0);
-    for (int r = 0; r < P.nRounds; ++r) {
-      const WideRound R = P.rounds[r];
-      const WideRec *rp = P.recs + (size_t)R.recBase + (size_t)tok * R.tokStride + tid;
-      double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
-      float s = 0.0f;
-#pragma unroll 2
-      for (int j = 0; j < R.depth; ++j) {
-        const WideRec rc = rp[(size_t)j * W];
-        const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
-        const int base = sel == 0 ? curOff : (sel == 1 ? extraOff : prevOff);
-        const double v = V[base + (int)idx] + rc.w;
-        if (MODE == MB_VITERBI) m = dmax(m, v);
+    const int shift = (c & 1) * 16;
+    double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
+    float s = 0.0f;
+    for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
+#pragma unroll
+      for (int k = 0; k < WIDE_RING; ++k) {
+        const WideRec rc = q[k];
+        fetch(q[k]);
+        int at;
+        if (FAST) at = (int)((rc.src >> shift) & 0xffffu);
         else {
-          const double mn = dmax(m, v);
-          s = s * __expf((float)(m - mn)) + __expf((float)(v - mn));
-          m = mn;
+          const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
+          at = (sel == 0 ? curOff : (sel == 1 ? extraOff : prevOff)) + (int)idx;
+        }
+        wide_fold<MODE>(m, s, V[at] + rc.w, 1.0f);
+        const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
+        if (flags & 0x80000000u) {
+          const uint32_t dst = rc.pad;
+          const int g = 1 << ((dst >> 26) & 7);
+          // groups are laid out by decreasing size: the first lane of a wavefront carries the wavefront's largest group
+          const int gWave = 1 << ((flags >> 26) & 7);
+          if (gWave > 32) wide_reduce_step<MODE, 32>(m, s, g);
+          if (gWave > 16) wide_reduce_step<MODE, 16>(m, s, g);
+          if (gWave > 8) wide_reduce_step<MODE, 8>(m, s, g);
+          if (gWave > 4) wide_reduce_step<MODE, 4>(m, s, g);
+          if (gWave > 2) wide_reduce_step<MODE, 2>(m, s, g);
+          if (gWave > 1) wide_reduce_step<MODE, 1>(m, s, g);
+          if ((dst & W_IDX_MASK) != W_NO_DST) {
+            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__logf(s) : -INFINITY);
+            V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
+          }
+          m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
+          s = 0.0f;
+          if (flags & 0x40000000u) __syncthreads();
         }
       }
-      const uint32_t dst = P.dsts[R.dstBase + tid];
-      const int g = 1 << ((dst >> 27) & 7);
-      // groups are laid out by decreasing size, so the first lane of a wavefront carries the largest group of the wavefront
-      const int gWave = __builtin_amdgcn_readfirstlane(g);
-      for (int k = gWave >> 1; k; k >>= 1) {
-        double mo = __shfl_down(m, k, 64);
-        float so = __shfl_down(s, k, 64);
-        if (k >= g) { mo = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG; so = 0.0f; }
-        if (MODE == MB_VITERBI) m = dmax(m, mo);
-        else {
-          const double mn = dmax(m, mo);
-          s = s * __expf((float)(m - mn)) + so * __expf((float)(mo - mn));
-          m = mn;
-        }
-      }
-      if ((dst & W_IDX_MASK) != W_NO_DST) {
-        const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__logf(s) : -INFINITY);
-        V[((dst >> 30) ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
-      }
-      if (R.sync) __syncthreads();
     }
     // the last round of a column always synchronises: the column is complete here
     if (cells) {
@@ -177,13 +223,13 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
     R.tokStride = t2 ? depth * W : 0;
     const WideRec padRec{-INFINITY, PREV(P->dev.S), 0};
     P->recs.resize(P->recs.size() + (size_t)nTab * depth * W, padRec);
-    P->dsts.resize(P->dsts.size() + W, W_NO_DST);
+    P->dsts.resize(P->dsts.size() + W, W_NO_DST);     // idle lanes: group of one, no destination
     int lane = 0;
     for (int q = pos; q < e; ++q) {
       const WNode &nd = *nodes[order[q]];
       const int g = grp[order[q]];
       for (int sub = 0; sub < g; ++sub)
-        P->dsts[R.dstBase + lane + sub] = (sub == 0 ? (nd.dst & 0xc0000000u) | (nd.dst & W_IDX_MASK) : W_NO_DST) | ((uint32_t)ilog2(g) << 27);
+        P->dsts[R.dstBase + lane + sub] = (sub == 0 ? ((nd.dst >> 30) << 29) | (nd.dst & W_IDX_MASK) : W_NO_DST) | ((uint32_t)ilog2(g) << 26);
       for (int t = 0; t < nTab; ++t) {
         const std::vector<WCand> *l2 = (t < (int)nd.t2.size()) ? &nd.t2[t] : nullptr;
         const int n2 = l2 ? (int)l2->size() : 0, tot = n2 + (int)nd.t3.size();
@@ -214,10 +260,54 @@ bool wide_applicable(const mb_machine *m) {
 }
 
 void wide_free(WideProgram &P) {
-  if (P.d_rounds) (void)hipFree(P.d_rounds);
-  if (P.d_recs) (void)hipFree(P.d_recs);
-  if (P.d_dsts) (void)hipFree(P.d_dsts);
+  if (P.d_segA) (void)hipFree(P.d_segA);
+  if (P.d_segB) (void)hipFree(P.d_segB);
   P = WideProgram();
+}
+
+// rounds -> the two record streams the kernel reads (see WideDev)
+static void wide_linearise(WideProgram &P, int nTok) {
+  const int W = P.W, nR = (int)P.rounds.size();
+  int lastTok = -1;
+  for (int r = 0; r < nR; ++r) if (P.rounds[r].tokStride) lastTok = r;
+  int nA = 0, nB = 0;
+  for (int r = 0; r < nR; ++r) (r <= lastTok ? nA : nB) += P.rounds[r].depth;
+  const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
+  (nB || lastTok < 0 ? nB : nA) += padSlots;
+  const WideRec padRec{-INFINITY, PREV(P.dev.S), 0};
+  P.segA.assign((size_t)nTok * nA * W, padRec);
+  P.segB.assign((size_t)nB * W, padRec);
+  for (int t = 0; t < nTok; ++t) {
+    size_t ja = 0, jb = 0;
+    for (int r = 0; r < nR; ++r) {
+      const WideRound &R = P.rounds[r];
+      const bool inA = r <= lastTok;
+      if (!inA && t) continue;
+      for (int j = 0; j < R.depth; ++j) {
+        WideRec *dstp = inA ? &P.segA[((size_t)t * nA + ja++) * W] : &P.segB[(jb++) * W];
+        const WideRec *srcp = &P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W];
+        const bool last = j + 1 == R.depth;
+        for (int l = 0; l < W; ++l) {
+          dstp[l] = srcp[l];
+          dstp[l].pad = last ? (0x80000000u | (R.sync ? 0x40000000u : 0u) | P.dsts[R.dstBase + l]) : 0u;
+        }
+      }
+    }
+  }
+  P.dev.nA = nA; P.dev.nB = nB; P.dev.strideA = (long long)nA * W;
+  // every entry of the workgroup's vectors addressable with 16 bits: both parities' indices precomputed in the record
+  P.fastIdx = 2 * P.NV + P.NX <= 65536 && env_int_w("MB_WIDE_FAST_INDEX", 1);
+  if (P.fastIdx) {
+    const uint32_t NV = (uint32_t)P.NV;
+    auto conv = [&](WideRec &rc) {
+      const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
+      const uint32_t even = sel == 0 ? NV + idx : (sel == 1 ? 2 * NV + idx : idx);      // even column: prev = vector 0, cur = vector 1
+      const uint32_t odd = sel == 0 ? idx : (sel == 1 ? 2 * NV + idx : NV + idx);
+      rc.src = even | (odd << 16);
+    };
+    for (WideRec &rc : P.segA) conv(rc);
+    for (WideRec &rc : P.segB) conv(rc);
+  }
 }
 
 // nodes of the program for K closure stages (K = 0: levelled)
@@ -363,30 +453,34 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.dev.S = S;
   wide_plan(bestNodes, bestStages, m->nOut + 1, P.W, true, &P);
   if (P.rounds.empty()) { set_error("wide program: empty machine"); return false; }
-  if (!up_w(P.d_rounds, P.rounds) || !up_w(P.d_recs, P.recs) || !up_w(P.d_dsts, P.dsts)) return false;
-  P.dev.rounds = P.d_rounds; P.dev.recs = P.d_recs; P.dev.dsts = P.d_dsts;
-  P.dev.nRounds = (int)P.rounds.size(); P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
+  wide_linearise(P, m->nOut + 1);
+  if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
+  const size_t nRecs = P.segA.size() + P.segB.size();
+  P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
+  P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
+  std::vector<WideRec>().swap(P.recs); std::vector<uint32_t>().swap(P.dsts);
+  std::vector<WideRec>().swap(P.segA); std::vector<WideRec>().swap(P.segB);
   P.dev.resultIdx = backward ? 0 : S - 1;
   P.dev.backward = backward ? 1 : 0;
   P.ok = true; P.dirty = false;
   if (verbose)
     fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column, %zu records, vectors %zu bytes\n",
-            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK, P.rounds.size(), P.slotsPerColumn, P.nSync, P.recs.size(), P.vecBytes());
+            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK, P.rounds.size(), P.slotsPerColumn, P.nSync, nRecs, P.vecBytes());
   return true;
 }
 
 static const size_t WIDE_LDS_MAX = 160 * 1024;
 
-template <int MODE, bool GV>
+template <int MODE, bool GV, bool FAST>
 static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
                        double *scratch, hipStream_t st) {
   const size_t lds = GV ? 0 : P.vecBytes();
-  static bool attr[2][2] = {{false, false}, {false, false}};
-  if (!GV && !attr[MODE == MB_VITERBI][0]) {
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_sweep<MODE, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-    attr[MODE == MB_VITERBI][0] = true;
+  static bool attr = false;     // one flag per instantiation
+  if (!GV && !attr) {
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_sweep<MODE, GV, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    attr = true;
   }
-  hipLaunchKernelGGL((k_wide_sweep<MODE, GV>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev, d_desc, d_out, pool, loglike, scratch);
+  hipLaunchKernelGGL((k_wide_sweep<MODE, GV, FAST>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev, d_desc, d_out, pool, loglike, scratch);
   MB_HIP(hipGetLastError());
   return 0;
 }
@@ -400,10 +494,12 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   double *scratch = nullptr;
   if (gv) MB_HIP(hipMalloc((void **)&scratch, (size_t)nPairs * P.vecBytes()));
   int rc;
-  if (P.viterbi) rc = gv ? launch_wide<MB_VITERBI, true>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st)
-                         : launch_wide<MB_VITERBI, false>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st);
-  else rc = gv ? launch_wide<MB_FORWARD, true>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st)
-               : launch_wide<MB_FORWARD, false>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st);
+#define WIDE_GO(M, G, F) launch_wide<M, G, F>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st)
+  if (P.viterbi) rc = gv ? (P.fastIdx ? WIDE_GO(MB_VITERBI, true, true) : WIDE_GO(MB_VITERBI, true, false))
+                         : (P.fastIdx ? WIDE_GO(MB_VITERBI, false, true) : WIDE_GO(MB_VITERBI, false, false));
+  else rc = gv ? (P.fastIdx ? WIDE_GO(MB_FORWARD, true, true) : WIDE_GO(MB_FORWARD, true, false))
+               : (P.fastIdx ? WIDE_GO(MB_FORWARD, false, true) : WIDE_GO(MB_FORWARD, false, false));
+#undef WIDE_GO
   g_last_launches += 1;
   if (gv) {
     if (!rc && !hip_ok(hipStreamSynchronize(st), "wide sweep")) rc = 1;

@@ -837,6 +837,8 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
         monkeypatch.setenv("MB_WIDE_CLOSURE_STAGES", str(stages))
     if stages == 3:
         monkeypatch.setenv("MB_WIDE_GLOBAL_VECTORS", "1")
+    if stages in (0, 1):
+        monkeypatch.setenv("MB_WIDE_FAST_INDEX", "0")
     om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
     rng = np.random.RandomState(11 + stages)
     x = np.zeros(0, np.int32)
