@@ -118,6 +118,10 @@ def buildParser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="boss", description=__doc__.split("\n\n")[0])
     ap.add_argument("machine", nargs="*", help="transducer JSON file")
     ap.add_argument("--preset", action="append", default=[], help="preset name (dnapsw, protpsw, psw2dna, translate); repeatable")
+    ap.add_argument("-H", "--hmmer", help="generator from a HMMER3 model file, local alignment mode (target/boss.cpp:574-579); leftmost")
+    ap.add_argument("--hmmer-global", help="the same in global alignment mode")
+    ap.add_argument("--hmmer-plan7", help="Plan7 generator (single hit, N/C flanks)")
+    ap.add_argument("--hmmer-multihit", help="Plan7 generator with the J loop")
     ap.add_argument("--generate-chars", help="compose a generator of this sequence in front of the machine(s)")
     ap.add_argument("--recognize-chars", help="compose a recogniser of this sequence behind the machine(s)")
     ap.add_argument("-P", "--params", action="append", default=[])
@@ -150,6 +154,11 @@ def loadMachine(args) -> Machine:
     first, in the order given."""
     from .algebra import composeAll, generator, recognizer
     machines = [loadPreset(n) for n in args.preset] + [Machine.fromFile(f) for f in args.machine]
+    from .hmmer import HmmerModel               # profile generators go in front of the transducers (target/boss.cpp:574-600)
+    for path, build in ((args.hmmer, lambda h: h.machine(True)), (args.hmmer_global, lambda h: h.machine(False)),
+                        (args.hmmer_plan7, lambda h: h.plan7Machine(False)), (args.hmmer_multihit, lambda h: h.plan7Machine(True))):
+        if path is not None:
+            machines.insert(0, build(HmmerModel.fromFile(path)))
     if args.generate_chars is not None:       # leftmost: a generator of the sequence (target/boss.cpp:362-364)
         machines.insert(0, generator(list(args.generate_chars), args.generate_chars))
     if args.recognize_chars is not None:      # rightmost: a recogniser of the sequence (target/boss.cpp:384-386)

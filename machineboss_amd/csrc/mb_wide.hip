@@ -45,22 +45,46 @@ __device__ __forceinline__ void wide_fold(double &m, float &s, double v, float s
   m = __builtin_fmax(m, v);
 }
 
-// value of lane (l + H) of the same 16-lane row through the DPP crossbar (row_shl), H = 1, 2, 4, 8; lanes whose source
-// falls outside the row keep their own value (they are never the first lane of a group that still needs the step)
+// value of lane (l ^ H) of the lane group: H = 1, 2 quad permutes, H = 4, 8 half-row / row mirrors (equivalent to the
+// xor once the smaller steps have made quads / half-rows uniform), H = 16, 32 through the LDS crossbar
 template <int H>
-__device__ __forceinline__ int wide_row_down(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x100 + H, 0xf, 0xf, false); }
+__device__ __forceinline__ int wide_xor_lane(int v) {
+  if (H == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);       // quad_perm:[1,0,3,2]
+  if (H == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);       // quad_perm:[2,3,0,1]
+  if (H == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);      // row_half_mirror
+  if (H == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);      // row_mirror
+  return __shfl_xor(v, H, 64);
+}
 
-// one step of the lane-group reduction: fold the partial result of lane l + H into lane l when both belong to one group
+// lane-group reduction, all lanes of the group end with the group's result: butterfly over the maxima, one rescale of
+// the lane's own sum to the group maximum, butterfly over the sums
 template <int MODE, int H>
-__device__ __forceinline__ void wide_reduce_step(double &m, float &s, int g) {
-  double mo; float so;
-  if (H >= 16) { mo = __shfl_down(m, H, 64); so = __shfl_down(s, H, 64); }
-  else {
-    mo = __hiloint2double(wide_row_down<H>(__double2hiint(m)), wide_row_down<H>(__double2loint(m)));
-    so = __int_as_float(wide_row_down<H>(__float_as_int(s)));
-  }
-  if (H >= g) { mo = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG; so = 0.0f; }
-  wide_fold<MODE>(m, s, mo, so);
+__device__ __forceinline__ void wide_max_step(double &m, int g) {
+  const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
+  if (H < g) m = (MODE == MB_VITERBI) ? dmax(m, mo) : __builtin_fmax(m, mo);
+}
+template <int H>
+__device__ __forceinline__ void wide_sum_step(float &s, int g) {
+  const float so = __int_as_float(wide_xor_lane<H>(__float_as_int(s)));
+  if (H < g) s += so;
+}
+template <int MODE>
+__device__ __forceinline__ void wide_group_reduce(double &m, float &s, int g, int gWave) {
+  const double own = m;
+  if (gWave > 1) wide_max_step<MODE, 1>(m, g);
+  if (gWave > 2) wide_max_step<MODE, 2>(m, g);
+  if (gWave > 4) wide_max_step<MODE, 4>(m, g);
+  if (gWave > 8) wide_max_step<MODE, 8>(m, g);
+  if (gWave > 16) wide_max_step<MODE, 16>(m, g);
+  if (gWave > 32) wide_max_step<MODE, 32>(m, g);
+  if (MODE == MB_VITERBI) return;
+  s *= __expf((float)(own - m));                    // own <= m; an empty lane (own = W_NEG_BIG, s = 0) stays 0
+  if (gWave > 1) wide_sum_step<1>(s, g);
+  if (gWave > 2) wide_sum_step<2>(s, g);
+  if (gWave > 4) wide_sum_step<4>(s, g);
+  if (gWave > 8) wide_sum_step<8>(s, g);
+  if (gWave > 16) wide_sum_step<16>(s, g);
+  if (gWave > 32) wide_sum_step<32>(s, g);
 }
 
 // FAST: all vector entries of a workgroup are addressable with 16 bits, and a record carries the source index for both
@@ -102,6 +126,11 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
   for (int c = 0; c <= outLen; ++c) {
     const int o = P.backward ? outLen - c : c;
     const int shift = (c & 1) * 16;
+    auto at = [&](const WideRec &rc) -> int {
+      if (FAST) return (int)((rc.src >> shift) & 0xffffu);
+      const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
+      return (sel == 0 ? curOff : (sel == 1 ? extraOff : prevOff)) + (int)idx;
+    };
     double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
     float s = 0.0f;
     for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
@@ -109,25 +138,14 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
         fetch(q[k]);
-        int at;
-        if (FAST) at = (int)((rc.src >> shift) & 0xffffu);
-        else {
-          const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
-          at = (sel == 0 ? curOff : (sel == 1 ? extraOff : prevOff)) + (int)idx;
-        }
-        wide_fold<MODE>(m, s, V[at] + rc.w, 1.0f);
+        wide_fold<MODE>(m, s, V[at(rc)] + rc.w, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
         if (flags & 0x80000000u) {
           const uint32_t dst = rc.pad;
           const int g = 1 << ((dst >> 26) & 7);
           // groups are laid out by decreasing size: the first lane of a wavefront carries the wavefront's largest group
           const int gWave = 1 << ((flags >> 26) & 7);
-          if (gWave > 32) wide_reduce_step<MODE, 32>(m, s, g);
-          if (gWave > 16) wide_reduce_step<MODE, 16>(m, s, g);
-          if (gWave > 8) wide_reduce_step<MODE, 8>(m, s, g);
-          if (gWave > 4) wide_reduce_step<MODE, 4>(m, s, g);
-          if (gWave > 2) wide_reduce_step<MODE, 2>(m, s, g);
-          if (gWave > 1) wide_reduce_step<MODE, 1>(m, s, g);
+          if (gWave > 1) wide_group_reduce<MODE>(m, s, g, gWave);
           if ((dst & W_IDX_MASK) != W_NO_DST) {
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__logf(s) : -INFINITY);
             V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
@@ -233,7 +251,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
       for (int t = 0; t < nTab; ++t) {
         const std::vector<WCand> *l2 = (t < (int)nd.t2.size()) ? &nd.t2[t] : nullptr;
         const int n2 = l2 ? (int)l2->size() : 0, tot = n2 + (int)nd.t3.size();
-        for (int k = 0; k < tot; ++k) {
+        for (int k = 0; k < tot; ++k) {       // (LDS bank conflicts of the data-dependent reads: measured negligible, SQ_LDS_BANK_CONFLICT)
           const WCand &cd = k < n2 ? (*l2)[k] : nd.t3[k - n2];
           const int j = k / g, sub = k % g;
           WideRec &rc = P->recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + lane + sub];
@@ -418,7 +436,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   const int keepStages = P.ok ? P.stages : -1;     // a weight refresh keeps the shape that was chosen
   wide_free(P);
   P.backward = backward; P.viterbi = viterbi;
-  P.W = m->S >= 768 ? 1024 : 256;
+  P.W = env_int_w("MB_WIDE_LANES", m->S >= 768 ? 1024 : 256);
   const int S = m->S, nLev = backward ? m->nLevB : m->nLevF;
   long long nSilent = 0;
   for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);

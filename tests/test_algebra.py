@@ -87,3 +87,43 @@ def test_silent_cycle_summation():
     # state b: b -> a -> b is a silent self-loop of weight r: exits are scaled by 1/(1-r)
     w = [t.weight for t in am.state[1].trans if t.out == "x"][0]
     assert A.weightToJson(A._canon(w)) == {"*": [{"geomsum": "r"}, "s"]}
+
+
+# ---- HMMER3 profile importer (src/hmmer.cpp) against the reference's construct-test goldens ------------------------------
+def _round3(x):
+    return float("%.3g" % x)
+
+
+@pytest.mark.parametrize("golden,build", [("fn3.json", lambda h: h.machine(False)), ("fn3-plan7.json", lambda h: h.plan7Machine(False)),
+                                          ("fn3-multihit.json", lambda h: h.plan7Machine(True))])
+def test_hmmer_importer_goldens(golden, build):
+    """`boss --hmmer-global / --hmmer-plan7 / --hmmer-multihit t/hmmer/fn3.hmm` (Makefile test-hmmer*, 3 significant digits)."""
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd.algebra import machineToJson
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm"))
+    assert len(h.node) == 86 and len(h.alph) == 20
+    got = machineToJson(build(h)); want = load_json("expect", golden)
+    assert len(got["state"]) == len(want["state"])
+    for a, b in zip(got["state"], want["state"]):
+        assert a.get("id") == b.get("id") and len(a.get("trans", [])) == len(b.get("trans", []))
+        for ta, tb in zip(a.get("trans", []), b.get("trans", [])):
+            assert ta["to"] == tb["to"] and ta.get("out") == tb.get("out") and ta.get("in") == tb.get("in")
+            assert _round3(ta.get("weight", 1)) == pytest.approx(_round3(tb.get("weight", 1)), rel=1e-2)
+
+
+def test_hmmer_local_mode_and_profile_composition():
+    """Local mode: entry weights occ[k]/Z (p7_ProfileConfig), unit exits from every match / delete state; and BASELINE
+    config 5's machine at test size -- profile . simple_introns . translate . dnapsw is a one-tape advancing machine."""
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd import algebra as A
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm"))
+    m = h.machine(True)
+    assert len(m.state) == 5 * 86 + 4 and len(m.state[0].trans) == 85
+    assert abs(sum(t.weight * (87 - k) for k, t in enumerate(m.state[0].trans, 1)) - 1.0) < 1e-12
+    assert [t.dest for t in m.state[h.d_idx(3)].trans][-1] == h.core_end_idx() and m.state[h.d_idx(3)].trans[-1].weight == 1
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    c = A.composeAll([h.truncated(3).machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
+    em = EvaluatedMachine.fromMachine(c, None, useDefaults=True)
+    assert (em.nStates, em.nTransitions, em.nInTok, em.nOutTok) == (600, 1989, 0, 4)
