@@ -237,7 +237,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
   if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
-    g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : "k_wide_sweep<0>";
+    g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : (W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>");
     return wide_fill(m, *W, d_desc, (long long)hp.size(), d_out, pool, nullptr, g_stream);
   }
   if (!env && use_medium(m)) {
@@ -447,7 +447,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     else {
       tm.start();
       rc = wide_fill(m, *W, b->d_pairs, b->nPairs, b->d_out, nullptr, d_ll, g_stream);
-      g_last_kernel = "k_wide_sweep<0>";
+      g_last_kernel = W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;
     }

@@ -40,6 +40,22 @@ struct WideDev {
   int backward;
 };
 
+// Forward / Backward (log-sum-exp) run in single precision RELATIVE TO A PER-COLUMN fp64 REFERENCE: a column's vector
+// holds x - R with R the running sum of the column maxima, so the entries that carry the probability mass are near 0
+// where fp32 resolves 1e-7, and a cell of the materialised matrix is R + (double)entry.  Stream entry = 8 bytes
+// (weight as float, 16-bit source indices for both column parities); slot flags (uniform) come from a byte table read
+// with scalar loads; the per-lane destination word of a round is the `src` of a control entry that follows the round.
+struct WideRec32 { float w; uint32_t src; };
+enum { WIDE_F_END = 1, WIDE_F_SYNC = 2, WIDE_F_CTRL = 4 };
+struct WideDev32 {
+  const WideRec32 *segA, *segB;
+  const unsigned long long *flags;   // 8 slot-flag bytes per word
+  long long strideA;
+  int nA, nB;
+  int S, NV, NX, W;
+  int resultIdx, backward;
+};
+
 struct WideProgram {
   bool ok = false, dirty = true;
   bool backward = false, viterbi = false;
@@ -56,6 +72,11 @@ struct WideProgram {
   bool fastIdx = false;              // records carry 16-bit vector indices for both column parities
   WideRec *d_segA = nullptr, *d_segB = nullptr;
   WideDev dev{};
+  bool f32 = false;                  // log-sum-exp program compiled for the single-precision relative kernel
+  WideRec32 *d_seg32A = nullptr, *d_seg32B = nullptr;
+  unsigned long long *d_flags = nullptr;
+  WideDev32 dev32{};
+  size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };
 

@@ -30,6 +30,7 @@ namespace mb {
 static constexpr double W_NEG_BIG = -1e300;       // finite stand-in for -inf in the running maximum (avoids inf - inf)
 static constexpr uint32_t W_IDX_MASK = 0x03ffffffu;
 static constexpr uint32_t W_NO_DST = 0x03ffffffu;
+static const size_t WIDE_LDS_MAX = 160 * 1024;
 
 // ------------------------------------------------------------------------------------------------------------
 // device
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
           const int gWave = 1 << ((flags >> 26) & 7);
           if (gWave > 1) wide_group_reduce<MODE>(m, s, g, gWave);
           if ((dst & W_IDX_MASK) != W_NO_DST) {
-            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__logf(s) : -INFINITY);
+            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
             V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -165,6 +166,121 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
     const int t = prevOff; prevOff = curOff; curOff = t;
   }
   if (loglike && tid == 0) loglike[blockIdx.x] = V[prevOff + P.resultIdx];
+}
+
+// ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
+static constexpr float W_NEG_BIG32 = -3.0e38f;
+
+__device__ __forceinline__ void wide_fold32(float &m, float &s, float v, float sv) {
+  const float e = __expf(-fabsf(v - m));
+  const bool up = v > m;
+  s = __fmaf_rn(up ? s : sv, e, up ? sv : s);
+  m = fmaxf(m, v);
+}
+template <int H>
+__device__ __forceinline__ float wide_xor_lane_f(float v) { return __int_as_float(wide_xor_lane<H>(__float_as_int(v))); }
+template <int H>
+__device__ __forceinline__ void wide_max_step32(float &m, int g) { const float mo = wide_xor_lane_f<H>(m); if (H < g) m = fmaxf(m, mo); }
+__device__ __forceinline__ void wide_group_reduce32(float &m, float &s, int g, int gWave) {
+  const float own = m;
+  if (gWave > 1) wide_max_step32<1>(m, g);
+  if (gWave > 2) wide_max_step32<2>(m, g);
+  if (gWave > 4) wide_max_step32<4>(m, g);
+  if (gWave > 8) wide_max_step32<8>(m, g);
+  if (gWave > 16) wide_max_step32<16>(m, g);
+  if (gWave > 32) wide_max_step32<32>(m, g);
+  s *= __expf(own - m);
+  if (gWave > 1) wide_sum_step<1>(s, g);
+  if (gWave > 2) wide_sum_step<2>(s, g);
+  if (gWave > 4) wide_sum_step<4>(s, g);
+  if (gWave > 8) wide_sum_step<8>(s, g);
+  if (gWave > 16) wide_sum_step<16>(s, g);
+  if (gWave > 32) wide_sum_step<32>(s, g);
+}
+
+template <bool GV>
+__global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
+                                                     double *__restrict__ pool, double *__restrict__ loglike, float *__restrict__ scratch) {
+  extern __shared__ float wldsf[];
+  __shared__ float wmax[16];
+  const PairDesc pd = pairs[blockIdx.x];
+  const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
+  const int outLen = pd.outLen, nA = P.nA, n = P.nA + P.nB;
+  float *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wldsf;
+  for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
+  __syncthreads();
+  if (tid == 0) V[S + 1] = 0.0f;                    // the seed, read by the first column only
+  __syncthreads();
+  const int extraOff = 2 * NV;
+  const int *out = outTok + pd.outBase;
+  double *cells = pool ? pool + pd.cellBase : nullptr;
+  auto tokOf = [&](int c) -> int {
+    if (c > outLen) return 0;
+    const int o = P.backward ? outLen - c : c;
+    return P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0);
+  };
+  const WideRec32 *cursor = P.segA + (size_t)tokOf(0) * P.strideA;
+  int jn = 0, cc = 0, tokAhead = tokOf(1);
+  WideRec32 q[WIDE_RING];
+  auto fetch = [&](WideRec32 &dst) {
+    dst = cursor[tid];
+    cursor += W; ++jn;
+    if (jn == nA) cursor = P.segB;
+    if (jn == n) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
+  };
+#pragma unroll
+  for (int k = 0; k < WIDE_RING; ++k) fetch(q[k]);
+  double R = 0.0;                                   // reference of the previous column: cell = R + entry
+  unsigned long long fcur = P.flags[0];
+  for (int c = 0; c <= outLen; ++c) {
+    const int o = P.backward ? outLen - c : c;
+    const int shift = (c & 1) * 16;
+    const int curOff = (c & 1) ? 0 : NV, prevOff = (c & 1) ? NV : 0;
+    float m = W_NEG_BIG32, s = 0.0f, lm = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
+      const unsigned long long fnext = P.flags[(j0 + WIDE_RING < n ? j0 + WIDE_RING : 0) / WIDE_RING];
+#pragma unroll
+      for (int k = 0; k < WIDE_RING; ++k) {
+        const unsigned fl = (unsigned)(fcur >> (8 * k)) & 0xffu;
+        const WideRec32 rc = q[k];
+        fetch(q[k]);
+        if (!(fl & WIDE_F_CTRL)) wide_fold32(m, s, V[(rc.src >> shift) & 0xffffu] + rc.w, 1.0f);
+        if (fl & WIDE_F_END) {
+          const uint32_t dst = q[(k + 1) % WIDE_RING].src;      // the control entry behind the round
+          const int g = 1 << ((dst >> 26) & 7);
+          const int gWave = 1 << (((uint32_t)__builtin_amdgcn_readfirstlane((int)dst) >> 26) & 7);
+          if (gWave > 1) wide_group_reduce32(m, s, g, gWave);
+          if ((dst & W_IDX_MASK) != W_NO_DST) {
+            const float res = s > 0.0f ? __fmaf_rn(__log2f(s), 0.6931471805599453f, m) : -INFINITY;   // s in [1, lanes x slots]: v_log_f32 needs no range fix-up
+            const bool extra = (dst >> 29) & 1;
+            V[(extra ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
+            if (!extra) lm = fmaxf(lm, res);
+          }
+          m = W_NEG_BIG32; s = 0.0f;
+          if (fl & WIDE_F_SYNC) __syncthreads();
+        }
+      }
+      fcur = fnext;
+    }
+    // column maximum -> new reference; the column is rewritten relative to it (and copied out as fp64 cells)
+#pragma unroll
+    for (int h = 32; h; h >>= 1) lm = fmaxf(lm, __shfl_xor(lm, h, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = lm;
+    __syncthreads();
+    float M = -INFINITY;
+    for (int w = 0; w < (W >> 6); ++w) M = fmaxf(M, wmax[w]);
+    if (!(M > -INFINITY)) M = 0.0f;
+    double *col = cells ? cells + (long long)o * S : nullptr;
+    for (int k = tid; k < S; k += W) {
+      const float y = V[curOff + k];
+      if (col) col[k] = R + (double)y;
+      if (c == outLen && k == P.resultIdx && loglike) loglike[blockIdx.x] = R + (double)y;   // the same rounding as the stored cell
+      V[curOff + k] = y - M;
+    }
+    R += (double)M;
+    if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -280,6 +396,9 @@ bool wide_applicable(const mb_machine *m) {
 void wide_free(WideProgram &P) {
   if (P.d_segA) (void)hipFree(P.d_segA);
   if (P.d_segB) (void)hipFree(P.d_segB);
+  if (P.d_seg32A) (void)hipFree(P.d_seg32A);
+  if (P.d_seg32B) (void)hipFree(P.d_seg32B);
+  if (P.d_flags) (void)hipFree(P.d_flags);
   P = WideProgram();
 }
 
@@ -326,6 +445,56 @@ static void wide_linearise(WideProgram &P, int nTok) {
     for (WideRec &rc : P.segA) conv(rc);
     for (WideRec &rc : P.segB) conv(rc);
   }
+}
+
+// the same rounds as 8-byte entries + control entries + slot flags for k_wide_sum32 (needs 16-bit vector indices)
+static bool wide_linearise32(WideProgram &P, int nTok, std::vector<WideRec32> &segA, std::vector<WideRec32> &segB, std::vector<unsigned long long> &flagWords) {
+  if (2 * P.NV + P.NX > 65536) return false;
+  const int W = P.W, nR = (int)P.rounds.size();
+  const uint32_t NV = (uint32_t)P.NV;
+  int lastTok = -1;
+  for (int r = 0; r < nR; ++r) if (P.rounds[r].tokStride) lastTok = r;
+  int nA = 0, nB = 0;
+  for (int r = 0; r < nR; ++r) (r <= lastTok ? nA : nB) += P.rounds[r].depth + 1;      // + the control entry
+  const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
+  (nB || lastTok < 0 ? nB : nA) += padSlots;
+  const int n = nA + nB;
+  auto dual = [&](uint32_t src) {
+    const uint32_t sel = src >> 30, idx = src & 0x3fffffffu;
+    const uint32_t even = sel == 0 ? NV + idx : (sel == 1 ? 2 * NV + idx : idx);
+    const uint32_t odd = sel == 0 ? idx : (sel == 1 ? 2 * NV + idx : NV + idx);
+    return even | (odd << 16);
+  };
+  const WideRec32 padRec{-INFINITY, dual(PREV(P.dev.S))};
+  segA.assign((size_t)nTok * nA * W, padRec);
+  segB.assign((size_t)nB * W, padRec);
+  std::vector<unsigned char> fl(n, WIDE_F_CTRL);       // padding slots are skipped
+  for (int t = 0; t < nTok; ++t) {
+    size_t ja = 0, jb = 0;
+    for (int r = 0; r < nR; ++r) {
+      const WideRound &R = P.rounds[r];
+      const bool inA = r <= lastTok;
+      if (!inA && t) continue;
+      for (int j = 0; j <= R.depth; ++j) {
+        const size_t slot = inA ? ja++ : jb++;
+        WideRec32 *dstp = inA ? &segA[((size_t)t * nA + slot) * W] : &segB[slot * W];
+        const size_t gslot = inA ? slot : nA + slot;
+        if (j == R.depth) {                              // control entry: the destination words of the round
+          for (int l = 0; l < W; ++l) dstp[l] = WideRec32{-INFINITY, P.dsts[R.dstBase + l]};
+          fl[gslot] = WIDE_F_CTRL;
+          continue;
+        }
+        const WideRec *srcp = &P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W];
+        for (int l = 0; l < W; ++l) dstp[l] = WideRec32{(float)srcp[l].w, dual(srcp[l].src)};
+        // the last round of a column does not synchronise by itself: the kernel's column epilogue does
+        fl[gslot] = j + 1 == R.depth ? (unsigned char)(WIDE_F_END | ((R.sync && r + 1 < nR) ? WIDE_F_SYNC : 0)) : 0;
+      }
+    }
+  }
+  flagWords.assign((size_t)n / WIDE_RING, 0ull);
+  for (int j = 0; j < n; ++j) flagWords[j / WIDE_RING] |= (unsigned long long)fl[j] << (8 * (j % WIDE_RING));
+  P.dev32.nA = nA; P.dev32.nB = nB; P.dev32.strideA = (long long)nA * W;
+  return true;
 }
 
 // nodes of the program for K closure stages (K = 0: levelled)
@@ -471,9 +640,29 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.dev.S = S;
   wide_plan(bestNodes, bestStages, m->nOut + 1, P.W, true, &P);
   if (P.rounds.empty()) { set_error("wide program: empty machine"); return false; }
-  wide_linearise(P, m->nOut + 1);
-  if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
-  const size_t nRecs = P.segA.size() + P.segB.size();
+  static_assert(WIDE_RING == 8, "slot flags are packed eight to a 64-bit word");
+  size_t nRecs = 0;
+  // single precision relative to the column reference where it buys something: when two fp64 columns do not fit the LDS of
+  // a CU (fp64 arithmetic is full rate on this chip: with both in LDS the fp64 kernel is the faster one, 39.9 vs 45.4 ms
+  // on the 20-node profile machine).  MB_WIDE_FP32 = 1 / 0 forces it on / off.
+  const int want32 = env_int_w("MB_WIDE_FP32", -1);
+  if (!viterbi && (want32 > 0 || (want32 < 0 && (size_t)(2 * P.NV + P.NX) * sizeof(double) > WIDE_LDS_MAX))) {
+    std::vector<WideRec32> a32, b32;
+    std::vector<unsigned long long> fw;
+    if (wide_linearise32(P, m->nOut + 1, a32, b32, fw)) {
+      if (!up_w(P.d_seg32A, a32) || !up_w(P.d_seg32B, b32) || !up_w(P.d_flags, fw)) return false;
+      P.f32 = true;
+      nRecs = a32.size() + b32.size();
+      P.dev32.segA = P.d_seg32A; P.dev32.segB = P.d_seg32B; P.dev32.flags = P.d_flags;
+      P.dev32.S = S; P.dev32.NV = P.NV; P.dev32.NX = P.NX; P.dev32.W = P.W;
+      P.dev32.resultIdx = backward ? 0 : S - 1; P.dev32.backward = backward ? 1 : 0;
+    }
+  }
+  if (!P.f32) {
+    wide_linearise(P, m->nOut + 1);
+    if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
+    nRecs = P.segA.size() + P.segB.size();
+  }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
   std::vector<WideRec>().swap(P.recs); std::vector<uint32_t>().swap(P.dsts);
@@ -487,7 +676,6 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   return true;
 }
 
-static const size_t WIDE_LDS_MAX = 160 * 1024;
 
 template <int MODE, bool GV, bool FAST>
 static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
@@ -503,11 +691,37 @@ static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long n
   return 0;
 }
 
+template <bool GV>
+static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
+                         float *scratch, hipStream_t st) {
+  const size_t lds = GV ? 0 : P.vecBytes32();
+  static bool attr = false;
+  if (!GV && !attr) {
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_sum32<GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX - 64));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_wide_sum32<GV>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev32, d_desc, d_out, pool, loglike, scratch);
+  MB_HIP(hipGetLastError());
+  return 0;
+}
+
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool,
               double *loglike, hipStream_t st) {
   (void)m;
   if (!P.ok) { set_error("wide program not built"); return 1; }
   if (nPairs <= 0) return 0;
+  if (P.f32) {
+    const bool gv32 = P.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0);
+    float *scr = nullptr;
+    if (gv32) MB_HIP(hipMalloc((void **)&scr, (size_t)nPairs * P.vecBytes32()));
+    int rc32 = gv32 ? launch_wide32<true>(P, d_desc, nPairs, d_out, pool, loglike, scr, st) : launch_wide32<false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st);
+    g_last_launches += 1;
+    if (gv32) {
+      if (!rc32 && !hip_ok(hipStreamSynchronize(st), "wide sweep")) rc32 = 1;
+      (void)hipFree(scr);
+    }
+    return rc32;
+  }
   const bool gv = P.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0);
   double *scratch = nullptr;
   if (gv) MB_HIP(hipMalloc((void **)&scratch, (size_t)nPairs * P.vecBytes()));
