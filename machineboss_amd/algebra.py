@@ -579,6 +579,16 @@ def composeAll(machines: List[Machine]) -> Machine:
     return m
 
 
+def composeLeftToRight(machines: List[Machine]) -> Machine:
+    """((a . b) . c) . d -- pairwise Machine::compose from the left, the order SURVEY.md section 8(d) probed config 5 in
+    (fn3 . simple_introns . translate . dnapsw = 21 761 states / 63 267 transitions).  Every intermediate result is trimmed
+    to its accessible states, so the state count differs from the right-to-left order of the `boss` command line."""
+    m = machines[0]
+    for nxt in machines[1:]:
+        m = compose(m, nxt, True, True, SumSilentCycles)
+    return m
+
+
 def machineToJson(m: Machine, showParams: bool = False) -> dict:
     """The structure Machine::writeJson prints (src/machine.cpp:203-345), for comparison with expected machines."""
     states = []

@@ -46,7 +46,7 @@ struct WideDev {
 // (weight as float, 16-bit source indices for both column parities); slot flags (uniform) come from a byte table read
 // with scalar loads; the per-lane destination word of a round is the `src` of a control entry that follows the round.
 struct WideRec32 { float w; uint32_t src; };
-enum { WIDE_F_END = 1, WIDE_F_SYNC = 2, WIDE_F_CTRL = 4 };
+enum { WIDE_F_END = 1, WIDE_F_SYNC = 2, WIDE_F_CTRL = 4, WIDE_F_PREV = 8 };   // PREV: the slot reads the previous column (hybrid layout)
 struct WideDev32 {
   const WideRec32 *segA, *segB;
   const unsigned long long *flags;   // 8 slot-flag bytes per word
@@ -73,6 +73,7 @@ struct WideProgram {
   WideRec *d_segA = nullptr, *d_segB = nullptr;
   WideDev dev{};
   bool f32 = false;                  // log-sum-exp program compiled for the single-precision relative kernel
+  bool hyb = false;                  // ... with the current column in LDS and the previous one in L2
   WideRec32 *d_seg32A = nullptr, *d_seg32B = nullptr;
   unsigned long long *d_flags = nullptr;
   WideDev32 dev32{};

@@ -198,7 +198,10 @@ __device__ __forceinline__ void wide_group_reduce32(float &m, float &s, int g, i
   if (gWave > 32) wide_sum_step<32>(s, g);
 }
 
-template <bool GV>
+// HYB: the current column (and the extra entries) in LDS, the previous column in an L2-resident vector of the workgroup --
+// for machines whose two columns do not fit the LDS even in single precision (the whole fn3 composition: 21 761 states).
+// Only the emitting rounds read the previous column (slot flag WIDE_F_PREV, uniform), the column epilogue writes it.
+template <bool GV, bool HYB>
 __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                      double *__restrict__ pool, double *__restrict__ loglike, float *__restrict__ scratch) {
   extern __shared__ float wldsf[];
@@ -207,11 +210,13 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
   const int outLen = pd.outLen, nA = P.nA, n = P.nA + P.nB;
   float *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wldsf;
-  for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
+  float *Pg = HYB ? scratch + (size_t)blockIdx.x * (size_t)NV : nullptr;
+  for (int k = tid; k < (HYB ? NV + P.NX : 2 * NV + P.NX); k += W) V[k] = -INFINITY;
+  if (HYB) for (int k = tid; k < NV; k += W) Pg[k] = -INFINITY;
   __syncthreads();
-  if (tid == 0) V[S + 1] = 0.0f;                    // the seed, read by the first column only
+  if (tid == 0) (HYB ? Pg : V)[S + 1] = 0.0f;       // the seed, read by the first column only
   __syncthreads();
-  const int extraOff = 2 * NV;
+  const int extraOff = HYB ? NV : 2 * NV;
   const int *out = outTok + pd.outBase;
   double *cells = pool ? pool + pd.cellBase : nullptr;
   auto tokOf = [&](int c) -> int {
@@ -234,8 +239,8 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
   unsigned long long fcur = P.flags[0];
   for (int c = 0; c <= outLen; ++c) {
     const int o = P.backward ? outLen - c : c;
-    const int shift = (c & 1) * 16;
-    const int curOff = (c & 1) ? 0 : NV, prevOff = (c & 1) ? NV : 0;
+    const int shift = HYB ? 0 : (c & 1) * 16;
+    const int curOff = HYB ? 0 : ((c & 1) ? 0 : NV), prevOff = (c & 1) ? NV : 0;
     float m = W_NEG_BIG32, s = 0.0f, lm = -INFINITY;
     for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
       const unsigned long long fnext = P.flags[(j0 + WIDE_RING < n ? j0 + WIDE_RING : 0) / WIDE_RING];
@@ -244,7 +249,12 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
         const unsigned fl = (unsigned)(fcur >> (8 * k)) & 0xffu;
         const WideRec32 rc = q[k];
         fetch(q[k]);
-        if (!(fl & WIDE_F_CTRL)) wide_fold32(m, s, V[(rc.src >> shift) & 0xffffu] + rc.w, 1.0f);
+        if (!(fl & WIDE_F_CTRL)) {
+          float x;
+          if (HYB) x = (fl & WIDE_F_PREV) ? Pg[rc.src] : V[rc.src];
+          else x = V[(rc.src >> shift) & 0xffffu];
+          wide_fold32(m, s, x + rc.w, 1.0f);
+        }
         if (fl & WIDE_F_END) {
           const uint32_t dst = q[(k + 1) % WIDE_RING].src;      // the control entry behind the round
           const int g = 1 << ((dst >> 26) & 7);
@@ -275,10 +285,10 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
       const float y = V[curOff + k];
       if (col) col[k] = R + (double)y;
       if (c == outLen && k == P.resultIdx && loglike) loglike[blockIdx.x] = R + (double)y;   // the same rounding as the stored cell
-      V[curOff + k] = y - M;
+      if (HYB) Pg[k] = y - M; else V[curOff + k] = y - M;
     }
     R += (double)M;
-    if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent
+    if (tid == 0) { if (HYB) Pg[S + 1] = -INFINITY; else V[prevOff + S + 1] = -INFINITY; }   // the seed is spent
     __syncthreads();
   }
 }
@@ -448,8 +458,8 @@ static void wide_linearise(WideProgram &P, int nTok) {
 }
 
 // the same rounds as 8-byte entries + control entries + slot flags for k_wide_sum32 (needs 16-bit vector indices)
-static bool wide_linearise32(WideProgram &P, int nTok, std::vector<WideRec32> &segA, std::vector<WideRec32> &segB, std::vector<unsigned long long> &flagWords) {
-  if (2 * P.NV + P.NX > 65536) return false;
+static bool wide_linearise32(WideProgram &P, int nTok, bool hyb, std::vector<WideRec32> &segA, std::vector<WideRec32> &segB, std::vector<unsigned long long> &flagWords) {
+  if (!hyb && 2 * P.NV + P.NX > 65536) return false;
   const int W = P.W, nR = (int)P.rounds.size();
   const uint32_t NV = (uint32_t)P.NV;
   int lastTok = -1;
@@ -465,32 +475,58 @@ static bool wide_linearise32(WideProgram &P, int nTok, std::vector<WideRec32> &s
     const uint32_t odd = sel == 0 ? idx : (sel == 1 ? 2 * NV + idx : NV + idx);
     return even | (odd << 16);
   };
-  const WideRec32 padRec{-INFINITY, dual(PREV(P.dev.S))};
+  // HYB: one index per record -- into the previous column (slots flagged WIDE_F_PREV) or into the LDS image [cur | extra]
+  const uint32_t ldsSentinel = NV + (uint32_t)P.NX - 1;        // the dummy extra entry: never written, always -inf
+  auto isPad = [&](const WideRec &rc) { return rc.src == PREV(P.dev.S) && rc.w == -INFINITY; };
+  const WideRec32 padRec{-INFINITY, hyb ? ldsSentinel : dual(PREV(P.dev.S))};
   segA.assign((size_t)nTok * nA * W, padRec);
   segB.assign((size_t)nB * W, padRec);
   std::vector<unsigned char> fl(n, WIDE_F_CTRL);       // padding slots are skipped
-  for (int t = 0; t < nTok; ++t) {
-    size_t ja = 0, jb = 0;
-    for (int r = 0; r < nR; ++r) {
-      const WideRound &R = P.rounds[r];
-      const bool inA = r <= lastTok;
-      if (!inA && t) continue;
-      for (int j = 0; j <= R.depth; ++j) {
-        const size_t slot = inA ? ja++ : jb++;
-        WideRec32 *dstp = inA ? &segA[((size_t)t * nA + slot) * W] : &segB[slot * W];
-        const size_t gslot = inA ? slot : nA + slot;
-        if (j == R.depth) {                              // control entry: the destination words of the round
-          for (int l = 0; l < W; ++l) dstp[l] = WideRec32{-INFINITY, P.dsts[R.dstBase + l]};
-          fl[gslot] = WIDE_F_CTRL;
-          continue;
+  // slot walk shared by the two passes: f(round, slot-in-round or depth for the control entry, token, slot in segment, global slot)
+  auto walk = [&](auto &&f) {
+    for (int t = 0; t < nTok; ++t) {
+      size_t ja = 0, jb = 0;
+      for (int r = 0; r < nR; ++r) {
+        const bool inA = r <= lastTok;
+        if (!inA && t) continue;
+        for (int j = 0; j <= P.rounds[r].depth; ++j) {
+          const size_t slot = inA ? ja++ : jb++;
+          f(r, j, t, inA, slot, inA ? slot : nA + slot);
         }
-        const WideRec *srcp = &P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W];
-        for (int l = 0; l < W; ++l) dstp[l] = WideRec32{(float)srcp[l].w, dual(srcp[l].src)};
-        // the last round of a column does not synchronise by itself: the kernel's column epilogue does
-        fl[gslot] = j + 1 == R.depth ? (unsigned char)(WIDE_F_END | ((R.sync && r + 1 < nR) ? WIDE_F_SYNC : 0)) : 0;
       }
     }
+  };
+  std::vector<unsigned char> readsPrev(n, 0), readsCur(n, 0);
+  if (hyb) {
+    walk([&](int r, int j, int t, bool, size_t, size_t gslot) {
+      const WideRound &R = P.rounds[r];
+      if (j == R.depth) return;
+      const WideRec *srcp = &P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W];
+      for (int l = 0; l < W; ++l) if (!isPad(srcp[l])) ((srcp[l].src >> 30) == 2 ? readsPrev : readsCur)[gslot] = 1;
+    });
+    for (int j = 0; j < n; ++j) if (readsPrev[j] && readsCur[j]) return false;   // a slot reads one memory or the other (closure programs do)
   }
+  walk([&](int r, int j, int t, bool inA, size_t slot, size_t gslot) {
+    const WideRound &R = P.rounds[r];
+    WideRec32 *dstp = inA ? &segA[((size_t)t * nA + slot) * W] : &segB[slot * W];
+    if (j == R.depth) {                                  // control entry: the destination words of the round
+      for (int l = 0; l < W; ++l) dstp[l] = WideRec32{-INFINITY, P.dsts[R.dstBase + l]};
+      fl[gslot] = WIDE_F_CTRL;
+      return;
+    }
+    const WideRec *srcp = &P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W];
+    const unsigned char prevFlag = (hyb && readsPrev[gslot]) ? WIDE_F_PREV : 0;
+    for (int l = 0; l < W; ++l) {
+      uint32_t at;
+      if (hyb) {
+        const uint32_t sel = srcp[l].src >> 30, idx = srcp[l].src & 0x3fffffffu;
+        at = isPad(srcp[l]) ? (prevFlag ? (uint32_t)P.dev.S : ldsSentinel) : (sel == 1 ? NV + idx : idx);
+      } else at = dual(srcp[l].src);
+      dstp[l] = WideRec32{(float)srcp[l].w, at};
+    }
+    // the last round of a column does not synchronise by itself: the kernel's column epilogue does
+    fl[gslot] = (unsigned char)((j + 1 == R.depth ? (WIDE_F_END | ((R.sync && r + 1 < nR) ? WIDE_F_SYNC : 0)) : 0) | prevFlag);
+  });
   flagWords.assign((size_t)n / WIDE_RING, 0ull);
   for (int j = 0; j < n; ++j) flagWords[j / WIDE_RING] |= (unsigned long long)fl[j] << (8 * (j % WIDE_RING));
   P.dev32.nA = nA; P.dev32.nB = nB; P.dev32.strideA = (long long)nA * W;
@@ -649,7 +685,13 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   if (!viterbi && (want32 > 0 || (want32 < 0 && (size_t)(2 * P.NV + P.NX) * sizeof(double) > WIDE_LDS_MAX))) {
     std::vector<WideRec32> a32, b32;
     std::vector<unsigned long long> fw;
-    if (wide_linearise32(P, m->nOut + 1, a32, b32, fw)) {
+    // both columns in LDS when they fit; else the current one in LDS and the previous one in L2; else both in L2
+    const size_t lds32 = WIDE_LDS_MAX - 64;
+    const bool fits2 = (size_t)(2 * P.NV + P.NX) * sizeof(float) <= lds32;
+    const int wantHyb = env_int_w("MB_WIDE_HYBRID", -1);
+    P.hyb = (wantHyb > 0 || (wantHyb < 0 && !fits2)) && (size_t)(P.NV + P.NX) * sizeof(float) <= lds32 &&
+            wide_linearise32(P, m->nOut + 1, true, a32, b32, fw);
+    if (P.hyb || wide_linearise32(P, m->nOut + 1, false, a32, b32, fw)) {
       if (!up_w(P.d_seg32A, a32) || !up_w(P.d_seg32B, b32) || !up_w(P.d_flags, fw)) return false;
       P.f32 = true;
       nRecs = a32.size() + b32.size();
@@ -691,16 +733,16 @@ static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long n
   return 0;
 }
 
-template <bool GV>
+template <bool GV, bool HYB>
 static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
                          float *scratch, hipStream_t st) {
-  const size_t lds = GV ? 0 : P.vecBytes32();
+  const size_t lds = GV ? 0 : (HYB ? (size_t)(P.NV + P.NX) * sizeof(float) : P.vecBytes32());
   static bool attr = false;
   if (!GV && !attr) {
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_sum32<GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX - 64));
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_sum32<GV, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX - 64));
     attr = true;
   }
-  hipLaunchKernelGGL((k_wide_sum32<GV>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev32, d_desc, d_out, pool, loglike, scratch);
+  hipLaunchKernelGGL((k_wide_sum32<GV, HYB>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev32, d_desc, d_out, pool, loglike, scratch);
   MB_HIP(hipGetLastError());
   return 0;
 }
@@ -711,12 +753,15 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   if (!P.ok) { set_error("wide program not built"); return 1; }
   if (nPairs <= 0) return 0;
   if (P.f32) {
-    const bool gv32 = P.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0);
+    const bool gv32 = !P.hyb && (P.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0));
     float *scr = nullptr;
     if (gv32) MB_HIP(hipMalloc((void **)&scr, (size_t)nPairs * P.vecBytes32()));
-    int rc32 = gv32 ? launch_wide32<true>(P, d_desc, nPairs, d_out, pool, loglike, scr, st) : launch_wide32<false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st);
+    if (P.hyb) MB_HIP(hipMalloc((void **)&scr, (size_t)nPairs * P.NV * sizeof(float)));
+    int rc32 = P.hyb ? launch_wide32<false, true>(P, d_desc, nPairs, d_out, pool, loglike, scr, st)
+                     : (gv32 ? launch_wide32<true, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st)
+                             : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st));
     g_last_launches += 1;
-    if (gv32) {
+    if (gv32 || P.hyb) {
       if (!rc32 && !hip_ok(hipStreamSynchronize(st), "wide sweep")) rc32 = 1;
       (void)hipFree(scr);
     }

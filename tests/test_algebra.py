@@ -127,3 +127,25 @@ def test_hmmer_local_mode_and_profile_composition():
     c = A.composeAll([h.truncated(3).machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
     em = EvaluatedMachine.fromMachine(c, None, useDefaults=True)
     assert (em.nStates, em.nTransitions, em.nInTok, em.nOutTok) == (600, 1989, 0, 4)
+    # SURVEY.md section 8(d) probed the reference composing from the left; at 5 nodes the two orders give 1268 / 998 states
+    five = [h.truncated(5).machine(True), P("simple_introns"), P("translate"), P("dnapsw")]
+    assert len(A.composeLeftToRight(five).state) == 1268 and len(A.composeAll(five).state) == 998
+
+
+def test_config5_machine_matches_survey_probe():
+    """The whole fn3 profile . simple_introns . translate . dnapsw, composed pairwise from the left like the probe of the
+    reference in SURVEY.md section 8(d) row 5: 21 761 states, 63 267 transitions (32 340 out-only, 30 927 silent), 1554
+    silent levels, no input alphabet.  Pins the HMMER importer and the composition together (about a minute of host time)."""
+    from machineboss_amd.hmmer import HmmerModel
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm"))
+    c = A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
+    em = EvaluatedMachine.fromMachine(c, None, useDefaults=True)
+    outOnly = sum(1 for i, o in zip(em.inTok, em.outTok) if i == 0 and o != 0)
+    silent = sum(1 for i, o in zip(em.inTok, em.outTok) if i == 0 and o == 0)
+    assert (em.nStates, em.nTransitions, outOnly, silent, em.nInTok) == (21761, 63267, 32340, 30927, 0)
+    lev = [0] * em.nStates
+    for s_, d_, i, o in zip(em.src, em.dst, em.inTok, em.outTok):      # edges are in ascending source order
+        if i == 0 and o == 0 and s_ < d_:
+            lev[d_] = max(lev[d_], lev[s_] + 1)
+    assert max(lev) + 1 == 1554

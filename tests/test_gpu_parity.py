@@ -822,13 +822,13 @@ def _profile_machine(nodes):
     from machineboss_amd.evalmachine import EvaluatedMachine
     P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
     h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).truncated(nodes)
-    m = A.composeAll([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
+    m = A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
     return m, EvaluatedMachine.fromMachine(m, None, useDefaults=True)
 
 
 @pytest.mark.parametrize("stages", [-1, 0, 1, 3, 40])
 def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
-    """BASELINE config 5 at test size: a 3-node profile composed with simple_introns . translate . dnapsw (600 states,
+    """BASELINE config 5 at test size: a 3-node profile composed with simple_introns . translate . dnapsw (762 states,
     one tape) through the one-tape kernel family -- Forward / Backward matrices, rolling log-likelihood, bit-exact Viterbi
     matrix and path, posterior counts -- for the levelled program and several closure groupings, LDS and L2 vectors."""
     m, em = _profile_machine(3)
@@ -839,6 +839,8 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
         monkeypatch.setenv("MB_WIDE_GLOBAL_VECTORS", "1")
     if stages in (0, 1):
         monkeypatch.setenv("MB_WIDE_FAST_INDEX", "0")
+    if stages in (1, 40):
+        monkeypatch.setenv("MB_WIDE_HYBRID", "1")     # ... with the previous column in L2 (closure programs only)
     if stages in (-1, 1, 40):
         monkeypatch.setenv("MB_WIDE_FP32", "1")       # the fp32-relative log-sum-exp kernel (default only when fp64 columns exceed the LDS)
     om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
