@@ -363,6 +363,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
     }
     WideRound R{};
     R.recBase = (int)P->recs.size(); R.depth = depth; R.dstBase = (int)P->dsts.size(); R.maxG = mg; R.sync = 0;
+    R.pad0 = lanes;                                   // lanes that carry nodes
     const int nTab = t2 ? nTokTables : 1;
     R.tokStride = t2 ? depth * W : 0;
     const WideRec padRec{-INFINITY, PREV(P->dev.S), 0};
@@ -676,6 +677,16 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.dev.S = S;
   wide_plan(bestNodes, bestStages, m->nOut + 1, P.W, true, &P);
   if (P.rounds.empty()) { set_error("wide program: empty machine"); return false; }
+  // Runs of thin levels (a profile's delete chain: 2-20 states per level, hundreds of levels): when a stage and the next
+  // one each fit the first wavefront, the LDS pipeline already orders that wavefront's store before its next read, so
+  // the workgroup barrier between them is dropped; the other wavefronts run ahead to the barrier that ends the run.
+  // (LDS columns only: the same-wavefront ordering is not relied upon for the L2 scratch vectors.)
+  if (env_int_w("MB_WIDE_WAVE_LOCAL", 1) && P.vecBytes() <= WIDE_LDS_MAX && !env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) && bestK == 0) {
+    int dropped = 0;
+    for (size_t r = 0; r + 1 < P.rounds.size(); ++r)
+      if (P.rounds[r].sync && P.rounds[r].pad0 <= 64 && P.rounds[r + 1].pad0 <= 64 && P.rounds[r + 1].sync) { P.rounds[r].sync = 0; ++dropped; }
+    P.nSync -= dropped;
+  }
   static_assert(WIDE_RING == 8, "slot flags are packed eight to a 64-bit word");
   size_t nRecs = 0;
   // single precision relative to the column reference where it buys something: when two fp64 columns do not fit the LDS of
