@@ -248,11 +248,13 @@ class DeviceBatch:
         if not paths:
             _check(load().mb_batch_viterbi(self.h, _p(ll, C.c_double), None, None, 0))
             return ll, None, None
-        cap = sum(self.dm.path_bound(int(self.inOff[k + 1] - self.inOff[k]), int(self.outOff[k + 1] - self.outOff[k]))
-                  for k in range(self.nPairs))
-        off = np.zeros(self.nPairs + 1, np.int64); edges = np.empty(max(cap, 1), np.uint32)
+        # mb_viterbi_path_bound is linear in the lengths: (inLen + outLen + 1) * levels + 1 per pair
+        per = self.dm.path_bound(1, 0) - self.dm.path_bound(0, 0)
+        lens = np.diff(self.inOff) + np.diff(self.outOff)
+        cap = int((lens + 1).sum() * per + self.nPairs) if self.nPairs else 0
+        off = np.zeros(self.nPairs + 1, np.int64); edges = np.empty(max(cap, 1), np.uint32)   # worst case; only the used part is touched
         _check(load().mb_batch_viterbi(self.h, _p(ll, C.c_double), _p(off, C.c_int64), _p(edges, C.c_uint32), cap))
-        return ll, off, edges[:off[-1]].copy()
+        return ll, off, edges[:off[-1]]
 
     def counts(self, counts: Optional[np.ndarray] = None):
         """Returns (counts[nTrans], loglikeSum, loglike[nPairs]); accumulates into ``counts`` if given."""

@@ -46,7 +46,7 @@ static int ensure_init() {
 // Grow-only device workspaces, kept across calls so that steady-state batch calls do no hipMalloc/hipFree
 // (a 200 GB hipMalloc costs far more than the kernels it feeds).  Slot 0/1: matrix pools, 2: halo columns.
 struct Workspace { void *p = nullptr; size_t bytes = 0; };
-static Workspace g_ws[6];   // 0/1 matrix pools, 2 halo columns, 3/4/5 Viterbi path slots / lengths / edges
+static Workspace g_ws[8];   // 0/1 matrix pools, 2 halo columns, 3/4/5 Viterbi path slots / lengths / edges
 
 static size_t cached_bytes() { size_t t = 0; for (const Workspace &w : g_ws) t += w.bytes; return t; }
 
@@ -77,6 +77,7 @@ int launch_fill_neg_inf(double *, long long, hipStream_t);
 int launch_gather_loglike(const PairDesc *, long long, const double *, int, int, double *, hipStream_t);
 int launch_generic_counts(const mb_machine *, const PairDesc *, long long, long long, const int *, const int *,
                           const double *, const double *, double *, hipStream_t);
+int launch_compact_paths(const uint32_t *, const long long *, const long long *, const long long *, uint32_t *, long long, hipStream_t);
 int launch_traceback(const mb_machine *, const PairDesc *, long long, const int *, const int *, const double *,
                      const long long *, uint32_t *, long long *, hipStream_t);
 
@@ -138,6 +139,7 @@ static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_ou
 // ---- kernel-family state attached to a machine ------------------------------------------------------------
 struct FastState {
   bool tried = false, mediumOk = false;
+  bool exactOk = false;      // one-tape machines: only the exact (levelled) tiled program is built, for Viterbi
   int G = 0;
   // exact (leveled) programs: Viterbi and Forward with a custom start state; "sum" programs: Forward / Backward,
   // silent closure when it stays small, otherwise the exact program of that direction
@@ -199,11 +201,20 @@ static FastState *fast_state(mb_machine *m) {
       if (ok) ok = medium_build(m, false, choose(false), G, f->fwdSum, f->geoFS);
       if (ok) ok = medium_build(m, true, choose(true), G, f->bwdSum, f->geoBS);
       f->mediumOk = ok;
+      f->exactOk = ok;
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
         int Gc = env_int("MB_MEDIUM_COUNT_G", 0);
         if (!medium_valid_G(Gc)) Gc = env_int("MB_MEDIUM_G", 0) ? G : medium_default_count_G(m->S);
         f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt);
       }
+    } else if (wide_applicable(m) && m->S <= env_int("MB_WIDE_VITERBI_MIN_STATES", 2048)) {
+      // One-tape machine of moderate size: the log-sum-exp sweeps belong to the one-tape family, but its Viterbi sweep
+      // walks the silent levels one record at a time (0.2 us per level), where the run-time specialised tile kernel has
+      // them as straight-line code (762 states: 32 vs 14.5 G cells/s, 1268 states: 22.8 vs 15.6).
+      int G = env_int("MB_MEDIUM_G", 0);
+      if (!medium_valid_G(G)) G = medium_default_G(m->S);
+      f->G = G;
+      f->exactOk = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
     }
   }
   return f;
@@ -234,13 +245,14 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     for (const PairDesc &pd : hp) cells = std::max(cells, pd.cellBase + (long long)(pd.inLen + 1) * (pd.outLen + 1) * m->S);
     if (launch_fill_neg_inf(pool, cells, g_stream)) return 1;
   }
-  if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1) {
+  const bool tiledViterbi = !env && mode == MB_VITERBI && wide_applicable(m) && g_kernel_choice != 1 && fast_state(m)->exactOk;
+  if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1 && !tiledViterbi) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
     g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : (W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>");
     return wide_fill(m, *W, d_desc, (long long)hp.size(), d_out, pool, nullptr, g_stream);
   }
-  if (!env && use_medium(m)) {
+  if (!env && (use_medium(m) || tiledViterbi)) {
     FastState *f = fast_state(m);
     const bool exactFwd = mode == MB_VITERBI || (mode == MB_FORWARD && startState != 0);
     MedProgram &P = mode == MB_BACKWARD ? f->bwdSum : (exactFwd ? f->fwdExact : f->fwdSum);
@@ -310,6 +322,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
+    if (!f->mediumOk && f->exactOk && !medium_refresh_weights(m, f->fwdExact)) return 1;
     if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
     f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = true;
   }
@@ -537,7 +550,6 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
     PairDesc *d_desc = nullptr; double *pool = nullptr, *d_ll = nullptr;
     long long *d_slot = nullptr, *d_len = nullptr; uint32_t *d_path = nullptr;
     std::vector<long long> slot(np + 1, 0), len(np, 0);
-    std::vector<uint32_t> hpath;
     std::vector<double> hll(np);
     std::vector<PairDesc> hp;
     do {
@@ -562,17 +574,28 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
       if (!hip_ok(hipMemcpy(hll.data(), d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
       std::memcpy(loglike + c.p0, hll.data(), np * sizeof(double));
       if (wantPaths) {
-        hpath.resize(slot[np]);
         if (!hip_ok(hipMemcpy(len.data(), d_len, np * sizeof(long long), hipMemcpyDeviceToHost), "D2H path lengths")) { rc = 1; break; }
-        if (slot[np] && !hip_ok(hipMemcpy(hpath.data(), d_path, slot[np] * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H paths")) { rc = 1; break; }
+        std::vector<long long> off(np, -1);
+        long long total = 0;
         for (long long p = 0; p < np && !rc; ++p) {
-          long long n = len[p];
-          if (n == -1) n = 0;  // -inf end cell: no path (src/dpmatrix.defs.h:84)
+          const long long n = len[p];
+          if (n == -1) continue;   // -inf end cell: no path (src/dpmatrix.defs.h:84)
           if (n < 0) { set_error(n == -2 ? "Viterbi traceback exceeded its path bound" : "Viterbi traceback reached a dead end"); rc = 1; break; }
-          if (written + n > pathCap) { set_error("pathCap too small for the Viterbi paths of this batch"); rc = 1; break; }
-          const uint32_t *srcp = hpath.data() + slot[p + 1] - n;  // stored backwards from the slot end == start->end order
-          std::memcpy(pathEdges + written, srcp, n * sizeof(uint32_t));
-          written += n;
+          off[p] = total; total += n;
+        }
+        if (rc) break;
+        if (written + total > pathCap) { set_error("pathCap too small for the Viterbi paths of this batch"); rc = 1; break; }
+        // packed on the device, then ONE copy of exactly the used bytes into the caller's array (the slots are sized for
+        // the worst case, (inLen+outLen+1) x levels edges per pair: 32 MB for 1024 x 1 kb x 1 kb dnapsw pairs, 15 MB used)
+        long long *d_off = (long long *)ws_get(6, np * sizeof(long long));
+        uint32_t *d_packed = (uint32_t *)ws_get(7, std::max<long long>(total, 1) * sizeof(uint32_t));
+        if (!d_off || !d_packed) { rc = 1; break; }
+        if (!hip_ok(hipMemcpyAsync(d_off, off.data(), np * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
+        if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
+        if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
+        if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
+        for (long long p = 0; p < np; ++p) {
+          if (len[p] > 0) written += len[p];
           pathOff[c.p0 + p + 1] = written;
         }
       }

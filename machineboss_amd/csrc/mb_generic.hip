@@ -385,6 +385,25 @@ int launch_generic_counts(const mb_machine *m, const PairDesc *d_pairs, long lon
   return hip_ok(hipGetLastError(), "counts launch") ? 0 : 1;
 }
 
+// Paths are written backwards from the END of each pair's slot (its worst-case length); this packs them back to back in
+// start -> end order so that one D2H of exactly the used bytes lands in the caller's array.  off[p] < 0: no path.
+__global__ __launch_bounds__(256) void k_compact_paths(const uint32_t *__restrict__ pathBuf, const long long *__restrict__ slotOff,
+                                                       const long long *__restrict__ pathLen, const long long *__restrict__ off,
+                                                       uint32_t *__restrict__ out) {
+  const long long p = blockIdx.x, n = pathLen[p];
+  if (n <= 0) return;
+  const uint32_t *src = pathBuf + slotOff[p + 1] - n;
+  uint32_t *dst = out + off[p];
+  for (long long k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
+}
+
+int launch_compact_paths(const uint32_t *d_pathBuf, const long long *d_slotOff, const long long *d_pathLen, const long long *d_off,
+                         uint32_t *d_out, long long nPairs, hipStream_t st) {
+  if (nPairs == 0) return 0;
+  hipLaunchKernelGGL(k_compact_paths, dim3((unsigned)nPairs), dim3(256), 0, st, d_pathBuf, d_slotOff, d_pathLen, d_off, d_out);
+  return hip_ok(hipGetLastError(), "path compaction launch") ? 0 : 1;
+}
+
 int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_in, const int *d_out,
                      const double *d_pool, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen,
                      hipStream_t st) {

@@ -642,7 +642,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   const int keepStages = P.ok ? P.stages : -1;     // a weight refresh keeps the shape that was chosen
   wide_free(P);
   P.backward = backward; P.viterbi = viterbi;
-  P.W = env_int_w("MB_WIDE_LANES", m->S >= 768 ? 1024 : 256);
+  P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);      // 509 states: 48 G cells/s with 1024 lanes, 35 with 256
   const int S = m->S, nLev = backward ? m->nLevB : m->nLevF;
   long long nSilent = 0;
   for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
