@@ -888,3 +888,22 @@ def test_one_tape_family_small_machines(capi, oracle_mod, monkeypatch):
         assert capi.last_kernel_name().startswith("k_wide_sweep")
         assert np.array_equal(V, om.viterbi(x, y))
         assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+
+
+def test_boss_cli_hmmer_generator(capi, oracle_mod):
+    """`boss --hmmer fn3.hmm --output-chars <protein> -L / -V` (target/boss.cpp:574-579): the profile is a one-tape machine
+    (434 states) swept by the one-tape family; printed values against the oracle on the machine hmmer.py builds."""
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    hmm = golden_path("hmmer", "fn3.hmm")
+    em = EvaluatedMachine.fromMachine(HmmerModel.fromFile(hmm).machine(True), {})
+    om = oracle_mod.OracleMachine(em)
+    prot = "PSAPTNLRVTDVTSTSVTLSWEPPPGPITGYRVEYREAGSEDWKEVTVPGSETSYTLTGLKPGTEYEVRVRAVNGAGEGPPSE"
+    y = np.asarray(em.outputTokenizer.tokenize(list(prot)), np.int32); x = np.zeros(0, np.int32)
+    got = json.loads(_boss(["--hmmer", hmm, "--output-chars", prot, "-L"]))
+    assert capi.last_kernel_name().startswith("k_wide_")
+    assert got[0][1] == prot and got[0][2] == float("%.6g" % om.loglike(x, y, oracle_mod.SUM_EXACT))
+    got = json.loads(_boss(["--hmmer-global", hmm, "--output-chars", prot[:40], "-V"]))
+    emg = EvaluatedMachine.fromMachine(HmmerModel.fromFile(hmm).machine(False), {})
+    yg = np.asarray(emg.outputTokenizer.tokenize(list(prot[:40])), np.int32)
+    assert got[0][2] == float("%.6g" % oracle_mod.OracleMachine(emg).viterbi(x, yg)[-1, -1, -1])
