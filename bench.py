@@ -126,14 +126,14 @@ def main():
     value = total_cells / dt / 1e9
 
     extra = {}
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:
         other = capi.MB_ROLLING if flags == capi.MB_MATERIALISE else capi.MB_MATERIALISE
         batch.forward(other)
         t1 = time.perf_counter(); batch.forward(other); d1 = time.perf_counter() - t1
         extra["rolling_gcells_per_gpu" if other == capi.MB_ROLLING else "materialised_gcells_per_gpu"] = round(cells_rank / d1 / 1e9, 3)
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg runs at N = 1 only (the other ranks would idle behind it)
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle   # checker / baseline only: never on the product path
         om = oracle.OracleMachine(em)

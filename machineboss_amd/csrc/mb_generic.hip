@@ -4,7 +4,8 @@
 // states of all its supercells are finalised silent-level by silent-level (one __syncthreads() per level).
 // The matrix lives in HBM in the reference's layout (src/dpmatrix.h:90-96), so this family is also what backs
 // mb_fill(), Backward matrices, the posterior-count sweep and the Viterbi traceback for every machine size.
-// The fast families (mb_small.hip: lanes = supercells; mb_medium.hip: lanes = states) are checked against it.
+// The fast families (mb_medium.hip: lanes = states, tiled; mb_wide.hip: one workgroup per one-tape sequence) are checked
+// against it.
 #include <algorithm>
 
 #include "mb_internal.h"
