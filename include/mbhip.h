@@ -130,6 +130,19 @@ int mb_counts_batch(mb_machine *m, int64_t nPairs, const int32_t *inTok, const i
                     const int32_t *outTok, const int64_t *outOff, double *counts, double *loglikeSum,
                     double *loglike);
 
+/* ---- multi-GPU: the one exchange step of the path ---------------------------------------------------------------
+ * Pairs are independent, so a sharded pair list needs no collective for --loglike / --viterbi / --align.  For
+ * --counts / --train the per-rank MachineCounts are summed (MachineCounts::operator+=, src/counts.cpp:66-71): ONE
+ * all-reduce of nTransitions + 1 doubles per EM iteration over RCCL (xGMI).  The communicator is bootstrapped by the
+ * host: rank 0 calls mb_comm_unique_id and ships the 128 bytes to the other ranks by its own means, every rank calls
+ * mb_comm_init (after mb_set_device).  comm == NULL (single process) makes mb_allreduce_counts a no-op.  RCCL is
+ * opened on first use; a caller that never shards never needs it. */
+typedef struct mb_comm mb_comm;
+int mb_comm_unique_id(char id[128]);
+mb_comm *mb_comm_init(const char id[128], int nRanks, int rank);
+void mb_comm_destroy(mb_comm *comm);
+int mb_allreduce_counts(mb_comm *comm, double *counts, size_t n, double *loglike);   /* in place; loglike may be NULL */
+
 /* ---- tuning / introspection (not part of the reference surface) ------------------------------------------ */
 /* Select the kernel family: 0 = auto, 1 = generic (any machine), 2 = small-S lanes=cells, 3 = medium-S
  * lanes=states.  Used by tests to cross-check kernels against each other and by bench.py. */

@@ -26,6 +26,7 @@ EXPORTS = [
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source",
     "mb_batch_set_envelopes", "mb_fill_env",
+    "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
 
 _lib = None
@@ -78,6 +79,10 @@ def load():
     L.mb_fill_env.argtypes = [vp, C.c_int, i32p, C.c_int64, i32p, C.c_int64, C.c_int32, i32p, i32p, dp]
     L.mb_debug_jit_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_comm_unique_id.argtypes = [C.c_char_p]
+    L.mb_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int]; L.mb_comm_init.restype = vp
+    L.mb_comm_destroy.argtypes = [vp]; L.mb_comm_destroy.restype = None
+    L.mb_allreduce_counts.argtypes = [vp, dp, C.c_size_t, dp]
     _lib = L
     return L
 
@@ -121,6 +126,32 @@ def last_launch_count() -> int:
 
 def last_kernel_name() -> str:
     return load().mb_last_kernel_name().decode()
+
+
+class Comm:
+    """RCCL communicator of the C-ABI (mb_comm*): the route a C++ host takes; Python hosts use torch.distributed (shard.py)."""
+
+    def __init__(self, unique_id: bytes, nRanks: int, rank: int):
+        self.h = load().mb_comm_init(unique_id, nRanks, rank)
+        if not self.h:
+            raise MbError(load().mb_last_error().decode())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load().mb_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce_counts(self, counts: np.ndarray, loglike: float):
+        assert counts.dtype == np.float64 and counts.flags.c_contiguous
+        ll = C.c_double(loglike)
+        _check(load().mb_allreduce_counts(self.h, _p(counts, C.c_double), counts.size, C.byref(ll)))
+        return counts, ll.value
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mb_comm_destroy(self.h)
+            self.h = None
 
 
 def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: int = 1, G: int = 2):

@@ -1,0 +1,107 @@
+// mb_rccl.cpp -- the one exchange step of the path: MachineCounts::operator+= across processes (src/counts.cpp:66-71),
+// i.e. the sum of the E-step statistics of `boss --train` / `--counts` when the pair list is sharded over GPUs.
+//
+// One all-reduce (sum, fp64) of nTransitions + 1 values per EM iteration over RCCL (xGMI inside a node).  The RCCL
+// library is opened on first use (dlopen), so that a single-GPU caller never needs it and a Python caller that already
+// has torch's copy loaded keeps using that one.  A C++ host (the reference is one) bootstraps the communicator with
+// mb_comm_unique_id on rank 0, ships the 128 bytes to the other ranks by whatever it already has (MPI, a file, a socket),
+// and calls mb_comm_init everywhere; a Python host uses torch.distributed instead (machineboss_amd/shard.py).
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+
+#include "mb_internal.h"
+
+namespace {
+struct UniqueId { char internal[128]; };
+typedef int (*GetUniqueIdFn)(UniqueId *);
+typedef int (*CommInitRankFn)(void **, int, UniqueId, int);
+typedef int (*CommDestroyFn)(void *);
+typedef int (*AllReduceFn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*ErrStrFn)(int);
+struct Rccl {
+  void *lib = nullptr;
+  GetUniqueIdFn getUniqueId = nullptr;
+  CommInitRankFn commInitRank = nullptr;
+  CommDestroyFn commDestroy = nullptr;
+  AllReduceFn allReduce = nullptr;
+  ErrStrFn errStr = nullptr;
+};
+Rccl g_rccl;
+
+bool rccl_load() {
+  if (g_rccl.lib) return true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) { mb::set_error(std::string("RCCL library not found: ") + dlerror()); return false; }
+  g_rccl.getUniqueId = (GetUniqueIdFn)dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.commInitRank = (CommInitRankFn)dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.commDestroy = (CommDestroyFn)dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.allReduce = (AllReduceFn)dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.errStr = (ErrStrFn)dlsym(g_rccl.lib, "ncclGetErrorString");
+  if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allReduce) {
+    mb::set_error("RCCL library lacks the expected entry points");
+    g_rccl.lib = nullptr;
+    return false;
+  }
+  return true;
+}
+
+bool rccl_ok(int rc, const char *what) {
+  if (rc == 0) return true;
+  mb::set_error(std::string(what) + ": " + (g_rccl.errStr ? g_rccl.errStr(rc) : "RCCL error"));
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
+int mb_comm_unique_id(char id[128]) {
+  if (!id) { mb::set_error("null argument"); return 1; }
+  if (!rccl_load()) return 1;
+  UniqueId u;
+  if (!rccl_ok(g_rccl.getUniqueId(&u), "ncclGetUniqueId")) return 1;
+  std::memcpy(id, u.internal, 128);
+  return 0;
+}
+
+mb_comm *mb_comm_init(const char id[128], int nRanks, int rank) {
+  if (!id || nRanks < 1 || rank < 0 || rank >= nRanks) { mb::set_error("mb_comm_init: bad argument"); return nullptr; }
+  if (!rccl_load()) return nullptr;
+  UniqueId u;
+  std::memcpy(u.internal, id, 128);
+  void *comm = nullptr;
+  if (!rccl_ok(g_rccl.commInitRank(&comm, nRanks, u, rank), "ncclCommInitRank")) return nullptr;
+  return (mb_comm *)comm;
+}
+
+void mb_comm_destroy(mb_comm *comm) {
+  if (comm && g_rccl.commDestroy) (void)g_rccl.commDestroy((void *)comm);
+}
+
+int mb_allreduce_counts(mb_comm *comm, double *counts, size_t n, double *loglike) {
+  if (!comm) return 0;   // single process: the counts are already complete
+  if (!counts && n) { mb::set_error("null argument"); return 1; }
+  if (!rccl_load()) return 1;
+  const size_t total = n + (loglike ? 1 : 0);
+  if (!total) return 0;
+  double *d = nullptr;
+  MB_HIP(hipMalloc((void **)&d, total * sizeof(double)));
+  int rc = 0;
+  do {
+    if (n && !mb::hip_ok(hipMemcpyAsync(d, counts, n * sizeof(double), hipMemcpyHostToDevice, mb::g_stream), "H2D counts")) { rc = 1; break; }
+    if (loglike && !mb::hip_ok(hipMemcpyAsync(d + n, loglike, sizeof(double), hipMemcpyHostToDevice, mb::g_stream), "H2D loglike")) { rc = 1; break; }
+    if (!rccl_ok(g_rccl.allReduce(d, d, total, /*ncclDouble*/ 8, /*ncclSum*/ 0, (void *)comm, mb::g_stream), "ncclAllReduce")) { rc = 1; break; }
+    if (n && !mb::hip_ok(hipMemcpyAsync(counts, d, n * sizeof(double), hipMemcpyDeviceToHost, mb::g_stream), "D2H counts")) { rc = 1; break; }
+    if (loglike && !mb::hip_ok(hipMemcpyAsync(loglike, d + n, sizeof(double), hipMemcpyDeviceToHost, mb::g_stream), "D2H loglike")) { rc = 1; break; }
+    if (!mb::hip_ok(hipStreamSynchronize(mb::g_stream), "all-reduce of counts")) { rc = 1; break; }
+  } while (0);
+  (void)hipFree(d);
+  return rc;
+}
+
+}  // extern "C"

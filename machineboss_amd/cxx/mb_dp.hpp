@@ -237,6 +237,15 @@ struct MachineCounts {
     loglike += s;
     return ll;
   }
+  // operator+= over every rank of `comm` at once: one RCCL all-reduce of nTransitions + 1 doubles (mb_allreduce_counts);
+  // comm == nullptr (single process) leaves the counts as they are
+  void allReduce(mb_comm *comm) {
+    std::vector<double> flat;
+    for (const auto &row : count) flat.insert(flat.end(), row.begin(), row.end());
+    check(mb_allreduce_counts(comm, flat.data(), flat.size(), &loglike));
+    size_t k = 0;
+    for (auto &row : count) for (double &c : row) c = flat[k++];
+  }
   MachineCounts &operator+=(const MachineCounts &o) {       // src/counts.cpp:66-71 (the RCCL all-reduce across ranks)
     for (size_t s = 0; s < count.size(); ++s) for (size_t t = 0; t < count[s].size(); ++t) count[s][t] += o.count[s][t];
     loglike += o.loglike;

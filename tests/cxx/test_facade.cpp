@@ -26,7 +26,17 @@ int main() {
   Envelope area; area.initPathArea({{true, true}, {true, true}, {true, true}}, 1);
   const bool areaOk = area.inStart == std::vector<int32_t>({0, 0, 1, 2}) && area.inEnd == std::vector<int32_t>({2, 3, 4, 4});
   std::printf("env %d %d %d\n", (int)envOk, (int)envDp, (int)areaOk);
-  const bool all = ok && envOk && envDp && areaOk;
+  // the collective of --train: a one-rank communicator (all a single-GPU box can form) and the no-communicator no-op
+  char id[128];
+  bool commOk = mb_comm_unique_id(id) == 0;
+  mb_comm *comm = commOk ? mb_comm_init(id, 1, 0) : nullptr;
+  commOk = commOk && comm != nullptr;
+  const double before = mc.count[0][0], llBefore = mc.loglike;
+  mc.allReduce(nullptr); mc.allReduce(comm);
+  commOk = commOk && mc.count[0][0] == before && mc.loglike == llBefore;
+  mb_comm_destroy(comm);
+  std::printf("comm %d\n", (int)commOk);
+  const bool all = ok && envOk && envDp && areaOk && commOk;
   std::printf(all ? "FACADE OK\n" : "FACADE MISMATCH\n");
   return all ? 0 : 1;
 }

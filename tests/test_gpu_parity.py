@@ -907,3 +907,19 @@ def test_boss_cli_hmmer_generator(capi, oracle_mod):
     emg = EvaluatedMachine.fromMachine(HmmerModel.fromFile(hmm).machine(False), {})
     yg = np.asarray(emg.outputTokenizer.tokenize(list(prot[:40])), np.int32)
     assert got[0][2] == float("%.6g" % oracle_mod.OracleMachine(emg).viterbi(x, yg)[-1, -1, -1])
+
+
+def test_rccl_allreduce_entry_points(capi):
+    """mb_comm_* / mb_allreduce_counts: the C-ABI route to the one collective of the path.  A one-rank communicator is all
+    a single-GPU box can form -- the reduction is the identity there -- and a NULL communicator is a no-op; the N > 1
+    arithmetic is covered by the gloo world-size-2 tests of the Python route (tests/test_distributed.py)."""
+    import ctypes as C
+    counts = np.arange(7, dtype=np.float64) * 0.5
+    ll = C.c_double(-3.25)
+    assert capi.load().mb_allreduce_counts(None, counts.ctypes.data_as(C.POINTER(C.c_double)), counts.size, C.byref(ll)) == 0
+    comm = capi.Comm(capi.Comm.unique_id(), 1, 0)
+    try:
+        got, gl = comm.allreduce_counts(counts.copy(), -3.25)
+    finally:
+        comm.close()
+    assert np.array_equal(got, counts) and gl == -3.25
