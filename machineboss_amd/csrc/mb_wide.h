@@ -62,7 +62,7 @@ struct WideProgram {
   int stages = 0;            // closure stages the silent levels were grouped into (0 = levelled, exact)
   int W = 1024;
   long long nPairs = 0;      // closure pairs
-  long long slotsPerColumn = 0;
+  long long slotsPerColumn = 0, candsPerColumn = 0;
   int nSync = 0;
   std::vector<WideRound> rounds;     // planning tables (host only)
   std::vector<WideRec> recs;

@@ -383,6 +383,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
           const int j = k / g, sub = k % g;
           WideRec &rc = P->recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + lane + sub];
           rc.w = cd.w; rc.src = cd.src;
+          if (t == nTab - 1) P->candsPerColumn++;
         }
       }
       lane += g;
@@ -724,8 +725,9 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.dev.backward = backward ? 1 : 0;
   P.ok = true; P.dirty = false;
   if (verbose)
-    fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column, %zu records, vectors %zu bytes\n",
-            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK, P.rounds.size(), P.slotsPerColumn, P.nSync, nRecs, P.vecBytes());
+    fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column (%lld candidates = %.0f %% of the lane slots), %zu records, vectors %zu bytes\n",
+            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK, P.rounds.size(), P.slotsPerColumn, P.nSync, P.candsPerColumn,
+            100.0 * (double)P.candsPerColumn / (double)std::max<long long>(1, P.slotsPerColumn * P.W), nRecs, P.vecBytes());
   return true;
 }
 
