@@ -3,6 +3,7 @@
 // Host orchestration only: device memory pools, chunking of a batch so that materialised matrices fit the HBM
 // budget (288 GB per MI355X), kernel-family selection, HIP-event timing on the library stream.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -59,8 +60,41 @@ static void *ws_get(int slot, size_t bytes) {
   return w.p;
 }
 
+// Small per-call device buffers (pair descriptors, log-likelihoods, offsets): a hipMalloc / hipFree pair per call is
+// normally microseconds but now and then tens of milliseconds (measured: 23 ms ahead of a 25 ms Viterbi batch), so freed
+// blocks are kept by size class and handed out again.
+struct SmallBlock { void *p; size_t bytes; };
+static std::vector<SmallBlock> g_smallFree, g_smallLive;
+hipError_t sm_alloc(void **out, size_t bytes) {
+  size_t cls = 4096;
+  while (cls < bytes) cls <<= 1;
+  for (size_t k = 0; k < g_smallFree.size(); ++k)
+    if (g_smallFree[k].bytes == cls) {
+      *out = g_smallFree[k].p;
+      g_smallLive.push_back(g_smallFree[k]);
+      g_smallFree.erase(g_smallFree.begin() + k);
+      return hipSuccess;
+    }
+  const hipError_t e = hipMalloc(out, cls);
+  if (e == hipSuccess) g_smallLive.push_back({*out, cls});
+  return e;
+}
+void sm_free(void *p) {
+  if (!p) return;
+  for (size_t k = 0; k < g_smallLive.size(); ++k)
+    if (g_smallLive[k].p == p) {
+      if (g_smallLive[k].bytes <= ((size_t)64 << 20) && g_smallFree.size() < 32) g_smallFree.push_back(g_smallLive[k]);
+      else (void)hipFree(p);
+      g_smallLive.erase(g_smallLive.begin() + k);
+      return;
+    }
+  (void)hipFree(p);
+}
+
 static void ws_release() {
   for (Workspace &w : g_ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+  for (SmallBlock &b : g_smallFree) (void)hipFree(b.p);
+  g_smallFree.clear();
 }
 
 static size_t budget_bytes() {
@@ -129,7 +163,7 @@ static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_ou
   tmp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
   long long base = 0;
   for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S; }
-  MB_HIP(hipMalloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
+  MB_HIP(sm_alloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
   MB_HIP(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream));
   MB_HIP(hipStreamSynchronize(g_stream));
   return 0;
@@ -444,7 +478,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   if (b->nPairs == 0) return 0;
   mb_machine *m = b->m;
   double *d_ll = nullptr;
-  MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
+  MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
   Timer tm;
   // The rolling sweep runs ONE workgroup per pair: with fewer pairs than CUs the tile pipeline (which cuts every pair
@@ -473,7 +507,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     double *d_halo = nullptr; long long *d_hb = nullptr;
     do {
       if (!(d_halo = (double *)ws_get(2, std::max<long long>(tot, 1) * sizeof(double)))) { rc = 1; break; }
-      if (!hip_ok(hipMalloc((void **)&d_hb, b->nPairs * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
+      if (!hip_ok(sm_alloc((void **)&d_hb, b->nPairs * sizeof(long long)), "hipMalloc")) { rc = 1; break; }
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
       tm.start();
       rc = medium_forward_rolling(m, f->fwdSum, f->geoFS, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
@@ -481,7 +515,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
-    if (d_hb) (void)hipFree(d_hb);
+    if (d_hb) sm_free(d_hb);
   } else if (mode == MB_FORWARD && !b->hasEnv && use_medium(m) && env_int("MB_MEDIUM_PIPELINE", 1) &&
              (size_t)b->totalCells * 8 > budget_bytes()) {
     // the matrices of the batch do not fit the device-memory budget together:
@@ -500,23 +534,23 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     }
   } else {
     std::vector<Chunk> chunks;
-    if (!plan_chunks(b, 1, chunks)) { (void)hipFree(d_ll); return 1; }
+    if (!plan_chunks(b, 1, chunks)) { sm_free(d_ll); return 1; }
     for (const Chunk &c : chunks) {
       PairDesc *d_desc = nullptr; double *pool = nullptr;
       std::vector<PairDesc> hp;
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { (void)hipFree(d_desc); rc = 1; break; }
+      if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { sm_free(d_desc); rc = 1; break; }
       tm.start();
       rc = fill_chunk(m, mode, d_desc, hp, b->d_in, b->d_out, pool, 0, b);
       if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, m->S, 0, d_ll + c.p0, g_stream);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
-      (void)hipFree(d_desc);
+      sm_free(d_desc);
       if (rc) break;
     }
   }
   if (!rc && !hip_ok(hipMemcpy(loglike, d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
-  (void)hipFree(d_ll);
+  sm_free(d_ll);
   return rc;
 }
 
@@ -545,6 +579,10 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   int rc = 0;
   Timer tm;
   long long written = 0;
+  const bool timing = getenv("MB_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now(), tPrev = t0;
+  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip] viterbi %-28s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
   for (const Chunk &c : chunks) {
     const long long np = c.p1 - c.p0;
     PairDesc *d_desc = nullptr; double *pool = nullptr, *d_ll = nullptr;
@@ -555,7 +593,8 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
     do {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
       if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
-      if (!hip_ok(hipMalloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+      if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+      lap("chunk set-up");
       tm.start();
       if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0, b))) break;
       if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
@@ -569,8 +608,10 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
         if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
       }
+      lap("launches (host side)");
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "viterbi kernels")) { rc = 1; break; }
+      lap("kernels");
       if (!hip_ok(hipMemcpy(hll.data(), d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
       std::memcpy(loglike + c.p0, hll.data(), np * sizeof(double));
       if (wantPaths) {
@@ -594,6 +635,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
         if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
         if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
+        lap("pack + D2H paths");
         for (long long p = 0; p < np; ++p) {
           if (len[p] > 0) written += len[p];
           pathOff[c.p0 + p + 1] = written;
@@ -601,7 +643,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
       }
     } while (0);
     void *ptrs[] = {d_desc, d_ll};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (void *q : ptrs) sm_free(q);
     if (rc) break;
   }
   return rc;
@@ -617,8 +659,8 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;
-  MB_HIP(hipMalloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)));
-  MB_HIP(hipMalloc((void **)&d_ll, b->nPairs * sizeof(double)));
+  MB_HIP(sm_alloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)));
+  MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   MB_HIP(hipMemsetAsync(d_counts, 0, std::max<long long>(nT, 1) * sizeof(double), g_stream));
   int rc = 0;
   Timer tm;
@@ -651,8 +693,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
     } while (0);
-    void *ptrs[] = {d_desc};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    sm_free(d_desc);
     if (rc) break;
   }
   if (!rc) {
@@ -666,7 +707,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       if (loglikeSum) *loglikeSum += s;
     }
   }
-  (void)hipFree(d_counts); (void)hipFree(d_ll);
+  sm_free(d_counts); sm_free(d_ll);
   return rc;
 }
 

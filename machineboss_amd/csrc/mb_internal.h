@@ -90,6 +90,9 @@ extern hipStream_t g_stream;
 extern thread_local long long g_last_launches;   // kernel launches of the dominant kernel in the last batch call
 extern int g_kernel_choice;
 extern size_t g_mem_budget;
+// cached small device buffers (mb_api.hip): per-call descriptor / offset / tile-list arrays
+hipError_t sm_alloc(void **out, size_t bytes);
+void sm_free(void *p);
 #define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)
 
 // host-side machine compiler (mb_machine.cpp)

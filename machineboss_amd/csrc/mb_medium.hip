@@ -884,10 +884,10 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
     }
   }
   int2 *d_tiles = nullptr;
-  if (!hip_ok(hipMalloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
-  if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { (void)hipFree(d_tiles); return 1; }
+  if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
+  if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { sm_free(d_tiles); return 1; }
   const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level)] : nullptr;
-  if (mode == MED_MODE_COUNT && !J) { (void)hipFree(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
+  if (mode == MED_MODE_COUNT && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   MedTileArgs A{};
@@ -906,7 +906,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
     else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
   }
   const bool ok = hip_ok(hipGetLastError(), "medium tile launch") && hip_ok(hipStreamSynchronize(st), "medium tile kernels");
-  (void)hipFree(d_tiles);
+  sm_free(d_tiles);
   return ok ? 0 : 1;
 }
 
@@ -1032,10 +1032,10 @@ int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &
     ++launch;
   }
   PairDesc *d_pairs = nullptr;
-  if (!hip_ok(hipMalloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
-  if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { (void)hipFree(d_pairs); return 1; }
+  if (!hip_ok(sm_alloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
+  if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { sm_free(d_pairs); return 1; }
   const int rc = launch_wavefront(m, P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st);
-  (void)hipFree(d_pairs);
+  sm_free(d_pairs);
   return rc;
 }
 
