@@ -923,3 +923,26 @@ def test_rccl_allreduce_entry_points(capi):
     finally:
         comm.close()
     assert np.array_equal(got, counts) and gl == -3.25
+
+
+@pytest.mark.parametrize("fp32", [0, 1])
+def test_one_tape_family_long_sequences(capi, monkeypatch, fp32):
+    """Lengths the CPU oracle would need minutes for: the one-tape family against the generic family (one barrier per
+    silent level, exact fp64 log1p/exp) on an 8-node profile machine, 3 x 1500 nt -- Forward within 1e-6 relative for
+    both arithmetic variants (fp64 columns; fp32 relative to the running column maximum), Viterbi scores and paths identical."""
+    monkeypatch.setenv("MB_WIDE_FP32", str(fp32))
+    m, em = _profile_machine(8)
+    dm = capi.DeviceMachine(em)
+    b = capi.DeviceBatch(dm, *synth_batch(5, 3, 0, 1500, em.nInTok, em.nOutTok))
+    res = {}
+    for fam in (capi.KERNEL_AUTO, capi.KERNEL_GENERIC):
+        capi.set_kernel(fam)
+        try:
+            res[fam] = (b.forward(capi.MB_ROLLING), b.forward(capi.MB_MATERIALISE), b.viterbi(paths=True))
+            kern = capi.last_kernel_name()
+        finally:
+            capi.set_kernel(capi.KERNEL_AUTO)
+        assert kern.startswith("k_generic") == (fam == capi.KERNEL_GENERIC)
+    a, g = res[capi.KERNEL_AUTO], res[capi.KERNEL_GENERIC]
+    assert close(a[0], g[0], 1e-6) and close(a[1], g[1], 1e-6) and close(a[0], a[1], 1e-9, 1e-12)
+    assert np.array_equal(a[2][0], g[2][0]) and np.array_equal(a[2][1], g[2][1]) and np.array_equal(a[2][2], g[2][2])
