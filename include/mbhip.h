@@ -9,6 +9,9 @@
  * Conventions
  *  - plain pointers and sizes only; all buffers are caller-owned host memory unless stated otherwise;
  *    the library owns device memory.  Calls are synchronous.
+ *  - threading: like the reference (no threads on this path) the library expects ONE host
+ *    thread per process to drive it -- the device workspaces and compiled programs are process-wide and unlocked;
+ *    scale out with one process per GPU.  A filled matrix handed back to the caller is plain host memory.
  *  - every function returning int returns 0 on success, non-zero on error; mb_last_error() then gives the
  *    message the reference would have put into its runtime_error (src/util.cpp:39-48).
  *  - tokens are int32, token 0 = epsilon, tokens 1..N index the sorted alphabet (src/eval.h:13-22).
