@@ -59,7 +59,7 @@ class HmmerModel:
     def t_idx(self): return self.nCoreStates() + 7
     def nPlan7States(self): return self.nCoreStates() + 8
 
-    # ---- parser (src/hmmer.cpp:43-105) --------------------------------------------------------------------------
+    # ---- parser (format read by src/hmmer.cpp:43-105) -------------------------------------------------------------
     @classmethod
     def fromFile(cls, path: str) -> "HmmerModel":
         with open(path) as f:
@@ -67,49 +67,51 @@ class HmmerModel:
 
     @classmethod
     def fromText(cls, text: str) -> "HmmerModel":
+        """HMMER3 ASCII save file: everything up to the line starting with the tag `HMM` is header; that line lists the
+        alphabet; two lines on (transition labels, optional COMPO) come the node-0 insert emissions and the begin
+        transitions, then three lines per node (match emissions with the node number first and five annotation fields
+        last, insert emissions, seven transitions) until `//`."""
         h = cls()
-        lines = text.split("\n")
-        k = 0
-        while k < len(lines):
-            line = lines[k]; k += 1
-            tag = re.match(r"^([A-Z]+)", line)
-            if not tag or tag.group(1) != "HMM":
-                continue
-            fields = line.split()
-            if len(fields) <= 1:
-                raise MachineError("HMM parse error: empty alphabet")
-            h.alph = fields[1:]
-            k += 2                              # the transition-label line and the optional COMPO line
-            if k >= len(lines): break
-            ins0 = lines[k].split(); k += 1
-            if len(ins0) != len(h.alph):
-                raise MachineError("HMM parse error: wrong number of fields in node 0 insert line")
-            h.ins0Emit = [strToProb(s) for s in ins0]
-            if k >= len(lines): break
-            bt = lines[k].split(); k += 1
-            h.b_to_m1, h.b_to_i0, h.b_to_d1, h.i0_to_m1, h.i0_to_i0 = (strToProb(s) for s in bt[:5])
-            while k < len(lines):
-                line = lines[k]; k += 1
-                if line.startswith("//"):
-                    break
-                ml = line.split()
-                if len(ml) != len(h.alph) + 6:
-                    raise MachineError("HMM parse error: wrong number of fields in node match line")
-                if int(ml[0]) != len(h.node) + 1:
-                    raise MachineError("HMM parse error: incorrect node index")
-                if k + 1 >= len(lines):
-                    raise MachineError("HMM parse error: premature truncation of node")
-                il = lines[k].split(); tl = lines[k + 1].split(); k += 2
-                if len(il) != len(h.alph):
-                    raise MachineError("HMM parse error: wrong number of fields in node insert line")
-                if len(tl) != 7:
-                    raise MachineError("HMM parse error: wrong number of fields in node transitions line")
-                n = HmmerNode()
-                n.matchEmit = [strToProb(s) for s in ml[1:len(h.alph) + 1]]
-                n.insEmit = [strToProb(s) for s in il]
-                n.m_to_m, n.m_to_i, n.m_to_d, n.i_to_m, n.i_to_i, n.d_to_m, n.d_to_d = (strToProb(s) for s in tl)
-                h.node.append(n)
-            break
+        rows = [ln.split() for ln in text.split("\n")]
+        start = next((k for k, ln in enumerate(text.split("\n")) if re.match(r"^HMM(?![A-Z])", ln)), None)
+        if start is None:
+            h.loadNullModel()
+            return h
+        if len(rows[start]) <= 1:
+            raise MachineError("HMM parse error: empty alphabet")
+        h.alph = rows[start][1:]
+        nSym = len(h.alph)
+        body = rows[start + 3:]
+        if not body:
+            h.loadNullModel()
+            return h
+        if len(body[0]) != nSym:
+            raise MachineError("HMM parse error: wrong number of fields in node 0 insert line")
+        h.ins0Emit = [strToProb(f) for f in body[0]]
+        if len(body) > 1:
+            h.b_to_m1, h.b_to_i0, h.b_to_d1, h.i0_to_m1, h.i0_to_i0 = (strToProb(f) for f in body[1][:5])
+        k = 2
+        raw = text.split("\n")[start + 3:]
+        while k < len(body) and not raw[k].startswith("//"):
+            match = body[k]
+            if len(match) != nSym + 6:
+                raise MachineError("HMM parse error: wrong number of fields in node match line")
+            if int(match[0]) != len(h.node) + 1:
+                raise MachineError("HMM parse error: incorrect node index")
+            if k + 2 >= len(body):
+                raise MachineError("HMM parse error: premature truncation of node")
+            ins, trans = body[k + 1], body[k + 2]
+            if len(ins) != nSym:
+                raise MachineError("HMM parse error: wrong number of fields in node insert line")
+            if len(trans) != 7:
+                raise MachineError("HMM parse error: wrong number of fields in node transitions line")
+            nd = HmmerNode()
+            nd.matchEmit = [strToProb(f) for f in match[1:nSym + 1]]
+            nd.insEmit = [strToProb(f) for f in ins]
+            for name, f in zip(HmmerNode.__slots__[2:], trans):
+                setattr(nd, name, strToProb(f))
+            h.node.append(nd)
+            k += 3
         h.loadNullModel()
         return h
 
@@ -133,65 +135,66 @@ class HmmerModel:
             mocc[k] = mocc[k - 1] * (nd[k].m_to_m + nd[k].m_to_i) + (1.0 - mocc[k - 1]) * nd[k].d_to_m
         return mocc
 
-    # ---- core machine (src/hmmer.cpp:107-177) -------------------------------------------------------------------
+    # ---- core machine (same states, transition order and weights as src/hmmer.cpp:107-177) -----------------------------
     def machine(self, local: bool = True) -> Machine:
+        """B, then per node k: Ix(k) I(k) | Mx(k) M(k) D(k), then E.  M(k) / I(k) emit and move to their `x` twin, which carries
+        the node's outgoing transitions.  Local mode (p7_ProfileConfig): B enters M(k) with occupancy-weighted probability
+        and every M(k), D(k) may leave to E with weight 1; global mode: B -> M1 / I0 / D1 and only the last node reaches E."""
         if not self.node:
             raise MachineError("Attempt to create a transducer from an empty HMMER model")
         N = len(self.node)
+        E = self.core_end_idx()
         m = Machine()
         m.state = [MachineState() for _ in range(self.nCoreStates())]
-        T = MachineTransition
-        st = m.state
-        st[self.b_idx()].name = "B"
+        names = {self.b_idx(): "B", E: "E"}
+        for k in range(N + 1):
+            names[self.i_idx(k)] = "I%d" % k; names[self.ix_idx(k)] = "Ix%d" % k
+            if k:
+                names[self.m_idx(k)] = "M%d" % k; names[self.mx_idx(k)] = "Mx%d" % k; names[self.d_idx(k)] = "D%d" % k
+        for idx, nm in names.items():
+            m.state[idx].name = nm
+
+        def arc(src, dst, w, out=""):
+            m.state[src].trans.append(MachineTransition(dst, "", out, w))
+
+        def emit(src, dst, probs):
+            for sym, p in zip(self.alph, probs):
+                arc(src, dst, p, sym)
+
         if local:
             occ = self.calcMatchOccupancy()
-            Z = 0.0
+            Z = sum(occ[k] * (N - k + 1) for k in range(1, N))
             for k in range(1, N):
-                Z += occ[k] * (N - k + 1)
-            for k in range(1, N):
-                st[self.b_idx()].trans.append(T(self.m_idx(k), "", "", occ[k] / Z))
+                arc(self.b_idx(), self.m_idx(k), occ[k] / Z)
         else:
-            st[self.b_idx()].trans.append(T(self.m_idx(1), "", "", self.b_to_m1))
-            st[self.b_idx()].trans.append(T(self.i_idx(0), "", "", self.b_to_i0))
-            st[self.b_idx()].trans.append(T(self.d_idx(1), "", "", self.b_to_d1))
-        st[self.ix_idx(0)].trans.append(T(self.m_idx(1), "", "", self.i0_to_m1))
-        st[self.ix_idx(0)].trans.append(T(self.i_idx(0), "", "", self.i0_to_i0))
-        for sym, p in zip(self.alph, self.ins0Emit):
-            st[self.i_idx(0)].trans.append(T(self.ix_idx(0), "", sym, p))
-        for n in range(N + 1):
-            st[self.i_idx(n)].name = "I%d" % n
-            st[self.ix_idx(n)].name = "Ix%d" % n
-            if n == 0:
-                continue
-            nd = self.node[n - 1]
-            st[self.m_idx(n)].name = "M%d" % n
-            st[self.mx_idx(n)].name = "Mx%d" % n
-            st[self.d_idx(n)].name = "D%d" % n
-            end = (n == N)
-            mx, ix, d = st[self.mx_idx(n)], st[self.ix_idx(n)], st[self.d_idx(n)]
-            if end:
-                if not local:
-                    mx.trans.append(T(self.core_end_idx(), "", "", nd.m_to_m))
-            else:
-                mx.trans.append(T(self.m_idx(n + 1), "", "", nd.m_to_m))
-            mx.trans.append(T(self.i_idx(n), "", "", nd.m_to_i))
-            if not end:
-                mx.trans.append(T(self.d_idx(n + 1), "", "", nd.m_to_d))
-            ix.trans.append(T(self.core_end_idx() if end else self.m_idx(n + 1), "", "", nd.i_to_m))
-            ix.trans.append(T(self.i_idx(n), "", "", nd.i_to_i))
-            if end:
-                if not local:
-                    d.trans.append(T(self.core_end_idx(), "", "", nd.d_to_m))
-            else:
-                d.trans.append(T(self.m_idx(n + 1), "", "", nd.d_to_m))
-                d.trans.append(T(self.d_idx(n + 1), "", "", nd.d_to_d))
-            for sym, pm, pi in zip(self.alph, nd.matchEmit, nd.insEmit):
-                st[self.m_idx(n)].trans.append(T(self.mx_idx(n), "", sym, pm))
-                st[self.i_idx(n)].trans.append(T(self.ix_idx(n), "", sym, pi))
+            for dst, w in ((self.m_idx(1), self.b_to_m1), (self.i_idx(0), self.b_to_i0), (self.d_idx(1), self.b_to_d1)):
+                arc(self.b_idx(), dst, w)
+        arc(self.ix_idx(0), self.m_idx(1), self.i0_to_m1)
+        arc(self.ix_idx(0), self.i_idx(0), self.i0_to_i0)
+        emit(self.i_idx(0), self.ix_idx(0), self.ins0Emit)
+        for k, nd in enumerate(self.node, 1):
+            last = (k == N)
+            nextM = E if last else self.m_idx(k + 1)
+            # outgoing transitions of the node, from the post-emission states Mx / Ix and from D
+            if not last or not local:
+                arc(self.mx_idx(k), nextM, nd.m_to_m)
+            arc(self.mx_idx(k), self.i_idx(k), nd.m_to_i)
+            if not last:
+                arc(self.mx_idx(k), self.d_idx(k + 1), nd.m_to_d)
+            arc(self.ix_idx(k), nextM, nd.i_to_m)
+            arc(self.ix_idx(k), self.i_idx(k), nd.i_to_i)
+            if not last:
+                arc(self.d_idx(k), nextM, nd.d_to_m)
+                arc(self.d_idx(k), self.d_idx(k + 1), nd.d_to_d)
+            elif not local:
+                arc(self.d_idx(k), E, nd.d_to_m)
+            # emissions, symbol by symbol: the match and the insert state alternate in the reference's loop, which only
+            # fixes the order inside each state's own list
+            emit(self.m_idx(k), self.mx_idx(k), nd.matchEmit)
+            emit(self.i_idx(k), self.ix_idx(k), nd.insEmit)
             if local:
-                st[self.m_idx(n)].trans.append(T(self.core_end_idx(), "", "", 1))
-                d.trans.append(T(self.core_end_idx(), "", "", 1))
-        st[self.core_end_idx()].name = "E"
+                arc(self.m_idx(k), E, 1)
+                arc(self.d_idx(k), E, 1)
         return m
 
     # ---- Plan7 flanks (src/hmmer.cpp:179-235) -------------------------------------------------------------------
