@@ -334,7 +334,10 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
     len[i] = std::max(1, t2 + (int)nodes[i]->t3.size());
     maxLen = std::max(maxLen, len[i]);
   }
-  const double cSlot = 60.0, cRound = 40.0, cShfl = 45.0, cSync = 150.0;
+  // calibrated on the box (forced K sweeps, least squares over slots / rounds / barriers per column): a candidate slot of
+  // 1024 lanes costs 0.19 us (fp64 columns in LDS) to 0.30 us (fp32, previous column in L2), a ROUND -- epilogue with the
+  // lane-group reduction, log, store -- 0.30 to 0.58 us, i.e. 1.6-1.9 slots, and the barrier itself next to nothing
+  const double cSlot = 60.0, cRound = 105.0, cShfl = 3.0, cSync = 10.0;
   auto groupOf = [&](int L, int d) { return std::min(64, pow2ceil((L + d - 1) / d)); };
   int bestD = 1; double best = 1e300;
   for (int d = 1; d <= maxLen; ++d) {
