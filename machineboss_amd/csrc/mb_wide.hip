@@ -563,7 +563,7 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pair
     }
   emitC[seedNode][0].push_back({PREV(S + 1), 0.0});
   nodes.clear(); nExtra = 0; nPairs = 0;
-  if (K <= 0) {
+  if (K == 0) {
     for (int x = 0; x < S; ++x) {
       bool any = !sil[x].empty();
       for (const auto &l : emitC[x]) if (!l.empty()) any = true;
@@ -575,11 +575,16 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pair
     nStages = nLev;
     return true;
   }
-  K = std::max(1, std::min(K, std::max(1, nLev - 1)));
+  // K > 0: the silent levels 1..nLev-1 cut into K groups of equal level count;  K < 0: ADAPTIVE -- levels are added to the
+  // current stage while its closure stays within -K candidates, so the long thin runs of a profile's delete chain (a few
+  // states per level, cheap to close) end up in few stages and the wide levels in stages of their own
+  const bool adaptive = K < 0;
+  const long long budget = adaptive ? -(long long)K : 0;
+  if (!adaptive) K = std::max(1, std::min(K, std::max(1, nLev - 1)));
   std::vector<int> stg(S, 0);
   std::vector<char> isBase(S, 0);
   for (int x = 0; x < S; ++x) {
-    if (lev[x] > 0) stg[x] = 1 + (int)(((long long)(lev[x] - 1) * K) / std::max(1, nLev - 1));
+    if (!adaptive && lev[x] > 0) stg[x] = 1 + (int)(((long long)(lev[x] - 1) * K) / std::max(1, nLev - 1));
     for (const auto &l : emitC[x]) if (!l.empty()) isBase[x] = 1;
   }
   std::vector<int> eslot(S, -1);
@@ -593,9 +598,8 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pair
     if (acc[a] == -INFINITY) { touched.push_back(a); acc[a] = w; }
     else acc[a] = host_lse2(acc[a], w);
   };
-  for (int q = 0; q < S; ++q) {
-    const int x = backward ? S - 1 - q : q;
-    if (sil[x].empty()) continue;
+  auto closeRow = [&](int x) {          // uses stg[] of x and of everything before it in the sweep
+    clos[x].clear();
     touched.clear();
     for (auto &pe : sil[x]) {
       const int y = pe.first; const double w = pe.second;
@@ -607,8 +611,30 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pair
     std::sort(touched.begin(), touched.end());
     clos[x].reserve(touched.size());
     for (int a : touched) { clos[x].push_back({a, acc[a]}); acc[a] = -INFINITY; }
-    nPairs += (long long)touched.size();
-    if (nPairs > pairCap) return false;
+    return (long long)clos[x].size();
+  };
+  if (!adaptive) {
+    for (int q = 0; q < S; ++q) {
+      const int x = backward ? S - 1 - q : q;
+      if (sil[x].empty()) continue;
+      nPairs += closeRow(x);
+      if (nPairs > pairCap) return false;
+    }
+  } else {
+    const std::vector<int> &levOff = backward ? m->levBOff : m->levFOff, &levState = backward ? m->levBState : m->levFState;
+    int cur = 1; long long inStage = 0;
+    for (int L = 1; L < nLev; ++L) {
+      long long cands = 0;
+      for (int k = levOff[L]; k < levOff[L + 1]; ++k) { const int x = levState[k]; stg[x] = cur; cands += closeRow(x) + (isBase[x] ? 1 : 0); }
+      if (inStage > 0 && inStage + cands > budget) {       // the level opens a new stage: its rows are its direct predecessors
+        ++cur; inStage = 0; cands = 0;
+        for (int k = levOff[L]; k < levOff[L + 1]; ++k) { const int x = levState[k]; stg[x] = cur; cands += closeRow(x) + (isBase[x] ? 1 : 0); }
+      }
+      inStage += cands;
+      nPairs += cands;
+      if (nPairs > pairCap) return false;
+    }
+    K = cur;
   }
   for (int x = 0; x < S; ++x) {
     if (isBase[x]) nodes.push_back(WNode{eslot[x] >= 0 ? EXTRA(eslot[x]) : CUR(x), 0, emitC[x], {}});
@@ -643,7 +669,8 @@ static bool up_w(T *&d, const std::vector<T> &h) {
 }
 
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {
-  const int keepStages = P.ok ? P.stages : -1;     // a weight refresh keeps the shape that was chosen
+  const bool haveShape = P.ok;                     // a weight refresh keeps the shape that was chosen
+  const int keepStages = P.stages;
   wide_free(P);
   P.backward = backward; P.viterbi = viterbi;
   P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);      // 509 states: 48 G cells/s with 1024 lanes, 35 with 256
@@ -665,14 +692,18 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   };
   if (viterbi) consider(0);
   else {
-    const int forced = keepStages >= 0 ? keepStages : env_int_w("MB_WIDE_CLOSURE_STAGES", -1);
-    if (forced >= 0) consider(forced);
+    // MB_WIDE_CLOSURE_STAGES: K >= 0 uniform level groups (0 = levelled); -n = adaptive stages of at most n slots of candidates
+    const int envK = env_int_w("MB_WIDE_CLOSURE_STAGES", -1000000);
+    if (haveShape) consider(keepStages);
+    else if (envK > -1000000) consider(envK >= 0 ? envK : envK * P.W);
     else {
       consider(0);
       for (int K = std::max(1, nLev - 1); K >= 1; K = (K * 2) / 3) {
         if (!consider(K)) break;
         if (K == 1) break;
       }
+      if (env_int_w("MB_WIDE_ADAPTIVE_STAGES", 1))
+        for (int q = 2; q <= 32; q += (q < 12 ? 1 : (q < 20 ? 2 : 4))) consider(-(q * P.W) / 4);      // 0.5 ... 8 slots of candidates per stage
     }
   }
   if (best >= 1e300) { set_error("wide program: no feasible shape"); return false; }
@@ -729,7 +760,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.ok = true; P.dirty = false;
   if (verbose)
     fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column (%lld candidates = %.0f %% of the lane slots), %zu records, vectors %zu bytes\n",
-            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK, P.rounds.size(), P.slotsPerColumn, P.nSync, P.candsPerColumn,
+            backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK ? bestStages - 1 : 0, P.rounds.size(), P.slotsPerColumn, P.nSync, P.candsPerColumn,
             100.0 * (double)P.candsPerColumn / (double)std::max<long long>(1, P.slotsPerColumn * P.W), nRecs, P.vecBytes());
   return true;
 }
