@@ -30,6 +30,7 @@ namespace mb {
 static constexpr double W_NEG_BIG = -1e300;       // finite stand-in for -inf in the running maximum (avoids inf - inf)
 static constexpr uint32_t W_IDX_MASK = 0x03ffffffu;
 static constexpr uint32_t W_NO_DST = 0x03ffffffu;
+static constexpr long long WIDE_STAGES_DP = 1ll << 30;      // wide_nodes(K = -WIDE_STAGES_DP): stage boundaries by dynamic programming
 static const size_t WIDE_LDS_MAX = 160 * 1024;
 
 // ------------------------------------------------------------------------------------------------------------
@@ -539,7 +540,7 @@ static bool wide_linearise32(WideProgram &P, int nTok, bool hyb, std::vector<Wid
 }
 
 // nodes of the program for K closure stages (K = 0: levelled)
-static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pairCap, std::vector<WNode> &nodes, int &nExtra,
+static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long long pairCap, std::vector<WNode> &nodes, int &nExtra,
                        int &nStages, long long &nPairs) {
   const int S = m->S, nOut = m->nOut;
   const std::vector<int> &lev = backward ? m->levB : m->levF;
@@ -622,19 +623,57 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, long long pair
     }
   } else {
     const std::vector<int> &levOff = backward ? m->levBOff : m->levFOff, &levState = backward ? m->levBState : m->levFState;
-    int cur = 1; long long inStage = 0;
-    for (int L = 1; L < nLev; ++L) {
+    auto closeLevel = [&](int L, int stage) {
       long long cands = 0;
-      for (int k = levOff[L]; k < levOff[L + 1]; ++k) { const int x = levState[k]; stg[x] = cur; cands += closeRow(x) + (isBase[x] ? 1 : 0); }
-      if (inStage > 0 && inStage + cands > budget) {       // the level opens a new stage: its rows are its direct predecessors
-        ++cur; inStage = 0; cands = 0;
-        for (int k = levOff[L]; k < levOff[L + 1]; ++k) { const int x = levState[k]; stg[x] = cur; cands += closeRow(x) + (isBase[x] ? 1 : 0); }
+      for (int k = levOff[L]; k < levOff[L + 1]; ++k) { const int x = levState[k]; stg[x] = stage; cands += closeRow(x) + (isBase[x] ? 1 : 0); }
+      return cands;
+    };
+    std::vector<int> startOf;          // first level of every stage, ascending
+    if (budget == WIDE_STAGES_DP) {
+      // Optimal cut of the levels into stages under the planner's cost (slots of ~80 % filled lanes + one round per stage):
+      // the rows of a stage depend on its first level only, so for every possible first level a the stage is grown level by
+      // level once, and best[b] = min over a of best[a] + cost(levels a..b-1).
+      const double cStage = 115.0, cSlotDp = 60.0, fill = 0.8 * W;
+      const long long cap = 16ll * W;
+      std::vector<double> best(nLev + 1, 1e300);
+      std::vector<int> from(nLev + 1, -1);
+      for (int x = 0; x < S; ++x) stg[x] = lev[x];          // every level its own stage: "earlier" == lower level
+      best[1] = 0.0;
+      for (int a = 1; a < nLev; ++a) {
+        if (best[a] >= 1e300) continue;
+        long long cum = 0; int L = a;
+        for (; L < nLev; ++L) {
+          cum += closeLevel(L, a);
+          const double c = best[a] + std::ceil((double)cum / fill) * cSlotDp + cStage;
+          if (c < best[L + 1]) { best[L + 1] = c; from[L + 1] = a; }
+          if (cum > cap) { ++L; break; }
+        }
+        for (int l = a; l < L && l < nLev; ++l)
+          for (int k = levOff[l]; k < levOff[l + 1]; ++k) stg[levState[k]] = l;
       }
-      inStage += cands;
-      nPairs += cands;
-      if (nPairs > pairCap) return false;
+      for (int b = nLev; b > 1; b = from[b]) { if (from[b] < 1) return false; startOf.push_back(from[b]); }
+      std::reverse(startOf.begin(), startOf.end());
+      int cur = 0; size_t nxt = 0;
+      for (int L = 1; L < nLev; ++L) {
+        if (nxt < startOf.size() && startOf[nxt] == L) { ++cur; ++nxt; }
+        nPairs += closeLevel(L, cur);
+        if (nPairs > pairCap) return false;
+      }
+      K = std::max(cur, 1);
+    } else {
+      int cur = 1; long long inStage = 0;
+      for (int L = 1; L < nLev; ++L) {
+        long long cands = closeLevel(L, cur);
+        if (inStage > 0 && inStage + cands > budget) {       // the level opens a new stage: its rows are its direct predecessors
+          ++cur; inStage = 0;
+          cands = closeLevel(L, cur);
+        }
+        inStage += cands;
+        nPairs += cands;
+        if (nPairs > pairCap) return false;
+      }
+      K = cur;
     }
-    K = cur;
   }
   for (int x = 0; x < S; ++x) {
     if (isBase[x]) nodes.push_back(WNode{eslot[x] >= 0 ? EXTRA(eslot[x]) : CUR(x), 0, emitC[x], {}});
@@ -684,7 +723,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   double best = 1e300;
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   auto consider = [&](int K) {
-    if (!wide_nodes(m, backward, K, pairCap, nodes, nExtra, nStages, nPairs)) return false;
+    if (!wide_nodes(m, backward, K, P.W, pairCap, nodes, nExtra, nStages, nPairs)) return false;
     const double c = wide_plan(nodes, nStages, m->nOut + 1, P.W, false, nullptr);
     if (verbose) fprintf(stderr, "[mbhip] wide %s program, closure stages %d: modelled %.0f cycles per column (%lld pairs)\n", backward ? "backward" : "forward", K, c, nPairs);
     if (c < best) { best = c; bestNodes.swap(nodes); bestExtra = nExtra; bestStages = nStages; bestK = K; bestPairs = nPairs; }
@@ -695,13 +734,14 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     // MB_WIDE_CLOSURE_STAGES: K >= 0 uniform level groups (0 = levelled); -n = adaptive stages of at most n slots of candidates
     const int envK = env_int_w("MB_WIDE_CLOSURE_STAGES", -1000000);
     if (haveShape) consider(keepStages);
-    else if (envK > -1000000) consider(envK >= 0 ? envK : envK * P.W);
+    else if (envK > -1000000) consider(envK >= 0 ? envK : (envK == -999 ? -(int)WIDE_STAGES_DP : envK * P.W));
     else {
       consider(0);
       for (int K = std::max(1, nLev - 1); K >= 1; K = (K * 2) / 3) {
         if (!consider(K)) break;
         if (K == 1) break;
       }
+      if (env_int_w("MB_WIDE_ADAPTIVE_STAGES", 1)) consider(-(int)WIDE_STAGES_DP);
       if (env_int_w("MB_WIDE_ADAPTIVE_STAGES", 1))
         for (int q = 2; q <= 32; q += (q < 12 ? 1 : (q < 20 ? 2 : 4))) consider(-(q * P.W) / 4);      // 0.5 ... 8 slots of candidates per stage
     }

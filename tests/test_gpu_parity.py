@@ -826,14 +826,14 @@ def _profile_machine(nodes):
     return m, EvaluatedMachine.fromMachine(m, None, useDefaults=True)
 
 
-@pytest.mark.parametrize("stages", [None, 0, 1, 3, 40, -2])
+@pytest.mark.parametrize("stages", [None, 0, 1, 3, 40, -2, -999])
 def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     """BASELINE config 5 at test size: a 3-node profile composed with simple_introns . translate . dnapsw (762 states,
     one tape) through the one-tape kernel family -- Forward / Backward matrices, rolling log-likelihood, bit-exact Viterbi
     matrix and path, posterior counts -- for the levelled program and several closure groupings, LDS and L2 vectors."""
     m, em = _profile_machine(3)
     assert em.nInTok == 0 and em.nStates >= 256
-    if stages is not None:                              # None: the planner's own choice; -2: adaptive stages of <= 2 slots
+    if stages is not None:                              # None: the planner's own choice; -2: adaptive stages of <= 2 slots; -999: stage cuts by dynamic programming
         monkeypatch.setenv("MB_WIDE_CLOSURE_STAGES", str(stages))
     if stages == 3:
         monkeypatch.setenv("MB_WIDE_GLOBAL_VECTORS", "1")
