@@ -844,7 +844,7 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     if stages in (None, 1, 40):
         monkeypatch.setenv("MB_WIDE_FP32", "1")       # the fp32-relative log-sum-exp kernel (default only when fp64 columns exceed the LDS)
     om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
-    rng = np.random.RandomState(11 + (stages or 0))
+    rng = np.random.RandomState(11 + abs(stages or 0))
     x = np.zeros(0, np.int32)
     ys = [rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (41, 0, 1, 17)]
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
