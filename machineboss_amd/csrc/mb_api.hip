@@ -215,25 +215,67 @@ static FastState *fast_state(mb_machine *m) {
         for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + (ri.sync ? 6 : 0);
         return c;
       };
-      auto choose = [&](bool backward) {
+      // Beyond even level groups: explicit stage boundaries, grown greedily -- the cut that lowers the cost most is added
+      // until none does (protpsw.translate.dnapsw, 22 levels: even K = 3 costs 86 slots, cuts at levels 7 and 14 cost 73;
+      // psw2dna Backward: 96 -> 80 with one cut at level 2).  Returns K (0 = levelled) and fills `cuts` when cuts win.
+      auto choose = [&](bool backward, std::vector<int> &cuts) {
+        cuts.clear();
         int bestK = 0; long long best = -1;
         const int forced = env_int("MB_MEDIUM_CLOSURE_STAGES", -1);
         if (forced >= 0) return forced;
         if (!wantClosure) return 0;
         const int nLev = backward ? m->nLevB : m->nLevF;
-        for (int K = 0; K <= std::min(std::max(nLev - 1, 1), 12); ++K) {
+        const bool verbose = getenv("MB_MEDIUM_JIT_VERBOSE") != nullptr;
+        auto tryBuild = [&](int K, const std::vector<int> &cs, long long &c) {
           MedProgram P; MedGeom g;
-          if (!medium_build_host(m, backward, K, G, P, g)) continue;
-          if (K && P.nPairs > 16 * nSilent + 4 * m->S) continue;      // record tables would not stay cache-resident
-          const long long c = cost(P);
-          if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] %s program, closure stages %d: cost %lld (pairs %d)\n", backward ? "backward" : "forward", K, c, P.nPairs);
+          medium_set_cuts(cs);
+          const bool ok = medium_build_host(m, backward, K, G, P, g);
+          medium_set_cuts({});
+          if (!ok) return false;
+          if (K && P.nPairs > 16 * nSilent + 4 * m->S) return false;      // record tables would not stay cache-resident
+          c = cost(P);
+          return true;
+        };
+        for (int K = 0; K <= std::min(std::max(nLev - 1, 1), 12); ++K) {
+          long long c;
+          if (!tryBuild(K, {}, c)) continue;
+          if (verbose) fprintf(stderr, "[mbhip] %s program, closure stages %d: cost %lld\n", backward ? "backward" : "forward", K, c);
           if (best < 0 || c < best) { best = c; bestK = K; }
+        }
+        if (env_int("MB_MEDIUM_CUTS_SEARCH", 1) && nLev > 2 && !getenv("MB_MEDIUM_CUTS")) {
+          std::vector<int> cur;
+          long long curCost;
+          if (tryBuild(1, {}, curCost)) {
+            const int step = std::max(1, (nLev - 2 + 31) / 32);
+            for (int it = 0; it < 6; ++it) {
+              int bestCut = -1; long long bestC = curCost;
+              for (int c = 2; c < nLev; c += step) {
+                if (std::find(cur.begin(), cur.end(), c) != cur.end()) continue;
+                std::vector<int> t = cur; t.push_back(c);
+                long long cc;
+                if (tryBuild(1, t, cc) && cc < bestC) { bestC = cc; bestCut = c; }
+              }
+              if (bestCut < 0) break;
+              cur.push_back(bestCut); curCost = bestC;
+            }
+            std::sort(cur.begin(), cur.end());
+            if (verbose) { fprintf(stderr, "[mbhip] %s program, stage cuts at levels", backward ? "backward" : "forward"); for (int c : cur) fprintf(stderr, " %d", c); fprintf(stderr, ": cost %lld (even groups: %lld)\n", curCost, best); }
+            if (!cur.empty() && (best < 0 || curCost < best)) { cuts = cur; return (int)cur.size() + 1; }
+          }
         }
         return bestK;
       };
+      auto buildWith = [&](bool backward, MedProgram &P, MedGeom &geo) {
+        std::vector<int> cuts;
+        const int K = choose(backward, cuts);
+        medium_set_cuts(cuts);
+        const bool okb = medium_build(m, backward, K, G, P, geo);
+        medium_set_cuts({});
+        return okb;
+      };
       bool ok = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
-      if (ok) ok = medium_build(m, false, choose(false), G, f->fwdSum, f->geoFS);
-      if (ok) ok = medium_build(m, true, choose(true), G, f->bwdSum, f->geoBS);
+      if (ok) ok = buildWith(false, f->fwdSum, f->geoFS);
+      if (ok) ok = buildWith(true, f->bwdSum, f->geoBS);
       f->mediumOk = ok;
       f->exactOk = ok;
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
@@ -759,6 +801,11 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   if (mode == MED_MODE_COUNT) {
     if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
+  if (getenv("MB_MEDIUM_JIT_VERBOSE")) {
+    long long c = 0; int syncs = 0;
+    for (const MedRoundInfo &ri : P.roundInfo) { c += (long long)ri.slots.size() + (ri.sync ? 6 : 0); syncs += ri.sync; }
+    fprintf(stderr, "[mbhip] program cost %lld (rounds %zu, syncs %d, pairs %d, levels %d)\n", c, P.roundInfo.size(), syncs, P.nPairs, backward ? m.nLevB : m.nLevF);
+  }
   const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD), true);
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }

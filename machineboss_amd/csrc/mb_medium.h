@@ -120,6 +120,8 @@ long long medium_jit_spill_count(const std::string &codeObject);
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo);
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool materialise);
 void medium_free(MedProgram &P);
+// stage boundaries of the next closure programs built (first silent level of stages 2, 3, ...); empty = even level groups
+void medium_set_cuts(const std::vector<int> &cuts);
 bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,

@@ -363,6 +363,9 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
 // ------------------------------------------------------------------------------------------------------------
 struct Cand { int src; int wref; };   // src: index into the LDS state vector; wref: see MedProgram::wref
 
+std::vector<int> g_medium_cuts;
+void medium_set_cuts(const std::vector<int> &cuts) { g_medium_cuts = cuts; }
+
 static int env_int_m(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -435,10 +438,20 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
     P.isBase.assign(S, 0);
     for (int s = 0; s < S; ++s) P.isBase[s] = (emitDeg[s][0] || emitDeg[s][1] || emitDeg[s][2] || s == startNode) ? 1 : 0;
     // stage of a state: 0 = no silent predecessor (its value is its emit part), else the group of its silent level
-    const int K = std::max(1, std::min(closure, std::max(1, nLev - 1)));
+    int K = std::max(1, std::min(closure, std::max(1, nLev - 1)));
     P.stageOf.assign(S, 0);
     for (int s = 0; s < S; ++s)
       if (lev[s] > 0) P.stageOf[s] = 1 + (int)(((long long)(lev[s] - 1) * K) / std::max(1, nLev - 1));
+    // explicit stage boundaries (first silent level of stages 2, 3, ...): set by the chooser (medium_set_cuts) or
+    // MB_MEDIUM_CUTS="l1,l2,..." for experiments; levels need not be cut evenly -- a cut belongs where the closure is cheap
+    std::vector<int> cuts = g_medium_cuts;
+    if (const char *e = getenv("MB_MEDIUM_CUTS")) { cuts.clear(); for (const char *q = e; *q;) { cuts.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (!cuts.empty()) {
+      std::sort(cuts.begin(), cuts.end());
+      for (int s = 0; s < S; ++s)
+        if (lev[s] > 0) { int st = 1; for (int c : cuts) if (lev[s] >= c) ++st; P.stageOf[s] = st; }
+      K = (int)cuts.size() + 1;
+    }
     const std::vector<int> &stg = P.stageOf;
     // closure structure: ancestors through silent paths whose intermediate states lie in the node's own stage, in
     // topological order.  An ancestor is either final already (earlier stage) or an emit-fed state of the same stage
