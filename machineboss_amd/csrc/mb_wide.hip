@@ -12,10 +12,15 @@
 //   * a state is finalised by a GROUP of 1..64 lanes: each lane folds every g-th candidate of the state, the group is
 //     reduced with wavefront shuffles (max, or max + sum of exp in the log-sum-exp semiring), the first lane stores;
 //     group sizes are chosen per stage so that the candidates of the stage spread over all lanes of the workgroup;
-//   * Forward / Backward: the silent levels are grouped into K stages, each closed transitively on the host (the same
-//     construction as the tiled family, mb_medium.hip), K picked by a cost model -- one __syncthreads() per stage
-//     instead of one per level;  Viterbi: level by level, one rounded add per edge, bit-identical to the reference.
-//   * candidate records are streamed from L2 ([slot][lane] order: one coalesced 16-byte load per lane and slot).
+//   * Forward / Backward: the silent levels are grouped into stages, each closed transitively on the host (the same
+//     construction as the tiled family, mb_medium.hip) -- one __syncthreads() per stage instead of one per level.  Stage
+//     boundaries are adaptive (levels join a stage while its closure stays within a budget of candidates: the thin runs
+//     of a profile's delete chain end up in few stages), the shape is picked by a cost model fitted on the box.
+//     Viterbi: level by level, one rounded add per edge, bit-identical to the reference; stages that fit the first
+//     wavefront follow each other without a barrier.
+//   * candidate records are streamed from L2 ([slot][lane] order: one coalesced load per lane and slot, 8 slots ahead).
+//   * log-sum-exp sweeps of machines whose fp64 columns exceed the LDS run in fp32 relative to a per-column fp64
+//     reference (k_wide_sum32), current column in LDS, previous one in L2 if need be.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -320,18 +325,14 @@ int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
 // lane groups and rounds of one stage: returns the modelled cost (cycles), appends to P when `emit`
-struct StagePlan { int dstar; double cost; };
-double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W, bool emit, WideProgram *P, int *nExtraDummy) {
-  (void)nExtraDummy;
+double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W, bool emit, WideProgram *P) {
   const int n = (int)nodes.size();
   if (!n) return 0.0;
   std::vector<int> len(n);
   int maxLen = 1;
-  bool anyT2 = false;
   for (int i = 0; i < n; ++i) {
     int t2 = 0;
     for (const auto &l : nodes[i]->t2) t2 = std::max(t2, (int)l.size());
-    if (t2) anyT2 = true;
     len[i] = std::max(1, t2 + (int)nodes[i]->t3.size());
     maxLen = std::max(maxLen, len[i]);
   }
@@ -398,7 +399,6 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
   }
   P->rounds.back().sync = 1;
   P->nSync++;
-  (void)anyT2;
   return best;
 }
 }  // namespace
@@ -695,7 +695,7 @@ static double wide_plan(const std::vector<WNode> &nodes, int nStages, int nTok, 
   std::vector<std::vector<const WNode *>> byStage(nStages + 1);
   for (const WNode &n : nodes) byStage[std::min(n.stage, nStages)].push_back(&n);
   double cost = 0.0;
-  for (auto &v : byStage) cost += plan_stage(v, nTok, W, emit, P, nullptr);
+  for (auto &v : byStage) cost += plan_stage(v, nTok, W, emit, P);
   return cost;
 }
 
