@@ -946,3 +946,13 @@ def test_one_tape_family_long_sequences(capi, monkeypatch, fp32):
     a, g = res[capi.KERNEL_AUTO], res[capi.KERNEL_GENERIC]
     assert close(a[0], g[0], 1e-6) and close(a[1], g[1], 1e-6) and close(a[0], a[1], 1e-9, 1e-12)
     assert np.array_equal(a[2][0], g[2][0]) and np.array_equal(a[2][1], g[2][1]) and np.array_equal(a[2][2], g[2][2])
+
+
+def test_randomised_sweep(capi):
+    """scripts/fuzz_gpu.py at a size for the suite: random two-tape and one-tape machines (duplicate edges, -inf weights,
+    uneven silent levels, 1 to 900 states), ragged batches, automatically chosen family against the generic family and the
+    oracle -- fills, rolling log-likelihoods, Viterbi paths, counts.  (250 cases were run by hand in round 1: 0 mismatches.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_gpu.py"), "24", "4242"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "24 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
