@@ -326,7 +326,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
     g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : (W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>");
-    return wide_fill(m, *W, d_desc, (long long)hp.size(), d_out, pool, nullptr, g_stream);
+    return wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream);
   }
   if (!env && (use_medium(m) || tiledViterbi)) {
     FastState *f = fast_state(m);
@@ -535,7 +535,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     if (!W) rc = 1;
     else {
       tm.start();
-      rc = wide_fill(m, *W, b->d_pairs, b->nPairs, b->d_out, nullptr, d_ll, g_stream);
+      rc = wide_fill(m, *W, b->d_pairs, b->nPairs, m->nOut ? b->d_out : b->d_in, nullptr, d_ll, g_stream);
       g_last_kernel = W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;

@@ -38,6 +38,7 @@ struct WideDev {
   int S, NV, NX, W;
   int resultIdx;       // state whose value in the last column is the log-likelihood
   int backward;
+  int inputTape;       // 1: the machine is a recogniser, the column index is the input position
 };
 
 // Forward / Backward (log-sum-exp) run in single precision RELATIVE TO A PER-COLUMN fp64 REFERENCE: a column's vector
@@ -54,6 +55,7 @@ struct WideDev32 {
   int nA, nB;
   int S, NV, NX, W;
   int resultIdx, backward;
+  int inputTape;
 };
 
 struct WideProgram {
@@ -81,14 +83,15 @@ struct WideProgram {
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };
 
-// which machines this family takes: one-tape generators (no input alphabet) with enough states to fill a workgroup
+// which machines this family takes: one-tape machines (generators: no input alphabet; recognisers: no output alphabet)
+// with enough states to fill a workgroup
 bool wide_applicable(const mb_machine *m);
 // (re)build the program of one direction/semiring from the machine's current weights and upload it
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P);
 void wide_free(WideProgram &P);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
-int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool,
+int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st);
 
 }  // namespace mb

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
   extern __shared__ double wlds[];
   const PairDesc pd = pairs[blockIdx.x];
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
-  const int outLen = pd.outLen, nA = P.nA, n = P.nA + P.nB;
+  const int outLen = P.inputTape ? pd.inLen : pd.outLen, nA = P.nA, n = P.nA + P.nB;   // the one tape the machine has
   double *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wlds;
   for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
   __syncthreads();
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
   __syncthreads();
   int prevOff = 0, curOff = NV;
   const int extraOff = 2 * NV;
-  const int *out = outTok + pd.outBase;
+  const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
   double *cells = pool ? pool + pd.cellBase : nullptr;
   auto tokOf = [&](int c) -> int {                  // output token the column c of the sweep consumes
     if (c > outLen) return 0;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
   __shared__ float wmax[16];
   const PairDesc pd = pairs[blockIdx.x];
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
-  const int outLen = pd.outLen, nA = P.nA, n = P.nA + P.nB;
+  const int outLen = P.inputTape ? pd.inLen : pd.outLen, nA = P.nA, n = P.nA + P.nB;   // the one tape the machine has
   float *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wldsf;
   float *Pg = HYB ? scratch + (size_t)blockIdx.x * (size_t)NV : nullptr;
   for (int k = tid; k < (HYB ? NV + P.NX : 2 * NV + P.NX); k += W) V[k] = -INFINITY;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
   if (tid == 0) (HYB ? Pg : V)[S + 1] = 0.0f;       // the seed, read by the first column only
   __syncthreads();
   const int extraOff = HYB ? NV : 2 * NV;
-  const int *out = outTok + pd.outBase;
+  const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
   double *cells = pool ? pool + pd.cellBase : nullptr;
   auto tokOf = [&](int c) -> int {
     if (c > outLen) return 0;
@@ -404,7 +404,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
 }  // namespace
 
 bool wide_applicable(const mb_machine *m) {
-  if (m->nIn != 0 || m->nOut <= 0) return false;
+  if ((m->nIn != 0) == (m->nOut != 0)) return false;      // exactly one tape: a generator (outputs only) or a recogniser (inputs only)
   if (!env_int_w("MB_WIDE", 1)) return false;
   return m->S >= env_int_w("MB_WIDE_MIN_STATES", 256) && m->S < (1 << 26);
 }
@@ -542,7 +542,7 @@ static bool wide_linearise32(WideProgram &P, int nTok, bool hyb, std::vector<Wid
 // nodes of the program for K closure stages (K = 0: levelled)
 static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long long pairCap, std::vector<WNode> &nodes, int &nExtra,
                        int &nStages, long long &nPairs) {
-  const int S = m->S, nOut = m->nOut;
+  const int S = m->S, nOut = m->nOut ? m->nOut : m->nIn;     // the alphabet of the machine's one tape
   const std::vector<int> &lev = backward ? m->levB : m->levF;
   const int nLev = backward ? m->nLevB : m->nLevF;
   const std::vector<int> &off = backward ? m->outOff : m->inOff;
@@ -554,7 +554,7 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long lo
   std::vector<std::vector<std::pair<int, double>>> sil(S);
   for (int x = 0; x < S; ++x)
     for (int tok = 0; tok <= nOut; ++tok) {
-      const long long rw = (long long)x * (nOut + 1) + tok;      // nIn = 0: row = (state * 1 + 0) * (nOut + 1) + tok
+      const long long rw = (long long)x * (nOut + 1) + tok;      // row = (state * (nIn+1) + inTok) * (nOut+1) + outTok with one of the alphabets empty
       for (int a = off[rw]; a < off[rw + 1]; ++a) {
         const uint32_t e = perm[a];
         const int y = other(e);
@@ -724,7 +724,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   auto consider = [&](int K) {
     if (!wide_nodes(m, backward, K, P.W, pairCap, nodes, nExtra, nStages, nPairs)) return false;
-    const double c = wide_plan(nodes, nStages, m->nOut + 1, P.W, false, nullptr);
+    const double c = wide_plan(nodes, nStages, (m->nOut ? m->nOut : m->nIn) + 1, P.W, false, nullptr);
     if (verbose) fprintf(stderr, "[mbhip] wide %s program, closure stages %d: modelled %.0f cycles per column (%lld pairs)\n", backward ? "backward" : "forward", K, c, nPairs);
     if (c < best) { best = c; bestNodes.swap(nodes); bestExtra = nExtra; bestStages = nStages; bestK = K; bestPairs = nPairs; }
     return true;
@@ -750,7 +750,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.stages = bestK; P.nPairs = bestPairs;
   P.NV = S + 2; P.NX = bestExtra + 1;
   P.dev.S = S;
-  wide_plan(bestNodes, bestStages, m->nOut + 1, P.W, true, &P);
+  wide_plan(bestNodes, bestStages, (m->nOut ? m->nOut : m->nIn) + 1, P.W, true, &P);
   if (P.rounds.empty()) { set_error("wide program: empty machine"); return false; }
   // Runs of thin levels (a profile's delete chain: 2-20 states per level, hundreds of levels): when a stage and the next
   // one each fit the first wavefront, the LDS pipeline already orders that wavefront's store before its next read, so
@@ -776,18 +776,18 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     const bool fits2 = (size_t)(2 * P.NV + P.NX) * sizeof(float) <= lds32;
     const int wantHyb = env_int_w("MB_WIDE_HYBRID", -1);
     P.hyb = (wantHyb > 0 || (wantHyb < 0 && !fits2)) && (size_t)(P.NV + P.NX) * sizeof(float) <= lds32 &&
-            wide_linearise32(P, m->nOut + 1, true, a32, b32, fw);
-    if (P.hyb || wide_linearise32(P, m->nOut + 1, false, a32, b32, fw)) {
+            wide_linearise32(P, (m->nOut ? m->nOut : m->nIn) + 1, true, a32, b32, fw);
+    if (P.hyb || wide_linearise32(P, (m->nOut ? m->nOut : m->nIn) + 1, false, a32, b32, fw)) {
       if (!up_w(P.d_seg32A, a32) || !up_w(P.d_seg32B, b32) || !up_w(P.d_flags, fw)) return false;
       P.f32 = true;
       nRecs = a32.size() + b32.size();
       P.dev32.segA = P.d_seg32A; P.dev32.segB = P.d_seg32B; P.dev32.flags = P.d_flags;
       P.dev32.S = S; P.dev32.NV = P.NV; P.dev32.NX = P.NX; P.dev32.W = P.W;
-      P.dev32.resultIdx = backward ? 0 : S - 1; P.dev32.backward = backward ? 1 : 0;
+      P.dev32.resultIdx = backward ? 0 : S - 1; P.dev32.backward = backward ? 1 : 0; P.dev32.inputTape = m->nOut ? 0 : 1;
     }
   }
   if (!P.f32) {
-    wide_linearise(P, m->nOut + 1);
+    wide_linearise(P, (m->nOut ? m->nOut : m->nIn) + 1);
     if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
     nRecs = P.segA.size() + P.segB.size();
   }
@@ -797,6 +797,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   std::vector<WideRec>().swap(P.segA); std::vector<WideRec>().swap(P.segB);
   P.dev.resultIdx = backward ? 0 : S - 1;
   P.dev.backward = backward ? 1 : 0;
+  P.dev.inputTape = m->nOut ? 0 : 1;
   P.ok = true; P.dirty = false;
   if (verbose)
     fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column (%lld candidates = %.0f %% of the lane slots), %zu records, vectors %zu bytes\n",
@@ -834,9 +835,10 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
   return 0;
 }
 
-int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool,
+int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st) {
   (void)m;
+  const int *d_out = d_tape;       // the token array of the machine's one tape (outputs of a generator, inputs of a recogniser)
   if (!P.ok) { set_error("wide program not built"); return 1; }
   if (nPairs <= 0) return 0;
   if (P.f32) {

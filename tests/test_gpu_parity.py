@@ -879,15 +879,20 @@ def test_one_tape_family_small_machines(capi, oracle_mod, monkeypatch):
         {"id": "A", "trans": [{"to": "A", "out": "x", "weight": 0.5}, {"to": "B", "out": "y", "weight": 0.3}, {"to": "E", "weight": 0.2}]},
         {"id": "B", "trans": [{"to": "A", "out": "y", "weight": 0.6}, {"to": "B", "out": "x", "weight": 0.1}, {"to": "E", "weight": 0.3}]},
         {"id": "E"}]})
-    em = EvaluatedMachine.fromMachine(gen, {})
-    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
-    x = np.zeros(0, np.int32)
-    for ol in (0, 1, 23):
-        y = np.random.RandomState(ol).randint(1, 3, size=ol).astype(np.int32)
-        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
-        assert capi.last_kernel_name().startswith("k_wide_sweep")
-        assert np.array_equal(V, om.viterbi(x, y))
-        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+    # the same machine as a recogniser: its one tape is the input
+    rec = Machine.fromJson(json.loads(json.dumps({"state": [{"id": st.name, "trans": [dict(to=t.dest, weight=t.weight, **({"in": t.out} if t.out else {})) for t in st.trans]} for st in gen.state]})))
+    for mach, tape in ((gen, 1), (rec, 0)):
+        em = EvaluatedMachine.fromMachine(mach, {})
+        om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+        for ol in (0, 1, 23):
+            seq = np.random.RandomState(ol).randint(1, 3, size=ol).astype(np.int32)
+            x, y = (np.zeros(0, np.int32), seq) if tape else (seq, np.zeros(0, np.int32))
+            V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+            assert capi.last_kernel_name().startswith("k_wide_sweep")
+            assert np.array_equal(V, om.viterbi(x, y))
+            assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+            b = capi.DeviceBatch.from_pairs(dm, [(x, y)] * 2)
+            assert close(b.forward(capi.MB_ROLLING), [F[-1, -1, -1]] * 2, 1e-9, 1e-12)
 
 
 def test_boss_cli_hmmer_generator(capi, oracle_mod):
