@@ -164,6 +164,12 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
                         const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
                         int mode, int backward, int closure, int G, const char *path);
 
+/* The same for the small-machine family (machines of <= 16 states: lane = column, states in registers); mode 0 = sum
+ * semiring, 1 = max with fp64 cells, 2 = max with one traceback byte per cell, 3 = Forward fused with posterior counts. */
+int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
+                          const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
+                          int mode, int backward, int materialise, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

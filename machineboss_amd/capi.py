@@ -24,7 +24,7 @@ EXPORTS = [
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
-    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source",
+    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
@@ -79,6 +79,8 @@ def load():
     L.mb_fill_env.argtypes = [vp, C.c_int, i32p, C.c_int64, i32p, C.c_int64, C.c_int32, i32p, i32p, dp]
     L.mb_debug_jit_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_debug_small_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
+                                        C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_comm_unique_id.argtypes = [C.c_char_p]
     L.mb_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int]; L.mb_comm_init.restype = vp
     L.mb_comm_destroy.argtypes = [vp]; L.mb_comm_destroy.restype = None
@@ -163,6 +165,17 @@ def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = Fal
     _check(load().mb_debug_jit_source(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
                                       _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
                                       mode, int(backward), int(closure), G, path.encode()))
+
+
+def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, materialise: bool = True):
+    """Write the HIP source of the small-machine family's sweep for this machine (host only, no GPU needed).
+    mode: 0 sum, 1 max (fp64 cells), 2 max (traceback bytes), 3 Forward fused with posterior counts."""
+    a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+         np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+         np.ascontiguousarray(em.logWeight, np.float64)]
+    _check(load().mb_debug_small_source(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                        _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
+                                        mode, int(backward), int(materialise), path.encode()))
 
 
 class DeviceMachine:

@@ -6,11 +6,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "mb_internal.h"
 #include "mb_medium.h"
+#include "mb_small.h"
 #include "mb_wide.h"
 
 namespace mb {
@@ -46,17 +48,42 @@ static int ensure_init() {
 
 // Grow-only device workspaces, kept across calls so that steady-state batch calls do no hipMalloc/hipFree
 // (a 200 GB hipMalloc costs far more than the kernels it feeds).  Slot 0/1: matrix pools, 2: halo columns.
-struct Workspace { void *p = nullptr; size_t bytes = 0; };
-static Workspace g_ws[8];   // 0/1 matrix pools, 2 halo columns, 3/4/5 Viterbi path slots / lengths / edges
+struct Workspace { void *p = nullptr; size_t bytes = 0; bool pinned = false; };
+static const int WS_SLOTS = 16;
+static Workspace g_ws[WS_SLOTS];   // 0/1 matrix pools, 2 halo columns, 3..7 Viterbi path buffers, 8.. small-machine family
 
 static size_t cached_bytes() { size_t t = 0; for (const Workspace &w : g_ws) t += w.bytes; return t; }
 
-static void *ws_get(int slot, size_t bytes) {
+// A slot handed out during the current API call is pinned until the next call begins; growing one slot may release every
+// unpinned one (a Viterbi batch that needs 80 % of HBM in slot 0 must be able to reclaim the Backward pool a previous
+// count sweep left in slot 1 -- budget_bytes() counts cached bytes as available).
+static void ws_begin_call() { for (Workspace &w : g_ws) w.pinned = false; }
+static void ws_release_unpinned(int except) {
+  for (int k = 0; k < WS_SLOTS; ++k) {
+    Workspace &w = g_ws[k];
+    if (k == except || w.pinned || !w.p) continue;
+    (void)hipFree(w.p); w.p = nullptr; w.bytes = 0;
+  }
+}
+
+void *ws_get(int slot, size_t bytes) {
   Workspace &w = g_ws[slot];
+  w.pinned = true;
   if (w.bytes >= bytes && w.p) return w.p;
   if (w.p) { (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
-  if (!hip_ok(hipMalloc(&w.p, std::max<size_t>(bytes, 256)), "hipMalloc(workspace)")) { w.p = nullptr; return nullptr; }
-  w.bytes = std::max<size_t>(bytes, 256);
+  const size_t want = std::max<size_t>(bytes, 256);
+  size_t freeB = 0, totalB = 0;
+  // an explicit budget (mb_set_memory_budget) bounds everything the library keeps; otherwise only a shortage evicts
+  const bool over = g_mem_budget && cached_bytes() + want > g_mem_budget;
+  if (over || (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < want + ((size_t)256 << 20))) ws_release_unpinned(slot);
+  hipError_t e = hipMalloc(&w.p, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ws_release_unpinned(slot);
+    e = hipMalloc(&w.p, want);
+  }
+  if (!hip_ok(e, "hipMalloc(workspace)")) { w.p = nullptr; return nullptr; }
+  w.bytes = want;
   return w.p;
 }
 
@@ -97,7 +124,7 @@ static void ws_release() {
   g_smallFree.clear();
 }
 
-static size_t budget_bytes() {
+size_t budget_bytes() {
   if (g_mem_budget) return g_mem_budget;
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return (size_t)8 << 30;
@@ -185,6 +212,9 @@ struct FastState {
   MedGeom geoCnt;
   // large one-tape machines (mb_wide.hip): programs built on first use, rebuilt after a weight update
   WideProgram wFwd, wBwd, wVit;
+  // machines with a handful of states (mb_small.cpp): lane = column, states in registers
+  bool smallTried = false, smallOk = false;
+  SmallProgram smF, smB;
 };
 
 static int env_int(const char *name, int dflt) {
@@ -296,6 +326,19 @@ static FastState *fast_state(mb_machine *m) {
   return f;
 }
 
+// The small-machine family: preferred whenever the machine qualifies (mb_set_kernel: 0 auto, 2 forces it; 1 / 3 skip it).
+static bool use_small(mb_machine *m) {
+  if (g_kernel_choice == 1 || g_kernel_choice == 3) return false;
+  if (!small_eligible(m)) return false;
+  if (!m->fast) m->fast = new FastState();
+  FastState *f = (FastState *)m->fast;
+  if (!f->smallTried) {
+    f->smallTried = true;
+    if (env_int("MB_SMALL", 1)) f->smallOk = small_build(m, false, f->smF) && small_build(m, true, f->smB);
+  }
+  return f->smallOk;
+}
+
 static bool use_medium(mb_machine *m) {
   if (g_kernel_choice == 1) return false;
   FastState *f = fast_state(m);
@@ -341,6 +384,224 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
   return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream,
                              env ? b->d_envStart : nullptr, env ? b->d_envEnd : nullptr);
+}
+
+// ---- the small-machine family (mb_small.cpp): placement of its per-pair buffers and chunking -----------------------------
+struct SmallPlan {
+  std::vector<SmAux> aux;
+  long long poolD = 0, tbB = 0, haloD = 0, boundD = 0;
+};
+
+static void small_plan(const SmallProgram &P, const PairDesc *hp, long long n, bool wantPool, bool wantTb, SmallPlan &pl) {
+  pl = SmallPlan();
+  pl.aux.resize((size_t)n);
+  for (long long k = 0; k < n; ++k) {
+    const PairDesc &pd = hp[k];
+    SmAux &a = pl.aux[(size_t)k];
+    a.pool = pl.poolD; a.tb = pl.tbB; a.halo = pl.haloD; a.bound = pl.boundD;
+    if (wantPool) pl.poolD += small_pair_doubles(P.S, pd.inLen, pd.outLen);
+    if (wantTb) pl.tbB += (small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 15) & ~15ll;
+    pl.haloD += 2ll * (pd.outLen + 1) * std::max(P.H, 1);
+    pl.boundD += (long long)small_strips(pd.inLen) * 64 * P.NBD;
+  }
+}
+
+// Split the batch into chunks whose buffers fit the memory budget (pairs are independent).
+static bool small_chunks_plan(const mb_batch *b, const SmallProgram &P, bool wantPool, bool wantTb, std::vector<Chunk> &out) {
+  const long long budget = (long long)budget_bytes();
+  long long p0 = 0, acc = 0;
+  for (long long p = 0; p < b->nPairs; ++p) {
+    const PairDesc &pd = b->pairs[p];
+    long long c = (2ll * (pd.outLen + 1) * std::max(P.H, 1) + (long long)small_strips(pd.inLen) * 64 * P.NBD) * 8;
+    if (wantPool) c += small_pair_doubles(P.S, pd.inLen, pd.outLen) * 8;
+    if (wantTb) c += small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 16;
+    if (c > budget) { set_error("a single DP matrix (" + std::to_string(c) + " bytes) exceeds the device memory budget"); return false; }
+    if (acc + c > budget) { out.push_back({p0, p, acc}); p0 = p; acc = 0; }
+    acc += c;
+  }
+  if (b->nPairs > p0) out.push_back({p0, b->nPairs, acc});
+  return true;
+}
+
+// buffers of one chunk: aux records uploaded, workspaces sized; fills `sw`
+static int small_prepare(const mb_batch *b, const Chunk &c, const SmallProgram &P, bool wantPool, bool wantTb, SmallPlan &pl,
+                         std::vector<PairDesc> &hp, SmAux **d_aux, SmSweep &sw) {
+  hp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
+  small_plan(P, hp.data(), (long long)hp.size(), wantPool, wantTb, pl);
+  MB_HIP(sm_alloc((void **)d_aux, hp.size() * sizeof(SmAux)));
+  MB_HIP(hipMemcpyAsync(*d_aux, pl.aux.data(), hp.size() * sizeof(SmAux), hipMemcpyHostToDevice, g_stream));
+  sw = SmSweep();
+  sw.d_pairs = b->d_pairs + c.p0; sw.pairs = &hp; sw.d_in = b->d_in; sw.d_out = b->d_out; sw.d_aux = *d_aux;
+  if (wantPool && !(sw.d_pool = (double *)ws_get(0, (size_t)std::max<long long>(pl.poolD, 1) * 8))) return 1;
+  if (wantTb && !(sw.d_tb = (unsigned char *)ws_get(8, (size_t)std::max<long long>(pl.tbB, 16)))) return 1;
+  if (!(sw.d_halo = (double *)ws_get(9, (size_t)std::max<long long>(pl.haloD, 1) * 8))) return 1;
+  if (!(sw.d_bound = (double *)ws_get(10, (size_t)std::max<long long>(pl.boundD, 1) * 8))) return 1;
+  return 0;
+}
+
+static int small_forward(mb_batch *b, int flags, double *loglike) {
+  FastState *f = (FastState *)b->m->fast;
+  const bool mat = !(flags & MB_ROLLING);
+  std::vector<Chunk> chunks;
+  if (!small_chunks_plan(b, f->smF, mat, false, chunks)) return 1;
+  double *d_ll = nullptr;
+  MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
+  int rc = 0;
+  Timer tm;
+  for (const Chunk &c : chunks) {
+    SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
+    if (!(rc = small_prepare(b, c, f->smF, mat, false, pl, hp, &d_aux, sw))) {
+      sw.d_loglike = d_ll + c.p0;
+      tm.start();
+      rc = small_sweep(f->smF, SM_SUM, mat, sw, g_stream);
+      g_last_ms += tm.stop();
+    }
+    sm_free(d_aux);
+    if (rc) break;
+  }
+  g_last_kernel = "k_small_jit";
+  if (!rc && !hip_ok(hipMemcpy(loglike, d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
+  sm_free(d_ll);
+  return rc;
+}
+
+// ViterbiMatrix(eval, sp).logLike() / path(): one traceback byte per cell, walked on the device
+static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
+  FastState *f = (FastState *)b->m->fast;
+  const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
+  std::vector<Chunk> chunks;
+  if (!small_chunks_plan(b, f->smF, false, true, chunks)) return 1;
+  int rc = 0;
+  Timer tm;
+  long long written = 0;
+  for (const Chunk &c : chunks) {
+    const long long np = c.p1 - c.p0;
+    SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
+    double *d_ll = nullptr;
+    std::vector<long long> slot(np + 1, 0), len(np, 0);
+    do {
+      if ((rc = small_prepare(b, c, f->smF, false, true, pl, hp, &d_aux, sw))) break;
+      if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+      sw.d_loglike = d_ll;
+      tm.start();
+      if ((rc = small_sweep(f->smF, SM_TB, false, sw, g_stream))) break;
+      long long *d_slot = nullptr, *d_len = nullptr; uint32_t *d_path = nullptr;
+      if (wantPaths) {
+        for (long long p = 0; p < np; ++p) slot[p + 1] = slot[p] + mb_viterbi_path_bound(b->m, hp[p].inLen, hp[p].outLen);
+        if (!(d_slot = (long long *)ws_get(3, (np + 1) * sizeof(long long)))) { rc = 1; break; }
+        if (!(d_len = (long long *)ws_get(4, np * sizeof(long long)))) { rc = 1; break; }
+        if (!(d_path = (uint32_t *)ws_get(5, std::max<long long>(slot[np], 1) * sizeof(uint32_t)))) { rc = 1; break; }
+        if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
+        if ((rc = launch_small_traceback(f->smF, sw.d_pairs, np, b->d_in, b->d_out, sw.d_tb, d_aux, d_ll, d_slot, d_path, d_len, g_stream))) break;
+      }
+      g_last_ms += tm.stop();
+      if (!hip_ok(hipMemcpy(loglike + c.p0, d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
+      if (wantPaths) {
+        if (!hip_ok(hipMemcpy(len.data(), d_len, np * sizeof(long long), hipMemcpyDeviceToHost), "D2H path lengths")) { rc = 1; break; }
+        std::vector<long long> off(np, -1);
+        long long total = 0;
+        for (long long p = 0; p < np && !rc; ++p) {
+          const long long n = len[p];
+          if (n == -1) continue;   // -inf end cell: no path (src/dpmatrix.defs.h:84)
+          if (n < 0) { set_error("Viterbi traceback exceeded its path bound"); rc = 1; break; }
+          off[p] = total; total += n;
+        }
+        if (rc) break;
+        if (written + total > pathCap) { set_error("pathCap too small for the Viterbi paths of this batch"); rc = 1; break; }
+        long long *d_off = (long long *)ws_get(6, np * sizeof(long long));
+        uint32_t *d_packed = (uint32_t *)ws_get(7, std::max<long long>(total, 1) * sizeof(uint32_t));
+        if (!d_off || !d_packed) { rc = 1; break; }
+        if (!hip_ok(hipMemcpyAsync(d_off, off.data(), np * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
+        if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
+        if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
+        if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
+        for (long long p = 0; p < np; ++p) {
+          if (len[p] > 0) written += len[p];
+          pathOff[c.p0 + p + 1] = written;
+        }
+      }
+    } while (0);
+    sm_free(d_aux); sm_free(d_ll);
+    if (rc) break;
+  }
+  g_last_kernel = "k_small_jit";
+  return rc;
+}
+
+// MachineCounts(eval, seqPairList): Backward matrices written once (tile-major), then a Forward sweep that reads them and
+// keeps the posterior usage sums on chip -- the Forward matrix itself never reaches HBM.
+static const int SMALL_COUNT_REPLICAS = 64;
+static int small_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
+  FastState *f = (FastState *)b->m->fast;
+  const long long nT = b->m->nTrans;
+  std::vector<Chunk> chunks;
+  if (!small_chunks_plan(b, f->smB, true, false, chunks)) return 1;
+  double *d_rep = nullptr, *d_ll = nullptr, *d_bll = nullptr;
+  int rc = 0;
+  Timer tm;
+  do {
+    if (!hip_ok(sm_alloc((void **)&d_rep, std::max<long long>(nT, 1) * SMALL_COUNT_REPLICAS * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+    if (!hip_ok(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+    if (!hip_ok(sm_alloc((void **)&d_bll, b->nPairs * sizeof(double)), "hipMalloc")) { rc = 1; break; }
+    if (!hip_ok(hipMemsetAsync(d_rep, 0, std::max<long long>(nT, 1) * SMALL_COUNT_REPLICAS * sizeof(double), g_stream), "memset")) { rc = 1; break; }
+    for (const Chunk &c : chunks) {
+      SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
+      if (!(rc = small_prepare(b, c, f->smB, true, false, pl, hp, &d_aux, sw))) {
+        tm.start();
+        sw.d_loglike = d_bll + c.p0;
+        rc = small_sweep(f->smB, SM_SUM, true, sw, g_stream);                 // BackwardMatrix::fill, src/backward.cpp:18-46
+        if (!rc) {
+          sw.d_loglike = d_ll + c.p0; sw.d_bwdLL = d_bll + c.p0; sw.d_counts = d_rep; sw.nRep = SMALL_COUNT_REPLICAS;
+          rc = small_sweep(f->smF, SM_COUNT, false, sw, g_stream);            // Forward + getCounts, src/backward.cpp:58-87
+        }
+        g_last_ms += tm.stop();
+      }
+      sm_free(d_aux);
+      if (rc) break;
+    }
+    if (rc) break;
+    std::vector<double> hc((size_t)nT * SMALL_COUNT_REPLICAS), hll(b->nPairs);
+    if (nT && !hip_ok(hipMemcpy(hc.data(), d_rep, hc.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) { rc = 1; break; }
+    if (!hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
+    for (long long e = 0; e < nT; ++e) {
+      double s = 0.0;
+      for (int r = 0; r < SMALL_COUNT_REPLICAS; ++r) s += hc[(size_t)r * nT + e];
+      counts[e] += s;
+    }
+    double s = 0;
+    for (long long p = 0; p < b->nPairs; ++p) { s += hll[p]; if (loglike) loglike[p] = hll[p]; }   // loglike += forward.logLike(), src/counts.cpp:61-62
+    if (loglikeSum) *loglikeSum += s;
+  } while (0);
+  sm_free(d_rep); sm_free(d_ll); sm_free(d_bll);
+  g_last_kernel = "k_small_jit";
+  return rc;
+}
+
+// one full matrix in the reference's layout (mb_fill): sweep tile-major, convert on the device, copy out
+static int small_fill(mb_batch *b, int mode, double *cellsOut) {
+  FastState *f = (FastState *)b->m->fast;
+  SmallProgram &P = mode == MB_BACKWARD ? f->smB : f->smF;
+  const PairDesc &pd = b->pairs[0];
+  const long long n = (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S;
+  const Chunk c{0, 1, 0};
+  SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
+  double *d_ll = nullptr, *d_cells = nullptr;
+  int rc = 0;
+  do {
+    if ((size_t)(small_pair_doubles(P.S, pd.inLen, pd.outLen) + n) * 8 > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; break; }
+    if ((rc = small_prepare(b, c, P, true, false, pl, hp, &d_aux, sw))) break;
+    if (!hip_ok(sm_alloc((void **)&d_ll, sizeof(double)), "hipMalloc")) { rc = 1; break; }
+    if (!(d_cells = (double *)ws_get(1, (size_t)std::max<long long>(n, 1) * 8))) { rc = 1; break; }
+    sw.d_loglike = d_ll;
+    if ((rc = small_sweep(P, mode == MB_VITERBI ? SM_MAX : SM_SUM, true, sw, g_stream))) break;
+    if ((rc = launch_fill_neg_inf(d_cells, n, g_stream))) break;
+    if ((rc = launch_small_unpack(sw.d_pool, P.S, pd.inLen, pd.outLen, mode == MB_BACKWARD, d_cells, g_stream))) break;
+    if (!hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) { rc = 1; break; }
+    if (!hip_ok(hipMemcpy(cellsOut, d_cells, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) { rc = 1; break; }
+  } while (0);
+  sm_free(d_aux); sm_free(d_ll);
+  g_last_kernel = "k_small_jit";
+  return rc;
 }
 
 }  // namespace mb
@@ -400,6 +661,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
     if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
     if (!f->mediumOk && f->exactOk && !medium_refresh_weights(m, f->fwdExact)) return 1;
     if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
+    if (f->smallOk && !(small_refresh_weights(m, f->smF) && small_refresh_weights(m, f->smB))) return 1;
     f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = true;
   }
   return 0;
@@ -411,6 +673,7 @@ void mb_machine_destroy(mb_machine *m) {
     FastState *f = (FastState *)m->fast;
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt);
     wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit);
+    small_free(f->smF); small_free(f->smB);
     delete f;
   }
   free_machine_device(m);
@@ -519,6 +782,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   mb_machine *m = b->m;
+  if (mode == MB_FORWARD && !b->hasEnv && use_small(m)) return small_forward(b, flags, loglike);
   double *d_ll = nullptr;
   MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
@@ -616,6 +880,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
   if (pathOff) pathOff[0] = 0;
   if (b->nPairs == 0) return 0;
+  if (!b->hasEnv && use_small(b->m)) return small_viterbi(b, loglike, pathOff, pathEdges, pathCap);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 1, chunks)) return 1;
   int rc = 0;
@@ -698,6 +963,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   const long long nT = b->m->nTrans;
+  if (!b->hasEnv && use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF)) return small_counts(b, counts, loglikeSum, loglike);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;
@@ -766,6 +1032,11 @@ int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const
     const int64_t envOff[2] = {0, outLen + 1};
     if (mb_batch_set_envelopes(b, envOff, envStart, envEnd)) { mb_batch_destroy(b); return 1; }
   }
+  if (!b->hasEnv && startState == 0 && use_small(m)) {
+    const int rcs = small_fill(b, mode, cellsOut);
+    mb_batch_destroy(b);
+    return rcs;
+  }
   const long long n = b->totalCells;
   double *pool = nullptr;
   int rc = 0;
@@ -811,6 +1082,30 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
   fprintf(f, "// G=%d C=%d waves=%d ldsBytes=%zu ldsRecs=%zu rounds=%zu\n", G, geo.C, geo.waves, medium_jit_lds_bytes(P, geo),
           P.ldsImageIdx.size(), P.roundInfo.size());
+  fputs(code.c_str(), f);
+  fclose(f);
+  return 0;
+}
+
+// generated source of the small-machine family's sweep (mode: 0 sum, 1 max, 2 traceback bytes, 3 counts); host only
+int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                          const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward,
+                          int materialise, const char *path) {
+  if (nStates <= 0 || nTrans < 0 || !path || mode < 0 || mode >= SM_NMODE) { set_error("mb_debug_small_source: bad argument"); return 1; }
+  mb_machine m;
+  m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
+  m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);
+  m.inTok.assign(inTok, inTok + nTrans); m.outTok.assign(outTok, outTok + nTrans);
+  m.logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  SmallProgram P;
+  if (!small_build_host(&m, backward != 0, P)) { set_error("machine does not qualify for the small-machine family"); return 1; }
+  const std::string code = small_jit_source(P, mode, materialise != 0);
+  FILE *f = fopen(path, "w");
+  if (!f) { set_error("mb_debug_small_source: cannot open output file"); return 1; }
+  fprintf(f, "// ldsBytes=%zu H=%d NBD=%d tables: silent %d input %d output %d match %d\n", small_jit_lds_bytes(P, mode), P.H, P.NBD,
+          P.nTab[3], P.nTab[1], P.nTab[2], P.nTab[0]);
   fputs(code.c_str(), f);
   fclose(f);
   return 0;

@@ -93,6 +93,9 @@ extern size_t g_mem_budget;
 // cached small device buffers (mb_api.hip): per-call descriptor / offset / tile-list arrays
 hipError_t sm_alloc(void **out, size_t bytes);
 void sm_free(void *p);
+// grow-only device workspaces by slot (mb_api.hip); pinned for the duration of the current API call
+void *ws_get(int slot, size_t bytes);
+size_t budget_bytes();
 #define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)
 
 // host-side machine compiler (mb_machine.cpp)

@@ -1,0 +1,113 @@
+// mb_jit.cpp -- hiprtc front end with an on-disk code-object cache (see mb_jit.h).
+#include "mb_jit.h"
+
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mb {
+
+static double g_jit_ms = 0.0;
+static long long g_jit_compiles = 0, g_jit_hits = 0;
+double jit_compile_ms() { return g_jit_ms; }
+long long jit_compiles() { return g_jit_compiles; }
+long long jit_cache_hits() { return g_jit_hits; }
+
+static const char *kOpts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics"};
+static const int kNOpts = 5;
+
+static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t k = 0; k < n; ++k) { h ^= b[k]; h *= 1099511628211ull; }
+  return h;
+}
+
+static bool mkdir_p(const std::string &dir) {
+  std::string cur;
+  for (size_t k = 0; k <= dir.size(); ++k) {
+    if (k == dir.size() || dir[k] == '/') {
+      if (!cur.empty() && mkdir(cur.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    }
+    if (k < dir.size()) cur += dir[k];
+  }
+  return true;
+}
+
+static std::string cache_dir() {
+  const char *off = getenv("MB_JIT_CACHE");
+  if (off && *off == '0') return "";
+  std::string d;
+  if (const char *e = getenv("MB_JIT_CACHE_DIR")) d = e;
+  else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/mbhip";
+  else if (const char *h = getenv("HOME")) d = std::string(h) + "/.cache/mbhip";
+  if (d.empty() || !mkdir_p(d) || access(d.c_str(), W_OK) != 0) {
+    d = "/tmp/mbhip-cache-" + std::to_string((long long)getuid());
+    if (!mkdir_p(d) || access(d.c_str(), W_OK) != 0) return "";
+  }
+  return d;
+}
+
+bool jit_compile(const std::string &src, const char *name, std::string &code, std::string *log, bool *fromCache) {
+  if (fromCache) *fromCache = false;
+  unsigned long long h = 1469598103934665603ull;
+  h = fnv1a(src.data(), src.size(), h);
+  for (int k = 0; k < kNOpts; ++k) h = fnv1a(kOpts[k], strlen(kOpts[k]) + 1, h);
+  int vmaj = 0, vmin = 0;
+  (void)hiprtcVersion(&vmaj, &vmin);
+  h = fnv1a(&vmaj, sizeof(vmaj), h); h = fnv1a(&vmin, sizeof(vmin), h);
+  static const std::string dir = cache_dir();
+  char fname[64];
+  snprintf(fname, sizeof(fname), "/%016llx-%zu.co", h, src.size());
+  const std::string path = dir.empty() ? "" : dir + fname;
+  if (!path.empty()) {
+    if (FILE *f = fopen(path.c_str(), "rb")) {
+      fseek(f, 0, SEEK_END);
+      const long n = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      if (n > 0) {
+        code.assign((size_t)n, 0);
+        const bool ok = fread(&code[0], 1, (size_t)n, f) == (size_t)n;
+        fclose(f);
+        if (ok) { ++g_jit_hits; if (fromCache) *fromCache = true; return true; }
+      } else fclose(f);
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { if (log) *log = "hiprtcCreateProgram failed"; return false; }
+  const hiprtcResult rc = hiprtcCompileProgram(prog, kNOpts, kOpts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string lg(ls, 0);
+    if (ls) hiprtcGetProgramLog(prog, &lg[0]);
+    if (log) *log = lg;
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code.assign(cs, 0);
+  hiprtcGetCode(prog, &code[0]);
+  hiprtcDestroyProgram(&prog);
+  g_jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ++g_jit_compiles;
+  if (!path.empty()) {   // write to a private name, then rename: readers never see a partial file
+    const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+    if (FILE *f = fopen(tmp.c_str(), "wb")) {
+      const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+      fclose(f);
+      if (!ok || rename(tmp.c_str(), path.c_str()) != 0) unlink(tmp.c_str());
+    }
+  }
+  return true;
+}
+
+}  // namespace mb

@@ -1,0 +1,19 @@
+// mb_jit.h -- run-time compilation of generated HIP source with hiprtc, shared by the kernel families that specialise a
+// kernel per machine (mb_medium_jit.cpp, mb_small.cpp), with an on-disk cache of the code objects.
+#pragma once
+#include <string>
+
+namespace mb {
+
+// Compiles `src` for gfx950 and returns the code object in `code`.  The result is cached on disk under
+// $MB_JIT_CACHE_DIR (default: $XDG_CACHE_HOME/mbhip, ~/.cache/mbhip, else /tmp/mbhip-cache-<uid>), keyed by a hash of the
+// source text, the compile options and the hiprtc version, so that a second process (or a second machine with the same
+// topology and geometry) pays no compile.  MB_JIT_CACHE=0 disables the cache.  *fromCache tells which happened.
+bool jit_compile(const std::string &src, const char *name, std::string &code, std::string *log, bool *fromCache);
+
+// cumulative wall-clock milliseconds this process spent inside hiprtc, and the number of compiles / cache hits
+double jit_compile_ms();
+long long jit_compiles();
+long long jit_cache_hits();
+
+}  // namespace mb

@@ -10,13 +10,13 @@
 //
 // With REG + LDS placement the step loop issues no vector-memory LOAD other than the halo supercell, so nothing in
 // a step waits (through the in-order vmcnt counter of gfx9) for the previous step's global stores to be acknowledged.
-#include <hip/hiprtc.h>
 
 #include <algorithm>
 #include <cstdlib>
 #include <sstream>
 #include <string>
 
+#include "mb_jit.h"
 #include "mb_medium.h"
 #include "mb_medium_jit_src.h"
 
@@ -248,24 +248,11 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
     if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
       if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : ".sum")) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
-    hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "mb_medium_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
-    if (rc != HIPRTC_SUCCESS) {
-      size_t ls = 0;
-      hiprtcGetProgramLogSize(prog, &ls);
-      std::string log(ls, 0);
-      if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    std::string log;
+    if (!jit_compile(src, "mb_medium_jit.hip", code, &log, nullptr)) {
       if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
-      hiprtcDestroyProgram(&prog);
       return false;
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    code.assign(cs, 0);
-    hiprtcGetCode(prog, &code[0]);
-    hiprtcDestroyProgram(&prog);
     const long long spills = medium_jit_spill_count(code);
     if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : "sum"), P.regBudget, spills);
     if (spills <= 0 || P.regBudget == 0) break;

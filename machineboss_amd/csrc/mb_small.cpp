@@ -1,0 +1,629 @@
+// mb_small.cpp -- "lane = column, states in registers": the kernel family for machines with a handful of states.
+//
+// BASELINE configs 1-3 run on 8-state machines (dnapsw, protpsw).  The tiled family (mb_medium.hip) spends a supercell's
+// states on the lanes of a lane group and keeps the anti-diagonals in an LDS ring, which for 8 states means two lanes per
+// supercell, four rounds with a wave-level LDS round trip each, and a workgroup barrier per step.  Here instead
+//   * a WAVEFRONT is a strip of 64 consecutive input positions, one lane per column, sweeping the output axis with the
+//     usual skew (lane c works on output position t - c at step t); the states of a lane's supercell are named scalars
+//     in VGPRs, evaluated by straight-line code in state order -- the reference's own order (src/forward.defs.h:32-43),
+//     so silent transitions need no synchronisation at all;
+//   * the three neighbour supercells come from registers: (i,o-1) is the lane's own previous result, (i-1,o) is the left
+//     lane's previous result (ONE v_mov_b32_dpp wave_shr:1 per 32 bits -- only for the states that are sources of
+//     input-consuming transitions), (i-1,o-1) is what that shift delivered a step earlier.  Lane 0 takes its left
+//     neighbour from the halo column the previous strip wrote (staged in LDS 64 steps at a time, read as a broadcast);
+//   * no workgroup barrier, no LDS ring: the four wavefronts of a workgroup are four independent tiles that only share
+//     the weight tables (output-token and match tables in LDS; input-token weights are per-lane registers loaded once
+//     per tile; silent weights are scalar registers);
+//   * a strip is cut into tiles of TS steps; tile (strip a, block b) runs in launch 2a + b, so kernel boundaries are
+//     the only synchronisation between tiles (same scheme as the tiled family); the register state a tile hands to the
+//     next block of its strip goes through a small boundary record, the last column through the halo column;
+//   * matrices are stored TILE-MAJOR (strip, step, chunk, lane): every store instruction of a wavefront writes 64 x 16
+//     contiguous bytes.  In the reference's layout ((outPos * (inLen+1) + inPos) * nStates) the 64 supercells of a step
+//     are 64 pieces of 64 bytes, (inLen) supercells apart: measured 3.7 TB/s against 6.3 TB/s for a streaming fill
+//     (scripts/micro/store_pattern_probe.hip).  mb_fill() converts to the reference's layout on the way out;
+//   * Viterbi stores ONE traceback byte per cell (the index of the first maximal candidate in the reference's
+//     enumeration order, src/dpmatrix.defs.h:93-103) instead of the fp64 cell -- SURVEY.md section 8(d): 1 B per cell;
+//   * the posterior-count sweep (src/backward.cpp:58-87) is a Forward sweep that reads the Backward matrix (16 B per
+//     lattice cell moved in total: Backward written once, read once; Forward never touches HBM) and keeps usage sums in
+//     registers (silent and input-token transitions: the transition is fixed for a lane's whole tile) or in lane-private
+//     LDS rows indexed by the output token (no two lanes ever share an address), folded into a workgroup table and
+//     flushed with one fp64 atomic per used transition per four tiles.
+//
+// Arithmetic: as in the tiled family -- candidates, maxima and cells are fp64; the log-sum-exp correction term is
+// evaluated in fp32 (v_exp_f32 / v_log_f32); max mode is exact, so Viterbi scores and traceback bytes reproduce the
+// reference's choices bit for bit.
+#include "mb_small.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <sstream>
+
+#include "mb_jit.h"
+
+namespace mb {
+
+static int env_int_s(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+static const int SM_MAX_STATES = 16;
+
+bool small_eligible(const mb_machine *m) {
+  if (m->S < 1 || m->S > env_int_s("MB_SMALL_MAX_STATES", SM_MAX_STATES)) return false;
+  if (m->nIn < 1 || m->nOut < 1) return false;            // one-tape machines: other families
+  if (m->nTrans > 8000) return false;                     // the workgroup's count table lives in LDS
+  for (long long e = 0; e < m->nTrans; ++e)
+    if (m->inTok[e] == 0 && m->outTok[e] == 0 && m->dst[e] <= m->src[e]) return false;   // silent self-loop on state 0
+  return true;
+}
+
+// ---- program: candidates per state in the reference's enumeration order ------------------------------------------------
+bool small_build_host(const mb_machine *m, bool backward, SmallProgram &P) {
+  P = SmallProgram();
+  if (!small_eligible(m)) return false;
+  const int S = m->S, nIn = m->nIn, nOut = m->nOut;
+  P.backward = backward; P.S = S; P.nIn = nIn; P.nOut = nOut; P.nTrans = m->nTrans;
+  const std::vector<int> &off = backward ? m->outOff : m->inOff;
+  const std::vector<uint32_t> &perm = backward ? m->outPerm : m->inPerm;
+  auto other = [&](uint32_t e) { return (int)(backward ? m->dst[e] : m->src[e]); };
+  auto row = [&](int st, int it, int ot) { return ((long long)st * (nIn + 1) + it) * (nOut + 1) + ot; };
+  P.order.resize(S);
+  for (int k = 0; k < S; ++k) P.order[k] = backward ? S - 1 - k : k;
+  P.seedState = backward ? S - 1 : 0;
+  P.endState = backward ? 0 : S - 1;
+  P.cand.assign(S, {});
+  // slot (state, T, src, dup) -> per-token (weight, edge)
+  struct Tab { int T; std::vector<int> e; };   // e: edge id per token index (-1: none)
+  std::vector<Tab> tabs[4];
+  for (int d = 0; d < S; ++d) {
+    for (int T = 0; T < 4; ++T) {
+      // token grid of this kind
+      const int nI = (T == 0 || T == 1) ? nIn : 0, nO = (T == 0 || T == 2) ? nOut : 0;
+      const int nTok = T == 0 ? (nIn + 1) * (nOut + 1) : (T == 1 ? nIn + 1 : (T == 2 ? nOut + 1 : 1));
+      std::map<std::pair<int, int>, std::vector<int>> slots;   // (src, dup) -> edge per token index
+      auto visit = [&](int it, int ot, int tokIdx) {
+        const long long rw = row(d, it, ot);
+        int prevSrc = -1, dup = 0;
+        for (int a = off[rw]; a < off[rw + 1]; ++a) {
+          const uint32_t e = perm[a];
+          const int o = other(e);
+          if (T == 3 && (backward ? o <= d : o >= d)) return false;   // excluded by small_eligible
+          dup = (o == prevSrc) ? dup + 1 : 0;
+          prevSrc = o;
+          auto &v = slots[{o, dup}];
+          if (v.empty()) v.assign(nTok, -1);
+          v[tokIdx] = (int)e;
+        }
+        return true;
+      };
+      if (T == 3) { if (!visit(0, 0, 0)) return false; }
+      else if (T == 1) { for (int it = 1; it <= nI; ++it) visit(it, 0, it); }
+      else if (T == 2) { for (int ot = 1; ot <= nO; ++ot) visit(0, ot, ot); }
+      else for (int it = 1; it <= nI; ++it) for (int ot = 1; ot <= nO; ++ot) visit(it, ot, it * (nOut + 1) + ot);
+      for (auto &kv : slots) {
+        P.cand[d].push_back({T, kv.first.first, kv.first.second, (int)tabs[T].size()});
+        tabs[T].push_back({T, kv.second});
+      }
+    }
+    if (P.cand[d].size() > 255) return false;
+  }
+  for (const SmSlot &sl : P.cand[P.seedState]) if (sl.T == 3) P.seedSimple = false;
+  if (!P.seedSimple) return false;   // (a start state fed by silent transitions: the other families take it)
+  for (int T = 0; T < 4; ++T) P.nTab[T] = (int)tabs[T].size();
+  if (P.nTab[3] > 48 || P.nTab[1] > 48) return false;   // scalar / vector registers held for the whole tile
+  const long long szT[4] = {(long long)(nIn + 1) * (nOut + 1), nIn + 1, nOut + 1, 1};
+  P.off[3] = 0;
+  P.off[1] = P.off[3] + P.nTab[3];
+  P.off[2] = P.off[1] + (long long)P.nTab[1] * szT[1];
+  P.off[0] = P.off[2] + (long long)P.nTab[2] * szT[2];
+  P.nEntries = P.off[0] + (long long)P.nTab[0] * szT[0];
+  if ((P.nEntries - P.off[2]) * 8 > 64 * 1024) return false;   // LDS copy of the output-token and match tables
+  P.eid.assign((size_t)P.nEntries, -1);
+  for (int T = 0; T < 4; ++T)
+    for (int k = 0; k < P.nTab[T]; ++k)
+      for (long long j = 0; j < szT[T]; ++j) P.eid[(size_t)(P.off[T] + k * szT[T] + j)] = tabs[T][k].e[(size_t)j];
+  // which states cross a step
+  std::set<int> L, Dg, Dn;
+  for (int d = 0; d < S; ++d)
+    for (const SmSlot &sl : P.cand[d]) {
+      if (sl.T == 0) { Dg.insert(sl.src); L.insert(sl.src); }
+      else if (sl.T == 1) L.insert(sl.src);
+      else if (sl.T == 2) Dn.insert(sl.src);
+    }
+  P.needLeft.assign(L.begin(), L.end()); P.needDiag.assign(Dg.begin(), Dg.end()); P.needDown.assign(Dn.begin(), Dn.end());
+  std::set<int> sv(L.begin(), L.end()); sv.insert(Dn.begin(), Dn.end());
+  P.saveCells.assign(sv.begin(), sv.end());
+  P.H = (int)P.needLeft.size();
+  P.NBD = std::max(1, (int)(P.saveCells.size() + P.needDiag.size()));
+  // traceback decode table
+  P.decOff.assign(S + 1, 0);
+  for (int d = 0; d < S; ++d) {
+    P.decOff[d + 1] = P.decOff[d] + (int)P.cand[d].size();
+    for (const SmSlot &sl : P.cand[d]) P.dec.push_back((uint32_t)sl.T | ((uint32_t)sl.src << 8) | ((uint32_t)sl.tab << 16));
+  }
+  P.w.assign((size_t)P.nEntries, -INFINITY);
+  for (size_t k = 0; k < P.w.size(); ++k) if (P.eid[k] >= 0) P.w[k] = m->logW[P.eid[k]];
+  P.ok = true;
+  return true;
+}
+
+template <class T>
+static bool up_s(T *&d, const std::vector<T> &h) {
+  if (d) { (void)hipFree(d); d = nullptr; }
+  if (!hip_ok(hipMalloc((void **)&d, std::max<size_t>(h.size(), 1) * sizeof(T)), "hipMalloc(small program)")) return false;
+  if (!h.empty() && !hip_ok(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice), "H2D(small program)")) return false;
+  return true;
+}
+
+bool small_refresh_weights(const mb_machine *m, SmallProgram &P) {
+  if (!P.ok) return true;
+  for (size_t k = 0; k < P.w.size(); ++k) P.w[k] = P.eid[k] >= 0 ? m->logW[P.eid[k]] : -INFINITY;
+  if (!P.d_w) return up_s(P.d_w, P.w);
+  return hip_ok(hipMemcpy(P.d_w, P.w.data(), P.w.size() * sizeof(double), hipMemcpyHostToDevice), "H2D(small weights)");
+}
+
+bool small_build(const mb_machine *m, bool backward, SmallProgram &P) {
+  if (!small_build_host(m, backward, P)) return false;
+  if (!(up_s(P.d_w, P.w) && up_s(P.d_eid, P.eid) && up_s(P.d_decOff, P.decOff) && up_s(P.d_dec, P.dec))) { small_free(P); return false; }
+  return true;
+}
+
+void small_free(SmallProgram &P) {
+  for (int mo = 0; mo < SM_NMODE; ++mo)
+    for (int ma = 0; ma < 2; ++ma)
+      if (P.jit[mo][ma].module) (void)hipModuleUnload((hipModule_t)P.jit[mo][ma].module);
+  void *ptrs[] = {P.d_w, P.d_eid, P.d_decOff, P.d_dec};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  P = SmallProgram();
+}
+
+// ---- LDS budget ---------------------------------------------------------------------------------------------------------
+static long long lds_w_doubles(const SmallProgram &P) { return ((P.nEntries - P.off[2]) + 1) & ~1ll; }
+static int row_floats(const SmallProgram &P) {   // count mode: lane-private usage rows, one float per (output-token / match table, output token)
+  int n = (P.nTab[2] + P.nTab[0]) * (P.nOut + 1);
+  return n | 1;   // odd stride: the 64 rows start in different LDS banks
+}
+static long long wave_doubles(const SmallProgram &P, int mode) {
+  long long d = 32 + 64ll * std::max(P.H, 1);
+  if (mode == SM_COUNT) d += (64ll * row_floats(P) + 1) / 2;
+  return (d + 1) & ~1ll;
+}
+size_t small_jit_lds_bytes(const SmallProgram &P, int mode) {
+  long long d = lds_w_doubles(P) + 4 * wave_doubles(P, mode);
+  if (mode == SM_COUNT) d += (P.nTrans + 1) & ~1ll;
+  return (size_t)d * 8;
+}
+
+// ---- source generator ----------------------------------------------------------------------------------------------------
+static const char *kSmallSkeleton = R"MBSM(
+/*@DEFS@*/
+#define NEG_INF (-__builtin_inf())
+#define SM_L2E 1.44269504088896f
+#define SM_LN2 0.693147180559945f
+struct PairDesc { long long inBase, outBase; int inLen, outLen; long long cellBase; int launch0; int pad; long long envBase; };
+struct SmAux { long long pool, halo, bound, tb; };
+struct SmallArgs {
+  const PairDesc *pairs; const int *inTok; const int *outTok;
+  const int4 *tiles; int tileBase, tileEnd, TS, nRep;
+  double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
+  double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
+};
+typedef const __attribute__((address_space(4))) double *cdbl_t;
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }   // operands are never NaN
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((float)d * SM_L2E); }
+// lane l takes the value of lane l-1; lane 0 takes `old`
+__device__ __forceinline__ int shri(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double shr1(double v, double old) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// log(exp(a) + exp(b)): fp64 maximum, correction term log(1 + exp(min - max)) in fp32
+__device__ __forceinline__ double lse2(double a, double b) {
+  const double mx = dmax(a, b), mn = dmin(a, b);
+  float df = (float)(mn - mx);                    // NaN when both are -inf
+  df = (mx == NEG_INF) ? 0.0f : df;
+  const float e = __builtin_amdgcn_exp2f(df * SM_L2E);
+  return mx + (double)(__builtin_amdgcn_logf(1.0f + e) * SM_LN2);
+}
+__device__ __forceinline__ void lds_add_f32(float *p, float x) {
+  (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add_f64(double *p, double x) {
+  (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_small_jit(SmallArgs A) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double *wL = lds;                                          // output-token and match weight tables
+#if JMODE == 3
+  double *accT = lds + JLDSW;                                // posterior counts of this workgroup's tiles
+  double *myL = accT + ((JNTRANS + 1) & ~1) + wv * JWAVEDBL;
+#else
+  double *myL = lds + JLDSW + wv * JWAVEDBL;
+#endif
+  int *tokL = (int *)myL;                                    // output tokens entering lane 0, one block of 64 steps
+  double *haloL = myL + 32;                                  // halo rows entering lane 0, same block
+#if JMODE == 3
+  float *rowL = (float *)(haloL + 64 * JHP) + lane * JROWF;  // this lane's usage sums by output token
+#endif
+  for (int j = tid; j < JLDSW; j += 256) wL[j] = (j < JLDSWN) ? A.w[JOFFOUT + j] : 0.0;
+#if JMODE == 3
+  for (int j = tid; j < JNTRANS; j += 256) accT[j] = 0.0;
+#endif
+  __syncthreads();
+  const int tile = A.tileBase + blockIdx.x * 4 + wv;
+  if (tile < A.tileEnd) {
+    const int4 tl = A.tiles[tile];
+    const int pairIdx = tl.x, a = tl.y, b = tl.z;
+    const PairDesc pd = A.pairs[pairIdx];
+    const SmAux ax = A.aux[pairIdx];
+    const int inLen = pd.inLen, outLen = pd.outLen;
+    const int NA = (inLen + 64) >> 6;
+    const int Te = (outLen + 65) & ~1;
+    const int t0 = b * A.TS, t1 = min(t0 + A.TS, Te);
+    const int i = a * 64 + lane;
+    const bool colValid = i <= inLen;
+    const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
+    const int it = (colValid && i > 0) ? (JREV ? in[inLen - i] : in[i - 1]) : 0;
+    auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (JREV ? out[outLen - o] : out[o - 1]) : 0; };
+    cdbl_t wc = (cdbl_t)A.w;
+    const int mrow = it * (JNOUT + 1);
+    (void)wc; (void)mrow; (void)NA;
+/*@WEIGHTS@*/
+    const double *haloIn = A.halo + ax.halo + (long long)((a + 1) & 1) * (outLen + 1) * JHP;   // written by strip a-1
+    double *haloOut = A.halo + ax.halo + (long long)(a & 1) * (outLen + 1) * JHP;
+    double *bnd = A.bound + ax.bound + ((long long)a * 64 + lane) * JNBD;
+    (void)haloIn; (void)haloOut;
+#if JMAT
+    double *poolPair = A.pool + ax.pool;
+#endif
+#if JMODE == 2
+    unsigned char *tbPair = A.tb + ax.tb;
+#endif
+#if JMODE == 3
+    // the Backward matrix of the pair (stored in the reversed frame of the Backward sweep) and its log-likelihood
+    const double *poolB = A.pool + ax.pool;
+    const double bLL = A.bwdLL[pairIdx];                          // BackwardMatrix::logLike(), src/backward.cpp:48-50,66
+    const double negLL = (bLL > NEG_INF) ? -bLL : NEG_INF;        // -inf likelihood: every term becomes exp(-inf) = 0
+    auto bPtr = [&](int o) -> const double * {                    // chunk 0 of cell (i, o), clamped into the lattice
+      const int ib = inLen - min(i, inLen), ob = outLen - min(max(o, 0), outLen);
+      const int ab = ib >> 6, cb = ib & 63;
+      return poolB + (((long long)ab * Te + (ob + cb)) * (JNCH * 64) + cb) * (JCHB / 8);
+    };
+    for (int j = 0; j < JROWF; ++j) rowL[j] = 0.0f;
+#endif
+/*@STATE@*/
+    if (b > 0) {
+/*@LOADBND@*/
+    }
+    int ot = tokAt(t0 - 1 - lane);
+#if JH > 0
+    if (a == 0) for (int h = 0; h < JH; ++h) haloL[lane * JH + h] = NEG_INF;
+#endif
+    for (int tb = t0; tb < t1; tb += 64) {
+      tokL[lane] = tokAt(tb + lane);
+#if JH > 0
+      if (a > 0) {
+        const int ho = tb + lane;
+#pragma unroll
+        for (int h = 0; h < JH; ++h) haloL[lane * JH + h] = (ho <= outLen) ? haloIn[(long long)min(ho, outLen) * JH + h] : NEG_INF;
+      }
+#endif
+      wave_sync();
+      const int nj = min(64, t1 - tb);
+      for (int j = 0; j < nj; j += 2) {
+/*@STEP0@*/
+/*@STEP1@*/
+      }
+      wave_sync();   // the block buffers are rewritten next
+    }
+    if (t1 < Te) {
+/*@SAVEBND@*/
+    }
+#if JMODE == 3
+/*@FLUSH@*/
+#endif
+  }
+#if JMODE == 3
+  __syncthreads();
+  {
+    double *rep = A.counts + (long long)(blockIdx.x % A.nRep) * JNTRANS;
+    for (int e = tid; e < JNTRANS; e += 256) {
+      const double x = accT[e];
+      if (x != 0.0) (void)__hip_atomic_fetch_add(rep + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
+}
+)MBSM";
+
+static std::string I(long long v) { return std::to_string(v); }
+
+std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) {
+  std::ostringstream defs, weights, state, loadb, saveb, flush;
+  const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
+  const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
+  const int rowF = row_floats(P);
+  defs << "#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
+       << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
+       << "\n#define JNBD " << P.NBD << "\n#define JCHB " << CB << "\n#define JNCH " << NCH << "\n#define JTBSTRIDE " << small_tb_stride(S)
+       << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JLDSW " << lds_w_doubles(P)
+       << "\n#define JLDSWN " << (P.nEntries - P.off[2]) << "\n#define JWAVEDBL " << wave_doubles(P, mode)
+       << "\n#define JOFFSIL " << P.off[3] << "\n#define JOFFIN " << P.off[1] << "\n#define JOFFOUT " << P.off[2] << "\n#define JOFFMAT " << P.off[0]
+       << "\n#define JENDSTATE " << P.endState << "\n";
+  for (int k = 0; k < P.nTab[3]; ++k) weights << "    const double wS" << k << " = wc[JOFFSIL + " << k << "];\n";
+  for (int k = 0; k < P.nTab[1]; ++k) weights << "    const double wI" << k << " = A.w[JOFFIN + " << (long long)k * (P.nIn + 1) << " + it];\n";
+  // persistent state: two sets of cells and of left-neighbour values, alternating by step parity
+  for (int p = 0; p < 2; ++p) {
+    state << "    double";
+    for (int s = 0; s < S; ++s) state << (s ? "," : "") << " c" << p << "_" << s << " = NEG_INF";
+    state << ";\n";
+    if (!P.needLeft.empty()) {
+      state << "    double";
+      for (size_t k = 0; k < P.needLeft.size(); ++k) state << (k ? "," : "") << " l" << p << "_" << P.needLeft[k] << " = NEG_INF";
+      state << ";\n";
+    }
+  }
+  if (counting) {
+    if (P.nTab[3] + P.nTab[1] > 0) {
+      state << "    float";
+      bool first = true;
+      for (int k = 0; k < P.nTab[3]; ++k) { state << (first ? "" : ",") << " aS" << k << " = 0.0f"; first = false; }
+      for (int k = 0; k < P.nTab[1]; ++k) { state << (first ? "" : ",") << " aI" << k << " = 0.0f"; first = false; }
+      state << ";\n";
+    }
+    // Backward supercells of the next two steps, fetched two steps ahead
+    for (int p = 0; p < 2; ++p) {
+      state << "    " << (CB == 16 ? "d2" : "double");
+      for (int k = 0; k < NCH; ++k) state << (k ? "," : "") << " bq" << p << "_" << k;
+      state << ";\n    { const double *bp = bPtr(t0 + " << p << " - lane);\n";
+      for (int k = 0; k < NCH; ++k)
+        state << "      bq" << p << "_" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
+      state << "    }\n";
+    }
+  }
+  {  // boundary record: cells of the last step, then the left values of the last step (the next step's diagonal)
+    int k = 0;
+    for (int s : P.saveCells) { loadb << "      c1_" << s << " = bnd[" << k << "];\n"; saveb << "      bnd[" << k << "] = c1_" << s << ";\n"; ++k; }
+    for (int s : P.needDiag) { loadb << "      l1_" << s << " = bnd[" << k << "];\n"; saveb << "      bnd[" << k << "] = l1_" << s << ";\n"; ++k; }
+  }
+  auto step = [&](int p) {
+    const int q = 1 - p;
+    std::ostringstream b;
+    const std::string cp = "c" + I(p) + "_", cq = "c" + I(q) + "_", lp = "l" + I(p) + "_", lq = "l" + I(q) + "_";
+    b << "        {  // step parity " << p << "\n";
+    b << "          const int jj = j + " << p << ", t = tb + jj, o = t - lane;\n";
+    b << "          const bool active = colValid && o >= 0 && o <= outLen;\n";
+    b << "          ot = shri(ot, tokL[jj]);\n";
+    for (size_t k = 0; k < P.needLeft.size(); ++k)
+      b << "          " << lp << P.needLeft[k] << " = shr1(" << cq << P.needLeft[k] << ", haloL[jj * JH + " << k << "]);\n";
+    for (int k = 0; k < P.nTab[2]; ++k) b << "          const double wO" << k << " = wL[" << (long long)k * (P.nOut + 1) << " + ot];\n";
+    for (int k = 0; k < P.nTab[0]; ++k)
+      b << "          const double wM" << k << " = wL[" << (P.off[0] - P.off[2]) + (long long)k * (P.nIn + 1) * (P.nOut + 1) << " + mrow + ot];\n";
+    if (counting) b << "          float *rowp = rowL + ot;\n";
+    if (tbmode) b << "          unsigned int xw[" << small_tb_stride(S) / 4 << "] = {0};\n";
+    for (int d : P.order) {
+      const std::vector<SmSlot> &cs = P.cand[d];
+      const int n = (int)cs.size();
+      b << "          {  // state " << d << "\n";
+      for (int k = 0; k < n; ++k) {
+        const SmSlot &sl = cs[k];
+        const std::string src = (sl.T == 0 ? lq : (sl.T == 1 ? lp : (sl.T == 2 ? cq : cp))) + I(sl.src);
+        const std::string w = std::string(sl.T == 0 ? "wM" : (sl.T == 1 ? "wI" : (sl.T == 2 ? "wO" : "wS"))) + I(sl.tab);
+        b << "            const double v" << k << " = " << src << " + " << w << ";\n";
+      }
+      if (n == 0) b << "            double res = NEG_INF;\n";
+      else if (maxmode) {
+        b << "            double res = v0;\n";
+        if (tbmode) b << "            unsigned int x = 0u;\n";
+        for (int k = 1; k < n; ++k) {
+          if (tbmode) b << "            { const bool g = v" << k << " > res; res = g ? v" << k << " : res; x = g ? " << k << "u : x; }\n";
+          else b << "            res = dmax(res, v" << k << ");\n";
+        }
+        if (tbmode) b << "            xw[" << d / 4 << "] |= x << " << 8 * (d % 4) << ";\n";
+      } else if (n == 1) b << "            double res = v0;\n";
+      else if (n == 2) b << "            double res = lse2(v0, v1);\n";
+      else {
+        b << "            double mx = dmax(v0, v1);\n";
+        for (int k = 2; k < n; ++k) b << "            mx = dmax(mx, v" << k << ");\n";
+        b << "            const double gM = (mx == NEG_INF) ? 0.0 : mx;\n            const float sm = ex2(v0 - gM)";
+        for (int k = 1; k < n; ++k) b << " + ex2(v" << k << " - gM)";
+        b << ";\n            double res = gM + (double)(__builtin_amdgcn_logf(sm) * SM_LN2);\n";
+      }
+      if (d == P.seedState) b << "            res = ((t | a | lane) == 0) ? 0.0 : res;   // cell(0,0,start) = 0: no other candidate is finite there\n";
+      b << "            " << cp << d << " = res;\n";
+      if (counting && n > 0) {
+        // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
+        const std::string B = CB == 16 ? ("bq" + I(p) + "_" + I(d / 2) + (d % 2 ? ".y" : ".x")) : ("bq" + I(p) + "_" + I(d));
+        b << "            const double bl = active ? (" << B << " + negLL) : NEG_INF;\n";
+        for (int k = 0; k < n; ++k) {
+          const SmSlot &sl = cs[k];
+          if (sl.T == 3) b << "            aS" << sl.tab << " += ex2(v" << k << " + bl);\n";
+          else if (sl.T == 1) b << "            aI" << sl.tab << " += ex2(v" << k << " + bl);\n";
+          else if (sl.T == 2) b << "            lds_add_f32(rowp + " << (long long)sl.tab * (P.nOut + 1) << ", ex2(v" << k << " + bl));\n";
+          else b << "            lds_add_f32(rowp + " << (long long)(P.nTab[2] + sl.tab) * (P.nOut + 1) << ", ex2(v" << k << " + bl));\n";
+        }
+      }
+      b << "          }\n";
+    }
+    // ---- outputs of the step ----
+    if (materialise) {
+      b << "          if (active) {\n            double *dst = poolPair + ((long long)(a * Te + t) * (JNCH * 64) + lane) * (JCHB / 8);\n";
+      for (int k = 0; k < NCH; ++k) {
+        if (CB == 16) b << "            { d2 v; v.x = " << cp << 2 * k << "; v.y = " << cp << 2 * k + 1 << "; *(d2 *)(dst + " << k * 128 << ") = v; }\n";
+        else b << "            dst[" << k * 64 << "] = " << cp << k << ";\n";
+      }
+      b << "          }\n";
+    }
+    if (tbmode) {
+      b << "          if (active) {\n            unsigned int *tp = (unsigned int *)(tbPair + ((long long)(a * Te + t) * 64 + lane) * JTBSTRIDE);\n";
+      for (int k = 0; k < small_tb_stride(S) / 4; ++k) b << "            tp[" << k << "] = xw[" << k << "];\n";
+      b << "          }\n";
+    }
+    if (P.H > 0) {
+      b << "          if (lane == 63 && a + 1 < NA && o >= 0 && o <= outLen) {\n";
+      for (size_t k = 0; k < P.needLeft.size(); ++k) b << "            haloOut[(long long)o * JH + " << k << "] = " << cp << P.needLeft[k] << ";\n";
+      b << "          }\n";
+    }
+    b << "          if (active && i == inLen && o == outLen) A.loglike[pairIdx] = " << cp << P.endState << ";\n";
+    if (counting) {
+      b << "          { const double *bp = bPtr(o + 2);\n";
+      for (int k = 0; k < NCH; ++k)
+        b << "            bq" << p << "_" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
+      b << "          }\n";
+    }
+    b << "        }\n";
+    return b.str();
+  };
+  if (counting) {
+    // lane sums -> the workgroup's table.  Silent transitions: the edge is known here; input-token transitions: the edge
+    // of this lane's input token; output-token and match rows: one entry per output token.
+    for (int k = 0; k < P.nTab[3]; ++k) flush << "    lds_add_f64(accT + " << P.eid[(size_t)(P.off[3] + k)] << ", (double)aS" << k << ");\n";
+    for (int k = 0; k < P.nTab[1]; ++k)
+      flush << "    { const int e = A.eid[JOFFIN + " << (long long)k * (P.nIn + 1) << " + it]; if (e >= 0) lds_add_f64(accT + e, (double)aI" << k << "); }\n";
+    flush << "    for (int k = 0; k < " << P.nTab[2] << "; ++k)\n      for (int x = 1; x <= JNOUT; ++x) {\n"
+          << "        const int e = A.eid[JOFFOUT + k * (JNOUT + 1) + x]; const float r = rowL[k * (JNOUT + 1) + x];\n"
+          << "        if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n      }\n";
+    flush << "    for (int k = 0; k < " << P.nTab[0] << "; ++k)\n      for (int x = 1; x <= JNOUT; ++x) {\n"
+          << "        const int e = A.eid[JOFFMAT + k * ((JNIN + 1) * (JNOUT + 1)) + mrow + x]; const float r = rowL[(" << P.nTab[2] << " + k) * (JNOUT + 1) + x];\n"
+          << "        if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n      }\n";
+  }
+  std::string src = kSmallSkeleton;
+  auto replace = [&](const std::string &mark, const std::string &with) {
+    const size_t p = src.find(mark);
+    if (p != std::string::npos) src.replace(p, mark.size(), with);
+  };
+  replace("/*@DEFS@*/", defs.str());
+  replace("/*@WEIGHTS@*/", weights.str());
+  replace("/*@STATE@*/", state.str());
+  replace("/*@LOADBND@*/", loadb.str());
+  replace("/*@SAVEBND@*/", saveb.str());
+  replace("/*@STEP0@*/", step(0));
+  replace("/*@STEP1@*/", step(1));
+  replace("/*@FLUSH@*/", flush.str());
+  return src;
+}
+
+bool small_jit_get(SmallProgram &P, int mode, bool materialise) {
+  SmJit &J = P.jit[mode][materialise ? 1 : 0];
+  if (J.tried) return J.func != nullptr;
+  J.tried = true;
+  if (!P.ok) return false;
+  J.ldsBytes = small_jit_lds_bytes(P, mode);
+  if (J.ldsBytes > 160 * 1024) { set_error("small-machine kernel: tables exceed the LDS"); return false; }
+  const std::string src = small_jit_source(P, mode, materialise);
+  if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
+    const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
+    if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+  }
+  std::string code, log;
+  if (!jit_compile(src, "mb_small_jit.hip", code, &log, nullptr)) {
+    if (getenv("MB_SMALL_JIT_VERBOSE") || getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
+    set_error("run-time compilation of the small-machine kernel failed: " + log.substr(0, 400));
+    return false;
+  }
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("small-machine kernel: hipModuleLoadData failed"); return false; }
+  if (hipModuleGetFunction(&fn, mod, "k_small_jit") != hipSuccess) { (void)hipModuleUnload(mod); set_error("small-machine kernel: entry point missing"); return false; }
+  (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  J.module = mod; J.func = fn;
+  return true;
+}
+
+// the count sweep keeps one usage row per lane in LDS: machines with many output-token / match tables do not fit
+bool small_count_fits(const SmallProgram &P) { return P.ok && small_jit_lds_bytes(P, SM_COUNT) <= 96 * 1024; }
+
+// ---- one sweep: the wavefront of tiles --------------------------------------------------------------------------------------
+struct SmallArgsHost {   // must match SmallArgs in the generated source
+  const PairDesc *pairs; const int *inTok; const int *outTok;
+  const int4 *tiles; int tileBase, tileEnd, TS, nRep;
+  double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
+  double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
+};
+
+// Steps per tile: the longest tile that still leaves ~12 tiles per CU in an average launch; 64 (the minimum: a tile must
+// not run ahead of the halo rows the strip to its left has produced) when the batch cannot fill the chip anyway.
+static int pick_tile_steps(const std::vector<PairDesc> &pairs) {
+  const int forced = env_int_s("MB_SMALL_TS", 0);
+  if (forced >= 64 && forced % 64 == 0) return forced;
+  int best = 64;
+  for (int TS : {128, 256, 512}) {
+    long long tiles = 0; int nLaunch = 0;
+    for (const PairDesc &pd : pairs) {
+      const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+      tiles += (long long)NA * NB;
+      nLaunch = std::max(nLaunch, 2 * (NA - 1) + NB);
+    }
+    if (tiles / std::max(nLaunch, 1) >= 3072) best = TS;
+  }
+  return best;
+}
+
+int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st) {
+  const std::vector<PairDesc> &pairs = *sw.pairs;
+  if (pairs.empty()) return 0;
+  if (!small_jit_get(P, mode, materialise)) return 1;
+  const SmJit &J = P.jit[mode][materialise ? 1 : 0];
+  const int TS = pick_tile_steps(pairs);
+  int nLaunch = 0;
+  for (const PairDesc &pd : pairs) {
+    const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+    nLaunch = std::max(nLaunch, 2 * (NA - 1) + NB);
+  }
+  std::vector<long long> cnt(nLaunch + 1, 0);
+  for (const PairDesc &pd : pairs) {
+    const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) cnt[2 * a + b]++;
+  }
+  std::vector<long long> off(nLaunch + 1, 0);
+  for (int l = 0; l < nLaunch; ++l) off[l + 1] = off[l] + cnt[l];
+  if (off[nLaunch] > 0x7fffffffLL) { set_error("too many tiles in one sweep"); return 1; }
+  std::vector<int4> tiles((size_t)off[nLaunch]);
+  {
+    std::vector<long long> fill(off.begin(), off.end() - 1);
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      const PairDesc &pd = pairs[p];
+      const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+      for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, 0);
+    }
+  }
+  int4 *d_tiles = nullptr;
+  if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4)), "hipMalloc(tile list)")) return 1;
+  if (!hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, st), "H2D tile list")) { sm_free(d_tiles); return 1; }
+  SmallArgsHost A{};
+  A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1);
+  A.pool = sw.d_pool; A.tb = sw.d_tb; A.halo = sw.d_halo; A.bound = sw.d_bound; A.aux = sw.d_aux; A.loglike = sw.d_loglike;
+  A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
+  bool ok = true;
+  for (int l = 0; l < nLaunch && ok; ++l) {
+    if (cnt[l] <= 0) continue;
+    ++g_last_launches;
+    A.tileBase = (int)off[l]; A.tileEnd = (int)off[l + 1];
+    void *args[] = {&A};
+    const unsigned grid = (unsigned)((cnt[l] + 3) / 4);
+    ok = hipModuleLaunchKernel((hipFunction_t)J.func, grid, 1, 1, 256, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
+  }
+  if (!ok) set_error("small-machine kernel launch failed");
+  ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipStreamSynchronize(st), "small tile kernels");
+  sm_free(d_tiles);
+  return ok ? 0 : 1;
+}
+
+}  // namespace mb

@@ -1,0 +1,168 @@
+"""The small-machine family (mb_small.cpp: lane = column, states in registers, tile-major matrices, traceback bytes,
+count sweep over the Backward matrix) against the CPU oracle -- GPU tests -- and its host-side program / generated source
+-- CPU tests.
+
+Bars as in test_gpu_parity.py: Viterbi matrices, scores and tracebacks bit-exact; Forward / Backward within FAST_REL of
+the oracle's exact-logsumexp mode (the correction term is evaluated in fp32) and within 1e-4 of the reference's table mode.
+"""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_json
+from machineboss_amd.seqgen import synth_tokens
+
+FAST_REL = 2e-6
+FAST_ABS = 2e-5
+
+
+def close(a, b, rel, abs_=0.0):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    both_ninf = np.isneginf(a) & np.isneginf(b)
+    fin = np.isfinite(a) & np.isfinite(b)
+    if not np.all(both_ninf | fin):
+        return False
+    return bool(np.all(np.abs(a[fin] - b[fin]) <= abs_ + rel * np.abs(b[fin])))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from machineboss_amd import capi as c
+    if c.device_count() == 0:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    return c
+
+
+def _check_pairs(capi, oracle_mod, em, pairs, matrices=True):
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    if matrices:
+        for x, y in pairs:
+            V = dm.fill(capi.MB_VITERBI, x, y)
+            assert capi.last_kernel_name() == "k_small_jit"
+            F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+            assert np.array_equal(V, om.viterbi(x, y))
+            assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+            assert close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    ref = [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs]
+    for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
+        ll = b.forward(flags)
+        assert capi.last_kernel_name() == "k_small_jit"
+        assert close(ll, ref, FAST_REL, FAST_ABS)
+        assert close(ll, [om.loglike(x, y) for x, y in pairs], 1e-4, 1e-4)
+    vll, off, edges = b.viterbi()
+    for k, (x, y) in enumerate(pairs):
+        V = om.viterbi(x, y)
+        assert vll[k] == V[-1, -1, -1]
+        got = edges[off[k]:off[k + 1]]
+        if V[-1, -1, -1] > -math.inf:
+            assert np.array_equal(got, om.traceback(x, y, V))
+        else:
+            assert len(got) == 0
+    counts, s, cll = b.counts()
+    ref_c = np.zeros(em.nTransitions); ref_s = 0.0
+    for (x, y), l in zip(pairs, ref):
+        ref_s += om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT) if l > -math.inf else l
+    assert close(counts, ref_c, 1e-5, 1e-7)
+    assert close(s, ref_s, FAST_REL, FAST_ABS) if math.isfinite(ref_s) else s == ref_s
+    assert close(cll, ref, FAST_REL, FAST_ABS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,shapes", [
+    ("dnapsw", [(37, 53), (0, 0), (0, 9), (11, 0), (63, 1), (64, 64), (65, 130), (200, 70), (130, 260)]),
+    ("protpsw", [(50, 50), (64, 3), (127, 129), (1, 200)]),
+])
+def test_small_presets(capi, oracle_mod, machines, name, shapes):
+    """Single strip, several strips (inLen >= 64), several tiles (outLen + 64 > tile length), empty sequences."""
+    m, em = machines(name, None, useDefaults=True, preset=True)
+    pairs = [synth_tokens(300 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate(shapes)]
+    _check_pairs(capi, oracle_mod, em, pairs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ts", ["64", "128"])
+def test_small_tile_lengths(capi, oracle_mod, machines, monkeypatch, ts):
+    """Every tile length cuts the sweeps differently (boundary records, halo rows): same results."""
+    monkeypatch.setenv("MB_SMALL_TS", ts)
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    pairs = [synth_tokens(500 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(150, 333), (70, 64), (3, 190)])]
+    _check_pairs(capi, oracle_mod, em, pairs, matrices=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,seed", [(2, 1), (3, 2), (5, 3), (8, 4), (12, 5), (16, 6), (7, 7), (9, 8)])
+def test_small_random_machines(capi, oracle_mod, S, seed):
+    """Random machines: odd state counts (8-byte chunks), duplicate edges, several edges per label, match edges, -inf weights."""
+    from randmachine import random_machine, random_seq
+    em = random_machine(S, 3, 4, seed, allow_inf=(seed % 3 == 0))
+    rng = np.random.RandomState(seed)
+    pairs = [(random_seq(rng, il, 3), random_seq(rng, ol, 4)) for il, ol in [(25, 31), (0, 9), (80, 45), (5, 140)]]
+    _check_pairs(capi, oracle_mod, em, pairs)
+
+
+@pytest.mark.gpu
+def test_small_reference_goldens(capi, oracle_mod, machines):
+    """The reference's tiny machines (bitnoise: 1 state... bitstutter-noise) run through this family too when they qualify."""
+    p = load_json("io", "params.json")
+    for name, il, ol in (("bitnoise", 3, 3), ("bitstutter-noise", 5, 9)):
+        m, em = machines(name, p)
+        x, y = synth_tokens(7, il, ol, em.nInTok, em.nOutTok)
+        _check_pairs(capi, oracle_mod, em, [(x, y)])
+
+
+@pytest.mark.gpu
+def test_small_vs_medium_large(capi, machines):
+    """Size-independent check at a larger shape: this family and the tiled family give the same Viterbi scores and paths
+    (bit for bit), Forward log-likelihoods within the fp32-correction tolerance, counts within 1e-6."""
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    pairs = [synth_tokens(900 + k, 700 + 13 * k, 900 - 7 * k, em.nInTok, em.nOutTok) for k in range(6)]
+    b = capi.DeviceBatch.from_pairs(dm, pairs)
+    res = {}
+    for fam in (capi.KERNEL_AUTO, capi.KERNEL_MEDIUM):
+        capi.set_kernel(fam)
+        try:
+            res[fam] = (b.forward(capi.MB_ROLLING), b.forward(capi.MB_MATERIALISE), b.viterbi(), b.counts(), capi.last_kernel_name())
+        finally:
+            capi.set_kernel(capi.KERNEL_AUTO)
+    a, g = res[capi.KERNEL_AUTO], res[capi.KERNEL_MEDIUM]
+    assert a[4] == "k_small_jit" and "k_medium" in g[4]
+    assert close(a[0], g[0], FAST_REL) and close(a[1], g[1], FAST_REL) and close(a[0], a[1], 1e-12)
+    assert np.array_equal(a[2][0], g[2][0]) and np.array_equal(a[2][1], g[2][1]) and np.array_equal(a[2][2], g[2][2])
+    assert close(a[3][0], g[3][0], 1e-5, 1e-6) and close(a[3][1], g[3][1], FAST_REL)
+
+
+# ---- CPU: program structure and generated source ---------------------------------------------------------------------------
+def test_small_source_compiles_for_gfx950(tmp_path, machines):
+    """Every mode of the generated kernel cross-compiles for gfx950 without spills (hipcc needs no GPU)."""
+    from machineboss_amd import capi
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    m, em = machines("protpsw", None, useDefaults=True, preset=True)
+    for mode, backward, mat in ((0, False, True), (0, True, True), (0, False, False), (1, False, True), (2, False, False), (3, False, False)):
+        src = str(tmp_path / ("k%d%d%d.hip" % (mode, backward, mat)))
+        capi.debug_small_source(em, src, mode=mode, backward=backward, materialise=mat)
+        full = src.replace(".hip", "_full.hip")
+        open(full, "w").write("#include <hip/hip_runtime.h>\n" + open(src).read())
+        asm = src.replace(".hip", ".s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics",
+                               "--cuda-device-only", "-S", "-o", asm, full], stderr=subprocess.DEVNULL)
+        txt = open(asm).read()
+        assert ".vgpr_spill_count: 0" in txt and "wave_shr:1" in txt
+        assert not [l for l in txt.splitlines() if l.startswith("\tflat_")]      # LDS / global accesses stay typed (no flat fallback)
+
+
+def test_small_rejects_what_it_cannot_run(machines):
+    """Machines outside the family's envelope (too many states, one-tape) are refused by the generator, so the library
+    falls back to the other families."""
+    from machineboss_amd import capi
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    with pytest.raises(capi.MbError, match="does not qualify"):
+        capi.debug_small_source(em, "/tmp/never.hip")
