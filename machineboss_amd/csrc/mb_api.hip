@@ -459,7 +459,7 @@ static int small_forward(mb_batch *b, int flags, double *loglike) {
     sm_free(d_aux);
     if (rc) break;
   }
-  g_last_kernel = "k_small_jit";
+  g_last_kernel = small_kernel_name(f->smF, SM_SUM, mat);
   if (!rc && !hip_ok(hipMemcpy(loglike, d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
   sm_free(d_ll);
   return rc;
@@ -474,6 +474,10 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
   int rc = 0;
   Timer tm;
   long long written = 0;
+  const bool timing = getenv("MB_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tPrev = now();
+  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip] viterbi %-28s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
   for (const Chunk &c : chunks) {
     const long long np = c.p1 - c.p0;
     SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
@@ -483,8 +487,10 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
       if ((rc = small_prepare(b, c, f->smF, false, true, pl, hp, &d_aux, sw))) break;
       if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       sw.d_loglike = d_ll;
+      lap("chunk set-up");
       tm.start();
       if ((rc = small_sweep(f->smF, SM_TB, false, sw, g_stream))) break;
+      lap("fill (traceback bytes)");
       long long *d_slot = nullptr, *d_len = nullptr; uint32_t *d_path = nullptr;
       if (wantPaths) {
         for (long long p = 0; p < np; ++p) slot[p + 1] = slot[p] + mb_viterbi_path_bound(b->m, hp[p].inLen, hp[p].outLen);
@@ -495,6 +501,7 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
         if ((rc = launch_small_traceback(f->smF, sw.d_pairs, np, b->d_in, b->d_out, sw.d_tb, d_aux, d_ll, d_slot, d_path, d_len, g_stream))) break;
       }
       g_last_ms += tm.stop();
+      lap("traceback kernel");
       if (!hip_ok(hipMemcpy(loglike + c.p0, d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
       if (wantPaths) {
         if (!hip_ok(hipMemcpy(len.data(), d_len, np * sizeof(long long), hipMemcpyDeviceToHost), "D2H path lengths")) { rc = 1; break; }
@@ -515,6 +522,7 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
         if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
         if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
         if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
+        lap("pack + D2H paths");
         for (long long p = 0; p < np; ++p) {
           if (len[p] > 0) written += len[p];
           pathOff[c.p0 + p + 1] = written;
@@ -524,7 +532,7 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
     sm_free(d_aux); sm_free(d_ll);
     if (rc) break;
   }
-  g_last_kernel = "k_small_jit";
+  g_last_kernel = "k_small_tb";
   return rc;
 }
 
@@ -573,7 +581,7 @@ static int small_counts(mb_batch *b, double *counts, double *loglikeSum, double 
     if (loglikeSum) *loglikeSum += s;
   } while (0);
   sm_free(d_rep); sm_free(d_ll); sm_free(d_bll);
-  g_last_kernel = "k_small_jit";
+  g_last_kernel = "k_small_count";
   return rc;
 }
 
@@ -600,7 +608,7 @@ static int small_fill(mb_batch *b, int mode, double *cellsOut) {
     if (!hip_ok(hipMemcpy(cellsOut, d_cells, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) { rc = 1; break; }
   } while (0);
   sm_free(d_aux); sm_free(d_ll);
-  g_last_kernel = "k_small_jit";
+  g_last_kernel = small_kernel_name(P, mode == MB_VITERBI ? SM_MAX : SM_SUM, true);
   return rc;
 }
 

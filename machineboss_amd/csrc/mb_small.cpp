@@ -35,6 +35,7 @@
 #include "mb_small.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -184,13 +185,14 @@ void small_free(SmallProgram &P) {
 
 // ---- LDS budget ---------------------------------------------------------------------------------------------------------
 static long long lds_w_doubles(const SmallProgram &P) { return ((P.nEntries - P.off[2]) + 1) & ~1ll; }
-static int row_floats(const SmallProgram &P) {   // count mode: lane-private usage rows, one float per (output-token / match table, output token)
-  int n = (P.nTab[2] + P.nTab[0]) * (P.nOut + 1);
+static int row_floats(const SmallProgram &P) {   // count mode: lane-private usage rows, one float per (match table, output token)
+  int n = P.nTab[0] * (P.nOut + 1);
   return n | 1;   // odd stride: the 64 rows start in different LDS banks
 }
+static int outacc_floats(const SmallProgram &P) { return (P.nTab[2] * (P.nOut + 1) + 1) & ~1; }   // count mode: usage by (output-token table, token)
 static long long wave_doubles(const SmallProgram &P, int mode) {
   long long d = 32 + 64ll * std::max(P.H, 1);
-  if (mode == SM_COUNT) d += (64ll * row_floats(P) + 1) / 2;
+  if (mode == SM_COUNT) d += (64ll * row_floats(P) + 1) / 2 + outacc_floats(P) / 2;
   return (d + 1) & ~1ll;
 }
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode) {
@@ -227,6 +229,9 @@ __device__ __forceinline__ double shr1(double v, double old) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float shrf(float v, float old) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -240,6 +245,12 @@ __device__ __forceinline__ double lse2(double a, double b) {
   const float e = __builtin_amdgcn_exp2f(df * SM_L2E);
   return mx + (double)(__builtin_amdgcn_logf(1.0f + e) * SM_LN2);
 }
+// sum over the 64 lanes (butterfly through the LDS crossbar; every lane ends up with the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 __device__ __forceinline__ void lds_add_f32(float *p, float x) {
   (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -247,7 +258,7 @@ __device__ __forceinline__ void lds_add_f64(double *p, double x) {
   (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_small_jit(SmallArgs A) {
+extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double *wL = lds;                                          // output-token and match weight tables
@@ -260,7 +271,8 @@ extern "C" __global__ __launch_bounds__(256) void k_small_jit(SmallArgs A) {
   int *tokL = (int *)myL;                                    // output tokens entering lane 0, one block of 64 steps
   double *haloL = myL + 32;                                  // halo rows entering lane 0, same block
 #if JMODE == 3
-  float *rowL = (float *)(haloL + 64 * JHP) + lane * JROWF;  // this lane's usage sums by output token
+  float *rowL = (float *)(haloL + 64 * JHP) + lane * JROWF;  // this lane's usage sums of the match transitions, by output token
+  float *outAcc = (float *)(haloL + 64 * JHP) + 64 * JROWF + (JROWF & 1);   // this wavefront's usage sums of the output-only transitions
 #endif
   for (int j = tid; j < JLDSW; j += 256) wL[j] = (j < JLDSWN) ? A.w[JOFFOUT + j] : 0.0;
 #if JMODE == 3
@@ -306,7 +318,9 @@ extern "C" __global__ __launch_bounds__(256) void k_small_jit(SmallArgs A) {
       const int ab = ib >> 6, cb = ib & 63;
       return poolB + (((long long)ab * Te + (ob + cb)) * (JNCH * 64) + cb) * (JCHB / 8);
     };
+#pragma unroll 1
     for (int j = 0; j < JROWF; ++j) rowL[j] = 0.0f;
+    for (int j = lane; j < JOUTACC; j += 64) outAcc[j] = 0.0f;
 #endif
 /*@STATE@*/
     if (b > 0) {
@@ -355,15 +369,23 @@ extern "C" __global__ __launch_bounds__(256) void k_small_jit(SmallArgs A) {
 
 static std::string I(long long v) { return std::to_string(v); }
 
+// kernel names tell the sweeps apart in a rocprof trace
+const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise) {
+  if (mode == SM_COUNT) return "k_small_count";
+  if (mode == SM_TB) return "k_small_tb";
+  if (mode == SM_MAX) return "k_small_max";
+  return P.backward ? "k_small_sum_bwd" : (materialise ? "k_small_sum_mat" : "k_small_sum_roll");
+}
+
 std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) {
   std::ostringstream defs, weights, state, loadb, saveb, flush;
   const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
   const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
   const int rowF = row_floats(P);
-  defs << "#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
+  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? 3 : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
        << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
        << "\n#define JNBD " << P.NBD << "\n#define JCHB " << CB << "\n#define JNCH " << NCH << "\n#define JTBSTRIDE " << small_tb_stride(S)
-       << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JLDSW " << lds_w_doubles(P)
+       << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
        << "\n#define JLDSWN " << (P.nEntries - P.off[2]) << "\n#define JWAVEDBL " << wave_doubles(P, mode)
        << "\n#define JOFFSIL " << P.off[3] << "\n#define JOFFIN " << P.off[1] << "\n#define JOFFOUT " << P.off[2] << "\n#define JOFFMAT " << P.off[0]
        << "\n#define JENDSTATE " << P.endState << "\n";
@@ -388,15 +410,9 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       for (int k = 0; k < P.nTab[1]; ++k) { state << (first ? "" : ",") << " aI" << k << " = 0.0f"; first = false; }
       state << ";\n";
     }
-    // Backward supercells of the next two steps, fetched two steps ahead
-    for (int p = 0; p < 2; ++p) {
-      state << "    " << (CB == 16 ? "d2" : "double");
-      for (int k = 0; k < NCH; ++k) state << (k ? "," : "") << " bq" << p << "_" << k;
-      state << ";\n    { const double *bp = bPtr(t0 + " << p << " - lane);\n";
-      for (int k = 0; k < NCH; ++k)
-        state << "      bq" << p << "_" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
-      state << "    }\n";
-    }
+    // usage of an output-only transition travels with its output token from lane to lane (one position of the output
+    // sequence visits every column of the strip) and is set down when the token leaves lane 63
+    for (int k = 0; k < P.nTab[2]; ++k) state << "    float aO" << k << " = 0.0f;\n";
   }
   {  // boundary record: cells of the last step, then the left values of the last step (the next step's diagonal)
     int k = 0;
@@ -410,6 +426,21 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
     b << "        {  // step parity " << p << "\n";
     b << "          const int jj = j + " << p << ", t = tb + jj, o = t - lane;\n";
     b << "          const bool active = colValid && o >= 0 && o <= outLen;\n";
+    if (counting) {
+      // the Backward supercell of this step's cell: requested now, used after the Forward values of the step are done
+      b << "          " << (CB == 16 ? "d2" : "double");
+      for (int k = 0; k < NCH; ++k) b << (k ? "," : "") << " bq" << k;
+      b << ";\n          { const double *bp = bPtr(o);\n";
+      for (int k = 0; k < NCH; ++k)
+        b << "            bq" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
+      b << "          }\n";
+    }
+    if (counting && P.nTab[2] > 0) {
+      b << "          if (lane == 63) {\n";
+      for (int k = 0; k < P.nTab[2]; ++k) b << "            lds_add_f32(outAcc + " << (long long)k * (P.nOut + 1) << " + ot, aO" << k << ");\n";
+      b << "          }\n";
+      for (int k = 0; k < P.nTab[2]; ++k) b << "          aO" << k << " = shrf(aO" << k << ", 0.0f);\n";
+    }
     b << "          ot = shri(ot, tokL[jj]);\n";
     for (size_t k = 0; k < P.needLeft.size(); ++k)
       b << "          " << lp << P.needLeft[k] << " = shr1(" << cq << P.needLeft[k] << ", haloL[jj * JH + " << k << "]);\n";
@@ -448,23 +479,14 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       }
       if (d == P.seedState) b << "            res = ((t | a | lane) == 0) ? 0.0 : res;   // cell(0,0,start) = 0: no other candidate is finite there\n";
       b << "            " << cp << d << " = res;\n";
-      if (counting && n > 0) {
-        // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
-        const std::string B = CB == 16 ? ("bq" + I(p) + "_" + I(d / 2) + (d % 2 ? ".y" : ".x")) : ("bq" + I(p) + "_" + I(d));
-        b << "            const double bl = active ? (" << B << " + negLL) : NEG_INF;\n";
-        for (int k = 0; k < n; ++k) {
-          const SmSlot &sl = cs[k];
-          if (sl.T == 3) b << "            aS" << sl.tab << " += ex2(v" << k << " + bl);\n";
-          else if (sl.T == 1) b << "            aI" << sl.tab << " += ex2(v" << k << " + bl);\n";
-          else if (sl.T == 2) b << "            lds_add_f32(rowp + " << (long long)sl.tab * (P.nOut + 1) << ", ex2(v" << k << " + bl));\n";
-          else b << "            lds_add_f32(rowp + " << (long long)(P.nTab[2] + sl.tab) * (P.nOut + 1) << ", ex2(v" << k << " + bl));\n";
-        }
-      }
       b << "          }\n";
     }
     // ---- outputs of the step ----
     if (materialise) {
-      b << "          if (active) {\n            double *dst = poolPair + ((long long)(a * Te + t) * (JNCH * 64) + lane) * (JCHB / 8);\n";
+      // every lane stores, also the ones outside the lattice (their slots exist and are never read): a store instruction
+      // then always writes 64 x CB contiguous bytes -- with the inactive lanes masked off the partial cache lines at the two
+      // ends of the active range cost more than the bytes saved (scripts/micro/tile_major_probe.hip: 3.3 vs 5.4 TB/s)
+      b << "          {\n            double *dst = poolPair + ((long long)(a * Te + t) * (JNCH * 64) + lane) * (JCHB / 8);\n";
       for (int k = 0; k < NCH; ++k) {
         if (CB == 16) b << "            { d2 v; v.x = " << cp << 2 * k << "; v.y = " << cp << 2 * k + 1 << "; *(d2 *)(dst + " << k * 128 << ") = v; }\n";
         else b << "            dst[" << k * 64 << "] = " << cp << k << ";\n";
@@ -472,7 +494,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       b << "          }\n";
     }
     if (tbmode) {
-      b << "          if (active) {\n            unsigned int *tp = (unsigned int *)(tbPair + ((long long)(a * Te + t) * 64 + lane) * JTBSTRIDE);\n";
+      b << "          {\n            unsigned int *tp = (unsigned int *)(tbPair + ((long long)(a * Te + t) * 64 + lane) * JTBSTRIDE);\n";
       for (int k = 0; k < small_tb_stride(S) / 4; ++k) b << "            tp[" << k << "] = xw[" << k << "];\n";
       b << "          }\n";
     }
@@ -483,10 +505,26 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
     }
     b << "          if (active && i == inLen && o == outLen) A.loglike[pairIdx] = " << cp << P.endState << ";\n";
     if (counting) {
-      b << "          { const double *bp = bPtr(o + 2);\n";
-      for (int k = 0; k < NCH; ++k)
-        b << "            bq" << p << "_" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
-      b << "          }\n";
+      // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87.  The
+      // candidate is formed again (one fp64 add) rather than kept alive across the step.
+      for (int d : P.order) {
+        const std::vector<SmSlot> &cs = P.cand[d];
+        if (cs.empty()) continue;
+        const std::string B = CB == 16 ? ("bq" + I(d / 2) + (d % 2 ? ".y" : ".x")) : ("bq" + I(d));
+        b << "          {  // usage of the transitions into state " << d << "\n";
+        b << "            const double bl = active ? (" << B << " + negLL) : NEG_INF;\n";
+        for (size_t k = 0; k < cs.size(); ++k) {
+          const SmSlot &sl = cs[k];
+          const std::string src = (sl.T == 0 ? lq : (sl.T == 1 ? lp : (sl.T == 2 ? cq : cp))) + I(sl.src);
+          const std::string w = std::string(sl.T == 0 ? "wM" : (sl.T == 1 ? "wI" : (sl.T == 2 ? "wO" : "wS"))) + I(sl.tab);
+          const std::string term = "ex2((" + src + " + " + w + ") + bl)";
+          if (sl.T == 3) b << "            aS" << sl.tab << " += " << term << ";\n";
+          else if (sl.T == 1) b << "            aI" << sl.tab << " += " << term << ";\n";
+          else if (sl.T == 2) b << "            aO" << sl.tab << " += " << term << ";\n";
+          else b << "            lds_add_f32(rowp + " << (long long)sl.tab * (P.nOut + 1) << ", " << term << ");\n";
+        }
+        b << "          }\n";
+      }
     }
     b << "        }\n";
     return b.str();
@@ -494,15 +532,18 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
   if (counting) {
     // lane sums -> the workgroup's table.  Silent transitions: the edge is known here; input-token transitions: the edge
     // of this lane's input token; output-token and match rows: one entry per output token.
-    for (int k = 0; k < P.nTab[3]; ++k) flush << "    lds_add_f64(accT + " << P.eid[(size_t)(P.off[3] + k)] << ", (double)aS" << k << ");\n";
+    for (int k = 0; k < P.nTab[3]; ++k)
+      flush << "    { const float r = wave_sum(aS" << k << "); if (lane == 0) lds_add_f64(accT + " << P.eid[(size_t)(P.off[3] + k)] << ", (double)r); }\n";
     for (int k = 0; k < P.nTab[1]; ++k)
       flush << "    { const int e = A.eid[JOFFIN + " << (long long)k * (P.nIn + 1) << " + it]; if (e >= 0) lds_add_f64(accT + e, (double)aI" << k << "); }\n";
-    flush << "    for (int k = 0; k < " << P.nTab[2] << "; ++k)\n      for (int x = 1; x <= JNOUT; ++x) {\n"
-          << "        const int e = A.eid[JOFFOUT + k * (JNOUT + 1) + x]; const float r = rowL[k * (JNOUT + 1) + x];\n"
-          << "        if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n      }\n";
-    flush << "    for (int k = 0; k < " << P.nTab[0] << "; ++k)\n      for (int x = 1; x <= JNOUT; ++x) {\n"
-          << "        const int e = A.eid[JOFFMAT + k * ((JNIN + 1) * (JNOUT + 1)) + mrow + x]; const float r = rowL[(" << P.nTab[2] << " + k) * (JNOUT + 1) + x];\n"
-          << "        if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n      }\n";
+    for (int k = 0; k < P.nTab[2]; ++k) flush << "    lds_add_f32(outAcc + " << (long long)k * (P.nOut + 1) << " + ot, aO" << k << ");\n";
+    flush << "    wave_sync();\n";
+    flush << "#pragma unroll 1\n    for (int j = lane; j < " << P.nTab[2] * (P.nOut + 1) << "; j += 64) {\n"
+          << "      const int e = A.eid[JOFFOUT + j]; const float r = outAcc[j];\n"
+          << "      if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n    }\n";
+    flush << "#pragma unroll 1\n    for (int k = 0; k < " << P.nTab[0] << "; ++k) {\n#pragma unroll 1\n      for (int x = 1; x <= JNOUT; ++x) {\n"
+          << "        const int e = A.eid[JOFFMAT + k * ((JNIN + 1) * (JNOUT + 1)) + mrow + x]; const float r = rowL[k * (JNOUT + 1) + x];\n"
+          << "        if (e >= 0 && r != 0.0f) lds_add_f64(accT + e, (double)r);\n      }\n    }\n";
   }
   std::string src = kSmallSkeleton;
   auto replace = [&](const std::string &mark, const std::string &with) {
@@ -541,7 +582,7 @@ bool small_jit_get(SmallProgram &P, int mode, bool materialise) {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("small-machine kernel: hipModuleLoadData failed"); return false; }
-  if (hipModuleGetFunction(&fn, mod, "k_small_jit") != hipSuccess) { (void)hipModuleUnload(mod); set_error("small-machine kernel: entry point missing"); return false; }
+  if (hipModuleGetFunction(&fn, mod, small_kernel_name(P, mode, materialise)) != hipSuccess) { (void)hipModuleUnload(mod); set_error("small-machine kernel: entry point missing"); return false; }
   (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   J.module = mod; J.func = fn;
   return true;
@@ -579,7 +620,12 @@ static int pick_tile_steps(const std::vector<PairDesc> &pairs) {
 int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st) {
   const std::vector<PairDesc> &pairs = *sw.pairs;
   if (pairs.empty()) return 0;
+  const bool timing = getenv("MB_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tPrev = now();
+  auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip]   sweep %-24s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
   if (!small_jit_get(P, mode, materialise)) return 1;
+  lap("kernel lookup / jit");
   const SmJit &J = P.jit[mode][materialise ? 1 : 0];
   const int TS = pick_tile_steps(pairs);
   int nLaunch = 0;
@@ -604,9 +650,11 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
       for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, 0);
     }
   }
+  lap("tile lists");
   int4 *d_tiles = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4)), "hipMalloc(tile list)")) return 1;
   if (!hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, st), "H2D tile list")) { sm_free(d_tiles); return 1; }
+  lap("tile list upload");
   SmallArgsHost A{};
   A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1);
   A.pool = sw.d_pool; A.tb = sw.d_tb; A.halo = sw.d_halo; A.bound = sw.d_bound; A.aux = sw.d_aux; A.loglike = sw.d_loglike;
@@ -620,8 +668,10 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     const unsigned grid = (unsigned)((cnt[l] + 3) / 4);
     ok = hipModuleLaunchKernel((hipFunction_t)J.func, grid, 1, 1, 256, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
   }
+  lap("launches");
   if (!ok) set_error("small-machine kernel launch failed");
   ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipStreamSynchronize(st), "small tile kernels");
+  lap("stream synchronize");
   sm_free(d_tiles);
   return ok ? 0 : 1;
 }

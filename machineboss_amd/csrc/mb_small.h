@@ -68,6 +68,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise);
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode);
 bool small_jit_get(SmallProgram &P, int mode, bool materialise);
 bool small_count_fits(const SmallProgram &P);
+const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise);
 
 // Per-pair placement of the buffers a sweep uses (all offsets relative to the chunk's workspaces)
 struct SmAux { long long pool, halo, bound, tb; };

@@ -33,7 +33,7 @@ int launch_small_unpack(const double *d_pool, int S, int inLen, int outLen, bool
 // DPMatrix::traceBack with selectMaxTrans (src/dpmatrix.defs.h:82-110,171-174) over the traceback bytes the SM_TB sweep
 // stored: byte (i,o,s) = index of the first maximal candidate of that cell in the reference's enumeration order (match,
 // input-only, output-only, silent; ascending source state, then insertion order), which is the choice std::max_element
-// makes there.  One LANE per pair: a step is a byte load and two table look-ups, no candidate is re-evaluated.
+// makes there.  One LANE per pair: a step is a byte and two table look-ups, no candidate is re-evaluated.
 // Edge ids are written backwards from the end of the pair's slot; pathLen[p] = number of transitions (-1: end cell is
 // -inf, -2: slot too small).
 struct SmTbTables {
@@ -42,11 +42,27 @@ struct SmTbTables {
   int S, nIn, nOut, tbStride;
 };
 
-__global__ __launch_bounds__(64) void k_small_traceback(SmTbTables T, const PairDesc *__restrict__ pairs, long long nPairs,
+// The walk is a chain of dependent look-ups, so what matters is the number of trips to memory per path step:
+//   * the traceback bytes of a supercell are one to four dwords; the lane holds the dwords of the supercell it stands on, so
+//     silent moves (same supercell) cost no memory access;
+//   * on arrival at a supercell the dwords of its three possible predecessors (i-1,o-1), (i-1,o), (i,o-1) and the two
+//     tokens in[i-2], out[o-2] are requested at once; the move into one of them happens after the silent chain in
+//     between, so an emitting move costs at most ONE memory round trip;
+//   * the decode and edge-id tables sit in LDS.
+template <int NW>
+__global__ __launch_bounds__(64) void k_small_traceback(SmTbTables T, int nDec, int nEid, const PairDesc *__restrict__ pairs, long long nPairs,
                                                         const int *__restrict__ inTok, const int *__restrict__ outTok,
                                                         const unsigned char *__restrict__ tb, const SmAux *__restrict__ aux,
                                                         const double *__restrict__ ll, const long long *__restrict__ slotOff,
                                                         uint32_t *__restrict__ pathBuf, long long *__restrict__ pathLen) {
+  extern __shared__ int tbl[];
+  int *lDecOff = tbl;                          // [S + 1]
+  uint32_t *lDec = (uint32_t *)(tbl + T.S + 1);   // [nDec]
+  int *lEid = (int *)(lDec + nDec);            // [nEid] (0: the table stays in global memory)
+  for (int k = threadIdx.x; k <= T.S; k += 64) lDecOff[k] = T.decOff[k];
+  for (int k = threadIdx.x; k < nDec; k += 64) lDec[k] = T.dec[k];
+  for (int k = threadIdx.x; k < nEid; k += 64) lEid[k] = T.eid[k];
+  __syncthreads();
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nPairs) return;
   if (!(ll[p] > -INFINITY)) { pathLen[p] = -1; return; }
@@ -54,26 +70,45 @@ __global__ __launch_bounds__(64) void k_small_traceback(SmTbTables T, const Pair
   const int inLen = pd.inLen, outLen = pd.outLen;
   const int Te = small_steps(outLen);
   const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
-  const unsigned char *bytes = tb + aux[p].tb;
+  const uint32_t *words = (const uint32_t *)(tb + aux[p].tb);
   const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  struct Cell { uint32_t w[NW]; };
+  auto load = [&](int ci, int co) -> Cell {   // clamped: cells outside the lattice are never moved into
+    Cell c;
+    const int x = max(ci, 0), y = max(co, 0);
+    const uint32_t *q = words + (((long long)(x >> 6) * Te + (y + (x & 63))) * 64 + (x & 63)) * NW;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) c.w[k] = q[k];
+    return c;
+  };
   int i = inLen, o = outLen, s = T.S - 1;
+  int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+  Cell cur = load(i, o), cd = load(i - 1, o - 1), cl = load(i - 1, o), cu = load(i, o - 1);
+  int itP = i > 1 ? in[i - 2] : 0, otP = o > 1 ? out[o - 2] : 0;
   long long n = 0;
   while (i > 0 || o > 0 || s != 0) {
-    const int a = i >> 6, c = i & 63;
-    const unsigned k = bytes[(((long long)a * Te + (o + c)) * 64 + c) * T.tbStride + s];
-    const uint32_t d = T.dec[T.decOff[s] + (int)k];
+    uint32_t wv = cur.w[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) wv = (s >> 2) == k ? cur.w[k] : wv;
+    const unsigned kc = (wv >> (8 * (s & 3))) & 255u;
+    const uint32_t d = lDec[lDecOff[s] + (int)kc];
     const int kind = (int)(d & 255u), src = (int)((d >> 8) & 255u), tab = (int)(d >> 16);
-    const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
     long long e;
     if (kind == 0) e = T.off0 + (long long)tab * (T.nIn + 1) * (T.nOut + 1) + (long long)it * (T.nOut + 1) + ot;
     else if (kind == 1) e = T.off1 + (long long)tab * (T.nIn + 1) + it;
     else if (kind == 2) e = T.off2 + (long long)tab * (T.nOut + 1) + ot;
     else e = T.off3 + tab;
     if (n >= cap) { pathLen[p] = -2; return; }
-    pathBuf[slot0 + cap - 1 - n] = (uint32_t)T.eid[e];
+    pathBuf[slot0 + cap - 1 - n] = (uint32_t)(nEid ? lEid[e] : T.eid[e]);
     ++n;
-    if (kind == 0) { --i; --o; } else if (kind == 1) --i; else if (kind == 2) --o;
     s = src;
+    if (kind != 3) {
+      if (kind == 0) { cur = cd; --i; --o; it = itP; ot = otP; }
+      else if (kind == 1) { cur = cl; --i; it = itP; }
+      else { cur = cu; --o; ot = otP; }
+      cd = load(i - 1, o - 1); cl = load(i - 1, o); cu = load(i, o - 1);
+      itP = i > 1 ? in[i - 2] : 0; otP = o > 1 ? out[o - 2] : 0;
+    }
   }
   pathLen[p] = n;
 }
@@ -86,8 +121,15 @@ int launch_small_traceback(const SmallProgram &P, const PairDesc *d_pairs, long 
   T.decOff = P.d_decOff; T.dec = P.d_dec; T.eid = P.d_eid;
   T.off0 = P.off[0]; T.off1 = P.off[1]; T.off2 = P.off[2]; T.off3 = P.off[3];
   T.S = P.S; T.nIn = P.nIn; T.nOut = P.nOut; T.tbStride = small_tb_stride(P.S);
-  hipLaunchKernelGGL(k_small_traceback, dim3((unsigned)((nPairs + 63) / 64)), dim3(64), 0, st, T, d_pairs, nPairs, d_in, d_out, d_tb,
-                     d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen);
+  const int nDec = (int)P.dec.size(), nEid = P.nEntries <= 12288 ? (int)P.nEntries : 0;
+  const size_t lds = (size_t)(P.S + 1 + nDec + nEid) * 4;
+  const dim3 grid((unsigned)((nPairs + 63) / 64)), block(64);
+  switch (T.tbStride / 4) {
+    case 1: hipLaunchKernelGGL(k_small_traceback<1>, grid, block, lds, st, T, nDec, nEid, d_pairs, nPairs, d_in, d_out, d_tb, d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen); break;
+    case 2: hipLaunchKernelGGL(k_small_traceback<2>, grid, block, lds, st, T, nDec, nEid, d_pairs, nPairs, d_in, d_out, d_tb, d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen); break;
+    case 3: hipLaunchKernelGGL(k_small_traceback<3>, grid, block, lds, st, T, nDec, nEid, d_pairs, nPairs, d_in, d_out, d_tb, d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen); break;
+    default: hipLaunchKernelGGL(k_small_traceback<4>, grid, block, lds, st, T, nDec, nEid, d_pairs, nPairs, d_in, d_out, d_tb, d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen); break;
+  }
   return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
 }
 

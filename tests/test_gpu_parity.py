@@ -656,7 +656,7 @@ def test_baseline_configs_full_size_properties(capi, machines, preset, config, n
     b = capi.DeviceBatch(dm, inTok, inOff, outTok, outOff)
     assert b.cells() == nPairs * (il + 1) * (ol + 1) * em.nStates
     llm = b.forward(capi.MB_MATERIALISE); llr = b.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() == ("k_medium_jit" if preset == "psw2dna" else "k_small_jit")
+    assert capi.last_kernel_name() == ("k_medium_jit" if preset == "psw2dna" else "k_small_sum_roll")
     assert np.all(np.isfinite(llm)) and close(llr, llm, 1e-12) and llm[0] == llm[1] and llr[0] == llr[1]
     npv = min(nPairs, 64)    # tracebacks of a sub-batch (the fill of all pairs is checked through the log-likelihoods)
     bv = capi.DeviceBatch(dm, inTok[:inOff[npv]], inOff[:npv + 1], outTok[:outOff[npv]], outOff[:npv + 1])

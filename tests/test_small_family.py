@@ -43,7 +43,7 @@ def _check_pairs(capi, oracle_mod, em, pairs, matrices=True):
     if matrices:
         for x, y in pairs:
             V = dm.fill(capi.MB_VITERBI, x, y)
-            assert capi.last_kernel_name() == "k_small_jit"
+            assert capi.last_kernel_name().startswith("k_small_")
             F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
             assert np.array_equal(V, om.viterbi(x, y))
             assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
@@ -52,7 +52,7 @@ def _check_pairs(capi, oracle_mod, em, pairs, matrices=True):
     ref = [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs]
     for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
         ll = b.forward(flags)
-        assert capi.last_kernel_name() == "k_small_jit"
+        assert capi.last_kernel_name().startswith("k_small_")
         assert close(ll, ref, FAST_REL, FAST_ABS)
         assert close(ll, [om.loglike(x, y) for x, y in pairs], 1e-4, 1e-4)
     vll, off, edges = b.viterbi()
@@ -132,7 +132,7 @@ def test_small_vs_medium_large(capi, machines):
         finally:
             capi.set_kernel(capi.KERNEL_AUTO)
     a, g = res[capi.KERNEL_AUTO], res[capi.KERNEL_MEDIUM]
-    assert a[4] == "k_small_jit" and "k_medium" in g[4]
+    assert a[4].startswith("k_small_") and "k_medium" in g[4]
     assert close(a[0], g[0], FAST_REL) and close(a[1], g[1], FAST_REL) and close(a[0], a[1], 1e-12)
     assert np.array_equal(a[2][0], g[2][0]) and np.array_equal(a[2][1], g[2][1]) and np.array_equal(a[2][2], g[2][2])
     assert close(a[3][0], g[3][0], 1e-5, 1e-6) and close(a[3][1], g[3][1], FAST_REL)
