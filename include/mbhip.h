@@ -154,6 +154,14 @@ int mb_set_kernel(int which);
 int mb_set_memory_budget(size_t bytes);
 /* The library keeps its matrix pools allocated between calls (grow-only); this frees them. */
 int mb_release_workspace(void);
+/* Run-time compilation (hiprtc) done by this process so far: wall-clock milliseconds, compiles, and code objects taken
+ * from the on-disk cache instead ($MB_JIT_CACHE_DIR, default ~/.cache/mbhip; MB_JIT_CACHE=0 disables it). */
+int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits);
+/* Tuning knobs (kernel family thresholds, strip geometry, closure stages ...: DESIGN.md section 4.4).  They are read when
+ * a machine's programs and kernels are built, from the process environment; these calls are the same switchboard for a
+ * host that prefers calls.  Names start with "MB_"; value NULL or "" restores the default. */
+int mb_set_option(const char *name, const char *value);
+const char *mb_get_option(const char *name);
 
 /* Writes the HIP source the run-time code generator produces for this machine (mode MB_FORWARD = sum semiring,
  * MB_VITERBI = max, 3 = Forward fused with posterior counts; backward and closure (0 = levelled, K >= 1 = silent closure in

@@ -25,6 +25,7 @@ EXPORTS = [
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source",
+    "mb_jit_stats", "mb_set_option", "mb_get_option",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
@@ -81,6 +82,9 @@ def load():
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_debug_small_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                         C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_jit_stats.argtypes = [dp, i64p, i64p]
+    L.mb_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.mb_get_option.argtypes = [C.c_char_p]; L.mb_get_option.restype = C.c_char_p
     L.mb_comm_unique_id.argtypes = [C.c_char_p]
     L.mb_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int]; L.mb_comm_init.restype = vp
     L.mb_comm_destroy.argtypes = [vp]; L.mb_comm_destroy.restype = None
@@ -116,6 +120,17 @@ def set_memory_budget(nbytes: int):
 
 def release_workspace():
     _check(load().mb_release_workspace())
+
+
+def jit_stats() -> dict:
+    """hiprtc work done by this process: compile wall time, number of compiles, code objects served by the disk cache."""
+    ms = C.c_double(0.0); n = C.c_int64(0); h = C.c_int64(0)
+    _check(load().mb_jit_stats(C.byref(ms), C.byref(n), C.byref(h)))
+    return {"compile_ms": round(ms.value, 1), "compiles": n.value, "cache_hits": h.value}
+
+
+def set_option(name: str, value=None):
+    _check(load().mb_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
 def last_device_ms() -> float:

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mb_internal.h"
+#include "mb_jit.h"
 #include "mb_medium.h"
 #include "mb_small.h"
 #include "mb_wide.h"
@@ -34,6 +35,19 @@ bool hip_ok(hipError_t e, const char *what) {
   return false;
 }
 
+// One lock for every entry point that touches the process-wide state (stream, workspaces, compiled programs): the reference
+// has no threads on this path and the library is built for one host thread per process, but two threads calling in
+// must not corrupt the pools.  The outermost entry also un-pins the workspaces of the previous call.
+static std::recursive_mutex g_api_mutex;
+static int g_api_depth = 0;
+static void ws_begin_call();
+struct ApiGuard {
+  std::lock_guard<std::recursive_mutex> lk;
+  ApiGuard() : lk(g_api_mutex) { if (g_api_depth++ == 0) ws_begin_call(); }
+  ~ApiGuard() { --g_api_depth; }
+};
+static int g_device = -1;   // device the library's stream and workspaces live on
+
 static int ensure_init() {
   if (g_init) return 0;
   int n = 0;
@@ -41,6 +55,7 @@ static int ensure_init() {
     set_error("no HIP device visible: the Machine Boss DP engine has no CPU fallback");
     return 1;
   }
+  MB_HIP(hipGetDevice(&g_device));
   MB_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_init = true;
   return 0;
@@ -57,7 +72,7 @@ static size_t cached_bytes() { size_t t = 0; for (const Workspace &w : g_ws) t +
 // A slot handed out during the current API call is pinned until the next call begins; growing one slot may release every
 // unpinned one (a Viterbi batch that needs 80 % of HBM in slot 0 must be able to reclaim the Backward pool a previous
 // count sweep left in slot 1 -- budget_bytes() counts cached bytes as available).
-static void ws_begin_call() { for (Workspace &w : g_ws) w.pinned = false; }
+static void ws_begin_call() { for (Workspace &w : g_ws) w.pinned = false; }   // (declared above, next to ApiGuard)
 static void ws_release_unpinned(int except) {
   for (int k = 0; k < WS_SLOTS; ++k) {
     Workspace &w = g_ws[k];
@@ -118,10 +133,60 @@ void sm_free(void *p) {
   (void)hipFree(p);
 }
 
+// Large device -> host copies into caller-owned (pageable) memory go through two pinned staging buffers: a hipMemcpy
+// straight into fresh pageable pages pins them on the fly, which now and then costs tens of milliseconds for a 15 MB
+// path array; the staged copy runs at the PCIe rate and overlaps the host-side memcpy of chunk k with the DMA of k+1.
+static void *g_pinned[2] = {nullptr, nullptr};
+static const size_t PINNED_CHUNK = (size_t)8 << 20;
+static int d2h_large(void *dst, const void *srcDev, size_t bytes) {
+  if (bytes < ((size_t)1 << 20)) {
+    if (!hip_ok(hipMemcpyAsync(dst, srcDev, bytes, hipMemcpyDeviceToHost, g_stream), "D2H")) return 1;
+    return hip_ok(hipStreamSynchronize(g_stream), "D2H") ? 0 : 1;
+  }
+  for (int k = 0; k < 2; ++k)
+    if (!g_pinned[k] && !hip_ok(hipHostMalloc(&g_pinned[k], PINNED_CHUNK, hipHostMallocDefault), "hipHostMalloc(staging)")) return 1;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) if (!hip_ok(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming), "hipEventCreate")) return 1;
+  const size_t nChunks = (bytes + PINNED_CHUNK - 1) / PINNED_CHUNK;
+  int rc = 0;
+  auto issue = [&](size_t c) {
+    const size_t off = c * PINNED_CHUNK, n = std::min(PINNED_CHUNK, bytes - off);
+    if (!hip_ok(hipMemcpyAsync(g_pinned[c & 1], (const char *)srcDev + off, n, hipMemcpyDeviceToHost, g_stream), "D2H (staged)")) return 1;
+    return hip_ok(hipEventRecord(ev[c & 1], g_stream), "hipEventRecord") ? 0 : 1;
+  };
+  rc = issue(0);
+  for (size_t c = 0; c < nChunks && !rc; ++c) {
+    if (c + 1 < nChunks) rc = issue(c + 1);
+    if (rc || !hip_ok(hipEventSynchronize(ev[c & 1]), "hipEventSynchronize")) { rc = 1; break; }
+    const size_t off = c * PINNED_CHUNK, n = std::min(PINNED_CHUNK, bytes - off);
+    std::memcpy((char *)dst + off, g_pinned[c & 1], n);
+  }
+  if (rc) (void)hipStreamSynchronize(g_stream);
+  for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
+  return rc;
+}
+
+int h2d_large(void *dstDev, const void *src, size_t bytes) {
+  if (bytes < ((size_t)256 << 10)) {
+    if (!hip_ok(hipMemcpyAsync(dstDev, src, bytes, hipMemcpyHostToDevice, g_stream), "H2D")) return 1;
+    return 0;   // small pageable copies are staged by the runtime itself before the call returns
+  }
+  for (int k = 0; k < 2; ++k)
+    if (!g_pinned[k] && !hip_ok(hipHostMalloc(&g_pinned[k], PINNED_CHUNK, hipHostMallocDefault), "hipHostMalloc(staging)")) return 1;
+  for (size_t off = 0, c = 0; off < bytes; off += PINNED_CHUNK, ++c) {
+    const size_t n = std::min(PINNED_CHUNK, bytes - off);
+    if (c >= 2 && !hip_ok(hipStreamSynchronize(g_stream), "H2D (staged)")) return 1;   // the buffer about to be overwritten has been read
+    std::memcpy(g_pinned[c & 1], (const char *)src + off, n);
+    if (!hip_ok(hipMemcpyAsync((char *)dstDev + off, g_pinned[c & 1], n, hipMemcpyHostToDevice, g_stream), "H2D (staged)")) return 1;
+  }
+  return hip_ok(hipStreamSynchronize(g_stream), "H2D (staged)") ? 0 : 1;
+}
+
 static void ws_release() {
   for (Workspace &w : g_ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
   for (SmallBlock &b : g_smallFree) (void)hipFree(b.p);
   g_smallFree.clear();
+  for (int k = 0; k < 2; ++k) if (g_pinned[k]) { (void)hipHostFree(g_pinned[k]); g_pinned[k] = nullptr; }
 }
 
 size_t budget_bytes() {
@@ -191,8 +256,8 @@ static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_ou
   long long base = 0;
   for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S; }
   MB_HIP(sm_alloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
-  MB_HIP(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream));
-  MB_HIP(hipStreamSynchronize(g_stream));
+  if (!hip_ok(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream), "H2D pair descriptors") ||
+      !hip_ok(hipStreamSynchronize(g_stream), "H2D pair descriptors")) { sm_free(*d_out); *d_out = nullptr; return 1; }
   return 0;
 }
 
@@ -424,14 +489,20 @@ static bool small_chunks_plan(const mb_batch *b, const SmallProgram &P, bool wan
 }
 
 // buffers of one chunk: aux records uploaded, workspaces sized; fills `sw`
-static int small_prepare(const mb_batch *b, const Chunk &c, const SmallProgram &P, bool wantPool, bool wantTb, SmallPlan &pl,
-                         std::vector<PairDesc> &hp, SmAux **d_aux, SmSweep &sw) {
+static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, bool wantPool, bool wantTb, SmallPlan &pl,
+                         std::vector<PairDesc> &hp, SmAux **d_aux, SmSweep &sw, size_t chunkNo = (size_t)-1) {
   hp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
   small_plan(P, hp.data(), (long long)hp.size(), wantPool, wantTb, pl);
-  MB_HIP(sm_alloc((void **)d_aux, hp.size() * sizeof(SmAux)));
+  MB_HIP(sm_alloc((void **)d_aux, hp.size() * sizeof(SmAux)));   // (the caller frees *d_aux on every path)
   MB_HIP(hipMemcpyAsync(*d_aux, pl.aux.data(), hp.size() * sizeof(SmAux), hipMemcpyHostToDevice, g_stream));
   sw = SmSweep();
   sw.d_pairs = b->d_pairs + c.p0; sw.pairs = &hp; sw.d_in = b->d_in; sw.d_out = b->d_out; sw.d_aux = *d_aux;
+  if (chunkNo != (size_t)-1) {
+    if (b->smTiles.size() <= chunkNo) b->smTiles.resize(chunkNo + 1);
+    SmTileCache &tc = b->smTiles[chunkNo];
+    if (tc.p0 != c.p0 || tc.p1 != c.p1) { if (tc.d_tiles) (void)hipFree(tc.d_tiles); tc = SmTileCache(); tc.p0 = c.p0; tc.p1 = c.p1; }
+    sw.tileCache = &tc;
+  }
   if (wantPool && !(sw.d_pool = (double *)ws_get(0, (size_t)std::max<long long>(pl.poolD, 1) * 8))) return 1;
   if (wantTb && !(sw.d_tb = (unsigned char *)ws_get(8, (size_t)std::max<long long>(pl.tbB, 16)))) return 1;
   if (!(sw.d_halo = (double *)ws_get(9, (size_t)std::max<long long>(pl.haloD, 1) * 8))) return 1;
@@ -448,9 +519,10 @@ static int small_forward(mb_batch *b, int flags, double *loglike) {
   MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
   Timer tm;
+  size_t chunkNo = 0;
   for (const Chunk &c : chunks) {
     SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
-    if (!(rc = small_prepare(b, c, f->smF, mat, false, pl, hp, &d_aux, sw))) {
+    if (!(rc = small_prepare(b, c, f->smF, mat, false, pl, hp, &d_aux, sw, chunkNo++))) {
       sw.d_loglike = d_ll + c.p0;
       tm.start();
       rc = small_sweep(f->smF, SM_SUM, mat, sw, g_stream);
@@ -478,13 +550,14 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tPrev = now();
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip] viterbi %-28s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
+  size_t chunkNo = 0;
   for (const Chunk &c : chunks) {
     const long long np = c.p1 - c.p0;
     SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
     double *d_ll = nullptr;
     std::vector<long long> slot(np + 1, 0), len(np, 0);
     do {
-      if ((rc = small_prepare(b, c, f->smF, false, true, pl, hp, &d_aux, sw))) break;
+      if ((rc = small_prepare(b, c, f->smF, false, true, pl, hp, &d_aux, sw, chunkNo++))) break;
       if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       sw.d_loglike = d_ll;
       lap("chunk set-up");
@@ -520,7 +593,7 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
         if (!d_off || !d_packed) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_off, off.data(), np * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
         if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
-        if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
+        if (total && d2h_large(pathEdges + written, d_packed, total * sizeof(uint32_t))) { rc = 1; break; }
         if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
         lap("pack + D2H paths");
         for (long long p = 0; p < np; ++p) {
@@ -552,9 +625,10 @@ static int small_counts(mb_batch *b, double *counts, double *loglikeSum, double 
     if (!hip_ok(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)), "hipMalloc")) { rc = 1; break; }
     if (!hip_ok(sm_alloc((void **)&d_bll, b->nPairs * sizeof(double)), "hipMalloc")) { rc = 1; break; }
     if (!hip_ok(hipMemsetAsync(d_rep, 0, std::max<long long>(nT, 1) * SMALL_COUNT_REPLICAS * sizeof(double), g_stream), "memset")) { rc = 1; break; }
-    for (const Chunk &c : chunks) {
+    size_t chunkNo = 0;
+  for (const Chunk &c : chunks) {
       SmallPlan pl; std::vector<PairDesc> hp; SmAux *d_aux = nullptr; SmSweep sw;
-      if (!(rc = small_prepare(b, c, f->smB, true, false, pl, hp, &d_aux, sw))) {
+      if (!(rc = small_prepare(b, c, f->smB, true, false, pl, hp, &d_aux, sw, chunkNo++))) {
         tm.start();
         sw.d_loglike = d_bll + c.p0;
         rc = small_sweep(f->smB, SM_SUM, true, sw, g_stream);                 // BackwardMatrix::fill, src/backward.cpp:18-46
@@ -625,6 +699,11 @@ int mb_device_count(void) {
 }
 
 int mb_set_device(int device) {
+  ApiGuard guard;
+  if (g_init && device != g_device) {   // the stream, the workspaces and every compiled program are bound to the first device
+    set_error("mb_set_device: the library is already initialised on device " + std::to_string(g_device) + " (one process drives one GPU)");
+    return 1;
+  }
   MB_HIP(hipSetDevice(device));
   return 0;
 }
@@ -642,10 +721,36 @@ int mb_set_kernel(int which) {
 
 int mb_set_memory_budget(size_t bytes) { g_mem_budget = bytes; return 0; }
 
-int mb_release_workspace(void) { ws_release(); return 0; }
+int mb_release_workspace(void) {
+  ApiGuard guard;
+  ws_release();
+  return 0;
+}
+
+int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits) {
+  if (compileMs) *compileMs = jit_compile_ms();
+  if (compiles) *compiles = jit_compiles();
+  if (cacheHits) *cacheHits = jit_cache_hits();
+  return 0;
+}
+
+// Tuning knobs are read from the environment when a machine's programs / kernels are built (DESIGN.md section 4.4 lists
+// them); this is the same switchboard for a host that prefers calls to environment variables.
+int mb_set_option(const char *name, const char *value) {
+  if (!name || strncmp(name, "MB_", 3) != 0) { set_error("mb_set_option: option names start with MB_"); return 1; }
+  const int rc = (value && *value) ? setenv(name, value, 1) : unsetenv(name);
+  if (rc) { set_error("mb_set_option: cannot set option"); return 1; }
+  return 0;
+}
+
+const char *mb_get_option(const char *name) {
+  if (!name || strncmp(name, "MB_", 3) != 0) return nullptr;
+  return getenv(name);
+}
 
 mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                               const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight) {
+  ApiGuard guard;
   if (nStates <= 0) { set_error("EvaluatedMachine has no states"); return nullptr; }
   if (nInTok < 0 || nOutTok < 0 || nTrans < 0) { set_error("mb_machine_create: negative size"); return nullptr; }
   if (ensure_init()) return nullptr;
@@ -661,6 +766,7 @@ mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, 
 }
 
 int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
+  ApiGuard guard;
   if (!m) { set_error("null machine"); return 1; }
   m->logW.assign(logWeight, logWeight + m->nTrans);
   if (!upload_weights(m)) return 1;
@@ -676,6 +782,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
 }
 
 void mb_machine_destroy(mb_machine *m) {
+  ApiGuard guard;
   if (!m) return;
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
@@ -701,6 +808,7 @@ int mb_machine_edge_order(const mb_machine *m, int which, uint32_t *out) {
 
 mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff, const int32_t *outTok,
                           const int64_t *outOff) {
+  ApiGuard guard;
   if (!m) { set_error("null machine"); return nullptr; }
   if (nPairs < 0) { set_error("negative pair count"); return nullptr; }
   mb_batch *b = new mb_batch();
@@ -737,12 +845,14 @@ mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, c
 }
 
 void mb_batch_destroy(mb_batch *b) {
+  ApiGuard guard;
   if (!b) return;
   if (b->d_in) (void)hipFree(b->d_in);
   if (b->d_out) (void)hipFree(b->d_out);
   if (b->d_pairs) (void)hipFree(b->d_pairs);
   if (b->d_envStart) (void)hipFree(b->d_envStart);
   if (b->d_envEnd) (void)hipFree(b->d_envEnd);
+  for (mb::SmTileCache &tc : b->smTiles) if (tc.d_tiles) (void)hipFree(tc.d_tiles);
   delete b;
 }
 
@@ -752,6 +862,7 @@ int64_t mb_batch_cells(const mb_batch *b) { return b ? b->totalCells : 0; }
 static bool env_overlapping(long long s1, long long e1, long long s2, long long e2) { return !(s1 >= e2 || s2 >= e1); }
 
 int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *inStart, const int32_t *inEnd) {
+  ApiGuard guard;
   if (!b || !envOff) { set_error("null argument"); return 1; }
   if (b->d_envStart) { (void)hipFree(b->d_envStart); b->d_envStart = nullptr; }
   if (b->d_envEnd) { (void)hipFree(b->d_envEnd); b->d_envEnd = nullptr; }
@@ -869,6 +980,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
 }
 
 int mb_batch_forward(mb_batch *b, int flags, double *loglike) {
+  ApiGuard guard;
   if (!b || !loglike) { set_error("null argument"); return 1; }
   return run_fill_loglike(b, MB_FORWARD, flags, loglike);
 }
@@ -882,6 +994,7 @@ int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen
 }
 
 int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
+  ApiGuard guard;
   if (!b || !loglike) { set_error("null argument"); return 1; }
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
@@ -948,7 +1061,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         if (!d_off || !d_packed) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_off, off.data(), np * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
         if ((rc = launch_compact_paths(d_path, d_slot, d_len, d_off, d_packed, np, g_stream))) break;
-        if (total && !hip_ok(hipMemcpyAsync(pathEdges + written, d_packed, total * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream), "D2H paths")) { rc = 1; break; }
+        if (total && d2h_large(pathEdges + written, d_packed, total * sizeof(uint32_t))) { rc = 1; break; }
         if (!hip_ok(hipStreamSynchronize(g_stream), "path compaction")) { rc = 1; break; }
         lap("pack + D2H paths");
         for (long long p = 0; p < np; ++p) {
@@ -966,6 +1079,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
 
 // ---- Forward-Backward counts --------------------------------------------------------------------------------
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
+  ApiGuard guard;
   if (!b || !counts) { set_error("null argument"); return 1; }
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
@@ -975,9 +1089,12 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;
-  MB_HIP(sm_alloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)));
-  MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
-  MB_HIP(hipMemsetAsync(d_counts, 0, std::max<long long>(nT, 1) * sizeof(double), g_stream));
+  if (!hip_ok(sm_alloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)), "hipMalloc(counts)")) return 1;
+  if (!hip_ok(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)), "hipMalloc(loglike)") ||
+      !hip_ok(hipMemsetAsync(d_counts, 0, std::max<long long>(nT, 1) * sizeof(double), g_stream), "memset(counts)")) {
+    sm_free(d_counts); sm_free(d_ll);
+    return 1;
+  }
   int rc = 0;
   Timer tm;
   for (const Chunk &c : chunks) {
@@ -1030,6 +1147,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
 // ---- single full matrix -------------------------------------------------------------------------------------
 int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int32_t *out, int64_t outLen,
                 int32_t startState, const int32_t *envStart, const int32_t *envEnd, double *cellsOut) {
+  ApiGuard guard;
   if (!m || !cellsOut) { set_error("null argument"); return 1; }
   if (mode < MB_FORWARD || mode > MB_BACKWARD) { set_error("mb_fill: unknown mode"); return 1; }
   if (startState < 0 || startState >= m->S) { set_error("mb_fill: start state out of range"); return 1; }

@@ -69,6 +69,11 @@ struct mb_machine {
   void *fast = nullptr;   // kernel-family specific compiled tables (owned; see mb_fast_*.hip)
 };
 
+namespace mb {
+// tile lists of one chunk of a batch for the small-machine family (mb_small.cpp), kept on the device between calls
+struct SmTileCache { long long p0 = -1, p1 = -1; int TS = 0; void *d_tiles = nullptr; std::vector<long long> off; };
+}
+
 struct mb_batch {
   mb_machine *m = nullptr;
   long long nPairs = 0;
@@ -81,6 +86,7 @@ struct mb_batch {
   // envelopes (src/seqpair.h:75-97): cell (x,y) of pair p exists <=> envStart[envBase+y] <= x < envEnd[envBase+y]
   bool hasEnv = false;
   int *d_envStart = nullptr, *d_envEnd = nullptr;
+  std::vector<mb::SmTileCache> smTiles;   // by chunk number
 };
 
 namespace mb {
@@ -96,6 +102,9 @@ void sm_free(void *p);
 // grow-only device workspaces by slot (mb_api.hip); pinned for the duration of the current API call
 void *ws_get(int slot, size_t bytes);
 size_t budget_bytes();
+// host -> device copy of a large pageable buffer through pinned staging buffers (a direct hipMemcpy pins fresh pageable
+// pages on the fly, which sporadically costs tens of milliseconds)
+int h2d_large(void *dstDev, const void *src, size_t bytes);
 #define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)
 
 // host-side machine compiler (mb_machine.cpp)

@@ -46,7 +46,7 @@ struct MedTileArgs {
   const long long *haloBase;  // rolling mode: per pair offset (in doubles) of its two buffers
   double *loglike;            // loglike[pairBase + blockIdx.y], written when the end cell is finalised (may be null)
   const int2 *tiles;          // materialised mode: (pair, strip) of workgroup tileBase + blockIdx.x
-  int C, TS, launch, rev, materialise, tileBase, debugNoStore;
+  int C, TS, launch, rev, materialise, tileBase, pad0;
   const double *poolB;        // count mode (specialised kernel only): Backward matrices, same layout and cellBase as pool
   double *counts;             // count mode: [nTrans] posterior transition counts, accumulated with fp64 atomics
 };
@@ -345,8 +345,7 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
     if (active) {
       if (A.materialise) {
         double *dstp = cellPtr(i, o);
-        if (!A.debugNoStore || c == C - 1)
-          for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
+        for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
       } else if (c == C - 1) {
         double *dstp = haloOut + (long long)o * S;
         for (int j = q; j < S; j += LPG) dstp[j] = cur[j];
@@ -898,7 +897,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   }
   int2 *d_tiles = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
-  if (!tiles.empty() && !hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, st), "H2D tile list")) { sm_free(d_tiles); return 1; }
+  if (!tiles.empty() && h2d_large(d_tiles, tiles.data(), tiles.size() * sizeof(int2))) { sm_free(d_tiles); return 1; }   // staged: see h2d_large
   const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level)] : nullptr;
   if (mode == MED_MODE_COUNT && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
   MedProgDev dev = devIn;
@@ -907,7 +906,6 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
   A.poolB = d_poolB; A.counts = d_counts;
-  { const char *e = getenv("MB_DEBUG_NOSTORE"); A.debugNoStore = e ? atoi(e) : 0; }   // timing experiments only: 1 = last column only, 2 = + every other column
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
     if (cnt[l] <= 0) continue;

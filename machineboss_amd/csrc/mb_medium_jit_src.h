@@ -36,7 +36,7 @@ struct MedTileArgs {
   const long long *haloBase;
   double *loglike;
   const int2 *tiles;
-  int C, TS, launch, rev, materialise, tileBase, debugNoStore;
+  int C, TS, launch, rev, materialise, tileBase, pad0;
   const double *poolB;
   double *counts;
 };
@@ -350,7 +350,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     if (active) {
       if (JMAT) {
         double *dstp = cellPtr(i, o);
-        if (!A.debugNoStore || c == C - 1 || (A.debugNoStore == 2 && (c & 1) == 0)) med_copy_out(dstp, cur, q);
+        med_copy_out(dstp, cur, q);
       } else if (c == C - 1) {
         med_copy_out(haloOut + (long long)o * S, cur, q);
       }

@@ -90,7 +90,7 @@ int mb_allreduce_counts(mb_comm *comm, double *counts, size_t n, double *loglike
   const size_t total = n + (loglike ? 1 : 0);
   if (!total) return 0;
   double *d = nullptr;
-  MB_HIP(hipMalloc((void **)&d, total * sizeof(double)));
+  MB_HIP(mb::sm_alloc((void **)&d, total * sizeof(double)));   // cached by size class: no hipMalloc / hipFree per EM iteration
   int rc = 0;
   do {
     if (n && !mb::hip_ok(hipMemcpyAsync(d, counts, n * sizeof(double), hipMemcpyHostToDevice, mb::g_stream), "H2D counts")) { rc = 1; break; }
@@ -100,7 +100,7 @@ int mb_allreduce_counts(mb_comm *comm, double *counts, size_t n, double *loglike
     if (loglike && !mb::hip_ok(hipMemcpyAsync(loglike, d + n, sizeof(double), hipMemcpyDeviceToHost, mb::g_stream), "D2H loglike")) { rc = 1; break; }
     if (!mb::hip_ok(hipStreamSynchronize(mb::g_stream), "all-reduce of counts")) { rc = 1; break; }
   } while (0);
-  (void)hipFree(d);
+  mb::sm_free(d);
   return rc;
 }
 

@@ -260,7 +260,9 @@ __device__ __forceinline__ void lds_add_f64(double *p, double x) {
 
 extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A) {
   extern __shared__ double lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the wavefront index is uniform inside a wavefront, which the compiler cannot see: taken through readfirstlane,
+  // everything derived from it (the tile, its pair descriptor, every base address) lives in scalar registers
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *wL = lds;                                          // output-token and match weight tables
 #if JMODE == 3
   double *accT = lds + JLDSW;                                // posterior counts of this workgroup's tiles
@@ -382,7 +384,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
   const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
   const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
   const int rowF = row_floats(P);
-  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? 3 : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
+  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? 4 : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
        << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
        << "\n#define JNBD " << P.NBD << "\n#define JCHB " << CB << "\n#define JNCH " << NCH << "\n#define JTBSTRIDE " << small_tb_stride(S)
        << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
@@ -426,15 +428,17 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
     b << "        {  // step parity " << p << "\n";
     b << "          const int jj = j + " << p << ", t = tb + jj, o = t - lane;\n";
     b << "          const bool active = colValid && o >= 0 && o <= outLen;\n";
-    if (counting) {
-      // the Backward supercell of this step's cell: requested now, used after the Forward values of the step are done
+    const bool lateB = env_int_s("MB_SMALL_BLOAD", 0) != 0;
+    auto loadB = [&]() {
+      // the Backward supercell of this step's cell: requested at the top of the step, used after its Forward values are done
       b << "          " << (CB == 16 ? "d2" : "double");
       for (int k = 0; k < NCH; ++k) b << (k ? "," : "") << " bq" << k;
       b << ";\n          { const double *bp = bPtr(o);\n";
       for (int k = 0; k < NCH; ++k)
         b << "            bq" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
       b << "          }\n";
-    }
+    };
+    if (counting && !lateB) loadB();
     if (counting && P.nTab[2] > 0) {
       b << "          if (lane == 63) {\n";
       for (int k = 0; k < P.nTab[2]; ++k) b << "            lds_add_f32(outAcc + " << (long long)k * (P.nOut + 1) << " + ot, aO" << k << ");\n";
@@ -504,6 +508,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       b << "          }\n";
     }
     b << "          if (active && i == inLen && o == outLen) A.loglike[pairIdx] = " << cp << P.endState << ";\n";
+    if (counting && lateB) loadB();
     if (counting) {
       // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87.  The
       // candidate is formed again (one fp64 add) rather than kept alive across the step.
@@ -628,32 +633,44 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   lap("kernel lookup / jit");
   const SmJit &J = P.jit[mode][materialise ? 1 : 0];
   const int TS = pick_tile_steps(pairs);
-  int nLaunch = 0;
-  for (const PairDesc &pd : pairs) {
-    const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
-    nLaunch = std::max(nLaunch, 2 * (NA - 1) + NB);
-  }
-  std::vector<long long> cnt(nLaunch + 1, 0);
-  for (const PairDesc &pd : pairs) {
-    const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
-    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) cnt[2 * a + b]++;
-  }
-  std::vector<long long> off(nLaunch + 1, 0);
-  for (int l = 0; l < nLaunch; ++l) off[l + 1] = off[l] + cnt[l];
-  if (off[nLaunch] > 0x7fffffffLL) { set_error("too many tiles in one sweep"); return 1; }
-  std::vector<int4> tiles((size_t)off[nLaunch]);
-  {
-    std::vector<long long> fill(off.begin(), off.end() - 1);
-    for (size_t p = 0; p < pairs.size(); ++p) {
-      const PairDesc &pd = pairs[p];
+  // the tile lists depend on the pairs' shapes only: built and uploaded once per batch chunk, reused by every later sweep
+  SmTileCache local;
+  SmTileCache &tc = sw.tileCache ? *sw.tileCache : local;
+  if (!tc.d_tiles || tc.TS != TS) {
+    if (tc.d_tiles) { (void)hipFree(tc.d_tiles); tc.d_tiles = nullptr; }
+    int nLaunch = 0;
+    for (const PairDesc &pd : pairs) {
       const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
-      for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, 0);
+      nLaunch = std::max(nLaunch, 2 * (NA - 1) + NB);
     }
+    std::vector<long long> cnt(nLaunch + 1, 0);
+    for (const PairDesc &pd : pairs) {
+      const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+      for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) cnt[2 * a + b]++;
+    }
+    tc.off.assign(nLaunch + 1, 0);
+    for (int l = 0; l < nLaunch; ++l) tc.off[l + 1] = tc.off[l] + cnt[l];
+    if (tc.off[nLaunch] > 0x7fffffffLL) { set_error("too many tiles in one sweep"); return 1; }
+    std::vector<int4> tiles((size_t)tc.off[nLaunch]);
+    {
+      std::vector<long long> fill(tc.off.begin(), tc.off.end() - 1);
+      for (size_t p = 0; p < pairs.size(); ++p) {
+        const PairDesc &pd = pairs[p];
+        const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+        for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, 0);
+      }
+    }
+    lap("tile lists");
+    if (!hip_ok(hipMalloc(&tc.d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4)), "hipMalloc(tile list)")) return 1;
+    if (h2d_large(tc.d_tiles, tiles.data(), tiles.size() * sizeof(int4)) || !hip_ok(hipStreamSynchronize(st), "H2D tile list")) {
+      (void)hipFree(tc.d_tiles); tc.d_tiles = nullptr;
+      return 1;
+    }
+    tc.TS = TS;
   }
-  lap("tile lists");
-  int4 *d_tiles = nullptr;
-  if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int4)), "hipMalloc(tile list)")) return 1;
-  if (!hip_ok(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, st), "H2D tile list")) { sm_free(d_tiles); return 1; }
+  const int nLaunch = (int)tc.off.size() - 1;
+  const std::vector<long long> &off = tc.off;
+  const int4 *d_tiles = (const int4 *)tc.d_tiles;
   lap("tile list upload");
   SmallArgsHost A{};
   A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1);
@@ -661,18 +678,19 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
   bool ok = true;
   for (int l = 0; l < nLaunch && ok; ++l) {
-    if (cnt[l] <= 0) continue;
+    const long long nt = off[l + 1] - off[l];
+    if (nt <= 0) continue;
     ++g_last_launches;
     A.tileBase = (int)off[l]; A.tileEnd = (int)off[l + 1];
     void *args[] = {&A};
-    const unsigned grid = (unsigned)((cnt[l] + 3) / 4);
+    const unsigned grid = (unsigned)((nt + 3) / 4);
     ok = hipModuleLaunchKernel((hipFunction_t)J.func, grid, 1, 1, 256, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
   }
   lap("launches");
   if (!ok) set_error("small-machine kernel launch failed");
   ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipStreamSynchronize(st), "small tile kernels");
   lap("stream synchronize");
-  sm_free(d_tiles);
+  if (!sw.tileCache && local.d_tiles) (void)hipFree(local.d_tiles);
   return ok ? 0 : 1;
 }
 

@@ -85,6 +85,7 @@ struct SmSweep {
   double *d_loglike = nullptr;                 // [nPairs]
   const double *d_bwdLL = nullptr;             // count mode
   double *d_counts = nullptr; int nRep = 0;    // count mode: nRep replicas of [nTrans]
+  SmTileCache *tileCache = nullptr;            // tile lists of this set of pairs, kept on the device between calls (may be null)
 };
 int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st);
 
