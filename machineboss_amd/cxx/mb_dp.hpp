@@ -1,15 +1,38 @@
-// mb_dp.hpp -- C++ shim with the reference's DP class names on top of the C-ABI (include/mbhip.h).
+// mb_dp.hpp -- C++ shim with the reference's DP class interface on top of the C-ABI (include/mbhip.h).
 //
-// This is the code a Machine Boss maintainer would put behind src/{forward,backward,viterbi,counts}.h to run the DP
-// hot path on an MI355X (see INTEGRATION.md for the glue to the real EvaluatedMachine / SeqPair / Machine classes).
-// Same contract as the reference: construction is computation (src/forward.defs.h:1-21, viterbi.cpp:6-16,
-// backward.cpp:6-16); results are read through logLike(), cell(), path(), getCounts()/MachineCounts::count; errors are
-// std::runtime_error carrying the library message (the reference throws runtime_error("Abort"), src/util.cpp:39-48).
+// This is the code a Machine Boss maintainer puts behind src/{dpmatrix,forward,backward,viterbi,counts}.h to run the DP
+// hot path on an MI355X.  Same contract as the reference: construction is computation (src/forward.defs.h:1-21,
+// viterbi.cpp:6-16, backward.cpp:6-16); results are read through logLike(), cell(), path(), getCounts() /
+// MachineCounts::count; errors are std::runtime_error carrying the library message (the reference throws
+// runtime_error("Abort") after printing, src/util.cpp:39-48).
+//
+// Two layers:
+//  * neutral types -- FlatMachine (struct-of-arrays EvaluatedMachine), TokSeqPair, Envelope, and the classes DPMatrix /
+//    ForwardMatrix / BackwardMatrix / ViterbiMatrix / RollingOutputForwardMatrix / MachineCounts over them.  The fills run
+//    on the GPU; the functions that only WALK a finished matrix (traceBack x4, traceForward x3, selectMaxTrans,
+//    randomTransSelector, ForwardMatrix::samplePath, BackwardMatrix::getCounts with a visitor / postTransQueue /
+//    traceFrom x3, writeJson: src/dpmatrix.h:136-162, src/forward.h:24-25, src/backward.h:50-58) run on the host over the
+//    device-filled matrix, candidate order and quirks as in the reference;
+//  * class templates over the CALLER's types (ForwardMatrixT<EvaluatedMachine, SeqPair> ...), duck-typed on the members
+//    the reference's classes have (eval.state[s].outgoing / logTransWeight / name, eval.inputTokenizer,
+//    seqPair.input.seq / .name / alignment, machine.state[s].getTransition(ti), MachinePath::trans), with the
+//    reference's constructor signatures and public members (machine, seqPair, input, output, inLen, outLen, nStates),
+//    so that boss.cpp-style callers compile unchanged once the glue header typedefs them (INTEGRATION.md section 2;
+//    tests/cxx/ compiles exactly that against a mock of the reference's headers).
 // Header-only; link with -lmbhip.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <iomanip>
 #include <limits>
+#include <list>
+#include <map>
+#include <memory>
+#include <ostream>
+#include <queue>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -22,8 +45,10 @@ namespace MachineBossHIP {
 typedef int InputToken;
 typedef int OutputToken;
 typedef unsigned long long StateIndex;   // src/machine.h:21
+typedef size_t TransIndex;               // EvaluatedMachineState::TransIndex, src/eval.h:60
 
 inline void check(int rc) { if (rc) throw std::runtime_error(mb_last_error()); }
+inline double negInf() { return -std::numeric_limits<double>::infinity(); }
 
 // Flattened EvaluatedMachine (src/eval.h:59-98): struct-of-arrays over global transition ids
 // e = transOffset[src] + transIndex, the order EvaluatedMachine::init visits them (src/eval.cpp:47-69).
@@ -35,6 +60,10 @@ struct FlatMachine {
   std::vector<size_t> transOffset;                    // [nStates+1]
   std::vector<size_t> outDegree;
   mutable mb_machine *dev = nullptr;
+  // host copies of the reference's iteration orders (src/eval.h:66-68): CSR by (state, inTok, outTok) over edge ids,
+  // rows sorted by the other endpoint, then by insertion order -- what the nested map / multimap iterate
+  mutable std::vector<uint32_t> inEdge, outEdge;
+  mutable std::vector<size_t> inOff, outOff;
 
   size_t nTransitions() const { return src.size(); }
   StateIndex startState() const { return 0; }
@@ -50,6 +79,27 @@ struct FlatMachine {
     if (outDegree.empty()) outDegree.assign(nStates, 0);
     transOffset.assign(nStates + 1, 0);
     for (int s = 0; s < nStates; ++s) transOffset[s + 1] = transOffset[s] + outDegree[s];
+    inEdge.clear(); outEdge.clear();
+  }
+  size_t key(StateIndex st, int it, int ot) const { return ((size_t)st * (nInTok + 1) + it) * (nOutTok + 1) + ot; }
+  void buildOrders() const {
+    if (!inOff.empty()) return;
+    for (int incoming = 0; incoming < 2; ++incoming) {
+      std::vector<uint32_t> &edge = incoming ? inEdge : outEdge;
+      std::vector<size_t> &off = incoming ? inOff : outOff;
+      const size_t nKeys = (size_t)nStates * (nInTok + 1) * (nOutTok + 1);
+      edge.resize(nTransitions());
+      for (size_t e = 0; e < edge.size(); ++e) edge[e] = (uint32_t)e;
+      auto rowOf = [&](uint32_t e) { return key(incoming ? dst[e] : src[e], inTok[e], outTok[e]); };
+      std::stable_sort(edge.begin(), edge.end(), [&](uint32_t a, uint32_t b) {
+        const size_t ra = rowOf(a), rb = rowOf(b);
+        if (ra != rb) return ra < rb;
+        return (incoming ? src[a] : dst[a]) < (incoming ? src[b] : dst[b]);
+      });
+      off.assign(nKeys + 1, 0);
+      for (uint32_t e : edge) off[rowOf(e) + 1]++;
+      for (size_t k = 0; k < nKeys; ++k) off[k + 1] += off[k];
+    }
   }
   mb_machine *device() const {
     if (!dev) {
@@ -74,7 +124,7 @@ struct TokSeqPair {                       // a tokenised SeqPair (Tokenizer::tok
   std::vector<OutputToken> output;
 };
 
-struct PathStep { StateIndex src; size_t transIndex; };   // MachinePath as (state, index into its transition list)
+struct PathStep { StateIndex src; TransIndex transIndex; };   // MachinePath as (state, index into its transition list)
 
 // Envelope (src/seqpair.h:75-97): cell (x,y) exists <=> inStart[y] <= x < inEnd[y].  An alignment column is
 // (gotInput, gotOutput); initPath / initPathArea restate src/seqpair.cpp:134-182.
@@ -121,66 +171,318 @@ struct Envelope {
   }
 };
 
-// DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163)
-class DPMatrix {
+// A path as the caller's transition objects; PathOf<MachineT> lets the glue substitute the reference's MachinePath
+// (anything with a `trans` sequence supporting push_back / push_front and a concatenate()).
+template <class TransT>
+struct MachinePathT {
+  std::list<TransT> trans;
+  MachinePathT() {}
+  explicit MachinePathT(const TransT &t) : trans(1, t) {}
+  void clear() { trans.clear(); }
+  MachinePathT concatenate(const MachinePathT &o) const { MachinePathT r(*this); r.trans.insert(r.trans.end(), o.trans.begin(), o.trans.end()); return r; }
+};
+template <class MachineT>
+struct PathOf {
+  typedef typename std::decay<decltype(std::declval<const MachineT &>().state[0].getTransition(0))>::type Transition;
+  typedef MachinePathT<Transition> type;
+};
+
+// ---- DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163) over neutral types -----------------------------------------------
+class DPMatrixCore {
+public:
+  typedef long InputIndex;
+  typedef long OutputIndex;
+  typedef std::function<bool(InputIndex, OutputIndex, StateIndex, TransIndex)> TraceTerminator;
+  typedef std::function<void(StateIndex, TransIndex, double)> TransVisitor;
+  typedef std::function<size_t(const std::vector<double> &)> TransSelector;
+
 protected:
   std::vector<double> cellStorage;
+  const FlatMachine &flat;
   void fill(int mode, int startState) {
     cellStorage.resize((size_t)(inLen + 1) * (outLen + 1) * nStates);
-    if (!env.fits(seqPair)) throw std::runtime_error("Envelope/sequence mismatch");      // DPMatrix::alloc, src/dpmatrix.defs.h:31
+    TokSeqPair tsp{input, output};
+    if (!env.fits(tsp)) throw std::runtime_error("Envelope/sequence mismatch");      // DPMatrix::alloc, src/dpmatrix.defs.h:31
     const bool full = env.isFull();
-    check(mb_fill_env(machine.device(), mode, seqPair.input.data(), inLen, seqPair.output.data(), outLen, startState,
+    check(mb_fill_env(flat.device(), mode, input.data(), inLen, output.data(), outLen, startState,
                       full ? nullptr : env.inStart.data(), full ? nullptr : env.inEnd.data(), cellStorage.data()));
   }
-public:
-  const FlatMachine &machine;
-  const TokSeqPair &seqPair;
-  const long inLen, outLen;
-  const StateIndex nStates;
-  Envelope env;     // the caller's glue passes Envelope(seqPair): path envelope of an aligned pair, else full (quirk Q1)
-  DPMatrix(const FlatMachine &m, const TokSeqPair &sp)
-      : machine(m), seqPair(sp), inLen((long)sp.input.size()), outLen((long)sp.output.size()), nStates(m.nStates) { env.initFull(inLen, outLen); }
-  DPMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e)
-      : machine(m), seqPair(sp), inLen((long)sp.input.size()), outLen((long)sp.output.size()), nStates(m.nStates), env(e) {}
-  double cell(long inPos, long outPos, StateIndex state) const {
-    if (inPos < 0 || inPos > inLen || outPos < 0 || outPos > outLen) return -std::numeric_limits<double>::infinity();
-    return cellStorage[((size_t)outPos * (inLen + 1) + inPos) * nStates + state];
+  // DPMatrix::iterate over one label group (src/dpmatrix.h:101-115): candidates in multimap order
+  void pathIterate(const TransVisitor &visit, bool incoming, StateIndex state, InputToken inTok, OutputToken outTok, InputIndex inPos, OutputIndex outPos) const {
+    flat.buildOrders();
+    const std::vector<size_t> &off = incoming ? flat.inOff : flat.outOff;
+    const std::vector<uint32_t> &edge = incoming ? flat.inEdge : flat.outEdge;
+    const size_t k = flat.key(state, inTok, outTok);
+    for (size_t a = off[k]; a < off[k + 1]; ++a) {
+      const uint32_t e = edge[a];
+      const StateIndex other = incoming ? flat.src[e] : flat.dst[e];
+      visit(other, flat.transIndex[e], cell(inPos, outPos, other) + flat.logWeight[e]);
+    }
   }
-  double startCell() const { return cell(0, 0, machine.startState()); }
-  double endCell() const { return cell(inLen, outLen, machine.endState()); }
+
+public:
+  const std::vector<InputToken> input;
+  const std::vector<OutputToken> output;
+  const InputIndex inLen;
+  const OutputIndex outLen;
+  const StateIndex nStates;
+  Envelope env;     // Envelope(seqPair): the path envelope of an aligned pair, else full (quirk Q1: src/dpmatrix.defs.h:16-17)
+
+  DPMatrixCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out)
+      : flat(m), input(in), output(out), inLen((long)in.size()), outLen((long)out.size()), nStates(m.nStates) { env.initFull(inLen, outLen); }
+  DPMatrixCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
+      : flat(m), input(in), output(out), inLen((long)in.size()), outLen((long)out.size()), nStates(m.nStates), env(e) {}
+
+  const FlatMachine &flatMachine() const { return flat; }
+  // the const accessor of the reference: -inf outside the envelope (src/dpmatrix.h:142-144)
+  double cell(InputIndex inPos, OutputIndex outPos, StateIndex state) const {
+    return env.contains(inPos, outPos) ? cellStorage[((size_t)outPos * (inLen + 1) + inPos) * nStates + state] : negInf();
+  }
+  double startCell() const { return cell(0, 0, flat.startState()); }
+  double endCell() const { return cell(inLen, outLen, flat.endState()); }
+
+  // DPMatrix::writeJson (src/dpmatrix.defs.h:39-53): every cell at setprecision(5), input position outermost.
+  // nameOf(s) must print the state's name as JSON (the reference streams machine.state[s].name, a json value).
+  template <class NameFn>
+  void writeJsonWith(std::ostream &outs, const std::string &inputName, const std::string &outputName, NameFn nameOf) const {
+    outs << "{" << std::endl << " \"input\": \"" << inputName << "\"," << std::endl << " \"output\": \"" << outputName << "\"," << std::endl << " \"cell\": [";
+    for (InputIndex i = 0; i <= inLen; ++i)
+      for (OutputIndex o = 0; o <= outLen; ++o)
+        for (StateIndex s = 0; s < nStates; ++s) {
+          outs << ((i || o || s) ? "," : "") << std::endl << "  { \"inPos\": " << i << ", \"outPos\": " << o << ", \"state\": ";
+          nameOf(outs, s);
+          outs << ", \"logLike\": " << std::setprecision(5) << cell(i, o, s) << " }";
+        }
+    outs << std::endl << " ]" << std::endl << "}" << std::endl;
+  }
+
+  static TransVisitor addTransToTraceOptions(std::vector<StateIndex> &state, std::vector<TransIndex> &transIndex, std::vector<double> &loglike) {
+    return [&](StateIndex s, TransIndex ti, double tll) { state.push_back(s); transIndex.push_back(ti); loglike.push_back(tll); };
+  }
+  // std::max_element: the FIRST maximum (src/dpmatrix.defs.h:171-174)
+  static size_t selectMaxTrans(const std::vector<double> &logWeights) {
+    return (size_t)std::distance(logWeights.begin(), std::max_element(logWeights.begin(), logWeights.end()));
+  }
+  // random_index over exp(logWeights) with random_double(rng) (src/dpmatrix.defs.h:176-186, src/util.h:102-106,151-165)
+  template <class Generator>
+  static TransSelector randomTransSelector(Generator &rng) {
+    return [&rng](const std::vector<double> &logWeights) -> size_t {
+      std::vector<double> weights;
+      weights.reserve(logWeights.size());
+      for (const double lw : logWeights) weights.push_back(std::exp(lw));
+      double norm = 0;
+      for (const double w : weights) { if (!(w >= 0)) throw std::runtime_error("Negative weights in random_index"); norm += w; }
+      if (!(norm > 0)) throw std::runtime_error("Zero weights in random_index");
+      double variate = (rng() / (((double)std::numeric_limits<typename Generator::result_type>::max()) + 1)) * norm;
+      for (size_t n = 0; n < weights.size(); ++n)
+        if ((variate -= weights[n]) <= 0) return n;
+      return weights.size();
+    };
+  }
+
+  // ---- the walkers proper: positions and (state, transIndex) only; the MachinePath forms below wrap them -----------------
+  // DPMatrix::traceBack (m, inPos, outPos, s, stopTrace, selectTrans), src/dpmatrix.defs.h:82-110
+  void traceBackSteps(InputIndex inPos, OutputIndex outPos, StateIndex s, const TraceTerminator &stopTrace, const TransSelector &selectTrans) const {
+    if (!(cell(inPos, outPos, s) > negInf())) throw std::runtime_error("Can't do traceback: no finite-weight paths");
+    while (inPos > 0 || outPos > 0 || s != 0) {
+      std::vector<double> loglike; std::vector<StateIndex> source; std::vector<TransIndex> transIndex;
+      const TransVisitor tv = addTransToTraceOptions(source, transIndex, loglike);
+      const InputToken inTok = inPos ? input[inPos - 1] : 0;
+      const OutputToken outTok = outPos ? output[outPos - 1] : 0;
+      if (inPos && outPos) pathIterate(tv, true, s, inTok, outTok, inPos - 1, outPos - 1);
+      if (inPos) pathIterate(tv, true, s, inTok, 0, inPos - 1, outPos);
+      if (outPos) pathIterate(tv, true, s, 0, outTok, inPos, outPos - 1);
+      pathIterate(tv, true, s, 0, 0, inPos, outPos);
+      if (loglike.empty()) throw std::runtime_error("Traceback reached a cell without incoming transitions");   // (undefined behaviour in the reference)
+      const size_t best = selectTrans(loglike);
+      const StateIndex bestSource = source[best];
+      const TransIndex bestTransIndex = transIndex[best];
+      const size_t e = flat.transOffset[bestSource] + bestTransIndex;     // = m.state[bestSource].getTransition(bestTransIndex)
+      if (flat.inTok[e]) --inPos;
+      if (flat.outTok[e]) --outPos;
+      s = bestSource;
+      if (stopTrace(inPos, outPos, s, bestTransIndex)) break;
+    }
+  }
+  // DPMatrix::traceForward (m, inPos, outPos, s, stopTrace, selectTrans), src/dpmatrix.defs.h:128-159
+  void traceForwardSteps(InputIndex inPos, OutputIndex outPos, StateIndex s, const TraceTerminator &stopTrace, const TransSelector &selectTrans) const {
+    if (!(cell(inPos, outPos, s) > negInf())) throw std::runtime_error("Can't do traceforward: no finite-weight paths");
+    while (inPos < inLen || outPos < outLen || s != nStates - 1) {
+      std::vector<double> loglike; std::vector<StateIndex> dest; std::vector<TransIndex> transIndex;
+      const TransVisitor tv = addTransToTraceOptions(dest, transIndex, loglike);
+      const bool endOfInput = (inPos == inLen), endOfOutput = (outPos == outLen);
+      const InputToken inTok = endOfInput ? 0 : input[inPos];
+      const OutputToken outTok = endOfOutput ? 0 : output[outPos];
+      if (!endOfInput && !endOfOutput) pathIterate(tv, false, s, inTok, outTok, inPos + 1, outPos + 1);
+      if (!endOfInput) pathIterate(tv, false, s, inTok, 0, inPos + 1, outPos);
+      if (!endOfOutput) pathIterate(tv, false, s, 0, outTok, inPos, outPos + 1);
+      pathIterate(tv, false, s, 0, 0, inPos, outPos);
+      if (loglike.empty()) throw std::runtime_error("Traceforward reached a cell without outgoing transitions");
+      const size_t best = selectTrans(loglike);
+      const StateIndex bestDest = dest[best];
+      const TransIndex bestTransIndex = transIndex[best];
+      if (stopTrace(inPos, outPos, s, bestTransIndex)) break;
+      const size_t e = flat.transOffset[s] + bestTransIndex;
+      if (flat.dst[e] != bestDest) throw std::runtime_error("Traceforward error");
+      if (flat.inTok[e]) ++inPos;
+      if (flat.outTok[e]) ++outPos;
+      s = bestDest;
+    }
+  }
+
+  // ---- the reference's overloads (src/dpmatrix.h:150-162).  Quirk Q2 is kept: the MachinePath overloads that take a
+  //      position ignore it and start at (inLen, outLen) (src/dpmatrix.defs.h:72-80,118-126); traceForward(m, selector)
+  //      is traceBack(m, 0, 0, 0, selector) (:112-115).  Only the TraceTerminator overloads honour their position. -----
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceBack(const MachineT &m, TransSelector ts = selectMaxTrans) const { return traceBack(m, inLen, outLen, nStates - 1, ts); }
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceBack(const MachineT &m, StateIndex s, TransSelector ts = selectMaxTrans) const { return traceBack(m, inLen, outLen, s, ts); }
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceBack(const MachineT &m, InputIndex, OutputIndex, StateIndex s, TransSelector ts = selectMaxTrans) const {
+    typename PathOf<MachineT>::type path;
+    const TraceTerminator stopTrace = [&](InputIndex, OutputIndex, StateIndex src, TransIndex ti) { path.trans.push_front(m.state[src].getTransition(ti)); return false; };
+    traceBackSteps(inLen, outLen, s, stopTrace, ts);
+    return path;
+  }
+  template <class MachineT>
+  void traceBack(const MachineT &, InputIndex inPos, OutputIndex outPos, StateIndex s, TraceTerminator stopTrace, TransSelector ts = selectMaxTrans) const {
+    traceBackSteps(inPos, outPos, s, stopTrace, ts);
+  }
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceForward(const MachineT &m, TransSelector ts = selectMaxTrans) const { return traceBack(m, 0, 0, 0, ts); }
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceForward(const MachineT &m, InputIndex, OutputIndex, StateIndex s, TransSelector ts = selectMaxTrans) const {
+    typename PathOf<MachineT>::type path;
+    const TraceTerminator stopTrace = [&](InputIndex, OutputIndex, StateIndex src, TransIndex ti) { path.trans.push_back(m.state[src].getTransition(ti)); return false; };
+    traceForwardSteps(inLen, outLen, s, stopTrace, ts);
+    return path;
+  }
+  template <class MachineT>
+  void traceForward(const MachineT &, InputIndex inPos, OutputIndex outPos, StateIndex s, TraceTerminator stopTrace, TransSelector ts = selectMaxTrans) const {
+    traceForwardSteps(inPos, outPos, s, stopTrace, ts);
+  }
 };
 
-class ForwardMatrix : public DPMatrix {      // src/forward.h:19-27
+class ForwardCore : public DPMatrixCore {      // src/forward.h:19-27
 public:
-  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, StateIndex startState = 0) : DPMatrix(m, sp) { fill(MB_FORWARD, (int)startState); }
-  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e, StateIndex startState = 0) : DPMatrix(m, sp, e) { fill(MB_FORWARD, (int)startState); }
+  ForwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, StateIndex startState = 0)
+      : DPMatrixCore(m, in, out, e) { fill(MB_FORWARD, (int)startState); }
   double logLike() const { return endCell(); }
+  // stochastic traceback (src/forward.cpp:17-23)
+  template <class MachineT, class Generator>
+  typename PathOf<MachineT>::type samplePath(const MachineT &m, Generator &rng) const { return traceBack(m, randomTransSelector(rng)); }
+  template <class MachineT, class Generator>
+  typename PathOf<MachineT>::type samplePath(const MachineT &m, StateIndex s, Generator &rng) const { return traceBack(m, s, randomTransSelector(rng)); }
 };
 
-class BackwardMatrix : public DPMatrix {     // src/backward.h:44-59
+class ViterbiCore : public DPMatrixCore {      // src/viterbi.h:9-18
 public:
-  BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp) : DPMatrix(m, sp) { fill(MB_BACKWARD, 0); }
-  BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : DPMatrix(m, sp, e) { fill(MB_BACKWARD, 0); }
-  double logLike() const { return startCell(); }
-};
-
-class ViterbiMatrix : public DPMatrix {      // src/viterbi.h:9-18
-public:
-  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp) : DPMatrix(m, sp) { fill(MB_VITERBI, 0); }
-  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : DPMatrix(m, sp, e) { fill(MB_VITERBI, 0); }
+  ViterbiCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
+      : DPMatrixCore(m, in, out, e) { fill(MB_VITERBI, 0); }
   double logLike() const { return endCell(); }
-  std::vector<PathStep> path() const {       // traceBack (src/dpmatrix.defs.h:61-110), run on the device
-    if (!(endCell() > -std::numeric_limits<double>::infinity())) throw std::runtime_error("Can't do traceback: no finite-weight paths");
+  template <class MachineT>
+  typename PathOf<MachineT>::type path(const MachineT &m) const { return traceBack(m); }      // src/viterbi.cpp:49-51
+  // the same path traced on the device (one traceback byte per cell or the matrix, whichever the machine's kernel family
+  // keeps), as (state, transIndex) steps -- what a batch caller uses through mb_viterbi_batch
+  std::vector<PathStep> path() const {
+    if (!(endCell() > negInf())) throw std::runtime_error("Can't do traceback: no finite-weight paths");
     const int64_t inOff[2] = {0, inLen}, outOff[2] = {0, outLen};
-    const int64_t cap = mb_viterbi_path_bound(machine.device(), inLen, outLen);
+    const int64_t cap = mb_viterbi_path_bound(flat.device(), inLen, outLen);
     std::vector<uint32_t> edges((size_t)cap);
     int64_t off[2] = {0, 0};
     double ll = 0;
-    check(mb_viterbi_batch(machine.device(), 1, seqPair.input.data(), inOff, seqPair.output.data(), outOff, &ll, off, edges.data(), cap));
+    check(mb_viterbi_batch(flat.device(), 1, input.data(), inOff, output.data(), outOff, &ll, off, edges.data(), cap));
     std::vector<PathStep> p;
-    for (int64_t k = 0; k < off[1]; ++k) p.push_back({machine.src[edges[k]], machine.transIndex[edges[k]]});
+    for (int64_t k = 0; k < off[1]; ++k) p.push_back({flat.src[edges[k]], flat.transIndex[edges[k]]});
     return p;
   }
+};
+
+class BackwardCore : public DPMatrixCore {     // src/backward.h:10-59
+public:
+  typedef std::function<void(StateIndex, TransIndex, InputIndex, OutputIndex, double)> BackTransVisitor;
+  struct PostTrans {
+    InputIndex inPos; OutputIndex outPos; StateIndex src; TransIndex transIndex; double weight;
+    bool operator<(const PostTrans &ptq) const { return weight < ptq.weight; }
+  };
+  typedef std::priority_queue<PostTrans> PostTransQueue;
+  static BackTransVisitor transitionSorter(PostTransQueue &ptq) {
+    return [&](StateIndex s, TransIndex ti, InputIndex ip, OutputIndex op, double postProb) { ptq.push(PostTrans{ip, op, s, ti, postProb}); };
+  }
+  BackwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
+      : DPMatrixCore(m, in, out, e) { fill(MB_BACKWARD, 0); }
+  double logLike() const { return startCell(); }
+
+  // BackwardMatrix::getCounts with a visitor (src/backward.cpp:62-87): every cell, every outgoing transition, in the
+  // reference's order; the position handed to the visitor is the transition's DESTINATION cell (:77-83)
+  void getCounts(const ForwardCore &forward, const BackTransVisitor &transCount) const {
+    const double ll = logLike();
+    for (OutputIndex outPos = outLen; outPos >= 0; --outPos) {
+      const bool endOfOutput = (outPos == outLen);
+      const OutputToken outTok = endOfOutput ? 0 : output[outPos];
+      for (InputIndex inPos = env.inEnd[outPos] - 1; inPos >= env.inStart[outPos]; --inPos) {
+        const bool endOfInput = (inPos == inLen);
+        const InputToken inTok = endOfInput ? 0 : input[inPos];
+        for (long long s = (long long)nStates - 1; s >= 0; --s) {
+          const double logOddsRatio = forward.cell(inPos, outPos, (StateIndex)s) - ll;
+          auto acc = [&](InputToken it, OutputToken ot, InputIndex ip, OutputIndex op) {
+            pathIterate([&](StateIndex, TransIndex ti, double tll) { transCount((StateIndex)s, ti, ip, op, std::exp(logOddsRatio + tll)); }, false, (StateIndex)s, it, ot, ip, op);
+          };
+          if (!endOfInput && !endOfOutput) acc(inTok, outTok, inPos + 1, outPos + 1);
+          if (!endOfInput) acc(inTok, 0, inPos + 1, outPos);
+          if (!endOfOutput) acc(0, outTok, inPos, outPos + 1);
+          acc(0, 0, inPos, outPos);
+        }
+      }
+    }
+  }
+  PostTransQueue postTransQueue(const ForwardCore &forward) const {     // src/backward.cpp:52-56
+    PostTransQueue ptq;
+    getCounts(forward, transitionSorter(ptq));
+    return ptq;
+  }
+  // traceFrom (src/backward.cpp:89-108)
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceFrom(const MachineT &m, const ForwardCore &forward, InputIndex inPos, OutputIndex outPos, StateIndex state) const {
+    return forward.traceBack(m, inPos, outPos, state).concatenate(traceForward(m, inPos, outPos, state));
+  }
+  template <class MachineT>
+  typename PathOf<MachineT>::type traceFrom(const MachineT &m, const ForwardCore &forward, InputIndex inPos, OutputIndex outPos, StateIndex state, TransIndex transIndex) const {
+    typedef typename PathOf<MachineT>::type Path;
+    return forward.traceBack(m, inPos, outPos, state).concatenate(Path(m.state[state].getTransition(transIndex)).concatenate(traceForward(m, inPos, outPos, state)));
+  }
+  template <class MachineT>
+  void traceFrom(const MachineT &m, const ForwardCore &forward, InputIndex inPos, OutputIndex outPos, StateIndex state, TransIndex transIndex, TraceTerminator stopTrace) const {
+    if (!stopTrace(inPos, outPos, state, transIndex)) {
+      forward.traceBack(m, inPos, outPos, state, stopTrace);
+      const size_t e = flat.transOffset[state] + transIndex;
+      const InputIndex nextInPos = inPos + (flat.inTok[e] ? 1 : 0);
+      const OutputIndex nextOutPos = outPos + (flat.outTok[e] ? 1 : 0);
+      traceForward(m, nextInPos, nextOutPos, (StateIndex)flat.dst[e], stopTrace);
+    }
+  }
+};
+
+// ---- neutral-type classes (FlatMachine + TokSeqPair), as before ------------------------------------------------------------
+inline Envelope fullEnvelope(const TokSeqPair &sp) { Envelope e; e.initFull((long)sp.input.size(), (long)sp.output.size()); return e; }
+
+class ForwardMatrix : public ForwardCore {
+public:
+  const FlatMachine &machine; const TokSeqPair &seqPair;
+  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, fullEnvelope(sp), startState), machine(m), seqPair(sp) {}
+  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, e, startState), machine(m), seqPair(sp) {}
+};
+class BackwardMatrix : public BackwardCore {
+public:
+  const FlatMachine &machine; const TokSeqPair &seqPair;
+  BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp) : BackwardCore(m, sp.input, sp.output, fullEnvelope(sp)), machine(m), seqPair(sp) {}
+  BackwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : BackwardCore(m, sp.input, sp.output, e), machine(m), seqPair(sp) {}
+};
+class ViterbiMatrix : public ViterbiCore {
+public:
+  const FlatMachine &machine; const TokSeqPair &seqPair;
+  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp) : ViterbiCore(m, sp.input, sp.output, fullEnvelope(sp)), machine(m), seqPair(sp) {}
+  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : ViterbiCore(m, sp.input, sp.output, e), machine(m), seqPair(sp) {}
 };
 
 // RollingOutputForwardMatrix (src/forward.h:29, dpmatrix.h:46-58): log-likelihood only, no matrix in HBM
@@ -221,8 +523,7 @@ struct MachineCounts {
     int rc = 0;
     if (!envelopes.empty()) {
       if (envelopes.size() != pairs.size()) { mb_batch_destroy(b); throw std::runtime_error("Envelope/training set mismatch"); }
-      std::vector<int64_t> envOff(1, 0); std::vector<int32_t> st(1, 0), en(1, 0);
-      st.clear(); en.clear();
+      std::vector<int64_t> envOff(1, 0); std::vector<int32_t> st, en;
       for (const Envelope &e : envelopes) {
         if (!e.isFull()) { st.insert(st.end(), e.inStart.begin(), e.inStart.end()); en.insert(en.end(), e.inEnd.begin(), e.inEnd.end()); }
         envOff.push_back((int64_t)st.size());
@@ -237,6 +538,10 @@ struct MachineCounts {
     loglike += s;
     return ll;
   }
+  // BackwardMatrix::transitionCounter (src/backward.h:12-18)
+  BackwardCore::BackTransVisitor transitionCounter() {
+    return [this](StateIndex s, TransIndex ti, long, long, double postProb) { count[s][ti] += postProb; };
+  }
   // operator+= over every rank of `comm` at once: one RCCL all-reduce of nTransitions + 1 doubles (mb_allreduce_counts);
   // comm == nullptr (single process) leaves the counts as they are
   void allReduce(mb_comm *comm) {
@@ -246,10 +551,143 @@ struct MachineCounts {
     size_t k = 0;
     for (auto &row : count) for (double &c : row) c = flat[k++];
   }
-  MachineCounts &operator+=(const MachineCounts &o) {       // src/counts.cpp:66-71 (the RCCL all-reduce across ranks)
+  MachineCounts &operator+=(const MachineCounts &o) {       // src/counts.cpp:66-71: counts only, like the reference
     for (size_t s = 0; s < count.size(); ++s) for (size_t t = 0; t < count[s].size(); ++t) count[s][t] += o.count[s][t];
-    loglike += o.loglike;
     return *this;
+  }
+};
+
+// ---- the caller's own types: duck-typed flattening, tokenising and envelopes --------------------------------------------------
+// EvaluatedMachine-shaped (src/eval.h:59-98): state[s].{outgoing[in][out] -> multimap<dest, {logWeight, transIndex}>,
+// logTransWeight, name}, inputTokenizer / outputTokenizer {tok2sym, tokenize()}.
+template <class EvalT>
+void flattenEvaluated(const EvalT &eval, FlatMachine &flat) {
+  flat.nStates = (int)eval.state.size();
+  flat.nInTok = (int)eval.inputTokenizer.tok2sym.size() - 1;      // token 0 = epsilon (src/eval.h:17)
+  flat.nOutTok = (int)eval.outputTokenizer.tok2sym.size() - 1;
+  for (StateIndex s = 0; s < eval.state.size(); ++s) {
+    const size_t n = eval.state[s].logTransWeight.size();
+    std::vector<uint32_t> dest(n); std::vector<uint16_t> in(n), out(n);
+    for (const auto &iost : eval.state[s].outgoing)
+      for (const auto &ost : iost.second)
+        for (const auto &st : ost.second) { dest[st.second.transIndex] = (uint32_t)st.first; in[st.second.transIndex] = (uint16_t)iost.first; out[st.second.transIndex] = (uint16_t)ost.first; }
+    for (size_t ti = 0; ti < n; ++ti) flat.addTransition((uint32_t)s, dest[ti], in[ti], out[ti], eval.state[s].logTransWeight[ti]);   // same walk as EvaluatedMachine::init
+  }
+  flat.finish();
+}
+
+// One device machine per EvaluatedMachine object: the matrices built from the same `eval` (the `for seqPair` loops of
+// target/boss.cpp:796,826) share it, new weights at the same address (an EM loop re-evaluating in place) are re-sent with
+// mb_machine_set_weights, a different topology rebuilds it.  forgetEvaluated() drops the entry when `eval` dies.
+inline std::map<const void *, std::shared_ptr<FlatMachine>> &flatRegistry() { static std::map<const void *, std::shared_ptr<FlatMachine>> r; return r; }
+template <class EvalT>
+std::shared_ptr<FlatMachine> flatOf(const EvalT &eval) {
+  std::shared_ptr<FlatMachine> fresh = std::make_shared<FlatMachine>();
+  flattenEvaluated(eval, *fresh);
+  std::shared_ptr<FlatMachine> &slot = flatRegistry()[(const void *)&eval];
+  if (slot && slot->nStates == fresh->nStates && slot->nInTok == fresh->nInTok && slot->nOutTok == fresh->nOutTok && slot->src == fresh->src &&
+      slot->dst == fresh->dst && slot->inTok == fresh->inTok && slot->outTok == fresh->outTok) {
+    if (slot->logWeight != fresh->logWeight) slot->setLogWeights(fresh->logWeight);
+    return slot;
+  }
+  slot = fresh;
+  return slot;
+}
+template <class EvalT>
+void forgetEvaluated(const EvalT &eval) { flatRegistry().erase((const void *)&eval); }
+
+// Envelope(const SeqPair&) (src/seqpair.cpp:104-110): the alignment's path envelope if the pair carries one, else full.
+// alignment: a sequence of (inputSymbol, outputSymbol) columns, empty symbol = gap (MachinePath::AlignCol, src/machine.h:208).
+template <class SeqPairT>
+Envelope envelopeOf(const SeqPairT &sp) {
+  Envelope e;
+  if (!sp.alignment.empty()) {
+    std::vector<Envelope::AlignCol> cols;
+    for (const auto &c : sp.alignment) cols.push_back(Envelope::AlignCol(!c.first.empty(), !c.second.empty()));
+    e.initPath(cols);
+  } else e.initFull((long)sp.input.seq.size(), (long)sp.output.seq.size());
+  return e;
+}
+
+template <class EvalT, class SeqPairT, class Core>
+class MatrixT : public Core {
+protected:
+  std::shared_ptr<FlatMachine> flatPtr;
+  template <class... Extra>
+  MatrixT(std::shared_ptr<FlatMachine> f, const EvalT &m, const SeqPairT &sp, Extra... extra)
+      : Core(*f, m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq), envelopeOf(sp), extra...), flatPtr(f), machine(m), seqPair(sp) {}
+public:
+  const EvalT &machine;       // the public members of the reference's DPMatrix (src/dpmatrix.h:125-131)
+  const SeqPairT &seqPair;
+  void writeJson(std::ostream &outs) const {
+    this->writeJsonWith(outs, seqPair.input.name, seqPair.output.name, [this](std::ostream &o, StateIndex s) { o << machine.state[s].name; });
+  }
+  friend std::ostream &operator<<(std::ostream &out, const MatrixT &m) { m.writeJson(out); return out; }
+};
+
+// The reference's constructors (src/forward.h:19-27, backward.h:47-48, viterbi.h:13-14).  Like the reference's, the ones
+// that take an Envelope IGNORE it and use Envelope(seqPair) (quirk Q1, src/dpmatrix.defs.h:16-17).
+template <class EvalT, class SeqPairT>
+class ForwardMatrixT : public MatrixT<EvalT, SeqPairT, ForwardCore> {
+  typedef MatrixT<EvalT, SeqPairT, ForwardCore> Base;
+public:
+  ForwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp, (StateIndex)0) {}
+  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp, (StateIndex)0) {}
+  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &, StateIndex startState) : Base(flatOf(m), m, sp, startState) {}
+};
+template <class EvalT, class SeqPairT>
+class BackwardMatrixT : public MatrixT<EvalT, SeqPairT, BackwardCore> {
+  typedef MatrixT<EvalT, SeqPairT, BackwardCore> Base;
+public:
+  BackwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp) {}
+  template <class EnvT> BackwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp) {}
+  using BackwardCore::getCounts;
+  template <class CountsT> void getCounts(const ForwardCore &forward, CountsT &counts) const {      // getCounts(forward, MachineCounts&), src/backward.cpp:58-60
+    BackwardCore::getCounts(forward, [&counts](StateIndex s, TransIndex ti, long, long, double postProb) { counts.count[s][ti] += postProb; });
+  }
+};
+template <class EvalT, class SeqPairT>
+class ViterbiMatrixT : public MatrixT<EvalT, SeqPairT, ViterbiCore> {
+  typedef MatrixT<EvalT, SeqPairT, ViterbiCore> Base;
+public:
+  ViterbiMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp) {}
+  template <class EnvT> ViterbiMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp) {}
+};
+template <class EvalT, class SeqPairT>
+class RollingOutputForwardMatrixT {        // MappedForwardMatrix<RollingOutputIndexMapper> (src/forward.h:29): logLike() only
+  double ll;
+public:
+  RollingOutputForwardMatrixT(const EvalT &m, const SeqPairT &sp) {
+    const std::shared_ptr<FlatMachine> f = flatOf(m);
+    const TokSeqPair tsp{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)};
+    ll = RollingOutputForwardMatrix(*f, tsp).logLike();
+  }
+  double logLike() const { return ll; }
+};
+
+// MachineCounts with the reference's constructors (src/counts.h:11-25).  A SeqPairList goes to the device as ONE batch.
+template <class EvalT, class SeqPairT, class SeqPairListT>
+struct MachineCountsT : MachineCounts {
+  MachineCountsT() {}
+  MachineCountsT(const EvalT &m) { init(m); }
+  MachineCountsT(const EvalT &m, const SeqPairT &sp) { init(m); (void)add(m, sp); }
+  MachineCountsT(const EvalT &m, const SeqPairListT &l) { init(m); addList(m, l); }
+  template <class EnvListT> MachineCountsT(const EvalT &m, const SeqPairListT &l, const EnvListT &) { init(m); addList(m, l); }   // envelopes: Envelope(seqPair) either way (Q1)
+  void init(const EvalT &m) { MachineCounts::init(*flatOf(m)); }
+  double add(const EvalT &m, const SeqPairT &sp) {
+    const std::shared_ptr<FlatMachine> f = flatOf(m);
+    const TokSeqPair tsp{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)};
+    return MachineCounts::add(*f, {tsp}, {envelopeOf(sp)})[0];
+  }
+  template <class EnvT> double add(const EvalT &m, const SeqPairT &sp, const EnvT &) { return add(m, sp); }
+  void addList(const EvalT &m, const SeqPairListT &l) {
+    const std::shared_ptr<FlatMachine> f = flatOf(m);
+    std::vector<TokSeqPair> pairs; std::vector<Envelope> envs;
+    for (const auto &sp : l.seqPairs) {
+      pairs.push_back(TokSeqPair{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)});
+      envs.push_back(envelopeOf(sp));
+    }
+    (void)MachineCounts::add(*f, pairs, envs);
   }
 };
 

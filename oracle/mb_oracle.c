@@ -357,3 +357,196 @@ long mbo_traceback(const mbo_machine *m, const int32_t *in, long inLen, const in
   for (long a = 0, b = n - 1; a < b; ++a, --b) { const uint32_t t = path[a]; path[a] = path[b]; path[b] = t; }
   return n;
 }
+
+/* ---- std::mt19937 as the reference's walkers consume it ------------------------------------------------------------
+ * DPMatrix::randomTransSelector (src/dpmatrix.defs.h:176-186) draws through random_index / random_double
+ * (src/util.h:102-106,151-165): one 32-bit output of std::mt19937 per choice, divided by 2^32.  The generator below is
+ * the published MT19937 algorithm (Matsumoto & Nishimura 1998: init_genrand / genrand_int32), which is what
+ * std::mt19937(seed) is defined to be. */
+typedef struct { uint32_t mt[624]; int idx; } mbo_mt19937;
+
+void mbo_mt_seed(mbo_mt19937 *g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+
+uint32_t mbo_mt_next(mbo_mt19937 *g) {
+  if (g->idx >= 624) {
+    for (int k = 0; k < 624; ++k) {
+      const uint32_t y = (g->mt[k] & 0x80000000u) | (g->mt[(k + 1) % 624] & 0x7fffffffu);
+      g->mt[k] = g->mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+
+mbo_mt19937 *mbo_mt_create(uint32_t seed) { mbo_mt19937 *g = (mbo_mt19937 *)malloc(sizeof(mbo_mt19937)); mbo_mt_seed(g, seed); return g; }
+void mbo_mt_destroy(mbo_mt19937 *g) { free(g); }
+
+/* random_index over exp(logWeights) (src/util.h:151-165 via src/dpmatrix.defs.h:178-184); -1 on zero total weight */
+static long select_random(const double *ll, long n, mbo_mt19937 *g) {
+  double norm = 0;
+  for (long k = 0; k < n; ++k) norm += exp(ll[k]);
+  if (!(norm > 0)) return -1;
+  double variate = (mbo_mt_next(g) / (((double)0xFFFFFFFFu) + 1)) * norm;
+  for (long k = 0; k < n; ++k)
+    if ((variate -= exp(ll[k])) <= 0) return k;
+  return n;
+}
+
+static long select_max(const double *ll, long n) { /* selectMaxTrans: std::max_element, first maximum (src/dpmatrix.defs.h:171-174) */
+  long best = 0;
+  for (long k = 1; k < n; ++k) if (ll[best] < ll[k]) best = k;
+  return best;
+}
+
+/* the TraceTerminator the tests use is Machine::downsample's (src/machine.cpp:2057-2064): a transition seen before stops
+ * the trace, a new one is marked and the trace goes on.  mask == NULL: never stop. */
+static int stop_mask(uint8_t *mask, uint32_t e) {
+  if (!mask) return 0;
+  if (mask[e]) return 1;
+  mask[e] = 1;
+  return 0;
+}
+
+/* DPMatrix::traceBack (m, inPos, outPos, s, stopTrace, selectTrans), src/dpmatrix.defs.h:82-110.
+ * selector 0 = selectMaxTrans, 1 = randomTransSelector(rng).  edges[] receives the global edge id of every step in the
+ * order the steps are taken (end -> start); the step that makes stopTrace return true is included.
+ * Returns the number of steps, -1: start cell is -inf, -2: cap too small, -3: empty candidate list / zero weights. */
+long mbo_trace_back(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *cells,
+                    long i, long o, int s, int selector, mbo_mt19937 *rng, uint8_t *mask, uint32_t *edges, long cap) {
+  const long I = inLen + 1; const int S = m->nStates;
+  if (!(CELL(cells, I, S, i, o, s) > NEG_INF)) return -1;
+  double *ll = (double *)malloc(sizeof(double) * (m->nTrans + 1));
+  uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (m->nTrans + 1));
+  long n = 0;
+  while (i > 0 || o > 0 || s != 0) {
+    const int it = i ? in[i - 1] : 0;
+    const int ot = o ? out[o - 1] : 0;
+    long nc = 0;
+    for (int grp = 0; grp < 4; ++grp) {
+      long k; const double *sc;
+      if (grp == 0) { if (!(i && o)) continue; k = KEY(m, s, it, ot); sc = &CELL(cells, I, S, i - 1, o - 1, 0); }
+      else if (grp == 1) { if (!i) continue; k = KEY(m, s, it, 0); sc = &CELL(cells, I, S, i - 1, o, 0); }
+      else if (grp == 2) { if (!o) continue; k = KEY(m, s, 0, ot); sc = &CELL(cells, I, S, i, o - 1, 0); }
+      else { k = KEY(m, s, 0, 0); sc = &CELL(cells, I, S, i, o, 0); }
+      for (long a = m->inOff[k]; a < m->inOff[k + 1]; ++a) {
+        const uint32_t e = m->inEdge[a];
+        cand[nc] = e; ll[nc++] = sc[m->src[e]] + m->logW[e];
+      }
+    }
+    if (!nc) { n = -3; break; }
+    const long best = selector ? select_random(ll, nc, rng) : select_max(ll, nc);
+    if (best < 0 || best >= nc) { n = -3; break; }
+    const uint32_t e = cand[best];
+    if (n >= cap) { n = -2; break; }
+    edges[n++] = e;
+    if (m->inTok[e]) --i;
+    if (m->outTok[e]) --o;
+    s = (int)m->src[e];
+    if (stop_mask(mask, e)) break;
+  }
+  free(ll); free(cand);
+  return n;
+}
+
+/* DPMatrix::traceForward (m, inPos, outPos, s, stopTrace, selectTrans), src/dpmatrix.defs.h:128-159, over a Backward
+ * matrix.  Same conventions; stopTrace is asked BEFORE the move (:149), and the step it stops at is not recorded
+ * unless the terminator itself records it -- here the mask terminator marks it, and it IS listed (as Machine::downsample
+ * counts it). */
+long mbo_trace_forward(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *cells,
+                       long i, long o, int s, int selector, mbo_mt19937 *rng, uint8_t *mask, uint32_t *edges, long cap) {
+  const long I = inLen + 1; const int S = m->nStates;
+  if (!(CELL(cells, I, S, i, o, s) > NEG_INF)) return -1;
+  double *ll = (double *)malloc(sizeof(double) * (m->nTrans + 1));
+  uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (m->nTrans + 1));
+  long n = 0;
+  while (i < inLen || o < outLen || s != S - 1) {
+    const int endIn = (i == inLen), endOut = (o == outLen);
+    const int it = endIn ? 0 : in[i];
+    const int ot = endOut ? 0 : out[o];
+    long nc = 0;
+    for (int grp = 0; grp < 4; ++grp) {
+      long k; const double *dc;
+      if (grp == 0) { if (endIn || endOut) continue; k = KEY(m, s, it, ot); dc = &CELL(cells, I, S, i + 1, o + 1, 0); }
+      else if (grp == 1) { if (endIn) continue; k = KEY(m, s, it, 0); dc = &CELL(cells, I, S, i + 1, o, 0); }
+      else if (grp == 2) { if (endOut) continue; k = KEY(m, s, 0, ot); dc = &CELL(cells, I, S, i, o + 1, 0); }
+      else { k = KEY(m, s, 0, 0); dc = &CELL(cells, I, S, i, o, 0); }
+      for (long a = m->outOff[k]; a < m->outOff[k + 1]; ++a) {
+        const uint32_t e = m->outEdge[a];
+        cand[nc] = e; ll[nc++] = dc[m->dst[e]] + m->logW[e];
+      }
+    }
+    if (!nc) { n = -3; break; }
+    const long best = selector ? select_random(ll, nc, rng) : select_max(ll, nc);
+    if (best < 0 || best >= nc) { n = -3; break; }
+    const uint32_t e = cand[best];
+    if (n >= cap) { n = -2; break; }
+    edges[n++] = e;
+    if (stop_mask(mask, e)) break;
+    if (m->inTok[e]) ++i;
+    if (m->outTok[e]) ++o;
+    s = (int)m->dst[e];
+  }
+  free(ll); free(cand);
+  return n;
+}
+
+/* BackwardMatrix::getCounts with a visitor (src/backward.cpp:58-87): every (cell, outgoing transition) usage in visit
+ * order, as BackwardMatrix::transitionSorter sees them (src/backward.h:28-34): position = the DESTINATION cell of the
+ * transition (accumulateCounts is handed inPos+1 / outPos+1, src/backward.cpp:77-83).  Returns the number of usages. */
+long mbo_post_trans(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *fwd,
+                    const double *bwd, long *pInPos, long *pOutPos, uint32_t *pEdge, double *pWeight, long cap) {
+  const long I = inLen + 1; const int S = m->nStates;
+  const double ll = CELL(bwd, I, S, 0, 0, 0);
+  long n = 0;
+  for (long o = outLen; o >= 0; --o) {
+    const int endOut = (o == outLen);
+    const int ot = endOut ? 0 : out[o];
+    for (long i = ENV_HI(o, inLen) - 1; i >= ENV_LO(o); --i) {
+      const int endIn = (i == inLen);
+      const int it = endIn ? 0 : in[i];
+      for (int s = S - 1; s >= 0; --s) {
+        const double logOdds = CELL(fwd, I, S, i, o, s) - ll;
+        for (int grp = 0; grp < 4; ++grp) {
+          long k, di, dq;
+          if (grp == 0) { if (endIn || endOut) continue; k = KEY(m, s, it, ot); di = i + 1; dq = o + 1; }
+          else if (grp == 1) { if (endIn) continue; k = KEY(m, s, it, 0); di = i + 1; dq = o; }
+          else if (grp == 2) { if (endOut) continue; k = KEY(m, s, 0, ot); di = i; dq = o + 1; }
+          else { k = KEY(m, s, 0, 0); di = i; dq = o; }
+          for (long a = m->outOff[k]; a < m->outOff[k + 1]; ++a) {
+            const uint32_t e = m->outEdge[a];
+            if (n >= cap) return -2;
+            pInPos[n] = di; pOutPos[n] = dq; pEdge[n] = e;
+            pWeight[n++] = exp(logOdds + CELL(bwd, I, S, di, dq, m->dst[e]) + m->logW[e]);
+          }
+        }
+      }
+    }
+  }
+  return n;
+}
+
+/* BackwardMatrix::traceFrom with a terminator (src/backward.cpp:99-108): the transition itself, then a traceback over
+ * the Forward matrix from (inPos,outPos,src), then a traceforward over the Backward matrix from the transition's far end.
+ * edges[]: the transition first (if the terminator did not stop on it: it is listed either way, as the terminator has
+ * marked it), then the traceback's steps, then the traceforward's. */
+long mbo_trace_from(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *fwd,
+                    const double *bwd, long i, long o, uint32_t e, uint8_t *mask, uint32_t *edges, long cap) {
+  long n = 0;
+  if (cap < 1) return -2;
+  edges[n++] = e;
+  if (stop_mask(mask, e)) return n;
+  const int s = (int)m->src[e];
+  long k = mbo_trace_back(m, in, inLen, out, outLen, fwd, i, o, s, 0, NULL, mask, edges + n, cap - n);
+  if (k < 0) return k;
+  n += k;
+  const long ni = i + (m->inTok[e] ? 1 : 0), no = o + (m->outTok[e] ? 1 : 0);
+  k = mbo_trace_forward(m, in, inLen, out, outLen, bwd, ni, no, (int)m->dst[e], 0, NULL, mask, edges + n, cap - n);
+  if (k < 0) return k;
+  return n + k;
+}

@@ -49,6 +49,17 @@ def lib():
         L.mbo_traceback.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, u32p, C.c_long]
         L.mbo_set_envelope.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.mbo_set_envelope.restype = None
+        u8p, lp = C.POINTER(C.c_uint8), C.POINTER(C.c_long)
+        L.mbo_mt_create.restype = vp; L.mbo_mt_create.argtypes = [C.c_uint32]
+        L.mbo_mt_destroy.argtypes = [vp]
+        L.mbo_mt_next.restype = C.c_uint32; L.mbo_mt_next.argtypes = [vp]
+        for fn in (L.mbo_trace_back, L.mbo_trace_forward):
+            fn.restype = C.c_long
+            fn.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, C.c_long, C.c_long, C.c_int, C.c_int, vp, u8p, u32p, C.c_long]
+        L.mbo_post_trans.restype = C.c_long
+        L.mbo_post_trans.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, dp, lp, lp, u32p, dp, C.c_long]
+        L.mbo_trace_from.restype = C.c_long
+        L.mbo_trace_from.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, dp, C.c_long, C.c_long, C.c_uint32, u8p, u32p, C.c_long]
         L.mbo_init()
         _LIB = L
     return _LIB
@@ -143,3 +154,68 @@ class OracleMachine:
         if n < 0:
             raise RuntimeError("Can't do traceback: no finite-weight paths" if n == -1 else "traceback error %d" % n)
         return path[:n].copy()
+
+    # ---- the matrix walkers (src/dpmatrix.defs.h:61-186, src/backward.cpp:52-108, src/forward.cpp:17-23) -------------
+    def _walk(self, fn, inp, out, cells, inPos, outPos, s, rng, mask):
+        i, o = self._seqs(inp, out)
+        cells = np.ascontiguousarray(cells, np.float64)
+        cap = (len(i) + len(o) + 2) * (self.nT + 2)
+        edges = np.empty(cap, np.uint32)
+        n = fn(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), _p(cells, C.c_double), inPos, outPos, s,
+               0 if rng is None else 1, None if rng is None else rng.h, None if mask is None else _p(mask, C.c_uint8), _p(edges, C.c_uint32), cap)
+        if n < 0:
+            raise RuntimeError("Can't do traceback: no finite-weight paths" if n == -1 else "walk error %d" % n)
+        return edges[:n].copy()
+
+    def trace_back(self, inp, out, cells, inPos=None, outPos=None, s=None, rng=None, mask=None):
+        """DPMatrix::traceBack with a terminator (mask: Machine::downsample's) and selectMaxTrans or, with ``rng`` (an
+        Mt19937), randomTransSelector.  Edge ids in the order the steps are taken (end -> start)."""
+        return self._walk(self.L.mbo_trace_back, inp, out, cells, len(inp) if inPos is None else inPos,
+                          len(out) if outPos is None else outPos, self.S - 1 if s is None else s, rng, mask)
+
+    def trace_forward(self, inp, out, cells, inPos=0, outPos=0, s=0, rng=None, mask=None):
+        return self._walk(self.L.mbo_trace_forward, inp, out, cells, inPos, outPos, s, rng, mask)
+
+    def post_trans(self, inp, out, fwd, bwd):
+        """BackwardMatrix::getCounts through a visitor: (inPos, outPos, edge, weight) arrays in visit order."""
+        i, o = self._seqs(inp, out)
+        cap = (len(i) + 1) * (len(o) + 1) * max(self.nT, 1) + 1
+        ip = np.empty(cap, np.int64); op = np.empty(cap, np.int64); e = np.empty(cap, np.uint32); w = np.empty(cap, np.float64)
+        fwd = np.ascontiguousarray(fwd, np.float64); bwd = np.ascontiguousarray(bwd, np.float64)
+        n = self.L.mbo_post_trans(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), _p(fwd, C.c_double), _p(bwd, C.c_double),
+                                  _p(ip, C.c_long), _p(op, C.c_long), _p(e, C.c_uint32), _p(w, C.c_double), cap)
+        assert n >= 0
+        return ip[:n].copy(), op[:n].copy(), e[:n].copy(), w[:n].copy()
+
+    def trace_from(self, inp, out, fwd, bwd, inPos, outPos, edge, mask=None):
+        """BackwardMatrix::traceFrom with a terminator: the transition, the traceback from its source, the traceforward
+        from its destination (edge ids in visit order)."""
+        i, o = self._seqs(inp, out)
+        fwd = np.ascontiguousarray(fwd, np.float64); bwd = np.ascontiguousarray(bwd, np.float64)
+        cap = 2 * (len(i) + len(o) + 2) * (self.nT + 2) + 1
+        edges = np.empty(cap, np.uint32)
+        n = self.L.mbo_trace_from(self.h, _p(i, C.c_int32), len(i), _p(o, C.c_int32), len(o), _p(fwd, C.c_double), _p(bwd, C.c_double),
+                                  inPos, outPos, int(edge), None if mask is None else _p(mask, C.c_uint8), _p(edges, C.c_uint32), cap)
+        if n < 0:
+            raise RuntimeError("traceFrom error %d" % n)
+        return edges[:n].copy()
+
+
+class Mt19937:
+    """std::mt19937(seed) of the oracle (mbo_mt_*)."""
+
+    def __init__(self, seed=5489):
+        self.L = lib(); self.h = self.L.mbo_mt_create(int(seed) & 0xFFFFFFFF)
+
+    def __call__(self):
+        return int(self.L.mbo_mt_next(self.h))
+
+    @staticmethod
+    def max():
+        return 0xFFFFFFFF
+
+    def __del__(self):
+        try:
+            self.L.mbo_mt_destroy(self.h)
+        except Exception:
+            pass

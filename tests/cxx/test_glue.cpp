@@ -1,0 +1,118 @@
+// boss.cpp / testforward.cpp / machine.cpp(downsample)-style caller code, written against the REFERENCE's class names and
+// signatures only (hipdp.h binds them to the HIP engine; mock_reference.h stands in for the reference's eval.h / seqpair.h /
+// machine.h).  Reads a machine and sequence pairs from a text file written by tests/test_cxx_glue.py, prints what the
+// reference's own callers would read; the Python test checks every line against the CPU oracle.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+
+#include "mock_reference.h"
+#include "hipdp.h"
+
+using namespace MachineBoss;
+using namespace std;
+
+static string sym(const string &s) { return s == "-" ? string() : s; }
+
+static void printPath(const char *tag, const MachinePath &p) {
+  cout << tag;
+  for (const auto &t : p.trans) cout << " " << t.dest << "," << (t.in.empty() ? "-" : t.in) << "," << (t.out.empty() ? "-" : t.out) << "," << setprecision(17) << t.weight;
+  cout << endl;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  ifstream f(argv[1]);
+  Machine machine;
+  size_t S; f >> S;
+  machine.state.resize(S);
+  for (size_t s = 0; s < S; ++s) {
+    size_t n; f >> machine.state[s].name.id >> n;
+    for (size_t k = 0; k < n; ++k) { MachineTransition t; string in, out; f >> t.dest >> in >> out >> t.weight; t.in = sym(in); t.out = sym(out); machine.state[s].trans.push_back(t); }
+  }
+  SeqPairList data;
+  size_t nPairs; f >> nPairs;
+  for (size_t p = 0; p < nPairs; ++p) {
+    SeqPair sp; size_t n;
+    f >> sp.input.name >> sp.output.name >> n; sp.input.seq.resize(n); for (auto &x : sp.input.seq) f >> x;
+    f >> n; sp.output.seq.resize(n); for (auto &x : sp.output.seq) f >> x;
+    data.seqPairs.push_back(sp);
+  }
+  unsigned seed; f >> seed;
+  const Params params;
+  try {
+    const EvaluatedMachine eval(machine, params);
+    const SeqPair &seqPair = data.seqPairs.front();
+
+    // t/src/testforward.cpp, testbackward.cpp
+    const ForwardMatrix forward(eval, seqPair);
+    cout << "FWDJSON_BEGIN" << endl; forward.writeJson(cout); cout << "FWDJSON_END" << endl;
+    const BackwardMatrix backward(eval, seqPair);
+    cout << "loglike " << setprecision(17) << forward.logLike() << " " << backward.logLike() << " dims " << forward.inLen << " " << forward.outLen << " " << forward.nStates
+         << " tok " << forward.input.size() << " " << forward.output.size() << " outside " << forward.cell(forward.inLen + 1, 0, 0) << endl;
+
+    // target/boss.cpp:796-805 (--loglike), :826-847 (--viterbi / --align)
+    for (const auto &sp : data.seqPairs) {
+      RollingOutputForwardMatrix roll(eval, sp);
+      ViterbiMatrix viterbi(eval, sp);
+      cout << "pair " << setprecision(17) << roll.logLike() << " " << viterbi.logLike() << endl;
+      if (viterbi.logLike() > -numeric_limits<double>::infinity()) printPath("align", viterbi.path(machine));
+    }
+
+    // target/boss.cpp:813, src/api.cpp:48-58 (--counts)
+    MachineCounts counts(eval, data);
+    cout << "counts " << setprecision(17) << counts.loglike;
+    for (const auto &row : counts.count) for (double c : row) cout << " " << c;
+    cout << endl;
+    MachineCounts one = forwardBackwardCounts(machine, params, seqPair), viaVisitor(eval);
+    backward.getCounts(forward, viaVisitor);                                     // src/counts.cpp:57-64 spelled out
+    double d = 0; for (size_t s = 0; s < one.count.size(); ++s) for (size_t t = 0; t < one.count[s].size(); ++t) d = max(d, fabs(one.count[s][t] - viaVisitor.count[s][t]));
+    cout << "counts_visitor_vs_device " << d << " api " << forwardLogLike(machine, params, seqPair) << " " << viterbiLogLike(machine, params, seqPair) << endl;
+    printPath("apialign", viterbiAlign(machine, params, seqPair));
+
+    // ForwardMatrix::samplePath (src/forward.cpp:17-23), stochasticDownsample's loop (src/machine.cpp:2107-2122)
+    mt19937 rng(seed);
+    for (int k = 0; k < 3; ++k) printPath("sample", forward.samplePath(machine, rng));
+    {
+      mt19937 rng2(seed + 1);
+      MachinePath mp;
+      DPMatrix<IdentityIndexMapper>::TraceTerminator neverStopTrace = [&](Envelope::InputIndex, Envelope::OutputIndex, StateIndex s, EvaluatedMachineState::TransIndex ti) {
+        mp.trans.push_front(machine.state[s].getTransition(ti)); return false; };
+      ForwardMatrix::TransSelector selectRandomTrans = forward.randomTransSelector(rng2);
+      forward.traceBack(machine, forward.inLen, forward.outLen, machine.endState(), neverStopTrace, selectRandomTrans);
+      printPath("sample2", mp);
+    }
+
+    // quirk Q2 overloads
+    printPath("tb_state", forward.traceBack(machine, (StateIndex)(S - 1)));
+    printPath("tf_quirk", backward.traceForward(machine));
+    printPath("tf_pos", backward.traceForward(machine, 0, 0, (StateIndex)(S - 1)));
+    printPath("tracefrom3", backward.traceFrom(machine, forward, 0, 0, (StateIndex)(S - 1)));
+
+    // Machine::downsample (src/machine.cpp:2053-2076): posterior queue + traceFrom with a terminator
+    vector<vector<bool>> transAllowed;
+    for (auto &ms : machine.state) transAllowed.push_back(vector<bool>(ms.trans.size()));
+    size_t nTrans = 0;
+    DPMatrix<IdentityIndexMapper>::TraceTerminator stopTrace = [&](Envelope::InputIndex, Envelope::OutputIndex, StateIndex s, EvaluatedMachineState::TransIndex ti) {
+      if (transAllowed[s][ti]) return true;
+      transAllowed[s][ti] = true; ++nTrans; return false; };
+    BackwardMatrix::PostTransQueue queue = backward.postTransQueue(forward);
+    cout << "queue " << queue.size() << endl;
+    size_t popped = 0;
+    while (!queue.empty() && popped < 12) {
+      const BackwardMatrix::PostTrans pt = queue.top();
+      queue.pop(); ++popped;
+      backward.traceFrom(machine, forward, pt.inPos, pt.outPos, pt.src, pt.transIndex, stopTrace);
+      cout << "pop " << pt.inPos << " " << pt.outPos << " " << pt.src << " " << pt.transIndex << " " << setprecision(17) << pt.weight << " allowed";
+      for (auto &row : transAllowed) for (bool b : row) cout << " " << (b ? 1 : 0);
+      cout << endl;
+    }
+    // errors surface as runtime_error with the reference's messages
+    try { SeqPair bad = seqPair; bad.input.seq.push_back("?"); ForwardMatrix oops(eval, bad); cout << "error none" << endl; }
+    catch (const runtime_error &e) { cout << "error " << e.what() << endl; }
+  } catch (const exception &e) { cout << "EXCEPTION " << e.what() << endl; return 1; }
+  cout << "GLUE OK" << endl;
+  return 0;
+}

@@ -1,0 +1,157 @@
+"""The C++ boundary, signature-compatible: tests/cxx/hipdp.h -- the glue header
+of INTEGRATION.md -- binds machineboss_amd/cxx/mb_dp.hpp's class templates to the reference's type shapes
+(tests/cxx/mock_reference.h), and tests/cxx/test_glue.cpp is caller code in the style of target/boss.cpp, t/src/test*.cpp
+and Machine::downsample, written against the reference's names only.
+
+CPU: the whole thing compiles and links.  GPU: it runs, and every line it prints is checked against the CPU oracle --
+the matrix walkers (traceBack / traceForward / samplePath / postTransQueue / traceFrom) EXACTLY, against oracle/mb_oracle.c's
+restatements of src/dpmatrix.defs.h:61-186, src/forward.cpp:17-23 and src/backward.cpp:52-108 walking the same matrices with
+the same std::mt19937 stream.
+"""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _build(tmp_path, name):
+    exe = str(tmp_path / name)
+    libdir = os.path.join(ROOT, "machineboss_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"),
+                           "-I", os.path.join(ROOT, "tests", "cxx"), os.path.join(ROOT, "tests", "cxx", name + ".cpp"), "-o", exe,
+                           "-L", libdir, "-lmbhip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_glue_compiles_against_reference_shapes(tmp_path):
+    """No GPU needed: the reference-style caller code compiles and links against the shim (-Wall -Werror)."""
+    from machineboss_amd import build
+    build.build()
+    assert os.path.exists(_build(tmp_path, "test_glue"))
+    assert os.path.exists(_build(tmp_path, "test_facade"))
+
+
+def _write_case(path, em, names, pairs, seed):
+    """Machine + pairs in the text form tests/cxx/test_glue.cpp reads (weights as exp(logWeight), 17 digits)."""
+    insym = [None] + list(em.inputTokenizer.tok2sym[1:]) if hasattr(em.inputTokenizer, "tok2sym") else None
+    with open(path, "w") as f:
+        f.write("%d\n" % em.nStates)
+        for s in range(em.nStates):
+            a, b = int(em.transOffset[s]), int(em.transOffset[s + 1])
+            f.write("%s %d\n" % (names[s], b - a))
+            for e in range(a, b):
+                f.write("%d %s %s %.17g\n" % (em.dst[e], em.inputTokenizer.detokenize([em.inTok[e]])[0] if em.inTok[e] else "-",
+                                              em.outputTokenizer.detokenize([em.outTok[e]])[0] if em.outTok[e] else "-", math.exp(em.logWeight[e])))
+        f.write("%d\n" % len(pairs))
+        for k, (x, y) in enumerate(pairs):
+            f.write("in%d out%d %d %s\n%d %s\n" % (k, k, len(x), " ".join(em.inputTokenizer.detokenize(x)), len(y), " ".join(em.outputTokenizer.detokenize(y))))
+        f.write("%d\n" % seed)
+
+
+def _edges_as_text(em, edges):
+    return ["%d,%s,%s" % (em.dst[e], em.inputTokenizer.detokenize([em.inTok[e]])[0] if em.inTok[e] else "-",
+                          em.outputTokenizer.detokenize([em.outTok[e]])[0] if em.outTok[e] else "-") for e in edges]
+
+
+def _path_of(line):
+    return [",".join(t.split(",")[:3]) for t in line.split()[1:]], [float(t.split(",")[3]) for t in line.split()[1:]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,seed", [(4, 11), (7, 12), (12, 13), (30, 14)])
+def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed):
+    from machineboss_amd import capi
+    from randmachine import random_machine, random_seq
+    if capi.device_count() == 0:
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    em = random_machine(S, 2, 3, seed, dup=True)
+    # EvaluatedMachine::init takes log(weight): round-trip the weights through exp/log so both sides hold identical doubles
+    lw = np.log(np.exp(em.logWeight)); em = em.withLogWeights(lw)
+    rng = np.random.RandomState(seed)
+    pairs = [(random_seq(rng, il, 2), random_seq(rng, ol, 3)) for il, ol in [(6, 7), (0, 4), (9, 3)]]
+    names = ["s%d" % s for s in range(S)]
+    case = str(tmp_path / "case.txt")
+    _write_case(case, em, names, pairs, 1000 + seed)
+    exe = _build(tmp_path, "test_glue")
+    out = subprocess.run([exe, case], capture_output=True, text=True)
+    assert out.returncode == 0 and "GLUE OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    get = lambda tag: [l for l in lines if l.split(" ")[0] == tag]
+    om = oracle_mod.OracleMachine(em)
+    dm = capi.DeviceMachine(em)
+    x, y = pairs[0]
+    F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y); V = dm.fill(capi.MB_VITERBI, x, y)   # the same device matrices the binary walked
+    lwv = np.asarray(em.logWeight)
+
+    def same_path(line, edges):
+        p, w = _path_of(line)
+        assert p == _edges_as_text(em, edges), (line, list(edges))
+        assert np.allclose(np.log(w), lwv[list(edges)], rtol=0, atol=1e-12) if len(w) else True
+
+    # writeJson: the reference's text layout, every cell at 5 significant digits
+    js = lines[lines.index("FWDJSON_BEGIN") + 1:lines.index("FWDJSON_END")]
+    assert js[0] == "{" and js[1] == ' "input": "in0",' and js[2] == ' "output": "out0",' and js[3] == ' "cell": ['
+    cells = [l for l in js if l.startswith("  { ")]
+    assert len(cells) == (len(x) + 1) * (len(y) + 1) * S
+    k = 0
+    for i in range(len(x) + 1):
+        for o in range(len(y) + 1):
+            for s in range(S):
+                v = F[o, i, s]
+                txt = ("%.5g" % v) if math.isfinite(v) else "-inf"
+                assert cells[k].rstrip(",") == '  { "inPos": %d, "outPos": %d, "state": "s%d", "logLike": %s }' % (i, o, s, txt), cells[k]
+                k += 1
+    ll = get("loglike")[0].split()
+    assert float(ll[1]) == F[-1, -1, -1] and float(ll[2]) == B[0, 0, 0] and ll[4:7] == [str(len(x)), str(len(y)), str(S)] and ll[-1] == "-inf"
+    # --loglike / --viterbi / --align per pair
+    pl = get("pair"); al = get("align"); ai = 0
+    for k, (a, b) in enumerate(pairs):
+        Vk = om.viterbi(a, b)
+        r, v = [float(t) for t in pl[k].split()[1:]]
+        ref = om.loglike(a, b, oracle_mod.SUM_EXACT)
+        assert v == Vk[-1, -1, -1] and (abs(r - ref) <= 2e-6 * abs(ref) + 2e-5 if math.isfinite(ref) else r == ref)
+        if Vk[-1, -1, -1] > -math.inf:
+            same_path(al[ai], om.traceback(a, b, Vk)); ai += 1
+    # MachineCounts over the list, the api.h wrappers, getCounts(forward, counts) on the host against the device sweep
+    cl = [float(t) for t in get("counts")[0].split()[1:]]
+    ref_c = np.zeros(em.nTransitions); ref_s = 0.0
+    for a, b in pairs:
+        l = om.loglike(a, b, oracle_mod.SUM_EXACT)
+        ref_s += om.counts_add(a, b, ref_c, oracle_mod.SUM_EXACT) if l > -math.inf else l
+    if math.isfinite(ref_s):
+        assert np.allclose(cl[1:], ref_c, rtol=1e-5, atol=1e-7) and abs(cl[0] - ref_s) <= 2e-6 * abs(ref_s) + 2e-5
+    cv = get("counts_visitor_vs_device")[0].split()
+    assert float(cv[1]) < 1e-6 and float(cv[3]) == F[-1, -1, -1] and float(cv[4]) == V[-1, -1, -1]
+    if V[-1, -1, -1] > -math.inf:
+        same_path(get("apialign")[0], om.traceback(x, y, V))
+    if F[-1, -1, -1] > -math.inf:
+        # samplePath: three draws from ONE generator, then stochasticDownsample's form with a second generator
+        g = oracle_mod.Mt19937(1000 + seed)
+        for line in get("sample"):
+            same_path(line, om.trace_back(x, y, F, rng=g)[::-1])
+        same_path(get("sample2")[0], om.trace_back(x, y, F, rng=oracle_mod.Mt19937(1001 + seed))[::-1])
+        # quirk Q2: MachinePath overloads start at (inLen, outLen) whatever position they are given; traceForward(m) = traceBack(m,0,0,0)
+        same_path(get("tb_state")[0], om.trace_back(x, y, F, s=S - 1)[::-1])
+        same_path(get("tf_quirk")[0], om.trace_back(x, y, B, s=0)[::-1])
+        same_path(get("tf_pos")[0], om.trace_forward(x, y, B, len(x), len(y), S - 1))
+        same_path(get("tracefrom3")[0], list(om.trace_back(x, y, F, s=S - 1)[::-1]) + list(om.trace_forward(x, y, B, len(x), len(y), S - 1)))
+        # Machine::downsample: the queue holds every posterior usage; replay the binary's pops through the oracle's traceFrom
+        ip, op, e, w = om.post_trans(x, y, F, B)
+        assert int(get("queue")[0].split()[1]) == len(w)
+        order = np.argsort(-w, kind="stable")
+        mask = np.zeros(em.nTransitions, np.uint8)
+        off = np.asarray(em.transOffset)
+        for n, line in enumerate(get("pop")):
+            t = line.split()
+            pi, po, src, ti, wt = int(t[1]), int(t[2]), int(t[3]), int(t[4]), float(t[5])
+            assert wt == w[order[n]]                                         # largest posterior weight first
+            edge = int(off[src]) + ti
+            cand = [k for k in range(len(w)) if w[k] == wt and e[k] == edge and ip[k] == pi and op[k] == po]
+            assert cand, line
+            om.trace_from(x, y, F, B, pi, po, edge, mask)
+            assert [int(b) for b in t[7:]] == list(mask), line
+    assert get("error")[0].startswith("error Can't tokenize symbol")
