@@ -82,11 +82,15 @@ def spawn_ranks(args) -> int:
 
 
 def timed(fn, reps=1):
-    fn()
+    """Mean wall time of `reps` calls after one warm-up call.  The results stay referenced until the clock stops: freeing
+    a large host array (munmap) inside the timed region stalls the NEXT GPU submission of the process by tens of
+    milliseconds on this driver (scripts/vit_timing.py keep / drop), which is the caller's cost, not the library's."""
+    held = [fn()]
     t0 = time.perf_counter()
     for _ in range(reps):
-        r = fn()
-    return r, (time.perf_counter() - t0) / reps
+        held.append(fn())
+    dt = (time.perf_counter() - t0) / reps
+    return held[-1], dt
 
 
 def extra_single_gpu(capi, np, hbm_peak):

@@ -303,12 +303,46 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
     return 0
 
 
+def _init_ranks():
+    """Launched under torchrun (WORLD_SIZE > 1): bind this rank to its GPU and open the process group BEFORE the first
+    GPU call, so that run() shards the pair list and reduces the counts (backend nccl = RCCL on GPUs, gloo without).
+    Returns the torch.distributed module if this call opened the group (the caller closes it), else None."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return None
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("MB_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")   # gloo: several ranks on ONE GPU (tests)
+    if torch.cuda.is_available() and backend != "nccl":
+        from . import capi
+        capi.set_device(local)
+        dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world)
+    elif torch.cuda.is_available():
+        from . import capi
+        capi.set_device(local)
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=world)
+    return dist
+
+
 def main(argv: Optional[List[str]] = None) -> int:
+    opened = None
     try:
+        opened = _init_ranks()
         return run(argv)
     except (MachineError, OSError, KeyError, ValueError) as e:   # main() of the reference prints what() and fails (boss.cpp:923-926)
         sys.stderr.write(str(e) + "\n")
         return 1
+    finally:
+        if opened is not None:
+            opened.destroy_process_group()
 
 
 if __name__ == "__main__":

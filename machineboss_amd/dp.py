@@ -363,6 +363,8 @@ class ViterbiMatrix(_DPMatrix):
         if not (self.endCell() > -math.inf):
             raise MachineError("Can't do traceback: no finite-weight paths")
         b = capi.DeviceBatch.from_pairs(self._dm, [(self.input, self.output)])
+        if not self.env.isFull():      # the matrix was filled inside Envelope(seqPair) (quirk Q1): the traceback must stay inside it too
+            b.set_envelopes([(self.env.inStart, self.env.inEnd)])
         _, off, edges = b.viterbi(paths=True)
         b.close()
         return edgesToPath(self.machine, m, edges)
@@ -386,6 +388,9 @@ def forwardLogLikeBatch(machine: EvaluatedMachine, pairs: Sequence[SeqPair], rol
     out = [-math.inf] * len(pairs)
     if toks:
         b = capi.DeviceBatch.from_pairs(dm, toks)
+        envs = [Envelope(sp) for sp, k in zip(pairs, ok) if k]      # quirk Q1: RollingOutputForwardMatrix(eval, seqPair) uses Envelope(seqPair)
+        if any(not e.isFull() for e in envs):
+            b.set_envelopes([None if e.isFull() else (e.inStart, e.inEnd) for e in envs])
         ll = b.forward(capi.MB_ROLLING if rolling else capi.MB_MATERIALISE)
         b.close()
         it = iter(ll)

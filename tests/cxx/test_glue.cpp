@@ -4,6 +4,7 @@
 // reference's own callers would read; the Python test checks every line against the CPU oracle.
 #include <cstdio>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <random>
 #include <sstream>
@@ -70,7 +71,10 @@ int main(int argc, char **argv) {
     backward.getCounts(forward, viaVisitor);                                     // src/counts.cpp:57-64 spelled out
     double d = 0; for (size_t s = 0; s < one.count.size(); ++s) for (size_t t = 0; t < one.count[s].size(); ++t) d = max(d, fabs(one.count[s][t] - viaVisitor.count[s][t]));
     cout << "counts_visitor_vs_device " << d << " api " << forwardLogLike(machine, params, seqPair) << " " << viterbiLogLike(machine, params, seqPair) << endl;
-    printPath("apialign", viterbiAlign(machine, params, seqPair));
+    const bool reachable = forward.logLike() > -numeric_limits<double>::infinity();      // boss.cpp checks the same before tracing (target/boss.cpp:831)
+    if (reachable) printPath("apialign", viterbiAlign(machine, params, seqPair));
+    else { try { (void)viterbiAlign(machine, params, seqPair); cout << "noalign none" << endl; } catch (const runtime_error &e) { cout << "noalign " << e.what() << endl; } }
+    if (reachable) {
 
     // ForwardMatrix::samplePath (src/forward.cpp:17-23), stochasticDownsample's loop (src/machine.cpp:2107-2122)
     mt19937 rng(seed);
@@ -86,10 +90,15 @@ int main(int argc, char **argv) {
     }
 
     // quirk Q2 overloads
-    printPath("tb_state", forward.traceBack(machine, (StateIndex)(S - 1)));
-    printPath("tf_quirk", backward.traceForward(machine));
-    printPath("tf_pos", backward.traceForward(machine, 0, 0, (StateIndex)(S - 1)));
-    printPath("tracefrom3", backward.traceFrom(machine, forward, 0, 0, (StateIndex)(S - 1)));
+    // (on a random machine these odd walks may start from a -inf cell or run into a cell without candidates -- an Assert /
+    //  undefined behaviour in the reference, a runtime_error here; the oracle must fail on exactly the same ones)
+    auto attempt = [&](const char *tag, function<MachinePath()> walk) {
+      try { printPath(tag, walk()); } catch (const runtime_error &e) { cout << tag << "_error " << e.what() << endl; }
+    };
+    attempt("tb_state", [&]() { return forward.traceBack(machine, (StateIndex)(S - 1)); });
+    attempt("tf_quirk", [&]() { return backward.traceForward(machine); });
+    attempt("tf_pos", [&]() { return backward.traceForward(machine, 0, 0, (StateIndex)(S - 1)); });
+    attempt("tracefrom3", [&]() { return backward.traceFrom(machine, forward, 0, 0, (StateIndex)(S - 1)); });
 
     // Machine::downsample (src/machine.cpp:2053-2076): posterior queue + traceFrom with a terminator
     vector<vector<bool>> transAllowed;
@@ -108,6 +117,7 @@ int main(int argc, char **argv) {
       cout << "pop " << pt.inPos << " " << pt.outPos << " " << pt.src << " " << pt.transIndex << " " << setprecision(17) << pt.weight << " allowed";
       for (auto &row : transAllowed) for (bool b : row) cout << " " << (b ? 1 : 0);
       cout << endl;
+    }
     }
     // errors surface as runtime_error with the reference's messages
     try { SeqPair bad = seqPair; bad.input.seq.push_back("?"); ForwardMatrix oops(eval, bad); cout << "error none" << endl; }

@@ -436,6 +436,65 @@ def test_backward_visitors_match_device_counts(capi, machines):
     assert emitted_in == len(x) and emitted_out == len(y) and len(used) > 0
 
 
+@pytest.mark.parametrize("name,il,ol", [("dnapsw", 9, 12), ("bitstutter-noise", 3, 6), ("protpsw", 7, 5)])
+def test_host_walkers_match_oracle_exactly(capi, oracle_mod, machines, name, il, ol):
+    """The host walkers of dp.py (rows a7 / a10 / a13: samplePath, traceBack / traceForward with selectors and terminators,
+    postTransQueue, traceFrom) against the oracle's restatements of src/dpmatrix.defs.h:61-186, src/forward.cpp:17-23 and
+    src/backward.cpp:52-108, walking the SAME device-filled matrices with the same std::mt19937 stream: identical steps."""
+    from machineboss_amd.dp import ForwardMatrix, BackwardMatrix, SeqPair, Mt19937, randomTransSelector
+    preset = name != "bitstutter-noise"
+    m, em = machines(name, None if preset else load_json("io", "params.json"), useDefaults=preset, preset=preset)
+    om = oracle_mod.OracleMachine(em)
+    x, y = synth_tokens(17, il, ol, em.nInTok, em.nOutTok)
+    if name == "bitstutter-noise":
+        x, y = em.inputTokenizer.tokenize(list("101")), em.outputTokenizer.tokenize(list("100110"))
+    sp = SeqPair(em.inputTokenizer.detokenize(x), em.outputTokenizer.detokenize(y))
+    fwd, back = ForwardMatrix(em, sp), BackwardMatrix(em, sp)
+    F, B = fwd.cells(), back.cells()
+    off = np.asarray(em.transOffset)
+    eid = lambda steps: [int(off[s]) + int(ti) for s, ti in steps]
+    # samplePath: several draws from one generator (the state of the stream carries over, as in stochasticDownsample)
+    g_host, g_or = Mt19937(42), oracle_mod.Mt19937(42)
+    for _ in range(4):
+        assert eid(fwd.samplePath(m, g_host).steps) == list(om.trace_back(x, y, F, rng=g_or)[::-1])
+    # traceBack with a terminator from an interior cell that carries probability, max and random selectors
+    for (ip, op) in [(len(x), len(y)), (len(x) // 2, len(y) // 2)]:
+        for s in range(em.nStates):
+            if not F[op, ip, s] > -math.inf:
+                continue
+            steps = []
+            fwd.traceBackFrom(m, ip, op, s, lambda a, b, src, ti: steps.append((src, ti)) or False)
+            assert eid(steps) == list(om.trace_back(x, y, F, ip, op, s))
+            steps = []; gh, go = Mt19937(7 + s), oracle_mod.Mt19937(7 + s)
+            fwd.traceBackFrom(m, ip, op, s, lambda a, b, src, ti: steps.append((src, ti)) or False, randomTransSelector(gh))
+            assert eid(steps) == list(om.trace_back(x, y, F, ip, op, s, rng=go))
+            if B[op, ip, s] > -math.inf:
+                steps = []
+                back.traceForwardFrom(m, ip, op, s, lambda a, b, src, ti: steps.append((src, ti)) or False)
+                assert eid(steps) == list(om.trace_forward(x, y, B, ip, op, s))
+    # postTransQueue: the same usages with the same weights, largest first
+    q = back.postTransQueue(fwd)
+    ipo, opo, eo, wo = om.post_trans(x, y, F, B)
+    assert len(q) == len(wo)
+    order = np.argsort(-wo, kind="stable")
+    assert [pt.weight for pt in q] == [wo[k] for k in order]
+    assert [(pt.inPos, pt.outPos, int(off[pt.src]) + pt.transIndex) for pt in q] == [(int(ipo[k]), int(opo[k]), int(eo[k])) for k in order]
+    # Machine::downsample's loop (src/machine.cpp:2053-2076): traceFrom with its terminator, over the head of the queue
+    allowed = np.zeros(em.nTransitions, np.uint8); mask = np.zeros(em.nTransitions, np.uint8)
+
+    def stop(a, b, src, ti):
+        e = int(off[src]) + ti
+        if allowed[e]:
+            return True
+        allowed[e] = 1
+        return False
+    for pt in q[:10]:
+        back.traceFrom(m, fwd, pt.inPos, pt.outPos, pt.src, pt.transIndex, stop)
+        om.trace_from(x, y, F, B, pt.inPos, pt.outPos, int(off[pt.src]) + pt.transIndex, mask)
+        assert np.array_equal(allowed, mask)
+    assert allowed.sum() > 0
+
+
 # ---- envelopes (src/seqpair.h:75-97; DPMatrix fills visit only the cells inside, dpmatrix.h:142-144 reads -inf outside) ----
 @pytest.mark.parametrize("name,il,ol,width", [("dnapsw", 14, 17, 2), ("bitstutter-noise", 4, 6, 1), ("psw2dna", 3, 11, 1)])
 def test_envelope_fills_match_oracle(capi, oracle_mod, machines, name, il, ol, width):
@@ -494,6 +553,14 @@ def test_path_envelope_through_dp_classes(capi, machines):
     mc = MachineCounts(em, aligned)
     # 3 + 2 aligned columns, each a match transition of the single state; nothing else is reachable in the envelope
     assert abs(sum(sum(r) for r in mc.count) - 5.0) < 1e-9
+    # the batch front ends keep the same envelope: --loglike of an aligned pair is its path's weight, and ViterbiMatrix::path
+    # traces inside the envelope the matrix was filled in (it agrees with logLike() and with the host walk over that matrix)
+    from machineboss_amd.dp import ViterbiMatrix, forwardLogLikeBatch
+    assert forwardLogLikeBatch(em, [aligned[0], plain[0]]) == [fa.logLike(), fp.logLike()]
+    va = ViterbiMatrix(em, aligned[0])
+    dev, host = va.path(m), va.traceBack(m)
+    assert dev.steps == host.steps and len(dev.steps) == 3
+    assert abs(sum(em.logWeight[em.transOffset[s] + ti] for s, ti in dev.steps) - va.logLike()) < 1e-12
 
 
 @pytest.mark.parametrize("idx", range(5))
@@ -962,3 +1029,32 @@ def test_randomised_sweep(capi):
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_gpu.py"), "24", "4242"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "24 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_boss_cli_two_ranks_end_to_end(capi, tmp_path):
+    """`torchrun -m machineboss_amd.boss` as the launcher sets it up (RANK / WORLD_SIZE / LOCAL_RANK in the environment):
+    main() opens the process group itself, the pairs are sharded, rank 0 prints exactly what one process prints -- for
+    --loglike (gathered in input order), --counts (all-reduced) and --train.  Two ranks share the one GPU of this box, so
+    the exchange runs over gloo here (MB_DIST_BACKEND); on a multi-GPU node the same code path takes RCCL."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, "-m", "machineboss_amd.boss", golden_path("machine", "bitnoise.json"), "-D", golden_path("io", "seqpairlist.json")]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    for extra in (["-P", golden_path("io", "params.json"), "-L"], ["-P", golden_path("io", "params.json"), "-C"], ["-N", golden_path("io", "pqcons.json"), "-T"]):
+        single = subprocess.run(base + extra, capture_output=True, text=True, cwd=ROOT)
+        assert single.returncode == 0, single.stderr
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MB_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        assert outs[1][0] == ""                                   # only rank 0 prints
+        if "-T" in extra:
+            a, b = json.loads(single.stdout), json.loads(outs[0][0])
+            assert a.keys() == b.keys() and all(abs(a[k] - b[k]) <= 1e-6 * abs(a[k]) for k in a)
+        else:
+            assert outs[0][0] == single.stdout
+        port += 1
