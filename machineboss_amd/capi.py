@@ -25,7 +25,7 @@ EXPORTS = [
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source",
-    "mb_jit_stats", "mb_set_option", "mb_get_option",
+    "mb_jit_stats", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
@@ -82,6 +82,9 @@ def load():
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_debug_small_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                         C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_log_sum_exp.argtypes = [C.c_double, C.c_double]; L.mb_log_sum_exp.restype = C.c_double
+    L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
+    L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
     L.mb_jit_stats.argtypes = [dp, i64p, i64p]
     L.mb_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.mb_get_option.argtypes = [C.c_char_p]; L.mb_get_option.restype = C.c_char_p

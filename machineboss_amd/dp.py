@@ -37,10 +37,18 @@ class MachinePath:
 
 
 class Mt19937:
-    """std::mt19937(seed) as the reference uses it (``generator()`` -> 32-bit unsigned; src/util.h:102-106)."""
+    """std::mt19937(seed) as the reference uses it (``generator()`` -> 32-bit outputs; src/util.h:102-106).
 
-    def __init__(self, seed: int = 5489):
+    ``result_bits`` is the width of ``std::mt19937::result_type`` (``uint_fast32_t``) on the platform the reference is built
+    on.  random_double divides by ``numeric_limits<result_type>::max() + 1``, NOT by ``Generator::max() + 1``: with
+    libstdc++ on LP64 Linux -- this container and the GPU box -- uint_fast32_t is a 64-bit unsigned long, so the variate lies
+    in [0, 2**-32) and random_index all but always returns the first candidate of non-negligible weight.  That is the
+    reference's behaviour here, hence the default (quirk Q12); ``result_bits=32`` is the libc++ (macOS) reading,
+    under which samplePath really samples."""
+
+    def __init__(self, seed: int = 5489, result_bits: int = 64):
         self._rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+        self.result_type_max = (1 << result_bits) - 1
 
     def __call__(self) -> int:
         return int(self._rs.randint(0, 2 ** 32, dtype=np.uint64))
@@ -51,8 +59,8 @@ class Mt19937:
 
 
 def random_double(rng) -> float:
-    """src/util.h:102-106."""
-    return rng() / (float(rng.max()) + 1.0)
+    """src/util.h:102-106: generator() / (numeric_limits<result_type>::max() + 1)."""
+    return rng() / (float(getattr(rng, "result_type_max", rng.max())) + 1.0)
 
 
 def random_index(weights: Sequence[float], rng) -> int:
@@ -320,7 +328,7 @@ class BackwardMatrix(_DPMatrix):
                     groups.append((0, 0, inPos, outPos))
                     for it, ot, ip, op in groups:
                         for dest, ti, lw in outg.get((s, it, ot), ()):
-                            visit(s, ti, ip, op, math.exp(logOdds + self.cell(ip, op, dest) + lw))
+                            visit(s, ti, ip, op, math.exp(logOdds + (self.cell(ip, op, dest) + lw)))   # iterate forms cell + logWeight first (src/dpmatrix.h:111)
 
     def postTransQueue(self, forward: "ForwardMatrix") -> List[PostTrans]:
         """All posterior transition usages as a max-heap ordered list, largest weight first (src/backward.cpp:52-56).

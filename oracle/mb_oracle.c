@@ -387,12 +387,22 @@ uint32_t mbo_mt_next(mbo_mt19937 *g) {
 mbo_mt19937 *mbo_mt_create(uint32_t seed) { mbo_mt19937 *g = (mbo_mt19937 *)malloc(sizeof(mbo_mt19937)); mbo_mt_seed(g, seed); return g; }
 void mbo_mt_destroy(mbo_mt19937 *g) { free(g); }
 
+/* random_double (src/util.h:102-106) divides one generator output by numeric_limits<Generator::result_type>::max() + 1.
+ * For std::mt19937 the result_type is uint_fast32_t, which libstdc++ on LP64 Linux -- the platform the reference is built
+ * on here and on the GPU box -- makes a 64-BIT unsigned long: the divisor is 2^64 although the generator only ever
+ * returns 32 bits, so the "uniform" variate lies in [0, 2^-32) and random_index all but always takes the first candidate
+ * of non-negligible weight.  That is what the reference does on this platform, so it is what the restatement does by
+ * default (SURVEY.md section 9 does not list it: quirk Q12 in DESIGN.md); with libc++ (macOS) uint_fast32_t is 32 bits
+ * and the divisor 2^32 -- mbo_set_result_bits(32) selects that reading. */
+static double mt_denominator = 18446744073709551616.0;   /* ((double) ULONG_MAX) + 1 */
+void mbo_set_result_bits(int bits) { mt_denominator = bits == 32 ? 4294967296.0 : 18446744073709551616.0; }
+
 /* random_index over exp(logWeights) (src/util.h:151-165 via src/dpmatrix.defs.h:178-184); -1 on zero total weight */
 static long select_random(const double *ll, long n, mbo_mt19937 *g) {
   double norm = 0;
   for (long k = 0; k < n; ++k) norm += exp(ll[k]);
   if (!(norm > 0)) return -1;
-  double variate = (mbo_mt_next(g) / (((double)0xFFFFFFFFu) + 1)) * norm;
+  double variate = (mbo_mt_next(g) / mt_denominator) * norm;
   for (long k = 0; k < n; ++k)
     if ((variate -= exp(ll[k])) <= 0) return k;
   return n;
@@ -420,6 +430,7 @@ static int stop_mask(uint8_t *mask, uint32_t e) {
 long mbo_trace_back(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *cells,
                     long i, long o, int s, int selector, mbo_mt19937 *rng, uint8_t *mask, uint32_t *edges, long cap) {
   const long I = inLen + 1; const int S = m->nStates;
+  if (i < 0 || i > inLen || o < 0 || o > outLen) return -1;   /* the const cell() reads -inf outside the envelope (src/dpmatrix.h:142-144) */
   if (!(CELL(cells, I, S, i, o, s) > NEG_INF)) return -1;
   double *ll = (double *)malloc(sizeof(double) * (m->nTrans + 1));
   uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (m->nTrans + 1));
@@ -461,6 +472,7 @@ long mbo_trace_back(const mbo_machine *m, const int32_t *in, long inLen, const i
 long mbo_trace_forward(const mbo_machine *m, const int32_t *in, long inLen, const int32_t *out, long outLen, const double *cells,
                        long i, long o, int s, int selector, mbo_mt19937 *rng, uint8_t *mask, uint32_t *edges, long cap) {
   const long I = inLen + 1; const int S = m->nStates;
+  if (i < 0 || i > inLen || o < 0 || o > outLen) return -1;
   if (!(CELL(cells, I, S, i, o, s) > NEG_INF)) return -1;
   double *ll = (double *)malloc(sizeof(double) * (m->nTrans + 1));
   uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (m->nTrans + 1));
@@ -522,7 +534,8 @@ long mbo_post_trans(const mbo_machine *m, const int32_t *in, long inLen, const i
             const uint32_t e = m->outEdge[a];
             if (n >= cap) return -2;
             pInPos[n] = di; pOutPos[n] = dq; pEdge[n] = e;
-            pWeight[n++] = exp(logOdds + CELL(bwd, I, S, di, dq, m->dst[e]) + m->logW[e]);
+            const double tll = CELL(bwd, I, S, di, dq, m->dst[e]) + m->logW[e];   /* DPMatrix::iterate forms cell + logWeight first (src/dpmatrix.h:111) */
+            pWeight[n++] = exp(logOdds + tll);                                      /* accumulateCounts, src/backward.h:38-40 */
           }
         }
       }

@@ -53,6 +53,7 @@ def lib():
         L.mbo_mt_create.restype = vp; L.mbo_mt_create.argtypes = [C.c_uint32]
         L.mbo_mt_destroy.argtypes = [vp]
         L.mbo_mt_next.restype = C.c_uint32; L.mbo_mt_next.argtypes = [vp]
+        L.mbo_set_result_bits.argtypes = [C.c_int]; L.mbo_set_result_bits.restype = None
         for fn in (L.mbo_trace_back, L.mbo_trace_forward):
             fn.restype = C.c_long
             fn.argtypes = [vp, i32p, C.c_long, i32p, C.c_long, dp, C.c_long, C.c_long, C.c_int, C.c_int, vp, u8p, u32p, C.c_long]
@@ -199,6 +200,12 @@ class OracleMachine:
         if n < 0:
             raise RuntimeError("traceFrom error %d" % n)
         return edges[:n].copy()
+
+
+def set_result_bits(bits: int):
+    """Width of std::mt19937::result_type assumed by random_double: 64 (libstdc++ on LP64 Linux, the default -- see
+    mb_oracle.c) or 32 (libc++)."""
+    lib().mbo_set_result_bits(bits)
 
 
 class Mt19937:

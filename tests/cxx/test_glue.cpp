@@ -100,24 +100,36 @@ int main(int argc, char **argv) {
     attempt("tf_pos", [&]() { return backward.traceForward(machine, 0, 0, (StateIndex)(S - 1)); });
     attempt("tracefrom3", [&]() { return backward.traceFrom(machine, forward, 0, 0, (StateIndex)(S - 1)); });
 
-    // Machine::downsample (src/machine.cpp:2053-2076): posterior queue + traceFrom with a terminator
-    vector<vector<bool>> transAllowed;
-    for (auto &ms : machine.state) transAllowed.push_back(vector<bool>(ms.trans.size()));
-    size_t nTrans = 0;
-    DPMatrix<IdentityIndexMapper>::TraceTerminator stopTrace = [&](Envelope::InputIndex, Envelope::OutputIndex, StateIndex s, EvaluatedMachineState::TransIndex ti) {
-      if (transAllowed[s][ti]) return true;
-      transAllowed[s][ti] = true; ++nTrans; return false; };
-    BackwardMatrix::PostTransQueue queue = backward.postTransQueue(forward);
-    cout << "queue " << queue.size() << endl;
-    size_t popped = 0;
-    while (!queue.empty() && popped < 12) {
-      const BackwardMatrix::PostTrans pt = queue.top();
-      queue.pop(); ++popped;
-      backward.traceFrom(machine, forward, pt.inPos, pt.outPos, pt.src, pt.transIndex, stopTrace);
-      cout << "pop " << pt.inPos << " " << pt.outPos << " " << pt.src << " " << pt.transIndex << " " << setprecision(17) << pt.weight << " allowed";
-      for (auto &row : transAllowed) for (bool b : row) cout << " " << (b ? 1 : 0);
-      cout << endl;
+    BackwardMatrix::PostTransQueue fullQueue = backward.postTransQueue(forward);
+    cout << "queue " << fullQueue.size() << " top " << setprecision(17) << (fullQueue.empty() ? 0.0 : fullQueue.top().weight) << endl;
     }
+    // Machine::downsample (src/machine.cpp:2036-2076), for machines it accepts (acyclic, topologically sorted): the labels are
+    // stripped, the matrices are those of the EMPTY sequence pair, and the posterior queue is drained through traceFrom
+    bool dag = true;
+    for (size_t s = 0; s < S; ++s) for (const auto &t : machine.state[s].trans) dag = dag && t.dest > s;
+    if (dag) {
+      Machine null(machine);
+      vector<vector<bool>> transAllowed;
+      for (auto &ms : null.state) { for (auto &mt : ms.trans) mt.in = mt.out = string(); transAllowed.push_back(vector<bool>(ms.trans.size())); }
+      const SeqPair emptySeqPair;
+      const EvaluatedMachine evalNull(null, params);
+      const ForwardMatrix fwd(evalNull, emptySeqPair);
+      const BackwardMatrix back(evalNull, emptySeqPair);
+      size_t nTrans = 0;
+      DPMatrix<IdentityIndexMapper>::TraceTerminator stopTrace = [&](Envelope::InputIndex, Envelope::OutputIndex, StateIndex s, EvaluatedMachineState::TransIndex ti) {
+        if (transAllowed[s][ti]) return true;
+        transAllowed[s][ti] = true; ++nTrans; return false; };
+      BackwardMatrix::PostTransQueue queue = back.postTransQueue(fwd);
+      cout << "nullqueue " << queue.size() << " " << setprecision(17) << fwd.logLike() << endl;
+      const size_t nTransTarget = (size_t)(null.state.size() ? 0.6 * queue.size() : 0);
+      while (!queue.empty() && (nTrans == 0 || nTrans < nTransTarget)) {
+        const BackwardMatrix::PostTrans pt = queue.top();
+        queue.pop();
+        back.traceFrom(null, fwd, pt.inPos, pt.outPos, pt.src, pt.transIndex, stopTrace);
+        cout << "pop " << pt.inPos << " " << pt.outPos << " " << pt.src << " " << pt.transIndex << " " << setprecision(17) << pt.weight << " allowed";
+        for (auto &row : transAllowed) for (bool b : row) cout << " " << (b ? 1 : 0);
+        cout << endl;
+      }
     }
     // errors surface as runtime_error with the reference's messages
     try { SeqPair bad = seqPair; bad.input.seq.push_back("?"); ForwardMatrix oops(eval, bad); cout << "error none" << endl; }

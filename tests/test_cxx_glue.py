@@ -45,7 +45,7 @@ def _write_case(path, em, names, pairs, seed):
             f.write("%s %d\n" % (names[s], b - a))
             for e in range(a, b):
                 f.write("%d %s %s %.17g\n" % (em.dst[e], em.inputTokenizer.detokenize([em.inTok[e]])[0] if em.inTok[e] else "-",
-                                              em.outputTokenizer.detokenize([em.outTok[e]])[0] if em.outTok[e] else "-", math.exp(em.logWeight[e])))
+                                              em.outputTokenizer.detokenize([em.outTok[e]])[0] if em.outTok[e] else "-", em._fileWeights[e]))
         f.write("%d\n" % len(pairs))
         for k, (x, y) in enumerate(pairs):
             f.write("in%d out%d %d %s\n%d %s\n" % (k, k, len(x), " ".join(em.inputTokenizer.detokenize(x)), len(y), " ".join(em.outputTokenizer.detokenize(y))))
@@ -61,21 +61,50 @@ def _path_of(line):
     return [",".join(t.split(",")[:3]) for t in line.split()[1:]], [float(t.split(",")[3]) for t in line.split()[1:]]
 
 
+def _random_dag(S, nIn, nOut, seed):
+    """Acyclic, topologically sorted machine (every transition goes to a higher state): what Machine::downsample accepts."""
+    from machineboss_amd.evalmachine import EvaluatedMachine, Tokenizer
+    rng = np.random.RandomState(seed)
+    edges = []
+    for s in range(S - 1):
+        for _ in range(rng.randint(1, 4)):
+            kind = rng.randint(0, 4)
+            it = rng.randint(1, nIn + 1) if kind in (0, 1) else 0
+            ot = rng.randint(1, nOut + 1) if kind in (0, 2) else 0
+            edges.append((s, rng.randint(s + 1, S), it, ot, float(np.log(rng.uniform(0.05, 1.0)))))
+        edges.append((s, s + 1, 0, 0, float(np.log(rng.uniform(0.2, 1.0)))))
+    edges.sort(key=lambda e: e[0])
+    src = np.array([e[0] for e in edges], np.uint32); dst = np.array([e[1] for e in edges], np.uint32)
+    it = np.array([e[2] for e in edges], np.uint16); ot = np.array([e[3] for e in edges], np.uint16)
+    lw = np.array([e[4] for e in edges], np.float64)
+    off = np.zeros(S + 1, np.int64)
+    for s in src:
+        off[s + 1] += 1
+    off = np.cumsum(off)
+    tidx = (np.arange(len(edges)) - off[src]).astype(np.uint32)
+    return EvaluatedMachine(S, Tokenizer([chr(65 + k) for k in range(nIn)]), Tokenizer([chr(97 + k) for k in range(nOut)]),
+                            src, dst, it, ot, tidx, lw, off, [None] * S)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,seed", [(4, 11), (7, 12), (12, 13), (30, 14)])
-def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed):
+@pytest.mark.parametrize("S,seed,dag", [(4, 11, False), (7, 12, False), (12, 13, False), (30, 14, False), (9, 21, True), (25, 22, True)])
+def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed, dag):
     from machineboss_amd import capi
     from randmachine import random_machine, random_seq
     if capi.device_count() == 0:
         pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
-    em = random_machine(S, 2, 3, seed, dup=True)
-    # EvaluatedMachine::init takes log(weight): round-trip the weights through exp/log so both sides hold identical doubles
-    lw = np.log(np.exp(em.logWeight)); em = em.withLogWeights(lw)
+    em = _random_dag(S, 2, 3, seed) if dag else random_machine(S, 2, 3, seed, dup=True)
+    # EvaluatedMachine::init takes log(weight) of the weight it is given: the file carries w = exp(logWeight) at 17 digits and
+    # this side keeps libm's log(w) (math.log, the function std::log calls), so both hold identical doubles
+    ws = [float("%.17g" % math.exp(l)) for l in em.logWeight]
+    em = em.withLogWeights(np.array([math.log(w) for w in ws]))
+    em._fileWeights = ws
     rng = np.random.RandomState(seed)
     om0 = oracle_mod.OracleMachine(em)
     first = None
-    for _ in range(200):      # the first pair is the one the walkers run on: one the machine can produce
-        cand = (random_seq(rng, 6, 2), random_seq(rng, 7, 3))
+    for k in range(400):      # the first pair is the one the walkers run on: one the machine can produce
+        il, ol = ((2, 2), (1, 3), (3, 1), (2, 3))[k % 4] if dag else (6, 7)
+        cand = (random_seq(rng, il, 2), random_seq(rng, ol, 3))
         if om0.loglike(*cand) > -math.inf:
             first = cand
             break
@@ -153,21 +182,32 @@ def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed):
         quirk("tf_quirk", lambda: om.trace_back(x, y, B, s=0)[::-1])
         quirk("tf_pos", lambda: om.trace_forward(x, y, B, len(x), len(y), S - 1))
         quirk("tracefrom3", lambda: list(om.trace_back(x, y, F, s=S - 1)[::-1]) + list(om.trace_forward(x, y, B, len(x), len(y), S - 1)))
-        # Machine::downsample: the queue holds every posterior usage; replay the binary's pops through the oracle's traceFrom
         ip, op, e, w = om.post_trans(x, y, F, B)
-        assert int(get("queue")[0].split()[1]) == len(w)
-        order = np.argsort(-w, kind="stable")
-        mask = np.zeros(em.nTransitions, np.uint8)
-        off = np.asarray(em.transOffset)
-        for n, line in enumerate(get("pop")):
-            t = line.split()
-            pi, po, src, ti, wt = int(t[1]), int(t[2]), int(t[3]), int(t[4]), float(t[5])
-            assert wt == w[order[n]]                                         # largest posterior weight first
-            edge = int(off[src]) + ti
-            cand = [k for k in range(len(w)) if w[k] == wt and e[k] == edge and ip[k] == pi and op[k] == po]
-            assert cand, line
-            om.trace_from(x, y, F, B, pi, po, edge, mask)
-            assert [int(b) for b in t[7:]] == list(mask), line
+        qn = get("queue")[0].split()
+        assert int(qn[1]) == len(w) and float(qn[3]) == w.max()
     else:
         assert get("noalign")[0] == "noalign Can't do traceback: no finite-weight paths"     # src/dpmatrix.defs.h:84
+    if dag:
+        # Machine::downsample on the label-stripped machine and the empty pair: replay the binary's pops through the oracle's
+        # traceFrom with the same terminator; the allowed-transition mask must agree after every pop
+        from machineboss_amd.evalmachine import EvaluatedMachine, Tokenizer
+        z = np.zeros(em.nTransitions, np.uint16)
+        en = EvaluatedMachine(em.nStates, Tokenizer([]), Tokenizer([]), em.src, em.dst, z, z, em.transIndex, em.logWeight, em.transOffset, [None] * S)
+        omn = oracle_mod.OracleMachine(en); dmn = capi.DeviceMachine(en)
+        e0 = np.zeros(0, np.int32)
+        Fn = dmn.fill(capi.MB_FORWARD, e0, e0); Bn = dmn.fill(capi.MB_BACKWARD, e0, e0)
+        ipn, opn, edn, wn = omn.post_trans(e0, e0, Fn, Bn)
+        nq = get("nullqueue")[0].split()
+        assert int(nq[1]) == len(wn) and float(nq[2]) == Fn[-1, -1, -1]
+        order = np.argsort(-wn, kind="stable")
+        mask = np.zeros(em.nTransitions, np.uint8)
+        off = np.asarray(em.transOffset)
+        pops = get("pop")
+        assert pops
+        for n, line in enumerate(pops):
+            t = line.split()
+            pi, po, src, ti, wt = int(t[1]), int(t[2]), int(t[3]), int(t[4]), float(t[5])
+            assert wt == wn[order[n]] and pi == 0 and po == 0                 # largest posterior weight first
+            omn.trace_from(e0, e0, Fn, Bn, 0, 0, int(off[src]) + ti, mask)
+            assert [int(b) for b in t[7:]] == list(mask), line
     assert get("error")[0].startswith("error Can't tokenize symbol")

@@ -165,3 +165,40 @@ def test_oracle_envelope_semantics(oracle_mod):
     fe = Envelope.fullEnvelope(sp)
     with oracle_mod.envelope(fe.inStart, fe.inEnd):
         assert np.array_equal(om.forward(x, y, oracle_mod.SUM_EXACT), full)
+
+
+def test_host_logsumexp_helpers_match_reference_table(oracle_mod):
+    """mb_log_sum_exp / _n / mb_log_inner_product (src/logsumexp.h:72-172: the helpers that stay exported when logsumexp.*
+    is replaced): the reference's interpolated-table arithmetic bit for bit -- against the oracle's restatement, which is
+    pinned to the reference's golden matrices -- incl. -inf handling and the 10-nat cut-off."""
+    import ctypes as C
+    from machineboss_amd import capi
+    L = capi.load(); O = oracle_mod.lib()
+    rng = np.random.RandomState(5)
+    inf = float("inf")
+    pairs = [(-inf, -inf), (-inf, 1.5), (1.5, -inf), (0.0, 0.0), (1.0, -9.0), (1.0, -9.00001), (3.0, 3.0 + 1e-9), (2.0, -8.0)]
+    pairs += [tuple(rng.uniform(-40, 5, 2)) for _ in range(20000)]
+    for a, b in pairs:
+        assert L.mb_log_sum_exp(a, b) == O.mbo_log_sum_exp(a, b, 0), (a, b)
+    assert L.mb_log_sum_exp(1.0, -9.5) == 1.0                 # terms 10 nats below the maximum are dropped entirely
+    v = rng.uniform(-12, 0, 37); w = rng.uniform(-3, 0, 37)
+    tot = -inf; lip = -inf
+    for x, y in zip(v, w):
+        tot = O.mbo_log_sum_exp(tot, x, 0); lip = O.mbo_log_sum_exp(lip, x + y, 0)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert L.mb_log_sum_exp_n(p(v), len(v)) == tot and L.mb_log_inner_product(p(v), p(w), None, len(v)) == lip
+    assert L.mb_log_sum_exp_n(p(v), 0) == -inf
+
+
+def test_logsumexp_header_compiles(tmp_path):
+    """machineboss_amd/cxx/mb_logsumexp.hpp: the reference's helper names over the C-ABI."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "mb_logsumexp.hpp"\n#include <cstdio>\nusing namespace MachineBossHIP;\n'
+                   'int main() { double a = -1; log_accum_exp(a, -2); std::vector<double> v{-1, -2, -3};\n'
+                   '  std::printf("%.17g %.17g %.17g\\n", a, log_sum_exp(v), logInnerProduct(v, v)); return log_sum_exp(-1., -2., -3.) == log_sum_exp(v) ? 0 : 1; }\n')
+    libdir = os.path.join(ROOT, "machineboss_amd")
+    exe = str(tmp_path / "t")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"), str(src), "-o", exe,
+                           "-L", libdir, "-lmbhip", "-Wl,-rpath," + libdir])
+    assert subprocess.run([exe]).returncode == 0
