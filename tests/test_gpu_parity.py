@@ -1070,6 +1070,7 @@ def test_boss_cli_two_ranks_end_to_end(capi, tmp_path):
             procs.append(subprocess.Popen(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
         outs = [p.communicate(timeout=300) for p in procs]
         assert all(p.returncode == 0 for p in procs), outs
+        outs = [("".join(l for l in o.splitlines(True) if not l.startswith("[Gloo]")), e) for o, e in outs]   # gloo's own connection banner
         assert outs[1][0] == ""                                   # only rank 0 prints
         if "-T" in extra:
             a, b = json.loads(single.stdout), json.loads(outs[0][0])
