@@ -291,8 +291,13 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     const int NA = (inLen + 64) >> 6;
     const int Te = (outLen + 65) & ~1;
     const int t0 = b * A.TS, t1 = min(t0 + A.TS, Te);
-    const int i = a * 64 + lane;
-    const bool colValid = i <= inLen;
+    // Backward programs (reversed frame) keep their padding columns in FRONT of the sequence: frame column i of lane c of
+    // strip a is then the mirror image of the Forward sweep's lane 63 - c of strip NA - 1 - a, so the count sweep reads
+    // every Backward step block whole, by one wavefront, in one run (reversed lane order) instead of two partial runs
+    // from two blocks that each share their border cache line with another wavefront.
+    const int pad = JREV ? NA * 64 - 1 - inLen : 0;
+    const int i = a * 64 + lane - pad;
+    const bool colValid = i >= 0 && i <= inLen;
     const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
     const int it = (colValid && i > 0) ? (JREV ? in[inLen - i] : in[i - 1]) : 0;
     auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (JREV ? out[outLen - o] : out[o - 1]) : 0; };
@@ -315,10 +320,12 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     const double *poolB = A.pool + ax.pool;
     const double bLL = A.bwdLL[pairIdx];                          // BackwardMatrix::logLike(), src/backward.cpp:48-50,66
     const double negLL = (bLL > NEG_INF) ? -bLL : NEG_INF;        // -inf likelihood: every term becomes exp(-inf) = 0
-    auto bPtr = [&](int o) -> const double * {                    // chunk 0 of cell (i, o), clamped into the lattice
-      const int ib = inLen - min(i, inLen), ob = outLen - min(max(o, 0), outLen);
-      const int ab = ib >> 6, cb = ib & 63;
-      return poolB + (((long long)ab * Te + (ob + cb)) * (JNCH * 64) + cb) * (JCHB / 8);
+    // Cell (i, o) of this lane at step t sits in the Backward sweep's strip NA-1-a, step (outLen - o) + (63 - lane) =
+    // outLen + 63 - t, lane 63 - lane: ONE step block for the whole wavefront, read whole (lanes outside the lattice read
+    // their mirror slot, which exists and is ignored, instead of a clamped address -- a clamped lane pulls a cache-line
+    // sector of its own from each of the block's chunk rows: 47 padding lanes of the last strip cost 1.3x the traffic).
+    auto bPtr = [&](int t) -> const double * {
+      return poolB + (((long long)(NA - 1 - a) * Te + max(outLen + 63 - t, 0)) * (JNCH * 64) + (63 - lane)) * (JCHB / 8);
     };
 #pragma unroll 1
     for (int j = 0; j < JROWF; ++j) rowL[j] = 0.0f;
@@ -433,7 +440,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       // the Backward supercell of this step's cell: requested at the top of the step, used after its Forward values are done
       b << "          " << (CB == 16 ? "d2" : "double");
       for (int k = 0; k < NCH; ++k) b << (k ? "," : "") << " bq" << k;
-      b << ";\n          { const double *bp = bPtr(o);\n";
+      b << ";\n          { const double *bp = bPtr(t);\n";
       for (int k = 0; k < NCH; ++k)
         b << "            bq" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
       b << "          }\n";
@@ -481,7 +488,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
         for (int k = 1; k < n; ++k) b << " + ex2(v" << k << " - gM)";
         b << ";\n            double res = gM + (double)(__builtin_amdgcn_logf(sm) * SM_LN2);\n";
       }
-      if (d == P.seedState) b << "            res = ((t | a | lane) == 0) ? 0.0 : res;   // cell(0,0,start) = 0: no other candidate is finite there\n";
+      if (d == P.seedState) b << "            res = ((i | o) == 0) ? 0.0 : res;   // cell(0,0,start) = 0: no other candidate is finite there\n";
       b << "            " << cp << d << " = res;\n";
       b << "          }\n";
     }

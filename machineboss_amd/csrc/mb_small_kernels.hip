@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_small_unpack(const double *__restrict__
     const long long sc = idx / S;
     const int s = (int)(idx - sc * S);
     const int o = (int)(sc / I), i = (int)(sc - (long long)o * I);
-    const int fi = reversed ? inLen - i : i, fo = reversed ? outLen - o : o;
+    // the reversed frame keeps its padding columns in front (mb_small.cpp): frame column inLen - i sits at NA*64 - 1 - i
+    const int fi = reversed ? small_strips(inLen) * 64 - 1 - i : i, fo = reversed ? outLen - o : o;
     const int a = fi >> 6, c = fi & 63, t = fo + c;
     cells[idx] = pool[((((long long)a * Te + t) * NCH + s / CBD) * 64 + c) * CBD + (s % CBD)];
   }
