@@ -220,7 +220,7 @@ def test_unreachable_is_minus_infinity(capi, machines):
     assert vll[0] == -math.inf and off[1] == 0
 
 
-@pytest.mark.parametrize("idx", [0, 1, 3])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
 def test_survey_anchors_gpu(capi, machines, idx):
     """Benchmark-scale reference outputs through the GPU path: Forward within 1e-4 relative
     (observed ~1e-8), Viterbi log-likelihood and path length exact at 10 significant digits."""
@@ -954,6 +954,79 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     lw = np.array(em.logWeight, dtype=np.float64) - 0.125
     dm.set_weights(lw); om.set_weights(lw)
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
+
+
+@pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])
+def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, nodes, nSeq, L):
+    """BASELINE config 5 at the sizes that select the one-tape family's DEFAULT paths (no environment forcing): the 20-node
+    machine (5 063 states: fp64 columns in LDS) on 64 x 2 kb and the whole fn3 profile (21 761 states: fp32-relative columns,
+    previous column in L2) on 8 x 300 nt.  Rolling == materialised; the other arithmetic variant agrees to 1e-6; the Viterbi
+    path re-scores to the Viterbi score and spells the sequence; counts keep the symbol-count invariant; one sequence of
+    30 nt against the oracle."""
+    m, em = _profile_machine(nodes)
+    assert em.nInTok == 0 and em.nStates == {20: 5063, 86: 21761}[nodes]
+    dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(nodes)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, 4, size=L).astype(np.int32) for _ in range(nSeq)]      # DNA over {A,C,G}: no stop codons
+    ys[1] = ys[0].copy()
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    llr = b.forward(capi.MB_ROLLING)
+    kern = capi.last_kernel_name()
+    assert kern == ("k_wide_sweep<0>" if nodes == 20 else "k_wide_sum32")
+    nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
+    bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
+    llm = bm.forward(capi.MB_MATERIALISE)
+    assert np.all(np.isfinite(llr)) and close(llm, llr[:nm], 1e-9) and llr[0] == llr[1]
+    # the other arithmetic (fp32-relative <-> fp64 columns) on a fresh machine object
+    monkeypatch.setenv("MB_WIDE_FP32", "1" if nodes == 20 else "0")             # (fp64 columns of the whole profile do not fit the LDS: they go to L2 by themselves)
+    dm2 = capi.DeviceMachine(em)
+    b2 = capi.DeviceBatch.from_pairs(dm2, [(x, y) for y in ys[:nm]])
+    ll2 = b2.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name() != kern and close(ll2, llr[:nm], 1e-6)
+    monkeypatch.delenv("MB_WIDE_FP32")
+    # Viterbi: score <= Forward, the path is contiguous, spells the sequence and re-scores to the score
+    bv = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:2]])
+    vll, off, edges = bv.viterbi()
+    lw = np.asarray(em.logWeight)
+    assert np.all(vll <= llr[:2] + 1e-9) and vll[0] == vll[1]
+    e = edges[off[0]:off[1]]
+    assert em.src[e[0]] == 0 and em.dst[e[-1]] == em.nStates - 1 and np.array_equal(em.dst[e[:-1]], em.src[e[1:]])
+    assert np.array_equal(em.outTok[e][em.outTok[e] != 0], ys[0])
+    acc = 0.0
+    for w in lw[e]:
+        acc += w
+    assert abs(acc - vll[0]) <= 1e-9 * abs(vll[0])
+    # counts: every output symbol is emitted exactly once per sequence
+    counts, s, cll = bv.counts()
+    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 1e-5 * 2 * L and close(cll, llr[:2], 1e-8)
+    # one short sequence against the oracle
+    om = oracle_mod.OracleMachine(em)
+    y30 = ys[0][:30]
+    b30 = capi.DeviceBatch.from_pairs(dm, [(x, y30)])
+    ref = om.loglike(x, y30, oracle_mod.SUM_EXACT)
+    assert close(b30.forward(capi.MB_ROLLING), [ref], FAST_REL, FAST_ABS)
+    v30, o30, e30 = b30.viterbi()
+    V = om.viterbi(x, y30)
+    assert v30[0] == V[-1, -1, -1] and np.array_equal(e30, om.traceback(x, y30, V))
+
+
+def test_pipelined_forward_matches_plain(capi, machines):
+    """Config 4a's 256-pair pipeline (matrix slots recycled while the sweep is in flight, medium_forward_pipelined) against
+    the same pairs filled without recycling: identical log-likelihoods."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    inTok, inOff, outTok, outOff = synth_batch(4, 24, 487, 1500, em.nInTok, em.nOutTok)
+    b = capi.DeviceBatch(dm, inTok, inOff, outTok, outOff)
+    plain = b.forward(capi.MB_MATERIALISE)
+    one = (487 + 1) * (1500 + 1) * em.nStates * 8
+    capi.set_memory_budget(5 * one)            # room for five matrices: the other 19 pairs reuse their slots
+    try:
+        piped = b.forward(capi.MB_MATERIALISE)
+        launches = capi.last_launch_count()
+    finally:
+        capi.set_memory_budget(0)
+    assert np.array_equal(piped, plain) and launches > 0 and "k_medium" in capi.last_kernel_name()
 
 
 def test_one_tape_family_small_machines(capi, oracle_mod, monkeypatch):
