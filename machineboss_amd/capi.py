@@ -185,7 +185,7 @@ def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = Fal
                                       mode, int(backward), int(closure), G, path.encode()))
 
 
-def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, materialise: bool = True):
+def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, materialise: bool = True, envelopes: bool = False):
     """Write the HIP source of the small-machine family's sweep for this machine (host only, no GPU needed).
     mode: 0 sum, 1 max (fp64 cells), 2 max (traceback bytes), 3 Forward fused with posterior counts."""
     a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
@@ -193,7 +193,7 @@ def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, mat
          np.ascontiguousarray(em.logWeight, np.float64)]
     _check(load().mb_debug_small_source(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
                                         _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
-                                        mode, int(backward), int(materialise), path.encode()))
+                                        mode, int(backward), int(materialise) | (2 if envelopes else 0), path.encode()))
 
 
 class DeviceMachine:

@@ -503,6 +503,7 @@ static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, boo
     if (tc.p0 != c.p0 || tc.p1 != c.p1) { if (tc.d_tiles) (void)hipFree(tc.d_tiles); tc = SmTileCache(); tc.p0 = c.p0; tc.p1 = c.p1; }
     sw.tileCache = &tc;
   }
+  if (b->hasEnv) { sw.d_envStart = b->d_envStart; sw.d_envEnd = b->d_envEnd; }   // PairDesc::envBase (-1: full) indexes them
   if (wantPool && !(sw.d_pool = (double *)ws_get(0, (size_t)std::max<long long>(pl.poolD, 1) * 8))) return 1;
   if (wantTb && !(sw.d_tb = (unsigned char *)ws_get(8, (size_t)std::max<long long>(pl.tbB, 16)))) return 1;
   if (!(sw.d_halo = (double *)ws_get(9, (size_t)std::max<long long>(pl.haloD, 1) * 8))) return 1;
@@ -901,7 +902,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   mb_machine *m = b->m;
-  if (mode == MB_FORWARD && !b->hasEnv && use_small(m)) return small_forward(b, flags, loglike);
+  if (mode == MB_FORWARD && use_small(m)) return small_forward(b, flags, loglike);
   double *d_ll = nullptr;
   MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
@@ -1001,7 +1002,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
   if (pathOff) pathOff[0] = 0;
   if (b->nPairs == 0) return 0;
-  if (!b->hasEnv && use_small(b->m)) return small_viterbi(b, loglike, pathOff, pathEdges, pathCap);
+  if (use_small(b->m)) return small_viterbi(b, loglike, pathOff, pathEdges, pathCap);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 1, chunks)) return 1;
   int rc = 0;
@@ -1085,7 +1086,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   const long long nT = b->m->nTrans;
-  if (!b->hasEnv && use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF)) return small_counts(b, counts, loglikeSum, loglike);
+  if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF)) return small_counts(b, counts, loglikeSum, loglike);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;
@@ -1158,7 +1159,7 @@ int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const
     const int64_t envOff[2] = {0, outLen + 1};
     if (mb_batch_set_envelopes(b, envOff, envStart, envEnd)) { mb_batch_destroy(b); return 1; }
   }
-  if (!b->hasEnv && startState == 0 && use_small(m)) {
+  if (startState == 0 && use_small(m)) {
     const int rcs = small_fill(b, mode, cellsOut);
     mb_batch_destroy(b);
     return rcs;
@@ -1227,7 +1228,7 @@ int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
   SmallProgram P;
   if (!small_build_host(&m, backward != 0, P)) { set_error("machine does not qualify for the small-machine family"); return 1; }
-  const std::string code = small_jit_source(P, mode, materialise != 0);
+  const std::string code = small_jit_source(P, mode, (materialise & 1) != 0, (materialise & 2) != 0);   // bit 1: the restricted-envelope variant
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_small_source: cannot open output file"); return 1; }
   fprintf(f, "// ldsBytes=%zu H=%d NBD=%d tables: silent %d input %d output %d match %d\n", small_jit_lds_bytes(P, mode), P.H, P.NBD,

@@ -177,7 +177,8 @@ bool small_build(const mb_machine *m, bool backward, SmallProgram &P) {
 void small_free(SmallProgram &P) {
   for (int mo = 0; mo < SM_NMODE; ++mo)
     for (int ma = 0; ma < 2; ++ma)
-      if (P.jit[mo][ma].module) (void)hipModuleUnload((hipModule_t)P.jit[mo][ma].module);
+      for (int en = 0; en < 2; ++en)
+        if (P.jit[mo][ma][en].module) (void)hipModuleUnload((hipModule_t)P.jit[mo][ma][en].module);
   void *ptrs[] = {P.d_w, P.d_eid, P.d_decOff, P.d_dec};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   P = SmallProgram();
@@ -191,7 +192,7 @@ static int row_floats(const SmallProgram &P) {   // count mode: lane-private usa
 }
 static int outacc_floats(const SmallProgram &P) { return (P.nTab[2] * (P.nOut + 1) + 1) & ~1; }   // count mode: usage by (output-token table, token)
 static long long wave_doubles(const SmallProgram &P, int mode) {
-  long long d = 32 + 64ll * std::max(P.H, 1);
+  long long d = 32 + 64 + 64ll * std::max(P.H, 1);   // tokens, envelope rows (start / end), halo rows
   if (mode == SM_COUNT) d += (64ll * row_floats(P) + 1) / 2 + outacc_floats(P) / 2;
   return (d + 1) & ~1ll;
 }
@@ -214,6 +215,7 @@ struct SmallArgs {
   const int4 *tiles; int tileBase, tileEnd, TS, nRep;
   double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
   double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
+  const int *envStart; const int *envEnd;
 };
 typedef const __attribute__((address_space(4))) double *cdbl_t;
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -271,7 +273,9 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
   double *myL = lds + JLDSW + wv * JWAVEDBL;
 #endif
   int *tokL = (int *)myL;                                    // output tokens entering lane 0, one block of 64 steps
-  double *haloL = myL + 32;                                  // halo rows entering lane 0, same block
+  int *envSL = (int *)(myL + 32), *envEL = envSL + 64;       // envelope rows (inStart, inEnd) entering lane 0, same block
+  double *haloL = myL + 96;                                  // halo rows entering lane 0, same block
+  (void)envSL; (void)envEL;
 #if JMODE == 3
   float *rowL = (float *)(haloL + 64 * JHP) + lane * JROWF;  // this lane's usage sums of the match transitions, by output token
   float *outAcc = (float *)(haloL + 64 * JHP) + 64 * JROWF + (JROWF & 1);   // this wavefront's usage sums of the output-only transitions
@@ -336,11 +340,22 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
 /*@LOADBND@*/
     }
     int ot = tokAt(t0 - 1 - lane);
+#if JENV
+    // restricted envelope of the pair (src/seqpair.h:75-97): cell (x, y) exists <=> inStart[y] <= x < inEnd[y]; rows travel
+    // along the lanes with their output position like the tokens do.  A full-envelope pair of the batch reads [0, inLen+1).
+    const int *envS = pd.envBase >= 0 ? A.envStart + pd.envBase : nullptr, *envE = pd.envBase >= 0 ? A.envEnd + pd.envBase : nullptr;
+    auto envRow = [&](int o, const int *e, int dflt) -> int { return (e && o >= 0 && o <= outLen) ? e[JREV ? outLen - o : o] : dflt; };
+    int es = envRow(t0 - 1 - lane, envS, 0), ee = envRow(t0 - 1 - lane, envE, inLen + 1);
+    const int iOrig = JREV ? inLen - i : i;
+#endif
 #if JH > 0
     if (a == 0) for (int h = 0; h < JH; ++h) haloL[lane * JH + h] = NEG_INF;
 #endif
     for (int tb = t0; tb < t1; tb += 64) {
       tokL[lane] = tokAt(tb + lane);
+#if JENV
+      envSL[lane] = envRow(tb + lane, envS, 0); envEL[lane] = envRow(tb + lane, envE, inLen + 1);
+#endif
 #if JH > 0
       if (a > 0) {
         const int ho = tb + lane;
@@ -386,13 +401,13 @@ const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise)
   return P.backward ? "k_small_sum_bwd" : (materialise ? "k_small_sum_mat" : "k_small_sum_roll");
 }
 
-std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) {
+std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env) {
   std::ostringstream defs, weights, state, loadb, saveb, flush;
   const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
   const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
   const int rowF = row_floats(P);
-  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? 4 : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
-       << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
+  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? (env ? 3 : 4) : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
+       << "\n#define JENV " << (env ? 1 : 0) << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
        << "\n#define JNBD " << P.NBD << "\n#define JCHB " << CB << "\n#define JNCH " << NCH << "\n#define JTBSTRIDE " << small_tb_stride(S)
        << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
        << "\n#define JLDSWN " << (P.nEntries - P.off[2]) << "\n#define JWAVEDBL " << wave_doubles(P, mode)
@@ -453,6 +468,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
       for (int k = 0; k < P.nTab[2]; ++k) b << "          aO" << k << " = shrf(aO" << k << ", 0.0f);\n";
     }
     b << "          ot = shri(ot, tokL[jj]);\n";
+    if (env) b << "          es = shri(es, envSL[jj]); ee = shri(ee, envEL[jj]);\n          const bool inside = active && iOrig >= es && iOrig < ee;\n";
     for (size_t k = 0; k < P.needLeft.size(); ++k)
       b << "          " << lp << P.needLeft[k] << " = shr1(" << cq << P.needLeft[k] << ", haloL[jj * JH + " << k << "]);\n";
     for (int k = 0; k < P.nTab[2]; ++k) b << "          const double wO" << k << " = wL[" << (long long)k * (P.nOut + 1) << " + ot];\n";
@@ -489,6 +505,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
         b << ";\n            double res = gM + (double)(__builtin_amdgcn_logf(sm) * SM_LN2);\n";
       }
       if (d == P.seedState) b << "            res = ((i | o) == 0) ? 0.0 : res;   // cell(0,0,start) = 0: no other candidate is finite there\n";
+      if (env) b << "            res = inside ? res : NEG_INF;   // cells outside the envelope stay -inf (src/dpmatrix.defs.h:36, dpmatrix.h:142-144)\n";
       b << "            " << cp << d << " = res;\n";
       b << "          }\n";
     }
@@ -524,7 +541,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
         if (cs.empty()) continue;
         const std::string B = CB == 16 ? ("bq" + I(d / 2) + (d % 2 ? ".y" : ".x")) : ("bq" + I(d));
         b << "          {  // usage of the transitions into state " << d << "\n";
-        b << "            const double bl = active ? (" << B << " + negLL) : NEG_INF;\n";
+        b << "            const double bl = " << (env ? "inside" : "active") << " ? (" << B << " + negLL) : NEG_INF;\n";
         for (size_t k = 0; k < cs.size(); ++k) {
           const SmSlot &sl = cs[k];
           const std::string src = (sl.T == 0 ? lq : (sl.T == 1 ? lp : (sl.T == 2 ? cq : cp))) + I(sl.src);
@@ -573,14 +590,14 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise) 
   return src;
 }
 
-bool small_jit_get(SmallProgram &P, int mode, bool materialise) {
-  SmJit &J = P.jit[mode][materialise ? 1 : 0];
+bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env) {
+  SmJit &J = P.jit[mode][materialise ? 1 : 0][env ? 1 : 0];
   if (J.tried) return J.func != nullptr;
   J.tried = true;
   if (!P.ok) return false;
   J.ldsBytes = small_jit_lds_bytes(P, mode);
   if (J.ldsBytes > 160 * 1024) { set_error("small-machine kernel: tables exceed the LDS"); return false; }
-  const std::string src = small_jit_source(P, mode, materialise);
+  const std::string src = small_jit_source(P, mode, materialise, env);
   if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
     const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
     if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -609,6 +626,7 @@ struct SmallArgsHost {   // must match SmallArgs in the generated source
   const int4 *tiles; int tileBase, tileEnd, TS, nRep;
   double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
   double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
+  const int *envStart; const int *envEnd;
 };
 
 // Steps per tile: the longest tile that still leaves ~12 tiles per CU in an average launch; 64 (the minimum: a tile must
@@ -636,9 +654,10 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tPrev = now();
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip]   sweep %-24s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
-  if (!small_jit_get(P, mode, materialise)) return 1;
+  const bool env = sw.d_envStart != nullptr;
+  if (!small_jit_get(P, mode, materialise, env)) return 1;
   lap("kernel lookup / jit");
-  const SmJit &J = P.jit[mode][materialise ? 1 : 0];
+  const SmJit &J = P.jit[mode][materialise ? 1 : 0][env ? 1 : 0];
   const int TS = pick_tile_steps(pairs);
   // the tile lists depend on the pairs' shapes only: built and uploaded once per batch chunk, reused by every later sweep
   SmTileCache local;
@@ -683,6 +702,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1);
   A.pool = sw.d_pool; A.tb = sw.d_tb; A.halo = sw.d_halo; A.bound = sw.d_bound; A.aux = sw.d_aux; A.loglike = sw.d_loglike;
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
+  A.envStart = sw.d_envStart; A.envEnd = sw.d_envEnd;
   bool ok = true;
   for (int l = 0; l < nLaunch && ok; ++l) {
     const long long nt = off[l + 1] - off[l];

@@ -45,7 +45,7 @@ struct SmallProgram {
   std::vector<uint32_t> dec;                 // T | src << 8 | tab << 16
   int *d_decOff = nullptr;
   uint32_t *d_dec = nullptr;
-  SmJit jit[SM_NMODE][2];                    // [mode][materialise]
+  SmJit jit[SM_NMODE][2][2];                 // [mode][materialise][restricted envelopes]
 };
 
 // Matrix storage of this family (device only; mb_fill converts to the reference's layout): strip a of a pair holds its
@@ -64,9 +64,9 @@ bool small_build_host(const mb_machine *m, bool backward, SmallProgram &P);
 bool small_build(const mb_machine *m, bool backward, SmallProgram &P);
 bool small_refresh_weights(const mb_machine *m, SmallProgram &P);
 void small_free(SmallProgram &P);
-std::string small_jit_source(const SmallProgram &P, int mode, bool materialise);
+std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env = false);
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode);
-bool small_jit_get(SmallProgram &P, int mode, bool materialise);
+bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env = false);
 bool small_count_fits(const SmallProgram &P);
 const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise);
 
@@ -86,6 +86,7 @@ struct SmSweep {
   const double *d_bwdLL = nullptr;             // count mode
   double *d_counts = nullptr; int nRep = 0;    // count mode: nRep replicas of [nTrans]
   SmTileCache *tileCache = nullptr;            // tile lists of this set of pairs, kept on the device between calls (may be null)
+  const int *d_envStart = nullptr, *d_envEnd = nullptr;   // restricted envelopes (Envelope::inStart / inEnd rows at PairDesc::envBase); null: all full
 };
 int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st);
 

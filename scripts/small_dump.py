@@ -10,11 +10,12 @@ from machineboss_amd.evalmachine import EvaluatedMachine
 preset = sys.argv[1]; mode = sys.argv[2] if len(sys.argv) > 2 else "sum"
 direction = sys.argv[3] if len(sys.argv) > 3 else "fwd"; mat = (sys.argv[4] if len(sys.argv) > 4 else "mat") == "mat"
 out = sys.argv[5] if len(sys.argv) > 5 else "/tmp/jit"
+envelopes = os.environ.get("SMALL_DUMP_ENV", "0") == "1"
 os.makedirs(out, exist_ok=True)
 path = preset if os.path.exists(preset) else "tests/golden/preset/%s.json" % preset
 m = Machine.fromFile(path); em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
 src = os.path.join(out, "small_%s_%s_%s_%s.hip" % (os.path.basename(preset).replace(".json", ""), mode, direction, "mat" if mat else "roll"))
-capi.debug_small_source(em, src, mode={"sum": 0, "max": 1, "tb": 2, "cnt": 3}[mode], backward=(direction == "bwd"), materialise=mat)
+capi.debug_small_source(em, src, mode={"sum": 0, "max": 1, "tb": 2, "cnt": 3}[mode], backward=(direction == "bwd"), materialise=mat, envelopes=envelopes)
 full = src.replace(".hip", "_full.hip")
 open(full, "w").write("#include <hip/hip_runtime.h>\n" + open(src).read())
 asm = src.replace(".hip", ".s")

@@ -515,9 +515,9 @@ def test_host_walkers_match_oracle_exactly(capi, oracle_mod, machines, name, il,
 
 
 # ---- envelopes (src/seqpair.h:75-97; DPMatrix fills visit only the cells inside, dpmatrix.h:142-144 reads -inf outside) ----
-@pytest.mark.parametrize("name,il,ol,width", [("dnapsw", 14, 17, 2), ("bitstutter-noise", 4, 6, 1), ("psw2dna", 3, 11, 1)])
+@pytest.mark.parametrize("name,il,ol,width", [("dnapsw", 14, 17, 2), ("dnapsw", 150, 170, 5), ("bitstutter-noise", 4, 6, 1), ("psw2dna", 3, 11, 1)])
 def test_envelope_fills_match_oracle(capi, oracle_mod, machines, name, il, ol, width):
-    """Forward / Viterbi / Backward / counts under a path-area envelope: device (generic family) vs oracle."""
+    """Forward / Viterbi / Backward / counts under a path-area envelope: device vs oracle."""
     from machineboss_amd.seqpair import Envelope
     preset = name != "bitstutter-noise"
     m, em = machines(name, None if preset else load_json("io", "params.json"), useDefaults=preset, preset=preset)
@@ -536,19 +536,23 @@ def test_envelope_fills_match_oracle(capi, oracle_mod, machines, name, il, ol, w
     V = dm.fill(capi.MB_VITERBI, x, y, 0, env.inStart, env.inEnd)
     F = dm.fill(capi.MB_FORWARD, x, y, 0, env.inStart, env.inEnd)
     B = dm.fill(capi.MB_BACKWARD, x, y, 0, env.inStart, env.inEnd)
-    assert "generic" in capi.last_kernel_name()
-    assert np.array_equal(V, Vr) and close(F, Fr, REL_EXACT) and close(B, Br, REL_EXACT)
+    # machines of <= 16 states keep their envelopes on the small-machine family (cells outside are forced to -inf inside
+    # the sweep); larger ones go to the generic family
+    small = em.nStates <= 16
+    assert capi.last_kernel_name().startswith("k_small_") if small else "generic" in capi.last_kernel_name()
+    rel, abs_ = (FAST_REL, FAST_ABS) if small else (REL_EXACT, 0.0)
+    assert np.array_equal(V, Vr) and close(F, Fr, rel, abs_) and close(B, Br, rel, abs_)
     b = capi.DeviceBatch.from_pairs(dm, [(x, y), (x, y)])
     b.set_envelopes([(env.inStart, env.inEnd), None])          # second pair keeps the full envelope
     ll = b.forward(capi.MB_ROLLING)
-    assert close(ll[0], Fr[-1, -1, -1], 1e-10) and close(ll[1], om.loglike(x, y, oracle_mod.SUM_EXACT), 1e-10)
+    assert close(ll[0], Fr[-1, -1, -1], max(rel, 1e-10), abs_) and close(ll[1], om.loglike(x, y, oracle_mod.SUM_EXACT), max(rel, 1e-10), abs_)
     vll, off, edges = b.viterbi()
     assert vll[0] == Vr[-1, -1, -1]
     if path_r is not None:
         assert np.array_equal(edges[off[0]:off[1]], path_r)
     counts, s, cll = b.counts()
     cf = np.zeros(em.nTransitions); llf = om.counts_add(x, y, cf, oracle_mod.SUM_EXACT)
-    assert close(counts, cr + cf, COUNT_TOL, 1e-12) and close(s, llr + llf, 1e-10)
+    assert close(counts, cr + cf, 1e-5 if small else COUNT_TOL, 1e-7 if small else 1e-12) and close(s, llr + llf, max(rel, 1e-10), abs_)
     # errors of DPMatrix::alloc (src/dpmatrix.defs.h:31-32)
     with pytest.raises(capi.MbError, match="mismatch"):
         b.set_envelopes([(env.inStart[:-1], env.inEnd[:-1]), None])
