@@ -466,7 +466,7 @@ static void small_plan(const SmallProgram &P, const PairDesc *hp, long long n, b
     a.pool = pl.poolD; a.tb = pl.tbB; a.halo = pl.haloD; a.bound = pl.boundD;
     if (wantPool) pl.poolD += small_pair_doubles(P.S, pd.inLen, pd.outLen);
     if (wantTb) pl.tbB += (small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 15) & ~15ll;
-    pl.haloD += 2ll * (pd.outLen + 1) * std::max(P.H, 1);
+    pl.haloD += (long long)small_strips(pd.inLen) * (pd.outLen + 1) * std::max(P.H, 1);   // one halo column per strip
     pl.boundD += (long long)small_strips(pd.inLen) * 64 * P.NBD;
   }
 }
@@ -477,7 +477,7 @@ static bool small_chunks_plan(const mb_batch *b, const SmallProgram &P, bool wan
   long long p0 = 0, acc = 0;
   for (long long p = 0; p < b->nPairs; ++p) {
     const PairDesc &pd = b->pairs[p];
-    long long c = (2ll * (pd.outLen + 1) * std::max(P.H, 1) + (long long)small_strips(pd.inLen) * 64 * P.NBD) * 8;
+    long long c = ((long long)small_strips(pd.inLen) * (pd.outLen + 1) * std::max(P.H, 1) + (long long)small_strips(pd.inLen) * 64 * P.NBD) * 8;
     if (wantPool) c += small_pair_doubles(P.S, pd.inLen, pd.outLen) * 8;
     if (wantTb) c += small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 16;
     if (c > budget) { set_error("a single DP matrix (" + std::to_string(c) + " bytes) exceeds the device memory budget"); return false; }
@@ -498,12 +498,21 @@ static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, boo
   sw = SmSweep();
   sw.d_pairs = b->d_pairs + c.p0; sw.pairs = &hp; sw.d_in = b->d_in; sw.d_out = b->d_out; sw.d_aux = *d_aux;
   if (chunkNo != (size_t)-1) {
-    if (b->smTiles.size() <= chunkNo) b->smTiles.resize(chunkNo + 1);
-    SmTileCache &tc = b->smTiles[chunkNo];
-    if (tc.p0 != c.p0 || tc.p1 != c.p1) { if (tc.d_tiles) (void)hipFree(tc.d_tiles); tc = SmTileCache(); tc.p0 = c.p0; tc.p1 = c.p1; }
-    sw.tileCache = &tc;
+    if (b->smTiles.size() <= 2 * chunkNo + 1) b->smTiles.resize(2 * chunkNo + 2);
+    for (int bw = 0; bw < 2; ++bw) {
+      SmTileCache &tc = b->smTiles[2 * chunkNo + bw];
+      if (tc.p0 != c.p0 || tc.p1 != c.p1 || tc.envVersion != b->envVersion) {
+        if (tc.d_tiles) (void)hipFree(tc.d_tiles);
+        tc = SmTileCache(); tc.p0 = c.p0; tc.p1 = c.p1; tc.envVersion = b->envVersion;
+      }
+    }
+    sw.tileCacheFwd = &b->smTiles[2 * chunkNo]; sw.tileCacheBwd = &b->smTiles[2 * chunkNo + 1];
   }
-  if (b->hasEnv) { sw.d_envStart = b->d_envStart; sw.d_envEnd = b->d_envEnd; }   // PairDesc::envBase (-1: full) indexes them
+  if (b->hasEnv) {   // PairDesc::envBase (-1: full) indexes them
+    sw.d_envStart = b->d_envStart; sw.d_envEnd = b->d_envEnd;
+    sw.h_envStart = b->h_envStart.data(); sw.h_envEnd = b->h_envEnd.data();
+    sw.haloDoubles = pl.haloD;
+  }
   if (wantPool && !(sw.d_pool = (double *)ws_get(0, (size_t)std::max<long long>(pl.poolD, 1) * 8))) return 1;
   if (wantTb && !(sw.d_tb = (unsigned char *)ws_get(8, (size_t)std::max<long long>(pl.tbB, 16)))) return 1;
   if (!(sw.d_halo = (double *)ws_get(9, (size_t)std::max<long long>(pl.haloD, 1) * 8))) return 1;
@@ -678,7 +687,9 @@ static int small_fill(mb_batch *b, int mode, double *cellsOut) {
     sw.d_loglike = d_ll;
     if ((rc = small_sweep(P, mode == MB_VITERBI ? SM_MAX : SM_SUM, true, sw, g_stream))) break;
     if ((rc = launch_fill_neg_inf(d_cells, n, g_stream))) break;
-    if ((rc = launch_small_unpack(sw.d_pool, P.S, pd.inLen, pd.outLen, mode == MB_BACKWARD, d_cells, g_stream))) break;
+    if ((rc = launch_small_unpack(sw.d_pool, P.S, pd.inLen, pd.outLen, mode == MB_BACKWARD, d_cells,
+                                  b->hasEnv && pd.envBase >= 0 ? b->d_envStart + pd.envBase : nullptr,
+                                  b->hasEnv && pd.envBase >= 0 ? b->d_envEnd + pd.envBase : nullptr, g_stream))) break;
     if (!hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) { rc = 1; break; }
     if (!hip_ok(hipMemcpy(cellsOut, d_cells, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) { rc = 1; break; }
   } while (0);
@@ -868,6 +879,7 @@ int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *in
   if (b->d_envStart) { (void)hipFree(b->d_envStart); b->d_envStart = nullptr; }
   if (b->d_envEnd) { (void)hipFree(b->d_envEnd); b->d_envEnd = nullptr; }
   b->hasEnv = false;
+  ++b->envVersion;
   const long long total = envOff[b->nPairs] - envOff[0];
   for (long long p = 0; p < b->nPairs; ++p) {
     PairDesc &pd = b->pairs[p];
@@ -891,6 +903,8 @@ int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *in
     MB_HIP(hipMalloc((void **)&b->d_envEnd, std::max<long long>(total, 1) * sizeof(int)));
     MB_HIP(hipMemcpy(b->d_envStart, inStart + envOff[0], total * sizeof(int), hipMemcpyHostToDevice));
     MB_HIP(hipMemcpy(b->d_envEnd, inEnd + envOff[0], total * sizeof(int), hipMemcpyHostToDevice));
+    b->h_envStart.assign(inStart + envOff[0], inStart + envOff[0] + total);
+    b->h_envEnd.assign(inEnd + envOff[0], inEnd + envOff[0] + total);
   }
   if (b->nPairs) MB_HIP(hipMemcpy(b->d_pairs, b->pairs.data(), b->nPairs * sizeof(PairDesc), hipMemcpyHostToDevice));
   return 0;

@@ -71,7 +71,7 @@ struct mb_machine {
 
 namespace mb {
 // tile lists of one chunk of a batch for the small-machine family (mb_small.cpp), kept on the device between calls
-struct SmTileCache { long long p0 = -1, p1 = -1; int TS = 0; void *d_tiles = nullptr; std::vector<long long> off; };
+struct SmTileCache { long long p0 = -1, p1 = -1; int TS = 0; long long envVersion = -1; void *d_tiles = nullptr; std::vector<long long> off; };
 }
 
 struct mb_batch {
@@ -86,7 +86,9 @@ struct mb_batch {
   // envelopes (src/seqpair.h:75-97): cell (x,y) of pair p exists <=> envStart[envBase+y] <= x < envEnd[envBase+y]
   bool hasEnv = false;
   int *d_envStart = nullptr, *d_envEnd = nullptr;
-  std::vector<mb::SmTileCache> smTiles;   // by chunk number
+  std::vector<int> h_envStart, h_envEnd;   // host copies: the tiled families skip tiles that lie outside every envelope row
+  long long envVersion = 0;                // bumped by mb_batch_set_envelopes (cached tile lists depend on it)
+  std::vector<mb::SmTileCache> smTiles;   // by 2 * chunk number + (backward sweep)
 };
 
 namespace mb {

@@ -309,8 +309,8 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     const int mrow = it * (JNOUT + 1);
     (void)wc; (void)mrow; (void)NA;
 /*@WEIGHTS@*/
-    const double *haloIn = A.halo + ax.halo + (long long)((a + 1) & 1) * (outLen + 1) * JHP;   // written by strip a-1
-    double *haloOut = A.halo + ax.halo + (long long)(a & 1) * (outLen + 1) * JHP;
+    const double *haloIn = A.halo + ax.halo + (long long)max(a - 1, 0) * (outLen + 1) * JHP;   // written by strip a-1
+    double *haloOut = A.halo + ax.halo + (long long)a * (outLen + 1) * JHP;
     double *bnd = A.bound + ax.bound + ((long long)a * 64 + lane) * JNBD;
     (void)haloIn; (void)haloOut;
 #if JMAT
@@ -336,7 +336,7 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     for (int j = lane; j < JOUTACC; j += 64) outAcc[j] = 0.0f;
 #endif
 /*@STATE@*/
-    if (b > 0) {
+    if (b > 0 && !(tl.w & 1)) {      // (bit 0: the block before this one lies outside the envelope and did not run: start from -inf)
 /*@LOADBND@*/
     }
     int ot = tokAt(t0 - 1 - lane);
@@ -654,14 +654,18 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tPrev = now();
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip]   sweep %-24s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
-  const bool env = sw.d_envStart != nullptr;
-  if (!small_jit_get(P, mode, materialise, env)) return 1;
+  if (!small_jit_get(P, mode, materialise, sw.d_envStart != nullptr)) return 1;
   lap("kernel lookup / jit");
-  const SmJit &J = P.jit[mode][materialise ? 1 : 0][env ? 1 : 0];
+  const SmJit &J = P.jit[mode][materialise ? 1 : 0][sw.d_envStart != nullptr ? 1 : 0];
   const int TS = pick_tile_steps(pairs);
-  // the tile lists depend on the pairs' shapes only: built and uploaded once per batch chunk, reused by every later sweep
+  // The tile lists depend on the pairs' shapes (and envelopes) only: built and uploaded once per batch chunk and sweep
+  // direction, reused by every later sweep.  With restricted envelopes a tile none of whose cells lies inside its pair's
+  // envelope is not launched at all: its cells stay -inf (the halo columns are pre-filled with -inf, the next block of
+  // the strip is told to start from -inf instead of loading the boundary record).
   SmTileCache local;
-  SmTileCache &tc = sw.tileCache ? *sw.tileCache : local;
+  SmTileCache *cached = P.backward ? sw.tileCacheBwd : sw.tileCacheFwd;
+  SmTileCache &tc = cached ? *cached : local;
+  const bool env = sw.d_envStart != nullptr, skipDead = env && sw.h_envStart != nullptr;
   if (!tc.d_tiles || tc.TS != TS) {
     if (tc.d_tiles) { (void)hipFree(tc.d_tiles); tc.d_tiles = nullptr; }
     int nLaunch = 0;
@@ -669,10 +673,31 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
       const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
       nLaunch = std::max(nLaunch, 2 * (NA - 1) + NB);
     }
-    std::vector<long long> cnt(nLaunch + 1, 0);
-    for (const PairDesc &pd : pairs) {
+    // live[p][a * NB + b]
+    std::vector<std::vector<char>> live(pairs.size());
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      const PairDesc &pd = pairs[p];
       const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
-      for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) cnt[2 * a + b]++;
+      live[p].assign((size_t)NA * NB, (skipDead && pd.envBase >= 0) ? 0 : 1);
+      if (!(skipDead && pd.envBase >= 0)) continue;
+      const int pad = P.backward ? NA * 64 - 1 - pd.inLen : 0;
+      for (int o = 0; o <= pd.outLen; ++o) {
+        const int es = sw.h_envStart[pd.envBase + o], ee = sw.h_envEnd[pd.envBase + o];   // original coordinates: columns [es, ee) of row o
+        if (ee <= es) continue;
+        const int fo = P.backward ? pd.outLen - o : o;
+        // frame columns of the row, as global lane indices (strip * 64 + lane)
+        const int g0 = (P.backward ? pd.inLen - (ee - 1) : es) + pad, g1 = (P.backward ? pd.inLen - es : ee - 1) + pad;
+        for (int a = g0 >> 6; a <= (g1 >> 6); ++a) {
+          const int c0 = std::max(g0, a * 64) - a * 64, c1 = std::min(g1, a * 64 + 63) - a * 64;
+          for (int b = (fo + c0) / TS; b <= (fo + c1) / TS; ++b) live[p][(size_t)a * NB + b] = 1;
+        }
+      }
+    }
+    std::vector<long long> cnt(nLaunch + 1, 0);
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      const PairDesc &pd = pairs[p];
+      const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+      for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) if (live[p][(size_t)a * NB + b]) cnt[2 * a + b]++;
     }
     tc.off.assign(nLaunch + 1, 0);
     for (int l = 0; l < nLaunch; ++l) tc.off[l + 1] = tc.off[l] + cnt[l];
@@ -683,7 +708,10 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
       for (size_t p = 0; p < pairs.size(); ++p) {
         const PairDesc &pd = pairs[p];
         const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
-        for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, 0);
+        for (int a = 0; a < NA; ++a)
+          for (int b = 0; b < NB; ++b)
+            if (live[p][(size_t)a * NB + b])
+              tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, (b > 0 && !live[p][(size_t)a * NB + b - 1]) ? 1 : 0);
       }
     }
     lap("tile lists");
@@ -694,6 +722,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     }
     tc.TS = TS;
   }
+  if (skipDead && sw.haloDoubles > 0 && launch_fill_neg_inf(sw.d_halo, sw.haloDoubles, st)) return 1;   // halo rows of tiles that do not run
   const int nLaunch = (int)tc.off.size() - 1;
   const std::vector<long long> &off = tc.off;
   const int4 *d_tiles = (const int4 *)tc.d_tiles;
@@ -717,7 +746,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   if (!ok) set_error("small-machine kernel launch failed");
   ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipStreamSynchronize(st), "small tile kernels");
   lap("stream synchronize");
-  if (!sw.tileCache && local.d_tiles) (void)hipFree(local.d_tiles);
+  if (!cached && local.d_tiles) (void)hipFree(local.d_tiles);
   return ok ? 0 : 1;
 }
 

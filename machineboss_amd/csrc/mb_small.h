@@ -85,13 +85,17 @@ struct SmSweep {
   double *d_loglike = nullptr;                 // [nPairs]
   const double *d_bwdLL = nullptr;             // count mode
   double *d_counts = nullptr; int nRep = 0;    // count mode: nRep replicas of [nTrans]
-  SmTileCache *tileCache = nullptr;            // tile lists of this set of pairs, kept on the device between calls (may be null)
+  SmTileCache *tileCacheFwd = nullptr, *tileCacheBwd = nullptr;   // tile lists of this set of pairs by sweep direction, kept on the device between calls (may be null)
   const int *d_envStart = nullptr, *d_envEnd = nullptr;   // restricted envelopes (Envelope::inStart / inEnd rows at PairDesc::envBase); null: all full
+  const int *h_envStart = nullptr, *h_envEnd = nullptr;   // their host copies: tiles outside every envelope row are not launched
+  long long haloDoubles = 0;                   // size of d_halo (pre-filled with -inf when tiles are skipped)
 };
 int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st);
 
 // kernels compiled ahead of time (mb_small_kernels.hip)
-int launch_small_unpack(const double *d_pool, int S, int inLen, int outLen, bool reversed, double *d_cells, hipStream_t st);
+int launch_small_unpack(const double *d_pool, int S, int inLen, int outLen, bool reversed, double *d_cells, const int *d_envStart,
+                        const int *d_envEnd, hipStream_t st);
+int launch_fill_neg_inf(double *d, long long n, hipStream_t st);
 int launch_small_traceback(const SmallProgram &P, const PairDesc *d_pairs, long long nPairs, const int *d_in, const int *d_out,
                            const unsigned char *d_tb, const SmAux *d_aux, const double *d_ll, const long long *d_slotOff,
                            uint32_t *d_pathBuf, long long *d_pathLen, hipStream_t st);

@@ -10,13 +10,15 @@ namespace mb {
 // tile-major (strip, step, chunk, lane) -> IdentityIndexMapper layout ((outPos * (inLen+1)) + inPos) * nStates + state
 // (src/dpmatrix.h:34-44,90-96).  `reversed`: the matrix was filled by the Backward sweep, which runs in the reversed frame.
 __global__ __launch_bounds__(256) void k_small_unpack(const double *__restrict__ pool, int S, int inLen, int outLen, int reversed,
-                                                      double *__restrict__ cells) {
+                                                      double *__restrict__ cells, const int *__restrict__ envStart,
+                                                      const int *__restrict__ envEnd) {
   const long long I = inLen + 1, n = I * (outLen + 1) * S;
   const int CBD = small_chunk_bytes(S) / 8, NCH = small_chunks(S), Te = small_steps(outLen);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
     const long long sc = idx / S;
     const int s = (int)(idx - sc * S);
     const int o = (int)(sc / I), i = (int)(sc - (long long)o * I);
+    if (envStart && (i < envStart[o] || i >= envEnd[o])) continue;   // outside the envelope: the caller's -inf stays (tiles there may not have run)
     // the reversed frame keeps its padding columns in front (mb_small.cpp): frame column inLen - i sits at NA*64 - 1 - i
     const int fi = reversed ? small_strips(inLen) * 64 - 1 - i : i, fo = reversed ? outLen - o : o;
     const int a = fi >> 6, c = fi & 63, t = fo + c;
@@ -24,10 +26,11 @@ __global__ __launch_bounds__(256) void k_small_unpack(const double *__restrict__
   }
 }
 
-int launch_small_unpack(const double *d_pool, int S, int inLen, int outLen, bool reversed, double *d_cells, hipStream_t st) {
+int launch_small_unpack(const double *d_pool, int S, int inLen, int outLen, bool reversed, double *d_cells, const int *d_envStart,
+                        const int *d_envEnd, hipStream_t st) {
   const long long n = (long long)(inLen + 1) * (outLen + 1) * S;
   hipLaunchKernelGGL(k_small_unpack, dim3((unsigned)std::min<long long>((n + 255) / 256, 16384)), dim3(256), 0, st, d_pool, S, inLen,
-                     outLen, reversed ? 1 : 0, d_cells);
+                     outLen, reversed ? 1 : 0, d_cells, d_envStart, d_envEnd);
   return hip_ok(hipGetLastError(), "unpack launch") ? 0 : 1;
 }
 
