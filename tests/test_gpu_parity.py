@@ -1155,3 +1155,26 @@ def test_boss_cli_two_ranks_end_to_end(capi, tmp_path):
         else:
             assert outs[0][0] == single.stdout
         port += 1
+
+
+def test_workspace_eviction_between_modes(capi, machines):
+    """the memory budget counts cached workspaces as reclaimable, so a call that needs a big slot must be able to
+    evict the pools earlier calls left behind.  Alternate Forward (pool 0), counts (pools 0 + 1) and Viterbi under an
+    explicit budget that holds ONE call's buffers but not the sum of what the calls cache: every call still succeeds and
+    gives the same results as with an unlimited budget."""
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)      # tiled family: fp64 matrices for every mode
+    dm = capi.DeviceMachine(em)
+    inTok, inOff, outTok, outOff = synth_batch(4, 6, 120, 700, em.nInTok, em.nOutTok)
+    b = capi.DeviceBatch(dm, inTok, inOff, outTok, outOff)
+    ref = (b.forward(capi.MB_MATERIALISE), b.viterbi(paths=False)[0], b.counts()[0])
+    cells = b.cells() * 8
+    capi.release_workspace()
+    capi.set_memory_budget(int(2.2 * cells))      # counts need 2 matrices per pair; Forward + Viterbi + counts cached together would need 4
+    try:
+        for _ in range(2):
+            assert np.array_equal(b.forward(capi.MB_MATERIALISE), ref[0])
+            assert close(b.counts()[0], ref[2], 1e-9, 1e-12)
+            assert np.array_equal(b.viterbi(paths=False)[0], ref[1])
+    finally:
+        capi.set_memory_budget(0)
+        capi.release_workspace()
