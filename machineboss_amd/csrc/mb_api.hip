@@ -423,7 +423,7 @@ static WideProgram *wide_program(mb_machine *m, int mode) {
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
                       const int *d_out, double *pool, int startState, const mb_batch *b) {
-  const bool env = b && b->hasEnv;   // envelopes: generic family only; cells outside keep the -inf written here
+  const bool env = b && b->hasEnv;   // envelopes: cells outside keep the -inf written here (tiles outside them do not even run)
   if (env) {
     long long cells = 0;
     for (const PairDesc &pd : hp) cells = std::max(cells, pd.cellBase + (long long)(pd.inLen + 1) * (pd.outLen + 1) * m->S);
@@ -436,15 +436,20 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     g_last_kernel = mode == MB_VITERBI ? "k_wide_sweep<1>" : (W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>");
     return wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream);
   }
-  if (!env && (use_medium(m) || tiledViterbi)) {
+  if ((use_medium(m) && !(env && wide_applicable(m))) || tiledViterbi) {
     FastState *f = fast_state(m);
     const bool exactFwd = mode == MB_VITERBI || (mode == MB_FORWARD && startState != 0);
     MedProgram &P = mode == MB_BACKWARD ? f->bwdSum : (exactFwd ? f->fwdExact : f->fwdSum);
     const MedGeom &geo = mode == MB_BACKWARD ? f->geoBS : (exactFwd ? f->geoFE : f->geoFS);
+    MedEnv me;
+    if (env) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
     const int rc = medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
-                                            (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream);
-    g_last_kernel = medium_jit_ready(P, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, true) ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
-    return rc;
+                                            (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream, me);
+    if (rc >= 0) {
+      g_last_kernel = medium_jit_ready(P, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, true) ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
+      return rc;
+    }
+    // (-1: envelopes need the run-time specialised kernel and it is unavailable: the generic family takes the chunk)
   }
   g_last_kernel = mode == MB_VITERBI ? "k_generic_fill_fwd<1>" : (mode == MB_BACKWARD ? "k_generic_fill_bwd" : "k_generic_fill_fwd<0>");
   return launch_generic_fill(m, mode, d_desc, (long long)hp.size(), d_in, d_out, pool, startState, g_stream,
@@ -1127,9 +1132,14 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;
       // fused path: the Forward sweep accumulates the counts while its anti-diagonals are still in LDS
       int fused = -1;
-      if (!b->hasEnv && use_medium(b->m) && fast_state(b->m)->countOk) {
+      if (use_medium(b->m) && fast_state(b->m)->countOk && !(b->hasEnv && wide_applicable(b->m))) {
         FastState *f = fast_state(b->m);
-        fused = medium_counts_materialised(b->m, f->fwdCnt, f->geoCnt, d_desc, hp, b->d_in, b->d_out, fwd, bwd, d_counts, d_ll + c.p0, g_stream);
+        MedEnv me;
+        if (b->hasEnv) {
+          me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data();
+          if ((rc = launch_fill_neg_inf(fwd, c.cells, g_stream))) break;      // tiles outside the envelopes do not run
+        }
+        fused = medium_counts_materialised(b->m, f->fwdCnt, f->geoCnt, d_desc, hp, b->d_in, b->d_out, fwd, bwd, d_counts, d_ll + c.p0, g_stream, me);
         if (fused > 0) { rc = 1; break; }
         if (fused == 0) g_last_kernel = "k_medium_jit";
       }

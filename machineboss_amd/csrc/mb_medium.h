@@ -84,13 +84,17 @@ struct MedProgram {
   MedProgDev dev{};
   // [2 * medium_jit_index(mode) + materialise][MedGeom::level]: sum / max / count, rolling / materialised, and the strip
   // width (level h = the program's widest strip halved h times; narrow strips for short input sequences)
-  MedJit jit[6 * MED_GEOM_LEVELS];
+  MedJit jit[12 * MED_GEOM_LEVELS];       // ... x restricted envelopes (MedGeom::env)
 };
 
 // haloSteps > 0: the materialised kernel loads the halo supercells of a whole tile (at most haloSteps steps) into LDS in
 // its prologue, so its step loop issues NO vector-memory load (machines with few states, where a step is shorter than
 // the time the previous step's stores need to be acknowledged)
-struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; int level = 0; };
+struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; int level = 0; bool env = false; };   // env: the kernel variant that clips to the pairs' envelopes
+
+// restricted envelopes of the pairs (PairDesc::envBase rows of the batch's inStart / inEnd arrays): device copies for the
+// kernel, host copies for the tile lists (tiles outside every envelope row are not launched); all null = full envelopes
+struct MedEnv { const int *d_start = nullptr, *d_end = nullptr, *h_start = nullptr, *h_end = nullptr; };
 
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
 bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
@@ -102,7 +106,7 @@ bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo)
 // run-time specialised kernel: returns -1 (nothing launched) when it is unavailable, 0 ok, 1 error
 int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                                const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_fwd,
-                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st);
+                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
 // G = columns (supercells) per wavefront, LPG = 64 / G lanes per supercell.  G = 64 is "one lane per supercell": the
 // mapping for machines with a handful of states (dnapsw, protpsw: 8 states).
 inline bool medium_valid_G(int G) { return G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
@@ -126,12 +130,12 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo);
 int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
-                             double *d_pool, hipStream_t st);
+                             double *d_pool, hipStream_t st, const MedEnv &env = MedEnv());
 // run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
 bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise);
-inline int medium_jit_slot(int mode, bool materialise, int level) { return (2 * medium_jit_index(mode) + (materialise ? 1 : 0)) * MED_GEOM_LEVELS + level; }
+inline int medium_jit_slot(int mode, bool materialise, int level, bool env = false) { return ((2 * medium_jit_index(mode) + (materialise ? 1 : 0)) * 2 + (env ? 1 : 0)) * MED_GEOM_LEVELS + level; }
 inline bool medium_jit_ready(const MedProgram &P, int mode, bool materialise) {
-  for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, materialise, h)].func) return true;
+  for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, materialise, h, false)].func || P.jit[medium_jit_slot(mode, materialise, h, true)].func) return true;
   return false;
 }
 // strip width for a batch (narrower strips for short input sequences)

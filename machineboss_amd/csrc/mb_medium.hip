@@ -49,6 +49,7 @@ struct MedTileArgs {
   int C, TS, launch, rev, materialise, tileBase, pad0;
   const double *poolB;        // count mode (specialised kernel only): Backward matrices, same layout and cellBase as pool
   double *counts;             // count mode: [nTrans] posterior transition counts, accumulated with fp64 atomics
+  const int *envStart, *envEnd;   // restricted envelopes (specialised kernel, JENV variant): rows at PairDesc::envBase
 };
 
 #define MED_L2E 1.44269504088896f
@@ -870,7 +871,7 @@ static void set_lds_attr() {
 static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev &devIn, const MedGeom &geo, int mode, int TS,
                             const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
                             double *d_pool, double *d_loglike, hipStream_t st, const double *d_poolB = nullptr,
-                            double *d_counts = nullptr) {
+                            double *d_counts = nullptr, const MedEnv &env = MedEnv()) {
   const int C = geo.C;
   const long long n = (long long)pairs.size();
   int nLaunch = 0;
@@ -878,34 +879,55 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
     const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
     nLaunch = std::max(nLaunch, pd.launch0 + 2 * (NA - 1) + NB);
   }
+  // With restricted envelopes a tile none of whose cells lies inside its pair's envelope is not launched: the pool was
+  // filled with -inf beforehand (fill_chunk), which is what its cells hold and what the neighbouring tiles' prologues read.
+  auto liveTiles = [&](const PairDesc &pd, std::vector<char> &live) {
+    const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
+    const bool clip = geo.env && env.h_start && pd.envBase >= 0;
+    live.assign((size_t)NA * NB, clip ? 0 : 1);
+    if (!clip) return;
+    for (int o = 0; o <= pd.outLen; ++o) {
+      const int es = env.h_start[pd.envBase + o], ee = env.h_end[pd.envBase + o];
+      if (ee <= es) continue;
+      const int fo = P.backward ? pd.outLen - o : o;
+      const int g0 = P.backward ? pd.inLen - (ee - 1) : es, g1 = P.backward ? pd.inLen - es : ee - 1;   // sweep-frame columns of the row
+      for (int a = g0 / C; a <= g1 / C; ++a) {
+        const int c0 = std::max(g0, a * C) - a * C, c1 = std::min(g1, a * C + C - 1) - a * C;
+        for (int b = (fo + c0) / TS; b <= (fo + c1) / TS && b < NB; ++b) live[(size_t)a * NB + b] = 1;
+      }
+    }
+  };
   std::vector<int> cnt(nLaunch + 1, 0);
+  std::vector<char> live;
   for (const PairDesc &pd : pairs) {
     const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
-    for (int a = 0; a < NA; ++a) { cnt[pd.launch0 + 2 * a] += 1; cnt[pd.launch0 + 2 * a + NB] -= 1; }
+    liveTiles(pd, live);
+    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) if (live[(size_t)a * NB + b]) cnt[pd.launch0 + 2 * a + b] += 1;
   }
   std::vector<long long> off(nLaunch + 1, 0);
-  { long long run = 0, tot = 0; for (int l = 0; l < nLaunch; ++l) { run += cnt[l]; off[l] = tot; tot += run; cnt[l] = (int)run; } off[nLaunch] = tot; }
+  { long long tot = 0; for (int l = 0; l < nLaunch; ++l) { off[l] = tot; tot += cnt[l]; } off[nLaunch] = tot; }
   std::vector<int2> tiles((size_t)off[nLaunch]);
   {
     std::vector<long long> fill(off.begin(), off.end() - 1);
     for (long long p = 0; p < n; ++p) {
       const PairDesc &pd = pairs[p];
       const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
+      liveTiles(pd, live);
       for (int a = 0; a < NA; ++a)
-        for (int b = 0; b < NB; ++b) tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a);
+        for (int b = 0; b < NB; ++b) if (live[(size_t)a * NB + b]) tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a);
     }
   }
   int2 *d_tiles = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && h2d_large(d_tiles, tiles.data(), tiles.size() * sizeof(int2))) { sm_free(d_tiles); return 1; }   // staged: see h2d_large
-  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level)] : nullptr;
-  if (mode == MED_MODE_COUNT && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode
+  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level, geo.env)] : nullptr;
+  if ((mode == MED_MODE_COUNT || geo.env) && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode or for envelopes
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
-  A.poolB = d_poolB; A.counts = d_counts;
+  A.poolB = d_poolB; A.counts = d_counts; A.envStart = env.d_start; A.envEnd = env.d_end;
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
     if (cnt[l] <= 0) continue;
@@ -961,27 +983,30 @@ static int max_out_len(const std::vector<PairDesc> &pairs) {
 // Materialised fill of a chunk of pairs whose matrices are all kept (Viterbi, Backward, counts, mb_fill).
 int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, int mode, int startNode,
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out,
-                             double *d_pool, hipStream_t st) {
+                             double *d_pool, hipStream_t st, const MedEnv &env) {
   if (pairsIn.empty()) return 0;
-  const MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  geo.env = env.d_start != nullptr;
   set_lds_attr();
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   MedProgDev dev = P.dev;
   if (startNode >= 0 && !P.closure && !P.backward) dev.seedOff = (unsigned)startNode * 8u;   // ForwardMatrix(.., startState)
-  return launch_wavefront(m, P, dev, geo, mode, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st);
+  return launch_wavefront(m, P, dev, geo, mode, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_pool, nullptr, st,
+                          nullptr, nullptr, env);
 }
 
 int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs,
                                const std::vector<PairDesc> &pairsIn, const int *d_in, const int *d_out, double *d_fwd,
-                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st) {
+                               const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st, const MedEnv &env) {
   if (pairsIn.empty()) return 0;
-  const MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  geo.env = env.d_start != nullptr;
   if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, true)) return -1;
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   return launch_wavefront(m, P, P.dev, geo, MED_MODE_COUNT, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_fwd,
-                          d_loglike, st, d_bwd, d_counts);
+                          d_loglike, st, d_bwd, d_counts, env);
 }
 
 // Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):

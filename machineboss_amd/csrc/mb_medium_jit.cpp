@@ -36,7 +36,7 @@ static int env_int(const char *name, int dflt) {
 static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) {   // rounded up to 16 bytes: the record image follows
   return ((((size_t)P.NS * (geo.C + 1) * P.Spad + 1) & ~(size_t)1)) * sizeof(double);
 }
-static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }
+static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 3 * 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }   // output tokens + the envelope rows (start, end) of the same window
 
 // count programs: one Backward supercell per column + the count accumulators
 static size_t count_bytes(const MedProgram &P, const MedGeom &geo) {
@@ -124,7 +124,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
        << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
        << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0)
-       << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
+       << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
        << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
@@ -178,9 +178,9 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
           body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
         }
       }
-      body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = res;\n";
+      body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
       if (counting) {   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
-        body << "        const double bl = med_lds(ldsb, aB + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
+        body << "        const double bl = med_lds(ldsb, aB + (int)(JINSIDE ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
         for (int k = 0; k < n; ++k) countTerm(ri.slots[k], nm[k], k);
       }
     } else {
@@ -194,7 +194,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         for (int k = k0; k < k1; ++k)
           body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
         if (counting) {
-          body << "        const double bl = med_lds(ldsb, aB + (int)(active ? dstOff : (unsigned)JDUMMYOFF)) + negLL;\n";
+          body << "        const double bl = med_lds(ldsb, aB + (int)(JINSIDE ? dstOff : (unsigned)JDUMMYOFF)) + negLL;\n";
           for (int k = k0; k < k1; ++k) countTerm(ri.slots[k], nm[k], k);
         }
         body << "        double mx = v" << k0 << ";\n";
@@ -209,7 +209,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       }
       if (mode == MB_VITERBI) body << "        const double res = accM;\n";
       else body << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
-      body << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = res;\n";
+      body << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
     }
     body << "      }\n";
     if (ri.sync) body << "      med_wave_sync();\n";
@@ -227,7 +227,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
 }
 
 bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
-  MedJit &J = P.jit[medium_jit_slot(mode, materialise, geo.level)];
+  MedJit &J = P.jit[medium_jit_slot(mode, materialise, geo.level, geo.env)];
   if (J.tried) return J.func != nullptr;
   if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;

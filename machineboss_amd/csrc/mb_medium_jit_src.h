@@ -39,7 +39,15 @@ struct MedTileArgs {
   int C, TS, launch, rev, materialise, tileBase, pad0;
   const double *poolB;
   double *counts;
+  const int *envStart, *envEnd;
 };
+#if JENV
+#define JCLIP(x) (inside ? (x) : NEG_INF)      // cells outside the pair's envelope stay -inf (src/dpmatrix.defs.h:36, dpmatrix.h:142-144)
+#define JINSIDE inside
+#else
+#define JCLIP(x) (x)
+#define JINSIDE active
+#endif
 #if JMODE == 2
 #define SRCOFF(x) ((int)((x) & 0xFFFFu))
 #else
@@ -189,9 +197,11 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   // output tokens of the sweep, kept in LDS one window of W steps at a time (double buffered): window k holds the
   // tokens of o in [k*W - C + 1, k*W + W - 1]; the token of column c at step t sits at index (t % W) + (C - 1 - c).
   int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
+  int *envSW = tokWin + 2 * (W + C), *envEW = envSW + 2 * (W + C);   // envelope rows (inStart, inEnd) of the same windows (JENV)
+  (void)envSW; (void)envEW;
 #if JMODE == 2
   // count mode: the Backward supercell of every column (this step's) and the count accumulators of the workgroup
-  double *bvec = (double *)(tokWin + 2 * (W + C));
+  double *bvec = (double *)(tokWin + 6 * (W + C));
   double *accL = bvec + (long long)C * Spad;
   const double *cellsB = A.poolB + pd.cellBase;
   auto cellPtrB = [&](int ci, int co) -> const double * { return cellsB + ((long long)co * I + ci) * S; };
@@ -200,12 +210,19 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   for (int j = tid; j < JNACC; j += NT) accL[j] = 0.0;
 #endif
   auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (rev ? out[outLen - o] : out[o - 1]) : 0; };
+#if JENV
+  // rows of the pair's envelope by (sweep-frame) output position; a pair of the batch without one has [0, inLen + 1)
+  const int *envS = pd.envBase >= 0 ? A.envStart + pd.envBase : nullptr, *envE = pd.envBase >= 0 ? A.envEnd + pd.envBase : nullptr;
+  auto envSAt = [&](int o) -> int { return (envS && o >= 0 && o <= outLen) ? envS[rev ? outLen - o : o] : 0; };
+  auto envEAt = [&](int o) -> int { return (envE && o >= 0 && o <= outLen) ? envE[rev ? outLen - o : o] : inLen + 1; };
+  const int iOrig = rev ? inLen - i : i;
+#endif
 #if JHALOT > 0
   // halo supercells (i0-1, t+1) of ALL the tile's steps, fetched here: the step loop then issues no vector-memory load
 #if JMODE == 2
   double *haloBuf = accL + JNACC;
 #else
-  double *haloBuf = (double *)(tokWin + 2 * (W + C));
+  double *haloBuf = (double *)(tokWin + 6 * (W + C));
 #endif
   if (i0 > 0)
     for (int idx = tid; idx < (t1 - t0) * S; idx += NT) {
@@ -223,6 +240,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   {
     const int k0 = t0 / W;
     for (int j = tid; j < W + C - 1; j += NT) tokWin[(k0 & 1) * (W + C) + j] = tokAt(k0 * W - C + 1 + j);
+#if JENV
+    for (int j = tid; j < W + C - 1; j += NT) { envSW[(k0 & 1) * (W + C) + j] = envSAt(k0 * W - C + 1 + j); envEW[(k0 & 1) * (W + C) + j] = envEAt(k0 * W - C + 1 + j); }
+#endif
   }
   __syncthreads();
   // ring state of steps t0-1 (and t0-2 when match edges exist); flat index over (column, state) so that machines with
@@ -275,14 +295,24 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     const bool active = colValid && o >= 0 && o <= outLen;
     const int kw = t / W, tw = t - kw * W;
     const int ot = tokWin[(kw & 1) * (W + C) + tw + (C - 1 - c)];
+#if JENV
+    const bool inside = active && iOrig >= envSW[(kw & 1) * (W + C) + tw + (C - 1 - c)] && iOrig < envEW[(kw & 1) * (W + C) + tw + (C - 1 - c)];
+#endif
     // prefetch the next token window (registers now, LDS at the end of the step)
     int tokPre[JTOKN];
+#if JENV
+    int envSPre[JTOKN], envEPre[JTOKN];
+#endif
     const bool wantTok = (tw == 0 || t == t0) && (kw + 1) * W < t1;
     if (wantTok) {
 #pragma unroll
       for (int k = 0; k < JTOKN; ++k) {
         const int j = tid + k * NT;
         tokPre[k] = (j < W + C - 1) ? tokAt((kw + 1) * W - C + 1 + j) : 0;
+#if JENV
+        envSPre[k] = (j < W + C - 1) ? envSAt((kw + 1) * W - C + 1 + j) : 0;
+        envEPre[k] = (j < W + C - 1) ? envEAt((kw + 1) * W - C + 1 + j) : 0;
+#endif
       }
     }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
@@ -328,6 +358,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       for (int k = 0; k < JTOKN; ++k) {
         const int j = tid + k * NT;
         if (j < W + C - 1) tokWin[((kw + 1) & 1) * (W + C) + j] = tokPre[k];
+#if JENV
+        if (j < W + C - 1) { envSW[((kw + 1) & 1) * (W + C) + j] = envSPre[k]; envEW[((kw + 1) & 1) * (W + C) + j] = envEPre[k]; }
+#endif
       }
     }
 #if JMODE == 2
