@@ -277,6 +277,7 @@ struct FastState {
   MedGeom geoCnt;
   // large one-tape machines (mb_wide.hip): programs built on first use, rebuilt after a weight update
   WideProgram wFwd, wBwd, wVit;
+  WideCountPlan wCnt;        // posterior counts of one-tape machines (any size): lane = transition
   // machines with a handful of states (mb_small.cpp): lane = column, states in registers
   bool smallTried = false, smallOk = false;
   SmallProgram smF, smB;
@@ -804,7 +805,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt);
-    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit);
+    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_counts_free(f->wCnt);
     small_free(f->smF); small_free(f->smB);
     delete f;
   }
@@ -1146,7 +1147,14 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       if (fused < 0) {
         if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0, b))) break;
         if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
-        if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
+        // one-tape machines: a lane owns a transition and walks the columns (mb_wide.hip); two tapes: one thread per cell
+        const bool oneTape = ((b->m->nIn != 0) != (b->m->nOut != 0)) && g_kernel_choice != 1 && env_int("MB_ONETAPE_COUNTS", 1);
+        if (oneTape) {
+          FastState *f = fast_state(b->m);
+          if (!f->wCnt.ok && !wide_counts_build(b->m, f->wCnt)) { rc = 1; break; }
+          if ((rc = wide_counts(b->m, f->wCnt, d_desc, hp, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, d_counts, g_stream))) break;
+          g_last_kernel = "k_onetape_counts";
+        } else if ((rc = launch_generic_counts(b->m, d_desc, np, maxc, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
       }
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }

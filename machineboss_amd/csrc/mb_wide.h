@@ -94,4 +94,12 @@ void wide_free(WideProgram &P);
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st);
 
+
+// posterior counts of a one-tape machine from its two materialised matrices (any state count): a lane owns a transition
+struct WideCountPlan { bool ok = false; int nWaves = 0; void *d_edges = nullptr; void *d_waveLabel = nullptr; };
+bool wide_counts_build(const mb_machine *m, WideCountPlan &C);
+void wide_counts_free(WideCountPlan &C);
+int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_tape,
+                const double *fwd, const double *bwd, double *d_counts, hipStream_t st);
+
 }  // namespace mb

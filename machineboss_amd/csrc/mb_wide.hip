@@ -874,4 +874,119 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   return rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// posterior transition counts of one-tape machines (BackwardMatrix::getCounts, src/backward.cpp:58-87)
+// ------------------------------------------------------------------------------------------------------------
+// count[e] += sum over columns of exp(F(src) - LL + B(dst) + w) has no dependency between columns, so it is not a sweep: a
+// LANE OWNS ONE TRANSITION and walks the columns of a sequence, summing in a register -- one atomic per (transition,
+// sequence part) instead of one per candidate.  Transitions are sorted by label, so a wavefront's 64 transitions share it
+// and a column whose token differs is skipped by a scalar branch.  The 2 x nStates doubles of a column are gathered by
+// every edge block of the sequence; blockIdx -> (sequence part, edge block) keeps the edge blocks of one part on ONE XCD
+// and next to each other in launch order, so they walk the columns together and the gathers hit that XCD's L2.
+struct OtEdge { uint32_t src, pos; };          // pos: position in the outgoing view (weight, destination, edge id); ~0u = padding
+
+__global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEdge *__restrict__ edges,
+                                                        const unsigned short *__restrict__ waveLabel, int nWaves, int nEB,
+                                                        const PairDesc *__restrict__ pairs, long long nUnits, int colSplit, int inputTape,
+                                                        const int *__restrict__ tape, const double *__restrict__ fwd,
+                                                        const double *__restrict__ bwd, double *__restrict__ counts) {
+  const long long bid = blockIdx.x, slot = bid >> 3;
+  const long long unit = (slot / nEB) * 8 + (bid & 7);
+  const int eb = (int)(slot % nEB);
+  if (unit >= nUnits) return;
+  const long long p = unit / colSplit;
+  const int part = (int)(unit - p * colSplit);
+  const PairDesc pd = pairs[p];
+  const int L = inputTape ? pd.inLen : pd.outLen;
+  const long long S = m.S;
+  const double *F = fwd + pd.cellBase, *B = bwd + pd.cellBase;
+  const double ll = B[0];                       // BackwardMatrix::logLike() = cell(0,0,start), src/backward.cpp:48-50,66
+  if (!(ll > -INFINITY)) return;
+  const int wave = __builtin_amdgcn_readfirstlane(eb * 4 + (int)(threadIdx.x >> 6));
+  if (wave >= nWaves) return;
+  const int y = waveLabel[wave];
+  const OtEdge e = edges[(long long)wave * 64 + (threadIdx.x & 63)];
+  const bool live = e.pos != 0xFFFFFFFFu;
+  const uint32_t pos = live ? e.pos : 0u;
+  const long long src = live ? e.src : 0, dst = m.outDst[pos];
+  const double wl = live ? m.outW[pos] - ll : -INFINITY;
+  const int per = (L + colSplit) / colSplit, cA = part * per, cB = min(L + 1, cA + per);   // source columns [cA, cB)
+  const int *tk = tape + (inputTape ? pd.inBase : pd.outBase);
+  auto term = [&](long long cs, long long cd) -> double {
+    return (double)__builtin_amdgcn_exp2f((float)(F[cs * S + src] + (B[cd * S + dst] + wl)) * 1.44269504088896f);
+  };
+  double acc = 0.0;
+  if (y == 0) {
+#pragma unroll 4
+    for (int c = cA; c < cB; ++c) acc += term(c, c);
+  } else {
+    const int cE = min(cB, L);
+    for (int c = cA; c < cE; ++c)
+      if (tk[c] == y) acc += term(c, c + 1);
+  }
+  if (live && acc != 0.0) atomicAdd(&counts[m.outEid[pos]], acc);
+}
+
+bool wide_counts_build(const mb_machine *m, WideCountPlan &C) {
+  if ((m->nIn != 0) == (m->nOut != 0)) return false;
+  const bool inputTape = m->nIn != 0;
+  std::vector<uint32_t> posOf(m->nTrans);
+  for (long long a = 0; a < m->nTrans; ++a) posOf[m->outPerm[a]] = (uint32_t)a;
+  auto label = [&](long long e) { return (int)(inputTape ? m->inTok[e] : m->outTok[e]); };
+  std::vector<uint32_t> ids(m->nTrans);
+  std::iota(ids.begin(), ids.end(), 0u);
+  std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
+    if (label(a) != label(b)) return label(a) < label(b);
+    if (m->src[a] != m->src[b]) return m->src[a] < m->src[b];
+    return m->dst[a] < m->dst[b];
+  });
+  std::vector<OtEdge> edges;
+  std::vector<unsigned short> wl;
+  for (size_t k = 0; k < ids.size();) {
+    const int y = label(ids[k]);
+    size_t k1 = k;
+    while (k1 < ids.size() && label(ids[k1]) == y) ++k1;
+    for (size_t j = k; j < k1; ++j) edges.push_back({m->src[ids[j]], posOf[ids[j]]});
+    while (edges.size() % 64) edges.push_back({0u, 0xFFFFFFFFu});
+    wl.resize(edges.size() / 64, (unsigned short)y);
+    k = k1;
+  }
+  C.nWaves = (int)wl.size();
+  if (C.d_edges) (void)hipFree(C.d_edges);
+  if (C.d_waveLabel) (void)hipFree(C.d_waveLabel);
+  C.d_edges = nullptr; C.d_waveLabel = nullptr;
+  if (!hip_ok(hipMalloc(&C.d_edges, std::max<size_t>(edges.size(), 1) * sizeof(OtEdge)), "hipMalloc(count edges)") ||
+      !hip_ok(hipMalloc(&C.d_waveLabel, std::max<size_t>(wl.size(), 1) * sizeof(unsigned short)), "hipMalloc(count labels)")) return false;
+  if (!edges.empty() && (!hip_ok(hipMemcpy(C.d_edges, edges.data(), edges.size() * sizeof(OtEdge), hipMemcpyHostToDevice), "H2D(count edges)") ||
+                         !hip_ok(hipMemcpy(C.d_waveLabel, wl.data(), wl.size() * sizeof(unsigned short), hipMemcpyHostToDevice), "H2D(count labels)"))) return false;
+  C.ok = true;
+  return true;
+}
+
+void wide_counts_free(WideCountPlan &C) {
+  if (C.d_edges) (void)hipFree(C.d_edges);
+  if (C.d_waveLabel) (void)hipFree(C.d_waveLabel);
+  C = WideCountPlan();
+}
+
+int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_tape,
+                const double *fwd, const double *bwd, double *d_counts, hipStream_t st) {
+  if (!C.ok) { set_error("one-tape count plan not built"); return 1; }
+  if (hp.empty() || C.nWaves == 0) return 0;
+  const bool inputTape = m->nIn != 0;
+  // few sequences: cut them into column parts so that every XCD has work (a part is never shorter than 64 columns)
+  int maxLen = 0;
+  for (const PairDesc &pd : hp) maxLen = std::max(maxLen, inputTape ? pd.inLen : pd.outLen);
+  int colSplit = 1;
+  const int want = env_int_w("MB_ONETAPE_COUNT_UNITS", 32);
+  while ((long long)hp.size() * colSplit < want && (maxLen + 1) / (colSplit * 2) >= 64) colSplit *= 2;
+  const long long nUnits = (long long)hp.size() * colSplit;
+  const int nEB = (C.nWaves + 3) / 4;
+  const long long grid = ((nUnits + 7) / 8) * 8 * nEB;
+  if (grid > 0x7fffffffll) { set_error("one-tape counts: launch too large"); return 1; }
+  hipLaunchKernelGGL(k_onetape_counts, dim3((unsigned)grid), dim3(256), 0, st, m->dev, (const OtEdge *)C.d_edges,
+                     (const unsigned short *)C.d_waveLabel, C.nWaves, nEB, d_desc, nUnits, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts);
+  return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
+}
+
 }  // namespace mb

@@ -32,9 +32,10 @@ llr = tm(lambda: b.forward(capi.MB_ROLLING), "forward rolling") if "r" in modes 
 llm = tm(lambda: b.forward(capi.MB_MATERIALISE), "forward materialised") if "m" in modes else None
 v = tm(lambda: b.viterbi(paths=False), "viterbi fill") if "v" in modes else None
 if "c" in modes:
+    b.counts()
     t0 = time.perf_counter(); cnt, lls, _ = b.counts(); dt = time.perf_counter() - t0
-    print("fwd+bwd+counts         %8.2f Gcells/s (2 matrices)  %.1f ms  %s  sum of out-edge counts / symbols = %.6f" %
-          (2 * cells / dt / 1e9, dt * 1e3, capi.last_kernel_name(), cnt[np.asarray(em.outTok) != 0].sum() / max(1, pairs * outlen)), flush=True)
+    print("fwd+bwd+counts         %8.2f Gcells/s (2 matrices)  %.1f ms (device %.1f)  %s  sum of out-edge counts / symbols = %.6f" %
+          (2 * cells / dt / 1e9, dt * 1e3, capi.last_device_ms(), capi.last_kernel_name(), cnt[np.asarray(em.outTok) != 0].sum() / max(1, pairs * outlen)), flush=True)
 from oracle import oracle
 om = oracle.OracleMachine(em)
 n = min(outlen, 300)

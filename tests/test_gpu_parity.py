@@ -948,6 +948,7 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     ll = b.forward(capi.MB_ROLLING)
     assert capi.last_kernel_name().startswith("k_wide_")
     llm = b.forward(capi.MB_MATERIALISE); vll, off, edges = b.viterbi(); counts, s, _ = b.counts()
+    assert capi.last_kernel_name() == "k_onetape_counts"
     ref = np.zeros(em.nTransitions)
     for k, y in enumerate(ys):
         V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
@@ -964,6 +965,51 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     lw = np.array(em.logWeight, dtype=np.float64) - 0.125
     dm.set_weights(lw); om.set_weights(lw)
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
+
+
+def test_one_tape_count_kernel(capi, oracle_mod, monkeypatch):
+    """Posterior counts of one-tape machines (lane = transition, mb_wide.hip k_onetape_counts): long sequences cut into
+    column parts, many short ones, a recogniser (the tape is the input), after a weight update; against the per-cell kernel
+    on the same matrices and against the oracle."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    m, em = _profile_machine(3)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(77)
+    x = np.zeros(0, np.int32)
+    for lens in ([700, 513, 64], [9, 0, 31, 2] * 10):
+        ys = [rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in lens]
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+        c1, s1, l1 = b.counts()
+        assert capi.last_kernel_name() == "k_onetape_counts"
+        monkeypatch.setenv("MB_ONETAPE_COUNTS", "0")
+        c0, s0, l0 = b.counts()
+        monkeypatch.delenv("MB_ONETAPE_COUNTS")
+        assert capi.last_kernel_name() != "k_onetape_counts"
+        assert close(c1, c0, 1e-6, 1e-9) and s1 == s0 and np.array_equal(l1, l0)
+        # every output symbol is emitted by exactly one transition of a path: expected emissions sum to the symbol count
+        assert abs(c1[np.asarray(em.outTok) != 0].sum() - sum(lens)) <= 5e-5 * max(1, sum(lens))   # Forward x Backward vs LL: fp32 correction terms over 700 columns
+    lw = np.array(em.logWeight, dtype=np.float64) - 0.0625 * (np.arange(em.nTransitions) % 3)
+    dm.set_weights(lw); om.set_weights(lw)
+    y = rng.randint(1, em.nOutTok + 1, size=37).astype(np.int32)
+    ref = np.zeros(em.nTransitions); om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+    c, _, _ = capi.DeviceBatch.from_pairs(dm, [(x, y)]).counts()
+    assert capi.last_kernel_name() == "k_onetape_counts" and close(c, ref, 1e-5, 1e-7)
+    # a recogniser with enough states for the one-tape family: a ring of 300 states reading a/b
+    states = [{"id": "s%d" % k, "trans": [{"to": "s%d" % ((k + 1) % 300), "in": "ab"[k % 2], "weight": 0.5},
+                                          {"to": "s%d" % ((k + 7) % 300), "in": "ab"[(k + 1) % 2], "weight": 0.25}] +
+               ([{"to": "end", "weight": 0.25}] if k % 5 == 0 else [])} for k in range(300)] + [{"id": "end"}]
+    er = EvaluatedMachine.fromMachine(Machine.fromJson({"state": states}), {})
+    orr = oracle_mod.OracleMachine(er); dr = capi.DeviceMachine(er)
+    xs = [rng.randint(1, 3, size=n).astype(np.int32) for n in (200, 45, 0, 130)]
+    br = capi.DeviceBatch.from_pairs(dr, [(xx, np.zeros(0, np.int32)) for xx in xs])
+    cr, sr, llr = br.counts()
+    assert capi.last_kernel_name() == "k_onetape_counts"
+    ref = np.zeros(er.nTransitions)
+    for xx, l in zip(xs, llr):
+        if l > -math.inf:
+            orr.counts_add(xx, np.zeros(0, np.int32), ref, oracle_mod.SUM_EXACT)
+    assert ref.any() and close(cr, ref, 1e-5, 1e-7)
 
 
 @pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])
