@@ -159,6 +159,32 @@ def extra_single_gpu(capi, np, hbm_peak):
     out["forward_config2"] = {"workload": "dnapsw 1024 x 1000 x 1000, Forward", "rolling": round(cells2 / tr / 1e9, 2), "materialised": round(cells2 / tm / 1e9, 2),
                               "unit": "Gcells/s", "roofline": {"bound": "hbm", "achieved": round(8.0 * cells2 / (devm / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                                                "frac": round(8.0 * cells2 / (devm / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name()}}
+    del b2
+
+    # config 5: HMMER profile . simple_introns . translate . dnapsw assembled here (first 20 nodes of the fn3 profile: 5063
+    # states, the "~5k states" of the config), a one-tape generator; 64 sequences x 2 kb (one workgroup per sequence)
+    try:
+        from machineboss_amd import algebra as A
+        from machineboss_amd.hmmer import HmmerModel
+        P = lambda n: Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", n + ".json"))
+        t0 = time.perf_counter()
+        h = HmmerModel.fromFile(os.path.join(ROOT, "tests", "golden", "hmmer", "fn3.hmm")).truncated(20)
+        em5 = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
+        tc = time.perf_counter() - t0
+        dm5 = capi.DeviceMachine(em5)
+        b5 = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 2000, em5.nInTok, em5.nOutTok))
+        cells5 = b5.cells()
+        ll5, t5 = timed(lambda: b5.forward(capi.MB_ROLLING), 2); k5 = capi.last_kernel_name()
+        _, t5v = timed(lambda: b5.viterbi(paths=False), 1)
+        (cnt5, s5, _), t5c = timed(lambda: b5.counts(), 1); k5c = capi.last_kernel_name()
+        out["config5"] = {"workload": "fn3 profile (20 nodes) . simple_introns . translate . dnapsw: %d states, %d transitions, one tape; 64 sequences x 2000 nt" % (em5.nStates, em5.nTransitions),
+                          "compose_s": round(tc, 2), "forward_rolling": round(cells5 / t5 / 1e9, 2), "viterbi_fill": round(cells5 / t5v / 1e9, 2),
+                          "counts_lattice": round(cells5 / t5c / 1e9, 2), "unit": "Gcells/s", "counts_ms": round(t5c * 1e3, 1),
+                          "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
+                          "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
+                          "roofline": {"bound": "valu", "note": "one workgroup per sequence, a column's silent closure is a dependent chain: bound by instruction issue on 64 of 256 CUs (DESIGN.md 4.2b); no HBM or MFMA bound applies"}}
+    except Exception as e:   # the extras never take the headline down
+        out["config5"] = {"error": str(e)}
     return out
 
 
