@@ -1,5 +1,6 @@
 // mb_medium.h -- host/device structures of the "lanes = states" tiled kernel family (see mb_medium.hip).
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "mb_internal.h"
@@ -115,7 +116,10 @@ inline int medium_default_G(int S) {   // measured with the specialised kernel: 
   // psw2dna (271 states): 4 >= 2 > 1; dnapsw/protpsw (8 states): 32 > 16 > 64 > 8
   return S >= 1024 ? 1 : (S >= 384 ? 2 : (S >= 48 ? 4 : (S >= 24 ? 8 : 32)));
 }
-inline int medium_default_count_G(int S) { return S >= 24 ? medium_default_G(S) : 16; }   // LDS count atomics collide across the lanes of a wavefront that share a transition
+// count sweep: LDS count atomics collide across the lanes of a wavefront that share a transition (few states: 16 columns
+// per wavefront, not 32); the Backward supercell per column in LDS caps the strip at 16 columns for psw2dna (271 states),
+// where 8 wavefronts x 2 columns (133 ms at 64 x 487 x 2 kb) beat 4 x 4 (150) and 16 x 1 (164)
+inline int medium_default_count_G(int S) { return S >= 128 ? std::min(medium_default_G(S), 2) : (S >= 24 ? medium_default_G(S) : 16); }
 inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
