@@ -302,6 +302,11 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     const int pad = JREV ? NA * 64 - 1 - inLen : 0;
     const int i = a * 64 + lane - pad;
     const bool colValid = i >= 0 && i <= inLen;
+    // lanes of this strip that hold a column of the lattice, and this lane's group of lanes that share a 128-byte line of a
+    // store instruction (see the stores below)
+    const int cLo = JREV ? max(pad - a * 64, 0) : 0, cHi = JREV ? 63 : min(inLen - a * 64, 63);
+    const int gLo = lane & ~(JLINELANES - 1), gHi = lane | (JLINELANES - 1);
+    (void)cLo; (void)cHi; (void)gLo; (void)gHi;
     const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
     const int it = (colValid && i > 0) ? (JREV ? in[inLen - i] : in[i - 1]) : 0;
     auto tokAt = [&](int o) -> int { return (o >= 1 && o <= outLen) ? (JREV ? out[outLen - o] : out[o - 1]) : 0; };
@@ -412,7 +417,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
        << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
        << "\n#define JLDSWN " << (P.nEntries - P.off[2]) << "\n#define JWAVEDBL " << wave_doubles(P, mode)
        << "\n#define JOFFSIL " << P.off[3] << "\n#define JOFFIN " << P.off[1] << "\n#define JOFFOUT " << P.off[2] << "\n#define JOFFMAT " << P.off[0]
-       << "\n#define JENDSTATE " << P.endState << "\n";
+       << "\n#define JENDSTATE " << P.endState << "\n#define JLINELANES " << (env_int_s("MB_SMALL_STORE_LINES", 1) ? 128 / CB : 64) << "\n";
   for (int k = 0; k < P.nTab[3]; ++k) weights << "    const double wS" << k << " = wc[JOFFSIL + " << k << "];\n";
   for (int k = 0; k < P.nTab[1]; ++k) weights << "    const double wI" << k << " = A.w[JOFFIN + " << (long long)k * (P.nIn + 1) << " + it];\n";
   // persistent state: two sets of cells and of left-neighbour values, alternating by step parity
@@ -450,14 +455,18 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
     b << "        {  // step parity " << p << "\n";
     b << "          const int jj = j + " << p << ", t = tb + jj, o = t - lane;\n";
     b << "          const bool active = colValid && o >= 0 && o <= outLen;\n";
+    if (materialise || counting)
+      b << "          const bool lineOn = gHi >= max(t - outLen, cLo) && gLo <= min(t, cHi);   // some lane of this lane's 128-byte line holds a cell\n";
     const bool lateB = env_int_s("MB_SMALL_BLOAD", 0) != 0;
     auto loadB = [&]() {
       // the Backward supercell of this step's cell: requested at the top of the step, used after its Forward values are done
       b << "          " << (CB == 16 ? "d2" : "double");
       for (int k = 0; k < NCH; ++k) b << (k ? "," : "") << " bq" << k;
-      b << ";\n          { const double *bp = bPtr(t);\n";
+      b << ";\n          if (lineOn) { const double *bp = bPtr(t);   // lines without a cell were not written by the Backward sweep\n";
       for (int k = 0; k < NCH; ++k)
         b << "            bq" << k << " = " << (CB == 16 ? "*(const d2 *)(bp + " + I(k * 128) + ")" : "bp[" + I(k * 64) + "]") << ";\n";
+      b << "          } else {\n";
+      for (int k = 0; k < NCH; ++k) b << "            bq" << k << " = " << (CB == 16 ? "d2{0.0, 0.0}" : "0.0") << ";\n";
       b << "          }\n";
     };
     if (counting && !lateB) loadB();
@@ -511,10 +520,12 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
     }
     // ---- outputs of the step ----
     if (materialise) {
-      // every lane stores, also the ones outside the lattice (their slots exist and are never read): a store instruction
-      // then always writes 64 x CB contiguous bytes -- with the inactive lanes masked off the partial cache lines at the two
-      // ends of the active range cost more than the bytes saved (scripts/micro/tile_major_probe.hip: 3.3 vs 5.4 TB/s)
-      b << "          {\n            double *dst = poolPair + ((long long)(a * Te + t) * (JNCH * 64) + lane) * (JCHB / 8);\n";
+      // stores are switched off in units of WHOLE 128-byte lines: a line with at least one cell of the lattice is written by
+      // all of its lanes (the slots of the others exist and are never read), a line with none is not written at all.  With
+      // single lanes masked off, the partial cache lines at the two ends of the active range cost more than the bytes saved
+      // (scripts/micro/tile_major_probe.hip: 3.3 vs 5.4 TB/s); with everything stored, the skewed start / end of a strip
+      // sweep and the padding columns of the last strip are 1.3 x the traffic on 400 x 400 pairs.
+      b << "          if (lineOn) {\n            double *dst = poolPair + ((long long)(a * Te + t) * (JNCH * 64) + lane) * (JCHB / 8);\n";
       for (int k = 0; k < NCH; ++k) {
         if (CB == 16) b << "            { d2 v; v.x = " << cp << 2 * k << "; v.y = " << cp << 2 * k + 1 << "; *(d2 *)(dst + " << k * 128 << ") = v; }\n";
         else b << "            dst[" << k * 64 << "] = " << cp << k << ";\n";
