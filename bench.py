@@ -201,10 +201,19 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    # MB_BENCH_BACKEND=gloo MB_BENCH_SHARE_DEVICE=1: every rank on GPU 0 with the collectives on the host -- a dry run of
+    # the N > 1 code path on a one-GPU box (tests/test_gpu_parity.py); the real thing is "nccl" (= RCCL), one GPU per rank
+    backend = os.environ.get("MB_BENCH_BACKEND", "nccl")
+    if os.environ.get("MB_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
+    cdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from machineboss_amd import capi
     from machineboss_amd.machine import Machine
@@ -258,10 +267,10 @@ def main():
     kernel = capi.last_kernel_name()
     total_cells = cells_rank
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(cells_rank)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = float(c.item())
     value = total_cells * args.steps / dt / 1e9
@@ -276,17 +285,17 @@ def main():
         per = 1024
         bp = capi.DeviceBatch(dmp, *synth_batch(3, per, 400, 400, emp.nInTok, emp.nOutTok, first=rank * per))
         bp.counts()
-        seen = torch.ones(1, dtype=torch.float64, device="cuda"); dist.all_reduce(seen)
+        seen = torch.ones(1, dtype=torch.float64, device=cdev); dist.all_reduce(seen)
         sync(); t1 = time.perf_counter()
         its = 3
         for _ in range(its):
             cnt, s, _ = bp.counts()
             te = time.perf_counter()
-            cnt, s = allreduce_counts(cnt, s, "cuda")
+            cnt, s = allreduce_counts(cnt, s, cdev)
             tr = time.perf_counter() - te
         sync(); d1 = (time.perf_counter() - t1) / its
         nsym = float(cnt[np.asarray(emp.inTok) != 0].sum())
-        extra["em_iteration"] = {"workload": "config 3: protpsw --train E-step, %d x 400 x 400 aa per GPU + all-reduce of %d doubles (backend nccl = RCCL)" % (per, emp.nTransitions + 1),
+        extra["em_iteration"] = {"workload": "config 3: protpsw --train E-step, %d x 400 x 400 aa per GPU + all-reduce of %d doubles (backend %s)" % (per, emp.nTransitions + 1, "nccl = RCCL" if backend == "nccl" else backend),
                                  "ms_per_iteration": round(d1 * 1e3, 3), "allreduce_ms": round(tr * 1e3, 3), "n_ranks_seen": int(seen.item()),
                                  "value": round(world * bp.cells() / d1 / 1e9, 2), "unit": "G lattice-cells/s over all ranks",
                                  "symbol_count_invariant": nsym / (world * per * 400)}

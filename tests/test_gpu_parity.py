@@ -1209,6 +1209,32 @@ def test_boss_cli_two_ranks_end_to_end(capi, tmp_path):
         port += 1
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_dry_run(capi, scaling):
+    """`python bench.py --gpus 2` as typed (the parent spawns the ranks before touching the GPU): the N > 1 path of the bench
+    -- sharding, barrier + max-over-ranks timing, the EM leg with its all-reduce -- on a reduced workload.  Both ranks share
+    the one GPU of this box and the collectives run over gloo (MB_BENCH_BACKEND / MB_BENCH_SHARE_DEVICE); on a multi-GPU
+    node the same code takes RCCL."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MB_BENCH_BACKEND="gloo", MB_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "6", "--outlen", "700",
+                        "--scaling", scaling], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    pairs_total = 12 if scaling == "weak" else 6
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 2
+    assert d["config"]["cells_per_gpu_per_step"] * 2 == pairs_total * 488 * 701 * 271
+    assert abs(d["value"] - pairs_total * 488 * 701 * 271 / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-3 * d["value"]
+    em = d["extra"]["em_iteration"]
+    assert em["n_ranks_seen"] == 2 and abs(em["symbol_count_invariant"] - 1.0) < 1e-4
+
+
 def test_workspace_eviction_between_modes(capi, machines):
     """the memory budget counts cached workspaces as reclaimable, so a call that needs a big slot must be able to
     evict the pools earlier calls left behind.  Alternate Forward (pool 0), counts (pools 0 + 1) and Viterbi under an
