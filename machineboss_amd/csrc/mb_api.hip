@@ -463,7 +463,14 @@ struct SmallPlan {
   long long poolD = 0, tbB = 0, haloD = 0, boundD = 0;
 };
 
-static void small_plan(const SmallProgram &P, const PairDesc *hp, long long n, bool wantPool, bool wantTb, SmallPlan &pl) {
+// Halo rows and boundary records are laid out for the LARGER of the two sweep directions' needs: a count call runs the
+// Backward and the Forward program over the same buffers (and offsets), and the two programs of an asymmetric machine
+// keep different numbers of values per halo row / boundary record.
+static int small_halo_width(const mb_machine *m) { const FastState *f = (const FastState *)m->fast; return std::max(1, std::max(f->smF.H, f->smB.H)); }
+static int small_bound_width(const mb_machine *m) { const FastState *f = (const FastState *)m->fast; return std::max(f->smF.NBD, f->smB.NBD); }
+
+static void small_plan(const mb_machine *m, const SmallProgram &P, const PairDesc *hp, long long n, bool wantPool, bool wantTb, SmallPlan &pl) {
+  const int HW = small_halo_width(m), BW = small_bound_width(m);
   pl = SmallPlan();
   pl.aux.resize((size_t)n);
   for (long long k = 0; k < n; ++k) {
@@ -472,8 +479,8 @@ static void small_plan(const SmallProgram &P, const PairDesc *hp, long long n, b
     a.pool = pl.poolD; a.tb = pl.tbB; a.halo = pl.haloD; a.bound = pl.boundD;
     if (wantPool) pl.poolD += small_pair_doubles(P.S, pd.inLen, pd.outLen);
     if (wantTb) pl.tbB += (small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 15) & ~15ll;
-    pl.haloD += (long long)small_strips(pd.inLen) * (pd.outLen + 1) * std::max(P.H, 1);   // one halo column per strip
-    pl.boundD += (long long)small_strips(pd.inLen) * 64 * P.NBD;
+    pl.haloD += (long long)small_strips(pd.inLen) * (pd.outLen + 1) * HW;   // one halo column per strip
+    pl.boundD += (long long)small_strips(pd.inLen) * 64 * BW;
   }
 }
 
@@ -483,7 +490,7 @@ static bool small_chunks_plan(const mb_batch *b, const SmallProgram &P, bool wan
   long long p0 = 0, acc = 0;
   for (long long p = 0; p < b->nPairs; ++p) {
     const PairDesc &pd = b->pairs[p];
-    long long c = ((long long)small_strips(pd.inLen) * (pd.outLen + 1) * std::max(P.H, 1) + (long long)small_strips(pd.inLen) * 64 * P.NBD) * 8;
+    long long c = ((long long)small_strips(pd.inLen) * (pd.outLen + 1) * small_halo_width(b->m) + (long long)small_strips(pd.inLen) * 64 * small_bound_width(b->m)) * 8;
     if (wantPool) c += small_pair_doubles(P.S, pd.inLen, pd.outLen) * 8;
     if (wantTb) c += small_pair_tb_bytes(P.S, pd.inLen, pd.outLen) + 16;
     if (c > budget) { set_error("a single DP matrix (" + std::to_string(c) + " bytes) exceeds the device memory budget"); return false; }
@@ -498,7 +505,7 @@ static bool small_chunks_plan(const mb_batch *b, const SmallProgram &P, bool wan
 static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, bool wantPool, bool wantTb, SmallPlan &pl,
                          std::vector<PairDesc> &hp, SmAux **d_aux, SmSweep &sw, size_t chunkNo = (size_t)-1) {
   hp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
-  small_plan(P, hp.data(), (long long)hp.size(), wantPool, wantTb, pl);
+  small_plan(b->m, P, hp.data(), (long long)hp.size(), wantPool, wantTb, pl);
   MB_HIP(sm_alloc((void **)d_aux, hp.size() * sizeof(SmAux)));   // (the caller frees *d_aux on every path)
   MB_HIP(hipMemcpyAsync(*d_aux, pl.aux.data(), hp.size() * sizeof(SmAux), hipMemcpyHostToDevice, g_stream));
   sw = SmSweep();
@@ -1106,7 +1113,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   const long long nT = b->m->nTrans;
-  if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF)) return small_counts(b, counts, loglikeSum, loglike);
+  if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF, b->hasEnv)) return small_counts(b, counts, loglikeSum, loglike);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;

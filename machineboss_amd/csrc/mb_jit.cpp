@@ -110,4 +110,17 @@ bool jit_compile(const std::string &src, const char *name, std::string &code, st
   return true;
 }
 
+long long jit_kernel_meta(const std::string &code, const char *key) {
+  const size_t klen = strlen(key);
+  const size_t p = code.find(key);
+  if (p == std::string::npos || p + klen >= code.size()) return -1;
+  const unsigned char *q = (const unsigned char *)code.data() + p + klen;
+  const size_t left = code.size() - (p + klen);
+  if (q[0] <= 0x7f) return q[0];
+  if (q[0] == 0xcc && left >= 2) return q[1];
+  if (q[0] == 0xcd && left >= 3) return ((long long)q[1] << 8) | q[2];
+  if (q[0] == 0xce && left >= 5) return ((long long)q[1] << 24) | ((long long)q[2] << 16) | ((long long)q[3] << 8) | q[4];
+  return -1;
+}
+
 }  // namespace mb

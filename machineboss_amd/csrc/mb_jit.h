@@ -16,4 +16,7 @@ double jit_compile_ms();
 long long jit_compiles();
 long long jit_cache_hits();
 
+// value of an unsigned-integer field of the (single) kernel's metadata note in a code object, e.g. ".vgpr_spill_count",
+// ".private_segment_fixed_size" (msgpack: positive fixint, or 0xcc/0xcd/0xce + big-endian uint8/16/32); -1 if missing
+long long jit_kernel_meta(const std::string &codeObject, const char *key);
 }  // namespace mb

@@ -193,7 +193,7 @@ static int row_floats(const SmallProgram &P) {   // count mode: lane-private usa
 static int outacc_floats(const SmallProgram &P) { return (P.nTab[2] * (P.nOut + 1) + 1) & ~1; }   // count mode: usage by (output-token table, token)
 static long long wave_doubles(const SmallProgram &P, int mode) {
   long long d = 32 + 64 + 64ll * std::max(P.H, 1);   // tokens, envelope rows (start / end), halo rows
-  if (mode == SM_COUNT) d += (64ll * row_floats(P) + 1) / 2 + outacc_floats(P) / 2;
+  if (mode == SM_COUNT) d += (64ll * row_floats(P) + (row_floats(P) & 1) + outacc_floats(P) + 1) / 2;   // rowL, then outAcc (the kernel starts it (JROWF & 1) floats further on)
   return (d + 1) & ~1ll;
 }
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode) {
@@ -406,12 +406,17 @@ const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise)
   return P.backward ? "k_small_sum_bwd" : (materialise ? "k_small_sum_mat" : "k_small_sum_roll");
 }
 
-std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env) {
+// wavefronts per SIMD the kernel is compiled for (register budget 512 / n): the count sweep hides the latency of its
+// Backward loads with occupancy; small_jit_get lowers it until the kernel needs no scratch memory
+int small_default_minwaves(int mode, bool env) { return std::max(1, env_int_s("MB_SMALL_MINWAVES", mode == SM_COUNT ? (env ? 3 : 4) : 1)); }
+
+std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env, int minWaves) {
   std::ostringstream defs, weights, state, loadb, saveb, flush;
   const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
   const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
   const int rowF = row_floats(P);
-  defs << "#define JMINWAVES " << env_int_s("MB_SMALL_MINWAVES", counting ? (env ? 3 : 4) : 1) << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
+  if (minWaves <= 0) minWaves = small_default_minwaves(mode, env);
+  defs << "#define JMINWAVES " << minWaves << "\n#define JKERNEL " << small_kernel_name(P, mode, materialise) << "\n#define JS " << S << "\n#define JNIN " << P.nIn << "\n#define JNOUT " << P.nOut << "\n#define JREV " << (P.backward ? 1 : 0)
        << "\n#define JENV " << (env ? 1 : 0) << "\n#define JMODE " << mode << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JH " << P.H << "\n#define JHP " << std::max(P.H, 1)
        << "\n#define JNBD " << P.NBD << "\n#define JCHB " << CB << "\n#define JNCH " << NCH << "\n#define JTBSTRIDE " << small_tb_stride(S)
        << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
@@ -608,16 +613,28 @@ bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env) {
   if (!P.ok) return false;
   J.ldsBytes = small_jit_lds_bytes(P, mode);
   if (J.ldsBytes > 160 * 1024) { set_error("small-machine kernel: tables exceed the LDS"); return false; }
-  const std::string src = small_jit_source(P, mode, materialise, env);
-  if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
-    const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
-    if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
-  }
+  // Registers: every state, neighbour value, weight and usage sum of the machine is a named VGPR; a machine near the
+  // family's limit (12-16 states, dozens of tables) does not fit the budget of 3-4 wavefronts per SIMD.  A kernel that
+  // spills to SCRATCH memory is not used: the budget is raised (fewer wavefronts per SIMD) until it needs none -- a spilled
+  // count sweep is slow, and on one randomised case (12 states, 469 spilled VGPRs) it produced wrong Forward values that
+  // no version without scratch does (scripts/fuzz_env_gpu.py seed 5229).  J.scratch tells the caller when even one
+  // wavefront per SIMD does not fit.
   std::string code, log;
-  if (!jit_compile(src, "mb_small_jit.hip", code, &log, nullptr)) {
-    if (getenv("MB_SMALL_JIT_VERBOSE") || getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
-    set_error("run-time compilation of the small-machine kernel failed: " + log.substr(0, 400));
-    return false;
+  for (int mw = small_default_minwaves(mode, env); mw >= 1; --mw) {
+    const std::string src = small_jit_source(P, mode, materialise, env, mw);
+    if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
+      const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
+      if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+    }
+    if (!jit_compile(src, "mb_small_jit.hip", code, &log, nullptr)) {
+      if (getenv("MB_SMALL_JIT_VERBOSE") || getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
+      set_error("run-time compilation of the small-machine kernel failed: " + log.substr(0, 400));
+      return false;
+    }
+    J.scratch = jit_kernel_meta(code, ".private_segment_fixed_size") > 0;
+    if (getenv("MB_SMALL_JIT_VERBOSE")) fprintf(stderr, "[mbhip] small family, mode %d: %d wavefront(s) per SIMD, %lld VGPRs, %lld spilled, scratch %lld bytes\n", mode, mw,
+                                                jit_kernel_meta(code, ".vgpr_count"), jit_kernel_meta(code, ".vgpr_spill_count"), jit_kernel_meta(code, ".private_segment_fixed_size"));
+    if (!J.scratch || env_int_s("MB_SMALL_ALLOW_SCRATCH", 0)) break;
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
@@ -629,7 +646,12 @@ bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env) {
 }
 
 // the count sweep keeps one usage row per lane in LDS: machines with many output-token / match tables do not fit
-bool small_count_fits(const SmallProgram &P) { return P.ok && small_jit_lds_bytes(P, SM_COUNT) <= 96 * 1024; }
+// ... and machines near the family's limits need more registers than a wavefront has: no count sweep through scratch
+// memory (the caller takes the tiled family's fused count sweep instead)
+bool small_count_fits(SmallProgram &P, bool env) {
+  if (!P.ok || small_jit_lds_bytes(P, SM_COUNT) > 96 * 1024) return false;
+  return small_jit_get(P, SM_COUNT, false, env) && !P.jit[SM_COUNT][0][env ? 1 : 0].scratch;
+}
 
 // ---- one sweep: the wavefront of tiles --------------------------------------------------------------------------------------
 struct SmallArgsHost {   // must match SmallArgs in the generated source

@@ -19,7 +19,7 @@ enum { SM_SUM = 0,     // log-sum-exp semiring: Forward, or Backward on the reve
 // 2 output-only = (i,o-1), 3 silent = same supercell), which state there, and which weight / edge-id table it uses.
 struct SmSlot { int T, src, dup, tab; };
 
-struct SmJit { bool tried = false; void *module = nullptr, *func = nullptr; size_t ldsBytes = 0; int vgprs = 0; };
+struct SmJit { bool tried = false; void *module = nullptr, *func = nullptr; size_t ldsBytes = 0; int vgprs = 0; bool scratch = false; };   // scratch: the kernel spills to scratch memory even at one wavefront per SIMD
 
 struct SmallProgram {
   bool ok = false, backward = false;
@@ -64,10 +64,11 @@ bool small_build_host(const mb_machine *m, bool backward, SmallProgram &P);
 bool small_build(const mb_machine *m, bool backward, SmallProgram &P);
 bool small_refresh_weights(const mb_machine *m, SmallProgram &P);
 void small_free(SmallProgram &P);
-std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env = false);
+std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env = false, int minWaves = 0);
+int small_default_minwaves(int mode, bool env);
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode);
 bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env = false);
-bool small_count_fits(const SmallProgram &P);
+bool small_count_fits(SmallProgram &P, bool env);
 const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise);
 
 // Per-pair placement of the buffers a sweep uses (all offsets relative to the chunk's workspaces)

@@ -138,6 +138,20 @@ def test_small_vs_medium_large(capi, machines):
     assert close(a[3][0], g[3][0], 1e-5, 1e-6) and close(a[3][1], g[3][1], FAST_REL)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5013, 5229, 5272, 5001, 5005, 5009])
+def test_small_envelope_batches_regressions(capi, oracle_mod, seed):
+    """Cases of scripts/fuzz_env_gpu.py (random machine, ragged batch, some pairs under the path-area envelope of a random
+    alignment), among them the three that exposed bugs in round 2: Backward and Forward programs of an asymmetric machine
+    keep different numbers of values per halo row / boundary record and share the buffers of a count call (5013, 5272);
+    a 12-state machine whose count sweep does not fit the registers of 3 wavefronts per SIMD (5229)."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_env_gpu", os.path.join(ROOT, "scripts", "fuzz_env_gpu.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run_case(seed) == {}
+
+
 # ---- CPU: program structure and generated source ---------------------------------------------------------------------------
 def test_small_source_compiles_for_gfx950(tmp_path, machines):
     """Every mode of the generated kernel cross-compiles for gfx950 without spills (hipcc needs no GPU)."""
