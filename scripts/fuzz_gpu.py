@@ -22,14 +22,14 @@ t0 = time.time()
 for c in range(cases):
     rng = np.random.RandomState(seed0 + c)
     oneTape = c % 3 == 2
-    S = int(rng.choice([1, 2, 3, 7, 17, 33, 64, 100, 257, 300, 700])) if not oneTape else int(rng.choice([5, 40, 260, 300, 900]))
+    S = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 16, 17, 33, 64, 100, 257, 300, 700])) if not oneTape else int(rng.choice([5, 40, 260, 300, 900]))
     nIn = 0 if oneTape else int(rng.randint(1, 4)); nOut = int(rng.randint(1, 4))
     if oneTape and c % 6 == 5: nIn, nOut = nOut, 0          # a recogniser: the one tape is the input
     em = random_machine(S, nIn, nOut, seed0 + c, density=float(rng.uniform(0.8, 3.0)), silent_density=float(rng.uniform(0.2, 2.0)), allow_inf=bool(c % 5 == 0))
     if oneTape: os.environ["MB_WIDE_MIN_STATES"] = "1" if c % 2 else "256"
     dm = capi.DeviceMachine(em); om = oracle.OracleMachine(em)
     n = int(rng.randint(1, 6))
-    scale = 6 if c % 7 == 3 and S <= 100 else 1         # some longer lattices (several tiles / strips) on the smaller machines
+    scale = 6 if (c % 7 == 3 and S <= 100) or (c % 2 == 1 and S <= 16) else 1   # longer lattices (several tiles / strips) on the smaller machines
     pairs = [(random_seq(rng, int(rng.randint(0, 40 * scale)) if nIn else 0, nIn), random_seq(rng, int(rng.randint(0, 60 * scale)) if nOut else 0, nOut)) for _ in range(n)]
     b = capi.DeviceBatch.from_pairs(dm, pairs)
     out = {}
