@@ -209,6 +209,7 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
   int i = inLen, o = outLen, s = S - 1;
   if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
   long long n = 0;
+  uint32_t held = 0;
   while (i > 0 || o > 0 || s != 0) {
     const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
     const double *cur = cells + ((long long)o * I + i) * S;
@@ -242,12 +243,16 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
     if (bestA < 0) { if (lane == 0) pathLen[p] = -3; return; }
     if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
     const uint32_t eid = m.inEid[bestA];
-    if (lane == 0) pathBuf[slot0 + cap - 1 - n] = eid;
+    // lane (n mod 64) keeps the step's edge; 64 of them go out in one store.  (On gfx9 a store counts in vmcnt like a load:
+    // a store per step would make the next step's wait for its cells also a wait for that store's acknowledgement.)
+    if ((int)(n & 63) == lane) held = eid;
     ++n;
+    if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
     if (m.eInTok[eid]) --i;
     if (m.eOutTok[eid]) --o;
     s = (int)m.inSrc[bestA];
   }
+  if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
   if (lane == 0) pathLen[p] = n;
 }
 
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
   int i = inLen, o = outLen, s = S - 1;
   if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
   long long n = 0;
+  uint32_t held = 0;
   const bool prefetch = 9 * S <= 128;
   double pfA = 0.0, pfB = 0.0;
   unsigned sink = 0;
@@ -329,12 +335,14 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
     if (bestA < 0) { if (lane == 0) pathLen[p] = -3; return; }
     if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
     const TbEdge be = lEdge[bestA];
-    if (lane == 0) pathBuf[slot0 + cap - 1 - n] = be.eid;
+    if ((int)(n & 63) == lane) held = be.eid;   // one store per 64 steps, see k_traceback
     ++n;
+    if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
     if (be.hasIn) --i;
     if (be.hasOut) --o;
     s = (int)be.src;
   }
+  if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
   if (lane == 0) pathLen[p] = (sink == 0x9e3779b9u && n < 0) ? -4 : n;   // `sink` keeps the touches alive; never true
 }
 
