@@ -35,7 +35,7 @@ def make_case(seed):
     nIn = int(rng.randint(1, 4)); nOut = int(rng.randint(1, 4))
     em = random_machine(S, nIn, nOut, seed, density=float(rng.uniform(0.8, 3.0)), silent_density=float(rng.uniform(0.2, 2.0)), allow_inf=bool(c % 5 == 0))
     n = int(rng.randint(1, 6))
-    scale = 5 if c % 4 == 1 and S <= 64 else 1          # longer lattices: several strips and tiles, most of them outside the band
+    scale = 5 if (c % 4 == 1 and S <= 64) or (c % 4 == 3 and S <= 100) else 1   # longer lattices: several strips and tiles, most of them outside the band
     pairs = [(random_seq(rng, int(rng.randint(0, 40 * scale)), nIn), random_seq(rng, int(rng.randint(0, 60 * scale)), nOut)) for _ in range(n)]
     envs = [random_envelope(rng, len(x), len(y)) if (k == 0 or rng.rand() < 0.6) else None for k, (x, y) in enumerate(pairs)]
     return em, pairs, envs
