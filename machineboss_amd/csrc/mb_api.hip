@@ -894,20 +894,27 @@ int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *in
   b->hasEnv = false;
   ++b->envVersion;
   const long long total = envOff[b->nPairs] - envOff[0];
+  auto fail = [&](const char *msg) {   // a rejected call leaves the batch with full envelopes, not with half of the new ones
+    for (PairDesc &pd : b->pairs) pd.envBase = -1;
+    b->hasEnv = false;
+    if (b->nPairs) (void)hipMemcpy(b->d_pairs, b->pairs.data(), b->nPairs * sizeof(PairDesc), hipMemcpyHostToDevice);
+    set_error(msg);
+    return 1;
+  };
+  for (PairDesc &pd : b->pairs) pd.envBase = -1;
   for (long long p = 0; p < b->nPairs; ++p) {
     PairDesc &pd = b->pairs[p];
     const long long rows = envOff[p + 1] - envOff[p];
-    pd.envBase = -1;
     if (rows == 0) continue;   // full envelope
-    if (!inStart || !inEnd) { set_error("null argument"); return 1; }
-    if (rows != (long long)pd.outLen + 1) { set_error("Envelope/sequence mismatch"); return 1; }
+    if (!inStart || !inEnd) return fail("null argument");
+    if (rows != (long long)pd.outLen + 1) return fail("Envelope/sequence mismatch");
     const int32_t *st = inStart + envOff[p], *en = inEnd + envOff[p];
     for (long long y = 0; y < rows; ++y)
-      if (st[y] < 0 || en[y] > pd.inLen + 1 || st[y] > en[y]) { set_error("Envelope/sequence mismatch"); return 1; }
+      if (st[y] < 0 || en[y] > pd.inLen + 1 || st[y] > en[y]) return fail("Envelope/sequence mismatch");
     bool conn = env_overlapping(st[0], en[0], 0, 1);
     for (long long y = 1; conn && y < rows; ++y) conn = env_overlapping(st[y - 1], (long long)en[y - 1] + 1, st[y], en[y]);
     conn = conn && env_overlapping(st[rows - 1], en[rows - 1], pd.inLen, (long long)pd.inLen + 1);
-    if (!conn) { set_error("Envelope is not connected"); return 1; }
+    if (!conn) return fail("Envelope is not connected");
     pd.envBase = envOff[p] - envOff[0];
     b->hasEnv = true;
   }
