@@ -340,6 +340,10 @@ __global__ __launch_bounds__(1024) void k_medium_tile(MedProgDev P, MedTileArgs 
         const int j = tid + k * blockDim.x;
         if (j < S) hd[j] = hv[k];
       }
+      // a strip narrowed for short input sequences (medium_pick_geometry) may leave the workgroup with fewer than S / 4
+      // threads: the rest of the supercell is copied directly
+      const double *hs = A.materialise ? cellPtr(i0 - 1, t + 1) : haloIn + (long long)(t + 1) * S;
+      for (int j = tid + 4 * (int)blockDim.x; j < S; j += blockDim.x) hd[j] = hs[j];
     }
     // ---- copy the finished supercell out ----------------------------------------------------------------------
     const double *cur = (const double *)(ldsb + (myColBase + sCur));

@@ -1209,6 +1209,26 @@ def test_boss_cli_two_ranks_end_to_end(capi, tmp_path):
         port += 1
 
 
+@pytest.mark.parametrize("S,il,ol", [(300, 22, 39), (700, 27, 39), (257, 18, 59)])
+def test_ahead_of_time_tile_kernel_many_states(capi, oracle_mod, monkeypatch, S, il, ol):
+    """The interpreter kernel the tiled family falls back to without hiprtc (MB_MEDIUM_JIT=0), machines of more than 256
+    states on short input sequences: the strip is narrowed to a workgroup of fewer than S / 4 threads, which the halo
+    prefetch of that kernel did not cover (found by scripts/fuzz_gpu.py under MB_MEDIUM_JIT=0)."""
+    from randmachine import random_machine, random_seq
+    monkeypatch.setenv("MB_MEDIUM_JIT", "0")
+    em = random_machine(S, 2, 3, S + il, density=1.6, silent_density=0.8)
+    rng = np.random.RandomState(S)
+    x, y = random_seq(rng, il, 2), random_seq(rng, ol, 3)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    V = dm.fill(capi.MB_VITERBI, x, y); kern = capi.last_kernel_name()
+    F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
+    assert kern.startswith("k_medium_tile")
+    assert np.array_equal(V, om.viterbi(x, y))
+    assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y), (x[:5], y)])
+    assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT), om.loglike(x[:5], y, oracle_mod.SUM_EXACT)], FAST_REL, FAST_ABS)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_dry_run(capi, scaling):
     """`python bench.py --gpus 2` as typed (the parent spawns the ranks before touching the GPU): the N > 1 path of the bench
