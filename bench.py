@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+TRANSCENDENTAL_PEAK_T = 157.0 / 2 / 4   # v_exp_f32 / v_log_f32 per second (x 1e12): fp32 vector peak 157 TFLOP/s = 78.5 T lane-ops/s, transcendentals at quarter rate (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 8      # materialised Forward: one fp64 store per cell (w = 8)
 
 
@@ -304,6 +305,13 @@ def main():
         _, d1 = timed(lambda: batch.forward(other))
         extra["rolling_gcells_per_gpu" if other == capi.MB_ROLLING else "materialised_gcells_per_gpu"] = round(cells_rank / d1 / 1e9, 3)
         if other == capi.MB_ROLLING:
+            # the rolling mode is priced against the transcendental issue rate, not HBM
+            ops = capi.sweep_ops(dm)
+            tr = (ops["exp_per_cell"] + ops["log_per_cell"]) * cells_rank / d1
+            extra["rolling_rate"] = {"exp_per_cell": round(ops["exp_per_cell"], 3), "log_per_cell": round(ops["log_per_cell"], 3), "family": ops["family"],
+                                     "achieved_transcendental_per_s": round(tr / 1e12, 3), "peak": TRANSCENDENTAL_PEAK_T, "unit": "T v_exp/v_log per s",
+                                     "frac": round(tr / 1e12 / TRANSCENDENTAL_PEAK_T, 4),
+                                     "note": "quarter-rate fp32 transcendentals: 157 TFLOP/s fp32 / 2 / 4 (MI355X_MICROARCH.md); the sweep is bound by total vector issue (fp64 add / max at half rate), of which these are a part"}
             extra["rolling_note"] = "boss --loglike mode: no matrix in HBM, bound by vector instruction issue (fp64 add/max, v_exp_f32/v_log_f32), not by HBM; the HBM fraction is not meaningful for it"
 
     cpu = None

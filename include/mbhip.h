@@ -165,6 +165,10 @@ int mb_release_workspace(void);
 /* Run-time compilation (hiprtc) done by this process so far: wall-clock milliseconds, compiles, and code objects taken
  * from the on-disk cache instead ($MB_JIT_CACHE_DIR, default ~/.cache/mbhip; MB_JIT_CACHE=0 disables it). */
 int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits);
+/* Transcendental instructions the log-sum-exp Forward sweep of this machine issues per lattice CELL (v_exp_f32, v_log_f32,
+ * padding lanes of the kernel family included) -- what the rolling (log-likelihood-only) mode is priced against, since it
+ * moves no matrix through HBM.  family: name of the kernel family that would run the sweep. */
+int mb_machine_sweep_ops(mb_machine *m, double *expPerCell, double *logPerCell, const char **family);
 /* Tuning knobs (kernel family thresholds, strip geometry, closure stages ...: DESIGN.md section 4.4).  They are read when
  * a machine's programs and kernels are built, from the process environment; these calls are the same switchboard for a
  * host that prefers calls.  Names start with "MB_"; value NULL or "" restores the default. */

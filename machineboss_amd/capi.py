@@ -25,7 +25,7 @@ EXPORTS = [
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source",
-    "mb_jit_stats", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
+    "mb_jit_stats", "mb_machine_sweep_ops", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
@@ -86,6 +86,7 @@ def load():
     L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
     L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
     L.mb_jit_stats.argtypes = [dp, i64p, i64p]
+    L.mb_machine_sweep_ops.argtypes = [C.c_void_p, dp, dp, C.POINTER(C.c_char_p)]
     L.mb_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.mb_get_option.argtypes = [C.c_char_p]; L.mb_get_option.restype = C.c_char_p
     L.mb_comm_unique_id.argtypes = [C.c_char_p]
@@ -130,6 +131,13 @@ def jit_stats() -> dict:
     ms = C.c_double(0.0); n = C.c_int64(0); h = C.c_int64(0)
     _check(load().mb_jit_stats(C.byref(ms), C.byref(n), C.byref(h)))
     return {"compile_ms": round(ms.value, 1), "compiles": n.value, "cache_hits": h.value}
+
+
+def sweep_ops(dm) -> dict:
+    """v_exp_f32 / v_log_f32 per lattice cell of the machine's log-sum-exp Forward sweep, and the kernel family that runs it."""
+    e = C.c_double(0.0); l = C.c_double(0.0); f = C.c_char_p()
+    _check(load().mb_machine_sweep_ops(dm.h, C.byref(e), C.byref(l), C.byref(f)))
+    return {"exp_per_cell": e.value, "log_per_cell": l.value, "family": (f.value or b"").decode()}
 
 
 def set_option(name: str, value=None):

@@ -759,6 +759,33 @@ int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits) {
   return 0;
 }
 
+int mb_machine_sweep_ops(mb_machine *m, double *expPerCell, double *logPerCell, const char **family) {
+  ApiGuard guard;
+  if (!m) { set_error("null argument"); return 1; }
+  double ne = 0.0, nl = 0.0; const char *fam = "generic";
+  if (use_small(m)) {
+    // per supercell and lane: two candidates -> exp + log of the pair; three or more -> one exp each + one log
+    const SmallProgram &P = ((FastState *)m->fast)->smF;
+    for (int d = 0; d < P.S; ++d) { const size_t n = P.cand[d].size(); if (n == 2) { ne += 1; nl += 1; } else if (n > 2) { ne += (double)n; nl += 1; } }
+    ne /= m->S; nl /= m->S; fam = "small";
+  } else if (wide_applicable(m) && g_kernel_choice != 1) {
+    WideProgram *W = wide_program(m, MB_FORWARD);
+    if (!W) return 1;
+    ne = (double)W->slotsPerColumn * W->W / m->S; nl = (double)W->rounds.size() * W->W / m->S; fam = "one-tape";   // one exp per slot and lane (+ the group reduction), one log per round
+  } else if (use_medium(m)) {
+    const MedProgram &P = fast_state(m)->fwdSum;
+    double slots = 0.0, logs = 0.0;   // a round with one candidate slot is a plain add: no exp, no log
+    for (const MedRoundInfo &ri : P.roundInfo) if (ri.slots.size() > 1) { slots += (double)ri.slots.size(); logs += 1.0; }
+    ne = slots * P.LPG / m->S; nl = logs * P.LPG / m->S; fam = "tiled";
+  } else {
+    ne = (double)m->nTrans / m->S; nl = ne;   // generic family: log1p(exp()) per candidate, token-filtered at run time (upper bound)
+  }
+  if (expPerCell) *expPerCell = ne;
+  if (logPerCell) *logPerCell = nl;
+  if (family) *family = fam;
+  return 0;
+}
+
 // Tuning knobs are read from the environment when a machine's programs / kernels are built (DESIGN.md section 4.4 lists
 // them); this is the same switchboard for a host that prefers calls to environment variables.
 int mb_set_option(const char *name, const char *value) {
