@@ -173,6 +173,29 @@ def test_small_source_compiles_for_gfx950(tmp_path, machines):
         assert not [l for l in txt.splitlines() if l.startswith("\tflat_")]      # LDS / global accesses stay typed (no flat fallback)
 
 
+def test_small_count_kernel_lds_block_holds_its_tables(tmp_path):
+    """The per-wavefront LDS block of the count sweep (tokens, envelope rows, halo rows, lane-private usage rows, the
+    output-only usage sums) as the generated source lays it out fits the size the host reserves for it (JWAVEDBL): it was
+    one float short when (output-only tables) x (alphabet + 1) is even, and the last usage sum landed on the next
+    wavefront's first token (scripts/fuzz_env_gpu.py seed 5229)."""
+    import re
+    from machineboss_amd import capi
+    from randmachine import random_machine
+    checked = 0
+    for S, nIn, nOut, seed in ((12, 1, 1, 5229), (8, 2, 3, 11), (5, 3, 1, 12), (3, 1, 2, 13), (16, 2, 2, 14), (7, 1, 3, 15)):
+        em = random_machine(S, nIn, nOut, seed, density=2.0, silent_density=1.0)
+        src = str(tmp_path / ("c%d.hip" % seed))
+        try:
+            capi.debug_small_source(em, src, mode=3, materialise=False)
+        except capi.MbError:
+            continue
+        d = {k: int(v) for k, v in re.findall(r"#define (J[A-Z]+) (-?\d+)", open(src).read())}
+        floats = 64 * d["JROWF"] + (d["JROWF"] & 1) + d["JOUTACC"]      # rowL rows, then outAcc (started (JROWF & 1) floats further on)
+        assert 32 + 64 + 64 * d["JHP"] + (floats + 1) // 2 <= d["JWAVEDBL"], (S, nIn, nOut, d)
+        checked += 1
+    assert checked >= 4
+
+
 def test_small_rejects_what_it_cannot_run(machines):
     """Machines outside the family's envelope (too many states, one-tape) are refused by the generator, so the library
     falls back to the other families."""
