@@ -13,6 +13,8 @@
 
 namespace mb {
 
+static int env_int_g(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+
 // ---- DPMatrix::accumulate over `incoming` (src/dpmatrix.h:101-115) -----------------------------------------
 template <int MODE>
 __device__ __forceinline__ double fold_in(const DevMachine &m, double acc, int d, int it, int ot,
@@ -261,7 +263,10 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
 // candidates point at) instead of three dependent ones (CSR offsets -> edges -> cells).  With few states per supercell
 // (S <= 16) the 3 x 3 block of supercells around the position -- every cell the NEXT step can read -- is touched one
 // step ahead, so that trip mostly ends in the XCD's L2.  Candidate order, tie-break and results are those of k_traceback.
+// OFFLDS = false: the CSR offsets stay in global memory (large alphabets: psw2dna has 271 x 105 rows) while the edges -- what
+// the inner loop reads -- still come from LDS: two trips to memory per step (offsets, cells) instead of six.
 struct TbEdge { double w; uint32_t eid; uint16_t src; uint8_t hasIn, hasOut; };
+template <bool OFFLDS>
 __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairDesc *__restrict__ pairs, long long nPairs,
                                                        long long nTrans, const int *__restrict__ inTok, const int *__restrict__ outTok,
                                                        const double *__restrict__ pool, const long long *__restrict__ slotOff,
@@ -269,8 +274,8 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
   extern __shared__ unsigned char tb_raw[];
   const int nRows = m.S * m.K;
   int *lOff = (int *)tb_raw;                                                   // [nRows + 1]
-  TbEdge *lEdge = (TbEdge *)(tb_raw + (((size_t)(nRows + 1) * 4 + 15) & ~(size_t)15));   // [nTrans]
-  for (int r = threadIdx.x; r <= nRows; r += blockDim.x) lOff[r] = m.inOff[r];
+  TbEdge *lEdge = (TbEdge *)(tb_raw + (OFFLDS ? (((size_t)(nRows + 1) * 4 + 15) & ~(size_t)15) : 0));   // [nTrans]
+  if (OFFLDS) for (int r = threadIdx.x; r <= nRows; r += blockDim.x) lOff[r] = m.inOff[r];
   for (int a = threadIdx.x; a < nTrans; a += blockDim.x) {
     const uint32_t eid = m.inEid[a];
     TbEdge e; e.w = m.inW[a]; e.eid = eid; e.src = (uint16_t)m.inSrc[a]; e.hasIn = m.eInTok[eid] != 0; e.hasOut = m.eOutTok[eid] != 0;
@@ -293,8 +298,10 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
   const bool prefetch = 9 * S <= 128;
   double pfA = 0.0, pfB = 0.0;
   unsigned sink = 0;
+  // tokens one step ahead: the next position consumes in[i - 1] (held) or in[i - 2] (requested now), likewise the output
+  int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
   while (i > 0 || o > 0 || s != 0) {
-    const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+    const int itP = i > 1 ? in[i - 2] : 0, otP = o > 1 ? out[o - 2] : 0;
     const double *cur = cells + ((long long)o * I + i) * S;
     double best = -INFINITY; int bestIdx = 0x7fffffff; int bestA = -1;
     int base = 0;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
       else if (grp == 2) { if (!o) continue; kit = 0; kot = ot; sc = cur - I * S; }
       else { kit = 0; kot = 0; sc = cur; }
       const int row = (s * (m.nIn + 1) + kit) * (m.nOut + 1) + kot;
-      const int a0 = lOff[row], a1 = lOff[row + 1];
+      const int a0 = OFFLDS ? lOff[row] : m.inOff[row], a1 = OFFLDS ? lOff[row + 1] : m.inOff[row + 1];
       for (int a = a0 + lane; a < a1; a += 64) {
         const double v = sc[lEdge[a].src] + lEdge[a].w;
         const int idx = base + (a - a0);
@@ -338,12 +345,87 @@ __global__ __launch_bounds__(256) void k_traceback_lds(DevMachine m, const PairD
     if ((int)(n & 63) == lane) held = be.eid;   // one store per 64 steps, see k_traceback
     ++n;
     if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
-    if (be.hasIn) --i;
-    if (be.hasOut) --o;
+    if (be.hasIn) { --i; it = itP; }
+    if (be.hasOut) { --o; ot = otP; }
     s = (int)be.src;
   }
   if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
   if (lane == 0) pathLen[p] = (sink == 0x9e3779b9u && n < 0) ? -4 : n;   // `sink` keeps the touches alive; never true
+}
+
+// Machines with large alphabets (psw2dna: 271 states x 105 label keys = 28 455 CSR rows for 1 684 edges): the row offsets do
+// not fit LDS, but a state's incoming edges are CONTIGUOUS in the `incoming` view, sorted by label key.  The lanes scan the
+// state's whole edge range from LDS and keep the edges whose key is one of the four the position allows (match, input-only,
+// output-only, silent); (group, position) orders the candidates exactly as the reference enumerates them.  One trip to
+// memory per step (the cells), tokens one step ahead, path stored 64 edges at a time.
+struct TbEdgeK { double w; uint32_t eid; uint16_t src; uint16_t key; };
+__global__ __launch_bounds__(256) void k_traceback_scan(DevMachine m, const PairDesc *__restrict__ pairs, long long nPairs,
+                                                        long long nTrans, const int *__restrict__ inTok, const int *__restrict__ outTok,
+                                                        const double *__restrict__ pool, const long long *__restrict__ slotOff,
+                                                        uint32_t *__restrict__ pathBuf, long long *__restrict__ pathLen) {
+  extern __shared__ unsigned char tbs_raw[];
+  TbEdgeK *lEdge = (TbEdgeK *)tbs_raw;                                  // [nTrans]
+  int *sBeg = (int *)(tbs_raw + (size_t)nTrans * sizeof(TbEdgeK));      // [S + 1]: first incoming edge of each state
+  const int S = m.S, K = m.K, NO = m.nOut + 1;
+  for (int st = threadIdx.x; st <= S; st += blockDim.x) sBeg[st] = m.inOff[(long long)st * K];
+  for (int a = threadIdx.x; a < nTrans; a += blockDim.x) {
+    const uint32_t eid = m.inEid[a];
+    TbEdgeK e; e.w = m.inW[a]; e.eid = eid; e.src = (uint16_t)m.inSrc[a]; e.key = (uint16_t)((int)m.eInTok[eid] * NO + (int)m.eOutTok[eid]);
+    lEdge[a] = e;
+  }
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= nPairs) return;
+  const PairDesc pd = pairs[p];
+  const int inLen = pd.inLen, outLen = pd.outLen;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  const double *cells = pool + pd.cellBase;
+  const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  int i = inLen, o = outLen, s = S - 1;
+  if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
+  long long n = 0;
+  uint32_t held = 0;
+  int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+  while (i > 0 || o > 0 || s != 0) {
+    const int itP = i > 1 ? in[i - 2] : 0, otP = o > 1 ? out[o - 2] : 0;
+    const double *cur = cells + ((long long)o * I + i) * S;
+    const int kM = (i && o) ? it * NO + ot : -1, kI = i ? it * NO : -1, kO = o ? ot : -1;   // keys of the groups the position allows (silent: 0)
+    double best = -INFINITY; int bestIdx = 0x7fffffff; int bestA = -1;
+    const int b0 = sBeg[s], b1 = sBeg[s + 1];
+    for (int a = b0 + lane; a < b1; a += 64) {
+      const TbEdgeK e = lEdge[a];
+      const int key = (int)e.key;
+      int grp; const double *sc;
+      if (key == kM) { grp = 0; sc = cur - (I + 1) * S; }
+      else if (key == kI) { grp = 1; sc = cur - S; }
+      else if (key == kO) { grp = 2; sc = cur - I * S; }
+      else if (key == 0) { grp = 3; sc = cur; }
+      else continue;
+      const double v = sc[e.src] + e.w;
+      const int idx = (grp << 24) | (a - b0);
+      if (bestA < 0 || v > best || (v == best && idx < bestIdx)) { best = v; bestIdx = idx; bestA = a; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bestIdx, off), oa = __shfl_xor(bestA, off);
+      const bool take = oa >= 0 && (bestA < 0 || ov > best || (ov == best && oi < bestIdx));
+      if (take) { best = ov; bestIdx = oi; bestA = oa; }
+    }
+    if (bestA < 0) { if (lane == 0) pathLen[p] = -3; return; }
+    if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
+    const TbEdgeK be = lEdge[bestA];
+    if ((int)(n & 63) == lane) held = be.eid;   // one store per 64 steps, see k_traceback
+    ++n;
+    if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
+    const int bk = (int)be.key;
+    if (bk / NO) { --i; it = itP; }
+    if (bk % NO) { --o; ot = otP; }
+    s = (int)be.src;
+  }
+  if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
+  if (lane == 0) pathLen[p] = n;
 }
 
 // ---- launch helpers (host) -----------------------------------------------------------------------------------
@@ -422,8 +504,18 @@ int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPa
   static int useLds = -1;
   if (useLds < 0) { const char *e = getenv("MB_TRACEBACK_LDS"); useLds = (e && *e == '0') ? 0 : 1; }
   if (useLds && nRows <= 8192 && m->nTrans <= 2048 && m->S <= 65535 && ldsBytes <= 64 * 1024) {
-    hipLaunchKernelGGL(k_traceback_lds, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), ldsBytes, st, m->dev, d_pairs, nPairs,
+    hipLaunchKernelGGL(k_traceback_lds<true>, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), ldsBytes, st, m->dev, d_pairs, nPairs,
                        (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
+    return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
+  }
+  if (useLds && m->nTrans <= 3584 && m->S <= 8192 && m->K <= 65535 && env_int_g("MB_TRACEBACK_SCAN", 1)) {   // edges (<= 56 KB) + one offset per state
+    hipLaunchKernelGGL(k_traceback_scan, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), (size_t)m->nTrans * sizeof(TbEdgeK) + (size_t)(m->S + 1) * 4, st,
+                       m->dev, d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
+    return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
+  }
+  if (useLds && m->nTrans <= 3584 && m->S <= 65535) {   // edges only (<= 56 KB): the offsets are read from global memory
+    hipLaunchKernelGGL(k_traceback_lds<false>, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), (size_t)m->nTrans * sizeof(TbEdge), st, m->dev,
+                       d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
     return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
   }
   hipLaunchKernelGGL(k_traceback, dim3((unsigned)nPairs), dim3(64), 0, st, m->dev, d_pairs, d_in, d_out, d_pool, d_slotOff,
