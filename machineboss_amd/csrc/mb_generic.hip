@@ -212,8 +212,9 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
   if (!(cells[((long long)o * I + i) * S + s] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
   long long n = 0;
   uint32_t held = 0;
+  int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;   // tokens one step ahead, see k_traceback_scan
   while (i > 0 || o > 0 || s != 0) {
-    const int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+    const int itP = i > 1 ? in[i - 2] : 0, otP = o > 1 ? out[o - 2] : 0;
     const double *cur = cells + ((long long)o * I + i) * S;
     double best = -INFINITY; int bestIdx = 0x7fffffff; int bestA = -1;
     int base = 0;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(64) void k_traceback(DevMachine m, const PairDesc *
     if ((int)(n & 63) == lane) held = eid;
     ++n;
     if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
-    if (m.eInTok[eid]) --i;
-    if (m.eOutTok[eid]) --o;
+    if (m.eInTok[eid]) { --i; it = itP; }
+    if (m.eOutTok[eid]) { --o; ot = otP; }
     s = (int)m.inSrc[bestA];
   }
   if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
