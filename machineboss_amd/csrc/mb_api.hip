@@ -207,6 +207,14 @@ int launch_compact_paths(const uint32_t *, const long long *, const long long *,
 int launch_traceback(const mb_machine *, const PairDesc *, long long, const int *, const int *, const double *,
                      const long long *, uint32_t *, long long *, hipStream_t);
 
+// a second stream for work that is independent of what g_stream runs (created on first use; nullptr if that fails)
+static hipStream_t second_stream() {
+  static hipStream_t s2 = nullptr;
+  static bool tried = false;
+  if (!tried) { tried = true; if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) s2 = nullptr; }
+  return s2;
+}
+
 struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   bool ok = false;
@@ -1171,7 +1179,33 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       for (long long p = c.p0; p < c.p1; ++p)
         maxc = std::max(maxc, (long long)(b->pairs[p].inLen + 1) * (b->pairs[p].outLen + 1) * b->m->S);
       tm.start();
-      if ((rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;
+      // One-tape machine (one workgroup per sequence): the Backward and the Forward fill are independent and a batch of fewer
+      // sequences than CUs leaves most of the chip idle, so the two run side by side on two streams (64 sequences: 64 + 64
+      // CUs); the count kernel waits for both.
+      bool fwdDone = false;
+      if (!b->hasEnv && wide_applicable(b->m) && g_kernel_choice != 1 && env_int("MB_ONETAPE_CONCURRENT_FILLS", 1)) {
+        WideProgram *WB = wide_program(b->m, MB_BACKWARD), *WF = wide_program(b->m, MB_FORWARD);
+        hipStream_t s2 = second_stream();
+        if (!WB || !WF) { rc = 1; break; }
+        if (s2) {
+          const int *tape = b->m->nOut ? b->d_out : b->d_in;
+          hipEvent_t evStart = nullptr, evDone = nullptr;
+          bool ok = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess;
+          ok = ok && hipEventRecord(evStart, g_stream) == hipSuccess && hipStreamWaitEvent(s2, evStart, 0) == hipSuccess;   // s2 starts after what g_stream has queued (descriptors)
+          if (ok) {
+            rc = wide_fill(b->m, *WF, d_desc, np, tape, fwd, nullptr, s2);
+            if (!rc) rc = wide_fill(b->m, *WB, d_desc, np, tape, bwd, nullptr, g_stream);
+            ok = hipEventRecord(evDone, s2) == hipSuccess && hipStreamWaitEvent(g_stream, evDone, 0) == hipSuccess;
+          }
+          if (evStart) (void)hipEventDestroy(evStart);
+          if (evDone) (void)hipEventDestroy(evDone);
+          if (!ok) { set_error("one-tape counts: stream synchronisation failed"); rc = 1; }
+          if (rc) break;
+          fwdDone = true;
+          g_last_kernel = WF->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";
+        }
+      }
+      if (!fwdDone && (rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;
       // fused path: the Forward sweep accumulates the counts while its anti-diagonals are still in LDS
       int fused = -1;
       if (use_medium(b->m) && fast_state(b->m)->countOk && !(b->hasEnv && wide_applicable(b->m))) {
@@ -1186,7 +1220,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
         if (fused == 0) g_last_kernel = "k_medium_jit";
       }
       if (fused < 0) {
-        if ((rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0, b))) break;
+        if (!fwdDone && (rc = fill_chunk(b->m, MB_FORWARD, d_desc, hp, b->d_in, b->d_out, fwd, 0, b))) break;
         if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
         // one-tape machines: a lane owns a transition and walks the columns (mb_wide.hip); two tapes: one thread per cell
         const bool oneTape = ((b->m->nIn != 0) != (b->m->nOut != 0)) && g_kernel_choice != 1 && env_int("MB_ONETAPE_COUNTS", 1);
