@@ -215,6 +215,15 @@ static hipStream_t second_stream() {
   return s2;
 }
 
+static int device_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  return cus;
+}
+
 struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   bool ok = false;
@@ -985,8 +994,51 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       ((flags & MB_ROLLING) || (size_t)b->totalCells * 8 > budget_bytes())) {
     // one-tape machine, log-likelihood only: the two live columns of every sequence stay in LDS, nothing goes to HBM
     WideProgram *W = wide_program(m, MB_FORWARD);
+    // Fewer sequences than half the CUs (one workgroup per sequence): every sequence is CUT IN TWO -- Forward over the prefix
+    // and Backward over the suffix behind the cut run side by side on two streams, k_onetape_join sums over the emitting
+    // transitions that cross the cut.  Same likelihood (a different summation order: ~1e-12 relative), half the sweep length.
+    int minLen = 1 << 30;
+    for (const PairDesc &pd : b->pairs) minLen = std::min(minLen, m->nOut ? pd.outLen : pd.inLen);
+    const bool split = W && env_int("MB_ONETAPE_SPLIT", 1) && 2 * b->nPairs <= device_cus() && minLen >= env_int("MB_ONETAPE_SPLIT_MIN_LEN", 64) && second_stream();
     if (!W) rc = 1;
-    else {
+    else if (split) {
+      WideProgram *WB = wide_program(m, MB_BACKWARD);
+      const long long n = b->nPairs, S = m->S;
+      std::vector<PairDesc> pre(b->pairs), suf(b->pairs);
+      for (long long p = 0; p < n; ++p) {
+        const int L = m->nOut ? b->pairs[p].outLen : b->pairs[p].inLen, mid = L / 2;
+        pre[p].cellBase = suf[p].cellBase = p * S;
+        if (m->nOut) { pre[p].outLen = mid; suf[p].outBase += mid + 1; suf[p].outLen = L - mid - 1; }
+        else { pre[p].inLen = mid; suf[p].inBase += mid + 1; suf[p].inLen = L - mid - 1; }
+      }
+      PairDesc *d_pre = nullptr, *d_suf = nullptr;
+      double *vec = nullptr;
+      hipEvent_t evStart = nullptr, evDone = nullptr;
+      do {
+        if (!WB) { rc = 1; break; }
+        if (!hip_ok(sm_alloc((void **)&d_pre, n * sizeof(PairDesc)), "hipMalloc") || !hip_ok(sm_alloc((void **)&d_suf, n * sizeof(PairDesc)), "hipMalloc")) { rc = 1; break; }
+        if (!(vec = (double *)ws_get(2, (size_t)(2 * n * S) * sizeof(double)))) { rc = 1; break; }
+        if (!hip_ok(hipMemcpyAsync(d_pre, pre.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream), "H2D") ||
+            !hip_ok(hipMemcpyAsync(d_suf, suf.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream), "H2D") ||
+            !hip_ok(hipStreamSynchronize(g_stream), "H2D")) { rc = 1; break; }   // (pre / suf are pageable host vectors)
+        const int *tape = m->nOut ? b->d_out : b->d_in;
+        hipStream_t s2 = second_stream();
+        tm.start();
+        if (hipEventCreateWithFlags(&evStart, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDone, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(evStart, g_stream) != hipSuccess || hipStreamWaitEvent(s2, evStart, 0) != hipSuccess) { set_error("one-tape split: stream set-up failed"); rc = 1; break; }
+        if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true))) break;
+        if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true))) break;
+        if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
+        if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
+        g_last_kernel = W->f32 ? "k_wide_sum32 x2 + k_onetape_join" : "k_wide_sweep<0> x2 + k_onetape_join";
+        g_last_ms += tm.stop();
+        if (!hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernels")) rc = 1;
+      } while (0);
+      if (rc) { (void)hipStreamSynchronize(g_stream); (void)hipStreamSynchronize(second_stream()); }
+      if (evStart) (void)hipEventDestroy(evStart);
+      if (evDone) (void)hipEventDestroy(evDone);
+      sm_free(d_pre); sm_free(d_suf);
+    } else {
       tm.start();
       rc = wide_fill(m, *W, b->d_pairs, b->nPairs, m->nOut ? b->d_out : b->d_in, nullptr, d_ll, g_stream);
       g_last_kernel = W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";

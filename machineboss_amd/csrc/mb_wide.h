@@ -39,6 +39,7 @@ struct WideDev {
   int resultIdx;       // state whose value in the last column is the log-likelihood
   int backward;
   int inputTape;       // 1: the machine is a recogniser, the column index is the input position
+  int lastOnly;        // 1: `pool` holds ONE column per pair (cellBase = its offset): only the last column of the sweep is stored
 };
 
 // Forward / Backward (log-sum-exp) run in single precision RELATIVE TO A PER-COLUMN fp64 REFERENCE: a column's vector
@@ -56,6 +57,7 @@ struct WideDev32 {
   int S, NV, NX, W;
   int resultIdx, backward;
   int inputTape;
+  int lastOnly;
 };
 
 struct WideProgram {
@@ -92,6 +94,10 @@ void wide_free(WideProgram &P);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
+              double *loglike, hipStream_t st, bool lastOnly = false);
+// log-likelihood of a sequence cut at position `mid` = inLen or outLen / 2: Forward column of the prefix x emitting transitions
+// labelled with the token at the cut x Backward column of the suffix behind it (every path crosses the cut exactly once)
+int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *fvec, const double *bvec,
               double *loglike, hipStream_t st);
 
 

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
       }
     }
     // the last round of a column always synchronises: the column is complete here
-    if (cells) {
-      double *col = cells + (long long)o * S;
+    if (cells && (!P.lastOnly || c == outLen)) {
+      double *col = P.lastOnly ? cells : cells + (long long)o * S;
       for (int k = tid; k < S; k += W) col[k] = V[curOff + k];
     }
     if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent (this vector is the next column's `cur`)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
     float M = -INFINITY;
     for (int w = 0; w < (W >> 6); ++w) M = fmaxf(M, wmax[w]);
     if (!(M > -INFINITY)) M = 0.0f;
-    double *col = cells ? cells + (long long)o * S : nullptr;
+    double *col = (cells && (!P.lastOnly || c == outLen)) ? (P.lastOnly ? cells : cells + (long long)o * S) : nullptr;
     for (int k = tid; k < S; k += W) {
       const float y = V[curOff + k];
       if (col) col[k] = R + (double)y;
@@ -809,69 +809,112 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
 
 template <int MODE, bool GV, bool FAST>
 static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
-                       double *scratch, hipStream_t st) {
+                       double *scratch, hipStream_t st, bool lastOnly) {
   const size_t lds = GV ? 0 : P.vecBytes();
   static bool attr = false;     // one flag per instantiation
   if (!GV && !attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_sweep<MODE, GV, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
     attr = true;
   }
-  hipLaunchKernelGGL((k_wide_sweep<MODE, GV, FAST>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev, d_desc, d_out, pool, loglike, scratch);
+  WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+  hipLaunchKernelGGL((k_wide_sweep<MODE, GV, FAST>), dim3((unsigned)nPairs), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch);
   MB_HIP(hipGetLastError());
   return 0;
 }
 
 template <bool GV, bool HYB>
 static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
-                         float *scratch, hipStream_t st) {
+                         float *scratch, hipStream_t st, bool lastOnly) {
   const size_t lds = GV ? 0 : (HYB ? (size_t)(P.NV + P.NX) * sizeof(float) : P.vecBytes32());
   static bool attr = false;
   if (!GV && !attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_sum32<GV, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX - 64));
     attr = true;
   }
-  hipLaunchKernelGGL((k_wide_sum32<GV, HYB>), dim3((unsigned)nPairs), dim3(P.W), lds, st, P.dev32, d_desc, d_out, pool, loglike, scratch);
+  WideDev32 dev = P.dev32; dev.lastOnly = lastOnly ? 1 : 0;
+  hipLaunchKernelGGL((k_wide_sum32<GV, HYB>), dim3((unsigned)nPairs), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch);
   MB_HIP(hipGetLastError());
   return 0;
 }
 
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
-              double *loglike, hipStream_t st) {
+              double *loglike, hipStream_t st, bool lastOnly) {
   (void)m;
   const int *d_out = d_tape;       // the token array of the machine's one tape (outputs of a generator, inputs of a recogniser)
   if (!P.ok) { set_error("wide program not built"); return 1; }
   if (nPairs <= 0) return 0;
+  // L2-resident column vectors of the kernels whose columns do not fit the LDS: from the library's workspaces (one slot per
+  // sweep direction, so that a Forward and a Backward sweep may run side by side on two streams); nothing here waits for
+  // the device
+  const int scratchSlot = P.backward ? 12 : 11;
   if (P.f32) {
     const bool gv32 = !P.hyb && (P.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0));
     float *scr = nullptr;
-    if (gv32) MB_HIP(hipMalloc((void **)&scr, (size_t)nPairs * P.vecBytes32()));
-    if (P.hyb) MB_HIP(hipMalloc((void **)&scr, (size_t)nPairs * P.NV * sizeof(float)));
-    int rc32 = P.hyb ? launch_wide32<false, true>(P, d_desc, nPairs, d_out, pool, loglike, scr, st)
-                     : (gv32 ? launch_wide32<true, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st)
-                             : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st));
+    if (gv32 && !(scr = (float *)ws_get(scratchSlot, (size_t)nPairs * P.vecBytes32()))) return 1;
+    if (P.hyb && !(scr = (float *)ws_get(scratchSlot, (size_t)nPairs * P.NV * sizeof(float)))) return 1;
+    const int rc32 = P.hyb ? launch_wide32<false, true>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly)
+                           : (gv32 ? launch_wide32<true, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly)
+                                   : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly));
     g_last_launches += 1;
-    if (gv32 || P.hyb) {
-      if (!rc32 && !hip_ok(hipStreamSynchronize(st), "wide sweep")) rc32 = 1;
-      (void)hipFree(scr);
-    }
     return rc32;
   }
   const bool gv = P.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0);
   double *scratch = nullptr;
-  if (gv) MB_HIP(hipMalloc((void **)&scratch, (size_t)nPairs * P.vecBytes()));
+  if (gv && !(scratch = (double *)ws_get(scratchSlot, (size_t)nPairs * P.vecBytes()))) return 1;
   int rc;
-#define WIDE_GO(M, G, F) launch_wide<M, G, F>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st)
+#define WIDE_GO(M, G, F) launch_wide<M, G, F>(P, d_desc, nPairs, d_out, pool, loglike, scratch, st, lastOnly)
   if (P.viterbi) rc = gv ? (P.fastIdx ? WIDE_GO(MB_VITERBI, true, true) : WIDE_GO(MB_VITERBI, true, false))
                          : (P.fastIdx ? WIDE_GO(MB_VITERBI, false, true) : WIDE_GO(MB_VITERBI, false, false));
   else rc = gv ? (P.fastIdx ? WIDE_GO(MB_FORWARD, true, true) : WIDE_GO(MB_FORWARD, true, false))
                : (P.fastIdx ? WIDE_GO(MB_FORWARD, false, true) : WIDE_GO(MB_FORWARD, false, false));
 #undef WIDE_GO
   g_last_launches += 1;
-  if (gv) {
-    if (!rc && !hip_ok(hipStreamSynchronize(st), "wide sweep")) rc = 1;
-    (void)hipFree(scratch);
-  }
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// a sequence cut in two: Forward over the prefix and Backward over the suffix run side by side, joined here
+// ------------------------------------------------------------------------------------------------------------
+// P(sequence) = sum over the EMITTING transitions (s -> s', label = the token at the cut) of F_cut(s) w B_behind(s'): every
+// path crosses the boundary between two columns exactly once (a sum over states of one column would count a path once per
+// state it visits there through silent moves).  One workgroup per sequence, exact fp64 log / exp.
+__global__ __launch_bounds__(256) void k_onetape_join(DevMachine m, const PairDesc *__restrict__ pairs, int inputTape, const int *__restrict__ tape,
+                                                      const double *__restrict__ fvec, const double *__restrict__ bvec, double *__restrict__ loglike) {
+  __shared__ double red[256];
+  const long long p = blockIdx.x;
+  const PairDesc pd = pairs[p];
+  const int L = inputTape ? pd.inLen : pd.outLen, S = m.S, mid = L / 2;
+  const int y = tape[(inputTape ? pd.inBase : pd.outBase) + mid];   // (the key of a one-tape label is the token itself)
+  const double *F = fvec + p * (long long)S, *B = bvec + p * (long long)S;
+  double mx = -INFINITY;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const double f = F[s];
+    const int row = s * m.K + y;
+    for (int a = m.outOff[row]; a < m.outOff[row + 1]; ++a) mx = fmax(mx, f + (m.outW[a] + B[m.outDst[a]]));
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + h]); __syncthreads(); }
+  mx = red[0];
+  __syncthreads();
+  double sum = 0.0;
+  if (mx > -INFINITY)
+    for (int s = threadIdx.x; s < S; s += 256) {
+      const double f = F[s];
+      const int row = s * m.K + y;
+      for (int a = m.outOff[row]; a < m.outOff[row + 1]; ++a) sum += exp(f + (m.outW[a] + B[m.outDst[a]]) - mx);
+    }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
+  if (threadIdx.x == 0) loglike[p] = mx > -INFINITY ? mx + log(red[0]) : -INFINITY;
+}
+
+int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *fvec, const double *bvec,
+              double *loglike, hipStream_t st) {
+  if (nPairs <= 0) return 0;
+  hipLaunchKernelGGL(k_onetape_join, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, d_pairs, m->nIn != 0 ? 1 : 0, d_tape, fvec, bvec, loglike);
+  return hip_ok(hipGetLastError(), "one-tape join launch") ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -30,8 +30,10 @@ for c in range(cases):
     dm = capi.DeviceMachine(em); om = oracle.OracleMachine(em)
     n = int(rng.randint(1, 6))
     scale = 6 if (c % 7 == 3 and S <= 100) or (c % 2 == 1 and S <= 16) else 1   # longer lattices (several tiles / strips) on the smaller machines
-    pairs = [(random_seq(rng, int(rng.randint(0, 40 * scale)) if nIn else 0, nIn), random_seq(rng, int(rng.randint(0, 60 * scale)) if nOut else 0, nOut)) for _ in range(n)]
+    lo = 64 if oneTape and c % 4 == 2 else 0            # one-tape batches of sequences >= 64 symbols are cut in two (k_onetape_join)
+    pairs = [(random_seq(rng, int(rng.randint(lo, lo + 40 * scale)) if nIn else 0, nIn), random_seq(rng, int(rng.randint(lo, lo + 60 * scale)) if nOut else 0, nOut)) for _ in range(n)]
     b = capi.DeviceBatch.from_pairs(dm, pairs)
+    cut = oneTape and min(max(len(x), len(y)) for x, y in pairs) >= 64      # the library cuts such batches in two
     out = {}
     for fam in (capi.KERNEL_AUTO, capi.KERNEL_GENERIC):
         capi.set_kernel(fam)
@@ -46,7 +48,7 @@ for c in range(cases):
     Vo = om.viterbi(x, y)
     checks = dict(V=np.array_equal(a["V"], g["V"]) and np.array_equal(a["V"], Vo),
                   F=close(a["F"], g["F"], 2e-6, 2e-5) and close(a["F"], om.forward(x, y, oracle.SUM_EXACT), 2e-6, 2e-5),
-                  B=close(a["B"], g["B"], 2e-6, 2e-5), ll=close(a["ll"], g["ll"], 2e-6, 2e-5) and close(a["ll"], a["llm"], 1e-9, 1e-12),
+                  B=close(a["B"], g["B"], 2e-6, 2e-5), ll=close(a["ll"], g["ll"], 2e-6, 2e-5) and close(a["ll"], a["llm"], 2e-6 if cut else 1e-9, 2e-5 if cut else 1e-12),   # (sequences cut in two: another summation order)
                   vit=np.array_equal(a["vit"][0], g["vit"][0]) and np.array_equal(a["vit"][1], g["vit"][1]) and np.array_equal(a["vit"][2], g["vit"][2]),
                   cnt=close(a["cnt"][0], g["cnt"][0], 1e-4, 1e-6))
     if Vo[-1, -1, -1] > -math.inf:

@@ -1012,6 +1012,49 @@ def test_one_tape_count_kernel(capi, oracle_mod, monkeypatch):
     assert ref.any() and close(cr, ref, 1e-5, 1e-7)
 
 
+def test_one_tape_split_forward(capi, oracle_mod, monkeypatch):
+    """Few sequences on a one-tape machine: the log-likelihood-only Forward cuts every sequence in two (Forward over the prefix,
+    Backward over the suffix, side by side; k_onetape_join sums over the emitting transitions that cross the cut) -- against
+    the plain sweep, the materialised fill and the oracle; generator and recogniser; fp64 and fp32-relative kernels."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    m, em = _profile_machine(3)
+    om = oracle_mod.OracleMachine(em)
+    rng = np.random.RandomState(5)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (64, 151, 400, 65)]
+    ref = [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys[:2]]
+    for fp32 in ("0", "1"):
+        monkeypatch.setenv("MB_WIDE_FP32", fp32)
+        dm = capi.DeviceMachine(em)
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+        ll = b.forward(capi.MB_ROLLING)
+        assert "k_onetape_join" in capi.last_kernel_name()
+        monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
+        ll0 = b.forward(capi.MB_ROLLING)
+        assert "join" not in capi.last_kernel_name()
+        monkeypatch.delenv("MB_ONETAPE_SPLIT")
+        llm = b.forward(capi.MB_MATERIALISE)
+        assert close(ll, ll0, FAST_REL, FAST_ABS) and close(ll, llm, FAST_REL, FAST_ABS)   # the fp32 correction terms fall differently in the two halves
+        assert close(ll[:2], ref, FAST_REL, FAST_ABS)
+        # a sequence shorter than the threshold keeps the whole batch on the plain sweep
+        b2 = capi.DeviceBatch.from_pairs(dm, [(x, ys[0]), (x, ys[0][:10])])
+        b2.forward(capi.MB_ROLLING)
+        assert "join" not in capi.last_kernel_name()
+    monkeypatch.delenv("MB_WIDE_FP32")
+    # recogniser: a ring of 300 states reading a/b, exits every fifth state
+    states = [{"id": "s%d" % k, "trans": [{"to": "s%d" % ((k + 1) % 300), "in": "ab"[k % 2], "weight": 0.5},
+                                          {"to": "s%d" % ((k + 7) % 300), "in": "ab"[(k + 1) % 2], "weight": 0.25}] +
+               ([{"to": "end", "weight": 0.25}] if k % 5 == 0 else [])} for k in range(300)] + [{"id": "end"}]
+    er = EvaluatedMachine.fromMachine(Machine.fromJson({"state": states}), {})
+    orr = oracle_mod.OracleMachine(er); dr = capi.DeviceMachine(er)
+    xs = [rng.randint(1, 3, size=n).astype(np.int32) for n in (200, 75, 130)]
+    br = capi.DeviceBatch.from_pairs(dr, [(xx, np.zeros(0, np.int32)) for xx in xs])
+    llr = br.forward(capi.MB_ROLLING)
+    assert "k_onetape_join" in capi.last_kernel_name()
+    assert close(llr, [orr.loglike(xx, np.zeros(0, np.int32), oracle_mod.SUM_EXACT) for xx in xs], FAST_REL, FAST_ABS)
+
+
 @pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])
 def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, nodes, nSeq, L):
     """BASELINE config 5 at the sizes that select the one-tape family's DEFAULT paths (no environment forcing): the 20-node
@@ -1029,11 +1072,11 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     llr = b.forward(capi.MB_ROLLING)
     kern = capi.last_kernel_name()
-    assert kern == ("k_wide_sweep<0>" if nodes == 20 else "k_wide_sum32")
+    assert kern.startswith("k_wide_sweep<0>" if nodes == 20 else "k_wide_sum32")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
     nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
     bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
     llm = bm.forward(capi.MB_MATERIALISE)
-    assert np.all(np.isfinite(llr)) and close(llm, llr[:nm], 1e-9) and llr[0] == llr[1]
+    assert np.all(np.isfinite(llr)) and close(llm, llr[:nm], FAST_REL, FAST_ABS) and llr[0] == llr[1]
     # the other arithmetic (fp32-relative <-> fp64 columns) on a fresh machine object
     monkeypatch.setenv("MB_WIDE_FP32", "1" if nodes == 20 else "0")             # (fp64 columns of the whole profile do not fit the LDS: they go to L2 by themselves)
     dm2 = capi.DeviceMachine(em)
@@ -1165,7 +1208,9 @@ def test_one_tape_family_long_sequences(capi, monkeypatch, fp32):
             capi.set_kernel(capi.KERNEL_AUTO)
         assert kern.startswith("k_generic") == (fam == capi.KERNEL_GENERIC)
     a, g = res[capi.KERNEL_AUTO], res[capi.KERNEL_GENERIC]
-    assert close(a[0], g[0], 1e-6) and close(a[1], g[1], 1e-6) and close(a[0], a[1], 1e-9, 1e-12)
+    assert close(a[0], g[0], 1e-6) and close(a[1], g[1], 1e-6) and close(a[0], a[1], FAST_REL, FAST_ABS)   # rolling: the three sequences are cut in two (k_onetape_join)
+    monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
+    assert close(b.forward(capi.MB_ROLLING), a[1], 1e-9, 1e-12)                                            # the plain rolling sweep is the materialised one without the stores
     assert np.array_equal(a[2][0], g[2][0]) and np.array_equal(a[2][1], g[2][1]) and np.array_equal(a[2][2], g[2][2])
 
 
