@@ -1026,9 +1026,13 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
         tm.start();
         if (hipEventCreateWithFlags(&evStart, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDone, hipEventDisableTiming) != hipSuccess ||
             hipEventRecord(evStart, g_stream) != hipSuccess || hipStreamWaitEvent(s2, evStart, 0) != hipSuccess) { set_error("one-tape split: stream set-up failed"); rc = 1; break; }
-        if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true))) break;
-        if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true))) break;
-        if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
+        const int fusedFill = wide_fill2(m, *W, *WB, d_pre, d_suf, n, n, tape, vec, vec + n * S, g_stream, true);   // both sweeps in ONE launch
+        if (fusedFill > 0) { rc = 1; break; }
+        if (fusedFill < 0) {                        // (programs of different kernel variants: two launches on two streams)
+          if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true))) break;
+          if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true))) break;
+          if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
+        }
         if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
         g_last_kernel = W->f32 ? "k_wide_sum32 x2 + k_onetape_join" : "k_wide_sweep<0> x2 + k_onetape_join";
         g_last_ms += tm.stop();
@@ -1239,7 +1243,10 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
         WideProgram *WB = wide_program(b->m, MB_BACKWARD), *WF = wide_program(b->m, MB_FORWARD);
         hipStream_t s2 = second_stream();
         if (!WB || !WF) { rc = 1; break; }
-        if (s2) {
+        const int fusedFill = wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch
+        if (fusedFill > 0) { rc = 1; break; }
+        if (fusedFill == 0) { fwdDone = true; g_last_kernel = WF->f32 ? "k_wide_sum32" : "k_wide_sweep<0>"; }
+        else if (s2) {                              // (programs of different kernel variants: two launches on two streams)
           const int *tape = b->m->nOut ? b->d_out : b->d_in;
           hipEvent_t evStart = nullptr, evDone = nullptr;
           bool ok = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess;

@@ -60,6 +60,9 @@ struct WideDev32 {
   int lastOnly;
 };
 
+// a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
+struct WideSecond { unsigned nFirst; const PairDesc *pairs; double *pool; void *scratch; };
+
 struct WideProgram {
   bool ok = false, dirty = true;
   bool backward = false, viterbi = false;
@@ -95,6 +98,11 @@ void wide_free(WideProgram &P);
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly = false);
+// Two sweeps (e.g. Forward over one set of pairs, Backward over another) in ONE launch: workgroups 0..nA-1 run program A,
+// the rest program B, so both are on the chip together whatever the queue scheduler does with two streams.  Returns -1
+// (nothing launched) when the two programs do not share a kernel variant.
+int wide_fill2(const mb_machine *m, WideProgram &A, WideProgram &B, const PairDesc *d_descA, const PairDesc *d_descB, long long nA, long long nB,
+               const int *d_tape, double *poolA, double *poolB, hipStream_t st, bool lastOnly);
 // log-likelihood of a sequence cut at position `mid` = inLen or outLen / 2: Forward column of the prefix x emitting transitions
 // labelled with the token at the cut x Backward column of the suffix behind it (every path crosses the cut exactly once)
 int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *fvec, const double *bvec,

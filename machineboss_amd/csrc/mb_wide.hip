@@ -97,13 +97,20 @@ __device__ __forceinline__ void wide_group_reduce(double &m, float &s, int g, in
 // FAST: all vector entries of a workgroup are addressable with 16 bits, and a record carries the source index for both
 // parities of the column (the two state vectors swap roles every column): src = index(even column) | index(odd) << 16.
 template <int MODE, bool GV, bool FAST>
-__global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
-                                                     double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
+__global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc *__restrict__ pairs1, const int *__restrict__ outTok,
+                                                     double *__restrict__ pool1, double *__restrict__ loglike1, double *__restrict__ scratch1,
+                                                     WideDev P2, WideSecond X) {
   extern __shared__ double wlds[];
-  const PairDesc pd = pairs[blockIdx.x];
+  // a fused launch runs a second sweep (another program, other pairs) in the workgroups from X.nFirst on
+  const bool second = blockIdx.x >= X.nFirst;
+  const WideDev P = second ? P2 : P1;
+  const PairDesc *pairs = second ? X.pairs : pairs1;
+  double *pool = second ? X.pool : pool1, *loglike = second ? nullptr : loglike1, *scratch = second ? (double *)X.scratch : scratch1;
+  const unsigned bid = blockIdx.x - (second ? X.nFirst : 0u);
+  const PairDesc pd = pairs[bid];
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
   const int outLen = P.inputTape ? pd.inLen : pd.outLen, nA = P.nA, n = P.nA + P.nB;   // the one tape the machine has
-  double *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wlds;
+  double *V = GV ? scratch + (size_t)bid * (size_t)(2 * NV + P.NX) : wlds;
   for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
   __syncthreads();
   if (tid == 0) V[S + 1] = 0.0;                     // the seed, read by the first column only
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P, const PairDesc *
     if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent (this vector is the next column's `cur`)
     const int t = prevOff; prevOff = curOff; curOff = t;
   }
-  if (loglike && tid == 0) loglike[blockIdx.x] = V[prevOff + P.resultIdx];
+  if (loglike && tid == 0) loglike[bid] = V[prevOff + P.resultIdx];
 }
 
 // ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
@@ -208,15 +215,22 @@ __device__ __forceinline__ void wide_group_reduce32(float &m, float &s, int g, i
 // for machines whose two columns do not fit the LDS even in single precision (the whole fn3 composition: 21 761 states).
 // Only the emitting rounds read the previous column (slot flag WIDE_F_PREV, uniform), the column epilogue writes it.
 template <bool GV, bool HYB>
-__global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
-                                                     double *__restrict__ pool, double *__restrict__ loglike, float *__restrict__ scratch) {
+__global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P1, const PairDesc *__restrict__ pairs1, const int *__restrict__ outTok,
+                                                     double *__restrict__ pool1, double *__restrict__ loglike1, float *__restrict__ scratch1,
+                                                     WideDev32 P2, WideSecond X) {
   extern __shared__ float wldsf[];
   __shared__ float wmax[16];
-  const PairDesc pd = pairs[blockIdx.x];
+  const bool second = blockIdx.x >= X.nFirst;     // fused launch: see k_wide_sweep
+  const WideDev32 P = second ? P2 : P1;
+  const PairDesc *pairs = second ? X.pairs : pairs1;
+  double *pool = second ? X.pool : pool1, *loglike = second ? nullptr : loglike1;
+  float *scratch = second ? (float *)X.scratch : scratch1;
+  const unsigned bid = blockIdx.x - (second ? X.nFirst : 0u);
+  const PairDesc pd = pairs[bid];
   const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
   const int outLen = P.inputTape ? pd.inLen : pd.outLen, nA = P.nA, n = P.nA + P.nB;   // the one tape the machine has
-  float *V = GV ? scratch + (size_t)blockIdx.x * (size_t)(2 * NV + P.NX) : wldsf;
-  float *Pg = HYB ? scratch + (size_t)blockIdx.x * (size_t)NV : nullptr;
+  float *V = GV ? scratch + (size_t)bid * (size_t)(2 * NV + P.NX) : wldsf;
+  float *Pg = HYB ? scratch + (size_t)bid * (size_t)NV : nullptr;
   for (int k = tid; k < (HYB ? NV + P.NX : 2 * NV + P.NX); k += W) V[k] = -INFINITY;
   if (HYB) for (int k = tid; k < NV; k += W) Pg[k] = -INFINITY;
   __syncthreads();
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P, const PairDesc
     for (int k = tid; k < S; k += W) {
       const float y = V[curOff + k];
       if (col) col[k] = R + (double)y;
-      if (c == outLen && k == P.resultIdx && loglike) loglike[blockIdx.x] = R + (double)y;   // the same rounding as the stored cell
+      if (c == outLen && k == P.resultIdx && loglike) loglike[bid] = R + (double)y;   // the same rounding as the stored cell
       if (HYB) Pg[k] = y - M; else V[curOff + k] = y - M;
     }
     R += (double)M;
@@ -809,30 +823,37 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
 
 template <int MODE, bool GV, bool FAST>
 static int launch_wide(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
-                       double *scratch, hipStream_t st, bool lastOnly) {
-  const size_t lds = GV ? 0 : P.vecBytes();
+                       double *scratch, hipStream_t st, bool lastOnly, const WideProgram *P2 = nullptr, const PairDesc *d_desc2 = nullptr,
+                       long long nPairs2 = 0, double *pool2 = nullptr, double *scratch2 = nullptr) {
+  const size_t lds = GV ? 0 : std::max(P.vecBytes(), P2 ? P2->vecBytes() : (size_t)0);
   static bool attr = false;     // one flag per instantiation
   if (!GV && !attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_sweep<MODE, GV, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
     attr = true;
   }
   WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
-  hipLaunchKernelGGL((k_wide_sweep<MODE, GV, FAST>), dim3((unsigned)nPairs), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch);
+  WideDev dev2 = P2 ? P2->dev : P.dev; dev2.lastOnly = dev.lastOnly;
+  const WideSecond X{P2 ? (unsigned)nPairs : 0xFFFFFFFFu, d_desc2, pool2, scratch2};
+  hipLaunchKernelGGL((k_wide_sweep<MODE, GV, FAST>), dim3((unsigned)(nPairs + nPairs2)), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch, dev2, X);
   MB_HIP(hipGetLastError());
   return 0;
 }
 
 template <bool GV, bool HYB>
 static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_out, double *pool, double *loglike,
-                         float *scratch, hipStream_t st, bool lastOnly) {
-  const size_t lds = GV ? 0 : (HYB ? (size_t)(P.NV + P.NX) * sizeof(float) : P.vecBytes32());
+                         float *scratch, hipStream_t st, bool lastOnly, const WideProgram *P2 = nullptr, const PairDesc *d_desc2 = nullptr,
+                         long long nPairs2 = 0, double *pool2 = nullptr, float *scratch2 = nullptr) {
+  auto ldsOf = [](const WideProgram &Q) { return HYB ? (size_t)(Q.NV + Q.NX) * sizeof(float) : Q.vecBytes32(); };
+  const size_t lds = GV ? 0 : std::max(ldsOf(P), P2 ? ldsOf(*P2) : (size_t)0);
   static bool attr = false;
   if (!GV && !attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_sum32<GV, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX - 64));
     attr = true;
   }
   WideDev32 dev = P.dev32; dev.lastOnly = lastOnly ? 1 : 0;
-  hipLaunchKernelGGL((k_wide_sum32<GV, HYB>), dim3((unsigned)nPairs), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch);
+  WideDev32 dev2 = P2 ? P2->dev32 : P.dev32; dev2.lastOnly = dev.lastOnly;
+  const WideSecond X{P2 ? (unsigned)nPairs : 0xFFFFFFFFu, d_desc2, pool2, scratch2};
+  hipLaunchKernelGGL((k_wide_sum32<GV, HYB>), dim3((unsigned)(nPairs + nPairs2)), dim3(P.W), lds, st, dev, d_desc, d_out, pool, loglike, scratch, dev2, X);
   MB_HIP(hipGetLastError());
   return 0;
 }
@@ -868,6 +889,38 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   else rc = gv ? (P.fastIdx ? WIDE_GO(MB_FORWARD, true, true) : WIDE_GO(MB_FORWARD, true, false))
                : (P.fastIdx ? WIDE_GO(MB_FORWARD, false, true) : WIDE_GO(MB_FORWARD, false, false));
 #undef WIDE_GO
+  g_last_launches += 1;
+  return rc;
+}
+
+int wide_fill2(const mb_machine *m, WideProgram &A, WideProgram &B, const PairDesc *d_descA, const PairDesc *d_descB, long long nA, long long nB,
+               const int *d_tape, double *poolA, double *poolB, hipStream_t st, bool lastOnly) {
+  (void)m;
+  if (!A.ok || !B.ok) { set_error("wide program not built"); return 1; }
+  if (nA <= 0 || nB <= 0) return -1;
+  if (A.viterbi || B.viterbi || A.f32 != B.f32 || A.hyb != B.hyb || A.fastIdx != B.fastIdx || A.W != B.W) return -1;
+  if (A.f32) {
+    auto gvOf = [](const WideProgram &Q) { return !Q.hyb && (Q.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0)); };
+    if (gvOf(A) != gvOf(B)) return -1;
+    const bool gv32 = gvOf(A);
+    float *sa = nullptr, *sb = nullptr;
+    if (gv32 && (!(sa = (float *)ws_get(11, (size_t)nA * A.vecBytes32())) || !(sb = (float *)ws_get(12, (size_t)nB * B.vecBytes32())))) return 1;
+    if (A.hyb && (!(sa = (float *)ws_get(11, (size_t)nA * A.NV * sizeof(float))) || !(sb = (float *)ws_get(12, (size_t)nB * B.NV * sizeof(float))))) return 1;
+    const int rc = A.hyb ? launch_wide32<false, true>(A, d_descA, nA, d_tape, poolA, nullptr, sa, st, lastOnly, &B, d_descB, nB, poolB, sb)
+                         : (gv32 ? launch_wide32<true, false>(A, d_descA, nA, d_tape, poolA, nullptr, sa, st, lastOnly, &B, d_descB, nB, poolB, sb)
+                                 : launch_wide32<false, false>(A, d_descA, nA, d_tape, poolA, nullptr, sa, st, lastOnly, &B, d_descB, nB, poolB, sb));
+    g_last_launches += 1;
+    return rc;
+  }
+  auto gvOf = [](const WideProgram &Q) { return Q.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) != 0; };
+  if (gvOf(A) != gvOf(B)) return -1;
+  const bool gv = gvOf(A);
+  double *sa = nullptr, *sb = nullptr;
+  if (gv && (!(sa = (double *)ws_get(11, (size_t)nA * A.vecBytes())) || !(sb = (double *)ws_get(12, (size_t)nB * B.vecBytes())))) return 1;
+  int rc;
+#define WIDE_GO2(G, F) launch_wide<MB_FORWARD, G, F>(A, d_descA, nA, d_tape, poolA, nullptr, sa, st, lastOnly, &B, d_descB, nB, poolB, sb)
+  rc = gv ? (A.fastIdx ? WIDE_GO2(true, true) : WIDE_GO2(true, false)) : (A.fastIdx ? WIDE_GO2(false, true) : WIDE_GO2(false, false));
+#undef WIDE_GO2
   g_last_launches += 1;
   return rc;
 }
@@ -970,6 +1023,72 @@ __global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEd
   if (live && acc != 0.0) atomicAdd(&counts[m.outEid[pos]], acc);
 }
 
+// The same sum with the columns staged in LDS, for machines whose three state vectors F(c), B(c), B(c + 1) fit it (<= 6 800
+// states: the 20-node config-5 machine): one workgroup per sequence part walks its columns from the back, loads F(c) and B(c)
+// with coalesced reads (B(c + 1) is the previous iteration's B(c)), and every thread evaluates its EPT transitions from LDS.
+// HBM traffic = both matrices exactly once, no L2 gathers (the kernel above: 12 ms on 64 x 2 kb, this one: the time of
+// streaming 10.4 GB).
+template <int EPT>
+__global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const OtEdge *__restrict__ edges, const unsigned short *__restrict__ waveLabel,
+                                                            int nEdges, const PairDesc *__restrict__ pairs, int colSplit, int inputTape,
+                                                            const int *__restrict__ tape, const double *__restrict__ fwd,
+                                                            const double *__restrict__ bwd, double *__restrict__ counts) {
+  extern __shared__ double cl[];
+  const int S = m.S, tid = threadIdx.x;
+  double *Fl = cl, *Ba = cl + S, *Bb = cl + 2 * (long long)S;
+  const long long unit = blockIdx.x, p = unit / colSplit;
+  const int part = (int)(unit - p * colSplit);
+  const PairDesc pd = pairs[p];
+  const int L = inputTape ? pd.inLen : pd.outLen;
+  const double *F = fwd + pd.cellBase, *B = bwd + pd.cellBase;
+  const double ll = B[0];                       // BackwardMatrix::logLike() = cell(0,0,start), src/backward.cpp:48-50,66
+  if (!(ll > -INFINITY)) return;
+  uint32_t esd[EPT]; int elab[EPT]; double ewl[EPT], acc[EPT];   // source | destination << 16 (S < 65 536 here), label, weight - LL, usage
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + k * 512;
+    const bool in = e < nEdges;
+    const OtEdge ed = in ? edges[e] : OtEdge{0u, 0xFFFFFFFFu};
+    const bool live = ed.pos != 0xFFFFFFFFu;
+    esd[k] = live ? (ed.src | (m.outDst[ed.pos] << 16)) : 0u;
+    ewl[k] = live ? m.outW[ed.pos] - ll : -INFINITY;
+    // (the edge list is padded to whole wavefronts per label: the label is uniform inside a wavefront -> scalar registers)
+    elab[k] = __builtin_amdgcn_readfirstlane((tid & ~63) + k * 512 < nEdges ? (int)waveLabel[((tid & ~63) + k * 512) >> 6] : -1);
+    acc[k] = 0.0;
+  }
+  const int per = (L + colSplit) / colSplit, cA = part * per, cB = min(L + 1, cA + per);   // source columns [cA, cB)
+  const int *tk = tape + (inputTape ? pd.inBase : pd.outBase);
+  double *Bcur = Ba, *Bnext = Bb;
+  if (cB <= L) for (int j = tid; j < S; j += 512) Bcur[j] = B[(long long)cB * S + j];   // B(cB): "next" of the first column handled
+  for (int c = cB - 1; c >= cA; --c) {
+    { double *t = Bcur; Bcur = Bnext; Bnext = t; }                // Bnext = B(c + 1), Bcur is refilled with B(c)
+    __syncthreads();                                              // the previous column's reads are done
+    for (int j = tid; j < S; j += 512) { Fl[j] = F[(long long)c * S + j]; Bcur[j] = B[(long long)c * S + j]; }
+    __syncthreads();
+    const int y = c < L ? tk[c] : -2;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (elab[k] == 0) acc[k] += (double)__builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bcur[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
+      else if (elab[k] == y) acc[k] += (double)__builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bnext[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + k * 512;
+    if (e < nEdges && acc[k] != 0.0) { const uint32_t pos = edges[e].pos; if (pos != 0xFFFFFFFFu) atomicAdd(&counts[m.outEid[pos]], acc[k]); }
+  }
+}
+
+template <int EPT>
+static void launch_counts_lds(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, long long nUnits, int colSplit, bool inputTape,
+                              const int *d_tape, const double *fwd, const double *bwd, double *d_counts, hipStream_t st) {
+  const size_t lds = (size_t)3 * m->S * sizeof(double);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)&k_onetape_counts_lds<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(k_onetape_counts_lds<EPT>, dim3((unsigned)nUnits), dim3(512), lds, st, m->dev, (const OtEdge *)C.d_edges,
+                     (const unsigned short *)C.d_waveLabel, C.nWaves * 64, d_desc, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts);
+}
+
 bool wide_counts_build(const mb_machine *m, WideCountPlan &C) {
   if ((m->nIn != 0) == (m->nOut != 0)) return false;
   const bool inputTape = m->nIn != 0;
@@ -1023,6 +1142,18 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
   int colSplit = 1;
   const int want = env_int_w("MB_ONETAPE_COUNT_UNITS", 32);
   while ((long long)hp.size() * colSplit < want && (maxLen + 1) / (colSplit * 2) >= 64) colSplit *= 2;
+  // columns staged in LDS when three state vectors fit and a thread's share of the transitions fits its registers
+  const long long nE = (long long)C.nWaves * 64;
+  if ((size_t)3 * m->S * sizeof(double) <= 158 * 1024 && nE <= 32 * 512 && env_int_w("MB_ONETAPE_COUNTS_LDS", 1)) {
+    int cs = 1;                                   // one workgroup per CU: cut until there are two parts per CU (parts of >= 64 columns)
+    const int wantUnits = env_int_w("MB_ONETAPE_COUNT_LDS_UNITS", 256);
+    while ((long long)hp.size() * cs < wantUnits && (maxLen + 1) / (cs * 2) >= 64) cs *= 2;
+    const long long units = (long long)hp.size() * cs;
+    if (nE <= 8 * 512) launch_counts_lds<8>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
+    else if (nE <= 16 * 512) launch_counts_lds<16>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
+    else launch_counts_lds<32>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
+    return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
+  }
   const long long nUnits = (long long)hp.size() * colSplit;
   const int nEB = (C.nWaves + 3) / 4;
   const long long grid = ((nUnits + 7) / 8) * 8 * nEB;
