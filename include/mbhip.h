@@ -9,9 +9,10 @@
  * Conventions
  *  - plain pointers and sizes only; all buffers are caller-owned host memory unless stated otherwise;
  *    the library owns device memory.  Calls are synchronous.
- *  - threading: like the reference (no threads on this path) the library expects ONE host
- *    thread per process to drive it -- the device workspaces and compiled programs are process-wide and unlocked;
- *    scale out with one process per GPU.  A filled matrix handed back to the caller is plain host memory.
+ *  - threading: the reference has no threads on this path.  Every entry point below takes one
+ *    process-wide lock (ApiGuard, mb_api.hip), so calls from several host threads are safe and are serialised -- the
+ *    device workspaces and compiled programs are process-wide; scale out with one process per GPU, not with threads.
+ *    mb_last_error() is thread-local.  A filled matrix handed back to the caller is plain host memory.
  *  - every function returning int returns 0 on success, non-zero on error; mb_last_error() then gives the
  *    message the reference would have put into its runtime_error (src/util.cpp:39-48).
  *  - tokens are int32, token 0 = epsilon, tokens 1..N index the sorted alphabet (src/eval.h:13-22).
@@ -84,12 +85,14 @@ int mb_machine_edge_order(const mb_machine *m, int which, uint32_t *out);
 mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, const int64_t *inOff,
                           const int32_t *outTok, const int64_t *outOff);
 void mb_batch_destroy(mb_batch *b);
-int64_t mb_batch_cells(const mb_batch *b);
+int64_t mb_batch_cells(const mb_batch *b); /* sum over pairs of (inLen+1)(outLen+1)nStates */
 /* Envelopes of the pairs (Envelope::inStart / inEnd, src/seqpair.h:75-97): pair p owns rows envOff[p]..envOff[p+1] of
  * inStart[] / inEnd[] -- either outLen+1 rows (cell (x,y) exists <=> inStart[y] <= x < inEnd[y]) or none (full).
  * Rejected like DPMatrix::alloc does (src/dpmatrix.defs.h:31-32): "Envelope/sequence mismatch", "Envelope is not
- * connected".  Batches with a restricted envelope run on the generic kernel family. */
-int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *inStart, const int32_t *inEnd); /* sum over pairs of (inLen+1)(outLen+1)nStates */
+ * connected".  Restricted envelopes run on the fast families too (the JENV variants of the small-machine and tiled
+ * kernels clip every cell outside its row's [inStart, inEnd) to -inf and do not launch tiles that hold no cell of any
+ * envelope); one-tape machines and the ahead-of-time fallback take the generic family. */
+int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *inStart, const int32_t *inEnd);
 
 /* Forward log-likelihoods, loglike[nPairs] (-inf allowed).
  * MB_MATERIALISE = ForwardMatrix(eval, sp).logLike()             src/forward.defs.h:23-55, src/api.cpp:32-35

@@ -33,6 +33,7 @@
 #include <ostream>
 #include <queue>
 #include <random>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -642,7 +643,11 @@ public:
   BackwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp) {}
   template <class EnvT> BackwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp) {}
   using BackwardCore::getCounts;
-  template <class CountsT> void getCounts(const ForwardCore &forward, CountsT &counts) const {      // getCounts(forward, MachineCounts&), src/backward.cpp:58-60
+  template <class CountsT> static BackwardCore::BackTransVisitor transitionCounter(CountsT &counts) {      // src/backward.h:13-19
+    return [&counts](StateIndex s, TransIndex ti, long, long, double postProb) { counts.count[s][ti] += postProb; };
+  }
+  // getCounts(forward, MachineCounts&), src/backward.cpp:58-60 (only for types with a `count` member: a visitor lvalue takes the overload above)
+  template <class CountsT> auto getCounts(const ForwardCore &forward, CountsT &counts) const -> decltype(counts.count, void()) {
     BackwardCore::getCounts(forward, [&counts](StateIndex s, TransIndex ti, long, long, double postProb) { counts.count[s][ti] += postProb; });
   }
 };
@@ -665,8 +670,12 @@ public:
   double logLike() const { return ll; }
 };
 
-// MachineCounts with the reference's constructors (src/counts.h:11-25).  A SeqPairList goes to the device as ONE batch.
-template <class EvalT, class SeqPairT, class SeqPairListT>
+// MachineCounts with the reference's whole surface (src/counts.h:11-25).  A SeqPairList goes to the device as ONE batch.
+// PolicyT names the caller's weight algebra and string helper for the three members that never touch the DP
+// (src/counts.cpp:73-106): static params(w, defs) / eval(w, defs) / deriv(w, defs, p) / asDouble(w) as in
+// src/weight.h:83-90, and escaped_str(s) (src/util.h:100).  The glue header passes the reference's own WeightAlgebra.
+struct NoAlgebraPolicy {};
+template <class EvalT, class SeqPairT, class SeqPairListT, class PolicyT = NoAlgebraPolicy>
 struct MachineCountsT : MachineCounts {
   MachineCountsT() {}
   MachineCountsT(const EvalT &m) { init(m); }
@@ -688,6 +697,49 @@ struct MachineCountsT : MachineCounts {
       envs.push_back(envelopeOf(sp));
     }
     (void)MachineCounts::add(*f, pairs, envs);
+  }
+  MachineCountsT &operator+=(const MachineCountsT &o) { MachineCounts::operator+=(o); return *this; }
+
+  // writeJson (src/counts.cpp:73-78): one bracketed row per state, numbers at the stream default (6 significant digits)
+  void writeJson(std::ostream &outs) const {
+    outs << "[";
+    for (size_t s = 0; s < count.size(); ++s) {
+      std::ostringstream row;
+      for (size_t t = 0; t < count[s].size(); ++t) row << (t ? "," : "") << count[s][t];
+      outs << (s ? ",\n " : "") << "[" << row.str() << "]";
+    }
+    outs << "]" << std::endl;
+  }
+  // paramCounts (src/counts.cpp:89-106): expectation of d(logLike)/d(logParam) = sum over transitions of
+  // count * (dw/dp) * p / w, through the caller's symbolic weights
+  template <class MachineT, class ParamAssignT>
+  std::map<std::string, double> paramCounts(const MachineT &machine, const ParamAssignT &prob) const {
+    typedef typename std::decay<decltype(prob.defs)>::type ParamDefsT;
+    std::map<std::string, double> paramCount;
+    if (count.size() != machine.state.size()) throw std::runtime_error("Number of states mismatch");
+    for (size_t s = 0; s < count.size(); ++s) {
+      if (count[s].size() != machine.state[s].trans.size()) throw std::runtime_error("State size mismatch");
+      auto transIter = machine.state[s].trans.begin();
+      for (const double c : count[s]) {
+        const auto &trans = *(transIter++);
+        const auto transParams = PolicyT::params(trans.weight, ParamDefsT());
+        const double w = PolicyT::eval(trans.weight, prob.defs);
+        for (const auto &p : transParams) {
+          const auto deriv = PolicyT::deriv(trans.weight, ParamDefsT(), p);
+          paramCount[p] += c * PolicyT::eval(deriv, prob.defs) * PolicyT::asDouble(prob.defs.at(p)) / w;
+        }
+      }
+    }
+    return paramCount;
+  }
+  // writeParamCountsJson (src/counts.cpp:80-87)
+  template <class MachineT, class ParamAssignT>
+  void writeParamCountsJson(std::ostream &outs, const MachineT &machine, const ParamAssignT &prob) const {
+    const std::map<std::string, double> pc = paramCounts(machine, prob);
+    outs << "{";
+    size_t n = 0;
+    for (const auto &name_count : pc) outs << (n++ ? "," : "") << "\"" << PolicyT::escaped_str(name_count.first) << "\":" << name_count.second;
+    outs << "}";
   }
 };
 

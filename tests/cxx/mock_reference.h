@@ -22,6 +22,18 @@ typedef std::string OutputSymbol;
 typedef unsigned long long StateIndex;
 typedef std::map<std::string, double> Params;
 
+// weights are plain numbers here: the mock algebra has no parameters (src/weight.h:83-90, src/params.h:26-30, src/util.h:100)
+typedef double WeightExpr;
+typedef std::map<std::string, WeightExpr> ParamDefs;
+struct ParamAssign { ParamDefs defs; };
+struct WeightAlgebra {
+  static std::set<std::string> params(const WeightExpr &, const ParamDefs &) { return std::set<std::string>(); }
+  static double eval(const WeightExpr &w, const ParamDefs &) { return w; }
+  static WeightExpr deriv(const WeightExpr &, const ParamDefs &, const std::string &) { return 0; }
+  static double asDouble(const WeightExpr &w) { return w; }
+};
+inline std::string escaped_str(const std::string &s) { return s; }
+
 struct StateName {                       // nlohmann::json in the reference: streams as a JSON value
   std::string id;
   bool is_null() const { return id.empty(); }

@@ -9,8 +9,15 @@
 #include <random>
 #include <sstream>
 
+#ifdef MB_GLUE_REAL      // parsed against the reference's own headers with the glue applied (apply_glue.py overlay)
+#include "backward.h"
+#include "viterbi.h"
+#include "counts.h"
+#include "api.h"
+#else
 #include "mock_reference.h"
-#include "hipdp.h"
+#include "api_bodies.h"
+#endif
 
 using namespace MachineBoss;
 using namespace std;
@@ -25,6 +32,12 @@ static void printPath(const char *tag, const MachinePath &p) {
 
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
+#ifdef MB_GLUE_REAL
+  Machine machine = MachineLoader::fromFile(argv[1]);
+  SeqPairList data = JsonLoader<SeqPairList>::fromFile(argv[2]);
+  const size_t S = machine.nStates();
+  ifstream f(argv[3]);
+#else
   ifstream f(argv[1]);
   Machine machine;
   size_t S; f >> S;
@@ -41,6 +54,7 @@ int main(int argc, char **argv) {
     f >> n; sp.output.seq.resize(n); for (auto &x : sp.output.seq) f >> x;
     data.seqPairs.push_back(sp);
   }
+#endif
   unsigned seed; f >> seed;
   const Params params;
   try {
@@ -67,6 +81,23 @@ int main(int argc, char **argv) {
     cout << "counts " << setprecision(17) << counts.loglike;
     for (const auto &row : counts.count) for (double c : row) cout << " " << c;
     cout << endl;
+    cout << "COUNTSJSON_BEGIN" << endl; counts.writeJson(cout); cout << "COUNTSJSON_END" << endl;      // t/src/testcounts.cpp:16
+    cout << "paramcounts "; counts.writeParamCountsJson(cout, machine, ParamAssign()); cout << endl;    // target/boss.cpp:814
+#ifdef MB_GLUE_REAL
+    {   // src/fitter.cpp:30-33 (Baum-Welch iteration), target/boss.cpp:811-816, src/counts.cpp:89-106
+      const list<Envelope> envelopes;
+      const MachineCounts fitCounts(eval, data, envelopes);
+      const Constraints constraints;
+      const MachineObjective objective(machine, fitCounts, constraints, Params());
+      const Params optParams = objective.optimize(params);
+      const map<string, double> pc = fitCounts.paramCounts(machine, ParamAssign(optParams));
+      fitCounts.writeParamCountsJson(cout, machine, params);
+      MachineCounts sum(eval); sum += fitCounts;
+      BackwardMatrix::BackTransVisitor tv = BackwardMatrix::transitionCounter(sum);
+      backward.getCounts(forward, tv);
+      cout << pc.size() << sum.add(eval, seqPair) << sum.add(eval, seqPair, Envelope(seqPair)) << endl;
+    }
+#endif
     MachineCounts one = forwardBackwardCounts(machine, params, seqPair), viaVisitor(eval);
     backward.getCounts(forward, viaVisitor);                                     // src/counts.cpp:57-64 spelled out
     double d = 0; for (size_t s = 0; s < one.count.size(); ++s) for (size_t t = 0; t < one.count[s].size(); ++t) d = max(d, fabs(one.count[s][t] - viaVisitor.count[s][t]));

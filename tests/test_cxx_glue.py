@@ -1,5 +1,5 @@
-"""The C++ boundary, signature-compatible: tests/cxx/hipdp.h -- the glue header
-of INTEGRATION.md -- binds machineboss_amd/cxx/mb_dp.hpp's class templates to the reference's type shapes
+"""The C++ boundary, signature-compatible: machineboss_amd/cxx/hipdp.h -- the glue
+header of INTEGRATION.md -- binds machineboss_amd/cxx/mb_dp.hpp's class templates to the reference's type shapes
 (tests/cxx/mock_reference.h), and tests/cxx/test_glue.cpp is caller code in the style of target/boss.cpp, t/src/test*.cpp
 and Machine::downsample, written against the reference's names only.
 
@@ -21,7 +21,7 @@ from conftest import ROOT
 def _build(tmp_path, name):
     exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "machineboss_amd")
-    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"),
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-DMB_GLUE_MOCK", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"),
                            "-I", os.path.join(ROOT, "tests", "cxx"), os.path.join(ROOT, "tests", "cxx", name + ".cpp"), "-o", exe,
                            "-L", libdir, "-lmbhip", "-Wl,-rpath," + libdir])
     return exe
@@ -33,6 +33,34 @@ def test_glue_compiles_against_reference_shapes(tmp_path):
     build.build()
     assert os.path.exists(_build(tmp_path, "test_glue"))
     assert os.path.exists(_build(tmp_path, "test_facade"))
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src")), reason="reference tree not present (it never travels to the GPU box)")
+@pytest.mark.parametrize("caller", ["t/src/testforward.cpp", "t/src/testbackward.cpp", "t/src/testcounts.cpp", "t/src/testmaximize.cpp", "test_glue.cpp"])
+def test_reference_callers_compile_against_real_headers_with_the_glue(tmp_path, caller):
+    """apply_glue.py on the REAL reference tree (as an overlay of symlinks: the tree is read-only and nothing of it is
+    copied into the repo), then the reference's own DP callers are parsed by g++ against the reference's real eval.h /
+    seqpair.h / machine.h / weight.h / constraints.h + the glue: t/src/test{forward,backward,counts,maximize}.cpp as they
+    lie (writeJson, MachineCounts::writeJson, MachineObjective(machine, counts, ...)), and this repo's boss.cpp / api.cpp /
+    downsample-style caller code with MB_GLUE_REAL.  -fsyntax-only: the reference's .cpp files need GSL and Boost, which
+    the image lacks, so nothing can be linked; HIPDP_SYNTAX_ONLY keeps logsumexp.h / logger.h (GSL / Boost) out."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "machineboss_amd", "cxx"))
+    import apply_glue
+    ov = apply_glue.overlay(REFERENCE, str(tmp_path / "overlay"))
+    srcfile = os.path.join(ov, caller) if caller.startswith("t/") else os.path.join(ROOT, "tests", "cxx", caller)
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-DHIPDP_SYNTAX_ONLY", "-DMB_GLUE_REAL", "-I", os.path.join(ov, "src"), "-I", os.path.join(ov, "ext"),
+           "-I", os.path.join(ov, "ext", "nlohmann_json"), srcfile]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # the overlay's counts.h still declares the M-step class and no longer declares the E-step struct
+    ch = open(os.path.join(ov, "src", "counts.h")).read()
+    assert "struct MachineObjective" in ch and "struct MachineCounts {" not in ch and '#include "hipdp.h"' in ch
+    cc = open(os.path.join(ov, "src", "counts.cpp")).read()
+    assert "MachineObjective::MachineObjective" in cc and "MachineCounts::add" not in cc and "MachineCounts::paramCounts" not in cc
 
 
 def _write_case(path, em, names, pairs, seed):
@@ -160,6 +188,12 @@ def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed, dag):
         ref_s += om.counts_add(a, b, ref_c, oracle_mod.SUM_EXACT) if l > -math.inf else l
     if math.isfinite(ref_s):
         assert np.allclose(cl[1:], ref_c, rtol=1e-5, atol=1e-7) and abs(cl[0] - ref_s) <= 2e-6 * abs(ref_s) + 2e-5
+    # MachineCounts::writeJson (src/counts.cpp:73-78): "[[row],\n [row]]", numbers at the stream default
+    cj = lines[lines.index("COUNTSJSON_BEGIN") + 1:lines.index("COUNTSJSON_END")]
+    off = np.asarray(em.transOffset)
+    rows = ["[" + ",".join("%.6g" % c for c in cl[1 + off[s]:1 + off[s + 1]]) + "]" for s in range(S)]
+    assert "\n".join(cj).replace("e-0", "e-").replace("e+0", "e+") == ("[" + ",\n ".join(rows) + "]").replace("e-0", "e-").replace("e+0", "e+")
+    assert get("paramcounts")[0] == "paramcounts {}"      # the mock's weights carry no parameters
     cv = get("counts_visitor_vs_device")[0].split()
     assert float(cv[1]) < 1e-6 and float(cv[3]) == F[-1, -1, -1] and float(cv[4]) == V[-1, -1, -1]
     if V[-1, -1, -1] > -math.inf:
