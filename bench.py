@@ -15,8 +15,10 @@ GPU (seed 1000*4 + k).  One step = one Forward fill over
 Prints ONE JSON line (rank 0).  Besides the contract's keys it carries `roofline`, `cpu_baseline` and, at N = 1, `extra`:
 the other modes of the path on the BASELINE configs they are quoted on (config 3: Forward-Backward counts on protpsw,
 config 2: Viterbi + traceback on dnapsw, config 1: cold-start latency of one 50-aa pair), each with its own roofline
-block.  At N > 1 `extra.em_iteration` times the one collective of the path: an E-step on the rank's shard of config 3
-followed by the RCCL all-reduce of the counts.
+block; the other two modes of the HEADLINE machine on config 4's own shape (`viterbi4`: one traceback byte per cell,
+`counts4`: no Forward matrix); config 5 at its stated 64 x 50 kb; and `nonuniform`, the second parameter set SURVEY 8(d) asks
+for (a Baum-Welch fit).  At N > 1 `extra.em_iteration` times the one collective of the path: an E-step on the rank's shard
+of config 3 followed by the RCCL all-reduce of the counts, and `per_rank` lists every rank's cells and seconds.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts N ranks itself (torch.distributed.run as a child
 process; this process has not touched the GPU at that point) and relays rank 0's line.
@@ -98,7 +100,7 @@ def extra_single_gpu(capi, np, hbm_peak):
     """The other modes of the hot path on the BASELINE configs they belong to (one GPU, inputs resident in HBM)."""
     from machineboss_amd.machine import Machine
     from machineboss_amd.evalmachine import EvaluatedMachine
-    from machineboss_amd.seqgen import synth_batch
+    from machineboss_amd.seqgen import synth_batch, synth_tokens
     out = {}
 
     def machine(preset):
@@ -162,6 +164,36 @@ def extra_single_gpu(capi, np, hbm_peak):
                                                                "frac": round(8.0 * cells2 / (devm / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name()}}
     del b2
 
+    # config 4's own shape for the other two modes of the HEADLINE machine (psw2dna, 487 aa x 10 kb): `--viterbi/--align` keeps ONE
+    # traceback byte per cell (1 B), `--train`'s E-step keeps no Forward matrix (16 B per lattice cell: the
+    # Backward matrix written once and read once)
+    em4 = machine("psw2dna")
+    dm4 = capi.DeviceMachine(em4)
+    nv = 256
+    b4 = capi.DeviceBatch(dm4, *synth_batch(4, nv, 487, 10000, em4.nInTok, em4.nOutTok))
+    cells4 = b4.cells()
+    (v4, off4, e4), tv4 = timed(lambda: b4.viterbi(paths=True), 1); devv4 = capi.last_device_ms(); kv4 = capi.last_kernel_name()
+    _, tvf4 = timed(lambda: b4.viterbi(paths=False), 1); devvf4 = capi.last_device_ms()
+    out["viterbi4"] = {"workload": "config 4: psw2dna (271 states), %d pairs x 487 aa x 10000 nt, ViterbiMatrix + traceBack, one traceback byte per cell" % nv,
+                       "value": round(cells4 / tv4 / 1e9, 2), "unit": "Gcells/s (fill + traceback + paths copied to the host)", "fill_only": round(cells4 / tvf4 / 1e9, 2),
+                       "device_ms": round(devv4, 3), "fill_device_ms": round(devvf4, 3), "path_edges": int(off4[-1]), "loglike_sum": float(v4.sum()),
+                       "roofline": {"bound": "valu", "note": "1 traceback byte per cell (+ boundary records and halo rows: profiles/r03_viterbi4_pmc_hbm.json); the max sweep is bound by vector instruction issue, not by HBM",
+                                    "achieved": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
+                                    "frac": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1, "kernel": kv4}}
+    del b4
+    nc4 = 63      # three chunks of Backward matrices (21 pairs of 10.6 GB each fit the 80 % budget of a 288 GB GPU)
+    b4c = capi.DeviceBatch(dm4, *synth_batch(4, nc4, 487, 10000, em4.nInTok, em4.nOutTok))
+    cells4c = b4c.cells()
+    (cnt4, s4, _), tc4 = timed(lambda: b4c.counts(), 1); devc4 = capi.last_device_ms()
+    ach4 = 16.0 * cells4c / (devc4 / 1e3) / 1e9
+    out["counts4"] = {"workload": "config 4: psw2dna, %d pairs x 487 aa x 10000 nt, Backward fill + Forward/count sweep without a Forward matrix (MachineCounts)" % nc4,
+                      "value": round(cells4c / tc4 / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(tc4 * 1e3, 2), "device_ms": round(devc4, 2),
+                      "roofline": {"bound": "hbm", "achieved": round(ach4, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(ach4 / hbm_peak, 4),
+                                   "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_medium_jit (Backward fill) + k_medium_jit (count sweep)", "traffic": None},
+                      "symbol_count_invariant": [float(cnt4[np.asarray(em4.inTok) != 0].sum()) / (nc4 * 487), float(cnt4[np.asarray(em4.outTok) != 0].sum()) / (nc4 * 10000)],
+                      "loglike_sum": float(s4)}
+    del b4c
+
     # config 5: HMMER profile . simple_introns . translate . dnapsw assembled here (first 20 nodes of the fn3 profile: 5063
     # states, the "~5k states" of the config), a one-tape generator; 64 sequences x 2 kb (one workgroup per sequence)
     try:
@@ -184,8 +216,52 @@ def extra_single_gpu(capi, np, hbm_peak):
                           "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
                           "roofline": {"bound": "valu", "note": "one workgroup per sequence, a column's silent closure is a dependent chain: bound by instruction issue on 64 of 256 CUs (DESIGN.md 4.2b); no HBM or MFMA bound applies"}}
+        del b5
+        # ... and at the config's STATED length: 64 sequences x 50 kb on this one GPU (16.2 G cells per matrix)
+        b5f = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 50000, em5.nInTok, em5.nOutTok))
+        cells5f = b5f.cells()
+        ll5f, t5f = timed(lambda: b5f.forward(capi.MB_ROLLING), 1); k5f = capi.last_kernel_name()
+        (v5f, _, _), t5vf = timed(lambda: b5f.viterbi(paths=False), 1); k5vf = capi.last_kernel_name()
+        out["config5"]["full_size"] = {"workload": "the same machine, 64 sequences x 50000 nt (BASELINE config 5 as stated, all on one GPU)", "cells": int(cells5f),
+                                       "forward_rolling": round(cells5f / t5f / 1e9, 2), "forward_ms": round(t5f * 1e3, 1), "viterbi_fill": round(cells5f / t5vf / 1e9, 2),
+                                       "viterbi_ms": round(t5vf * 1e3, 1), "unit": "Gcells/s", "kernels": [k5f, k5vf], "loglike_sum": float(np.sum(ll5f)),
+                                       "viterbi_le_forward": bool(np.all(v5f <= ll5f + 1e-6 * np.abs(ll5f)))}
+        del b5f
     except Exception as e:   # the extras never take the headline down
         out["config5"] = {"error": str(e)}
+
+    # "one non-uniform parameter set, e.g. a fit from --train, as a second case" -- uniform defaults tie every
+    # Viterbi choice, a fitted set does not.  Baum-Welch (fitter.py = src/fitter.cpp) on 16 short synthetic pairs, then the
+    # headline machine under the fitted parameters on config 4's shape.
+    try:
+        from machineboss_amd.fitter import MachineFitter
+        from machineboss_amd.seqpair import SeqPair
+        m4 = Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", "psw2dna.json"))
+        train = []
+        for k in range(16):
+            x, y = synth_tokens(1000 * 4 + 9000 + k, 40, 130, em4.nInTok, em4.nOutTok)
+            train.append(SeqPair(em4.inputTokenizer.detokenize(x), em4.outputTokenizer.detokenize(y), "in%d" % k, "out%d" % k))
+        t0 = time.perf_counter()
+        fitter = MachineFitter(m4)
+        params = fitter.fit(train)
+        tfit = time.perf_counter() - t0
+        allp = dict(m4.funcs); allp.update(params)
+        emn = EvaluatedMachine.fromMachine(m4, allp)
+        dmn = capi.DeviceMachine(emn)
+        bn = capi.DeviceBatch(dmn, *synth_batch(4, 32, 487, 10000, emn.nInTok, emn.nOutTok))
+        cellsn = bn.cells()
+        lln, tfn = timed(lambda: bn.forward(capi.MB_MATERIALISE), 1); devn = capi.last_device_ms()
+        (vn, offn, en), tvn = timed(lambda: bn.viterbi(paths=True), 1)
+        lw = np.asarray(emn.logWeight)
+        rescore = float(np.sum(lw[en[offn[0]:offn[1]]]))
+        out["nonuniform"] = {"workload": "psw2dna under parameters fitted by Baum-Welch (%d iterations, %.1f s, log-likelihood %.4f -> %.4f on 16 pairs of 40 aa x 130 nt); 32 pairs x 487 aa x 10000 nt"
+                                         % (len(fitter.log), tfit, fitter.log[0], fitter.log[-1]),
+                             "forward_materialised": round(cellsn / tfn / 1e9, 2), "viterbi_with_paths": round(cellsn / tvn / 1e9, 2), "unit": "Gcells/s",
+                             "roofline": {"bound": "hbm", "achieved": round(8.0 * cellsn / (devn / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(8.0 * cellsn / (devn / 1e3) / 1e9 / hbm_peak, 4)},
+                             "loglike_checksum": float(np.sum(lln)), "viterbi_checksum": float(np.sum(vn)),
+                             "path0_rescored_minus_viterbi": rescore - float(vn[0]), "_em": emn, "_dm": dmn}
+    except Exception as e:
+        out["nonuniform"] = {"error": str(e)}
     return out
 
 
@@ -263,6 +339,7 @@ def main():
         ll = batch.forward(flags)
         dev_ms += capi.last_device_ms()
         launches += capi.last_launch_count()
+    dt_rank = time.perf_counter() - t0      # this rank's own clock (before the closing barrier): reported per rank at N > 1
     sync()
     dt = time.perf_counter() - t0
     kernel = capi.last_kernel_name()
@@ -277,6 +354,16 @@ def main():
     value = total_cells * args.steps / dt / 1e9
 
     extra = {}
+    if world > 1:
+        # every rank's share and clock: an imbalance (ragged shard, a slow device) shows as one rank's seconds standing out
+        rec = torch.tensor([float(rank), float(cells_rank), dt_rank, dev_ms / 1e3], dtype=torch.float64, device=cdev)
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        rows = sorted([[float(v) for v in r.tolist()] for r in allrec])
+        extra["per_rank"] = [{"rank": int(r[0]), "cells_per_step": int(r[1]), "seconds": round(r[2], 4), "device_seconds": round(r[3], 4),
+                              "gcells_per_s": round(r[1] * args.steps / max(r[2], 1e-12) / 1e9, 2)} for r in rows]
+        slow = max(rows, key=lambda r: r[2])
+        extra["slowest_rank"] = {"rank": int(slow[0]), "seconds": round(slow[2], 4), "over_mean": round(slow[2] / (sum(r[2] for r in rows) / world), 4)}
     if world > 1 and not args.no_extra:
         # the ONE collective of the path (--train): E-step on this rank's shard of config 3, then the all-reduce of
         # nTransitions + 1 doubles over RCCL (xGMI)
@@ -343,13 +430,36 @@ def main():
         b1 = capi.DeviceBatch.from_pairs(dm, samples[:2])
         got = b1.forward(flags)
         assert all(abs(g - r) <= 1e-4 * abs(r) for g, r in zip(got, refs[:2])) and np.isfinite(ref1)   # same sample through the GPU path: parity at bench scale
+        single = (args.inlen + 1) * 1501 * em.nStates / d1 / 1e9
         cpu = {"value": round(cores * sample_cells / d2 / 1e9, 5), "unit": "Gcells/s", "cores": cores, "kind": "port",
-               "single_core_value": round((args.inlen + 1) * 1501 * em.nStates / d1 / 1e9, 5),
+               "single_core_value": round(single, 5),
+               # the REFERENCE's own rate is a recorded constant (its sources need GSL / Boost and cannot be built or travel):
+               "reference_per_core": {"value": 0.0116, "unit": "Gcells/s", "what": "the reference's src/*.cpp (RollingOutputForwardMatrix, -O3), psw2dna 100 aa x 100 nt, one core of a 2.1 GHz Xeon",
+                                      "source": "BASELINE.md section 2 (survey probe), recorded -- not measured in this run"},
+               "socket_extrapolation": {"cores": 64, "port_gcells": round(single * 64, 3), "reference_gcells": round(0.0116 * 64, 3),
+                                        "note": "one 64-core socket, perfect scaling over independent pairs assumed for both; the north star's '>= 50x single-socket CPU' is read against these"},
                "sample": "%d pairs (one per host core, concurrently) of %d aa x %d nt on %s (%.1f s wall), RollingOutputForwardMatrix restatement oracle/mb_oracle.c, table logsumexp"
                          % (cores, args.inlen, sample_out, args.preset, d2)}
 
     if rank == 0 and world == 1 and not args.no_extra:
         extra.update(extra_single_gpu(capi, np, HBM_PEAK_GBS))
+        nu = extra.get("nonuniform", {})
+        emn, dmn = nu.pop("_em", None), nu.pop("_dm", None)
+        if emn is not None and not args.no_cpu:
+            # CPU leg, checker only: the fitted machine through the oracle on two short pairs (Forward within 1e-4, Viterbi
+            # score and path bit for bit -- with non-uniform parameters the path is a genuine arg-max, not a chain of ties)
+            from oracle import oracle
+            omn = oracle.OracleMachine(emn)
+            small = [synth_tokens(1000 * 4 + 9500 + k, 35 + 5 * k, 110 + 20 * k, emn.nInTok, emn.nOutTok) for k in range(2)]
+            bs = capi.DeviceBatch.from_pairs(dmn, small)
+            gl = bs.forward(capi.MB_MATERIALISE); gv, go, ge = bs.viterbi(paths=True)
+            ok = True; worst = 0.0
+            for k, (x, y) in enumerate(small):
+                r = omn.loglike(x, y); V = omn.viterbi(x, y)
+                worst = max(worst, abs(gl[k] - r) / abs(r))
+                ok = ok and abs(gl[k] - r) <= 1e-4 * abs(r) and gv[k] == V[-1, -1, -1] and np.array_equal(ge[go[k]:go[k + 1]], omn.traceback(x, y, V))
+            nu["oracle_check"] = {"pairs": [[len(x), len(y)] for x, y in small], "forward_max_rel_err": worst, "viterbi_and_paths_bit_exact": bool(ok), "ok": bool(ok)}
+            assert ok, "non-uniform parameter case disagrees with the oracle"
 
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the
@@ -357,7 +467,7 @@ def main():
         ach = BYTES_PER_CELL * cells_rank * args.steps / (dev_ms / 1e3) / 1e9 if (dev_ms > 0 and flags == capi.MB_MATERIALISE) else 0.0
         traffic = None
         traffic_src = None
-        for tag in ("r02", "r01"):   # HBM bytes per launch from the committed PMC passes (profiles/): a recorded constant, valid for the default workload only
+        for tag in ("r03", "r02", "r01"):   # HBM bytes per launch from the committed PMC passes (profiles/): a recorded constant, valid for the default workload only
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")))
                 if pmc["kernel"] == kernel and pmc["cells_per_step"] == cells_rank and flags == capi.MB_MATERIALISE:

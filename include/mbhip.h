@@ -179,7 +179,8 @@ int mb_set_option(const char *name, const char *value);
 const char *mb_get_option(const char *name);
 
 /* Writes the HIP source the run-time code generator produces for this machine (mode MB_FORWARD = sum semiring,
- * MB_VITERBI = max, 3 = Forward fused with posterior counts; backward and closure (0 = levelled, K >= 1 = silent closure in
+ * MB_VITERBI = max, 3 = Forward fused with posterior counts, 4 = max keeping one traceback byte per cell; + 16 = the tile
+ * kernel that keeps no matrix (implied by 4); backward and closure (0 = levelled, K >= 1 = silent closure in
  * K stages) select the program; G = columns per
  * wavefront, 1/2/4/8) to `path`.  Host only:
  * works without a GPU, so the generated kernel can be inspected / cross-compiled offline. */

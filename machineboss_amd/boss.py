@@ -210,8 +210,19 @@ def _dist():
     return None
 
 
-def _gather_in_order(local: List[Any], n: int, rank: int, world: int) -> List[Any]:
-    """Results of round-robin sharded pairs back in input order on every rank (no data-path collective: host gather)."""
+def _shard(data: List[Any], machine, world: int) -> List[List[int]]:
+    """Which pairs each rank takes: sorted by DP cell count and dealt greedily to the least loaded rank
+    (shard.lpt_assign) -- pairs are independent units (the `for seqPair` loops of target/boss.cpp:796,826), and a ragged list
+    dealt round-robin leaves the rank that drew the long pairs working alone.  Deterministic: every rank computes the same."""
+    from .shard import lpt_assign
+    nStates = len(machine.state)
+    cells = [(len(sp.input) + 1) * (len(sp.output) + 1) * nStates for sp in data]
+    return lpt_assign(cells, world)
+
+
+def _gather_in_order(local: List[Any], n: int, rank: int, world: int, owned: Optional[List[List[int]]] = None) -> List[Any]:
+    """Results of the sharded pairs back in input order on every rank (no data-path collective: host gather).
+    owned[r] = indices of the pairs rank r took, in the order it processed them."""
     dist = _dist()
     if dist is None or world == 1:
         return local
@@ -219,7 +230,7 @@ def _gather_in_order(local: List[Any], n: int, rank: int, world: int) -> List[An
     dist.all_gather_object(parts, local)
     out: List[Any] = [None] * n
     for r in range(world):
-        for k, v in zip(range(r, n, world), parts[r]):
+        for k, v in zip(owned[r] if owned is not None else range(r, n, world), parts[r]):
             out[k] = v
     return out
 
@@ -248,7 +259,8 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
     dist = _dist()
     rank = dist.get_rank() if dist else 0
     world = dist.get_world_size() if dist else 1
-    mine = data[rank::world]                         # pairs are independent units: round-robin shard
+    owned = _shard(data, machine, world) if world > 1 else [list(range(len(data)))]
+    mine = [data[k] for k in owned[rank]]
     emit = (lambda s: out.write(s)) if rank == 0 else (lambda s: None)
 
     from . import dp
@@ -274,7 +286,7 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
 
     if args.loglike:
         ev = EvaluatedMachine.fromMachine(machine, params)
-        ll = _gather_in_order(dp.forwardLogLikeBatch(ev, mine, rolling=True), len(data), rank, world)
+        ll = _gather_in_order(dp.forwardLogLikeBatch(ev, mine, rolling=True), len(data), rank, world, owned)
         emit("[" + ",\n ".join('["%s","%s",%s]' % (escaped(sp.inputName), escaped(sp.outputName), fmt(x))
                                 for sp, x in zip(data, ll)) + "]\n")
 
@@ -293,7 +305,7 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
             raise MachineError("To align sequences, please specify a data file")
         ev = EvaluatedMachine.fromMachine(machine, params)
         res = dp.viterbiBatch(ev, machine, mine)
-        res = _gather_in_order(res, len(data), rank, world)
+        res = _gather_in_order(res, len(data), rank, world, owned)
         if args.viterbi:
             emit("[" + ",\n ".join('["%s","%s",%s]' % (escaped(sp.inputName), escaped(sp.outputName), fmt(v))
                                     for sp, (v, _) in zip(data, res)) + "]\n")

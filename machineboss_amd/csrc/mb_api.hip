@@ -206,6 +206,9 @@ int launch_generic_counts(const mb_machine *, const PairDesc *, long long, long 
 int launch_compact_paths(const uint32_t *, const long long *, const long long *, const long long *, uint32_t *, long long, hipStream_t);
 int launch_traceback(const mb_machine *, const PairDesc *, long long, const int *, const int *, const double *,
                      const long long *, uint32_t *, long long *, hipStream_t);
+size_t traceback_bytes_lds(const mb_machine *, int);
+int launch_traceback_bytes(const mb_machine *, const PairDesc *, long long, const int *, const int *, const unsigned char *, int, const double *,
+                           const long long *, uint32_t *, long long *, hipStream_t);
 
 // a second stream for work that is independent of what g_stream runs (created on first use; nullptr if that fails)
 static hipStream_t second_stream() {
@@ -242,9 +245,9 @@ struct Timer {
 
 // Split [0,nPairs) into chunks whose matrices (nMatrices per pair, doubles) fit the budget.
 struct Chunk { long long p0, p1, cells; };
-static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &out) {
+static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &out, double bytesPerCell = 0.0) {
   const size_t budget = budget_bytes();
-  long long maxCells = (long long)(budget / (8ull * nMatrices));
+  long long maxCells = bytesPerCell > 0.0 ? (long long)((double)budget / bytesPerCell) : (long long)(budget / (8ull * nMatrices));
   // balance: the same number of chunks as a greedy fill needs, but of even size (a short last chunk would leave
   // most of the chip idle)
   if (b->totalCells > maxCells && maxCells > 0) {
@@ -257,7 +260,7 @@ static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &ou
     const PairDesc &pd = b->pairs[p];
     const long long c = (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S;
     if (c > maxCells) {
-      set_error("a single DP matrix (" + std::to_string(c * 8ll * nMatrices) + " bytes) exceeds the device memory budget");
+      set_error("a single DP matrix (" + std::to_string(bytesPerCell > 0.0 ? (long long)((double)c * bytesPerCell) : c * 8ll * nMatrices) + " bytes) exceeds the device memory budget");
       return false;
     }
     if (acc + c > maxCells) { out.push_back({p0, p, acc}); p0 = p; acc = 0; }
@@ -268,10 +271,11 @@ static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &ou
 }
 
 // Upload PairDescs of a chunk with cellBase rebased to the chunk's pool.
-static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_out, std::vector<PairDesc> &tmp) {
+// tbStride > 0: traceback bytes instead of cells -- cellBase = BYTE offset, tbStride bytes per supercell
+static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_out, std::vector<PairDesc> &tmp, int tbStride = 0) {
   tmp.assign(b->pairs.begin() + c.p0, b->pairs.begin() + c.p1);
   long long base = 0;
-  for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S; }
+  for (auto &pd : tmp) { pd.cellBase = base; base += (long long)(pd.inLen + 1) * (pd.outLen + 1) * (tbStride > 0 ? tbStride : b->m->S); }
   MB_HIP(sm_alloc((void **)d_out, tmp.size() * sizeof(PairDesc)));
   if (!hip_ok(hipMemcpyAsync(*d_out, tmp.data(), tmp.size() * sizeof(PairDesc), hipMemcpyHostToDevice, g_stream), "H2D pair descriptors") ||
       !hip_ok(hipStreamSynchronize(g_stream), "H2D pair descriptors")) { sm_free(*d_out); *d_out = nullptr; return 1; }
@@ -288,6 +292,10 @@ struct FastState {
   // silent closure when it stays small, otherwise the exact program of that direction
   MedProgram fwdExact, fwdSum, bwdSum;
   MedGeom geoFE, geoFS, geoBS;
+  // Viterbi with traceback bytes: the exact program itself, or -- when that one splits high-degree states -- an unsplit twin
+  bool tbTried = false, tbOk = false;
+  MedProgram fwdTb;
+  MedGeom geoTb;
   // Forward fill fused with posterior counts (run-time specialised kernel only)
   bool countOk = false;
   MedProgram fwdCnt;
@@ -420,6 +428,19 @@ static bool use_small(mb_machine *m) {
     if (env_int("MB_SMALL", 1)) f->smallOk = small_build(m, false, f->smF) && small_build(m, true, f->smB);
   }
   return f->smallOk;
+}
+
+// the program of the traceback-byte Viterbi sweep of the tiled family (nullptr: the machine keeps the fp64 matrix)
+static MedProgram *medium_tb_program(mb_machine *m, MedGeom **geo) {
+  FastState *f = fast_state(m);
+  if (!f->mediumOk) return nullptr;
+  if (!f->fwdExact.hasSplits) { *geo = &f->geoFE; return medium_tb_eligible(m, f->fwdExact) ? &f->fwdExact : nullptr; }
+  if (!f->tbTried) {
+    f->tbTried = true;
+    f->tbOk = medium_build_unsplit(m, f->G, f->fwdTb, f->geoTb) && medium_tb_eligible(m, f->fwdTb);
+  }
+  *geo = &f->geoTb;
+  return f->tbOk ? &f->fwdTb : nullptr;
 }
 
 static bool use_medium(mb_machine *m) {
@@ -844,6 +865,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
     if (f->mediumOk && !(medium_refresh_weights(m, f->fwdExact) && medium_refresh_weights(m, f->fwdSum) && medium_refresh_weights(m, f->bwdSum))) return 1;
     if (!f->mediumOk && f->exactOk && !medium_refresh_weights(m, f->fwdExact)) return 1;
     if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
+    if (f->tbOk && !medium_refresh_weights(m, f->fwdTb)) return 1;
     if (f->smallOk && !(small_refresh_weights(m, f->smF) && small_refresh_weights(m, f->smB))) return 1;
     f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = true;
   }
@@ -855,7 +877,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (!m) return;
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
-    medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt);
+    medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt); medium_free(f->fwdTb);
     wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_counts_free(f->wCnt);
     small_free(f->smF); small_free(f->smB);
     delete f;
@@ -980,7 +1002,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   g_last_kernel = "";
   if (b->nPairs == 0) return 0;
   mb_machine *m = b->m;
-  if (mode == MB_FORWARD && use_small(m)) return small_forward(b, flags, loglike);
+  if (mode == MB_FORWARD && use_small(m) && small_can_run(((FastState *)m->fast)->smF, SM_SUM, !(flags & MB_ROLLING), b->hasEnv)) return small_forward(b, flags, loglike);
   double *d_ll = nullptr;
   MB_HIP(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)));
   int rc = 0;
@@ -1119,17 +1141,13 @@ int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen
   return (inLen + outLen + 1) * (int64_t)m->nLevF + 1;
 }
 
-int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
-  ApiGuard guard;
-  if (!b || !loglike) { set_error("null argument"); return 1; }
-  g_last_ms = 0.0; g_last_launches = 0;
-  g_last_kernel = "";
+// ViterbiMatrix over a batch on the tiled / generic families.  tb: ONE traceback byte per cell instead of the fp64 matrix (tiled
+// family, run-time specialised kernel; returns -1 before anything was written when that kernel is unavailable).
+static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap, bool tb) {
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
-  if (pathOff) pathOff[0] = 0;
-  if (b->nPairs == 0) return 0;
-  if (use_small(b->m)) return small_viterbi(b, loglike, pathOff, pathEdges, pathCap);
+  const int Sb = medium_tb_stride(b->m->S);
   std::vector<Chunk> chunks;
-  if (!plan_chunks(b, 1, chunks)) return 1;
+  if (!plan_chunks(b, 1, chunks, tb ? (double)Sb / b->m->S + 0.01 : 0.0)) return 1;
   int rc = 0;
   Timer tm;
   long long written = 0;
@@ -1145,13 +1163,25 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
     std::vector<double> hll(np);
     std::vector<PairDesc> hp;
     do {
-      if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!(pool = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
+      if ((rc = upload_chunk_descs(b, c, &d_desc, hp, tb ? Sb : 0))) break;
+      if (!(pool = (double *)ws_get(0, tb ? (size_t)std::max<long long>(c.cells / b->m->S * Sb, 16) : std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       lap("chunk set-up");
       tm.start();
-      if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0, b))) break;
-      if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
+      if (tb) {
+        MedEnv me;
+        if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
+        if ((rc = launch_fill_neg_inf(d_ll, np, g_stream))) break;   // (a pair whose end cell lies in a tile that does not run)
+        MedGeom *tbGeo = nullptr;
+        MedProgram *tbP = medium_tb_program(b->m, &tbGeo);
+        rc = tbP ? medium_viterbi_tb(b->m, *tbP, *tbGeo, d_desc, hp, b->d_in, b->d_out, (unsigned char *)pool, d_ll, g_stream, me) : -1;
+        if (rc < 0 && c.p0 > 0) { set_error("traceback-byte Viterbi kernel became unavailable mid-batch"); rc = 1; }
+        if (rc) break;
+        g_last_kernel = "k_medium_jit";
+      } else {
+        if ((rc = fill_chunk(b->m, MB_VITERBI, d_desc, hp, b->d_in, b->d_out, pool, 0, b))) break;
+        if ((rc = launch_gather_loglike(d_desc, np, pool, b->m->S, 0, d_ll, g_stream))) break;
+      }
       if (wantPaths) {
         for (long long p = 0; p < np; ++p)
           slot[p + 1] = slot[p] + mb_viterbi_path_bound(b->m, b->pairs[c.p0 + p].inLen, b->pairs[c.p0 + p].outLen);
@@ -1160,7 +1190,8 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
         if (!(d_len = (long long *)ws_get(4, np * sizeof(long long)))) { rc = 1; break; }
         if (!(d_path = (uint32_t *)ws_get(5, std::max<long long>(slot[np], 1) * sizeof(uint32_t)))) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
-        if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
+        if (tb) { if ((rc = launch_traceback_bytes(b->m, d_desc, np, b->d_in, b->d_out, (const unsigned char *)pool, Sb, d_ll, d_slot, d_path, d_len, g_stream))) break; }
+        else if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
       }
       lap("launches (host side)");
       g_last_ms += tm.stop();
@@ -1203,17 +1234,33 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   return rc;
 }
 
-// ---- Forward-Backward counts --------------------------------------------------------------------------------
-int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
+int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
   ApiGuard guard;
-  if (!b || !counts) { set_error("null argument"); return 1; }
+  if (!b || !loglike) { set_error("null argument"); return 1; }
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
+  if (pathOff) pathOff[0] = 0;
   if (b->nPairs == 0) return 0;
+  if (use_small(b->m) && small_can_run(((FastState *)b->m->fast)->smF, SM_TB, false, b->hasEnv)) return small_viterbi(b, loglike, pathOff, pathEdges, pathCap);
+  // tiled family: one traceback byte per cell when the machine's exact program allows it
+  MedGeom *tbGeo = nullptr;
+  if (!wide_applicable(b->m) && use_medium(b->m) && env_int("MB_MEDIUM_TB", 1) && medium_tb_program(b->m, &tbGeo) &&
+      traceback_bytes_lds(b->m, medium_tb_stride(b->m->S))) {
+    const int rc = viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, true);
+    if (rc >= 0) return rc;
+    g_last_ms = 0.0; g_last_launches = 0;
+    if (pathOff) pathOff[0] = 0;
+  }
+  return viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, false);
+}
+
+// ---- Forward-Backward counts --------------------------------------------------------------------------------
+// roll: the tiled family's count sweep WITHOUT a Forward matrix (medium_counts_rolling) -- one matrix per pair instead of two,
+// so twice the pairs per chunk; returns -1 before anything was accumulated when that kernel is unavailable
+static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double *loglike, bool roll) {
   const long long nT = b->m->nTrans;
-  if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF, b->hasEnv)) return small_counts(b, counts, loglikeSum, loglike);
   std::vector<Chunk> chunks;
-  if (!plan_chunks(b, 2, chunks)) return 1;
+  if (!plan_chunks(b, roll ? 1 : 2, chunks)) return 1;
   double *d_counts = nullptr, *d_ll = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_counts, std::max<long long>(nT, 1) * sizeof(double)), "hipMalloc(counts)")) return 1;
   if (!hip_ok(sm_alloc((void **)&d_ll, b->nPairs * sizeof(double)), "hipMalloc(loglike)") ||
@@ -1229,7 +1276,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
     std::vector<PairDesc> hp;
     do {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
-      if (!(fwd = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
+      if (!roll && !(fwd = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       if (!(bwd = (double *)ws_get(1, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       long long maxc = 0;
       for (long long p = c.p0; p < c.p1; ++p)
@@ -1239,7 +1286,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       // sequences than CUs leaves most of the chip idle, so the two run side by side on two streams (64 sequences: 64 + 64
       // CUs); the count kernel waits for both.
       bool fwdDone = false;
-      if (!b->hasEnv && wide_applicable(b->m) && g_kernel_choice != 1 && env_int("MB_ONETAPE_CONCURRENT_FILLS", 1)) {
+      if (!roll && !b->hasEnv && wide_applicable(b->m) && g_kernel_choice != 1 && env_int("MB_ONETAPE_CONCURRENT_FILLS", 1)) {
         WideProgram *WB = wide_program(b->m, MB_BACKWARD), *WF = wide_program(b->m, MB_FORWARD);
         hipStream_t s2 = second_stream();
         if (!WB || !WF) { rc = 1; break; }
@@ -1267,7 +1314,16 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
       if (!fwdDone && (rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;
       // fused path: the Forward sweep accumulates the counts while its anti-diagonals are still in LDS
       int fused = -1;
-      if (use_medium(b->m) && fast_state(b->m)->countOk && !(b->hasEnv && wide_applicable(b->m))) {
+      if (roll) {
+        FastState *f = fast_state(b->m);
+        MedEnv me;
+        if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
+        if ((rc = launch_fill_neg_inf(d_ll + c.p0, np, g_stream))) break;   // (a pair whose end cell lies in a tile that does not run)
+        fused = medium_counts_rolling(b->m, f->fwdCnt, f->geoCnt, d_desc, hp, b->d_in, b->d_out, bwd, d_counts, d_ll + c.p0, g_stream, me);
+        if (fused < 0 && c.p0 == 0) { rc = -1; break; }      // kernel unavailable: the caller runs the two-matrix path
+        if (fused) { if (fused < 0) set_error("count sweep kernel became unavailable mid-batch"); rc = 1; break; }
+        g_last_kernel = "k_medium_jit";
+      } else if (use_medium(b->m) && fast_state(b->m)->countOk && !(b->hasEnv && wide_applicable(b->m))) {
         FastState *f = fast_state(b->m);
         MedEnv me;
         if (b->hasEnv) {
@@ -1296,6 +1352,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
     sm_free(d_desc);
     if (rc) break;
   }
+  if (rc < 0) { (void)hipStreamSynchronize(g_stream); sm_free(d_counts); sm_free(d_ll); return -1; }
   if (!rc) {
     std::vector<double> hc(nT), hll(b->nPairs);
     if (nT && !hip_ok(hipMemcpy(hc.data(), d_counts, nT * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) rc = 1;
@@ -1309,6 +1366,22 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   }
   sm_free(d_counts); sm_free(d_ll);
   return rc;
+}
+
+int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
+  ApiGuard guard;
+  if (!b || !counts) { set_error("null argument"); return 1; }
+  g_last_ms = 0.0; g_last_launches = 0;
+  g_last_kernel = "";
+  if (b->nPairs == 0) return 0;
+  if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF, b->hasEnv) && small_can_run(((FastState *)b->m->fast)->smB, SM_SUM, true, b->hasEnv))
+    return small_counts(b, counts, loglikeSum, loglike);
+  if (!wide_applicable(b->m) && use_medium(b->m) && fast_state(b->m)->countOk && env_int("MB_MEDIUM_COUNTS_ROLL", 1)) {
+    const int rc = counts_chunks(b, counts, loglikeSum, loglike, true);
+    if (rc >= 0) return rc;
+    g_last_ms = 0.0; g_last_launches = 0;
+  }
+  return counts_chunks(b, counts, loglikeSum, loglike, false);
 }
 
 // ---- single full matrix -------------------------------------------------------------------------------------
@@ -1325,7 +1398,8 @@ int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const
     const int64_t envOff[2] = {0, outLen + 1};
     if (mb_batch_set_envelopes(b, envOff, envStart, envEnd)) { mb_batch_destroy(b); return 1; }
   }
-  if (startState == 0 && use_small(m)) {
+  if (startState == 0 && use_small(m) &&
+      small_can_run(mode == MB_BACKWARD ? ((FastState *)m->fast)->smB : ((FastState *)m->fast)->smF, mode == MB_VITERBI ? SM_MAX : SM_SUM, true, b->hasEnv)) {
     const int rcs = small_fill(b, mode, cellsOut);
     mb_batch_destroy(b);
     return rcs;
@@ -1361,7 +1435,11 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   m.logW.assign(logWeight, logWeight + nTrans);
   std::string err;
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  // mode: MB_FORWARD sum, MB_VITERBI max, 3 count, 4 max with traceback bytes; + 16: tiles without a matrix (MED_MAT_ROLL; implied by 4)
+  const int matKind = ((mode & 16) || (mode & 15) == MED_MODE_TB) ? MED_MAT_ROLL : MED_MAT_FULL;
+  mode &= 15;
   MedProgram P; MedGeom geo;
+  if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
   if (mode == MED_MODE_COUNT) {
     if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
@@ -1370,7 +1448,9 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     for (const MedRoundInfo &ri : P.roundInfo) { c += (long long)ri.slots.size() + (ri.sync ? 6 : 0); syncs += ri.sync; }
     fprintf(stderr, "[mbhip] program cost %lld (rounds %zu, syncs %d, pairs %d, levels %d)\n", c, P.roundInfo.size(), syncs, P.nPairs, backward ? m.nLevB : m.nLevF);
   }
-  const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD), true);
+  if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
+  if (mode == MED_MODE_TB && !medium_tb_eligible(&m, P)) { set_error("machine does not qualify for traceback bytes on the tiled family"); return 1; }
+  const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MED_MODE_TB ? MED_MODE_TB : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD)), matKind);
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
   fprintf(f, "// G=%d C=%d waves=%d ldsBytes=%zu ldsRecs=%zu rounds=%zu\n", G, geo.C, geo.waves, medium_jit_lds_bytes(P, geo),

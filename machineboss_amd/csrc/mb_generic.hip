@@ -496,6 +496,125 @@ int launch_compact_paths(const uint32_t *d_pathBuf, const long long *d_slotOff, 
   return hip_ok(hipGetLastError(), "path compaction launch") ? 0 : 1;
 }
 
+// DPMatrix::traceBack with selectMaxTrans over ONE TRACEBACK BYTE per cell (tiled family, MED_MODE_TB): byte (i, o, s) =
+// table << 6 | index, the first maximal candidate of the cell in the reference's enumeration order (tables: 0 match, 1 input-
+// only, 2 output-only, 3 silent; index: position in that label's `incoming` list, src/dpmatrix.defs.h:93-103) -- the choice
+// std::max_element makes there.  No candidate is re-evaluated.  One wavefront per pair, four pairs per workgroup sharing the
+// edges (state-major, sorted by label key, so a label's list is contiguous) in LDS.  The bytes of the supercell the walk
+// stands on sit in LDS (silent moves cost no memory access); on arrival the three supercells it can move to are requested
+// at once, so an emitting move waits for at most what is left of one trip to memory after the silent chain in between.
+struct TbEdgeB { uint32_t eid; uint16_t src; uint16_t key; };
+template <int R>
+__global__ __launch_bounds__(256) void k_traceback_bytes(DevMachine m, const PairDesc *__restrict__ pairs, long long nPairs, long long nTrans,
+                                                         const int *__restrict__ inTok, const int *__restrict__ outTok,
+                                                         const unsigned char *__restrict__ tb, int Sb, const double *__restrict__ ll,
+                                                         const long long *__restrict__ slotOff, uint32_t *__restrict__ pathBuf,
+                                                         long long *__restrict__ pathLen) {
+  extern __shared__ unsigned char tbb_raw[];
+  const int S = m.S, K = m.K, NO = m.nOut + 1;
+  TbEdgeB *lEdge = (TbEdgeB *)tbb_raw;                                                  // [nTrans]
+  int *sBeg = (int *)(tbb_raw + (size_t)nTrans * sizeof(TbEdgeB));                      // [S + 1]: first incoming edge of each state
+  unsigned char *cellAll = tbb_raw + ((((size_t)nTrans * sizeof(TbEdgeB) + (size_t)(S + 1) * 4) + 15) & ~(size_t)15);
+  for (int st = threadIdx.x; st <= S; st += blockDim.x) sBeg[st] = m.inOff[(long long)st * K];
+  for (int a = threadIdx.x; a < nTrans; a += blockDim.x) {
+    const uint32_t eid = m.inEid[a];
+    TbEdgeB e; e.eid = eid; e.src = (uint16_t)m.inSrc[a]; e.key = (uint16_t)((int)m.eInTok[eid] * NO + (int)m.eOutTok[eid]);
+    lEdge[a] = e;
+  }
+  __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + wv;
+  if (p >= nPairs) return;
+  if (!(ll[p] > -INFINITY)) { if (lane == 0) pathLen[p] = -1; return; }
+  unsigned char *cellB = cellAll + (size_t)wv * (size_t)(R * 1024);                    // this walk's current supercell
+  const PairDesc pd = pairs[p];
+  const int inLen = pd.inLen, outLen = pd.outLen;
+  const long long I = inLen + 1;
+  const int *in = inTok + pd.inBase, *out = outTok + pd.outBase;
+  const unsigned char *bytes = tb + pd.cellBase;
+  const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  struct SC { u4 r[R]; };
+  auto loadSC = [&](int ci, int co) -> SC {     // clamped, unconditional: cells outside the lattice are never moved into
+    SC c;
+    const unsigned char *q = bytes + ((long long)max(co, 0) * I + max(ci, 0)) * Sb;
+#pragma unroll
+    for (int k = 0; k < R; ++k) c.r[k] = *(const u4 *)(q + min((k * 64 + lane) * 16, Sb - 16));
+    return c;
+  };
+  auto stash = [&](const SC &c) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) if ((k * 64 + lane) * 16 < Sb) *(u4 *)(cellB + (k * 64 + lane) * 16) = c.r[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  int i = inLen, o = outLen, s = S - 1;
+  stash(loadSC(i, o));
+  SC nd = loadSC(i - 1, o - 1), nl = loadSC(i - 1, o), nu = loadSC(i, o - 1);
+  int it = i ? in[i - 1] : 0, ot = o ? out[o - 1] : 0;
+  int itP = i > 1 ? in[i - 2] : 0, otP = o > 1 ? out[o - 2] : 0;
+  long long n = 0;
+  uint32_t held = 0;
+  while (i > 0 || o > 0 || s != 0) {
+    const unsigned code = cellB[s];
+    const int T = (int)(code >> 6), j = (int)(code & 63u);
+    const int want = T == 0 ? it * NO + ot : (T == 1 ? it * NO : (T == 2 ? ot : 0));
+    const int b0 = sBeg[s], b1 = sBeg[s + 1];
+    int a = -1;
+    for (int base = b0; base < b1; base += 64) {       // the label's list is contiguous: its first edge + j
+      const int idx = base + lane;
+      const unsigned long long mask = __ballot(idx < b1 && (int)lEdge[min(idx, b1 - 1)].key == want);
+      if (mask) { a = base + __builtin_ctzll(mask) + j; break; }
+    }
+    if (a < 0 || a >= b1) { if (lane == 0) pathLen[p] = -3; return; }
+    if (n >= cap) { if (lane == 0) pathLen[p] = -2; return; }
+    const TbEdgeB be = lEdge[a];
+    if ((int)(n & 63) == lane) held = be.eid;          // one store per 64 steps (a store counts in vmcnt like a load on gfx9)
+    ++n;
+    if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
+    s = (int)be.src;
+    if (T != 3) {
+      if (T == 0) { stash(nd); --i; --o; it = itP; ot = otP; }
+      else if (T == 1) { stash(nl); --i; it = itP; }
+      else { stash(nu); --o; ot = otP; }
+      nd = loadSC(i - 1, o - 1); nl = loadSC(i - 1, o); nu = loadSC(i, o - 1);
+      itP = i > 1 ? in[i - 2] : 0; otP = o > 1 ? out[o - 2] : 0;
+    }
+  }
+  if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
+  if (lane == 0) pathLen[p] = n;
+}
+
+// bytes of LDS the kernel needs (edges + state offsets + four supercells); 0 = the machine does not fit
+size_t traceback_bytes_lds(const mb_machine *m, int Sb) {
+  if (Sb > 4096 || m->S > 65535 || m->K > 65535) return 0;
+  const int R = Sb <= 1024 ? 1 : (Sb <= 2048 ? 2 : 4);
+  const size_t b = ((((size_t)m->nTrans * sizeof(TbEdgeB) + (size_t)(m->S + 1) * 4) + 15) & ~(size_t)15) + 4 * (size_t)R * 1024;
+  return b <= 150 * 1024 ? b : 0;
+}
+
+int launch_traceback_bytes(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_in, const int *d_out,
+                           const unsigned char *d_tb, int Sb, const double *d_ll, const long long *d_slotOff, uint32_t *d_pathBuf,
+                           long long *d_pathLen, hipStream_t st) {
+  if (nPairs == 0) return 0;
+  const size_t lds = traceback_bytes_lds(m, Sb);
+  if (!lds) { set_error("traceback bytes: machine does not fit the LDS tables"); return 1; }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)&k_traceback_bytes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)&k_traceback_bytes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)&k_traceback_bytes<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const dim3 grid((unsigned)((nPairs + 3) / 4)), block(256);
+  if (Sb <= 1024) hipLaunchKernelGGL(k_traceback_bytes<1>, grid, block, lds, st, m->dev, d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_tb, Sb, d_ll, d_slotOff, d_pathBuf, d_pathLen);
+  else if (Sb <= 2048) hipLaunchKernelGGL(k_traceback_bytes<2>, grid, block, lds, st, m->dev, d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_tb, Sb, d_ll, d_slotOff, d_pathBuf, d_pathLen);
+  else hipLaunchKernelGGL(k_traceback_bytes<4>, grid, block, lds, st, m->dev, d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_tb, Sb, d_ll, d_slotOff, d_pathBuf, d_pathLen);
+  return hip_ok(hipGetLastError(), "traceback (bytes) launch") ? 0 : 1;
+}
+
 int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_in, const int *d_out,
                      const double *d_pool, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen,
                      hipStream_t st) {
@@ -509,8 +628,11 @@ int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPa
                        (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
     return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
   }
-  if (useLds && m->nTrans <= 3584 && m->S <= 8192 && m->K <= 65535 && env_int_g("MB_TRACEBACK_SCAN", 1)) {   // edges (<= 56 KB) + one offset per state
-    hipLaunchKernelGGL(k_traceback_scan, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), (size_t)m->nTrans * sizeof(TbEdgeK) + (size_t)(m->S + 1) * 4, st,
+  const size_t scanBytes = (size_t)m->nTrans * sizeof(TbEdgeK) + (size_t)(m->S + 1) * 4;   // edges (<= 56 KB) + one offset per state
+  if (useLds && m->nTrans <= 3584 && m->S <= 8192 && m->K <= 65535 && env_int_g("MB_TRACEBACK_SCAN", 1)) {
+    static bool attr = false;   // up to 56 KB + 32 KB: beyond the 64 KB a kernel may use without asking
+    if (!attr) { (void)hipFuncSetAttribute((const void *)&k_traceback_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_traceback_scan, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), scanBytes, st,
                        m->dev, d_pairs, nPairs, (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);
     return hip_ok(hipGetLastError(), "traceback launch") ? 0 : 1;
   }

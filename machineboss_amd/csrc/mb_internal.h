@@ -107,6 +107,7 @@ size_t budget_bytes();
 // host -> device copy of a large pageable buffer through pinned staging buffers (a direct hipMemcpy pins fresh pageable
 // pages on the fly, which sporadically costs tens of milliseconds)
 int h2d_large(void *dstDev, const void *src, size_t bytes);
+int launch_fill_neg_inf(double *d, long long n, hipStream_t st);
 #define MB_HIP(call) do { if (!mb::hip_ok((call), #call)) return 1; } while (0)
 
 // host-side machine compiler (mb_machine.cpp)

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 namespace mb {
 
@@ -22,6 +24,18 @@ long long jit_cache_hits() { return g_jit_hits; }
 
 static const char *kOpts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics"};
 static const int kNOpts = 5;
+// MB_JIT_EXTRA_OPTS: further space-separated hiprtc options (compiler experiments: "-mllvm -amdgpu-..."); part of the cache key
+static std::vector<std::string> extra_opts() {
+  std::vector<std::string> v;
+  const char *e = getenv("MB_JIT_EXTRA_OPTS");
+  if (!e) return v;
+  std::string cur;
+  for (const char *p = e;; ++p) {
+    if (*p == ' ' || *p == 0) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; }
+    else cur += *p;
+  }
+  return v;
+}
 
 static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
   const unsigned char *b = (const unsigned char *)p;
@@ -40,6 +54,16 @@ static bool mkdir_p(const std::string &dir) {
   return true;
 }
 
+// A cache directory is used only if it is a real directory (not a symlink) that belongs to this user and that nobody else
+// can write to: a code object is executable GPU code, so a directory somebody else could pre-create (the /tmp fallback)
+// or write into must never be trusted.
+static bool dir_is_private(const std::string &d) {
+  struct stat st;
+  if (lstat(d.c_str(), &st) != 0) return false;
+  return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && access(d.c_str(), W_OK) == 0;
+}
+
+// read on every compile: mb_set_option("MB_JIT_CACHE", "0") or a new MB_JIT_CACHE_DIR takes effect at once
 static std::string cache_dir() {
   const char *off = getenv("MB_JIT_CACHE");
   if (off && *off == '0') return "";
@@ -47,25 +71,40 @@ static std::string cache_dir() {
   if (const char *e = getenv("MB_JIT_CACHE_DIR")) d = e;
   else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/mbhip";
   else if (const char *h = getenv("HOME")) d = std::string(h) + "/.cache/mbhip";
-  if (d.empty() || !mkdir_p(d) || access(d.c_str(), W_OK) != 0) {
+  static std::string validated;      // the last directory that passed (mkdir + ownership check are not repeated for it)
+  if (!d.empty() && d == validated) return d;
+  if (d.empty() || !mkdir_p(d) || !dir_is_private(d)) {
     d = "/tmp/mbhip-cache-" + std::to_string((long long)getuid());
-    if (!mkdir_p(d) || access(d.c_str(), W_OK) != 0) return "";
+    if (d == validated) return d;
+    if (!mkdir_p(d) || !dir_is_private(d)) return "";
   }
+  validated = d;
   return d;
+}
+
+static std::string cache_path(const std::string &src) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return "";
+  unsigned long long h = 1469598103934665603ull;
+  h = fnv1a(src.data(), src.size(), h);
+  for (int k = 0; k < kNOpts; ++k) h = fnv1a(kOpts[k], strlen(kOpts[k]) + 1, h);
+  for (const std::string &o : extra_opts()) h = fnv1a(o.c_str(), o.size() + 1, h);
+  int vmaj = 0, vmin = 0;
+  (void)hiprtcVersion(&vmaj, &vmin);
+  h = fnv1a(&vmaj, sizeof(vmaj), h); h = fnv1a(&vmin, sizeof(vmin), h);
+  char fname[64];
+  snprintf(fname, sizeof(fname), "/%016llx-%zu.co", h, src.size());
+  return dir + fname;
+}
+
+void jit_evict(const std::string &src) {
+  const std::string path = cache_path(src);
+  if (!path.empty()) unlink(path.c_str());
 }
 
 bool jit_compile(const std::string &src, const char *name, std::string &code, std::string *log, bool *fromCache) {
   if (fromCache) *fromCache = false;
-  unsigned long long h = 1469598103934665603ull;
-  h = fnv1a(src.data(), src.size(), h);
-  for (int k = 0; k < kNOpts; ++k) h = fnv1a(kOpts[k], strlen(kOpts[k]) + 1, h);
-  int vmaj = 0, vmin = 0;
-  (void)hiprtcVersion(&vmaj, &vmin);
-  h = fnv1a(&vmaj, sizeof(vmaj), h); h = fnv1a(&vmin, sizeof(vmin), h);
-  static const std::string dir = cache_dir();
-  char fname[64];
-  snprintf(fname, sizeof(fname), "/%016llx-%zu.co", h, src.size());
-  const std::string path = dir.empty() ? "" : dir + fname;
+  const std::string path = cache_path(src);
   if (!path.empty()) {
     if (FILE *f = fopen(path.c_str(), "rb")) {
       fseek(f, 0, SEEK_END);
@@ -82,7 +121,10 @@ bool jit_compile(const std::string &src, const char *name, std::string &code, st
   const auto t0 = std::chrono::steady_clock::now();
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { if (log) *log = "hiprtcCreateProgram failed"; return false; }
-  const hiprtcResult rc = hiprtcCompileProgram(prog, kNOpts, kOpts);
+  const std::vector<std::string> extra = extra_opts();
+  std::vector<const char *> opts(kOpts, kOpts + kNOpts);
+  for (const std::string &o : extra) opts.push_back(o.c_str());
+  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);

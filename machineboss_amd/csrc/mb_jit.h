@@ -8,8 +8,13 @@ namespace mb {
 // Compiles `src` for gfx950 and returns the code object in `code`.  The result is cached on disk under
 // $MB_JIT_CACHE_DIR (default: $XDG_CACHE_HOME/mbhip, ~/.cache/mbhip, else /tmp/mbhip-cache-<uid>), keyed by a hash of the
 // source text, the compile options and the hiprtc version, so that a second process (or a second machine with the same
-// topology and geometry) pays no compile.  MB_JIT_CACHE=0 disables the cache.  *fromCache tells which happened.
+// topology and geometry) pays no compile.  MB_JIT_CACHE=0 disables the cache (both
+// are read on every compile); a directory that is a symlink, belongs to someone else or is group/world-writable is not used.  *fromCache tells which happened.
 bool jit_compile(const std::string &src, const char *name, std::string &code, std::string *log, bool *fromCache);
+
+// Removes the cached code object of `src` (a cached file that hipModuleLoadData rejects -- truncated, or written by another
+// compiler build behind the same version number -- must not latch an error: the caller evicts it and compiles again).
+void jit_evict(const std::string &src);
 
 // cumulative wall-clock milliseconds this process spent inside hiprtc, and the number of compiles / cache hits
 double jit_compile_ms();

@@ -10,6 +10,11 @@ namespace mb {
 constexpr int MED_MAXSLOT = 4;      // candidate slots evaluated together (two-pass max / sum-exp in registers)
 constexpr int MED_DESC_WORDS = 8;   // descriptor words per chunk (32 B, fetched with scalar loads)
 constexpr int MED_MODE_COUNT = 3;   // internal kernel mode: Forward fill (sum) fused with posterior transition counts
+constexpr int MED_MODE_TB = 4;      // internal kernel mode: Viterbi fill (max) that keeps ONE traceback byte per cell instead of the fp64 cell
+// what a tile kernel keeps in HBM (JMAT of the specialised kernel): MED_MAT_NONE = one workgroup sweeps a whole strip, halo
+// columns only; MED_MAT_FULL = tiles + the fp64 matrix; MED_MAT_ROLL = tiles without a matrix (halo columns of the few
+// states other strips read + a boundary record per strip): traceback-byte Viterbi, count sweep, log-likelihood-only Forward
+enum { MED_MAT_NONE = 0, MED_MAT_FULL = 1, MED_MAT_ROLL = 2 };
 constexpr int MED_GEOM_LEVELS = 5;  // strip widths a program is specialised for: its widest, halved 0..4 times
 
 // One candidate of one lane: 16 bytes, fetched with a single global_load_dwordx4.
@@ -61,6 +66,7 @@ struct MedJit {                 // one specialised kernel (per program and semir
 struct MedProgram {
   int G = 0, LPG = 0, NS = 0, Spad = 0, nChunks = 0, nRounds = 0;
   bool backward = false, closure = false;
+  bool hasSplits = false;           // high-degree states were cut into parts + combining nodes (build_program)
   bool counting = false;            // Forward fill + posterior counts program: the upper 16 bits of a record's srcOff hold
                                     // the byte offset of its transition's accumulator in the LDS count array
   int accEntries = 0;               // counting: nTrans accumulators + LPG dummies (padding candidates, one per lane of a group)
@@ -80,12 +86,13 @@ struct MedProgram {
   int regUsed = 0;                      // what the last plan spent of it
   int regBudget = -1;                   // VGPRs medium_jit_plan may spend on loop-invariant records (-1: default)
   int tokWindow = 64;                   // steps per output-token window kept in LDS by the specialised kernel
+  std::vector<int> haloStates;          // states whose values another strip reads (sources of input-consuming candidates), ascending
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
-  // [2 * medium_jit_index(mode) + materialise][MedGeom::level]: sum / max / count, rolling / materialised, and the strip
+  // [(3 * medium_jit_index(mode) + matKind) * 2 + env][MedGeom::level]: sum / max / count / traceback bytes, MED_MAT_*, and the strip
   // width (level h = the program's widest strip halved h times; narrow strips for short input sequences)
-  MedJit jit[12 * MED_GEOM_LEVELS];       // ... x restricted envelopes (MedGeom::env)
+  MedJit jit[24 * MED_GEOM_LEVELS];       // ... x restricted envelopes (MedGeom::env)
 };
 
 // haloSteps > 0: the materialised kernel loads the halo supercells of a whole tile (at most haloSteps steps) into LDS in
@@ -100,6 +107,7 @@ struct MedEnv { const int *d_start = nullptr, *d_end = nullptr, *h_start = nullp
 // host-only part (program, geometry, placement plan, numeric weights): needs no device, used by mb_debug_jit_source
 bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
 bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);
+bool medium_build_unsplit(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
 // exact Forward program whose records also name their transition's count accumulator (see MedProgram::counting)
 bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
 bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
@@ -108,6 +116,11 @@ bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo)
 int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,
                                const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_fwd,
                                const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
+int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs, const std::vector<PairDesc> &pairs,
+                      const int *d_in, const int *d_out, unsigned char *d_tb, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
+int medium_counts_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs, const std::vector<PairDesc> &pairs,
+                          const int *d_in, const int *d_out, const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st,
+                          const MedEnv &env = MedEnv());
 // G = columns (supercells) per wavefront, LPG = 64 / G lanes per supercell.  G = 64 is "one lane per supercell": the
 // mapping for machines with a handful of states (dnapsw, protpsw: 8 states).
 inline bool medium_valid_G(int G) { return G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
@@ -120,13 +133,17 @@ inline int medium_default_G(int S) {   // measured with the specialised kernel: 
 // per wavefront, not 32); the Backward supercell per column in LDS caps the strip at 16 columns for psw2dna (271 states),
 // where 8 wavefronts x 2 columns (133 ms at 64 x 487 x 2 kb) beat 4 x 4 (150) and 16 x 1 (164)
 inline int medium_default_count_G(int S) { return S >= 128 ? std::min(medium_default_G(S), 2) : (S >= 24 ? medium_default_G(S) : 16); }
-inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0); }
+inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : (mode == MED_MODE_TB ? 3 : 0)); }
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);
 long long medium_jit_spill_count(const std::string &codeObject);
-size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo);
-std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool materialise);
+size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode = MB_FORWARD);
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int matKind);
+// traceback bytes of the tiled family: bytes per supercell in HBM (reference order, one byte per state, padded so that a
+// lane stores 16 at a time), and whether the machine's Viterbi sweep can keep them (code = table << 6 | index)
+inline int medium_tb_stride(int S) { return (S + 15) & ~15; }
+bool medium_tb_eligible(const mb_machine *m, const MedProgram &P);
 void medium_free(MedProgram &P);
 // stage boundaries of the next closure programs built (first silent level of stages 2, 3, ...); empty = even level groups
 void medium_set_cuts(const std::vector<int> &cuts);
@@ -136,10 +153,10 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st, const MedEnv &env = MedEnv());
 // run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise);
-inline int medium_jit_slot(int mode, bool materialise, int level, bool env = false) { return ((2 * medium_jit_index(mode) + (materialise ? 1 : 0)) * 2 + (env ? 1 : 0)) * MED_GEOM_LEVELS + level; }
-inline bool medium_jit_ready(const MedProgram &P, int mode, bool materialise) {
-  for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, materialise, h, false)].func || P.jit[medium_jit_slot(mode, materialise, h, true)].func) return true;
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int matKind);
+inline int medium_jit_slot(int mode, int matKind, int level, bool env = false) { return ((3 * medium_jit_index(mode) + matKind) * 2 + (env ? 1 : 0)) * MED_GEOM_LEVELS + level; }
+inline bool medium_jit_ready(const MedProgram &P, int mode, int matKind) {
+  for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, matKind, h, false)].func || P.jit[medium_jit_slot(mode, matKind, h, true)].func) return true;
   return false;
 }
 // strip width for a batch (narrower strips for short input sequences)

@@ -50,6 +50,10 @@ struct MedTileArgs {
   const double *poolB;        // count mode (specialised kernel only): Backward matrices, same layout and cellBase as pool
   double *counts;             // count mode: [nTrans] posterior transition counts, accumulated with fp64 atomics
   const int *envStart, *envEnd;   // restricted envelopes (specialised kernel, JENV variant): rows at PairDesc::envBase
+  // tiles without a matrix (specialised kernel, JMAT == 2): colHalo / haloBase then hold one halo column per strip
+  double *bound;                  // tile-boundary records: the ring state a block hands to the next block of its strip
+  const long long *boundBase;     // per pair offset (doubles)
+  unsigned char *tb;              // Viterbi traceback bytes (MED_MODE_TB), medium_tb_stride(S) per supercell, PairDesc::cellBase = byte offset
 };
 
 #define MED_L2E 1.44269504088896f
@@ -563,6 +567,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   // [S] = -inf sentinel, the e-slots, one dummy entry idle lanes write to.  Even length keeps every column 16-byte
   // aligned; with one or two lanes per supercell the lanes of a wavefront read DIFFERENT columns at the same state
   // offset, and an odd length (stride of 2 x odd LDS banks) makes those reads conflict-free.
+  P.hasSplits = anySplit || anySplitCur;
   P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;
   if (LPG <= 2) P.Spad |= 1;
   P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
@@ -668,12 +673,17 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
             const size_t idx = b0 + (size_t)k * stride + (size_t)tok * LPG + ln;
             if (k == 0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u;
             const int j = c.j0 + k;
-            if (j < (int)tmp.size()) { P.rec[idx].srcOff = (uint32_t)tmp[j].src * 8u; P.wref[idx] = tmp[j].wref; }
+            if (j < (int)tmp.size()) {
+              P.rec[idx].srcOff = (uint32_t)tmp[j].src * 8u; P.wref[idx] = tmp[j].wref;
+              if (c.T < 2) P.haloStates.push_back(tmp[j].src);      // read from the column to the left: crosses a strip boundary
+            }
           }
         }
       }
     }
   }
+  std::sort(P.haloStates.begin(), P.haloStates.end());
+  P.haloStates.erase(std::unique(P.haloStates.begin(), P.haloStates.end()), P.haloStates.end());
   P.nChunks = (int)(P.desc.size() / DW);
   // where the seed goes: the stage-1 destination of the start node
   P.dev.seedOff = 0;
@@ -777,6 +787,23 @@ void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) 
   geo.ldsBytes = (size_t)P.NS * (geo.C + 1) * P.Spad * sizeof(double);
 }
 
+// the exact Forward program with every state's candidates in ONE node (no parts / combining nodes): what the traceback-byte
+// Viterbi sweep needs when the ordinary exact program splits high-degree states (a byte names a candidate of the state itself)
+bool medium_build_unsplit(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
+  build_program(m, false, 0, G, P, /*allowSplit=*/false);
+  if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 24)) return false;
+  MedProgDev &d = P.dev;
+  d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
+  d.nIn = m->nIn; d.nOut = m->nOut; d.startNode = 0; d.endNode = m->S - 1;
+  if (!medium_geometry(m, P, geo)) return false;
+  medium_fit_records(m, P, geo);
+  medium_jit_plan(m, P, geo);
+  medium_eval_weights(m, P);
+  if (!up(P.d_desc, P.desc)) return false;
+  P.dev.desc = P.d_desc;
+  return medium_refresh_weights(m, P);
+}
+
 bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo) {
   if (!medium_build_host(m, backward, closure, G, P, geo)) return false;
   if (!up(P.d_desc, P.desc)) return false;
@@ -872,10 +899,17 @@ static void set_lds_attr() {
 
 // Launch the wavefront of parallelogram tiles of a set of pairs whose first launches (PairDesc::launch0) are given:
 // tile (pair, strip a, block b) runs in launch launch0 + 2a + b.  Builds the dense per-launch tile lists.
+// buffers of a tile sweep that keeps no matrix (MED_MAT_ROLL)
+struct MedRoll {
+  double *halo = nullptr; const long long *haloBase = nullptr;     // one halo column per strip: [NA][outLen + 1][max(H, 1)]
+  double *bound = nullptr; const long long *boundBase = nullptr;   // one boundary record per strip: [NA][NS - 1][C][S]
+  unsigned char *tb = nullptr;                                     // MED_MODE_TB: traceback bytes (PairDesc::cellBase = byte offset)
+};
+
 static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev &devIn, const MedGeom &geo, int mode, int TS,
                             const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
                             double *d_pool, double *d_loglike, hipStream_t st, const double *d_poolB = nullptr,
-                            double *d_counts = nullptr, const MedEnv &env = MedEnv()) {
+                            double *d_counts = nullptr, const MedEnv &env = MedEnv(), int matKind = MED_MAT_FULL, const MedRoll *roll = nullptr) {
   const int C = geo.C;
   const long long n = (long long)pairs.size();
   int nLaunch = 0;
@@ -918,20 +952,23 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
       const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
       liveTiles(pd, live);
       for (int a = 0; a < NA; ++a)
-        for (int b = 0; b < NB; ++b) if (live[(size_t)a * NB + b]) tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a);
+        for (int b = 0; b < NB; ++b)
+          if (live[(size_t)a * NB + b])   // (bit 30 of the strip: the block before this one did not run -- a tile without a matrix then starts from -inf instead of its boundary record)
+            tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a | ((matKind == MED_MAT_ROLL && b > 0 && !live[(size_t)a * NB + b - 1]) ? (1 << 30) : 0));
     }
   }
   int2 *d_tiles = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int2)), "hipMalloc(tile list)")) return 1;
   if (!tiles.empty() && h2d_large(d_tiles, tiles.data(), tiles.size() * sizeof(int2))) { sm_free(d_tiles); return 1; }   // staged: see h2d_large
-  const MedJit *J = medium_jit_get(m, P, geo, mode, true) ? &P.jit[medium_jit_slot(mode, true, geo.level, geo.env)] : nullptr;
-  if ((mode == MED_MODE_COUNT || geo.env) && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for the count mode or for envelopes
+  const MedJit *J = medium_jit_get(m, P, geo, mode, matKind) ? &P.jit[medium_jit_slot(mode, matKind, geo.level, geo.env)] : nullptr;
+  if ((mode == MED_MODE_COUNT || mode == MED_MODE_TB || matKind == MED_MAT_ROLL || geo.env) && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for these
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
   A.poolB = d_poolB; A.counts = d_counts; A.envStart = env.d_start; A.envEnd = env.d_end;
+  if (roll) { A.colHalo = roll->halo; A.haloBase = roll->haloBase; A.bound = roll->bound; A.boundBase = roll->boundBase; A.tb = roll->tb; }
   const dim3 block(geo.waves * 64);
   for (int l = 0; l < nLaunch; ++l) {
     if (cnt[l] <= 0) continue;
@@ -1006,11 +1043,77 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
   if (pairsIn.empty()) return 0;
   MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
   geo.env = env.d_start != nullptr;
-  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, true)) return -1;
+  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, MED_MAT_FULL)) return -1;
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   return launch_wavefront(m, P, P.dev, geo, MED_MODE_COUNT, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, d_fwd,
                           d_loglike, st, d_bwd, d_counts, env);
+}
+
+// Halo columns and boundary records of a set of pairs for a tile sweep without a matrix, in workspaces 11 / 12.
+static int roll_buffers(const MedProgram &P, const MedGeom &geo, const std::vector<PairDesc> &pairs, bool env, hipStream_t st, MedRoll &R,
+                        long long **d_bases) {
+  const long long n = (long long)pairs.size(), H = std::max<long long>((long long)P.haloStates.size(), 1);
+  std::vector<long long> base(2 * n);
+  long long haloD = 0, boundD = 0;
+  for (long long p = 0; p < n; ++p) {
+    const long long NA = (pairs[p].inLen + geo.C) / geo.C;
+    base[p] = haloD; base[n + p] = boundD;
+    haloD += NA * (pairs[p].outLen + 1) * H;
+    boundD += NA * (P.NS - 1) * geo.C * P.dev.S;
+  }
+  if (!hip_ok(sm_alloc((void **)d_bases, 2 * n * sizeof(long long)), "hipMalloc(roll bases)")) return 1;
+  if (!hip_ok(hipMemcpyAsync(*d_bases, base.data(), 2 * n * sizeof(long long), hipMemcpyHostToDevice, st), "H2D roll bases") ||
+      !hip_ok(hipStreamSynchronize(st), "H2D roll bases")) return 1;   // (`base` is a pageable host vector)
+  R.halo = (double *)ws_get(11, (size_t)std::max<long long>(haloD, 1) * sizeof(double));
+  R.bound = (double *)ws_get(12, (size_t)std::max<long long>(boundD, 1) * sizeof(double));
+  if (!R.halo || !R.bound) return 1;
+  R.haloBase = *d_bases; R.boundBase = *d_bases + n;
+  if (env && launch_fill_neg_inf(R.halo, haloD, st)) return 1;   // halo rows of tiles that do not run
+  return 0;
+}
+
+// ViterbiMatrix::fill (src/viterbi.cpp:18-43) keeping ONE traceback byte per cell instead of the fp64 cell (1 B per
+// cell): tiles without a matrix, scores of the end cells in d_loglike.  pairs[].cellBase = BYTE offset of the pair's bytes in d_tb
+// (medium_tb_stride(S) per supercell, reference order).  Returns -1 (nothing launched) when the specialised kernel is unavailable.
+int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn,
+                      const int *d_in, const int *d_out, unsigned char *d_tb, double *d_loglike, hipStream_t st, const MedEnv &env) {
+  if (pairsIn.empty()) return 0;
+  if (!medium_tb_eligible(m, P)) return -1;
+  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  geo.env = env.d_start != nullptr; geo.haloSteps = 0;
+  // the byte vectors of a step (one per column) need LDS the widest strip does not leave: columns are given up, one wavefront
+  // at a time, until they fit (psw2dna: 32 -> 28 columns); the same rule for every batch, so a strip level maps to one kernel
+  while (geo.waves > 1 && medium_jit_lds_bytes(P, geo, MED_MODE_TB) > 160 * 1024) { --geo.waves; geo.C = geo.waves * P.G; }
+  if (!medium_jit_get(m, P, geo, MED_MODE_TB, MED_MAT_ROLL)) return -1;
+  std::vector<PairDesc> pairs = pairsIn;
+  for (PairDesc &pd : pairs) pd.launch0 = 0;
+  MedRoll R; long long *d_bases = nullptr;
+  int rc = roll_buffers(P, geo, pairs, geo.env, st, R, &d_bases);
+  R.tb = d_tb;
+  if (!rc) rc = launch_wavefront(m, P, P.dev, geo, MED_MODE_TB, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, nullptr,
+                                 d_loglike, st, nullptr, nullptr, env, MED_MAT_ROLL, &R);
+  sm_free(d_bases);
+  return rc;
+}
+
+// Forward sweep fused with MachineCounts accumulation that keeps NO Forward matrix (src/backward.cpp:58-87 needs F(i,o,src) only
+// while the supercell is in LDS): the Backward matrices are read once, nothing else moves -- 16 B per lattice cell with the
+// Backward fill.  Returns -1 when the specialised kernel is unavailable.
+int medium_counts_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn,
+                          const int *d_in, const int *d_out, const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st, const MedEnv &env) {
+  if (pairsIn.empty()) return 0;
+  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  geo.env = env.d_start != nullptr; geo.haloSteps = 0;
+  if (!P.counting || !medium_jit_get(m, P, geo, MED_MODE_COUNT, MED_MAT_ROLL)) return -1;
+  std::vector<PairDesc> pairs = pairsIn;
+  for (PairDesc &pd : pairs) pd.launch0 = 0;
+  MedRoll R; long long *d_bases = nullptr;
+  int rc = roll_buffers(P, geo, pairs, geo.env, st, R, &d_bases);
+  if (!rc) rc = launch_wavefront(m, P, P.dev, geo, MED_MODE_COUNT, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, nullptr,
+                                 d_loglike, st, d_bwd, d_counts, env, MED_MAT_ROLL, &R);
+  sm_free(d_bases);
+  return rc;
 }
 
 // Materialised Forward over a whole batch when only the log-likelihoods are kept (ForwardMatrix(...).logLike()):
@@ -1093,7 +1196,7 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = nullptr; A.colHalo = d_colHalo; A.haloBase = d_haloBase;
   A.loglike = d_loglike; A.C = C; A.TS = maxOut + C + 1; A.rev = 0; A.materialise = 0; A.tiles = nullptr; A.tileBase = 0;
   const dim3 grid((unsigned)pairs.size()), block(geo.waves * 64);
-  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, false) ? &P.jit[medium_jit_slot(MB_FORWARD, false, geo.level)] : nullptr;
+  const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_NONE) ? &P.jit[medium_jit_slot(MB_FORWARD, MED_MAT_NONE, geo.level)] : nullptr;
   MedProgDev dev = P.dev;
   dev.ldsImageRecs = (int)P.ldsImageIdx.size();
   for (int a = 0; a < NA; ++a) {

@@ -45,8 +45,26 @@ static size_t count_bytes(const MedProgram &P, const MedGeom &geo) {
 
 static size_t halo_bytes(const MedProgram &P, const MedGeom &geo) { return (size_t)geo.haloSteps * P.dev.S * sizeof(double); }
 
-size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo) {
-  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo);
+// traceback-byte Viterbi: one byte vector per column (the step's codes, copied out 16 bytes per lane), + alignment slack
+static int tb_lds_stride(const MedProgram &P) { return (P.Spad + 15) & ~15; }
+static size_t tb_bytes(const MedProgram &P, const MedGeom &geo, int mode) { return mode == MED_MODE_TB ? (size_t)geo.C * tb_lds_stride(P) + 16 : 0; }
+
+size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode) {
+  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo) + tb_bytes(P, geo, mode);
+}
+
+// Traceback bytes: code = table << 6 | index of the candidate in its table's list, so a state may have at most 64
+// candidates per table (any machine with a larger fan-in keeps the fp64 Viterbi matrix); a silent self-loop on state 0 --
+// the one non-advancing transition the reference lets through -- is a candidate of its traceback but not of the fill.
+bool medium_tb_eligible(const mb_machine *m, const MedProgram &P) {
+  if (P.closure || P.backward || P.counting || P.hasSplits) return false;
+  for (long long e = 0; e < m->nTrans; ++e)
+    if (m->inTok[e] == 0 && m->outTok[e] == 0 && m->dst[e] <= m->src[e]) return false;
+  for (const MedRoundInfo &ri : P.roundInfo) {
+    int perT[4] = {0, 0, 0, 0};
+    for (const MedSlotInfo &sl : ri.slots) if (++perT[sl.T] > 64) return false;
+  }
+  return true;
 }
 
 // Decide where every slot's records live (see the file header).  Deterministic in (program, geometry).
@@ -61,7 +79,9 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
   P.tokWindow = 64;
   const int LPG = P.LPG;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
-  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo) - (long long)halo_bytes(P, geo);
+  // (the traceback-byte vectors of MED_MODE_TB share the plan of the program's other kernels: reserved whenever they could be used)
+  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo) - (long long)halo_bytes(P, geo)
+                      - ((!P.closure && !P.backward && !P.counting) ? (long long)tb_bytes(P, geo, MED_MODE_TB) : 0);
   int regFree = P.regBudget;                               // VGPRs for loop-invariant records (3 per record, +1 per round)
   if (P.Spad * 8 >= (1 << 16)) regFree = 0;
   for (MedRoundInfo &ri : P.roundInfo) for (MedSlotInfo &sl : ri.slots) { sl.place = MED_PLACE_GLOBAL; sl.ldsOff = 0; }
@@ -115,21 +135,27 @@ long long medium_jit_spill_count(const std::string &code) {
   return -1;
 }
 
-std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
+std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int matKind) {
   std::ostringstream defs, pre, body, post;
   const int S = m->S;
-  const bool counting = mode == MED_MODE_COUNT;
+  const bool counting = mode == MED_MODE_COUNT, tbmode = mode == MED_MODE_TB, maxmode = mode == MB_VITERBI || tbmode;
+  const bool materialise = matKind == MED_MAT_FULL;
   const int threads = geo.waves * 64;
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
-       << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
+       << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (maxmode ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
        << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
-       << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0)
-       << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << (materialise ? 1 : 0) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
+       << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0) << "\n#define JSTDEFER " << (materialise ? env_int("MB_JIT_STORE_DEFER", 0) : 0)
+       << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << matKind << "\n#define JTB " << (tbmode ? 1 : 0) << "\n#define JTBS " << tb_lds_stride(P) << "\n#define JSB " << medium_tb_stride(S)
+       << "\n#define JNH " << P.haloStates.size() << "\n#define JNHP " << std::max<size_t>(P.haloStates.size(), 1)
+       << "\n#define JNHR " << std::max<size_t>((P.haloStates.size() + threads - 1) / threads, 1) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
        << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
        << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
        << "\n#define JDUMMYOFF " << P.dummyOff << "\n#define JHALO " << (S + threads - 1) / threads << "\n";
+  defs << "__device__ const int jHaloState[] = {";   // states whose values cross a strip boundary (halo rows of JMAT == 2)
+  for (size_t k = 0; k < std::max<size_t>(P.haloStates.size(), 1); ++k) defs << (k ? "," : "") << (k < P.haloStates.size() ? P.haloStates[k] : 0);
+  defs << "};\n#define JHSTATE(k) jHaloState[k]\n";
   static const char *vec[4] = {"aDiag", "aLeft", "aDown", "aCur"};
   static const char *tok[4] = {"tokM16", "itOff16", "otOff16", "q16"};
   for (size_t r = 0; r < P.roundInfo.size(); ++r) {
@@ -162,7 +188,24 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         body << "        cnt_add(ldsb, accBase + (" << name << ".srcOff >> 16), v" << k << " + bl);\n";
     };
     std::vector<std::string> nm(n);
-    if (n <= JIT_MAX_CANDS) {
+    if (tbmode) {
+      // max semiring with the index of the FIRST maximal candidate: slots come table by table (match, input-only, output-only,
+      // same-cell) and inside a table in the reference's list order, which is its enumeration order (src/dpmatrix.defs.h:93-103);
+      // strict > keeps the first maximum like std::max_element.  code = table << 6 | index in the table's list.
+      int perT[4] = {0, 0, 0, 0};
+      for (int k = 0; k < n; ++k) nm[k] = rec(k);
+      for (int k = 0; k < n; ++k)
+        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+      body << "        double res = v0; unsigned x = " << ((ri.slots[0].T << 6) | 0) << "u;\n";
+      perT[ri.slots[0].T] = 1;
+      for (int k = 1; k < n; ++k) {
+        const int code = (ri.slots[k].T << 6) | perT[ri.slots[k].T]++;
+        body << "        { const bool g = v" << k << " > res; res = g ? v" << k << " : res; x = g ? " << code << "u : x; }\n";
+      }
+      body << "        const int dOff = (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF);\n";
+      body << "        *(double *)(ldsb + (aCur + dOff)) = JCLIP(res);\n";
+      body << "        tbCol[dOff >> 3] = (unsigned char)x;\n";
+    } else if (n <= JIT_MAX_CANDS) {
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
       for (int k = 0; k < n; ++k)
         body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
@@ -171,7 +214,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       } else {
         body << "        double mx = dmax(v0, v1);\n";
         for (int k = 2; k < n; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
-        if (mode == MB_VITERBI) body << "        const double res = mx;\n";
+        if (maxmode) body << "        const double res = mx;\n";
         else {
           body << "        const double gM = (mx == NEG_INF) ? 0.0 : mx;\n        const float sm = ex2(v0 - gM)";
           for (int k = 1; k < n; ++k) body << " + ex2(v" << k << " - gM)";
@@ -199,7 +242,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         }
         body << "        double mx = v" << k0 << ";\n";
         for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
-        if (mode == MB_VITERBI) body << "        accM = dmax(accM, mx);\n";
+        if (maxmode) body << "        accM = dmax(accM, mx);\n";
         else {
           body << "        const double nm = dmax(accM, mx), gM = (nm == NEG_INF) ? 0.0 : nm;\n        accS = accS * ex2(accM - gM)";
           for (int k = k0; k < k1; ++k) body << " + ex2(v" << k << " - gM)";
@@ -207,12 +250,13 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         }
         body << "        }\n";
       }
-      if (mode == MB_VITERBI) body << "        const double res = accM;\n";
+      if (maxmode) body << "        const double res = accM;\n";
       else body << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
       body << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
     }
     body << "      }\n";
     if (ri.sync) body << "      med_wave_sync();\n";
+    if (r == 0 && materialise && env_int("MB_JIT_STORE_DEFER", 0) == 2) body << "      JSTORE_PENDING();\n";
   }
   std::string src = kMedJitSkeleton;
   auto replace = [&](const std::string &mark, const std::string &with) {
@@ -226,8 +270,11 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   return src;
 }
 
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, bool materialise) {
-  MedJit &J = P.jit[medium_jit_slot(mode, materialise, geo.level, geo.env)];
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, int mode, int matKind) {
+  MedGeom geo = geoIn;
+  if (matKind != MED_MAT_FULL) geo.haloSteps = 0;   // only the matrix kernel pre-loads a tile's halo supercells
+  const bool materialise = matKind == MED_MAT_FULL;
+  MedJit &J = P.jit[medium_jit_slot(mode, matKind, geo.level, geo.env)];
   if (J.tried) return J.func != nullptr;
   if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;
@@ -240,21 +287,22 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
   }
   if (totalSlots > 20000) return false;
   if (P.roundInfo.size() > 4096) return false;   // keep the generated code within reach of the instruction cache
-  std::string code;
+  std::string code, src;
+  bool fromCache = false;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    J.ldsBytes = medium_jit_lds_bytes(P, geo) - (materialise ? 0 : halo_bytes(P, geo));   // the rolling kernel has no halo tile
+    J.ldsBytes = medium_jit_lds_bytes(P, geo, mode);
     if (J.ldsBytes > 160 * 1024) return false;
-    const std::string src = medium_jit_source(m, P, geo, mode, materialise);
+    src = medium_jit_source(m, P, geo, mode, matKind);
     if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
-      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : ".sum")) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+      if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : (mode == MED_MODE_TB ? ".tb" : ".sum"))) + (materialise ? ".mat" : (matKind == MED_MAT_ROLL ? ".tiles" : ".roll")) + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     std::string log;
-    if (!jit_compile(src, "mb_medium_jit.hip", code, &log, nullptr)) {
+    if (!jit_compile(src, "mb_medium_jit.hip", code, &log, &fromCache)) {
       if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
       return false;
     }
     const long long spills = medium_jit_spill_count(code);
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : "sum"), P.regBudget, spills);
+    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : (mode == MED_MODE_TB ? "max+tb" : "sum")), P.regBudget, spills);
     if (spills <= 0 || P.regBudget == 0) break;
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.
@@ -269,7 +317,13 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int 
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+    // a cached code object the loader rejects (truncated file, other compiler build): drop it and compile afresh, once
+    std::string log;
+    mod = nullptr;
+    if (fromCache) { jit_evict(src); if (!jit_compile(src, "mb_medium_jit.hip", code, &log, nullptr) || hipModuleLoadData(&mod, code.data()) != hipSuccess) mod = nullptr; }
+    if (!mod) return false;
+  }
   if (hipModuleGetFunction(&fn, mod, "k_medium_jit") != hipSuccess) { (void)hipModuleUnload(mod); return false; }
   (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   J.module = mod; J.func = fn;

@@ -40,7 +40,16 @@ struct MedTileArgs {
   const double *poolB;
   double *counts;
   const int *envStart, *envEnd;
+  double *bound;                // JMAT == 2: tile-boundary records (ring state a block hands to the next block of its strip)
+  const long long *boundBase;   //            per pair offset (doubles); strip a's record follows at a * (JNS - 1) * JC * JS
+  unsigned char *tb;            // JTB: Viterbi traceback bytes, JSB per supercell, reference order; PairDesc::cellBase = byte offset
 };
+// JMAT: 0 = one workgroup sweeps a whole strip, no matrix (halo columns in colHalo); 1 = tiles, matrix in `pool` (the ring
+// state of a tile's first steps and the halo supercells are read back from it); 2 = tiles WITHOUT a matrix: halo columns
+// (JNH states per row: the sources of input-consuming transitions) in colHalo, one column per strip, and the ring state at
+// a block boundary in `bound` -- what Viterbi with traceback bytes and the count sweep use (nothing but the bytes / the
+// Backward matrix moves through HBM).
+#define JTILES (JMAT != 0)
 #if JENV
 #define JCLIP(x) (inside ? (x) : NEG_INF)      // cells outside the pair's envelope stay -inf (src/dpmatrix.defs.h:36, dpmatrix.h:142-144)
 #define JINSIDE inside
@@ -116,8 +125,10 @@ __device__ __forceinline__ void med_copy_out(double *dstp, const double *cur, in
 // generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
 __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
                                                 int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
-                                                unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL) {
+                                                unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL, int tbCol) {
   double accM = NEG_INF; float accS = 0.0f;
+  unsigned code = 0u, prevT = 99u, jT = 0u;   // JTB: (table << 6 | index in the table's list) of the first maximal candidate
+  (void)code; (void)prevT; (void)jT; (void)tbCol;
   for (int ch = 0; ch < nChunks; ++ch) {
     cdesc_t dp = desc + ch * 8;
     const int hdr = dp[0];
@@ -126,16 +137,26 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
     unsigned dstOff = 0xFFFFFFFFu;
     const int vecBase = myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride);
     const int idx0 = (int)__umul24(it, dp[2]) + (int)__umul24(ot, dp[3] & 0xFFFFFF) + dp[1] + q;
+    const unsigned Tsel = (unsigned)dp[3] >> 24;
+    if (first || Tsel != prevT) jT = 0u;
+    prevT = Tsel;
     for (int k = 0; k < ns; ++k) {
       const Rec r = mk_rec(grec[idx0 + k * dp[4]]);
+      bool firstCand = false;
       if (k == 0) {
         dstOff = r.dstOff;
         if (first) {
           const bool seed = origin && dstOff == seedOff;
           accM = seed ? 0.0 : NEG_INF; accS = seed ? 1.0f : 0.0f;
+          firstCand = true;
         }
       }
       const double v = med_lds(ldsb, vecBase + SRCOFF(r.srcOff)) + r.w;
+#if JTB
+      { const bool take = firstCand || v > accM; code = take ? ((Tsel << 6) | jT) : code; }   // strict >: the FIRST maximum, as std::max_element (src/dpmatrix.defs.h:171-174)
+      ++jT;
+#endif
+      (void)firstCand;
 #if JMODE == 2
       {  // every chunk's slot-0 record names the lane's destination state
         const double bl = (lanesOn && (int)dstOff >= 0) ? (med_lds(ldsb, aB + (int)dstOff) + negLL) : NEG_INF;
@@ -152,6 +173,9 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
     if (last) {
       const double res = (JMODE == 1) ? accM : ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
       if (lanesOn && (int)dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)dstOff)) = res;
+#if JTB
+      if (lanesOn && (int)dstOff >= 0) *(unsigned char *)(ldsb + (tbCol + (int)(dstOff >> 3))) = (unsigned char)code;
+#endif
     }
     if (sync) med_wave_sync();
   }
@@ -163,12 +187,14 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
   int pairIdx, a;
-  if (JMAT) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y; }
+  bool prevDead = false;      // JMAT == 2 with envelopes: the block before this one holds no cell of the envelope and did not run
+  if (JTILES) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y & 0x3fffffff; prevDead = (tl.y >> 30) & 1; }
   else { pairIdx = blockIdx.x; a = A.launch; }
+  (void)prevDead;
   const PairDesc pd = A.pairs[pairIdx];
   const int inLen = pd.inLen, outLen = pd.outLen;
   const long long I = inLen + 1;
-  const int b = JMAT ? A.launch - pd.launch0 - 2 * a : 0;
+  const int b = JTILES ? A.launch - pd.launch0 - 2 * a : 0;
   const int NA = (inLen + C) / C;
   const int T = outLen + C;
   if (a >= NA || b < 0 || (long long)b * A.TS >= T) return;
@@ -180,14 +206,30 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   const int *in = A.inTok + pd.inBase, *out = A.outTok + pd.outBase;
   const int rev = A.rev;
   const int it = (colValid && i > 0) ? (rev ? in[inLen - i] : in[i - 1]) : 0;
-  double *cells = JMAT ? A.pool + pd.cellBase : nullptr;
+  double *cells = JMAT == 1 ? A.pool + pd.cellBase : nullptr;
   double *haloIn = nullptr, *haloOut = nullptr;
-  if (!JMAT) {
+  if (JMAT == 0) {
     double *hb = A.colHalo + A.haloBase[pairIdx];
     const long long hsz = (long long)(outLen + 1) * S;
     haloIn = hb + ((a + 1) & 1) * hsz;
     haloOut = hb + (a & 1) * hsz;
   }
+#if JMAT == 2
+  {   // one halo column per strip: row o holds the JNH states other strips read, written by the strip's last column
+    double *hb = A.colHalo + A.haloBase[pairIdx];
+    const long long hsz = (long long)(outLen + 1) * JNHP;
+    haloIn = hb + (long long)max(a - 1, 0) * hsz;
+    haloOut = hb + (long long)a * hsz;
+  }
+  double *bnd = A.bound + A.boundBase[pairIdx] + (long long)a * ((NS - 1) * C * S);
+  // the states this thread moves between a halo row and column 0 of the ring: entries tid, tid + NT, ... of the row
+  int myHS[JNHR];
+#pragma unroll
+  for (int k = 0; k < JNHR; ++k) myHS[k] = JHSTATE(min(tid + k * NT, JNHP - 1));
+#endif
+#if JTB
+  unsigned char *tbPair = A.tb + pd.cellBase;
+#endif
   auto cellPtr = [&](int ci, int co) -> double * {
     const long long ri = rev ? inLen - ci : ci, ro = rev ? outLen - co : co;
     return cells + (ro * I + ri) * S;
@@ -199,6 +241,10 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
   int *envSW = tokWin + 2 * (W + C), *envEW = envSW + 2 * (W + C);   // envelope rows (inStart, inEnd) of the same windows (JENV)
   (void)envSW; (void)envEW;
+#if JTB
+  unsigned char *tbL = (unsigned char *)((((unsigned long long)(tokWin + 6 * (W + C))) + 15ull) & ~15ull);   // traceback bytes of this step's supercells: [C][JTBS], 16-byte aligned
+  for (int j = tid; j < C * JTBS / 4; j += NT) ((unsigned int *)tbL)[j] = 0u;
+#endif
 #if JMODE == 2
   // count mode: the Backward supercell of every column (this step's) and the count accumulators of the workgroup
   double *bvec = (double *)(tokWin + 6 * (W + C));
@@ -255,10 +301,26 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       const int cc = col - 1, ci = i0 + cc, co = tp - cc;
       if (ci < 0 || ci > inLen || co < 0 || co > outLen) continue;
       const double *src = nullptr;
-      if (JMAT) src = cellPtr(ci, co);
-      else if (cc == -1) src = haloIn + (long long)co * S;
+      if (JMAT == 1) src = cellPtr(ci, co);
+      else if (JMAT == 0 && cc == -1) src = haloIn + (long long)co * S;
       if (src) ring(slot, col)[j] = src[j];
     }
+#if JMAT == 2
+    // columns of the strip: the boundary record block b - 1 left behind (cells outside the lattice hold what the ring held:
+    // never read by a cell inside it); column 0: the halo rows of steps t0 - 1 (and t0 - 2)
+    if (b > 0 && !prevDead)
+      for (int idx = tid; idx < C * S; idx += NT) {
+        const int cc = idx / S, j = idx - cc * S;
+        ring(slot, cc + 1)[j] = bnd[(long long)(dt - 1) * C * S + idx];
+      }
+    {
+      const int co = tp + 1;
+      if (i0 > 0 && co >= 0 && co <= outLen) {
+#pragma unroll
+        for (int k = 0; k < JNHR; ++k) if (tid + k * NT < JNH) ring(slot, 0)[myHS[k]] = haloIn[(long long)co * JNHP + tid + k * NT];
+      }
+    }
+#endif
   }
   __syncthreads();
 
@@ -287,8 +349,23 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   constexpr int aB = 0; constexpr unsigned accBase = 0; constexpr double negLL = 0.0;
   (void)aB; (void)accBase; (void)negLL;
 #endif
+#if JTB
+  const int tbColOff = (int)((const char *)tbL - ldsb) + c * JTBS;
+#else
+  constexpr int tbColOff = 0;
+#endif
   // ---- loop-invariant candidate records (placement REG): one load per sweep, kept in VGPRs --------------------------
 /*@PRE@*/
+#if JSTDEFER
+  // EXPERIMENT (MB_JIT_STORE_DEFER): a finished supercell leaves LDS for REGISTERS at the end of its step and for HBM during
+  // the next one (1: at its top, 2: behind its first round), so that no LDS read stands between a step's rounds and its stores
+  constexpr int JSREG = (S + LPG - 1) / LPG;
+  double sreg[JSREG];
+  double *sdst = nullptr;
+#define JSTORE_PENDING() do { if (sdst) { _Pragma("unroll") for (int k_ = 0; k_ < JSREG; ++k_) { const int j_ = k_ * LPG + q; if (j_ < S) sdst[j_] = sreg[k_]; } sdst = nullptr; } } while (0)
+#else
+#define JSTORE_PENDING() do { } while (0)
+#endif
   int slotCur = t0 % NS;
   for (int t = t0; t < t1; ++t) {
     const int o = t - c;
@@ -321,7 +398,11 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     // is no halo): a conditionally initialised register would make the compiler wait for every outstanding memory
     // operation -- the previous step's stores included -- before overwriting it.
     const bool wantHalo = (i0 > 0) && (t + 1 <= outLen);
-#if JHALOT == 0
+#if JMAT == 2
+    double hvr[JNHR];
+#pragma unroll
+    for (int k = 0; k < JNHR; ++k) hvr[k] = haloIn[(long long)min(t + 1, outLen) * JNHP + min(tid + k * NT, JNHP - 1)];
+#elif JHALOT == 0
     double hv[JHALO];
     {
       const int hi = i0 > 0 ? i0 - 1 : 0, ho = min(t + 1, outLen);
@@ -339,15 +420,21 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       for (int k = 0; k < JBV; ++k) bpre[k] = bs[min(k * LPG + q, S - 1)];
     }
 #endif
+#if JSTDEFER == 1
+    JSTORE_PENDING();
+#endif
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
-                                      P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL);
+                                      P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff);
     } else {
       // LDS byte addresses of the four vectors this lane's column reads / writes
       const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
       const unsigned otOff16 = (unsigned)(ot * LPG + q) * 16u;
       const unsigned tokM16 = (unsigned)((it * (JNOUT + 1) + ot) * LPG + q) * 16u;
       (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
+#if JTB
+      unsigned char *tbCol = tbL + c * JTBS;
+#endif
 /*@BODY@*/
     }
     med_wave_sync();
@@ -367,6 +454,12 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #pragma unroll
     for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = bpre[k]; }
 #endif
+#if JMAT == 2
+    if (wantHalo) {
+#pragma unroll
+      for (int k = 0; k < JNHR; ++k) if (tid + k * NT < JNH) ring(slotCur, 0)[myHS[k]] = hvr[k];
+    }
+#else
     if (wantHalo) {
       double *hd = ring(slotCur, 0);
 #pragma unroll
@@ -379,19 +472,55 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
       }
     }
+#endif
     const double *cur = (const double *)(ldsb + (myColBase + sCur));
     if (active) {
-      if (JMAT) {
+#if JMAT == 1 && JSTDEFER
+      {
+        JSTORE_PENDING();      // (step t0 of strip 0 runs the generic path: nothing was flushed inside it)
+        sdst = cellPtr(i, o);
+#pragma unroll
+        for (int k = 0; k < JSREG; ++k) { const int j = k * LPG + q; sreg[k] = cur[min(j, S - 1)]; }
+      }
+#elif JMAT == 1
+      {
         double *dstp = cellPtr(i, o);
         med_copy_out(dstp, cur, q);
-      } else if (c == C - 1) {
-        med_copy_out(haloOut + (long long)o * S, cur, q);
       }
+#elif JMAT == 0
+      if (c == C - 1) med_copy_out(haloOut + (long long)o * S, cur, q);
+#else
+      if (c == C - 1 && a + 1 < NA)
+        for (int k = q; k < JNH; k += LPG) haloOut[(long long)o * JNHP + k] = cur[JHSTATE(k)];
+#endif
+#if JTB
+      {   // the supercell's traceback bytes, 16 (or 4) per lane and store, the lanes of the column side by side
+        unsigned char *dstb = tbPair + ((long long)o * I + i) * JSB;
+        const unsigned char *srcb = tbL + c * JTBS;
+#if JSB % 16 == 0
+        for (int j = q * 16; j < JSB; j += LPG * 16) *(u32x4 *)(dstb + j) = *(const u32x4 *)(srcb + j);
+#else
+        for (int j = q * 4; j < JSB; j += LPG * 4) *(unsigned int *)(dstb + j) = *(const unsigned int *)(srcb + j);
+#endif
+      }
+#endif
       if (i == inLen && o == outLen && q == 0 && A.loglike) A.loglike[pairIdx] = cur[JENDNODE];
     }
     med_block_sync();
     slotCur = (slotCur + 1) % NS;
   }
+  JSTORE_PENDING();
+#if JMAT == 2
+  // what the next block of this strip starts from: the ring slots of the last NS - 1 steps, every column
+  if (t1 < T)
+    for (int dt = 1; dt < NS; ++dt) {
+      const int slot = (((t1 - dt) % NS) + NS) % NS;
+      for (int idx = tid; idx < C * S; idx += NT) {
+        const int cc = idx / S, j = idx - cc * S;
+        bnd[(long long)(dt - 1) * C * S + idx] = ring(slot, cc + 1)[j];
+      }
+    }
+#endif
 #if JMODE == 2
   // usage summed in registers over the tile's steps (records held in VGPRs) -> the workgroup's LDS accumulators
 /*@POST@*/

@@ -55,7 +55,7 @@ static int env_int_s(const char *name, int dflt) {
 static const int SM_MAX_STATES = 16;
 
 bool small_eligible(const mb_machine *m) {
-  if (m->S < 1 || m->S > env_int_s("MB_SMALL_MAX_STATES", SM_MAX_STATES)) return false;
+  if (m->S < 1 || m->S > std::min(env_int_s("MB_SMALL_MAX_STATES", SM_MAX_STATES), SM_MAX_STATES)) return false;   // (the knob can only lower the limit: register tables, traceback words and decode entries are sized for 16)
   if (m->nIn < 1 || m->nOut < 1) return false;            // one-tape machines: other families
   if (m->nTrans > 8000) return false;                     // the workgroup's count table lives in LDS
   for (long long e = 0; e < m->nTrans; ++e)
@@ -344,6 +344,15 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     if (b > 0 && !(tl.w & 1)) {      // (bit 0: the block before this one lies outside the envelope and did not run: start from -inf)
 /*@LOADBND@*/
     }
+#if JENV && JH > 0
+    if (b > 0 && (tl.w & 1) && a > 0 && t0 - 1 <= outLen) {
+      // The block before this one holds no cell of the envelope and did not run, so there is no boundary record -- but lane 0's
+      // DIAGONAL predecessor at step t0, cell (64a - 1, t0 - 1), is not a cell of that block: it is the last column of strip
+      // a - 1, whose tile (a - 1, b) ran two launches ago and left it in the halo column (a gapless stretch of an alignment
+      // that crosses a strip boundary exactly at a block boundary: path envelope of width 0, quirk Q1's Envelope(seqPair)).
+/*@LOADDIAG@*/
+    }
+#endif
     int ot = tokAt(t0 - 1 - lane);
 #if JENV
     // restricted envelope of the pair (src/seqpair.h:75-97): cell (x, y) exists <=> inStart[y] <= x < inEnd[y]; rows travel
@@ -411,7 +420,7 @@ const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise)
 int small_default_minwaves(int mode, bool env) { return std::max(1, env_int_s("MB_SMALL_MINWAVES", mode == SM_COUNT ? (env ? 3 : 4) : 1)); }
 
 std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, bool env, int minWaves) {
-  std::ostringstream defs, weights, state, loadb, saveb, flush;
+  std::ostringstream defs, weights, state, loadb, loadd, saveb, flush;
   const int S = P.S, CB = small_chunk_bytes(S), NCH = small_chunks(S);
   const bool counting = mode == SM_COUNT, tbmode = mode == SM_TB, maxmode = mode == SM_MAX || mode == SM_TB;
   const int rowF = row_floats(P);
@@ -452,6 +461,10 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
     int k = 0;
     for (int s : P.saveCells) { loadb << "      c1_" << s << " = bnd[" << k << "];\n"; saveb << "      bnd[" << k << "] = c1_" << s << ";\n"; ++k; }
     for (int s : P.needDiag) { loadb << "      l1_" << s << " = bnd[" << k << "];\n"; saveb << "      bnd[" << k << "] = l1_" << s << ";\n"; ++k; }
+  }
+  for (int s : P.needDiag) {   // (needDiag is a subset of needLeft: the halo row holds every state of needLeft, in that order)
+    const size_t k = std::find(P.needLeft.begin(), P.needLeft.end(), s) - P.needLeft.begin();
+    loadd << "      { const double hv = haloIn[(long long)(t0 - 1) * JH + " << k << "]; l1_" << s << " = lane == 0 ? hv : l1_" << s << "; }\n";
   }
   auto step = [&](int p) {
     const int q = 1 - p;
@@ -599,6 +612,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
   replace("/*@WEIGHTS@*/", weights.str());
   replace("/*@STATE@*/", state.str());
   replace("/*@LOADBND@*/", loadb.str());
+  replace("/*@LOADDIAG@*/", loadd.str());
   replace("/*@SAVEBND@*/", saveb.str());
   replace("/*@STEP0@*/", step(0));
   replace("/*@STEP1@*/", step(1));
@@ -615,43 +629,51 @@ bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env) {
   if (J.ldsBytes > 160 * 1024) { set_error("small-machine kernel: tables exceed the LDS"); return false; }
   // Registers: every state, neighbour value, weight and usage sum of the machine is a named VGPR; a machine near the
   // family's limit (12-16 states, dozens of tables) does not fit the budget of 3-4 wavefronts per SIMD.  A kernel that
-  // spills to SCRATCH memory is not used: the budget is raised (fewer wavefronts per SIMD) until it needs none -- a spilled
-  // count sweep is slow, and on one randomised case (12 states, 469 spilled VGPRs) it produced wrong Forward values that
-  // no version without scratch does (scripts/fuzz_env_gpu.py seed 5229).  J.scratch tells the caller when even one
-  // wavefront per SIMD does not fit.
-  std::string code, log;
+  // spills to SCRATCH memory is not used, in ANY mode: the budget is raised (fewer wavefronts per SIMD) until it needs
+  // none, and if even one wavefront per SIMD does not fit, the kernel is reported as not runnable and the caller takes
+  // another family (small_can_run).  Why: DESIGN.md section 4.0 "Registers" -- a spilled sweep is slow, and one spilled
+  // build gave wrong values.  Metadata that cannot be read counts as "spills" (fail closed).
+  std::string code, log, src;
+  bool fromCache = false;
   for (int mw = small_default_minwaves(mode, env); mw >= 1; --mw) {
-    const std::string src = small_jit_source(P, mode, materialise, env, mw);
+    src = small_jit_source(P, mode, materialise, env, mw);
     if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
       const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
       if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
-    if (!jit_compile(src, "mb_small_jit.hip", code, &log, nullptr)) {
+    if (!jit_compile(src, "mb_small_jit.hip", code, &log, &fromCache)) {
       if (getenv("MB_SMALL_JIT_VERBOSE") || getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
       set_error("run-time compilation of the small-machine kernel failed: " + log.substr(0, 400));
       return false;
     }
-    J.scratch = jit_kernel_meta(code, ".private_segment_fixed_size") > 0;
+    J.scratch = jit_kernel_meta(code, ".private_segment_fixed_size") != 0;
     if (getenv("MB_SMALL_JIT_VERBOSE")) fprintf(stderr, "[mbhip] small family, mode %d: %d wavefront(s) per SIMD, %lld VGPRs, %lld spilled, scratch %lld bytes\n", mode, mw,
                                                 jit_kernel_meta(code, ".vgpr_count"), jit_kernel_meta(code, ".vgpr_spill_count"), jit_kernel_meta(code, ".private_segment_fixed_size"));
     if (!J.scratch || env_int_s("MB_SMALL_ALLOW_SCRATCH", 0)) break;
   }
+  if (J.scratch && !env_int_s("MB_SMALL_ALLOW_SCRATCH", 0)) { set_error("small-machine kernel: does not fit the register file (another kernel family takes the machine)"); return false; }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("small-machine kernel: hipModuleLoadData failed"); return false; }
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+    // a cached code object the loader rejects (truncated file, other compiler build): drop it and compile afresh, once
+    mod = nullptr;
+    if (fromCache) { jit_evict(src); if (!jit_compile(src, "mb_small_jit.hip", code, &log, nullptr) || hipModuleLoadData(&mod, code.data()) != hipSuccess) mod = nullptr; }
+    if (!mod) { set_error("small-machine kernel: hipModuleLoadData failed"); return false; }
+  }
   if (hipModuleGetFunction(&fn, mod, small_kernel_name(P, mode, materialise)) != hipSuccess) { (void)hipModuleUnload(mod); set_error("small-machine kernel: entry point missing"); return false; }
   (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   J.module = mod; J.func = fn;
   return true;
 }
 
-// the count sweep keeps one usage row per lane in LDS: machines with many output-token / match tables do not fit
-// ... and machines near the family's limits need more registers than a wavefront has: no count sweep through scratch
-// memory (the caller takes the tiled family's fused count sweep instead)
-bool small_count_fits(SmallProgram &P, bool env) {
-  if (!P.ok || small_jit_lds_bytes(P, SM_COUNT) > 96 * 1024) return false;
-  return small_jit_get(P, SM_COUNT, false, env) && !P.jit[SM_COUNT][0][env ? 1 : 0].scratch;
+// Can this sweep run on this family?  The kernel is built here if it has not been (it would be built by the sweep anyway).
+// The count sweep keeps one usage row per lane in LDS: machines with many output-token / match tables do not fit.
+bool small_can_run(SmallProgram &P, int mode, bool materialise, bool env) {
+  if (!P.ok) return false;
+  if (mode == SM_COUNT && small_jit_lds_bytes(P, SM_COUNT) > 96 * 1024) return false;
+  return small_jit_get(P, mode, materialise, env);
 }
+bool small_count_fits(SmallProgram &P, bool env) { return small_can_run(P, SM_COUNT, false, env); }
 
 // ---- one sweep: the wavefront of tiles --------------------------------------------------------------------------------------
 struct SmallArgsHost {   // must match SmallArgs in the generated source

@@ -68,6 +68,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
 int small_default_minwaves(int mode, bool env);
 size_t small_jit_lds_bytes(const SmallProgram &P, int mode);
 bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env = false);
+bool small_can_run(SmallProgram &P, int mode, bool materialise, bool env);   // built, loaded and free of scratch memory
 bool small_count_fits(SmallProgram &P, bool env);
 const char *small_kernel_name(const SmallProgram &P, int mode, bool materialise);
 

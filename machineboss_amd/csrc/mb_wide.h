@@ -40,6 +40,8 @@ struct WideDev {
   int backward;
   int inputTape;       // 1: the machine is a recogniser, the column index is the input position
   int lastOnly;        // 1: `pool` holds ONE column per pair (cellBase = its offset): only the last column of the sweep is stored
+  int bWave0;          // 1: every round of segment B fits the FIRST WAVEFRONT (a levelled max program's thin silent levels): the other
+                       //    wavefronts skip segment B altogether and meet the first one at the barrier that ends the column
 };
 
 // Forward / Backward (log-sum-exp) run in single precision RELATIVE TO A PER-COLUMN fp64 REFERENCE: a column's vector

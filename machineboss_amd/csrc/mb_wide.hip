@@ -128,12 +128,18 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
   // next column's token, ...) runs WIDE_RING slots ahead of the slot being folded; slot j sits in q[j % WIDE_RING]
   const WideRec *cursor = P.segA + (size_t)tokOf(0) * P.strideA;
   int jn = 0, cc = 0, tokAhead = tokOf(1);          // slot and column of the cursor, token of the column after it
+  // Levelled max programs (Viterbi: one rounded add per transition, silent levels in the reference's order) of profile-like
+  // machines have hundreds of THIN silent levels -- a dozen states each -- that only the first wavefront works on; dragging all
+  // 16 wavefronts through their slots is what made the sweep 4 x slower than the log-sum-exp one (which closes the levels in a
+  // few stages on the host -- not an option here: a closure adds weights in another order).  When every round of segment B fits
+  // the first wavefront (WideDev::bWave0), the other wavefronts' stream is segment A only; they wait at one barrier per column.
+  const int nMine = (MODE == MB_VITERBI && P.bWave0 && (tid >> 6) != 0) ? nA : n;
   WideRec q[WIDE_RING];
   auto fetch = [&](WideRec &dst) {
     dst = cursor[tid];
     cursor += W; ++jn;
     if (jn == nA) cursor = P.segB;
-    if (jn == n) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
+    if (jn == nMine) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
   };
 #pragma unroll
   for (int k = 0; k < WIDE_RING; ++k) fetch(q[k]);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
     };
     double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
     float s = 0.0f;
-    for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
+    for (int j0 = 0; j0 < nMine; j0 += WIDE_RING) {
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
         }
       }
     }
+    if (MODE == MB_VITERBI && nMine != n) __syncthreads();   // (pairs with the barrier behind the first wavefront's last round of segment B)
     // the last round of a column always synchronises: the column is complete here
     if (cells && (!P.lastOnly || c == outLen)) {
       double *col = P.lastOnly ? cells : cells + (long long)o * S;
@@ -439,8 +446,20 @@ static void wide_linearise(WideProgram &P, int nTok) {
   for (int r = 0; r < nR; ++r) if (P.rounds[r].tokStride) lastTok = r;
   int nA = 0, nB = 0;
   for (int r = 0; r < nR; ++r) (r <= lastTok ? nA : nB) += P.rounds[r].depth;
-  const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
-  (nB || lastTok < 0 ? nB : nA) += padSlots;
+  // first-wavefront-only segment B (see k_wide_sweep): needs a segment A that ends with a barrier (its results are the first
+  // wavefront's inputs), a segment B with the column's closing barrier only, and both segments whole rings of slots
+  bool bWave0 = P.viterbi && lastTok >= 0 && lastTok + 1 < nR && env_int_w("MB_WIDE_VITERBI_WAVE0", 1) != 0;
+  for (int r = lastTok + 1; r < nR && bWave0; ++r) bWave0 = P.rounds[r].pad0 <= 64 && (P.rounds[r].sync != 0) == (r + 1 == nR);
+  // (barriers inside segment A are met by every wavefront alike; the only barriers ever dropped sit between two thin rounds,
+  //  i.e. between two pieces of the first wavefront's own work, so its way from A into B needs none either)
+  P.dev.bWave0 = bWave0 ? 1 : 0;
+  if (bWave0) {
+    nA += (WIDE_RING - nA % WIDE_RING) % WIDE_RING;
+    nB += (WIDE_RING - nB % WIDE_RING) % WIDE_RING;
+  } else {
+    const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
+    (nB || lastTok < 0 ? nB : nA) += padSlots;
+  }
   const WideRec padRec{-INFINITY, PREV(P.dev.S), 0};
   P.segA.assign((size_t)nTok * nA * W, padRec);
   P.segB.assign((size_t)nB * W, padRec);
@@ -817,6 +836,16 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column (%lld candidates = %.0f %% of the lane slots), %zu records, vectors %zu bytes\n",
             backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK ? bestStages - 1 : 0, P.rounds.size(), P.slotsPerColumn, P.nSync, P.candsPerColumn,
             100.0 * (double)P.candsPerColumn / (double)std::max<long long>(1, P.slotsPerColumn * P.W), nRecs, P.vecBytes());
+  if (verbose && viterbi) {   // shape of the levelled program: how much of a column is work of the first wavefront alone?
+    long long thinRounds = 0, thinSlots = 0, wideRounds = 0, wideSlots = 0, tokRounds = 0; int maxLanes = 0;
+    for (const WideRound &R : P.rounds) {
+      if (R.tokStride) ++tokRounds;
+      if (R.pad0 <= 64) { ++thinRounds; thinSlots += R.depth; } else { ++wideRounds; wideSlots += R.depth; }
+      maxLanes = std::max(maxLanes, R.pad0);
+    }
+    fprintf(stderr, "[mbhip] wide (max) rounds: %lld fit the first wavefront (%lld slots), %lld do not (%lld slots, widest %d lanes), %lld read the previous column\n",
+            thinRounds, thinSlots, wideRounds, wideSlots, maxLanes, tokRounds);
+  }
   return true;
 }
 

@@ -11,7 +11,7 @@ from machineboss_amd.seqgen import synth_batch
 mode = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 preset, cfg, n, il, ol = {"counts": ("protpsw", 3, 1024, 400, 400), "forward3": ("protpsw", 3, 1024, 400, 400),
                           "viterbi": ("dnapsw", 2, 1024, 1000, 1000), "forward2": ("dnapsw", 2, 1024, 1000, 1000),
-                          "counts4": ("psw2dna", 4, 64, 487, 2000), "viterbi4": ("psw2dna", 4, 64, 487, 2000)}[mode]
+                          "counts4": ("psw2dna", 4, 21, 487, 10000), "viterbi4": ("psw2dna", 4, 64, 487, 10000)}[mode]   # config 4's own shape: one chunk of Backward matrices / 64 pairs of traceback bytes
 m = Machine.fromFile("tests/golden/preset/%s.json" % preset); em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
 dm = capi.DeviceMachine(em)
 b = capi.DeviceBatch(dm, *synth_batch(cfg, n, il, ol, em.nInTok, em.nOutTok))

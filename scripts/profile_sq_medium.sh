@@ -1,5 +1,5 @@
 #!/bin/bash
-# tiled family, psw2dna 64 x 487 x 2000: kernel trace of one mode, then its SQ counters (own rocprofv3 --pmc pass).
+# tiled family, psw2dna on config 4's shape (scripts/bench_mode.py counts4 / viterbi4): kernel trace of one mode, then its SQ counters (own rocprofv3 --pmc pass).
 # usage: bash scripts/profile_sq_medium.sh <counts4|viterbi4> <tag>
 set -u
 MODE=${1:-counts4}; TAG=${2:-r02}
@@ -19,7 +19,7 @@ for f in glob.glob(out + "/pmc/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("k_medium") or "traceback" in k: tot[k + " lds=" + r.get("LDS_Block_Size", "?")][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(os.path.join(out, "summary", "%s_%s_pmc_sq.txt" % (tag, mode)), "w") as g:
-    g.write("tiled family, psw2dna 64 x 487 x 2000, mode %s, dispatches summed per kernel and LDS size (rocprofv3 --pmc, own pass)\n" % mode)
+    g.write("tiled family, psw2dna x 487 aa x 10000 nt (scripts/bench_mode.py %s), mode %s, dispatches summed per kernel and LDS size (rocprofv3 --pmc, own pass)\n" % (mode, mode))
     for k in sorted(tot):
         wc = tot[k].get("SQ_WAVE_CYCLES", 1.0)
         g.write("%s\n" % k)

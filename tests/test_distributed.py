@@ -86,16 +86,23 @@ def _gather_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from machineboss_amd.boss import _gather_in_order
-    n = 7
-    mine = ["pair%d" % k for k in range(rank, n, world)]      # the CLI's round-robin shard (boss.py: data[rank::world])
-    q.put((rank, _gather_in_order(mine, n, rank, world)))
+    from machineboss_amd.boss import _gather_in_order, _shard
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.seqpair import SeqPair
+    machine = Machine.fromFile(golden_path("preset", "dnapsw.json"))
+    # a ragged list: one long pair and six short ones (the CLI's shard: sorted by DP cell count, dealt greedily -- SURVEY 8(e))
+    lens = [(10, 12), (400, 390), (11, 9), (30, 28), (8, 8), (25, 31), (12, 14)]
+    data = [SeqPair(["A"] * a, ["C"] * b, "in%d" % k, "out%d" % k) for k, (a, b) in enumerate(lens)]
+    owned = _shard(data, machine, world)
+    mine = ["pair%d" % k for k in owned[rank]]
+    q.put((rank, owned, _gather_in_order(mine, len(data), rank, world, owned)))
     dist.destroy_process_group()
 
 
 def test_cli_results_gathered_in_input_order_world2():
-    """`boss --loglike/--viterbi/--align` on N ranks: pairs are dealt round-robin, results come back in input order
-    (no data-path collective; a host-side object gather)."""
+    """`boss --loglike/--viterbi/--align` on N ranks: pairs are dealt by longest-processing-time-first on their DP cell
+    counts (target/boss.cpp:796,826 loops over independent pairs), every rank computes the same assignment, results come
+    back in input order (no data-path collective; a host-side object gather)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -104,5 +111,9 @@ def test_cli_results_gathered_in_input_order_world2():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
-    for rank, got in res:
+    assert res[0][1] == res[1][1]                                  # the same partition on both ranks
+    owned = res[0][1]
+    assert sorted(k for part in owned for k in part) == list(range(7))
+    assert [1] in owned                                            # the long pair alone on one rank, the six short ones on the other
+    for rank, _, got in res:
         assert got == ["pair%d" % k for k in range(7)]

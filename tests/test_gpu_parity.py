@@ -310,6 +310,92 @@ def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
     assert close(counts, ref_c, 1e-5, 1e-7) and close(s, ref_s, FAST_REL, FAST_ABS)
 
 
+@pytest.mark.parametrize("case", ["psw2dna", "random40", "random150", "random257", "random300split"])
+def test_tiled_family_keeps_no_fp64_matrix(capi, oracle_mod, machines, case):
+    """Round 3: on the tiled family, Viterbi keeps ONE traceback byte per cell (MED_MODE_TB: the winning candidate's table and
+    index, walked by k_traceback_bytes) and the count sweep keeps NO Forward matrix (tiles that hand their ring state over
+    through boundary records and halo columns of the few states other strips read).  Both against the oracle -- paths
+    bit-exact, first-maximum tie-break included -- and against the round-2 paths (fp64 Viterbi matrix, Forward matrix stored),
+    on lattices of several strips and several blocks, ragged, with empty sequences; H (states per halo row) from 3 to > 256;
+    one machine whose exact program splits high-degree states (the byte sweep then runs an unsplit twin)."""
+    from randmachine import random_machine, random_seq
+    if case == "psw2dna":
+        m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+        shapes = [(30, 90), (100, 300), (0, 5), (7, 0), (33, 257), (64, 129), (70, 700)]
+        pairs = [synth_tokens(k + 1, il, ol, em.nInTok, em.nOutTok) for k, (il, ol) in enumerate(shapes)]
+    else:
+        S = int(case[6:9].rstrip("s"))
+        rng = np.random.RandomState(S)
+        em = random_machine(S, 3, 2, 100 + S, density=4.0 if "split" in case else 2.0, silent_density=2.5 if "split" in case else 1.0, dup=True)
+        pairs = [(random_seq(rng, int(rng.randint(0, 90)), 3), random_seq(rng, int(rng.randint(0, 200)), 2)) for _ in range(5)] + [(random_seq(rng, 70, 3), random_seq(rng, 330, 2))]
+    om = oracle_mod.OracleMachine(em)
+    res = {}
+    for new in ("1", "0"):
+        capi.set_option("MB_MEDIUM_TB", new); capi.set_option("MB_MEDIUM_COUNTS_ROLL", new)
+        try:
+            dm = capi.DeviceMachine(em)
+            b = capi.DeviceBatch.from_pairs(dm, pairs)
+            v = b.viterbi(); kv = capi.last_kernel_name()
+            c = b.counts(); kc = capi.last_kernel_name()
+            res[new] = (v, c)
+            assert kv == "k_medium_jit" and kc == "k_medium_jit"
+            dm.close()
+        finally:
+            capi.set_option("MB_MEDIUM_TB", None); capi.set_option("MB_MEDIUM_COUNTS_ROLL", None)
+    (v1, c1), (v0, c0) = res["1"], res["0"]
+    assert np.array_equal(v1[0], v0[0]) and np.array_equal(v1[1], v0[1]) and np.array_equal(v1[2], v0[2])
+    assert close(c1[0], c0[0], 1e-6, 1e-9) and close(c1[2], c0[2], 1e-9, 1e-9)
+    ref_c = np.zeros(em.nTransitions)
+    for k, (x, y) in enumerate(pairs):
+        V = om.viterbi(x, y)
+        assert v1[0][k] == V[-1, -1, -1]
+        got = v1[2][v1[1][k]:v1[1][k + 1]]
+        if V[-1, -1, -1] > -math.inf:
+            assert np.array_equal(got, om.traceback(x, y, V))
+        else:
+            assert len(got) == 0
+        if om.loglike(x, y, oracle_mod.SUM_EXACT) > -math.inf:
+            om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
+    assert close(c1[0], ref_c, 1e-5, 1e-7)
+
+
+def test_tiled_family_byte_sweep_under_envelopes(capi, oracle_mod, machines):
+    """The same two sweeps with restricted envelopes: tiles without a cell of the envelope do not run (their halo rows read
+    -inf, the next block of the strip starts from -inf instead of a boundary record), among them a gapless stretch that
+    crosses strip and block boundaries on its diagonal (the case of test_gapless_path_envelope_... for this family)."""
+    from machineboss_amd.seqpair import Envelope
+    m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(5)
+    for il, ol, width in [(40, 130, 0), (70, 260, 3), (100, 100, 0)]:
+        x, y = synth_tokens(900 + il, il, ol, em.nInTok, em.nOutTok)
+        # an alignment that consumes three output symbols per input symbol where it can (protein -> DNA), gaps elsewhere
+        cols = []; i = o = 0
+        while i < il or o < ol:
+            if i < il and o + 3 <= ol and rng.rand() < 0.8: cols += [("a", "")] + [("", "b")] * 3; i += 1; o += 3
+            elif o < ol: cols.append(("", "b")); o += 1
+            else: cols.append(("a", "")); i += 1
+        env = Envelope.pathAreaEnvelope(cols, width)
+        with oracle_mod.envelope(env.inStart, env.inEnd):
+            Vo = om.viterbi(x, y)
+            po = om.traceback(x, y, Vo) if Vo[-1, -1, -1] > -math.inf else None
+            ref_c = np.zeros(em.nTransitions)
+            ref_ll = om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT) if om.loglike(x, y, oracle_mod.SUM_EXACT) > -math.inf else -math.inf
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y), (x[:20], y[:50])])
+        b.set_envelopes([(env.inStart, env.inEnd), None])
+        vll, off, edges = b.viterbi()
+        assert capi.last_kernel_name() == "k_medium_jit" and vll[0] == Vo[-1, -1, -1]
+        if po is not None:
+            assert np.array_equal(edges[off[0]:off[1]], po)
+        b1 = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+        b1.set_envelopes([(env.inStart, env.inEnd)])
+        counts, s_ll, cll = b1.counts()
+        if math.isfinite(ref_ll):
+            assert close(counts, ref_c, 1e-5, 1e-7) and close(cll[0], ref_ll, FAST_REL, FAST_ABS)
+        else:
+            assert cll[0] == -math.inf and not counts.any()
+
+
 def test_medium_vs_generic_large(capi, machines):
     """Size-independent check at a larger shape: both kernel families fill identical Viterbi matrices and agree on
     Forward; rolling == materialised log-likelihood."""
@@ -738,7 +824,7 @@ def _count_invariants(em, counts, nPairs, inLen, outLen):
 
 
 @pytest.mark.parametrize("preset,config,nPairs,il,ol", [("dnapsw", 2, 1024, 1000, 1000), ("protpsw", 3, 1024, 400, 400),
-                                                       ("psw2dna", 4, 16, 487, 10000)])
+                                                       ("psw2dna", 4, 256, 487, 10000)])
 def test_baseline_configs_full_size_properties(capi, machines, preset, config, nPairs, il, ol):
     """configs[1] (dnapsw, 1024 x 1 kb), configs[2] per GPU (protpsw, 1024 x 400 aa) and configs[3] (psw2dna, 10 kb DNA):
     rolling == materialised Forward; Viterbi <= Forward; duplicated pairs give identical results; the Viterbi path
@@ -754,7 +840,8 @@ def test_baseline_configs_full_size_properties(capi, machines, preset, config, n
     llm = b.forward(capi.MB_MATERIALISE); llr = b.forward(capi.MB_ROLLING)
     assert capi.last_kernel_name() == ("k_medium_jit" if preset == "psw2dna" else "k_small_sum_roll")
     assert np.all(np.isfinite(llm)) and close(llr, llm, 1e-12) and llm[0] == llm[1] and llr[0] == llr[1]
-    npv = min(nPairs, 64)    # tracebacks of a sub-batch (the fill of all pairs is checked through the log-likelihoods)
+    # tracebacks: all 256 pairs of config 4 (one traceback byte per cell: 340 GB of bytes in two chunks), a sub-batch for the others
+    npv = nPairs if preset == "psw2dna" else min(nPairs, 64)
     bv = capi.DeviceBatch(dm, inTok[:inOff[npv]], inOff[:npv + 1], outTok[:outOff[npv]], outOff[:npv + 1])
     vll, off, edges = bv.viterbi()
     assert np.all(vll <= llm[:npv] + 1e-9) and vll[0] == vll[1]
@@ -769,7 +856,7 @@ def test_baseline_configs_full_size_properties(capi, machines, preset, config, n
         for w in lw[e]:
             acc += w
         assert abs(acc - vll[k]) <= 1e-9 * abs(vll[k])
-    nc = min(nPairs, 256 if preset != "psw2dna" else 4)
+    nc = min(nPairs, 256 if preset != "psw2dna" else 24)    # config 4: more pairs than one chunk of Backward matrices holds (21)
     bc = capi.DeviceBatch(dm, inTok[:inOff[nc]], inOff[:nc + 1], outTok[:outOff[nc]], outOff[:nc + 1])
     counts, s, cll = bc.counts()
     assert _count_invariants(em, counts, nc, il, ol)
@@ -1110,6 +1197,56 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     assert v30[0] == V[-1, -1, -1] and np.array_equal(e30, om.traceback(x, y30, V))
 
 
+def test_baseline_config5_at_its_stated_length(capi, monkeypatch):
+    """BASELINE config 5 as stated -- 64 sequences x 50 kb on the ~5k-state machine (20-node fn3 profile . simple_introns .
+    translate . dnapsw, 5 063 states) -- on one GPU, through size-independent properties (the oracle needs minutes per
+    sequence here): the default log-likelihood path (every sequence CUT IN TWO, Forward over the prefix || Backward over the
+    suffix, joined over the crossing transitions, 25 000 columns per half) == the plain rolling sweep == the materialised
+    fill of a sub-batch; the fp32-relative arithmetic (running reference R over 50 000 columns) agrees to 1e-6; the Viterbi
+    path of a 50 kb sequence is contiguous, spells it and re-scores to the Viterbi score; the count sweep emits every symbol
+    exactly once; identical sequences give identical results wherever they run."""
+    L, nSeq = 50000, 64
+    m, em = _profile_machine(20)
+    assert em.nInTok == 0 and em.nStates == 5063
+    dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(2050)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, 4, size=L).astype(np.int32) for _ in range(nSeq)]      # DNA over {A,C,G}: no stop codons
+    ys[1] = ys[0].copy(); ys[63] = ys[0].copy()
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    assert b.cells() == nSeq * (L + 1) * 5063
+    llr = b.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name() == "k_wide_sweep<0> x2 + k_onetape_join"       # 2 x 64 workgroups <= 256 CUs: cut in two
+    assert np.all(np.isfinite(llr)) and llr[0] == llr[1] == llr[63]
+    monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
+    llp = b.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name() == "k_wide_sweep<0>" and close(llr, llp, 1e-8) and llp[0] == llp[1] == llp[63]
+    monkeypatch.delenv("MB_ONETAPE_SPLIT")
+    b2 = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:2]])                # 2 x 2.03 GB matrices
+    llm = b2.forward(capi.MB_MATERIALISE)
+    assert close(llm, llp[:2], 1e-9, 1e-12)                                       # the plain rolling sweep is the materialised one without the stores
+    monkeypatch.setenv("MB_WIDE_FP32", "1")
+    dm32 = capi.DeviceMachine(em)
+    b32 = capi.DeviceBatch.from_pairs(dm32, [(x, y) for y in ys[:4]])
+    monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
+    ll32 = b32.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name().startswith("k_wide_sum32") and close(ll32, llp[:4], 1e-6)
+    monkeypatch.delenv("MB_ONETAPE_SPLIT"); monkeypatch.delenv("MB_WIDE_FP32")
+    dm32.close()
+    vll, off, edges = b2.viterbi()
+    lw = np.asarray(em.logWeight)
+    assert np.all(vll <= llp[:2] + 1e-9) and vll[0] == vll[1] and np.array_equal(edges[off[0]:off[1]], edges[off[1]:off[2]])
+    e = edges[off[0]:off[1]]
+    assert em.src[e[0]] == 0 and em.dst[e[-1]] == em.nStates - 1 and np.array_equal(em.dst[e[:-1]], em.src[e[1:]])
+    assert np.array_equal(em.outTok[e][em.outTok[e] != 0], ys[0])
+    acc = 0.0
+    for w in lw[e]:
+        acc += w
+    assert abs(acc - vll[0]) <= 1e-9 * abs(vll[0])
+    counts, s, cll = b2.counts()
+    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 1e-5 * 2 * L and close(cll, llp[:2], 1e-8)
+
+
 def test_pipelined_forward_matches_plain(capi, machines):
     """Config 4a's 256-pair pipeline (matrix slots recycled while the sweep is in flight, medium_forward_pipelined) against
     the same pairs filled without recycling: identical log-likelihoods."""
@@ -1187,6 +1324,58 @@ def test_rccl_allreduce_entry_points(capi):
     finally:
         comm.close()
     assert np.array_equal(got, counts) and gl == -3.25
+
+
+_COMM_RANK = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from machineboss_amd import capi
+from machineboss_amd.machine import Machine
+from machineboss_amd.evalmachine import EvaluatedMachine
+from machineboss_amd.seqgen import synth_tokens
+rank, world, idfile = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+capi.set_device(rank)                                  # one process per GPU (mb_set_device before anything else)
+if rank == 0:
+    uid = capi.Comm.unique_id()                        # rank 0 makes the id and ships it by its own means (a file here)
+    open(idfile + ".tmp", "wb").write(uid); os.rename(idfile + ".tmp", idfile)
+else:
+    for _ in range(600):
+        if os.path.exists(idfile): break
+        time.sleep(0.1)
+    uid = open(idfile, "rb").read()
+comm = capi.Comm(uid, world, rank)
+em = EvaluatedMachine.fromMachine(Machine.fromFile(os.path.join(sys.argv[1], "tests", "golden", "preset", "protpsw.json")), None, useDefaults=True)
+dm = capi.DeviceMachine(em)
+pairs = [synth_tokens(5000 + k, 40 + k, 50, em.nInTok, em.nOutTok) for k in range(6)]
+mine = pairs[rank::world]
+counts, ll, _ = capi.DeviceBatch.from_pairs(dm, mine).counts()            # this rank's E-step (MachineCounts over its shard)
+counts, ll = comm.allreduce_counts(counts, ll)                            # MachineCounts::operator+= over the ranks: ONE RCCL all-reduce
+comm.close()
+np.save(idfile + ".rank%d.npy" % rank, np.concatenate([counts, [ll]]))
+"""
+
+
+def test_rccl_allreduce_two_gpus(capi, machines, tmp_path):
+    """The C-ABI collective on MORE than one GPU: two processes, one per device, bootstrap a communicator with
+    mb_comm_unique_id / mb_comm_init and sum their E-step counts with mb_allreduce_counts (RCCL over xGMI).  Every rank must
+    hold the single-process result (summation order differs: 1e-12).  Needs two visible GPUs: skipped on the
+    one-GPU test box, runs wherever the driver's scaling tier has a node."""
+    import subprocess, sys
+    from conftest import ROOT
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-GPU box can only form a one-rank communicator: test_rccl_allreduce_entry_points)")
+    idfile = str(tmp_path / "uid")
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    procs = [subprocess.Popen([sys.executable, "-c", _COMM_RANK, ROOT, str(r), "2", idfile], env=env) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    m, em = machines("protpsw", None, useDefaults=True, preset=True)
+    dm = capi.DeviceMachine(em)
+    pairs = [synth_tokens(5000 + k, 40 + k, 50, em.nInTok, em.nOutTok) for k in range(6)]
+    ref_c, ref_ll, _ = capi.DeviceBatch.from_pairs(dm, pairs).counts()
+    for r in range(2):
+        got = np.load(idfile + ".rank%d.npy" % r)
+        assert np.allclose(got[:-1], ref_c, rtol=1e-9, atol=1e-12) and abs(got[-1] - ref_ll) <= 1e-9 * abs(ref_ll)
 
 
 @pytest.mark.parametrize("fp32", [0, 1])

@@ -152,6 +152,50 @@ def test_small_envelope_batches_regressions(capi, oracle_mod, seed):
     assert mod.run_case(seed) == {}
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,kernel", [("dnapsw", 100, 0), ("dnapsw", 128, 0), ("dnapsw", 129, 0), ("dnapsw", 191, 0), ("protpsw", 257, 0),
+                                           ("dnapsw", 129, 3), ("dnapsw", 129, 1)])
+def test_gapless_path_envelope_across_strip_and_block_boundaries(capi, oracle_mod, machines, monkeypatch, name, n, kernel):
+    """Round-2 ADVICE (high): a gapless alignment of >= 64 columns under its own path envelope (width 0 -- what the reference's
+    Envelope(seqPair) gives an aligned pair, quirk Q1) crosses every strip boundary with a MATCH at (64a, 64a), i.e. at lane 0
+    of strip a at the first step of block b = a (64-step tiles), while block (a, a - 1) holds no cell of the envelope and is
+    not launched: lane 0's diagonal predecessor (64a - 1, 64a - 1) then has to come from the halo column of strip a - 1, not
+    from the boundary record the skipped block never wrote.  Before the fix every sweep returned -inf here.  Also a wider
+    band whose lower edge is that same diagonal, the Backward frame (mirrored strips), the tiled and the generic family."""
+    from machineboss_amd.seqpair import Envelope
+    monkeypatch.setenv("MB_SMALL_TS", "64")
+    m, em = machines(name, None, useDefaults=True, preset=True)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    x, y = synth_tokens(70 + n, n, n, em.nInTok, em.nOutTok)
+    cols = [("a", "b")] * n
+    capi.set_kernel(kernel)
+    try:
+        for env in (Envelope.pathAreaEnvelope(cols, 0), Envelope.pathEnvelope(cols), Envelope.pathAreaEnvelope(cols[:n // 2] + [("a", "")] * 3 + [("", "b")] * 3 + cols[n // 2 + 3:], 0)):
+            with oracle_mod.envelope(env.inStart, env.inEnd):
+                Fo = om.forward(x, y, oracle_mod.SUM_EXACT); Bo = om.backward(x, y, oracle_mod.SUM_EXACT); Vo = om.viterbi(x, y)
+                po = om.traceback(x, y, Vo)
+                ref_c = np.zeros(em.nTransitions); ref_ll = om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
+            assert math.isfinite(Fo[-1, -1, -1]) and math.isfinite(Vo[-1, -1, -1])
+            F = dm.fill(capi.MB_FORWARD, x, y, 0, env.inStart, env.inEnd)
+            if kernel == 0:
+                assert capi.last_kernel_name().startswith("k_small_")
+            B = dm.fill(capi.MB_BACKWARD, x, y, 0, env.inStart, env.inEnd); V = dm.fill(capi.MB_VITERBI, x, y, 0, env.inStart, env.inEnd)
+            assert np.array_equal(V, Vo)
+            assert close(F, Fo, FAST_REL, FAST_ABS) and close(B, Bo, FAST_REL, FAST_ABS)
+            b = capi.DeviceBatch.from_pairs(dm, [(x, y), (x[:70], y[:70])])
+            b.set_envelopes([(env.inStart, env.inEnd), None])
+            for flags in (capi.MB_MATERIALISE, capi.MB_ROLLING):
+                assert close(b.forward(flags)[0], Fo[-1, -1, -1], FAST_REL, FAST_ABS)
+            vll, off, edges = b.viterbi()
+            assert vll[0] == Vo[-1, -1, -1] and np.array_equal(edges[off[0]:off[1]], po)
+            b1 = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+            b1.set_envelopes([(env.inStart, env.inEnd)])
+            counts, s_ll, cll = b1.counts()
+            assert close(counts, ref_c, 1e-5, 1e-7) and close(cll[0], ref_ll, FAST_REL, FAST_ABS)
+    finally:
+        capi.set_kernel(0)
+
+
 # ---- CPU: program structure and generated source ---------------------------------------------------------------------------
 def test_small_source_compiles_for_gfx950(tmp_path, machines):
     """Every mode of the generated kernel cross-compiles for gfx950 without spills (hipcc needs no GPU)."""
