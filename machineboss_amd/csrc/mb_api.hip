@@ -997,6 +997,7 @@ int mb_batch_set_envelopes(mb_batch *b, const int64_t *envOff, const int32_t *in
 }
 
 // ---- Forward ------------------------------------------------------------------------------------------------
+static bool rolltiles_ok = true;      // (cleared while run_fill_loglike re-enters itself after the matrix-free tile kernel proved unavailable)
 static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
@@ -1071,6 +1072,21 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;
     }
+  } else if (mode == MB_FORWARD && (flags & MB_ROLLING) && use_medium(m) && !wide_applicable(m) && env_int("MB_MEDIUM_ROLLTILES", 1) &&
+             (b->nPairs < env_int("MB_ROLLING_MIN_PAIRS", 192) || b->hasEnv) && rolltiles_ok) {
+    // log-likelihoods only, few pairs or envelopes: the tile pipeline WITHOUT a matrix (halo columns + boundary records)
+    FastState *f = fast_state(m);
+    MedEnv me;
+    if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
+    std::vector<PairDesc> hp(b->pairs);
+    rc = launch_fill_neg_inf(d_ll, b->nPairs, g_stream);
+    tm.start();
+    const int r2 = rc ? rc : medium_forward_rolltiles(m, f->fwdSum, f->geoFS, b->d_pairs, hp, b->d_in, b->d_out, d_ll, g_stream, me);
+    g_last_ms += tm.stop();
+    if (r2 < 0) { sm_free(d_ll); rolltiles_ok = false; const int r3 = run_fill_loglike(b, mode, flags, loglike); rolltiles_ok = true; return r3; }   // kernel unavailable: the other paths
+    rc = r2;
+    g_last_kernel = "k_medium_jit";
+    if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernels")) rc = 1;
   } else if (mode == MB_FORWARD && (flags & MB_ROLLING) && !fewPairs && !b->hasEnv && use_medium(m)) {
     // RollingOutputForwardMatrix: no matrix in HBM, only two halo columns per pair
     FastState *f = fast_state(m);

@@ -118,6 +118,8 @@ int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom
                                const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
 int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs, const std::vector<PairDesc> &pairs,
                       const int *d_in, const int *d_out, unsigned char *d_tb, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
+int medium_forward_rolltiles(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs, const std::vector<PairDesc> &pairs,
+                             const int *d_in, const int *d_out, double *d_loglike, hipStream_t st, const MedEnv &env = MedEnv());
 int medium_counts_rolling(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs, const std::vector<PairDesc> &pairs,
                           const int *d_in, const int *d_out, const double *d_bwd, double *d_counts, double *d_loglike, hipStream_t st,
                           const MedEnv &env = MedEnv());

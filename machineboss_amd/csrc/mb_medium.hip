@@ -1097,6 +1097,26 @@ int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, 
   return rc;
 }
 
+// RollingOutputForwardMatrix semantics (`boss --loglike`: log-likelihoods only) through the TILE pipeline without a matrix: what a
+// batch of fewer pairs than CUs wants (one workgroup per pair, the JMAT == 0 sweep, would leave most of the chip idle; the tile
+// pipeline with a matrix pays 8 B per cell for nothing), and what an enveloped batch wants (tiles outside the band do not run).
+// d_loglike must be pre-filled with -inf when envelopes are present.  Returns -1 when the specialised kernel is unavailable.
+int medium_forward_rolltiles(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn,
+                             const int *d_in, const int *d_out, double *d_loglike, hipStream_t st, const MedEnv &env) {
+  if (pairsIn.empty()) return 0;
+  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
+  geo.env = env.d_start != nullptr; geo.haloSteps = 0;
+  if (P.counting || !medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_ROLL)) return -1;
+  std::vector<PairDesc> pairs = pairsIn;
+  for (PairDesc &pd : pairs) pd.launch0 = 0;
+  MedRoll R; long long *d_bases = nullptr;
+  int rc = roll_buffers(P, geo, pairs, geo.env, st, R, &d_bases);
+  if (!rc) rc = launch_wavefront(m, P, P.dev, geo, MB_FORWARD, tile_steps(geo.C, pairs.size(), max_out_len(pairs)), pairs, d_pairs, d_in, d_out, nullptr,
+                                 d_loglike, st, nullptr, nullptr, env, MED_MAT_ROLL, &R);
+  sm_free(d_bases);
+  return rc;
+}
+
 // Forward sweep fused with MachineCounts accumulation that keeps NO Forward matrix (src/backward.cpp:58-87 needs F(i,o,src) only
 // while the supercell is in LDS): the Backward matrices are read once, nothing else moves -- 16 B per lattice cell with the
 // Backward fill.  Returns -1 when the specialised kernel is unavailable.

@@ -144,7 +144,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
        << "\n#define JC " << geo.C << "\n#define JWAVES " << geo.waves << "\n#define JMODE " << (maxmode ? 1 : (mode == MED_MODE_COUNT ? 2 : 0))
        << "\n#define JSTORE2 " << env_int("MB_JIT_STORE2", (S % 2 == 0 && P.LPG <= 8) ? 1 : 0)
-       << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0) << "\n#define JSTDEFER " << (materialise ? env_int("MB_JIT_STORE_DEFER", 0) : 0)
+       << "\n#define JSTORENT " << env_int("MB_JIT_STORENT", 0)
        << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << matKind << "\n#define JTB " << (tbmode ? 1 : 0) << "\n#define JTBS " << tb_lds_stride(P) << "\n#define JSB " << medium_tb_stride(S)
        << "\n#define JNH " << P.haloStates.size() << "\n#define JNHP " << std::max<size_t>(P.haloStates.size(), 1)
        << "\n#define JNHR " << std::max<size_t>((P.haloStates.size() + threads - 1) / threads, 1) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
@@ -256,7 +256,6 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
     }
     body << "      }\n";
     if (ri.sync) body << "      med_wave_sync();\n";
-    if (r == 0 && materialise && env_int("MB_JIT_STORE_DEFER", 0) == 2) body << "      JSTORE_PENDING();\n";
   }
   std::string src = kMedJitSkeleton;
   auto replace = [&](const std::string &mark, const std::string &with) {

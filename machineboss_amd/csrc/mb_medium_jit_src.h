@@ -356,16 +356,6 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
   // ---- loop-invariant candidate records (placement REG): one load per sweep, kept in VGPRs --------------------------
 /*@PRE@*/
-#if JSTDEFER
-  // EXPERIMENT (MB_JIT_STORE_DEFER): a finished supercell leaves LDS for REGISTERS at the end of its step and for HBM during
-  // the next one (1: at its top, 2: behind its first round), so that no LDS read stands between a step's rounds and its stores
-  constexpr int JSREG = (S + LPG - 1) / LPG;
-  double sreg[JSREG];
-  double *sdst = nullptr;
-#define JSTORE_PENDING() do { if (sdst) { _Pragma("unroll") for (int k_ = 0; k_ < JSREG; ++k_) { const int j_ = k_ * LPG + q; if (j_ < S) sdst[j_] = sreg[k_]; } sdst = nullptr; } } while (0)
-#else
-#define JSTORE_PENDING() do { } while (0)
-#endif
   int slotCur = t0 % NS;
   for (int t = t0; t < t1; ++t) {
     const int o = t - c;
@@ -420,9 +410,6 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       for (int k = 0; k < JBV; ++k) bpre[k] = bs[min(k * LPG + q, S - 1)];
     }
 #endif
-#if JSTDEFER == 1
-    JSTORE_PENDING();
-#endif
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
                                       P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff);
@@ -475,14 +462,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
     const double *cur = (const double *)(ldsb + (myColBase + sCur));
     if (active) {
-#if JMAT == 1 && JSTDEFER
-      {
-        JSTORE_PENDING();      // (step t0 of strip 0 runs the generic path: nothing was flushed inside it)
-        sdst = cellPtr(i, o);
-#pragma unroll
-        for (int k = 0; k < JSREG; ++k) { const int j = k * LPG + q; sreg[k] = cur[min(j, S - 1)]; }
-      }
-#elif JMAT == 1
+#if JMAT == 1
       {
         double *dstp = cellPtr(i, o);
         med_copy_out(dstp, cur, q);
@@ -509,7 +489,6 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     med_block_sync();
     slotCur = (slotCur + 1) % NS;
   }
-  JSTORE_PENDING();
 #if JMAT == 2
   // what the next block of this strip starts from: the ring slots of the last NS - 1 steps, every column
   if (t1 < T)

@@ -40,8 +40,6 @@ struct WideDev {
   int backward;
   int inputTape;       // 1: the machine is a recogniser, the column index is the input position
   int lastOnly;        // 1: `pool` holds ONE column per pair (cellBase = its offset): only the last column of the sweep is stored
-  int bWave0;          // 1: every round of segment B fits the FIRST WAVEFRONT (a levelled max program's thin silent levels): the other
-                       //    wavefronts skip segment B altogether and meet the first one at the barrier that ends the column
 };
 
 // Forward / Backward (log-sum-exp) run in single precision RELATIVE TO A PER-COLUMN fp64 REFERENCE: a column's vector
@@ -60,6 +58,23 @@ struct WideDev32 {
   int resultIdx, backward;
   int inputTape;
   int lastOnly;
+};
+
+// Levelled max programs (Viterbi: one rounded add per transition, the silent levels in the reference's order) of profile-like
+// machines are hundreds of THIN levels -- a dozen states each, all in the first wavefront -- between a few wide rounds.  Walking
+// them with all 16 wavefronts through W-lane record slots made the sweep stream 6 MB of padding records per column and
+// workgroup (bandwidth-bound at 3.6 G cells/s where the log-sum-exp sweep, which closes the levels on the host, ran 16).
+// k_wide_viterbi walks a column as a list of PHASES: a wide phase is a run of rounds every wavefront works on (W-lane slots);
+// a thin phase is a run of rounds whose nodes all sit in the first wavefront -- 64-lane slots, read by that wavefront alone
+// with a deep prefetch ring while the others wait at the barrier that ends the phase.  Same rounds, same candidates, same
+// order as the generic kernel: the results are the same bits.
+constexpr int WIDE_THIN_RING = 16;
+struct WidePhase { int thin, inA, nSlots, off; };      // off: first slot of the phase within its stream (wide / thin, A / B)
+struct WideVitDev {
+  const WideRec *wideA, *wideB, *thinA, *thinB;        // A: one table per output token (the emitting rounds), B: shared
+  long long strideWideA, strideThinA;                  // records per token table
+  const WidePhase *phase;
+  int nPhases;
 };
 
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
@@ -86,6 +101,11 @@ struct WideProgram {
   WideRec32 *d_seg32A = nullptr, *d_seg32B = nullptr;
   unsigned long long *d_flags = nullptr;
   WideDev32 dev32{};
+  // the phase-structured streams of k_wide_viterbi (built for max programs whose vectors sit in LDS with 16-bit indices)
+  bool vitOk = false;
+  WideRec *d_vit[4] = {nullptr, nullptr, nullptr, nullptr};
+  WidePhase *d_phase = nullptr;
+  WideVitDev vit{};
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };

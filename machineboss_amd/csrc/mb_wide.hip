@@ -128,18 +128,12 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
   // next column's token, ...) runs WIDE_RING slots ahead of the slot being folded; slot j sits in q[j % WIDE_RING]
   const WideRec *cursor = P.segA + (size_t)tokOf(0) * P.strideA;
   int jn = 0, cc = 0, tokAhead = tokOf(1);          // slot and column of the cursor, token of the column after it
-  // Levelled max programs (Viterbi: one rounded add per transition, silent levels in the reference's order) of profile-like
-  // machines have hundreds of THIN silent levels -- a dozen states each -- that only the first wavefront works on; dragging all
-  // 16 wavefronts through their slots is what made the sweep 4 x slower than the log-sum-exp one (which closes the levels in a
-  // few stages on the host -- not an option here: a closure adds weights in another order).  When every round of segment B fits
-  // the first wavefront (WideDev::bWave0), the other wavefronts' stream is segment A only; they wait at one barrier per column.
-  const int nMine = (MODE == MB_VITERBI && P.bWave0 && (tid >> 6) != 0) ? nA : n;
   WideRec q[WIDE_RING];
   auto fetch = [&](WideRec &dst) {
     dst = cursor[tid];
     cursor += W; ++jn;
     if (jn == nA) cursor = P.segB;
-    if (jn == nMine) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
+    if (jn == n) { jn = 0; ++cc; cursor = P.segA + (size_t)tokAhead * P.strideA; tokAhead = tokOf(cc + 1); }
   };
 #pragma unroll
   for (int k = 0; k < WIDE_RING; ++k) fetch(q[k]);
@@ -153,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
     };
     double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
     float s = 0.0f;
-    for (int j0 = 0; j0 < nMine; j0 += WIDE_RING) {
+    for (int j0 = 0; j0 < n; j0 += WIDE_RING) {
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
@@ -176,13 +170,96 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
         }
       }
     }
-    if (MODE == MB_VITERBI && nMine != n) __syncthreads();   // (pairs with the barrier behind the first wavefront's last round of segment B)
     // the last round of a column always synchronises: the column is complete here
     if (cells && (!P.lastOnly || c == outLen)) {
       double *col = P.lastOnly ? cells : cells + (long long)o * S;
       for (int k = tid; k < S; k += W) col[k] = V[curOff + k];
     }
     if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent (this vector is the next column's `cur`)
+    const int t = prevOff; prevOff = curOff; curOff = t;
+  }
+  if (loglike && tid == 0) loglike[bid] = V[prevOff + P.resultIdx];
+}
+
+// ---- levelled max programs walked phase by phase (see WideVitDev) ----------------------------------------------------------
+// one slot of a round: fold the lane's candidate; on the round's last slot reduce the lane groups and store
+__device__ __forceinline__ void wide_vit_slot(const WideRec rc, double *V, int shift, int curOff, int extraOff, double &m) {
+  m = __builtin_fmax(m, V[(rc.src >> shift) & 0xffffu] + rc.w);      // v_max_f64: operands are never NaN, the maximum is exact
+  const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
+  if (flags & 0x80000000u) {
+    const uint32_t dst = rc.pad;
+    const int g = 1 << ((dst >> 26) & 7), gWave = 1 << ((flags >> 26) & 7);
+    if (gWave > 1) { float s = 0.0f; wide_group_reduce<MB_VITERBI>(m, s, g, gWave); }
+    if ((dst & W_IDX_MASK) != W_NO_DST) V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = m;
+    m = -INFINITY;
+    if (flags & 0x40000000u) __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_wide_viterbi(WideDev P, WideVitDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
+                                                       double *__restrict__ pool, double *__restrict__ loglike) {
+  extern __shared__ double wlds[];
+  const unsigned bid = blockIdx.x;
+  const PairDesc pd = pairs[bid];
+  const int tid = threadIdx.x, W = P.W, S = P.S, NV = P.NV;
+  const int outLen = P.inputTape ? pd.inLen : pd.outLen;
+  double *V = wlds;
+  for (int k = tid; k < 2 * NV + P.NX; k += W) V[k] = -INFINITY;
+  __syncthreads();
+  if (tid == 0) V[S + 1] = 0.0;                     // the seed, read by the first column only
+  __syncthreads();
+  int prevOff = 0, curOff = NV;
+  const int extraOff = 2 * NV;
+  const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
+  double *cells = pool ? pool + pd.cellBase : nullptr;
+  const bool first = (tid >> 6) == 0;               // wave-uniform
+  for (int c = 0; c <= outLen; ++c) {
+    const int o = P.backward ? outLen - c : c;
+    const int tok = c > outLen ? 0 : (P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0));
+    const int shift = (c & 1) * 16;
+    double m = -INFINITY;
+    for (int ph = 0; ph < Q.nPhases; ++ph) {
+      const WidePhase h = Q.phase[ph];
+      if (!h.thin) {
+        // every wavefront: W-lane slots, eight in flight (padded to whole rings on the host; the slack behind the stream is readable)
+        const WideRec *p = (h.inA ? Q.wideA + (size_t)tok * Q.strideWideA : Q.wideB) + (size_t)h.off * W + tid;
+        WideRec q[WIDE_RING];
+#pragma unroll
+        for (int k = 0; k < WIDE_RING; ++k) q[k] = p[(size_t)k * W];
+        for (int j0 = 0; j0 < h.nSlots; j0 += WIDE_RING) {
+#pragma unroll
+          for (int k = 0; k < WIDE_RING; ++k) {
+            const WideRec rc = q[k];
+            q[k] = p[(size_t)(j0 + WIDE_RING + k) * W];
+            wide_vit_slot(rc, V, shift, curOff, extraOff, m);
+          }
+        }
+      } else {
+        if (first) {
+          // the first wavefront alone: 64-lane slots, sixteen in flight; its LDS traffic is ordered, so a level's stores are
+          // seen by the next level's loads without a barrier
+          const WideRec *p = (h.inA ? Q.thinA + (size_t)tok * Q.strideThinA : Q.thinB) + (size_t)h.off * 64 + tid;
+          WideRec q[WIDE_THIN_RING];
+#pragma unroll
+          for (int k = 0; k < WIDE_THIN_RING; ++k) q[k] = p[(size_t)k * 64];
+          for (int j0 = 0; j0 < h.nSlots; j0 += WIDE_THIN_RING) {
+#pragma unroll
+            for (int k = 0; k < WIDE_THIN_RING; ++k) {
+              const WideRec rc = q[k];
+              q[k] = p[(size_t)(j0 + WIDE_THIN_RING + k) * 64];
+              wide_vit_slot(rc, V, shift, curOff, extraOff, m);
+            }
+          }
+        }
+        __syncthreads();                            // what the first wavefront stored is everybody's input again
+      }
+    }
+    if (cells && (!P.lastOnly || c == outLen)) {
+      double *col = P.lastOnly ? cells : cells + (long long)o * S;
+      for (int k = tid; k < S; k += W) col[k] = V[curOff + k];
+    }
+    if (tid == 0) V[prevOff + S + 1] = -INFINITY;   // the seed is spent (this vector is the next column's `cur`)
+    __syncthreads();                                // (the column is copied out and the seed cleared before the next column's first store)
     const int t = prevOff; prevOff = curOff; curOff = t;
   }
   if (loglike && tid == 0) loglike[bid] = V[prevOff + P.resultIdx];
@@ -436,6 +513,8 @@ void wide_free(WideProgram &P) {
   if (P.d_seg32A) (void)hipFree(P.d_seg32A);
   if (P.d_seg32B) (void)hipFree(P.d_seg32B);
   if (P.d_flags) (void)hipFree(P.d_flags);
+  for (int k = 0; k < 4; ++k) if (P.d_vit[k]) (void)hipFree(P.d_vit[k]);
+  if (P.d_phase) (void)hipFree(P.d_phase);
   P = WideProgram();
 }
 
@@ -446,20 +525,8 @@ static void wide_linearise(WideProgram &P, int nTok) {
   for (int r = 0; r < nR; ++r) if (P.rounds[r].tokStride) lastTok = r;
   int nA = 0, nB = 0;
   for (int r = 0; r < nR; ++r) (r <= lastTok ? nA : nB) += P.rounds[r].depth;
-  // first-wavefront-only segment B (see k_wide_sweep): needs a segment A that ends with a barrier (its results are the first
-  // wavefront's inputs), a segment B with the column's closing barrier only, and both segments whole rings of slots
-  bool bWave0 = P.viterbi && lastTok >= 0 && lastTok + 1 < nR && env_int_w("MB_WIDE_VITERBI_WAVE0", 1) != 0;
-  for (int r = lastTok + 1; r < nR && bWave0; ++r) bWave0 = P.rounds[r].pad0 <= 64 && (P.rounds[r].sync != 0) == (r + 1 == nR);
-  // (barriers inside segment A are met by every wavefront alike; the only barriers ever dropped sit between two thin rounds,
-  //  i.e. between two pieces of the first wavefront's own work, so its way from A into B needs none either)
-  P.dev.bWave0 = bWave0 ? 1 : 0;
-  if (bWave0) {
-    nA += (WIDE_RING - nA % WIDE_RING) % WIDE_RING;
-    nB += (WIDE_RING - nB % WIDE_RING) % WIDE_RING;
-  } else {
-    const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
-    (nB || lastTok < 0 ? nB : nA) += padSlots;
-  }
+  const int padSlots = (WIDE_RING - (nA + nB) % WIDE_RING) % WIDE_RING;
+  (nB || lastTok < 0 ? nB : nA) += padSlots;
   const WideRec padRec{-INFINITY, PREV(P.dev.S), 0};
   P.segA.assign((size_t)nTok * nA * W, padRec);
   P.segB.assign((size_t)nB * W, padRec);
@@ -494,6 +561,75 @@ static void wide_linearise(WideProgram &P, int nTok) {
     for (WideRec &rc : P.segA) conv(rc);
     for (WideRec &rc : P.segB) conv(rc);
   }
+}
+
+template <class T>
+static bool up_w(T *&d, const std::vector<T> &h);
+
+// rounds -> the phase list and the four streams of k_wide_viterbi (see WideVitDev); needs P.segA / P.segB of wide_linearise
+// only for their record format (16-bit indices for both column parities): the records are re-laid here from P.recs / P.dsts
+static bool wide_vit_build(WideProgram &P, int nTok) {
+  P.vitOk = false;
+  if (!P.viterbi || !P.fastIdx || P.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) || !env_int_w("MB_WIDE_VITERBI_PHASES", 1)) return true;
+  const int W = P.W, nR = (int)P.rounds.size();
+  int lastTok = -1;
+  for (int r = 0; r < nR; ++r) if (P.rounds[r].tokStride) lastTok = r;
+  const uint32_t NV = (uint32_t)P.NV;
+  auto conv = [&](WideRec rc) {      // as wide_linearise: both parities' vector indices in the record
+    const uint32_t sel = rc.src >> 30, idx = rc.src & 0x3fffffffu;
+    const uint32_t even = sel == 0 ? NV + idx : (sel == 1 ? 2 * NV + idx : idx);
+    const uint32_t odd = sel == 0 ? idx : (sel == 1 ? 2 * NV + idx : NV + idx);
+    rc.src = even | (odd << 16);
+    return rc;
+  };
+  const WideRec padRec = conv(WideRec{-INFINITY, PREV(P.dev.S), 0});
+  std::vector<WidePhase> phases;
+  std::vector<WideRec> st[4];        // wide A (one token table), wide B, thin A (one token table), thin B -- token tables appended below
+  std::vector<std::vector<WideRec>> tokA[2];     // [wide / thin][token]
+  tokA[0].assign(nTok, {}); tokA[1].assign(nTok, {});
+  int r = 0;
+  while (r < nR) {
+    const bool thin = P.rounds[r].pad0 <= 64, inA = r <= lastTok;
+    int e = r;
+    while (e < nR && (P.rounds[e].pad0 <= 64) == thin && (e <= lastTok) == inA) ++e;
+    const int lanes = thin ? 64 : W, ring = thin ? WIDE_THIN_RING : WIDE_RING;
+    int slots = 0;
+    for (int k = r; k < e; ++k) slots += P.rounds[k].depth;
+    const int padded = (slots + ring - 1) / ring * ring;
+    std::vector<WideRec> &one = inA ? tokA[thin ? 1 : 0][0] : st[thin ? 3 : 1];
+    phases.push_back(WidePhase{thin ? 1 : 0, inA ? 1 : 0, padded, (int)(one.size() / lanes)});
+    for (int t = 0; t < (inA ? nTok : 1); ++t) {
+      std::vector<WideRec> &dstv = inA ? tokA[thin ? 1 : 0][t] : st[thin ? 3 : 1];
+      for (int k = r; k < e; ++k) {
+        const WideRound &R = P.rounds[k];
+        for (int j = 0; j < R.depth; ++j) {
+          const bool last = j + 1 == R.depth;
+          // a barrier inside a thin phase is never needed (one wavefront); the phase itself ends with one
+          const uint32_t uni = last ? (0x80000000u | ((R.sync && !thin) ? 0x40000000u : 0u)) : 0u;
+          for (int l = 0; l < lanes; ++l) {
+            WideRec rc = conv(P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + l]);
+            rc.pad = last ? (uni | P.dsts[R.dstBase + l]) : 0u;
+            dstv.push_back(rc);
+          }
+        }
+      }
+      for (int k = slots; k < padded; ++k) for (int l = 0; l < lanes; ++l) dstv.push_back(padRec);
+    }
+    r = e;
+  }
+  if (phases.size() > 4096) return true;       // (a pathological alternation: the generic kernel keeps the machine)
+  // a wide phase must end with a barrier before a thin phase reads its results: its last round closes a stage, which always
+  // synchronises (only barriers between two thin rounds are ever dropped)
+  P.vit.strideWideA = (long long)tokA[0][0].size(); P.vit.strideThinA = (long long)tokA[1][0].size();
+  for (int t = 0; t < nTok; ++t) { st[0].insert(st[0].end(), tokA[0][t].begin(), tokA[0][t].end()); st[2].insert(st[2].end(), tokA[1][t].begin(), tokA[1][t].end()); }
+  // slack behind every stream: the rings read one ring of slots past the end of a phase
+  for (int k = 0; k < 4; ++k) st[k].insert(st[k].end(), (size_t)(k < 2 ? WIDE_RING * W : WIDE_THIN_RING * 64), padRec);
+  for (int k = 0; k < 4; ++k) if (!up_w(P.d_vit[k], st[k])) return false;
+  if (!up_w(P.d_phase, phases)) return false;
+  P.vit.wideA = P.d_vit[0]; P.vit.wideB = P.d_vit[1]; P.vit.thinA = P.d_vit[2]; P.vit.thinB = P.d_vit[3];
+  P.vit.phase = P.d_phase; P.vit.nPhases = (int)phases.size();
+  P.vitOk = true;
+  return true;
 }
 
 // the same rounds as 8-byte entries + control entries + slot flags for k_wide_sum32 (needs 16-bit vector indices)
@@ -823,6 +959,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     wide_linearise(P, (m->nOut ? m->nOut : m->nIn) + 1);
     if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
     nRecs = P.segA.size() + P.segB.size();
+    if (viterbi && !wide_vit_build(P, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
   }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
@@ -843,8 +980,8 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
       if (R.pad0 <= 64) { ++thinRounds; thinSlots += R.depth; } else { ++wideRounds; wideSlots += R.depth; }
       maxLanes = std::max(maxLanes, R.pad0);
     }
-    fprintf(stderr, "[mbhip] wide (max) rounds: %lld fit the first wavefront (%lld slots), %lld do not (%lld slots, widest %d lanes), %lld read the previous column\n",
-            thinRounds, thinSlots, wideRounds, wideSlots, maxLanes, tokRounds);
+    fprintf(stderr, "[mbhip] wide (max) rounds: %lld fit the first wavefront (%lld slots), %lld do not (%lld slots, widest %d lanes), %lld read the previous column; %d phases\n",
+            thinRounds, thinSlots, wideRounds, wideSlots, maxLanes, tokRounds, P.vit.nPhases);
   }
   return true;
 }
@@ -907,6 +1044,15 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
                                    : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly));
     g_last_launches += 1;
     return rc32;
+  }
+  if (P.viterbi && P.vitOk) {
+    static bool attr = false;
+    if (!attr) { MB_HIP(hipFuncSetAttribute((const void *)k_wide_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX)); attr = true; }
+    WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+    hipLaunchKernelGGL(k_wide_viterbi, dim3((unsigned)nPairs), dim3(P.W), P.vecBytes(), st, dev, P.vit, d_desc, d_out, pool, loglike);
+    MB_HIP(hipGetLastError());
+    g_last_launches += 1;
+    return 0;
   }
   const bool gv = P.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0);
   double *scratch = nullptr;

@@ -904,6 +904,13 @@ def test_rolling_small_batch_uses_pipeline(capi, oracle_mod, machines, monkeypat
     monkeypatch.setenv("MB_ROLLING_MIN_PAIRS", "192")
     got = b.forward(capi.MB_ROLLING); n1 = capi.last_launch_count()
     assert n1 != n0 and close(got, ref, 1e-12)
+    monkeypatch.setenv("MB_MEDIUM_ROLLTILES", "0")       # round 2: the same tiles WITH the matrix stored for nothing
+    assert close(b.forward(capi.MB_ROLLING), got, 1e-12)
+    monkeypatch.delenv("MB_MEDIUM_ROLLTILES")
+    pairs2 = pairs + [synth_tokens(70, 150, 700, em.nInTok, em.nOutTok)]     # several strips and blocks: halo columns and boundary records
+    b2 = capi.DeviceBatch.from_pairs(dm, pairs2)
+    g2 = b2.forward(capi.MB_ROLLING)
+    assert capi.last_kernel_name() == "k_medium_jit" and close(g2, b2.forward(capi.MB_MATERIALISE), 1e-12)
     om = oracle_mod.OracleMachine(em)
     assert close(got, [om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs], FAST_REL, FAST_ABS)
 
@@ -925,7 +932,12 @@ def test_memory_budget_chunking(capi, machines):
         assert np.array_equal(v[0], ref_v[0]) and np.array_equal(v[1], ref_v[1]) and np.array_equal(v[2], ref_v[2])
         c = b.counts()
         assert close(c[0], ref_c[0], 1e-5, 1e-9) and np.array_equal(c[2], ref_c[2])   # per-tile fp32 usage sums: tiling differs per sub-batch
-        capi.set_memory_budget(one // 2)
+        capi.set_memory_budget(one // 2)                  # no fp64 matrix fits: a materialised fill is refused ...
+        with pytest.raises(capi.MbError, match="exceeds the device memory budget"):
+            dm.fill(capi.MB_FORWARD, *pairs[-1])
+        v = b.viterbi()                                   # ... while Viterbi (one traceback byte per cell, an eighth of it) still runs
+        assert np.array_equal(v[0], ref_v[0]) and np.array_equal(v[2], ref_v[2])
+        capi.set_memory_budget(one // 16)
         with pytest.raises(capi.MbError, match="exceeds the device memory budget"):
             b.viterbi()
     finally:
@@ -1243,8 +1255,10 @@ def test_baseline_config5_at_its_stated_length(capi, monkeypatch):
     for w in lw[e]:
         acc += w
     assert abs(acc - vll[0]) <= 1e-9 * abs(vll[0])
+    # every symbol is emitted exactly once: at 50 kb to 2e-4 -- the fp32 correction terms of the log-sum-exp (1e-7 each) add up
+    # along 50 000 columns like a random walk (2 kb: 1e-5, test_baseline_config5_full_size_properties; measured here: 4.7e-5)
     counts, s, cll = b2.counts()
-    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 1e-5 * 2 * L and close(cll, llp[:2], 1e-8)
+    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 2e-4 * 2 * L and close(cll, llp[:2], 1e-8)
 
 
 def test_pipelined_forward_matches_plain(capi, machines):
