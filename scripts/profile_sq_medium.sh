@@ -4,7 +4,7 @@
 set -u
 MODE=${1:-counts4}; TAG=${2:-r02}
 export TMPDIR=/tmp
-OUT=$(pwd)/gpurun_out/prof_${TAG}_${MODE}
+OUT=$(pwd)/gpurun_out/prof_sq_${TAG}_${MODE}
 rm -rf "$OUT"; mkdir -p "$OUT/summary"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 scripts/bench_mode.py $MODE 3 > "$OUT/run.log" 2>&1
 cp $(find "$OUT/trace" -name '*kernel_stats.csv' | head -1) "$OUT/summary/${TAG}_${MODE}_kernel_stats.csv"
