@@ -68,15 +68,11 @@ struct WideDev32 {
 // a thin phase is a run of rounds whose nodes all sit in the first wavefront -- 64-lane slots, read by that wavefront alone
 // with a deep prefetch ring while the others wait at the barrier that ends the phase.  Same rounds, same candidates, same
 // order as the generic kernel: the results are the same bits.
-// A phase is `lanes` (64 ... W, a power of two) wide: its slots are rows of that many records and only the first lanes / 64
-// wavefronts read them; every phase ends with ONE workgroup barrier (none inside: the host cuts phases at the rounds that
-// synchronise).  Record control word (WideRec::pad) in these streams: bit 31 = last slot of a round, 29 = destination is an
-// extra entry, 28..26 = log2 of the lane-group size, 25 / 24 = chain flags (see mb_wide.hip), 23..0 = destination index.
 constexpr int WIDE_THIN_RING = 16;
-struct WidePhase { int lanes, inA, nSlots; long long off; };      // off: first RECORD of the phase within its stream
+struct WidePhase { int thin, inA, nSlots, off; };      // off: first slot of the phase within its stream (wide / thin, A / B)
 struct WideVitDev {
-  const WideRec *recA, *recB;                          // A: one table per output token (the emitting rounds), B: shared
-  long long strideA;                                   // records per token table
+  const WideRec *wideA, *wideB, *thinA, *thinB;        // A: one table per output token (the emitting rounds), B: shared
+  long long strideWideA, strideThinA;                  // records per token table
   const WidePhase *phase;
   int nPhases;
 };
@@ -107,8 +103,7 @@ struct WideProgram {
   WideDev32 dev32{};
   // the phase-structured streams of k_wide_viterbi (built for max programs whose vectors sit in LDS with 16-bit indices)
   bool vitOk = false;
-  bool chains = false;               // max program closed exactly over silent paths (chain records): k_wide_viterbi only
-  WideRec *d_vit[2] = {nullptr, nullptr};
+  WideRec *d_vit[4] = {nullptr, nullptr, nullptr, nullptr};
   WidePhase *d_phase = nullptr;
   WideVitDev vit{};
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
@@ -125,6 +120,7 @@ void wide_free(WideProgram &P);
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly = false);
+bool wide_viterbi_uses_phases(const WideProgram &P);      // the max program of this machine runs k_wide_viterbi (else k_wide_sweep<1>)
 // Two sweeps (e.g. Forward over one set of pairs, Backward over another) in ONE launch: workgroups 0..nA-1 run program A,
 // the rest program B, so both are on the chip together whatever the queue scheduler does with two streams.  Returns -1
 // (nothing launched) when the two programs do not share a kernel variant.

@@ -35,9 +35,6 @@ namespace mb {
 static constexpr double W_NEG_BIG = -1e300;       // finite stand-in for -inf in the running maximum (avoids inf - inf)
 static constexpr uint32_t W_IDX_MASK = 0x03ffffffu;
 static constexpr uint32_t W_NO_DST = 0x03ffffffu;
-// record flags of a chain step (WideRec::pad at planning time; the phase kernel's control word keeps them in the same bits)
-static constexpr uint32_t W_CH_CONT = 1u << 25;      // add the weight to the lane's running chain value instead of a freshly loaded entry
-static constexpr uint32_t W_CH_HOLD = 1u << 24;      // the chain goes on: do not fold its value yet
 static constexpr long long WIDE_STAGES_DP = 1ll << 30;      // wide_nodes(K = -WIDE_STAGES_DP): stage boundaries by dynamic programming
 static const size_t WIDE_LDS_MAX = 160 * 1024;
 
@@ -184,38 +181,18 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
   if (loglike && tid == 0) loglike[bid] = V[prevOff + P.resultIdx];
 }
 
-// ---- max programs walked phase by phase (see WideVitDev) ---------------------------------------------------------------------
-// one slot of a round: the lane's record is a plain candidate (V[src] + w, folded at once) or a step of a chain (see "exact
-// closure for the max semiring" below: the running value of the chain gets one more weight; folded when the chain ends);
-// on the round's last slot the lane groups are reduced and the group's first lane stores
-static constexpr uint32_t WV_CONT = 1u << 25, WV_HOLD = 1u << 24, WV_IDX = 0x00ffffffu;
-__device__ __forceinline__ void wide_vit_slot(const WideRec rc, double *V, int shift, int curOff, int extraOff, double &m, double &cv) {
-  const double x = V[(rc.src >> shift) & 0xffffu];
-  cv = ((rc.pad & WV_CONT) ? cv : x) + rc.w;
-  m = (rc.pad & WV_HOLD) ? m : __builtin_fmax(m, cv);      // v_max_f64: operands are never NaN, the maximum is exact
+// ---- levelled max programs walked phase by phase (see WideVitDev) ----------------------------------------------------------
+// one slot of a round: fold the lane's candidate; on the round's last slot reduce the lane groups and store
+__device__ __forceinline__ void wide_vit_slot(const WideRec rc, double *V, int shift, int curOff, int extraOff, double &m) {
+  m = __builtin_fmax(m, V[(rc.src >> shift) & 0xffffu] + rc.w);      // v_max_f64: operands are never NaN, the maximum is exact
   const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
   if (flags & 0x80000000u) {
     const uint32_t dst = rc.pad;
     const int g = 1 << ((dst >> 26) & 7), gWave = 1 << ((flags >> 26) & 7);
     if (gWave > 1) { float s = 0.0f; wide_group_reduce<MB_VITERBI>(m, s, g, gWave); }
-    if ((dst & WV_IDX) != WV_IDX) V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & WV_IDX)] = m;
+    if ((dst & W_IDX_MASK) != W_NO_DST) V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = m;
     m = -INFINITY;
-  }
-}
-
-template <int RING>
-__device__ __forceinline__ void wide_vit_phase(const WideRec *p, int lanes, int nSlots, double *V, int shift, int curOff, int extraOff) {
-  double m = -INFINITY, cv = 0.0;
-  WideRec q[RING];
-#pragma unroll
-  for (int k = 0; k < RING; ++k) q[k] = p[(size_t)k * lanes];
-  for (int j0 = 0; j0 < nSlots; j0 += RING) {
-#pragma unroll
-    for (int k = 0; k < RING; ++k) {
-      const WideRec rc = q[k];
-      q[k] = p[(size_t)(j0 + RING + k) * lanes];        // (one ring of slack behind every stream)
-      wide_vit_slot(rc, V, shift, curOff, extraOff, m, cv);
-    }
+    if (flags & 0x40000000u) __syncthreads();
   }
 }
 
@@ -235,21 +212,47 @@ __global__ __launch_bounds__(1024) void k_wide_viterbi(WideDev P, WideVitDev Q, 
   const int extraOff = 2 * NV;
   const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
   double *cells = pool ? pool + pd.cellBase : nullptr;
-  const int myWave = tid >> 6;                      // wave-uniform
+  const bool first = (tid >> 6) == 0;               // wave-uniform
   for (int c = 0; c <= outLen; ++c) {
     const int o = P.backward ? outLen - c : c;
-    const int tok = P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0);
+    const int tok = c > outLen ? 0 : (P.backward ? (o < outLen ? out[o] : 0) : (o ? out[o - 1] : 0));
     const int shift = (c & 1) * 16;
+    double m = -INFINITY;
     for (int ph = 0; ph < Q.nPhases; ++ph) {
       const WidePhase h = Q.phase[ph];
-      if (myWave < (h.lanes >> 6)) {
-        const WideRec *p = (h.inA ? Q.recA + (size_t)tok * Q.strideA : Q.recB) + h.off + tid;
-        // one wavefront alone: sixteen slots in flight, and its LDS traffic is ordered -- a level's stores are seen by the
-        // next level's loads without a barrier; several wavefronts: eight in flight, rounds inside the phase are independent
-        if (h.lanes == 64) wide_vit_phase<WIDE_THIN_RING>(p, 64, h.nSlots, V, shift, curOff, extraOff);
-        else wide_vit_phase<WIDE_RING>(p, h.lanes, h.nSlots, V, shift, curOff, extraOff);
+      if (!h.thin) {
+        // every wavefront: W-lane slots, eight in flight (padded to whole rings on the host; the slack behind the stream is readable)
+        const WideRec *p = (h.inA ? Q.wideA + (size_t)tok * Q.strideWideA : Q.wideB) + (size_t)h.off * W + tid;
+        WideRec q[WIDE_RING];
+#pragma unroll
+        for (int k = 0; k < WIDE_RING; ++k) q[k] = p[(size_t)k * W];
+        for (int j0 = 0; j0 < h.nSlots; j0 += WIDE_RING) {
+#pragma unroll
+          for (int k = 0; k < WIDE_RING; ++k) {
+            const WideRec rc = q[k];
+            q[k] = p[(size_t)(j0 + WIDE_RING + k) * W];
+            wide_vit_slot(rc, V, shift, curOff, extraOff, m);
+          }
+        }
+      } else {
+        if (first) {
+          // the first wavefront alone: 64-lane slots, sixteen in flight; its LDS traffic is ordered, so a level's stores are
+          // seen by the next level's loads without a barrier
+          const WideRec *p = (h.inA ? Q.thinA + (size_t)tok * Q.strideThinA : Q.thinB) + (size_t)h.off * 64 + tid;
+          WideRec q[WIDE_THIN_RING];
+#pragma unroll
+          for (int k = 0; k < WIDE_THIN_RING; ++k) q[k] = p[(size_t)k * 64];
+          for (int j0 = 0; j0 < h.nSlots; j0 += WIDE_THIN_RING) {
+#pragma unroll
+            for (int k = 0; k < WIDE_THIN_RING; ++k) {
+              const WideRec rc = q[k];
+              q[k] = p[(size_t)(j0 + WIDE_THIN_RING + k) * 64];
+              wide_vit_slot(rc, V, shift, curOff, extraOff, m);
+            }
+          }
+        }
+        __syncthreads();                            // what the first wavefront stored is everybody's input again
       }
-      __syncthreads();                              // what the phase stored is everybody's input
     }
     if (cells && (!P.lastOnly || c == outLen)) {
       double *col = P.lastOnly ? cells : cells + (long long)o * S;
@@ -510,7 +513,7 @@ void wide_free(WideProgram &P) {
   if (P.d_seg32A) (void)hipFree(P.d_seg32A);
   if (P.d_seg32B) (void)hipFree(P.d_seg32B);
   if (P.d_flags) (void)hipFree(P.d_flags);
-  for (int k = 0; k < 2; ++k) if (P.d_vit[k]) (void)hipFree(P.d_vit[k]);
+  for (int k = 0; k < 4; ++k) if (P.d_vit[k]) (void)hipFree(P.d_vit[k]);
   if (P.d_phase) (void)hipFree(P.d_phase);
   P = WideProgram();
 }
@@ -563,7 +566,8 @@ static void wide_linearise(WideProgram &P, int nTok) {
 template <class T>
 static bool up_w(T *&d, const std::vector<T> &h);
 
-// rounds -> the phase list and the two streams of k_wide_viterbi (see WideVitDev), straight from P.recs / P.dsts
+// rounds -> the phase list and the four streams of k_wide_viterbi (see WideVitDev); needs P.segA / P.segB of wide_linearise
+// only for their record format (16-bit indices for both column parities): the records are re-laid here from P.recs / P.dsts
 static bool wide_vit_build(WideProgram &P, int nTok) {
   P.vitOk = false;
   if (!P.viterbi || !P.fastIdx || P.vecBytes() > WIDE_LDS_MAX || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) || !env_int_w("MB_WIDE_VITERBI_PHASES", 1)) return true;
@@ -578,38 +582,33 @@ static bool wide_vit_build(WideProgram &P, int nTok) {
     rc.src = even | (odd << 16);
     return rc;
   };
-  WideRec padRec = conv(WideRec{-INFINITY, PREV(P.dev.S), 0});
-  auto widthOf = [&](const WideRound &R) { int w = 64; while (w < R.pad0 && w < W) w <<= 1; return w; };
+  const WideRec padRec = conv(WideRec{-INFINITY, PREV(P.dev.S), 0});
   std::vector<WidePhase> phases;
-  std::vector<std::vector<WideRec>> tokA(nTok);
-  std::vector<WideRec> recB;
+  std::vector<WideRec> st[4];        // wide A (one token table), wide B, thin A (one token table), thin B -- token tables appended below
+  std::vector<std::vector<WideRec>> tokA[2];     // [wide / thin][token]
+  tokA[0].assign(nTok, {}); tokA[1].assign(nTok, {});
   int r = 0;
   while (r < nR) {
-    const int lanes = widthOf(P.rounds[r]);
-    const bool inA = r <= lastTok;
-    int e = r;         // the phase: rounds of this width up to and including the first one that synchronises
-    while (e < nR && widthOf(P.rounds[e]) == lanes && (e <= lastTok) == inA) { ++e; if (P.rounds[e - 1].sync) break; }
-    const int ring = lanes == 64 ? WIDE_THIN_RING : WIDE_RING;
+    const bool thin = P.rounds[r].pad0 <= 64, inA = r <= lastTok;
+    int e = r;
+    while (e < nR && (P.rounds[e].pad0 <= 64) == thin && (e <= lastTok) == inA) ++e;
+    const int lanes = thin ? 64 : W, ring = thin ? WIDE_THIN_RING : WIDE_RING;
     int slots = 0;
     for (int k = r; k < e; ++k) slots += P.rounds[k].depth;
     const int padded = (slots + ring - 1) / ring * ring;
-    phases.push_back(WidePhase{lanes, inA ? 1 : 0, padded, (long long)(inA ? tokA[0].size() : recB.size())});
+    std::vector<WideRec> &one = inA ? tokA[thin ? 1 : 0][0] : st[thin ? 3 : 1];
+    phases.push_back(WidePhase{thin ? 1 : 0, inA ? 1 : 0, padded, (int)(one.size() / lanes)});
     for (int t = 0; t < (inA ? nTok : 1); ++t) {
-      std::vector<WideRec> &dstv = inA ? tokA[t] : recB;
+      std::vector<WideRec> &dstv = inA ? tokA[thin ? 1 : 0][t] : st[thin ? 3 : 1];
       for (int k = r; k < e; ++k) {
         const WideRound &R = P.rounds[k];
         for (int j = 0; j < R.depth; ++j) {
           const bool last = j + 1 == R.depth;
+          // a barrier inside a thin phase is never needed (one wavefront); the phase itself ends with one
+          const uint32_t uni = last ? (0x80000000u | ((R.sync && !thin) ? 0x40000000u : 0u)) : 0u;
           for (int l = 0; l < lanes; ++l) {
-            const WideRec &raw = P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + l];
-            WideRec rc = conv(raw);
-            uint32_t ctl = raw.pad & (W_CH_CONT | W_CH_HOLD);
-            if (last) {
-              const uint32_t d = P.dsts[R.dstBase + l], idx = d & W_IDX_MASK;
-              if (idx != W_NO_DST && idx >= 0x00ffffffu) return true;       // (more than 16 M vector entries: the generic kernel keeps the machine)
-              ctl |= 0x80000000u | (d & 0x3c000000u) | (idx == W_NO_DST ? 0x00ffffffu : idx);
-            }
-            rc.pad = ctl;
+            WideRec rc = conv(P.recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + l]);
+            rc.pad = last ? (uni | P.dsts[R.dstBase + l]) : 0u;
             dstv.push_back(rc);
           }
         }
@@ -618,15 +617,16 @@ static bool wide_vit_build(WideProgram &P, int nTok) {
     }
     r = e;
   }
-  if (phases.size() > 8192) return true;       // (a pathological alternation of widths: the generic kernel keeps the machine)
-  P.vit.strideA = (long long)tokA[0].size();
-  std::vector<WideRec> recA;
-  for (int t = 0; t < nTok; ++t) recA.insert(recA.end(), tokA[t].begin(), tokA[t].end());
-  // slack behind both streams: the rings read one ring of slots past the end of a phase
-  recA.insert(recA.end(), (size_t)WIDE_THIN_RING * W, padRec);
-  recB.insert(recB.end(), (size_t)WIDE_THIN_RING * W, padRec);
-  if (!up_w(P.d_vit[0], recA) || !up_w(P.d_vit[1], recB) || !up_w(P.d_phase, phases)) return false;
-  P.vit.recA = P.d_vit[0]; P.vit.recB = P.d_vit[1];
+  if (phases.size() > 4096) return true;       // (a pathological alternation: the generic kernel keeps the machine)
+  // a wide phase must end with a barrier before a thin phase reads its results: its last round closes a stage, which always
+  // synchronises (only barriers between two thin rounds are ever dropped)
+  P.vit.strideWideA = (long long)tokA[0][0].size(); P.vit.strideThinA = (long long)tokA[1][0].size();
+  for (int t = 0; t < nTok; ++t) { st[0].insert(st[0].end(), tokA[0][t].begin(), tokA[0][t].end()); st[2].insert(st[2].end(), tokA[1][t].begin(), tokA[1][t].end()); }
+  // slack behind every stream: the rings read one ring of slots past the end of a phase
+  for (int k = 0; k < 4; ++k) st[k].insert(st[k].end(), (size_t)(k < 2 ? WIDE_RING * W : WIDE_THIN_RING * 64), padRec);
+  for (int k = 0; k < 4; ++k) if (!up_w(P.d_vit[k], st[k])) return false;
+  if (!up_w(P.d_phase, phases)) return false;
+  P.vit.wideA = P.d_vit[0]; P.vit.wideB = P.d_vit[1]; P.vit.thinA = P.d_vit[2]; P.vit.thinB = P.d_vit[3];
   P.vit.phase = P.d_phase; P.vit.nPhases = (int)phases.size();
   P.vitOk = true;
   return true;
@@ -860,189 +860,6 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long lo
   return true;
 }
 
-// ---- exact closure for the max semiring ("chains") -------------------------------------------------------------------------
-// The log-sum-exp sweeps close the silent levels on the host (weights summed over silent paths), which is not available to
-// Viterbi: the reference adds ONE weight per transition, left to right along the path, and a pre-added closure weight rounds
-// differently.  But rounding is MONOTONE -- a <= b implies fl(a + w) <= fl(b + w) -- so adding a weight commutes with max:
-//     fl(max_k(a_k) + w) = max_k fl(a_k + w).
-// The value of a state is therefore the maximum over silent PATHS from (a) states final in earlier stages and (b) emit-only
-// parts of states of its own stage, of the path's weights added one by one IN PATH ORDER -- bit for bit what the reference's
-// level-by-level evaluation gives (every partial sum is the same rounded sum).  A chain is one such path: a source entry and
-// its weights; a lane evaluates v = ((V[src] + w1) + w2) + ... in registers (one LDS read, no stores in between) and folds v
-// into the group's running maximum.  Paths are not merged (their roundings differ), so stages stay short: levels are added
-// to a stage while the total number of additions stays within a budget.
-struct WChain { uint32_t src; std::vector<double> w; };
-struct WChainNode { uint32_t dst; int stage; std::vector<WChain> ch; long long steps; int lmax; };
-
-// stage >= 1 nodes of the chain program (stage-0 nodes = emit-only parts: as in wide_nodes, appended to `emitNodes`).
-// budgetSteps: additions per stage; returns false when a state's chains explode (caller takes a smaller budget / the levelled program)
-static bool wide_chain_nodes(const mb_machine *m, long long budgetSteps, std::vector<WNode> &emitNodes, std::vector<WChainNode> &cn, int &nExtra,
-                             int &nStages, long long &totalSteps) {
-  const int S = m->S, nOut = m->nOut ? m->nOut : m->nIn;
-  const std::vector<int> &off = m->inOff;
-  const std::vector<uint32_t> &perm = m->inPerm;
-  const int nLev = m->nLevF;
-  std::vector<std::vector<std::vector<WCand>>> emitC(S, std::vector<std::vector<WCand>>(nOut + 1));
-  std::vector<std::vector<std::pair<int, double>>> sil(S);
-  for (int x = 0; x < S; ++x)
-    for (int tok = 0; tok <= nOut; ++tok) {
-      const long long rw = (long long)x * (nOut + 1) + tok;
-      for (int a = off[rw]; a < off[rw + 1]; ++a) {
-        const uint32_t e = perm[a];
-        const int y = (int)m->src[e];
-        if (tok) emitC[x][tok].push_back({PREV(y), m->logW[e]});
-        else if (y < x) sil[x].push_back({y, m->logW[e]});
-      }
-    }
-  emitC[0][0].push_back({PREV(S + 1), 0.0});      // the seed
-  std::vector<char> isBase(S, 0);
-  for (int x = 0; x < S; ++x) for (const auto &l : emitC[x]) if (!l.empty()) isBase[x] = 1;
-  std::vector<int> eslot(S, -1);
-  nExtra = 0;
-  for (int x = 0; x < S; ++x) if (isBase[x] && !sil[x].empty()) eslot[x] = nExtra++;
-  std::vector<int> stg(S, 0);
-  std::vector<std::vector<WChain>> chains(S);
-  const long long perStateCap = 4096;
-  auto closeRow = [&](int x) -> long long {          // chains of x given stg[] of x and of everything below it; returns its additions (-1: explosion)
-    std::vector<WChain> &out = chains[x];
-    out.clear();
-    long long steps = 0;
-    for (auto &pe : sil[x]) {
-      const int y = pe.first; const double w = pe.second;
-      if (w == -INFINITY) continue;                  // a -inf candidate never wins a max that has a finite member, and changes nothing in one that has none
-      if (stg[y] < stg[x]) { out.push_back(WChain{CUR(y), {w}}); steps += 1; continue; }
-      if (isBase[y]) { out.push_back(WChain{EXTRA(eslot[y]), {w}}); steps += 1; }
-      for (const WChain &c : chains[y]) {
-        WChain n{c.src, c.w};
-        n.w.push_back(w);
-        steps += (long long)n.w.size();
-        out.push_back(std::move(n));
-        if ((long long)out.size() > perStateCap) return -1;
-      }
-    }
-    return steps;
-  };
-  const std::vector<int> &levOff = m->levFOff, &levState = m->levFState;
-  auto closeLevel = [&](int L, int stage) -> long long {
-    long long steps = 0;
-    for (int k = levOff[L]; k < levOff[L + 1]; ++k) {
-      const int x = levState[k];
-      stg[x] = stage;
-      const long long st = closeRow(x);
-      if (st < 0) return -1;
-      steps += st + (isBase[x] ? 1 : 0);
-    }
-    return steps;
-  };
-  int cur = 1; long long inStage = 0;
-  totalSteps = 0;
-  for (int L = 1; L < nLev; ++L) {
-    long long st = closeLevel(L, cur);
-    if (st < 0 || (inStage > 0 && inStage + st > budgetSteps)) {      // the level opens a new stage: its chains are its direct predecessors
-      if (inStage == 0) return false;                                  // (a single level cannot explode: every chain has one weight)
-      ++cur; inStage = 0;
-      st = closeLevel(L, cur);
-      if (st < 0) return false;
-    }
-    inStage += st; totalSteps += st;
-  }
-  nStages = cur + 1;
-  emitNodes.clear(); cn.clear();
-  for (int x = 0; x < S; ++x) {
-    if (isBase[x]) emitNodes.push_back(WNode{eslot[x] >= 0 ? EXTRA(eslot[x]) : CUR(x), 0, emitC[x], {}});
-    if (sil[x].empty()) continue;
-    WChainNode nd{CUR(x), stg[x], {}, 0, 1};
-    if (isBase[x]) nd.ch.push_back(WChain{EXTRA(eslot[x]), {0.0}});      // its own emit-only part (x + 0.0 = x for every value a cell takes)
-    for (WChain &c : chains[x]) nd.ch.push_back(std::move(c));
-    for (const WChain &c : nd.ch) { nd.steps += (long long)c.w.size(); nd.lmax = std::max(nd.lmax, (int)c.w.size()); }
-    if (!nd.ch.empty()) cn.push_back(std::move(nd));
-  }
-  return true;
-}
-
-// rounds of one chain stage; returns the modelled cost, appends rounds / records / destinations to P when `emit`
-static double plan_chain_stage(const std::vector<const WChainNode *> &nodes, int W, bool emit, WideProgram *P) {
-  const int n = (int)nodes.size();
-  if (!n) return 0.0;
-  const double cSlot = 60.0, cRound = 105.0, cSync = 10.0;
-  int lmax = 1; long long maxSteps = 1;
-  for (const WChainNode *nd : nodes) { lmax = std::max(lmax, nd->lmax); maxSteps = std::max(maxSteps, nd->steps); }
-  // lanes of a node for a target depth d, and the depth its chains really need on them (longest-first onto the least loaded lane)
-  auto layout = [&](const WChainNode &nd, int d, std::vector<std::vector<int>> *lanesOut) -> std::pair<int, int> {
-    const int g = (int)std::min<long long>(64, pow2ceil((int)((nd.steps + d - 1) / d)));
-    std::vector<int> order(nd.ch.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nd.ch[a].w.size() > nd.ch[b].w.size(); });
-    std::vector<long long> load(g, 0);
-    if (lanesOut) lanesOut->assign(g, {});
-    for (int c : order) {
-      int best = 0;
-      for (int l = 1; l < g; ++l) if (load[l] < load[best]) best = l;
-      load[best] += (long long)nd.ch[c].w.size();
-      if (lanesOut) (*lanesOut)[best].push_back(c);
-    }
-    long long depth = 1;
-    for (long long v : load) depth = std::max(depth, v);
-    return {g, (int)depth};
-  };
-  int bestD = lmax; double best = 1e300;
-  for (int d = lmax; d <= (int)std::min<long long>(maxSteps, 1 << 14); d = std::max(d + 1, (d * 5) / 4)) {
-    long long lanes = 0; int depth = 1;
-    for (const WChainNode *nd : nodes) { const auto gd = layout(*nd, d, nullptr); lanes += gd.first; depth = std::max(depth, gd.second); }
-    const long long R = (lanes + W - 1) / W;
-    const double c = R * (depth * cSlot + cRound) + cSync;
-    if (c < best) { best = c; bestD = d; }
-    if (R == 1 && lanes <= 64) break;
-  }
-  if (!emit) return best;
-  std::vector<int> order(n), grp(n);
-  for (int i = 0; i < n; ++i) grp[i] = layout(*nodes[i], bestD, nullptr).first;
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return grp[a] > grp[b]; });
-  int pos = 0;
-  while (pos < n) {
-    int lanes = 0, e = pos, depth = 1, mg = 1;
-    std::vector<std::vector<std::vector<int>>> lay;
-    while (e < n && lanes + grp[order[e]] <= W) {
-      lay.emplace_back();
-      const auto gd = layout(*nodes[order[e]], bestD, &lay.back());
-      lanes += gd.first; depth = std::max(depth, gd.second); mg = std::max(mg, gd.first);
-      ++e;
-    }
-    WideRound R{};
-    R.recBase = (int)P->recs.size(); R.depth = depth; R.dstBase = (int)P->dsts.size(); R.maxG = mg; R.sync = 0; R.pad0 = lanes; R.tokStride = 0;
-    const WideRec padRec{-INFINITY, PREV(P->dev.S), 0};
-    P->recs.resize(P->recs.size() + (size_t)depth * W, padRec);
-    P->dsts.resize(P->dsts.size() + W, W_NO_DST);
-    int lane = 0;
-    for (int q = pos; q < e; ++q) {
-      const WChainNode &nd = *nodes[order[q]];
-      const int g = grp[order[q]];
-      for (int sub = 0; sub < g; ++sub) {
-        P->dsts[R.dstBase + lane + sub] = (sub == 0 ? ((nd.dst >> 30) << 29) | (nd.dst & W_IDX_MASK) : W_NO_DST) | ((uint32_t)ilog2(g) << 26);
-        int j = 0;
-        for (int c : lay[q - pos][sub]) {
-          const WChain &chn = nd.ch[c];
-          for (size_t k = 0; k < chn.w.size(); ++k, ++j) {
-            WideRec &rc = P->recs[(size_t)R.recBase + (size_t)j * W + lane + sub];
-            rc.w = chn.w[k];
-            rc.src = k == 0 ? chn.src : PREV(P->dev.S);      // (a continuation loads the -inf sentinel and discards it)
-            rc.pad = (k ? W_CH_CONT : 0u) | (k + 1 < chn.w.size() ? W_CH_HOLD : 0u);
-            P->candsPerColumn++;
-          }
-        }
-      }
-      lane += g;
-    }
-    P->slotsPerColumn += depth;
-    P->rounds.push_back(R);
-    pos = e;
-  }
-  P->rounds.back().sync = 1;
-  P->nSync++;
-  return best;
-}
-
 static double wide_plan(const std::vector<WNode> &nodes, int nStages, int nTok, int W, bool emit, WideProgram *P) {
   std::vector<std::vector<const WNode *>> byStage(nStages + 1);
   for (const WNode &n : nodes) byStage[std::min(n.stage, nStages)].push_back(&n);
@@ -1081,35 +898,8 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     if (c < best) { best = c; bestNodes.swap(nodes); bestExtra = nExtra; bestStages = nStages; bestK = K; bestPairs = nPairs; }
     return true;
   };
-  // Viterbi: the levelled program (one stage per silent level), or -- forward sweeps whose vectors fit the LDS -- the EXACT closure
-  // over silent paths (chains), stage budget chosen by the same cost model
-  std::vector<WNode> chEmit, bestChEmit;
-  std::vector<WChainNode> chNodes, bestChNodes;
-  int bestChExtra = 0, bestChStages = 0; long long bestChSteps = 0;
-  double bestChain = 1e300;
-  if (viterbi) {
-    consider(0);
-    if (!backward && env_int_w("MB_WIDE_VITERBI_CHAINS", 1) && env_int_w("MB_WIDE_VITERBI_PHASES", 1) && !env_int_w("MB_WIDE_GLOBAL_VECTORS", 0)) {
-      const int nTok = (m->nOut ? m->nOut : m->nIn) + 1;
-      const int forced = env_int_w("MB_WIDE_VITERBI_CHAIN_BUDGET", 0);
-      for (long long budget : {(long long)P.W / 4, (long long)P.W / 2, (long long)P.W, 2ll * P.W, 4ll * P.W, 8ll * P.W, 16ll * P.W}) {
-        if (forced > 0) budget = forced;
-        int ex = 0, ns = 0; long long steps = 0;
-        if (wide_chain_nodes(m, budget, chEmit, chNodes, ex, ns, steps) &&
-            (size_t)(2 * (S + 2) + ex + 1) <= 65536 && (size_t)(2 * (S + 2) + ex + 1) * sizeof(double) <= WIDE_LDS_MAX) {
-          std::vector<const WNode *> e0;
-          for (const WNode &n : chEmit) e0.push_back(&n);
-          double c = plan_stage(e0, nTok, P.W, false, nullptr);
-          std::vector<std::vector<const WChainNode *>> byStage(ns + 1);
-          for (const WChainNode &n : chNodes) byStage[std::min(n.stage, ns)].push_back(&n);
-          for (auto &v : byStage) c += plan_chain_stage(v, P.W, false, nullptr);
-          if (verbose) fprintf(stderr, "[mbhip] wide max program, exact closure with %lld additions per stage: %d stages, %lld additions per column, modelled %.0f\n", budget, ns - 1, steps, c);
-          if (c < bestChain) { bestChain = c; bestChEmit.swap(chEmit); bestChNodes.swap(chNodes); bestChExtra = ex; bestChStages = ns; bestChSteps = steps; }
-        }
-        if (forced > 0) break;
-      }
-    }
-  } else {
+  if (viterbi) consider(0);
+  else {
     // MB_WIDE_CLOSURE_STAGES: K >= 0 uniform level groups (0 = levelled); -n = adaptive stages of at most n slots of candidates
     const int envK = env_int_w("MB_WIDE_CLOSURE_STAGES", -1000000);
     if (haveShape) consider(keepStages);
@@ -1129,17 +919,6 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.stages = bestK; P.nPairs = bestPairs;
   P.NV = S + 2; P.NX = bestExtra + 1;
   P.dev.S = S;
-  P.chains = viterbi && bestChain < best;
-  if (P.chains) {
-    P.stages = bestChStages - 1; P.nPairs = bestChSteps; P.NX = bestChExtra + 1;
-    bestK = -1;                                   // (not the levelled program: no barrier is dropped below)
-    std::vector<const WNode *> e0;
-    for (const WNode &n : bestChEmit) e0.push_back(&n);
-    plan_stage(e0, (m->nOut ? m->nOut : m->nIn) + 1, P.W, true, &P);
-    std::vector<std::vector<const WChainNode *>> byStage(bestChStages + 1);
-    for (const WChainNode &n : bestChNodes) byStage[std::min(n.stage, bestChStages)].push_back(&n);
-    for (auto &v : byStage) plan_chain_stage(v, P.W, true, &P);
-  } else
   wide_plan(bestNodes, bestStages, (m->nOut ? m->nOut : m->nIn) + 1, P.W, true, &P);
   if (P.rounds.empty()) { set_error("wide program: empty machine"); return false; }
   // Runs of thin levels (a profile's delete chain: 2-20 states per level, hundreds of levels): when a stage and the next
@@ -1181,7 +960,6 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
     nRecs = P.segA.size() + P.segB.size();
     if (viterbi && !wide_vit_build(P, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
-    if (P.chains && !P.vitOk) { set_error("wide max program: the chain program needs the phase kernel"); return false; }
   }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
@@ -1245,6 +1023,8 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
   MB_HIP(hipGetLastError());
   return 0;
 }
+
+bool wide_viterbi_uses_phases(const WideProgram &P) { return P.viterbi && P.vitOk; }
 
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly) {
