@@ -909,7 +909,8 @@ struct MedRoll {
 static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev &devIn, const MedGeom &geo, int mode, int TS,
                             const std::vector<PairDesc> &pairs, const PairDesc *d_pairs, const int *d_in, const int *d_out,
                             double *d_pool, double *d_loglike, hipStream_t st, const double *d_poolB = nullptr,
-                            double *d_counts = nullptr, const MedEnv &env = MedEnv(), int matKind = MED_MAT_FULL, const MedRoll *roll = nullptr) {
+                            double *d_counts = nullptr, const MedEnv &env = MedEnv(), int matKind = MED_MAT_FULL, const MedRoll *roll = nullptr,
+                            bool twoStreams = true) {
   const int C = geo.C;
   const long long n = (long long)pairs.size();
   int nLaunch = 0;
@@ -935,16 +936,36 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
       }
     }
   };
-  std::vector<int> cnt(nLaunch + 1, 0);
+  // TWO GROUPS OF PAIRS ON TWO STREAMS.  A launch is one kernel and the next launch waits for it, so a launch whose tiles are
+  // not a multiple of the chip's workgroup slots leaves CUs idle in its last round -- config 4's chunk of 21 pairs has 651 tiles
+  // on its plateau for 256 one-workgroup-per-CU slots: 3 rounds for the work of 2.5, and less on the ramps (modelled: 74 % of
+  // the slots used).  Pairs are independent: dealt in turn to two (MB_MEDIUM_STREAMS) groups whose launches go to streams of
+  // their own, the tail of one group's launch overlaps another group's next one.  Same tiles, same order inside a pair, same results.
+  constexpr int MAXG = 4;
+  hipStream_t sgs[MAXG] = {st, nullptr, nullptr, nullptr};
+  int nG = 1;
+  {
+    static hipStream_t extra[MAXG - 1] = {nullptr, nullptr, nullptr}; static bool tried = false;
+    if (!tried) { tried = true; for (int k = 0; k < MAXG - 1; ++k) if (hipStreamCreateWithFlags(&extra[k], hipStreamNonBlocking) != hipSuccess) extra[k] = nullptr; }
+    long long peak = 0;
+    const int want = std::min(MAXG, env_int_m("MB_MEDIUM_STREAMS", 2));
+    if (twoStreams && want > 1) {
+      for (const PairDesc &pd : pairs) peak += (pd.inLen + C) / C;                      // tiles of a launch on the plateau: every strip of every pair
+      if (peak < 16 * 256)                                                              // (far more tiles than slots: the tail is noise)
+        while (nG < want && nG < n && extra[nG - 1]) { sgs[nG] = extra[nG - 1]; ++nG; }
+    }
+  }
+  std::vector<int> cnt((size_t)nG * (nLaunch + 1), 0);        // [group][launch]
   std::vector<char> live;
-  for (const PairDesc &pd : pairs) {
+  for (long long p = 0; p < n; ++p) {
+    const PairDesc &pd = pairs[p];
     const int NA = (pd.inLen + C) / C, NB = (pd.outLen + C + TS - 1) / TS;
     liveTiles(pd, live);
-    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) if (live[(size_t)a * NB + b]) cnt[pd.launch0 + 2 * a + b] += 1;
+    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) if (live[(size_t)a * NB + b]) cnt[(size_t)(p % nG) * (nLaunch + 1) + pd.launch0 + 2 * a + b] += 1;
   }
-  std::vector<long long> off(nLaunch + 1, 0);
-  { long long tot = 0; for (int l = 0; l < nLaunch; ++l) { off[l] = tot; tot += cnt[l]; } off[nLaunch] = tot; }
-  std::vector<int2> tiles((size_t)off[nLaunch]);
+  std::vector<long long> off((size_t)nG * (nLaunch + 1) + 1, 0);
+  { long long tot = 0; for (size_t k = 0; k < (size_t)nG * (nLaunch + 1); ++k) { off[k] = tot; tot += cnt[k]; } off[(size_t)nG * (nLaunch + 1)] = tot; }
+  std::vector<int2> tiles((size_t)off[(size_t)nG * (nLaunch + 1)]);
   {
     std::vector<long long> fill(off.begin(), off.end() - 1);
     for (long long p = 0; p < n; ++p) {
@@ -954,7 +975,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
       for (int a = 0; a < NA; ++a)
         for (int b = 0; b < NB; ++b)
           if (live[(size_t)a * NB + b])   // (bit 30 of the strip: the block before this one did not run -- a tile without a matrix then starts from -inf instead of its boundary record)
-            tiles[(size_t)fill[pd.launch0 + 2 * a + b]++] = make_int2((int)p, a | ((matKind == MED_MAT_ROLL && b > 0 && !live[(size_t)a * NB + b - 1]) ? (1 << 30) : 0));
+            tiles[(size_t)fill[(size_t)(p % nG) * (nLaunch + 1) + pd.launch0 + 2 * a + b]++] = make_int2((int)p, a | ((matKind == MED_MAT_ROLL && b > 0 && !live[(size_t)a * NB + b - 1]) ? (1 << 30) : 0));
     }
   }
   int2 *d_tiles = nullptr;
@@ -970,16 +991,30 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   A.poolB = d_poolB; A.counts = d_counts; A.envStart = env.d_start; A.envEnd = env.d_end;
   if (roll) { A.colHalo = roll->halo; A.haloBase = roll->haloBase; A.bound = roll->bound; A.boundBase = roll->boundBase; A.tb = roll->tb; }
   const dim3 block(geo.waves * 64);
-  for (int l = 0; l < nLaunch; ++l) {
-    if (cnt[l] <= 0) continue;
-    ++g_last_launches;
-    A.launch = l; A.tileBase = (int)off[l];
-    const dim3 grid((unsigned)cnt[l]);
-    if (J && launch_jit(*J, grid, block, st, dev, A)) continue;
-    if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, st, dev, A);
-    else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, st, dev, A);
+  hipEvent_t evStart = nullptr, evDone = nullptr;
+  bool streamsOk = true;
+  if (nG > 1) {      // the other streams start behind what `st` has queued (tile list, buffers) and hand back to it at the end
+    streamsOk = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess &&
+                hipEventRecord(evStart, st) == hipSuccess;
+    for (int g = 1; g < nG && streamsOk; ++g) streamsOk = hipStreamWaitEvent(sgs[g], evStart, 0) == hipSuccess;
   }
-  const bool ok = hip_ok(hipGetLastError(), "medium tile launch") && hip_ok(hipStreamSynchronize(st), "medium tile kernels");
+  for (int l = 0; l < nLaunch && streamsOk; ++l)
+    for (int g = 0; g < nG; ++g) {
+      const size_t k = (size_t)g * (nLaunch + 1) + l;
+      if (cnt[k] <= 0) continue;
+      ++g_last_launches;
+      A.launch = l; A.tileBase = (int)off[k];
+      const dim3 grid((unsigned)cnt[k]);
+      hipStream_t sg = sgs[g];
+      if (J && launch_jit(*J, grid, block, sg, dev, A)) continue;
+      if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, sg, dev, A);
+      else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, sg, dev, A);
+    }
+  for (int g = 1; g < nG && streamsOk; ++g) streamsOk = hipEventRecord(evDone, sgs[g]) == hipSuccess && hipStreamWaitEvent(st, evDone, 0) == hipSuccess;
+  if (nG > 1 && !streamsOk) { for (int g = 1; g < nG; ++g) (void)hipStreamSynchronize(sgs[g]); set_error("tile sweep: stream synchronisation failed"); }
+  if (evStart) (void)hipEventDestroy(evStart);
+  if (evDone) (void)hipEventDestroy(evDone);
+  const bool ok = streamsOk && hip_ok(hipGetLastError(), "medium tile launch") && hip_ok(hipStreamSynchronize(st), "medium tile kernels");
   sm_free(d_tiles);
   return ok ? 0 : 1;
 }
@@ -1197,7 +1232,8 @@ int medium_forward_pipelined(const mb_machine *m, MedProgram &P, const MedGeom &
   PairDesc *d_pairs = nullptr;
   if (!hip_ok(sm_alloc((void **)&d_pairs, n * sizeof(PairDesc)), "hipMalloc(pairs)")) return 1;
   if (!hip_ok(hipMemcpyAsync(d_pairs, pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, st), "H2D pairs")) { sm_free(d_pairs); return 1; }
-  const int rc = launch_wavefront(m, P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st);
+  // (one stream: a matrix slot is handed from one pair to the next in stream order)
+  const int rc = launch_wavefront(m, P, P.dev, geo, MB_FORWARD, TS, pairs, d_pairs, d_in, d_out, d_pool, d_loglike, st, nullptr, nullptr, MedEnv(), MED_MAT_FULL, nullptr, false);
   sm_free(d_pairs);
   return rc;
 }

@@ -6,6 +6,8 @@ MB_MEDIUM_TS=128 python scripts/count_probe.py
 MB_MEDIUM_TS=256 python scripts/count_probe.py
 MB_MEDIUM_COUNT_G=4 python scripts/count_probe.py
 MB_MEDIUM_COUNT_G=1 python scripts/count_probe.py
+MB_MEDIUM_STREAMS=1 python scripts/count_probe.py
+MB_MEDIUM_STREAMS=3 python scripts/count_probe.py
 MB_MEDIUM_COUNTS_ROLL=0 python scripts/count_probe.py
 python scripts/count_probe.py 21 487 10000
 MB_MEDIUM_TS=256 python scripts/count_probe.py 21 487 10000
