@@ -472,7 +472,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
   if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1 && !tiledViterbi) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
-    g_last_kernel = mode == MB_VITERBI ? (wide_viterbi_uses_phases(*W) ? "k_wide_viterbi" : "k_wide_sweep<1>") : (W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>");
+    g_last_kernel = wide_kernel_name(*W);
     return wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream);
   }
   if ((use_medium(m) && !(env && wide_applicable(m))) || tiledViterbi) {

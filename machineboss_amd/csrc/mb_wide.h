@@ -77,6 +77,37 @@ struct WideVitDev {
   int nPhases;
 };
 
+// ---- RETIMED sweep (k_wide_retimed) --------------------------------------------------------------------------------------------
+// A column of a levelled one-tape program is a chain of hundreds of dependent silent levels, and columns follow one another -- but
+// the dependency graph over (column, state) is looser than that: a cell only waits for its own predecessors.  Give every
+// state s a time offset tau(s) and let cell (c, s) be computed at time step c * P + tau(s).  The schedule is valid iff
+//     tau(s) >= tau(u) + 1      for every silent transition    u -> s   (same column), and
+//     tau(s) + P >= tau(u) + 1  for every emitting transition  u -> s   (u in the column before);
+// the smallest feasible period P is the machine's largest (transitions per emission) over its cycles -- 9 for the 20-node
+// profile . simple_introns . translate . dnapsw machine whose columns are 366 levels deep.  Step t finalises every state with
+// tau = t (mod P), each for ITS OWN column (t - tau) / P: P wide rounds per period instead of hundreds of thin levels, with
+// tauMax / P columns in flight.  Every candidate is still ONE rounded add of one transition's weight and every state one maximum
+// (or one log-sum-exp) over its direct predecessors: the cells are the levelled program's, bit for bit in the max semiring.
+// The kernel sees a PERIOD as a flat list of rounds (one stage per residue of tau mod P, a barrier after each); a node carries
+// ktau = tau / P, the number of columns it lags the period's newest column.  Values live in a ring of NB column vectors; the few
+// sources read NB * P or more steps after they were written are copied (x + 0.0) into a long ring of NBL small vectors by relay
+// nodes.  Emitting transitions are candidates of their own that carry the token they emit and are compared with the token of the
+// lane's column (a 64-entry window of the sequence in LDS): no per-token tables.
+//   src = sel << 30 | ktau << 24 | em << 23 | dkm << 21 | tok << 15 | idx
+//           sel 0: ring vector (newest - ktau - em) mod NB, entry idx;  1: long ring vector (newest - ktau - em) mod NBL, entry idx;
+//           2: fixed LDS entry idx (S: -inf, S + 1: 0.0 -- the seed, whose tok is WIDE_RET_SEED_TOK = the "token" of column 0)
+//           em = the transition emits (its source is in the column before), dkm = (ktau + em) mod NB, tok = 0: silent
+//   pad (last slot of a round) = END << 31 | SYNC << 30 | LONG << 29 | log2(group) << 26 | ktau << 20 | (ktau mod NB) << 18 | destination
+constexpr int WIDE_RET_SEED_TOK = 63;
+constexpr int WIDE_RET_TOKWIN = 64;
+constexpr uint32_t WIDE_RET_NO_DST = 0x3ffffu;
+struct WideRetDev {
+  const WideRec *rec;          // [nSlots + WIDE_RING][W]: the rounds of one period, then its first WIDE_RING slots again
+  int nSlots;                  // multiple of WIDE_RING
+  int NB, NBL, nLong, NVs;     // ring depths, long-lived sources, doubles per ring vector (S + 2)
+  int kMax;                    // largest ktau: a sequence of L columns takes L + 1 + kMax periods
+};
+
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
 struct WideSecond { unsigned nFirst; const PairDesc *pairs; double *pool; void *scratch; };
 
@@ -106,6 +137,12 @@ struct WideProgram {
   WideRec *d_vit[4] = {nullptr, nullptr, nullptr, nullptr};
   WidePhase *d_phase = nullptr;
   WideVitDev vit{};
+  // the retimed program (wide_ret_build): preferred for max programs when it fits
+  bool retOk = false;
+  WideRec *d_ret = nullptr;
+  WideRetDev ret{};
+  size_t retLdsBytes = 0;
+  int retPeriod = 0, retTauMax = 0;
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };
@@ -120,7 +157,7 @@ void wide_free(WideProgram &P);
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly = false);
-bool wide_viterbi_uses_phases(const WideProgram &P);      // the max program of this machine runs k_wide_viterbi (else k_wide_sweep<1>)
+const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
 // Two sweeps (e.g. Forward over one set of pairs, Backward over another) in ONE launch: workgroups 0..nA-1 run program A,
 // the rest program B, so both are on the chip together whatever the queue scheduler does with two streams.  Returns -1
 // (nothing launched) when the two programs do not share a kernel variant.

@@ -265,6 +265,85 @@ __global__ __launch_bounds__(1024) void k_wide_viterbi(WideDev P, WideVitDev Q, 
   if (loglike && tid == 0) loglike[bid] = V[prevOff + P.resultIdx];
 }
 
+// ---- retimed programs: a period of rounds, every node on its own column (see WideRetDev) ---------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
+                                                       double *__restrict__ pool, double *__restrict__ loglike) {
+  extern __shared__ double wlds[];
+  const unsigned bid = blockIdx.x;
+  const PairDesc pd = pairs[bid];
+  const int tid = threadIdx.x, W = P.W, S = P.S;
+  const int L = P.inputTape ? pd.inLen : pd.outLen;
+  const int NVs = Q.NVs, NB = Q.NB, NBL = Q.NBL, nLong = Q.nLong;
+  const int longBase = NB * NVs, nVec = longBase + NBL * nLong;
+  double *V = wlds;
+  int *tokWin = (int *)(wlds + nVec);               // token of column c in entry c & 63, written one period ahead
+  for (int k = tid; k < nVec; k += W) V[k] = -INFINITY;
+  if (tid < WIDE_RET_TOKWIN) tokWin[tid] = 0;
+  __syncthreads();
+  if (tid == 0) { V[S + 1] = 0.0; tokWin[0] = WIDE_RET_SEED_TOK; }
+  const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
+  double *cells = pool ? pool + pd.cellBase : nullptr;
+  auto tokAt = [&](int c) -> int { return (c >= 1 && c <= L) ? (P.backward ? out[L - c] : out[c - 1]) : 0; };
+  int tokNext = tid == 0 ? tokAt(1) : 0;
+  __syncthreads();
+  const WideRec *p = Q.rec + tid;
+  WideRec q[WIDE_RING];
+#pragma unroll
+  for (int k = 0; k < WIDE_RING; ++k) q[k] = p[(size_t)k * W];
+  const int nPer = L + 1 + Q.kMax;
+  int cm = 0, cmL = 0;                              // newest column mod NB, mod NBL
+  double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
+  float s = 0.0f;
+  for (int tdiv = 0; tdiv < nPer; ++tdiv) {
+    if (tid == 0) {                                 // (entry of column tdiv - 63: no node lags that far)
+      tokWin[(tdiv + 1) & (WIDE_RET_TOKWIN - 1)] = tokNext;
+      tokNext = tokAt(tdiv + 2);
+    }
+    for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
+#pragma unroll
+      for (int k = 0; k < WIDE_RING; ++k) {
+        const WideRec rc = q[k];
+        q[k] = p[(size_t)(j0 + WIDE_RING + k) * W];
+        const uint32_t sw = rc.src;
+        const int sel = (int)(sw >> 30), kt = (int)((sw >> 24) & 63u), dkm = (int)((sw >> 21) & 3u);
+        const int tok = (int)((sw >> 15) & 63u), idx = (int)(sw & 0x7fffu);
+        int b = cm - dkm; b += b < 0 ? NB : 0;
+        int bl = cmL - (idx >> 9); bl += bl < 0 ? NBL : 0;      // (long ring entries carry their own lag mod NBL above a 9-bit index)
+        const int addr = sel == 0 ? b * NVs + idx : (sel == 1 ? longBase + bl * nLong + (idx & 511) : idx);
+        const int tc = tokWin[(tdiv - kt) & (WIDE_RET_TOKWIN - 1)];
+        const double v = V[addr] + rc.w;
+        wide_fold<MODE>(m, s, (tok == 0 || tok == tc) ? v : -INFINITY, 1.0f);
+        const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
+        if (flags & 0x80000000u) {
+          const uint32_t dst = rc.pad;
+          const int g = 1 << ((dst >> 26) & 7), gWave = 1 << ((flags >> 26) & 7);
+          if (gWave > 1) wide_group_reduce<MODE>(m, s, g, gWave);
+          const uint32_t x = dst & WIDE_RET_NO_DST;
+          const int dk = (int)((dst >> 20) & 63u), c = tdiv - dk;
+          if (x != WIDE_RET_NO_DST && c >= 0 && c <= L) {
+            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
+            if ((dst >> 29) & 1u) {
+              int dl = cmL - (int)(x >> 9); dl += dl < 0 ? NBL : 0;
+              V[longBase + dl * nLong + (int)(x & 511u)] = res;
+            } else {
+              int db = cm - (int)((dst >> 18) & 3u); db += db < 0 ? NB : 0;
+              V[db * NVs + (int)x] = res;
+              if (cells && (!P.lastOnly || c == L)) cells[(P.lastOnly ? 0ll : (long long)(P.backward ? L - c : c) * S) + (long long)x] = res;
+            }
+          }
+          m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
+          s = 0.0f;
+          if (flags & 0x40000000u) __syncthreads();
+        }
+      }
+    }
+    cm = cm + 1 == NB ? 0 : cm + 1;
+    cmL = cmL + 1 == NBL ? 0 : cmL + 1;
+  }
+  if (loglike && tid == 0) loglike[bid] = V[(L % NB) * NVs + P.resultIdx];
+}
+
 // ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
 static constexpr float W_NEG_BIG32 = -3.0e38f;
 
@@ -515,6 +594,7 @@ void wide_free(WideProgram &P) {
   if (P.d_flags) (void)hipFree(P.d_flags);
   for (int k = 0; k < 4; ++k) if (P.d_vit[k]) (void)hipFree(P.d_vit[k]);
   if (P.d_phase) (void)hipFree(P.d_phase);
+  if (P.d_ret) (void)hipFree(P.d_ret);
   P = WideProgram();
 }
 
@@ -876,6 +956,160 @@ static bool up_w(T *&d, const std::vector<T> &h) {
   return true;
 }
 
+// ---- the retimed program of a levelled one-tape machine (see WideRetDev) --------------------------------------------------------
+namespace {
+struct RetEdge { int src, dst, em, tok; double w; };
+
+// smallest tau >= 0 with tau(dst) >= tau(src) + 1 - em * period over all edges; false when some tau would exceed `bound` (the period
+// is shorter than a cycle of the machine needs, or the columns are deeper than the kernel's 6-bit lag)
+bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int bound, std::vector<int> &tau, long long &work) {
+  tau.assign(nStates, 0);
+  for (;;) {
+    bool moved = false;
+    for (const RetEdge &e : edges) {
+      const int t = tau[e.src] + 1 - (e.em ? period : 0);
+      if (t > tau[e.dst]) { tau[e.dst] = t; moved = true; if (t > bound) return false; }
+    }
+    work += (long long)edges.size();
+    if (!moved) return true;
+    if (work > 400000000ll) return false;
+  }
+}
+}  // namespace
+
+static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok) {
+  P.retOk = false;
+  const int S = m->S, W = P.W;
+  const int want = env_int_w("MB_WIDE_RETIMED", -1);          // 1 / 0: force on (both semirings) / off; default: max programs only
+  if (want == 0 || (want < 0 && !P.viterbi)) return true;
+  if (S + 2 > 0x7fff || nTok - 1 >= WIDE_RET_SEED_TOK || 2 * (size_t)(S + 2) * sizeof(double) > WIDE_LDS_MAX) return true;
+  const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
+  // the levelled nodes as a graph over states: t2[tok] = emitting candidates (source in the column before), t3 = silent ones
+  std::vector<char> live(S, 0);
+  for (const WNode &nd : nodes) live[nd.dst & W_IDX_MASK] = 1;
+  std::vector<RetEdge> edges;
+  for (const WNode &nd : nodes) {
+    const int x = (int)(nd.dst & W_IDX_MASK);
+    for (int tok = 0; tok < (int)nd.t2.size(); ++tok)
+      for (const WCand &cd : nd.t2[tok]) {
+        const int y = (int)(cd.src & 0x3fffffffu);
+        if (y >= S) continue;                                  // the seed: no dependency
+        if (tok == 0) return true;                             // (cannot happen: token 0 of a levelled node holds the seed only)
+        if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 1, tok, cd.w});
+      }
+    for (const WCand &cd : nd.t3) {
+      const int y = (int)(cd.src & 0x3fffffffu);
+      if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 0, 0, cd.w});
+    }
+  }
+  // silent edges in sweep order first, so that one relaxation pass carries a change through a whole column
+  std::stable_sort(edges.begin(), edges.end(), [&](const RetEdge &a, const RetEdge &b) {
+    if (a.em != b.em) return a.em < b.em;
+    return P.backward ? a.dst > b.dst : a.dst < b.dst;
+  });
+  long long work = 0;
+  std::vector<int> tau, tauBest;
+  auto feasible = [&](int period) { return ret_offsets(edges, S, period, (WIDE_RET_TOKWIN - 2) * period + period - 1, tau, work); };
+  const int forced = env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
+  int lo = 1, hi = 64;
+  if (!feasible(hi)) return true;
+  while (lo < hi) { const int mid = (lo + hi) / 2; if (feasible(mid)) hi = mid; else lo = mid + 1; }
+  const int pMin = lo;
+  // shape for one period length: ring depths, relays, nodes by residue; cost from the round planner
+  struct Shape { int period = 0, NB = 0, NBL = 0, nLong = 0, kMax = 0, tauMax = 0; double cost = 1e300; std::vector<WNode> nd; };
+  auto shape = [&](int period, Shape &sh) -> bool {
+    if (!feasible(period)) return false;
+    int tauMax = 0;
+    for (int x = 0; x < S; ++x) if (live[x]) tauMax = std::max(tauMax, tau[x]);
+    const int NVs = S + 2;
+    for (int NB = 4; NB >= 2; --NB) {
+      if ((size_t)NB * NVs * sizeof(double) > WIDE_LDS_MAX) continue;
+      // sources some reader sees NB periods or more after they were written go through the long ring
+      std::vector<int> longIdx(S, -1);
+      int nLong = 0, maxSpan = 0;
+      for (const RetEdge &e : edges) {
+        const int span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
+        if (span >= NB * period) { if (longIdx[e.src] < 0) longIdx[e.src] = nLong++; maxSpan = std::max(maxSpan, span); }
+      }
+      const int NBL = nLong ? (maxSpan + period - 1) / period + 1 : 1;
+      if (nLong > 512) continue;
+      const size_t lds = ((size_t)NB * NVs + (size_t)NBL * nLong) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+      if (lds > WIDE_LDS_MAX) continue;
+      // nodes: every live state, plus one relay per long-lived source at tau + 1
+      std::vector<std::vector<WCand>> cands(S);
+      for (const WNode &nd0 : nodes)       // the seed
+        for (const auto &l : nd0.t2) for (const WCand &cd : l) if ((int)(cd.src & 0x3fffffffu) == S + 1)
+          cands[nd0.dst & W_IDX_MASK].push_back(WCand{(2u << 30) | ((uint32_t)(tau[nd0.dst & W_IDX_MASK] / period) << 24) | ((uint32_t)WIDE_RET_SEED_TOK << 15) | (uint32_t)(S + 1), cd.w});
+      for (const RetEdge &e : edges) {
+        const int kt = tau[e.dst] / period, span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
+        const bool viaLong = span >= NB * period;
+        const uint32_t sw = ((viaLong ? 1u : 0u) << 30) | ((uint32_t)kt << 24) | ((uint32_t)e.em << 23) | ((uint32_t)((kt + e.em) % NB) << 21) |
+                            ((uint32_t)e.tok << 15) | (uint32_t)(viaLong ? (((kt + e.em) % NBL) << 9) | longIdx[e.src] : e.src);
+        cands[e.dst].push_back(WCand{sw, e.w});
+      }
+      sh.nd.clear();
+      int kMax = 0;
+      for (int x = 0; x < S; ++x) {      // (states nothing leads to are nodes too: their cells of the matrix are -inf)
+        const int kt = tau[x] / period;
+        kMax = std::max(kMax, kt);
+        sh.nd.push_back(WNode{CUR(((uint32_t)kt << 20) | ((uint32_t)(kt % NB) << 18) | (uint32_t)x), tau[x] % period, {}, std::move(cands[x])});
+        if (longIdx[x] >= 0) {
+          const int tr = tau[x] + 1, kr = tr / period;
+          kMax = std::max(kMax, kr);
+          const uint32_t sw = (0u << 30) | ((uint32_t)kr << 24) | ((uint32_t)(kr % NB) << 21) | (uint32_t)x;
+          sh.nd.push_back(WNode{EXTRA(((uint32_t)kr << 20) | ((uint32_t)(kr % NB) << 18) | ((uint32_t)(kr % NBL) << 9) | (uint32_t)longIdx[x]), tr % period, {}, {WCand{sw, 0.0}}});
+        }
+      }
+      if (kMax > WIDE_RET_TOKWIN - 2) return false;
+      sh.period = period; sh.NB = NB; sh.NBL = NBL; sh.nLong = nLong; sh.kMax = kMax; sh.tauMax = tauMax;
+      sh.cost = wide_plan(sh.nd, period - 1, 1, W, false, nullptr);
+      return true;
+    }
+    return false;
+  };
+  Shape best, cur;
+  for (int period = forced > 0 ? forced : pMin; period <= (forced > 0 ? forced : std::min(64, pMin + 8)); ++period) {
+    if (!shape(period, cur)) continue;
+    if (verbose) fprintf(stderr, "[mbhip] wide retimed, period %d: tauMax %d, ring %d, long ring %d x %d, modelled %.0f cycles per column\n",
+                         period, cur.tauMax, cur.NB, cur.NBL, cur.nLong, cur.cost);
+    if (cur.cost < best.cost) std::swap(best, cur);
+  }
+  if (best.cost >= 1e300) return true;
+  // rounds (one stage per residue) -> one stream of [slot][lane] records
+  WideProgram T;
+  T.W = W; T.dev.S = S;
+  wide_plan(best.nd, best.period - 1, 1, W, true, &T);
+  if (T.rounds.empty()) return true;
+  int nSlots = 0;
+  for (const WideRound &R : T.rounds) nSlots += R.depth;
+  const int padded = (nSlots + WIDE_RING - 1) / WIDE_RING * WIDE_RING;
+  const WideRec padRec{-INFINITY, PREV(S), 0};
+  std::vector<WideRec> st;
+  st.reserve((size_t)(padded + WIDE_RING) * W);
+  for (const WideRound &R : T.rounds)
+    for (int j = 0; j < R.depth; ++j) {
+      const bool last = j + 1 == R.depth;
+      for (int l = 0; l < W; ++l) {
+        WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
+        rc.pad = last ? (0x80000000u | (R.sync ? 0x40000000u : 0u) | T.dsts[R.dstBase + l]) : 0u;
+        st.push_back(rc);
+      }
+    }
+  st.resize((size_t)padded * W, padRec);
+  st.insert(st.end(), st.begin(), st.begin() + (size_t)WIDE_RING * W);      // the ring reads one ring of slots into the next period
+  if (!up_w(P.d_ret, st)) return false;
+  P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NBL = best.NBL; P.ret.nLong = best.nLong; P.ret.NVs = S + 2;
+  P.ret.kMax = best.kMax;
+  P.retLdsBytes = ((size_t)best.NB * (S + 2) + (size_t)best.NBL * best.nLong) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+  P.retPeriod = best.period; P.retTauMax = best.tauMax;
+  P.retOk = true;
+  if (verbose)
+    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d, %d relays x %d, LDS %zu bytes\n",
+            P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
+            100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.nLong, best.NBL, P.retLdsBytes);
+  return true;
+}
+
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {
   const bool haveShape = P.ok;                     // a weight refresh keeps the shape that was chosen
   const int keepStages = P.stages;
@@ -960,6 +1194,15 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
     nRecs = P.segA.size() + P.segB.size();
     if (viterbi && !wide_vit_build(P, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
+    {
+      // the retimed program is built from the LEVELLED nodes, whatever closure shape the column-by-column kernel chose
+      std::vector<WNode> levelled;
+      int xe = 0, xs = 0; long long xp = 0;
+      const std::vector<WNode> *lv = &bestNodes;
+      if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", -1) > 0) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
+      else if (bestK != 0) lv = nullptr;
+      if (lv && !wide_ret_build(m, P, *lv, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
+    }
   }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
@@ -1024,7 +1267,12 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
   return 0;
 }
 
-bool wide_viterbi_uses_phases(const WideProgram &P) { return P.viterbi && P.vitOk; }
+const char *wide_kernel_name(const WideProgram &P) {
+  if (P.f32) return "k_wide_sum32";
+  if (P.retOk) return P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>";
+  if (P.viterbi) return P.vitOk ? "k_wide_viterbi" : "k_wide_sweep<1>";
+  return "k_wide_sweep<0>";
+}
 
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly) {
@@ -1046,6 +1294,20 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
                                    : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly));
     g_last_launches += 1;
     return rc32;
+  }
+  if (P.retOk) {
+    static bool attr = false;
+    if (!attr) {
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      attr = true;
+    }
+    WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+    if (P.viterbi) hipLaunchKernelGGL(k_wide_retimed<MB_VITERBI>, dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike);
+    else hipLaunchKernelGGL(k_wide_retimed<MB_FORWARD>, dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike);
+    MB_HIP(hipGetLastError());
+    g_last_launches += 1;
+    return 0;
   }
   if (P.viterbi && P.vitOk) {
     static bool attr = false;
@@ -1075,7 +1337,7 @@ int wide_fill2(const mb_machine *m, WideProgram &A, WideProgram &B, const PairDe
   (void)m;
   if (!A.ok || !B.ok) { set_error("wide program not built"); return 1; }
   if (nA <= 0 || nB <= 0) return -1;
-  if (A.viterbi || B.viterbi || A.f32 != B.f32 || A.hyb != B.hyb || A.fastIdx != B.fastIdx || A.W != B.W) return -1;
+  if (A.viterbi || B.viterbi || A.retOk || B.retOk || A.f32 != B.f32 || A.hyb != B.hyb || A.fastIdx != B.fastIdx || A.W != B.W) return -1;
   if (A.f32) {
     auto gvOf = [](const WideProgram &Q) { return !Q.hyb && (Q.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0)); };
     if (gvOf(A) != gvOf(B)) return -1;
