@@ -404,8 +404,10 @@ static FastState *fast_state(mb_machine *m) {
         if (!medium_valid_G(Gc)) Gc = env_int("MB_MEDIUM_G", 0) ? G : medium_default_count_G(m->S);
         f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt);
       }
-    } else if (wide_applicable(m) && m->S <= env_int("MB_WIDE_VITERBI_MIN_STATES", 2048)) {
-      // One-tape machine of moderate size: the log-sum-exp sweeps belong to the one-tape family, but its Viterbi sweep
+    } else if (wide_applicable(m) && m->S <= env_int("MB_WIDE_VITERBI_MIN_STATES", 2048) &&
+               !(wide_build(m, false, true, f->wVit) && f->wVit.retOk)) {
+      // One-tape machine of moderate size whose max program has no retimed form (762 states: retimed 44 G cells/s, tiles 32;
+      // 1268 states: 73 vs 22): the log-sum-exp sweeps belong to the one-tape family, but its column-by-column Viterbi sweep
       // walks the silent levels one record at a time (0.2 us per level), where the run-time specialised tile kernel has
       // them as straight-line code (762 states: 32 vs 14.5 G cells/s, 1268 states: 22.8 vs 15.6).
       int G = env_int("MB_MEDIUM_G", 0);
@@ -1057,7 +1059,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
           if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
         }
         if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
-        g_last_kernel = W->f32 ? "k_wide_sum32 x2 + k_onetape_join" : "k_wide_sweep<0> x2 + k_onetape_join";
+        { static thread_local std::string nm; nm = std::string(wide_kernel_name(*W)) + " x2 + k_onetape_join"; g_last_kernel = nm.c_str(); }
         g_last_ms += tm.stop();
         if (!hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernels")) rc = 1;
       } while (0);
@@ -1068,7 +1070,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     } else {
       tm.start();
       rc = wide_fill(m, *W, b->d_pairs, b->nPairs, m->nOut ? b->d_out : b->d_in, nullptr, d_ll, g_stream);
-      g_last_kernel = W->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";
+      g_last_kernel = wide_kernel_name(*W);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;
     }
@@ -1308,7 +1310,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         if (!WB || !WF) { rc = 1; break; }
         const int fusedFill = wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch
         if (fusedFill > 0) { rc = 1; break; }
-        if (fusedFill == 0) { fwdDone = true; g_last_kernel = WF->f32 ? "k_wide_sum32" : "k_wide_sweep<0>"; }
+        if (fusedFill == 0) { fwdDone = true; g_last_kernel = wide_kernel_name(*WF); }
         else if (s2) {                              // (programs of different kernel variants: two launches on two streams)
           const int *tape = b->m->nOut ? b->d_out : b->d_in;
           hipEvent_t evStart = nullptr, evDone = nullptr;
@@ -1324,7 +1326,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
           if (!ok) { set_error("one-tape counts: stream synchronisation failed"); rc = 1; }
           if (rc) break;
           fwdDone = true;
-          g_last_kernel = WF->f32 ? "k_wide_sum32" : "k_wide_sweep<0>";
+          g_last_kernel = wide_kernel_name(*WF);
         }
       }
       if (!fwdDone && (rc = fill_chunk(b->m, MB_BACKWARD, d_desc, hp, b->d_in, b->d_out, bwd, 0, b))) break;

@@ -89,23 +89,24 @@ struct WideVitDev {
 // tauMax / P columns in flight.  Every candidate is still ONE rounded add of one transition's weight and every state one maximum
 // (or one log-sum-exp) over its direct predecessors: the cells are the levelled program's, bit for bit in the max semiring.
 // The kernel sees a PERIOD as a flat list of rounds (one stage per residue of tau mod P, a barrier after each); a node carries
-// ktau = tau / P, the number of columns it lags the period's newest column.  Values live in a ring of NB column vectors; the few
-// sources read NB * P or more steps after they were written are copied (x + 0.0) into a long ring of NBL small vectors by relay
-// nodes.  Emitting transitions are candidates of their own that carry the token they emit and are compared with the token of the
-// lane's column (a 64-entry window of the sequence in LDS): no per-token tables.
-//   src = sel << 30 | ktau << 24 | em << 23 | dkm << 21 | tok << 15 | idx
-//           sel 0: ring vector (newest - ktau - em) mod NB, entry idx;  1: long ring vector (newest - ktau - em) mod NBL, entry idx;
-//           2: fixed LDS entry idx (S: -inf, S + 1: 0.0 -- the seed, whose tok is WIDE_RET_SEED_TOK = the "token" of column 0)
-//           em = the transition emits (its source is in the column before), dkm = (ktau + em) mod NB, tok = 0: silent
-//   pad (last slot of a round) = END << 31 | SYNC << 30 | LONG << 29 | log2(group) << 26 | ktau << 20 | (ktau mod NB) << 18 | destination
-constexpr int WIDE_RET_SEED_TOK = 63;
+// ktau = tau / P, the number of columns it lags the period's newest column.  Values live in a ring of NB column vectors of NVs
+// doubles: the S states, two constants (-inf, 0.0 = the seed), and RELAY entries -- a source some reader sees NB * P or more
+// steps after it was written is copied (x + 0.0) every NB * P - 1 steps into an entry of its own, and the late reader takes the
+// youngest copy.  Emitting transitions are candidates of their own; whether the token they emit is the one of the lane's column
+// (and whether the column is the first one, for the seed) comes from a table of penalties (0 / -inf) per (ktau, token), rebuilt
+// every period one period ahead by the first lanes of the workgroup from a 64-entry window of the sequence.
+//   src = penalty entry byte offset << 16 | a0        a0: ring entry of the source when the newest column sits in vector 0,
+//           ((- ktau - emits) mod NB) * NVs + index; the kernel adds the rotation of the period and wraps once
+//   pad (last slot of a round) = END << 31 | SYNC << 30 | MIXED << 29 | log2(group) << 26 | ktau << 20 | ((- ktau) mod NB) << 18 | entry
+//           MIXED (first lane of a wavefront): the wavefront holds lane groups of different sizes -- the reduction steps are masked
 constexpr int WIDE_RET_TOKWIN = 64;
 constexpr uint32_t WIDE_RET_NO_DST = 0x3ffffu;
 struct WideRetDev {
   const WideRec *rec;          // [nSlots + WIDE_RING][W]: the rounds of one period, then its first WIDE_RING slots again
   int nSlots;                  // multiple of WIDE_RING
-  int NB, NBL, nLong, NVs;     // ring depths, long-lived sources, doubles per ring vector (S + 2)
+  int NB, NVs;                 // ring depth, doubles per ring vector (S + 2 + relays)
   int kMax;                    // largest ktau: a sequence of L columns takes L + 1 + kMax periods
+  int rowLen, nPen;            // penalty table: rowLen = tokens + 2 entries (silent, each token, seed) per ktau, nPen entries in all
 };
 
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side

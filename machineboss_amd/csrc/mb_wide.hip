@@ -266,6 +266,40 @@ __global__ __launch_bounds__(1024) void k_wide_viterbi(WideDev P, WideVitDev Q, 
 }
 
 // ---- retimed programs: a period of rounds, every node on its own column (see WideRetDev) ---------------------------------------
+// v_max_f64 as is: the operands here are sums of finite weights or -inf, never NaN, so the quieting moves the compiler puts
+// in front of fmax() (one v_max_f64 x, x per operand) buy nothing
+__device__ __forceinline__ double wide_max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// lane-group reduction of a wavefront whose groups all have gWave lanes: no per-lane masks
+template <int MODE, int H>
+__device__ __forceinline__ void wide_max_all(double &m) {
+  const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
+  m = wide_max_raw(m, mo);
+}
+template <int H>
+__device__ __forceinline__ void wide_sum_all(float &s) { s += __int_as_float(wide_xor_lane<H>(__float_as_int(s))); }
+template <int MODE>
+__device__ __forceinline__ void wide_group_reduce_all(double &m, float &s, int gWave) {
+  const double own = m;
+  wide_max_all<MODE, 1>(m);
+  if (gWave > 2) wide_max_all<MODE, 2>(m);
+  if (gWave > 4) wide_max_all<MODE, 4>(m);
+  if (gWave > 8) wide_max_all<MODE, 8>(m);
+  if (gWave > 16) wide_max_all<MODE, 16>(m);
+  if (gWave > 32) wide_max_all<MODE, 32>(m);
+  if (MODE == MB_VITERBI) return;
+  s *= __expf((float)(own - m));
+  wide_sum_all<1>(s);
+  if (gWave > 2) wide_sum_all<2>(s);
+  if (gWave > 4) wide_sum_all<4>(s);
+  if (gWave > 8) wide_sum_all<8>(s);
+  if (gWave > 16) wide_sum_all<16>(s);
+  if (gWave > 32) wide_sum_all<32>(s);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike) {
@@ -274,62 +308,80 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   const PairDesc pd = pairs[bid];
   const int tid = threadIdx.x, W = P.W, S = P.S;
   const int L = P.inputTape ? pd.inLen : pd.outLen;
-  const int NVs = Q.NVs, NB = Q.NB, NBL = Q.NBL, nLong = Q.nLong;
-  const int longBase = NB * NVs, nVec = longBase + NBL * nLong;
+  const int NVs = Q.NVs, NB = Q.NB, nVec = NB * NVs, nPen = Q.nPen, rowLen = Q.rowLen;
   double *V = wlds;
-  int *tokWin = (int *)(wlds + nVec);               // token of column c in entry c & 63, written one period ahead
+  double *pen = wlds + nVec;                         // [2][nPen]: this period's penalties and the next one's
+  int *tokWin = (int *)(pen + 2 * nPen);             // token of column c in entry c & 63, written two periods ahead
   for (int k = tid; k < nVec; k += W) V[k] = -INFINITY;
   if (tid < WIDE_RET_TOKWIN) tokWin[tid] = 0;
   __syncthreads();
-  if (tid == 0) { V[S + 1] = 0.0; tokWin[0] = WIDE_RET_SEED_TOK; }
+  if (tid < NB) V[tid * NVs + S + 1] = 0.0;         // the seed's source, in every ring vector
   const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
   double *cells = pool ? pool + pd.cellBase : nullptr;
   auto tokAt = [&](int c) -> int { return (c >= 1 && c <= L) ? (P.backward ? out[L - c] : out[c - 1]) : 0; };
-  int tokNext = tid == 0 ? tokAt(1) : 0;
+  if (tid == 0) tokWin[1] = tokAt(1);
+  int tokNext = tid == 0 ? tokAt(2) : 0;
+  // penalty of entry (ktau, col) in the period whose newest column is `newest`: col 0 silent, 1.. = the token, rowLen - 1 = the seed
+  const int myKt = tid / rowLen, myCol = tid - myKt * rowLen;
+  auto penalty = [&](int kt, int col, int newest) -> double {
+    const int c = newest - kt;
+    const bool ok = col == 0 || (col == rowLen - 1 ? c == 0 : (c >= 1 && tokWin[c & (WIDE_RET_TOKWIN - 1)] == col));
+    return ok ? 0.0 : -INFINITY;
+  };
   __syncthreads();
-  const WideRec *p = Q.rec + tid;
+  for (int e = tid; e < nPen; e += W) { const int kt = e / rowLen; pen[e] = penalty(kt, e - kt * rowLen, 0); }
+  __syncthreads();
+  const WideRec *rec = Q.rec;
   WideRec q[WIDE_RING];
 #pragma unroll
-  for (int k = 0; k < WIDE_RING; ++k) q[k] = p[(size_t)k * W];
+  for (int k = 0; k < WIDE_RING; ++k) q[k] = (rec + (size_t)k * W)[tid];
   const int nPer = L + 1 + Q.kMax;
-  int cm = 0, cmL = 0;                              // newest column mod NB, mod NBL
+  const unsigned ringBytes = (unsigned)nVec * 8u, vecBytes = (unsigned)NVs * 8u;
+  unsigned rot = 0;                                  // byte offset of the ring vector that holds the period's newest column
+  unsigned penCur = ringBytes, penNxt = ringBytes + (unsigned)nPen * 8u;
+  char *lds = (char *)wlds;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
   float s = 0.0f;
-  for (int tdiv = 0; tdiv < nPer; ++tdiv) {
-    if (tid == 0) {                                 // (entry of column tdiv - 63: no node lags that far)
-      tokWin[(tdiv + 1) & (WIDE_RET_TOKWIN - 1)] = tokNext;
-      tokNext = tokAt(tdiv + 2);
+  const bool storeAll = cells && !P.lastOnly, storeLast = cells && P.lastOnly;
+  const int rowSign = P.lastOnly ? 0 : (P.backward ? 1 : -1), rowS = P.lastOnly ? 0 : S;
+  for (int t = 0; t < nPer; ++t) {
+    if (tid == 0) {                                  // (the entry of column t - 62: no node lags that far)
+      tokWin[(t + 2) & (WIDE_RET_TOKWIN - 1)] = tokNext;
+      tokNext = tokAt(t + 3);
     }
+    if (tid < nPen) *(double *)(lds + penNxt + (unsigned)tid * 8u) = penalty(myKt, myCol, t + 1);
+    for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; *(double *)(lds + penNxt + (unsigned)e * 8u) = penalty(kt, e - kt * rowLen, t + 1); }
+    const int rowBase = P.lastOnly ? 0 : (P.backward ? L - t : t);      // matrix row of a node that lags kt columns: rowBase + rowSign * kt
     for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
-        q[k] = p[(size_t)(j0 + WIDE_RING + k) * W];
-        const uint32_t sw = rc.src;
-        const int sel = (int)(sw >> 30), kt = (int)((sw >> 24) & 63u), dkm = (int)((sw >> 21) & 3u);
-        const int tok = (int)((sw >> 15) & 63u), idx = (int)(sw & 0x7fffu);
-        int b = cm - dkm; b += b < 0 ? NB : 0;
-        int bl = cmL - (idx >> 9); bl += bl < 0 ? NBL : 0;      // (long ring entries carry their own lag mod NBL above a 9-bit index)
-        const int addr = sel == 0 ? b * NVs + idx : (sel == 1 ? longBase + bl * nLong + (idx & 511) : idx);
-        const int tc = tokWin[(tdiv - kt) & (WIDE_RET_TOKWIN - 1)];
-        const double v = V[addr] + rc.w;
-        wide_fold<MODE>(m, s, (tok == 0 || tok == tc) ? v : -INFINITY, 1.0f);
+        q[k] = (rec + (size_t)(j0 + WIDE_RING + k) * W)[tid];
+        unsigned a = ((rc.src & 0x7fffu) << 3) + rot;
+        a = min(a, a - ringBytes);                   // one wrap
+        const double v = *(const double *)(lds + a) + rc.w;
+        const double cand = v + *(const double *)(lds + penCur + (rc.src >> 16));      // + 0.0 or -inf
+        if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
+        else wide_fold<MODE>(m, s, cand, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
         if (flags & 0x80000000u) {
           const uint32_t dst = rc.pad;
-          const int g = 1 << ((dst >> 26) & 7), gWave = 1 << ((flags >> 26) & 7);
-          if (gWave > 1) wide_group_reduce<MODE>(m, s, g, gWave);
-          const uint32_t x = dst & WIDE_RET_NO_DST;
-          const int dk = (int)((dst >> 20) & 63u), c = tdiv - dk;
-          if (x != WIDE_RET_NO_DST && c >= 0 && c <= L) {
+          const int gWave = 1 << ((flags >> 26) & 7);
+          if (gWave > 1) {
+            if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
+            else wide_group_reduce_all<MODE>(m, s, gWave);
+          }
+          const uint32_t x = dst & WIDE_RET_NO_DST, kt = (dst >> 20) & 63u;
+          const int c = t - (int)kt;
+          if (x < (unsigned)NVs && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
-            if ((dst >> 29) & 1u) {
-              int dl = cmL - (int)(x >> 9); dl += dl < 0 ? NBL : 0;
-              V[longBase + dl * nLong + (int)(x & 511u)] = res;
-            } else {
-              int db = cm - (int)((dst >> 18) & 3u); db += db < 0 ? NB : 0;
-              V[db * NVs + (int)x] = res;
-              if (cells && (!P.lastOnly || c == L)) cells[(P.lastOnly ? 0ll : (long long)(P.backward ? L - c : c) * S) + (long long)x] = res;
+            unsigned d = __umul24((dst >> 18) & 3u, vecBytes) + rot;
+            d += x << 3;
+            d = min(d, d - ringBytes);
+            *(double *)(lds + d) = res;
+            if (storeAll | (storeLast & (c == L))) {
+              const unsigned row = (unsigned)(rowBase + rowSign * (int)kt);      // c, or L - c for a backward sweep, or 0
+              if (x < (unsigned)S) cells[(size_t)row * (size_t)rowS + x] = res;
             }
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -338,8 +390,8 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
         }
       }
     }
-    cm = cm + 1 == NB ? 0 : cm + 1;
-    cmL = cmL + 1 == NBL ? 0 : cmL + 1;
+    rot += vecBytes; rot = rot == ringBytes ? 0u : rot;
+    const unsigned sw = penCur; penCur = penNxt; penNxt = sw;
   }
   if (loglike && tid == 0) loglike[bid] = V[(L % NB) * NVs + P.resultIdx];
 }
@@ -502,7 +554,7 @@ int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
 // lane groups and rounds of one stage: returns the modelled cost (cycles), appends to P when `emit`
-double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W, bool emit, WideProgram *P) {
+double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W, bool emit, WideProgram *P, double cRound = 105.0) {
   const int n = (int)nodes.size();
   if (!n) return 0.0;
   std::vector<int> len(n);
@@ -516,7 +568,8 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
   // calibrated on the box (forced K sweeps, least squares over slots / rounds / barriers per column): a candidate slot of
   // 1024 lanes costs 0.19 us (fp64 columns in LDS) to 0.30 us (fp32, previous column in L2), a ROUND -- epilogue with the
   // lane-group reduction, log, store -- 0.30 to 0.58 us, i.e. 1.6-1.9 slots, and the barrier itself next to nothing
-  const double cSlot = 60.0, cRound = 105.0, cShfl = 3.0, cSync = 10.0;
+  // (the retimed kernel, whose slots are leaner: 0.08 us a slot, 0.37 us a round with its barrier -- cRound = 280)
+  const double cSlot = 60.0, cShfl = 3.0, cSync = 10.0;
   auto groupOf = [&](int L, int d) { return std::min(64, pow2ceil((L + d - 1) / d)); };
   int bestD = 1; double best = 1e300;
   for (int d = 1; d <= maxLen; ++d) {
@@ -940,11 +993,11 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long lo
   return true;
 }
 
-static double wide_plan(const std::vector<WNode> &nodes, int nStages, int nTok, int W, bool emit, WideProgram *P) {
+static double wide_plan(const std::vector<WNode> &nodes, int nStages, int nTok, int W, bool emit, WideProgram *P, double cRound = 105.0) {
   std::vector<std::vector<const WNode *>> byStage(nStages + 1);
   for (const WNode &n : nodes) byStage[std::min(n.stage, nStages)].push_back(&n);
   double cost = 0.0;
-  for (auto &v : byStage) cost += plan_stage(v, nTok, W, emit, P);
+  for (auto &v : byStage) cost += plan_stage(v, nTok, W, emit, P, cRound);
   return cost;
 }
 
@@ -980,21 +1033,23 @@ bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int
 static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok) {
   P.retOk = false;
   const int S = m->S, W = P.W;
-  const int want = env_int_w("MB_WIDE_RETIMED", -1);          // 1 / 0: force on (both semirings) / off; default: max programs only
-  if (want == 0 || (want < 0 && !P.viterbi)) return true;
-  if (S + 2 > 0x7fff || nTok - 1 >= WIDE_RET_SEED_TOK || 2 * (size_t)(S + 2) * sizeof(double) > WIDE_LDS_MAX) return true;
+  const int want = env_int_w("MB_WIDE_RETIMED", 1);
+  if (want == 0) return true;
+  const int rowLen = nTok + 1;                                 // penalty columns: silent, tokens 1 .. nTok - 1, the seed
+  if (S + 2 > 0x7fff || rowLen > 64 || 2 * (size_t)(S + 2) * sizeof(double) > WIDE_LDS_MAX) return true;
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   // the levelled nodes as a graph over states: t2[tok] = emitting candidates (source in the column before), t3 = silent ones
   std::vector<char> live(S, 0);
   for (const WNode &nd : nodes) live[nd.dst & W_IDX_MASK] = 1;
   std::vector<RetEdge> edges;
+  int seedState = -1; double seedW = 0.0;
   for (const WNode &nd : nodes) {
     const int x = (int)(nd.dst & W_IDX_MASK);
     for (int tok = 0; tok < (int)nd.t2.size(); ++tok)
       for (const WCand &cd : nd.t2[tok]) {
         const int y = (int)(cd.src & 0x3fffffffu);
-        if (y >= S) continue;                                  // the seed: no dependency
-        if (tok == 0) return true;                             // (cannot happen: token 0 of a levelled node holds the seed only)
+        if (y == S + 1) { seedState = x; seedW = cd.w; continue; }      // the seed: no dependency
+        if (y >= S || tok == 0) return true;                           // (cannot happen: token 0 of a levelled node holds the seed only)
         if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 1, tok, cd.w});
       }
     for (const WCand &cd : nd.t3) {
@@ -1008,61 +1063,57 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     return P.backward ? a.dst > b.dst : a.dst < b.dst;
   });
   long long work = 0;
-  std::vector<int> tau, tauBest;
-  auto feasible = [&](int period) { return ret_offsets(edges, S, period, (WIDE_RET_TOKWIN - 2) * period + period - 1, tau, work); };
+  std::vector<int> tau;
+  const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
+  auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau, work); };
   const int forced = env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
   int lo = 1, hi = 64;
   if (!feasible(hi)) return true;
   while (lo < hi) { const int mid = (lo + hi) / 2; if (feasible(mid)) hi = mid; else lo = mid + 1; }
   const int pMin = lo;
-  // shape for one period length: ring depths, relays, nodes by residue; cost from the round planner
-  struct Shape { int period = 0, NB = 0, NBL = 0, nLong = 0, kMax = 0, tauMax = 0; double cost = 1e300; std::vector<WNode> nd; };
+  // shape for one period length: ring depth, relays, nodes by residue; cost from the round planner
+  struct Shape { int period = 0, NB = 0, NVs = 0, nRelay = 0, kMax = 0, tauMax = 0; double cost = 1e300; std::vector<WNode> nd; };
   auto shape = [&](int period, Shape &sh) -> bool {
     if (!feasible(period)) return false;
     int tauMax = 0;
     for (int x = 0; x < S; ++x) if (live[x]) tauMax = std::max(tauMax, tau[x]);
-    const int NVs = S + 2;
     for (int NB = 4; NB >= 2; --NB) {
-      if ((size_t)NB * NVs * sizeof(double) > WIDE_LDS_MAX) continue;
-      // sources some reader sees NB periods or more after they were written go through the long ring
-      std::vector<int> longIdx(S, -1);
-      int nLong = 0, maxSpan = 0;
+      // a value is readable for NB * period - 1 steps after it was written; sources with later readers are copied every `hop`
+      // steps into relay entries of their own (relay k of u: a silent copy of relay k - 1 at tau(u) + k * hop)
+      const int hop = NB * period - 1;
+      std::vector<int> nHops(S, 0), relayBase(S, 0);
       for (const RetEdge &e : edges) {
         const int span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
-        if (span >= NB * period) { if (longIdx[e.src] < 0) longIdx[e.src] = nLong++; maxSpan = std::max(maxSpan, span); }
+        nHops[e.src] = std::max(nHops[e.src], (span - 1) / hop);
       }
-      const int NBL = nLong ? (maxSpan + period - 1) / period + 1 : 1;
-      if (nLong > 512) continue;
-      const size_t lds = ((size_t)NB * NVs + (size_t)NBL * nLong) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
-      if (lds > WIDE_LDS_MAX) continue;
-      // nodes: every live state, plus one relay per long-lived source at tau + 1
+      int nRelay = 0, kMax = 0;
+      for (int x = 0; x < S; ++x) { relayBase[x] = nRelay; nRelay += nHops[x]; kMax = std::max(kMax, (tau[x] + nHops[x] * hop) / period); }
+      const int NVs = S + 2 + nRelay, nPen = (kMax + 1) * rowLen;
+      if (kMax > kLimit) continue;
+      const size_t lds = ((size_t)NB * NVs + 2 * (size_t)nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+      if (lds > WIDE_LDS_MAX || (size_t)NB * NVs > 0x8000) continue;
+      auto srcWord = [&](int ktDst, int em, int col, int entry) {
+        const int back = (ktDst + em) % NB;
+        return ((uint32_t)((ktDst * rowLen + col) * 8) << 16) | (uint32_t)(((NB - back) % NB) * NVs + entry);
+      };
+      auto dstWord = [&](int kt, int entry) { return ((uint32_t)kt << 20) | ((uint32_t)((NB - kt % NB) % NB) << 18) | (uint32_t)entry; };
       std::vector<std::vector<WCand>> cands(S);
-      for (const WNode &nd0 : nodes)       // the seed
-        for (const auto &l : nd0.t2) for (const WCand &cd : l) if ((int)(cd.src & 0x3fffffffu) == S + 1)
-          cands[nd0.dst & W_IDX_MASK].push_back(WCand{(2u << 30) | ((uint32_t)(tau[nd0.dst & W_IDX_MASK] / period) << 24) | ((uint32_t)WIDE_RET_SEED_TOK << 15) | (uint32_t)(S + 1), cd.w});
+      if (seedState >= 0) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
       for (const RetEdge &e : edges) {
         const int kt = tau[e.dst] / period, span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
-        const bool viaLong = span >= NB * period;
-        const uint32_t sw = ((viaLong ? 1u : 0u) << 30) | ((uint32_t)kt << 24) | ((uint32_t)e.em << 23) | ((uint32_t)((kt + e.em) % NB) << 21) |
-                            ((uint32_t)e.tok << 15) | (uint32_t)(viaLong ? (((kt + e.em) % NBL) << 9) | longIdx[e.src] : e.src);
-        cands[e.dst].push_back(WCand{sw, e.w});
+        const int k = (span - 1) / hop;
+        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : e.src), e.w});
       }
       sh.nd.clear();
-      int kMax = 0;
       for (int x = 0; x < S; ++x) {      // (states nothing leads to are nodes too: their cells of the matrix are -inf)
-        const int kt = tau[x] / period;
-        kMax = std::max(kMax, kt);
-        sh.nd.push_back(WNode{CUR(((uint32_t)kt << 20) | ((uint32_t)(kt % NB) << 18) | (uint32_t)x), tau[x] % period, {}, std::move(cands[x])});
-        if (longIdx[x] >= 0) {
-          const int tr = tau[x] + 1, kr = tr / period;
-          kMax = std::max(kMax, kr);
-          const uint32_t sw = (0u << 30) | ((uint32_t)kr << 24) | ((uint32_t)(kr % NB) << 21) | (uint32_t)x;
-          sh.nd.push_back(WNode{EXTRA(((uint32_t)kr << 20) | ((uint32_t)(kr % NB) << 18) | ((uint32_t)(kr % NBL) << 9) | (uint32_t)longIdx[x]), tr % period, {}, {WCand{sw, 0.0}}});
+        sh.nd.push_back(WNode{CUR(dstWord(tau[x] / period, x)), tau[x] % period, {}, std::move(cands[x])});
+        for (int k = 1; k <= nHops[x]; ++k) {
+          const int tr = tau[x] + k * hop, kr = tr / period, entry = S + 2 + relayBase[x] + k - 1;
+          sh.nd.push_back(WNode{CUR(dstWord(kr, entry)), tr % period, {}, {WCand{srcWord(kr, 0, 0, k == 1 ? x : entry - 1), 0.0}}});
         }
       }
-      if (kMax > WIDE_RET_TOKWIN - 2) return false;
-      sh.period = period; sh.NB = NB; sh.NBL = NBL; sh.nLong = nLong; sh.kMax = kMax; sh.tauMax = tauMax;
-      sh.cost = wide_plan(sh.nd, period - 1, 1, W, false, nullptr);
+      sh.period = period; sh.NB = NB; sh.NVs = NVs; sh.nRelay = nRelay; sh.kMax = kMax; sh.tauMax = tauMax;
+      sh.cost = wide_plan(sh.nd, period - 1, 1, W, false, nullptr, 280.0);
       return true;
     }
     return false;
@@ -1070,20 +1121,20 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   Shape best, cur;
   for (int period = forced > 0 ? forced : pMin; period <= (forced > 0 ? forced : std::min(64, pMin + 8)); ++period) {
     if (!shape(period, cur)) continue;
-    if (verbose) fprintf(stderr, "[mbhip] wide retimed, period %d: tauMax %d, ring %d, long ring %d x %d, modelled %.0f cycles per column\n",
-                         period, cur.tauMax, cur.NB, cur.NBL, cur.nLong, cur.cost);
+    if (verbose) fprintf(stderr, "[mbhip] wide retimed, period %d: tauMax %d, ring %d x %d (%d relays), modelled %.0f cycles per column\n",
+                         period, cur.tauMax, cur.NB, cur.NVs, cur.nRelay, cur.cost);
     if (cur.cost < best.cost) std::swap(best, cur);
   }
   if (best.cost >= 1e300) return true;
   // rounds (one stage per residue) -> one stream of [slot][lane] records
   WideProgram T;
   T.W = W; T.dev.S = S;
-  wide_plan(best.nd, best.period - 1, 1, W, true, &T);
+  wide_plan(best.nd, best.period - 1, 1, W, true, &T, 280.0);
   if (T.rounds.empty()) return true;
   int nSlots = 0;
   for (const WideRound &R : T.rounds) nSlots += R.depth;
   const int padded = (nSlots + WIDE_RING - 1) / WIDE_RING * WIDE_RING;
-  const WideRec padRec{-INFINITY, PREV(S), 0};
+  const WideRec padRec{-INFINITY, (uint32_t)S, 0};            // ring entry S of the newest vector (-inf), penalty entry 0 (0.0)
   std::vector<WideRec> st;
   st.reserve((size_t)(padded + WIDE_RING) * W);
   for (const WideRound &R : T.rounds)
@@ -1091,22 +1142,33 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       const bool last = j + 1 == R.depth;
       for (int l = 0; l < W; ++l) {
         WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
-        rc.pad = last ? (0x80000000u | (R.sync ? 0x40000000u : 0u) | T.dsts[R.dstBase + l]) : 0u;
+        if (rc.w == -INFINITY) rc = padRec;                    // (the planner's own padding names the previous column)
+        rc.pad = 0u;
+        if (last) {
+          rc.pad = 0x80000000u | (R.sync ? 0x40000000u : 0u) | T.dsts[R.dstBase + l];
+          if (l % 64 == 0) {                                   // groups of different sizes in this wavefront: masked reduction
+            const uint32_t g0 = (T.dsts[R.dstBase + l] >> 26) & 7u;
+            for (int q = l; q < std::min(W, l + 64); ++q) {
+              const uint32_t dq = T.dsts[R.dstBase + q];
+              if ((dq & WIDE_RET_NO_DST) != WIDE_RET_NO_DST && ((dq >> 26) & 7u) != g0) rc.pad |= 0x20000000u;
+            }
+          }
+        }
         st.push_back(rc);
       }
     }
   st.resize((size_t)padded * W, padRec);
   st.insert(st.end(), st.begin(), st.begin() + (size_t)WIDE_RING * W);      // the ring reads one ring of slots into the next period
   if (!up_w(P.d_ret, st)) return false;
-  P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NBL = best.NBL; P.ret.nLong = best.nLong; P.ret.NVs = S + 2;
-  P.ret.kMax = best.kMax;
-  P.retLdsBytes = ((size_t)best.NB * (S + 2) + (size_t)best.NBL * best.nLong) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+  P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
+  P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
+  P.retLdsBytes = ((size_t)best.NB * best.NVs + 2 * (size_t)P.ret.nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
   P.retPeriod = best.period; P.retTauMax = best.tauMax;
   P.retOk = true;
   if (verbose)
-    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d, %d relays x %d, LDS %zu bytes\n",
+    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays), LDS %zu bytes\n",
             P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
-            100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.nLong, best.NBL, P.retLdsBytes);
+            100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.NVs, best.nRelay, P.retLdsBytes);
   return true;
 }
 
@@ -1199,7 +1261,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
       std::vector<WNode> levelled;
       int xe = 0, xs = 0; long long xp = 0;
       const std::vector<WNode> *lv = &bestNodes;
-      if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", -1) > 0) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
+      if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", 1)) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
       else if (bestK != 0) lv = nullptr;
       if (lv && !wide_ret_build(m, P, *lv, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
     }

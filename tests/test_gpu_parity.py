@@ -1029,6 +1029,7 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     matrix and path, posterior counts -- for the levelled program and several closure groupings, LDS and L2 vectors."""
     m, em = _profile_machine(3)
     assert em.nInTok == 0 and em.nStates >= 256
+    monkeypatch.setenv("MB_WIDE_RETIMED", "0")        # the column-by-column kernels (the retimed sweep: test_one_tape_retimed_sweep)
     if stages is not None:                              # None: the planner's own choice; -2: adaptive stages of <= 2 slots; -999: stage cuts by dynamic programming
         monkeypatch.setenv("MB_WIDE_CLOSURE_STAGES", str(stages))
     if stages == 3:
@@ -1064,6 +1065,62 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     lw = np.array(em.logWeight, dtype=np.float64) - 0.125
     dm.set_weights(lw); om.set_weights(lw)
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
+
+
+@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}])
+def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
+    """The retimed sweep of the one-tape family (mb_wide.hip k_wide_retimed: every state on its own column, a period of a
+    few wide rounds instead of one round per silent level): Viterbi matrices bit for bit, Forward / Backward matrices and
+    rolling log-likelihoods within the fast-path tolerance, paths and counts -- tiny generators and recognisers (period 1),
+    the fn3 profile (protein alphabet: 22 penalty columns, 44 columns in flight, relay entries), the 3-node composite of
+    config 5 (period 9); lengths on both sides of the 64-column token window; a longer period than the shortest and
+    256-lane workgroups (several rounds per residue)."""
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
+    for k, v in knobs.items():
+        if k != "MB_WIDE_RETIMED_PERIOD": monkeypatch.setenv(k, v)
+    gen = Machine.fromJson({"state": [
+        {"id": "S", "trans": [{"to": "A"}, {"to": "B", "weight": 0.25}]},
+        {"id": "A", "trans": [{"to": "A", "out": "x", "weight": 0.5}, {"to": "B", "out": "y", "weight": 0.3}, {"to": "E", "weight": 0.2}]},
+        {"id": "B", "trans": [{"to": "A", "out": "y", "weight": 0.6}, {"to": "B", "out": "x", "weight": 0.1}, {"to": "E", "weight": 0.3}]},
+        {"id": "E"}]})
+    rec = Machine.fromJson(json.loads(json.dumps({"state": [{"id": st.name, "trans": [dict(to=t.dest, weight=t.weight, **({"in": t.out} if t.out else {})) for t in st.trans]} for st in gen.state]})))
+    cases = [(EvaluatedMachine.fromMachine(gen, {}), 1, 1, (0, 1, 23, 150)), (EvaluatedMachine.fromMachine(rec, {}), 0, 1, (0, 5, 70)),
+             (EvaluatedMachine.fromMachine(HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).machine(True), {}), 1, 2, (0, 1, 40, 130)),
+             (_profile_machine(3)[1], 1, 9, (0, 1, 41, 100))]
+    for em, tape, pMin, lens in cases:
+        if "MB_WIDE_RETIMED_PERIOD" in knobs: monkeypatch.setenv("MB_WIDE_RETIMED_PERIOD", str(pMin + int(knobs["MB_WIDE_RETIMED_PERIOD"])))
+        om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+        nt = em.nOutTok if tape else em.nInTok
+        z = np.zeros(0, np.int32)
+        seqs = [np.random.RandomState(100 + n).randint(1, nt + 1, size=n).astype(np.int32) for n in lens]
+        pairs = [(z, q) if tape else (q, z) for q in seqs]
+        ref = np.zeros(em.nTransitions)
+        for x, y in pairs:
+            V = dm.fill(capi.MB_VITERBI, x, y); assert capi.last_kernel_name() == "k_wide_retimed<1>"
+            F = dm.fill(capi.MB_FORWARD, x, y); assert capi.last_kernel_name() == "k_wide_retimed<0>"
+            B = dm.fill(capi.MB_BACKWARD, x, y)
+            assert np.array_equal(V, om.viterbi(x, y))
+            assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+            if F[-1, -1, -1] > -math.inf: om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+        b = capi.DeviceBatch.from_pairs(dm, pairs)
+        ll = b.forward(capi.MB_ROLLING); assert capi.last_kernel_name().startswith("k_wide_retimed<0>")
+        vll, off, edges = b.viterbi()
+        counts, s, _ = b.counts()
+        assert close(counts, ref, 1e-5, 1e-7)
+        for k, (x, y) in enumerate(pairs):
+            Vo = om.viterbi(x, y)
+            assert close([ll[k]], [om.loglike(x, y, oracle_mod.SUM_EXACT)], FAST_REL, FAST_ABS) and vll[k] == Vo[-1, -1, -1]
+            if Vo[-1, -1, -1] > -math.inf:
+                assert np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, Vo))
+        # a weight update rebuilds the program (same schedule, new records)
+        lw = np.array(em.logWeight, dtype=np.float64) - 0.0625
+        dm.set_weights(lw); om.set_weights(lw)
+        x, y = pairs[-1]
+        assert np.array_equal(dm.fill(capi.MB_VITERBI, x, y), om.viterbi(x, y))
+        dm.close()
 
 
 def test_one_tape_count_kernel(capi, oracle_mod, monkeypatch):
@@ -1171,7 +1228,7 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     llr = b.forward(capi.MB_ROLLING)
     kern = capi.last_kernel_name()
-    assert kern.startswith("k_wide_sweep<0>" if nodes == 20 else "k_wide_sum32")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
+    assert kern.startswith("k_wide_retimed<0>" if nodes == 20 else "k_wide_sum32")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
     nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
     bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
     llm = bm.forward(capi.MB_MATERIALISE)
@@ -1228,11 +1285,11 @@ def test_baseline_config5_at_its_stated_length(capi, monkeypatch):
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     assert b.cells() == nSeq * (L + 1) * 5063
     llr = b.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() == "k_wide_sweep<0> x2 + k_onetape_join"       # 2 x 64 workgroups <= 256 CUs: cut in two
+    assert capi.last_kernel_name() == "k_wide_retimed<0> x2 + k_onetape_join"     # 2 x 64 workgroups <= 256 CUs: cut in two
     assert np.all(np.isfinite(llr)) and llr[0] == llr[1] == llr[63]
     monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
     llp = b.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() == "k_wide_sweep<0>" and close(llr, llp, 1e-8) and llp[0] == llp[1] == llp[63]
+    assert capi.last_kernel_name() == "k_wide_retimed<0>" and close(llr, llp, 1e-8) and llp[0] == llp[1] == llp[63]
     monkeypatch.delenv("MB_ONETAPE_SPLIT")
     b2 = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:2]])                # 2 x 2.03 GB matrices
     llm = b2.forward(capi.MB_MATERIALISE)
@@ -1298,7 +1355,7 @@ def test_one_tape_family_small_machines(capi, oracle_mod, monkeypatch):
             seq = np.random.RandomState(ol).randint(1, 3, size=ol).astype(np.int32)
             x, y = (np.zeros(0, np.int32), seq) if tape else (seq, np.zeros(0, np.int32))
             V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y); B = dm.fill(capi.MB_BACKWARD, x, y)
-            assert capi.last_kernel_name().startswith("k_wide_sweep")
+            assert capi.last_kernel_name().startswith("k_wide_")
             assert np.array_equal(V, om.viterbi(x, y))
             assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
             b = capi.DeviceBatch.from_pairs(dm, [(x, y)] * 2)
