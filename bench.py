@@ -215,8 +215,16 @@ def extra_single_gpu(capi, np, hbm_peak):
                           "counts_lattice": round(cells5 / t5c / 1e9, 2), "unit": "Gcells/s", "counts_ms": round(t5c * 1e3, 1),
                           "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
-                          "roofline": {"bound": "valu", "note": "one workgroup per sequence, a column's silent closure is a dependent chain: bound by instruction issue on 64 of 256 CUs (DESIGN.md 4.2b); no HBM or MFMA bound applies"}}
+                          "roofline": {"bound": "valu", "note": "one workgroup per sequence on 64 of 256 CUs; the retimed sweep (DESIGN.md 4.2b) turns a column's 366 dependent silent levels into a period of 10 barrier-separated rounds with 37 columns in flight: bound by instruction issue + one barrier bubble per round; no HBM or MFMA bound applies"}}
         del b5
+        # ... with every CU busy: 256 sequences x 4 kb
+        b5w = capi.DeviceBatch(dm5, *synth_batch(5, 256, 0, 4000, em5.nInTok, em5.nOutTok))
+        cells5w = b5w.cells()
+        _, t5w = timed(lambda: b5w.forward(capi.MB_ROLLING), 1); k5w = capi.last_kernel_name()
+        _, t5wv = timed(lambda: b5w.viterbi(paths=False), 1); k5wv = capi.last_kernel_name()
+        out["config5"]["all_cus"] = {"workload": "the same machine, 256 sequences x 4000 nt (one workgroup per CU)", "forward_rolling": round(cells5w / t5w / 1e9, 2),
+                                     "viterbi_fill": round(cells5w / t5wv / 1e9, 2), "unit": "Gcells/s", "kernels": [k5w, k5wv]}
+        del b5w
         # ... and at the config's STATED length: 64 sequences x 50 kb on this one GPU (16.2 G cells per matrix)
         b5f = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 50000, em5.nInTok, em5.nOutTok))
         cells5f = b5f.cells()

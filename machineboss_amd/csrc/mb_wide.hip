@@ -300,10 +300,17 @@ __device__ __forceinline__ void wide_group_reduce_all(double &m, float &s, int g
   if (gWave > 32) wide_sum_all<32>(s);
 }
 
+// LDS by raw byte address (the records of the retimed sweep carry addresses, not indices)
+typedef __attribute__((address_space(3))) double wide_lds_f64;
+__device__ __forceinline__ double wide_lds_read(unsigned a) { return *(const wide_lds_f64 *)(uintptr_t)a; }
+__device__ __forceinline__ void wide_lds_write(unsigned a, double v) { *(wide_lds_f64 *)(uintptr_t)a = v; }
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike) {
   extern __shared__ double wlds[];
+  // the records carry raw LDS byte addresses: the dynamic array is this kernel's only LDS, so it starts at 0
+  if ((unsigned)(uintptr_t)wlds != 0u) __builtin_trap();
   const unsigned bid = blockIdx.x;
   const PairDesc pd = pairs[bid];
   const int tid = threadIdx.x, W = P.W, S = P.S;
@@ -331,36 +338,46 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   __syncthreads();
   for (int e = tid; e < nPen; e += W) { const int kt = e / rowLen; pen[e] = penalty(kt, e - kt * rowLen, 0); }
   __syncthreads();
+  // one record stream per rotation of the ring (the newest column sits in vector t mod NB); a stream runs on into the next one
+  const size_t perStream = (size_t)Q.nSlots * W;
   const WideRec *rec = Q.rec;
   WideRec q[WIDE_RING];
 #pragma unroll
   for (int k = 0; k < WIDE_RING; ++k) q[k] = (rec + (size_t)k * W)[tid];
   const int nPer = L + 1 + Q.kMax;
-  const unsigned ringBytes = (unsigned)nVec * 8u, vecBytes = (unsigned)NVs * 8u;
-  unsigned rot = 0;                                  // byte offset of the ring vector that holds the period's newest column
-  unsigned penCur = ringBytes, penNxt = ringBytes + (unsigned)nPen * 8u;
-  char *lds = (char *)wlds;
+  unsigned penCur = (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
   float s = 0.0f;
   const bool storeAll = cells && !P.lastOnly, storeLast = cells && P.lastOnly;
-  const int rowSign = P.lastOnly ? 0 : (P.backward ? 1 : -1), rowS = P.lastOnly ? 0 : S;
+  // a node's lag comes as kq = kMax - ktau (ktau for a backward sweep): its column is cBase + cSign * kq, its matrix row starts
+  // kq * rowS doubles behind rowPtr
+  const int cSign = P.backward ? -1 : 1, rowS = P.lastOnly ? 0 : S;
+  int cm = 0;
+  // the LDS reads of a slot are issued one slot ahead (behind a barrier they are issued again: what they fetched may be stale)
+  double vAhead = wide_lds_read(q[0].src >> 14), pAhead = wide_lds_read(((q[0].src & 0x1fffu) << 3) + penCur);
   for (int t = 0; t < nPer; ++t) {
     if (tid == 0) {                                  // (the entry of column t - 62: no node lags that far)
       tokWin[(t + 2) & (WIDE_RET_TOKWIN - 1)] = tokNext;
       tokNext = tokAt(t + 3);
     }
-    if (tid < nPen) *(double *)(lds + penNxt + (unsigned)tid * 8u) = penalty(myKt, myCol, t + 1);
-    for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; *(double *)(lds + penNxt + (unsigned)e * 8u) = penalty(kt, e - kt * rowLen, t + 1); }
-    const int rowBase = P.lastOnly ? 0 : (P.backward ? L - t : t);      // matrix row of a node that lags kt columns: rowBase + rowSign * kt
+    if (tid < nPen) wide_lds_write(penNxt + (unsigned)tid * 8u, penalty(myKt, myCol, t + 1));
+    for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; wide_lds_write(penNxt + (unsigned)e * 8u, penalty(kt, e - kt * rowLen, t + 1)); }
+    const int cBase = P.backward ? t : t - Q.kMax;
+    const char *rowPtr = (const char *)(P.lastOnly ? cells : cells + (long long)(P.backward ? L - t : t - Q.kMax) * S);
+    const WideRec *rcm = rec + (size_t)cm * perStream;
     for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
+      // (the slot after this period's last one belongs to the next period: its penalties are the other table's)
+      const unsigned penHere = penCur, penLast = j0 + WIDE_RING == Q.nSlots ? penNxt : penCur;
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
-        q[k] = (rec + (size_t)(j0 + WIDE_RING + k) * W)[tid];
-        unsigned a = ((rc.src & 0x7fffu) << 3) + rot;
-        a = min(a, a - ringBytes);                   // one wrap
-        const double v = *(const double *)(lds + a) + rc.w;
-        const double cand = v + *(const double *)(lds + penCur + (rc.src >> 16));      // + 0.0 or -inf
+        q[k] = (rcm + (size_t)(j0 + WIDE_RING + k) * W)[tid];
+        const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one just requested)
+        const unsigned penN = k + 1 == WIDE_RING ? penLast : penHere;
+        const double vNow = vAhead, pNow = pAhead;
+        vAhead = wide_lds_read(nx.src >> 14);
+        pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
+        const double cand = (vNow + rc.w) + pNow;              // + 0.0 or -inf
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
         else wide_fold<MODE>(m, s, cand, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
@@ -371,26 +388,27 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
             else wide_group_reduce_all<MODE>(m, s, gWave);
           }
-          const uint32_t x = dst & WIDE_RET_NO_DST, kt = (dst >> 20) & 63u;
-          const int c = t - (int)kt;
-          if (x < (unsigned)NVs && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
+          const uint32_t d = dst & 0x7fffu, kq = (dst >> 20) & 63u;
+          const int c = cBase + cSign * (int)kq;
+          if (d != 0x7fffu && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry d = all ones)
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
-            unsigned d = __umul24((dst >> 18) & 3u, vecBytes) + rot;
-            d += x << 3;
-            d = min(d, d - ringBytes);
-            *(double *)(lds + d) = res;
+            wide_lds_write(d << 3, res);
             if (storeAll | (storeLast & (c == L))) {
-              const unsigned row = (unsigned)(rowBase + rowSign * (int)kt);      // c, or L - c for a backward sweep, or 0
-              if (x < (unsigned)S) cells[(size_t)row * (size_t)rowS + x] = res;
+              const uint32_t x = d - __umul24((dst >> 18) & 3u, (unsigned)NVs);      // entry within its vector: the state (relays: >= S + 2)
+              if (x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
             }
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
           s = 0.0f;
-          if (flags & 0x40000000u) __syncthreads();
+          if (flags & 0x40000000u) {
+            __syncthreads();
+            vAhead = wide_lds_read(nx.src >> 14);
+            pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
+          }
         }
       }
     }
-    rot += vecBytes; rot = rot == ringBytes ? 0u : rot;
+    cm = cm + 1 == NB ? 0 : cm + 1;
     const unsigned sw = penCur; penCur = penNxt; penNxt = sw;
   }
   if (loglike && tid == 0) loglike[bid] = V[(L % NB) * NVs + P.resultIdx];
@@ -570,7 +588,8 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
   // lane-group reduction, log, store -- 0.30 to 0.58 us, i.e. 1.6-1.9 slots, and the barrier itself next to nothing
   // (the retimed kernel, whose slots are leaner: 0.08 us a slot, 0.37 us a round with its barrier -- cRound = 280)
   const double cSlot = 60.0, cShfl = 3.0, cSync = 10.0;
-  auto groupOf = [&](int L, int d) { return std::min(64, pow2ceil((L + d - 1) / d)); };
+  const int maxGroup = std::max(1, std::min(64, env_int_w("MB_WIDE_MAX_GROUP", 64)));
+  auto groupOf = [&](int L, int d) { return std::min(maxGroup, pow2ceil((L + d - 1) / d)); };
   int bestD = 1; double best = 1e300;
   for (int d = 1; d <= maxLen; ++d) {
     long long lanes = 0; int depth = 0, mg = 1;
@@ -1091,7 +1110,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       const int NVs = S + 2 + nRelay, nPen = (kMax + 1) * rowLen;
       if (kMax > kLimit) continue;
       const size_t lds = ((size_t)NB * NVs + 2 * (size_t)nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
-      if (lds > WIDE_LDS_MAX || (size_t)NB * NVs > 0x8000) continue;
+      if (lds > WIDE_LDS_MAX || (size_t)NB * NVs >= 0x7fff || nPen > 0x2000) continue;
       auto srcWord = [&](int ktDst, int em, int col, int entry) {
         const int back = (ktDst + em) % NB;
         return ((uint32_t)((ktDst * rowLen + col) * 8) << 16) | (uint32_t)(((NB - back) % NB) * NVs + entry);
@@ -1134,31 +1153,55 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   int nSlots = 0;
   for (const WideRound &R : T.rounds) nSlots += R.depth;
   const int padded = (nSlots + WIDE_RING - 1) / WIDE_RING * WIDE_RING;
-  const WideRec padRec{-INFINITY, (uint32_t)S, 0};            // ring entry S of the newest vector (-inf), penalty entry 0 (0.0)
+  // one stream per rotation cm of the ring (newest column in vector cm): a record names its source by LDS byte address
+  //   src = byte address << 14 | penalty entry;   pad (last slot) = flags | kq << 20 | vector << 18 | ring entry (see WideRetDev)
+  const int NB = best.NB, NVs = best.NVs;
   std::vector<WideRec> st;
-  st.reserve((size_t)(padded + WIDE_RING) * W);
-  for (const WideRound &R : T.rounds)
-    for (int j = 0; j < R.depth; ++j) {
-      const bool last = j + 1 == R.depth;
-      for (int l = 0; l < W; ++l) {
-        WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
-        if (rc.w == -INFINITY) rc = padRec;                    // (the planner's own padding names the previous column)
-        rc.pad = 0u;
-        if (last) {
-          rc.pad = 0x80000000u | (R.sync ? 0x40000000u : 0u) | T.dsts[R.dstBase + l];
-          if (l % 64 == 0) {                                   // groups of different sizes in this wavefront: masked reduction
-            const uint32_t g0 = (T.dsts[R.dstBase + l] >> 26) & 7u;
-            for (int q = l; q < std::min(W, l + 64); ++q) {
-              const uint32_t dq = T.dsts[R.dstBase + q];
-              if ((dq & WIDE_RET_NO_DST) != WIDE_RET_NO_DST && ((dq >> 26) & 7u) != g0) rc.pad |= 0x20000000u;
+  st.reserve((size_t)(NB * padded + WIDE_RING) * W);
+  for (int cm = 0; cm < NB; ++cm) {
+    const WideRec padRec{-INFINITY, (uint32_t)(S * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
+    const size_t start = st.size();
+    for (const WideRound &R : T.rounds)
+      for (int j = 0; j < R.depth; ++j) {
+        const bool last = j + 1 == R.depth;
+        for (int l = 0; l < W; ++l) {
+          WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
+          if (rc.w == -INFINITY) rc = padRec;                    // (the planner's own padding)
+          else {
+            const uint32_t a0 = rc.src & 0xffffu, penOff = rc.src >> 16;      // shape(): entry for rotation 0, penalty byte offset
+            const uint32_t vec = (a0 / NVs + cm) % NB, entry = a0 % NVs;
+            rc.src = ((vec * NVs + entry) * 8u) << 14 | (penOff >> 3);
+          }
+          rc.pad = 0u;
+          if (last) {
+            const uint32_t dw = T.dsts[R.dstBase + l], x = dw & WIDE_RET_NO_DST, kt = (dw >> 20) & 63u, nkm = (dw >> 18) & 3u;
+            uint32_t word = dw & 0x1c000000u;                    // log2 of the lane group
+            if (x == WIDE_RET_NO_DST) word |= 0x7fffu;
+            else {
+              const uint32_t vec = (nkm + cm) % NB;
+              word |= ((P.backward ? kt : (uint32_t)best.kMax - kt) << 20) | (vec << 18) | (vec * NVs + x);
+            }
+            rc.pad = 0x80000000u | (R.sync ? 0x40000000u : 0u) | word;
+            if (l % 64 == 0) {                                   // groups of different sizes in this wavefront: masked reduction
+              const uint32_t g0 = (dw >> 26) & 7u;
+              for (int q = l; q < std::min(W, l + 64); ++q) {
+                const uint32_t dq = T.dsts[R.dstBase + q];
+                if ((dq & WIDE_RET_NO_DST) != WIDE_RET_NO_DST && ((dq >> 26) & 7u) != g0) rc.pad |= 0x20000000u;
+              }
             }
           }
+          st.push_back(rc);
         }
-        st.push_back(rc);
       }
-    }
-  st.resize((size_t)padded * W, padRec);
+    st.resize(start + (size_t)padded * W, padRec);
+  }
   st.insert(st.end(), st.begin(), st.begin() + (size_t)WIDE_RING * W);      // the ring reads one ring of slots into the next period
+  if (verbose)
+    for (const WideRound &R : T.rounds) {
+      int hist[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int l = 0; l < W; ++l) { const uint32_t dw = T.dsts[R.dstBase + l]; if ((dw & WIDE_RET_NO_DST) != WIDE_RET_NO_DST) hist[(dw >> 26) & 7u]++; }
+      fprintf(stderr, "[mbhip]   round: %d lanes, depth %d, sync %d, nodes by group size 1/2/4/8/16/32/64: %d %d %d %d %d %d %d\n", R.pad0, R.depth, R.sync, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
+    }
   if (!up_w(P.d_ret, st)) return false;
   P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;

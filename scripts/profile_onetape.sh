@@ -8,23 +8,32 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_onetape_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} ${ONETAPE_MODES:-rmv} > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} r > "$OUT/pmc.log" 2>&1
+for MODE in r v; do
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_$MODE" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} $MODE > "$OUT/pmc_$MODE.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc2_$MODE" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} $MODE > "$OUT/pmc2_$MODE.log" 2>&1
+done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, collections, sys, os, shutil
 out, tag = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.join(out, "summary"), exist_ok=True)
 st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if st: shutil.copy(st[0], os.path.join(out, "summary", "%s_onetape_kernel_stats.csv" % tag))
-f = glob.glob(os.path.join(out, "pmc", "**", "*counter_collection.csv"), recursive=True)
-if f:
-    best = collections.defaultdict(float)
-    for r in csv.DictReader(open(f[0])):
-        if "k_wide" in r["Kernel_Name"]:
-            best[r["Counter_Name"]] = max(best[r["Counter_Name"]], float(r["Counter_Value"]))   # the large dispatch of the run
-    with open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag), "w") as g:
-        g.write("k_wide_sweep<0> (the fused Forward || Backward launch of the cut-in-two log-likelihood), 20-node profile machine (5063 states), 64 sequences x %s nt, largest dispatch (rocprofv3 --pmc, separate pass)\n" % os.environ.get("ONETAPE_LEN", "2000"))
+with open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag), "w") as g:
+    for mode, what in (("r", "rolling log-likelihood (sequences cut in two: Forward over the prefixes || Backward over the suffixes)"), ("v", "Viterbi fill (materialised)")):
+        best = {}
+        for sub in ("pmc_", "pmc2_"):
+            for f in glob.glob(os.path.join(out, sub + mode, "**", "*counter_collection.csv"), recursive=True):
+                per = collections.defaultdict(lambda: collections.defaultdict(float))
+                for r in csv.DictReader(open(f)):
+                    if "k_wide" in r["Kernel_Name"]: per[(r["Kernel_Name"].split("(")[0], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+                if per:      # the largest dispatch of the run
+                    key = max(per, key=lambda k: max(per[k].values()))
+                    best.setdefault("kernel", key[0]); best.update(per[key])
+        if not best: continue
+        g.write("%s, %s: 20-node profile machine (5063 states), 64 sequences x %s nt, largest dispatch (rocprofv3 --pmc, two separate passes)\n" % (best.pop("kernel"), what, os.environ.get("ONETAPE_LEN", "2000")))
         wc = best.get("SQ_WAVE_CYCLES", 1.0)
         for k in sorted(best): g.write("%-24s %16.0f  %6.1f %% of SQ_WAVE_CYCLES\n" % (k, best[k], 100 * best[k] / wc))
-    print(open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag)).read())
+        g.write("\n")
+print(open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag)).read())
 PY
 grep -E "forward|viterbi fill" "$OUT/stats.log"
