@@ -85,6 +85,7 @@ struct MedProgram {
   std::vector<long long> ldsImageIdx;   // record indices copied into the LDS image (slots placed in LDS by medium_jit_plan)
   int regUsed = 0;                      // what the last plan spent of it
   int regBudget = -1;                   // VGPRs medium_jit_plan may spend on loop-invariant records (-1: default)
+  int planC = 0, planHalo = 0, planWaves = 0;   // geometry the placement is made for (the program's own: its widest strips)
   int tokWindow = 64;                   // steps per output-token window kept in LDS by the specialised kernel
   std::vector<int> haloStates;          // states whose values another strip reads (sources of input-consuming candidates), ascending
   int *d_desc = nullptr;

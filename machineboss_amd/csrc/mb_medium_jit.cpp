@@ -68,7 +68,14 @@ bool medium_tb_eligible(const mb_machine *m, const MedProgram &P) {
 }
 
 // Decide where every slot's records live (see the file header).  Deterministic in (program, geometry).
-void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo) {
+void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geoIn) {
+  // One placement serves every kernel of the program -- all strip widths (medium_pick_geometry), with and without halo
+  // supercells -- so it is made for the geometry the program was built with (the widest strips, the largest ring): a
+  // re-plan after a spill, called with the narrower strips of a short batch, otherwise fills the LDS those strips leave
+  // free and the wider kernels no longer fit (they then ran the ahead-of-time kernel: right, but slow).
+  if (P.planC == 0) { P.planC = geoIn.C; P.planHalo = geoIn.haloSteps; P.planWaves = geoIn.waves; }
+  MedGeom geo = geoIn;
+  geo.C = std::max(geo.C, P.planC); geo.haloSteps = std::max(geo.haloSteps, P.planHalo); geo.waves = std::max(geo.waves, P.planWaves);
   if (P.regBudget < 0) {
     // VGPRs left for loop-invariant records: a wavefront of a W-wave workgroup may use 512 / ceil(W / 4) registers and
     // the specialised kernel needs ~90 of them for everything else; medium_jit_get lowers this if the compiler spills
@@ -290,7 +297,10 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
   bool fromCache = false;
   for (int attempt = 0; attempt < 8; ++attempt) {
     J.ldsBytes = medium_jit_lds_bytes(P, geo, mode);
-    if (J.ldsBytes > 160 * 1024) return false;
+    if (J.ldsBytes > 160 * 1024) {
+      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit (mode %d, matrix kind %d): %zu bytes of LDS at register budget %d -- ahead-of-time kernel\n", mode, matKind, (size_t)J.ldsBytes, P.regBudget);
+      return false;
+    }
     src = medium_jit_source(m, P, geo, mode, matKind);
     if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
       if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : (mode == MED_MODE_TB ? ".tb" : ".sum"))) + (materialise ? ".mat" : (matKind == MED_MAT_ROLL ? ".tiles" : ".roll")) + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -306,7 +316,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.
     P.regBudget = std::max(0, std::min(P.regBudget, P.regUsed) - std::max(9, (int)spills + 3));   // cut from what the plan really spent
-    medium_jit_plan(m, P, geo);
+    medium_jit_plan(m, P, geoIn);
     if (!medium_refresh_weights(m, P)) return false;
     for (MedJit &O : P.jit) {
       if (&O == &J) continue;

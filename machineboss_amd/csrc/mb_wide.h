@@ -139,7 +139,7 @@ struct WideProgram {
   WidePhase *d_phase = nullptr;
   WideVitDev vit{};
   // the retimed program (wide_ret_build): preferred for max programs when it fits
-  bool retOk = false;
+  bool retOk = false, retGv = false;                    // retGv: the ring lives in an L2-resident scratch vector
   WideRec *d_ret = nullptr;
   WideRetDev ret{};
   size_t retLdsBytes = 0;

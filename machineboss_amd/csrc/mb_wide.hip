@@ -305,9 +305,11 @@ typedef __attribute__((address_space(3))) double wide_lds_f64;
 __device__ __forceinline__ double wide_lds_read(unsigned a) { return *(const wide_lds_f64 *)(uintptr_t)a; }
 __device__ __forceinline__ void wide_lds_write(unsigned a, double v) { *(wide_lds_f64 *)(uintptr_t)a = v; }
 
-template <int MODE>
+// GV: the ring lives in an L2-resident scratch vector of the workgroup (machines whose ring exceeds the LDS: the whole fn3
+// profile composite, 21 761 states); penalties and the token window stay in LDS.  Records then carry ring ENTRIES (src >> 13).
+template <int MODE, bool GV>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
-                                                       double *__restrict__ pool, double *__restrict__ loglike) {
+                                                       double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
   extern __shared__ double wlds[];
   // the records carry raw LDS byte addresses: the dynamic array is this kernel's only LDS, so it starts at 0
   if ((unsigned)(uintptr_t)wlds != 0u) __builtin_trap();
@@ -316,8 +318,8 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   const int tid = threadIdx.x, W = P.W, S = P.S;
   const int L = P.inputTape ? pd.inLen : pd.outLen;
   const int NVs = Q.NVs, NB = Q.NB, nVec = NB * NVs, nPen = Q.nPen, rowLen = Q.rowLen;
-  double *V = wlds;
-  double *pen = wlds + nVec;                         // [2][nPen]: this period's penalties and the next one's
+  double *V = GV ? scratch + (size_t)bid * (size_t)nVec : wlds;
+  double *pen = GV ? wlds : wlds + nVec;             // [2][nPen]: this period's penalties and the next one's
   int *tokWin = (int *)(pen + 2 * nPen);             // token of column c in entry c & 63, written two periods ahead
   for (int k = tid; k < nVec; k += W) V[k] = -INFINITY;
   if (tid < WIDE_RET_TOKWIN) tokWin[tid] = 0;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
 #pragma unroll
   for (int k = 0; k < WIDE_RING; ++k) q[k] = (rec + (size_t)k * W)[tid];
   const int nPer = L + 1 + Q.kMax;
-  unsigned penCur = (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
+  unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
   float s = 0.0f;
   const bool storeAll = cells && !P.lastOnly, storeLast = cells && P.lastOnly;
@@ -353,8 +355,9 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   // kq * rowS doubles behind rowPtr
   const int cSign = P.backward ? -1 : 1, rowS = P.lastOnly ? 0 : S;
   int cm = 0;
-  // the LDS reads of a slot are issued one slot ahead (behind a barrier they are issued again: what they fetched may be stale)
-  double vAhead = wide_lds_read(q[0].src >> 14), pAhead = wide_lds_read(((q[0].src & 0x1fffu) << 3) + penCur);
+  auto ring = [&](uint32_t src) -> double { return GV ? *(const double *)((const char *)V + ((size_t)(src >> 13) << 3)) : wide_lds_read(src >> 14); };
+  // the ring reads of a slot are issued one slot ahead (behind a barrier they are issued again: what they fetched may be stale)
+  double vAhead = ring(q[0].src), pAhead = wide_lds_read(((q[0].src & 0x1fffu) << 3) + penCur);
   for (int t = 0; t < nPer; ++t) {
     if (tid == 0) {                                  // (the entry of column t - 62: no node lags that far)
       tokWin[(t + 2) & (WIDE_RET_TOKWIN - 1)] = tokNext;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
         const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one just requested)
         const unsigned penN = k + 1 == WIDE_RING ? penLast : penHere;
         const double vNow = vAhead, pNow = pAhead;
-        vAhead = wide_lds_read(nx.src >> 14);
+        vAhead = ring(nx.src);
         pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
         const double cand = (vNow + rc.w) + pNow;              // + 0.0 or -inf
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
@@ -388,21 +391,19 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
             else wide_group_reduce_all<MODE>(m, s, gWave);
           }
-          const uint32_t d = dst & 0x7fffu, kq = (dst >> 20) & 63u;
+          const uint32_t x = dst & WIDE_RET_NO_DST, kq = (dst >> 20) & 63u;      // entry within its vector: the state (relays: >= S + 2)
           const int c = cBase + cSign * (int)kq;
-          if (d != 0x7fffu && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry d = all ones)
+          if (x != WIDE_RET_NO_DST && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
-            wide_lds_write(d << 3, res);
-            if (storeAll | (storeLast & (c == L))) {
-              const uint32_t x = d - __umul24((dst >> 18) & 3u, (unsigned)NVs);      // entry within its vector: the state (relays: >= S + 2)
-              if (x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
-            }
+            const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
+            if (GV) V[d] = res; else wide_lds_write(d << 3, res);
+            if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
           s = 0.0f;
           if (flags & 0x40000000u) {
             __syncthreads();
-            vAhead = wide_lds_read(nx.src >> 14);
+            vAhead = ring(nx.src);
             pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
           }
         }
@@ -1034,8 +1035,10 @@ struct RetEdge { int src, dst, em, tok; double w; };
 
 // smallest tau >= 0 with tau(dst) >= tau(src) + 1 - em * period over all edges; false when some tau would exceed `bound` (the period
 // is shorter than a cycle of the machine needs, or the columns are deeper than the kernel's 6-bit lag)
-bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int bound, std::vector<int> &tau, long long &work) {
+bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int bound, std::vector<int> &tau, long long &total) {
   tau.assign(nStates, 0);
+  long long work = 0;
+  total += 1;
   for (;;) {
     bool moved = false;
     for (const RetEdge &e : edges) {
@@ -1055,7 +1058,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   const int want = env_int_w("MB_WIDE_RETIMED", 1);
   if (want == 0) return true;
   const int rowLen = nTok + 1;                                 // penalty columns: silent, tokens 1 .. nTok - 1, the seed
-  if (S + 2 > 0x7fff || rowLen > 64 || 2 * (size_t)(S + 2) * sizeof(double) > WIDE_LDS_MAX) return true;
+  if (S + 2 >= (int)WIDE_RET_NO_DST || rowLen > 64) return true;
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   // the levelled nodes as a graph over states: t2[tok] = emitting candidates (source in the column before), t3 = silent ones
   std::vector<char> live(S, 0);
@@ -1091,11 +1094,14 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   while (lo < hi) { const int mid = (lo + hi) / 2; if (feasible(mid)) hi = mid; else lo = mid + 1; }
   const int pMin = lo;
   // shape for one period length: ring depth, relays, nodes by residue; cost from the round planner
-  struct Shape { int period = 0, NB = 0, NVs = 0, nRelay = 0, kMax = 0, tauMax = 0; double cost = 1e300; std::vector<WNode> nd; };
+  struct Shape { int period = 0, NB = 0, NVs = 0, nRelay = 0, kMax = 0, tauMax = 0; bool gv = false; double cost = 1e300; std::vector<WNode> nd; };
+  const bool forceGv = env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) != 0, allowGv = env_int_w("MB_WIDE_RETIMED_L2", 1) != 0;
   auto shape = [&](int period, Shape &sh) -> bool {
     if (!feasible(period)) return false;
     int tauMax = 0;
     for (int x = 0; x < S; ++x) if (live[x]) tauMax = std::max(tauMax, tau[x]);
+    // the deepest ring that fits the LDS (fewest relays); when none does, a ring of 4 in L2
+    for (int pass = 0; pass < 2; ++pass)
     for (int NB = 4; NB >= 2; --NB) {
       // a value is readable for NB * period - 1 steps after it was written; sources with later readers are copied every `hop`
       // steps into relay entries of their own (relay k of u: a silent copy of relay k - 1 at tau(u) + k * hop)
@@ -1109,11 +1115,13 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       for (int x = 0; x < S; ++x) { relayBase[x] = nRelay; nRelay += nHops[x]; kMax = std::max(kMax, (tau[x] + nHops[x] * hop) / period); }
       const int NVs = S + 2 + nRelay, nPen = (kMax + 1) * rowLen;
       if (kMax > kLimit) continue;
-      const size_t lds = ((size_t)NB * NVs + 2 * (size_t)nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
-      if (lds > WIDE_LDS_MAX || (size_t)NB * NVs >= 0x7fff || nPen > 0x2000) continue;
-      auto srcWord = [&](int ktDst, int em, int col, int entry) {
+      const size_t ldsPen = 2 * (size_t)nPen * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int), ldsAll = ldsPen + (size_t)NB * NVs * sizeof(double);
+      const bool inLds = ldsAll <= WIDE_LDS_MAX && !forceGv;
+      if ((pass == 0) != inLds) continue;
+      if ((!inLds && (ldsPen > WIDE_LDS_MAX || !allowGv)) || (size_t)NB * NVs >= (1u << 19) || NVs >= (int)WIDE_RET_NO_DST || nPen > 0x2000) continue;
+      auto srcWord = [&](int ktDst, int em, int col, int entry) {      // penalty entry << 19 | ring entry for rotation 0
         const int back = (ktDst + em) % NB;
-        return ((uint32_t)((ktDst * rowLen + col) * 8) << 16) | (uint32_t)(((NB - back) % NB) * NVs + entry);
+        return ((uint32_t)(ktDst * rowLen + col) << 19) | (uint32_t)(((NB - back) % NB) * NVs + entry);
       };
       auto dstWord = [&](int kt, int entry) { return ((uint32_t)kt << 20) | ((uint32_t)((NB - kt % NB) % NB) << 18) | (uint32_t)entry; };
       std::vector<std::vector<WCand>> cands(S);
@@ -1131,7 +1139,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
           sh.nd.push_back(WNode{CUR(dstWord(kr, entry)), tr % period, {}, {WCand{srcWord(kr, 0, 0, k == 1 ? x : entry - 1), 0.0}}});
         }
       }
-      sh.period = period; sh.NB = NB; sh.NVs = NVs; sh.nRelay = nRelay; sh.kMax = kMax; sh.tauMax = tauMax;
+      sh.period = period; sh.NB = NB; sh.NVs = NVs; sh.nRelay = nRelay; sh.kMax = kMax; sh.tauMax = tauMax; sh.gv = !inLds;
       sh.cost = wide_plan(sh.nd, period - 1, 1, W, false, nullptr, 280.0);
       return true;
     }
@@ -1159,7 +1167,8 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   std::vector<WideRec> st;
   st.reserve((size_t)(NB * padded + WIDE_RING) * W);
   for (int cm = 0; cm < NB; ++cm) {
-    const WideRec padRec{-INFINITY, (uint32_t)(S * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
+    const bool gv = best.gv;                                   // records name ring entries (L2 ring) or LDS byte addresses
+    const WideRec padRec{-INFINITY, gv ? (uint32_t)S << 13 : (uint32_t)(S * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
     const size_t start = st.size();
     for (const WideRound &R : T.rounds)
       for (int j = 0; j < R.depth; ++j) {
@@ -1168,19 +1177,16 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
           WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
           if (rc.w == -INFINITY) rc = padRec;                    // (the planner's own padding)
           else {
-            const uint32_t a0 = rc.src & 0xffffu, penOff = rc.src >> 16;      // shape(): entry for rotation 0, penalty byte offset
-            const uint32_t vec = (a0 / NVs + cm) % NB, entry = a0 % NVs;
-            rc.src = ((vec * NVs + entry) * 8u) << 14 | (penOff >> 3);
+            const uint32_t a0 = rc.src & 0x7ffffu, penIdx = rc.src >> 19;      // shape(): entry for rotation 0, penalty entry
+            const uint32_t vec = (a0 / NVs + cm) % NB, entry = vec * NVs + a0 % NVs;
+            rc.src = (gv ? entry << 13 : (entry * 8u) << 14) | penIdx;
           }
           rc.pad = 0u;
           if (last) {
             const uint32_t dw = T.dsts[R.dstBase + l], x = dw & WIDE_RET_NO_DST, kt = (dw >> 20) & 63u, nkm = (dw >> 18) & 3u;
             uint32_t word = dw & 0x1c000000u;                    // log2 of the lane group
-            if (x == WIDE_RET_NO_DST) word |= 0x7fffu;
-            else {
-              const uint32_t vec = (nkm + cm) % NB;
-              word |= ((P.backward ? kt : (uint32_t)best.kMax - kt) << 20) | (vec << 18) | (vec * NVs + x);
-            }
+            if (x == WIDE_RET_NO_DST) word |= WIDE_RET_NO_DST;
+            else word |= ((P.backward ? kt : (uint32_t)best.kMax - kt) << 20) | (((nkm + cm) % NB) << 18) | x;
             rc.pad = 0x80000000u | (R.sync ? 0x40000000u : 0u) | word;
             if (l % 64 == 0) {                                   // groups of different sizes in this wavefront: masked reduction
               const uint32_t g0 = (dw >> 26) & 7u;
@@ -1205,13 +1211,14 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   if (!up_w(P.d_ret, st)) return false;
   P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
-  P.retLdsBytes = ((size_t)best.NB * best.NVs + 2 * (size_t)P.ret.nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+  P.retGv = best.gv;
+  P.retLdsBytes = ((best.gv ? 0 : (size_t)best.NB * best.NVs) + 2 * (size_t)P.ret.nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
   P.retPeriod = best.period; P.retTauMax = best.tauMax;
   P.retOk = true;
   if (verbose)
-    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays), LDS %zu bytes\n",
+    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
             P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
-            100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.NVs, best.nRelay, P.retLdsBytes);
+            100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.NVs, best.nRelay, best.gv ? " in L2" : "", P.retLdsBytes);
   return true;
 }
 
@@ -1299,15 +1306,15 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     if (!up_w(P.d_segA, P.segA) || !up_w(P.d_segB, P.segB)) return false;
     nRecs = P.segA.size() + P.segB.size();
     if (viterbi && !wide_vit_build(P, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
-    {
-      // the retimed program is built from the LEVELLED nodes, whatever closure shape the column-by-column kernel chose
-      std::vector<WNode> levelled;
-      int xe = 0, xs = 0; long long xp = 0;
-      const std::vector<WNode> *lv = &bestNodes;
-      if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", 1)) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
-      else if (bestK != 0) lv = nullptr;
-      if (lv && !wide_ret_build(m, P, *lv, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
-    }
+  }
+  {
+    // the retimed program is built from the LEVELLED nodes, whatever closure shape / arithmetic the column-by-column kernel chose
+    std::vector<WNode> levelled;
+    int xe = 0, xs = 0; long long xp = 0;
+    const std::vector<WNode> *lv = &bestNodes;
+    if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", 1)) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
+    else if (bestK != 0) lv = nullptr;
+    if (lv && want32 <= 0 && !wide_ret_build(m, P, *lv, (m->nOut ? m->nOut : m->nIn) + 1)) return false;      // (MB_WIDE_FP32 = 1 asks for the fp32 kernel)
   }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
@@ -1373,8 +1380,8 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
 }
 
 const char *wide_kernel_name(const WideProgram &P) {
+  if (P.retOk) return P.retGv ? (P.viterbi ? "k_wide_retimed<1,L2>" : "k_wide_retimed<0,L2>") : (P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>");
   if (P.f32) return "k_wide_sum32";
-  if (P.retOk) return P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>";
   if (P.viterbi) return P.vitOk ? "k_wide_viterbi" : "k_wide_sweep<1>";
   return "k_wide_sweep<0>";
 }
@@ -1389,6 +1396,26 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   // sweep direction, so that a Forward and a Backward sweep may run side by side on two streams); nothing here waits for
   // the device
   const int scratchSlot = P.backward ? 12 : 11;
+  if (P.retOk) {
+    static bool attr = false;
+    if (!attr) {
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      attr = true;
+    }
+    double *ringScratch = nullptr;
+    if (P.retGv && !(ringScratch = (double *)ws_get(scratchSlot, (size_t)nPairs * (size_t)P.ret.NB * P.ret.NVs * sizeof(double)))) return 1;
+    WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+#define WIDE_RET_GO(M, G) hipLaunchKernelGGL((k_wide_retimed<M, G>), dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike, ringScratch)
+    if (P.viterbi) { if (P.retGv) WIDE_RET_GO(MB_VITERBI, true); else WIDE_RET_GO(MB_VITERBI, false); }
+    else { if (P.retGv) WIDE_RET_GO(MB_FORWARD, true); else WIDE_RET_GO(MB_FORWARD, false); }
+#undef WIDE_RET_GO
+    MB_HIP(hipGetLastError());
+    g_last_launches += 1;
+    return 0;
+  }
   if (P.f32) {
     const bool gv32 = !P.hyb && (P.vecBytes32() > WIDE_LDS_MAX - 64 || env_int_w("MB_WIDE_GLOBAL_VECTORS", 0));
     float *scr = nullptr;
@@ -1399,20 +1426,6 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
                                    : launch_wide32<false, false>(P, d_desc, nPairs, d_out, pool, loglike, scr, st, lastOnly));
     g_last_launches += 1;
     return rc32;
-  }
-  if (P.retOk) {
-    static bool attr = false;
-    if (!attr) {
-      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-      attr = true;
-    }
-    WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
-    if (P.viterbi) hipLaunchKernelGGL(k_wide_retimed<MB_VITERBI>, dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike);
-    else hipLaunchKernelGGL(k_wide_retimed<MB_FORWARD>, dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike);
-    MB_HIP(hipGetLastError());
-    g_last_launches += 1;
-    return 0;
   }
   if (P.viterbi && P.vitOk) {
     static bool attr = false;

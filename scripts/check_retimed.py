@@ -24,6 +24,7 @@ cases = [("tiny generator", EvaluatedMachine.fromMachine(gen, {}), 1, (0, 1, 23,
          ("fn3 profile", EvaluatedMachine.fromMachine(HmmerModel.fromFile("tests/golden/hmmer/fn3.hmm").machine(True), {}), 1, (0, 1, 40, 300)),
          ("3-node composite", profile(3), 1, (0, 1, 41, 150)),
          ("20-node composite", profile(20), 1, (0, 3, 120))]
+if len(sys.argv) > 1 and sys.argv[1] == "whole": cases = [("whole fn3 composite", profile(86), 1, (0, 3, 70))]      # ring in L2
 os.environ["MB_WIDE_MIN_STATES"] = "1"; os.environ["MB_WIDE_VITERBI_MIN_STATES"] = "0"      # the one-tape family for every machine and mode
 bad = 0
 def close(a, b, rel=1e-6, abs_=1e-6):

@@ -311,6 +311,24 @@ def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
 
 
 @pytest.mark.parametrize("case", ["psw2dna", "random40", "random150", "random257", "random300split"])
+def test_tiled_family_placement_serves_every_strip_width(capi):
+    """A 17-state machine whose rolling kernel (narrow strips of a short batch, tiles without a matrix) spills at the first
+    register budget: the re-plan that follows is shared with the matrix kernel of the wider strips, which must still fit the
+    LDS -- it silently ran the ahead-of-time interpreter (scripts/fuzz_gpu.py seed 80033, round 3).  Both calls run the
+    specialised kernel and give the same bits."""
+    from randmachine import random_machine, random_seq
+    rng = np.random.RandomState(80033)
+    S = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 16, 17, 33, 64, 100, 257, 300, 700])); nIn = int(rng.randint(1, 4)); nOut = int(rng.randint(1, 4))
+    em = random_machine(S, nIn, nOut, 80033, density=float(rng.uniform(0.8, 3.0)), silent_density=float(rng.uniform(0.2, 2.0)), allow_inf=False)
+    assert em.nStates == 17
+    n = int(rng.randint(1, 6))
+    pairs = [(random_seq(rng, int(rng.randint(0, 40)), nIn), random_seq(rng, int(rng.randint(0, 60)), nOut)) for _ in range(n)]
+    dm = capi.DeviceMachine(em); b = capi.DeviceBatch.from_pairs(dm, pairs)
+    ll = b.forward(capi.MB_ROLLING); k1 = capi.last_kernel_name()
+    llm = b.forward(capi.MB_MATERIALISE); k2 = capi.last_kernel_name()
+    assert k1 == k2 == "k_medium_jit" and np.array_equal(ll, llm)
+
+
 def test_tiled_family_keeps_no_fp64_matrix(capi, oracle_mod, machines, case):
     """Round 3: on the tiled family, Viterbi keeps ONE traceback byte per cell (MED_MODE_TB: the winning candidate's table and
     index, walked by k_traceback_bytes) and the count sweep keeps NO Forward matrix (tiles that hand their ring state over
@@ -1067,14 +1085,15 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}])
+@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}, {"MB_WIDE_GLOBAL_VECTORS": "1"}])
 def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
     """The retimed sweep of the one-tape family (mb_wide.hip k_wide_retimed: every state on its own column, a period of a
     few wide rounds instead of one round per silent level): Viterbi matrices bit for bit, Forward / Backward matrices and
     rolling log-likelihoods within the fast-path tolerance, paths and counts -- tiny generators and recognisers (period 1),
     the fn3 profile (protein alphabet: 22 penalty columns, 44 columns in flight, relay entries), the 3-node composite of
-    config 5 (period 9); lengths on both sides of the 64-column token window; a longer period than the shortest and
-    256-lane workgroups (several rounds per residue)."""
+    config 5 (period 9); lengths on both sides of the 64-column token window; a longer period than the shortest,
+    256-lane workgroups (several rounds per residue), and the ring in an L2-resident vector instead of the LDS (what
+    machines of tens of thousands of states get)."""
     from machineboss_amd.machine import Machine
     from machineboss_amd.evalmachine import EvaluatedMachine
     from machineboss_amd.hmmer import HmmerModel
@@ -1099,14 +1118,14 @@ def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
         pairs = [(z, q) if tape else (q, z) for q in seqs]
         ref = np.zeros(em.nTransitions)
         for x, y in pairs:
-            V = dm.fill(capi.MB_VITERBI, x, y); assert capi.last_kernel_name() == "k_wide_retimed<1>"
-            F = dm.fill(capi.MB_FORWARD, x, y); assert capi.last_kernel_name() == "k_wide_retimed<0>"
+            V = dm.fill(capi.MB_VITERBI, x, y); assert capi.last_kernel_name() == ("k_wide_retimed<1,L2>" if "MB_WIDE_GLOBAL_VECTORS" in knobs else "k_wide_retimed<1>")
+            F = dm.fill(capi.MB_FORWARD, x, y); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
             B = dm.fill(capi.MB_BACKWARD, x, y)
             assert np.array_equal(V, om.viterbi(x, y))
             assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
             if F[-1, -1, -1] > -math.inf: om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
         b = capi.DeviceBatch.from_pairs(dm, pairs)
-        ll = b.forward(capi.MB_ROLLING); assert capi.last_kernel_name().startswith("k_wide_retimed<0>")
+        ll = b.forward(capi.MB_ROLLING); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
         vll, off, edges = b.viterbi()
         counts, s, _ = b.counts()
         assert close(counts, ref, 1e-5, 1e-7)
@@ -1214,8 +1233,8 @@ def test_one_tape_split_forward(capi, oracle_mod, monkeypatch):
 @pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])
 def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, nodes, nSeq, L):
     """BASELINE config 5 at the sizes that select the one-tape family's DEFAULT paths (no environment forcing): the 20-node
-    machine (5 063 states: fp64 columns in LDS) on 64 x 2 kb and the whole fn3 profile (21 761 states: fp32-relative columns,
-    previous column in L2) on 8 x 300 nt.  Rolling == materialised; the other arithmetic variant agrees to 1e-6; the Viterbi
+    machine (5 063 states: retimed sweep, ring in LDS) on 64 x 2 kb and the whole fn3 profile (21 761 states: retimed sweep,
+    ring in L2) on 8 x 300 nt.  Rolling == materialised; the other arithmetic variant agrees to 1e-6; the Viterbi
     path re-scores to the Viterbi score and spells the sequence; counts keep the symbol-count invariant; one sequence of
     30 nt against the oracle."""
     m, em = _profile_machine(nodes)
@@ -1228,18 +1247,19 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     llr = b.forward(capi.MB_ROLLING)
     kern = capi.last_kernel_name()
-    assert kern.startswith("k_wide_retimed<0>" if nodes == 20 else "k_wide_sum32")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
+    assert kern.startswith("k_wide_retimed<0>" if nodes == 20 else "k_wide_retimed<0,L2>")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
     nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
     bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
     llm = bm.forward(capi.MB_MATERIALISE)
     assert np.all(np.isfinite(llr)) and close(llm, llr[:nm], FAST_REL, FAST_ABS) and llr[0] == llr[1]
     # the other arithmetic (fp32-relative <-> fp64 columns) on a fresh machine object
-    monkeypatch.setenv("MB_WIDE_FP32", "1" if nodes == 20 else "0")             # (fp64 columns of the whole profile do not fit the LDS: they go to L2 by themselves)
+    other = ("MB_WIDE_FP32", "1") if nodes == 20 else ("MB_WIDE_RETIMED", "0")   # (the whole profile without the retimed sweep: fp32-relative columns, the previous one in L2)
+    monkeypatch.setenv(*other)
     dm2 = capi.DeviceMachine(em)
     b2 = capi.DeviceBatch.from_pairs(dm2, [(x, y) for y in ys[:nm]])
     ll2 = b2.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() != kern and close(ll2, llr[:nm], 1e-6)
-    monkeypatch.delenv("MB_WIDE_FP32")
+    assert capi.last_kernel_name().startswith("k_wide_sum32") and close(ll2, llr[:nm], 1e-6)
+    monkeypatch.delenv(other[0])
     # Viterbi: score <= Forward, the path is contiguous, spells the sequence and re-scores to the score
     bv = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:2]])
     vll, off, edges = bv.viterbi()
