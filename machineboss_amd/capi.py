@@ -24,7 +24,7 @@ EXPORTS = [
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
-    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source",
+    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source", "mb_debug_wide_retimed",
     "mb_jit_stats", "mb_machine_sweep_ops", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
@@ -82,6 +82,8 @@ def load():
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_debug_small_source.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                         C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_debug_wide_retimed.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
+                                        C.c_int, C.c_int, C.c_char_p]
     L.mb_log_sum_exp.argtypes = [C.c_double, C.c_double]; L.mb_log_sum_exp.restype = C.c_double
     L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
     L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
@@ -202,6 +204,26 @@ def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, mat
     _check(load().mb_debug_small_source(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
                                         _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
                                         mode, int(backward), int(materialise) | (2 if envelopes else 0), path.encode()))
+
+
+def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = False) -> dict:
+    """The retimed program of a one-tape machine as the kernel reads it (host only, no GPU needed): the header fields and
+    the record streams, one per rotation of the ring, as a structured array [stream][slot][lane] of (w, src, pad)."""
+    a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+         np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+         np.ascontiguousarray(em.logWeight, np.float64)]
+    _check(load().mb_debug_wide_retimed(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                        _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
+                                        mode, int(backward), path.encode()))
+    head = np.fromfile(path, np.int32, 12)
+    assert head[0] == 0x52455431
+    keys = ("lanes", "slots", "NB", "NVs", "kMax", "rowLen", "nPen", "period", "S", "inL2", "streams")
+    out = {k: int(v) for k, v in zip(keys, head[1:])}
+    rec = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), offset=48)
+    assert rec.size == (out["NB"] * out["slots"] + 8) * out["lanes"]
+    out["records"] = rec[:out["NB"] * out["slots"] * out["lanes"]].reshape(out["NB"], out["slots"], out["lanes"])
+    out["tail"] = rec[out["NB"] * out["slots"] * out["lanes"]:].reshape(8, out["lanes"])
+    return out
 
 
 class DeviceMachine:

@@ -1478,6 +1478,32 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   return 0;
 }
 
+// The retimed program of a one-tape machine (mb_wide.hip, k_wide_retimed) as the kernel reads it, written to `path`: 12 int32
+// (magic 0x52455431, lanes, slots per period, ring depth NB, doubles per ring vector, largest lag, penalty row length, penalty
+// entries, period, states, 1 = ring in L2, streams) followed by (NB * slots + 8) * lanes records of 16 bytes.  Host only: the
+// planner can be checked without a device (tests/test_retimed_plan.py simulates the stream and compares with the oracle).
+int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                          const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, const char *path) {
+  if (nStates <= 0 || nTrans < 0 || !path || (nInTok != 0) == (nOutTok != 0)) { set_error("mb_debug_wide_retimed: bad argument (one-tape machines only)"); return 1; }
+  mb_machine m;
+  m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
+  m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);
+  m.inTok.assign(inTok, inTok + nTrans); m.outTok.assign(outTok, outTok + nTrans);
+  m.logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  WideProgram P;
+  std::vector<WideRec> stream;
+  if (!wide_ret_host(&m, backward != 0, mode == MB_VITERBI, P, stream)) { set_error("machine has no retimed program"); return 1; }
+  FILE *f = fopen(path, "wb");
+  if (!f) { set_error("mb_debug_wide_retimed: cannot open output file"); return 1; }
+  const int32_t head[12] = {0x52455431, P.W, P.ret.nSlots, P.ret.NB, P.ret.NVs, P.ret.kMax, P.ret.rowLen, P.ret.nPen, P.retPeriod, nStates, P.retGv ? 1 : 0, P.ret.NB};
+  const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(stream.data(), sizeof(WideRec), stream.size(), f) == stream.size();
+  fclose(f);
+  if (!ok) { set_error("mb_debug_wide_retimed: short write"); return 1; }
+  return 0;
+}
+
 // generated source of the small-machine family's sweep (mode: 0 sum, 1 max, 2 traceback bytes, 3 counts); host only
 int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
                           const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward,

@@ -154,6 +154,8 @@ bool wide_applicable(const mb_machine *m);
 // (re)build the program of one direction/semiring from the machine's current weights and upload it
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P);
 void wide_free(WideProgram &P);
+// the retimed program of a machine, planned and linearised on the host only (no device): P.ret / P.retGv / P.retPeriod + the record stream
+bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
         const double vNow = vAhead, pNow = pAhead;
         vAhead = ring(nx.src);
         pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
-        const double cand = (vNow + rc.w) + pNow;              // + 0.0 or -inf
+        const double cand = vNow + (rc.w + pNow);              // w + 0.0 = w, w + -inf = -inf: the reference's one rounded add, or -inf
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
         else wide_fold<MODE>(m, s, cand, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
@@ -403,8 +403,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
           s = 0.0f;
           if (flags & 0x40000000u) {
             __syncthreads();
-            vAhead = ring(nx.src);
-            pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
+            vAhead = ring(nx.src);                             // (the penalties of a period were written a period ahead: what was fetched stands)
           }
         }
       }
@@ -1052,7 +1051,8 @@ bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int
 }
 }  // namespace
 
-static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok) {
+// hostOut: keep the record stream on the host instead of uploading it (mb_debug_wide_retimed: the planner without a device)
+static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr) {
   P.retOk = false;
   const int S = m->S, W = P.W;
   const int want = env_int_w("MB_WIDE_RETIMED", 1);
@@ -1208,7 +1208,8 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       for (int l = 0; l < W; ++l) { const uint32_t dw = T.dsts[R.dstBase + l]; if ((dw & WIDE_RET_NO_DST) != WIDE_RET_NO_DST) hist[(dw >> 26) & 7u]++; }
       fprintf(stderr, "[mbhip]   round: %d lanes, depth %d, sync %d, nodes by group size 1/2/4/8/16/32/64: %d %d %d %d %d %d %d\n", R.pad0, R.depth, R.sync, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
     }
-  if (!up_w(P.d_ret, st)) return false;
+  if (hostOut) hostOut->swap(st);
+  else if (!up_w(P.d_ret, st)) return false;
   P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
   P.retGv = best.gv;
@@ -1220,6 +1221,16 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
             P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
             100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.NVs, best.nRelay, best.gv ? " in L2" : "", P.retLdsBytes);
   return true;
+}
+
+bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream) {
+  P = WideProgram();
+  P.backward = backward; P.viterbi = viterbi;
+  P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);
+  std::vector<WNode> nodes;
+  int nExtra = 0, nStages = 0; long long nPairs = 0;
+  if (!wide_nodes(m, backward, 0, P.W, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
+  return wide_ret_build(m, P, nodes, (m->nOut ? m->nOut : m->nIn) + 1, &stream) && P.retOk;
 }
 
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {

@@ -310,7 +310,6 @@ def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
     assert close(counts, ref_c, 1e-5, 1e-7) and close(s, ref_s, FAST_REL, FAST_ABS)
 
 
-@pytest.mark.parametrize("case", ["psw2dna", "random40", "random150", "random257", "random300split"])
 def test_tiled_family_placement_serves_every_strip_width(capi):
     """A 17-state machine whose rolling kernel (narrow strips of a short batch, tiles without a matrix) spills at the first
     register budget: the re-plan that follows is shared with the matrix kernel of the wider strips, which must still fit the
@@ -329,6 +328,7 @@ def test_tiled_family_placement_serves_every_strip_width(capi):
     assert k1 == k2 == "k_medium_jit" and np.array_equal(ll, llm)
 
 
+@pytest.mark.parametrize("case", ["psw2dna", "random40", "random150", "random257", "random300split"])
 def test_tiled_family_keeps_no_fp64_matrix(capi, oracle_mod, machines, case):
     """Round 3: on the tiled family, Viterbi keeps ONE traceback byte per cell (MED_MODE_TB: the winning candidate's table and
     index, walked by k_traceback_bytes) and the count sweep keeps NO Forward matrix (tiles that hand their ring state over

@@ -1,0 +1,141 @@
+"""The retimed sweep of the one-tape family (machineboss_amd/csrc/mb_wide.hip: wide_ret_build -> k_wide_retimed), checked
+WITHOUT a device: `mb_debug_wide_retimed` hands back the record streams exactly as the kernel reads them, `simulate`
+below restates what the kernel does with them -- a period of slots, every lane folding `(ring[src] + w) + penalty`, lane
+groups reduced at a round's end, the node stored into the ring vector of its own column -- and the cells it produces are
+compared with the oracle (src/viterbi.cpp:18-43 for max: bit for bit; src/forward.defs.h:23-49 for sum).  What this pins: the
+time offsets (a value is never read before it is written nor after its ring vector was reused), the relay entries, the
+penalty table (tokens, the seed), the rotation streams and the end-of-round words.  The arithmetic of the kernel itself is
+covered on the GPU (tests/test_gpu_parity.py::test_one_tape_retimed_sweep)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from randmachine import random_machine
+
+NO_DST = 0x3ffff
+
+
+def simulate(prog, seq, backward, mode_max):
+    """cells[column][state] of one sequence from the record streams (the kernel's data flow, slot by slot)."""
+    W, NB, NVs, kMax, rowLen, S, inL2 = (prog[k] for k in ("lanes", "NB", "NVs", "kMax", "rowLen", "S", "inL2"))
+    L = len(seq)
+    V = np.full(NB * NVs, -np.inf)
+    for b in range(NB):
+        V[b * NVs + S + 1] = 0.0
+    cells = np.full((L + 1, S), np.nan)
+    tok_at = lambda c: (int(seq[L - c]) if backward else int(seq[c - 1])) if 1 <= c <= L else 0
+    lanes = np.arange(W)
+    for t in range(L + 1 + kMax):
+        cm = t % NB
+        pen = np.full((kMax + 1, rowLen), -np.inf)
+        for kt in range(kMax + 1):
+            c = t - kt
+            pen[kt, 0] = 0.0
+            if c == 0: pen[kt, rowLen - 1] = 0.0
+            if c >= 1 and 0 < tok_at(c) < rowLen - 1: pen[kt, tok_at(c)] = 0.0
+        pen = pen.reshape(-1)
+        m = np.full(W, -np.inf); ssum = np.zeros(W)
+        for rec in prog["records"][cm]:
+            src = rec["src"].astype(np.int64)
+            entry = (src >> 13) if inL2 else ((src >> 14) >> 3)
+            assert inL2 or np.all(((src >> 14) & 7) == 0)
+            cand = (V[entry] + rec["w"]) + pen[src & 0x1fff]
+            if mode_max: m = np.maximum(m, cand)
+            else:      # max and sum of exp relative to it, as the kernel keeps them (in fp64 here)
+                new = np.maximum(m, cand)
+                with np.errstate(invalid="ignore"):
+                    ssum = np.where(np.isneginf(new), 0.0, ssum * np.exp(np.where(np.isneginf(m), -np.inf, m - new)) + np.exp(np.where(np.isneginf(cand), -np.inf, cand - new)))
+                m = new
+            flags = int(rec["pad"][0])
+            if not flags & 0x80000000: assert not np.any(rec["pad"]); continue
+            pad = rec["pad"].astype(np.int64)
+            assert np.all(pad & 0x80000000) and np.all(((pad >> 30) & 1) == ((flags >> 30) & 1))
+            log2g = (pad >> 26) & 7
+            heads = lanes[(pad & NO_DST) != NO_DST]
+            # a wavefront's first lane tells whether its groups have different sizes (masked reduction in the kernel)
+            for w0 in range(0, W, 64):
+                hw = heads[(heads >= w0) & (heads < w0 + 64)]
+                mixed = bool(hw.size) and bool(np.any(log2g[hw] != log2g[w0]))
+                assert mixed == bool((int(pad[w0]) >> 29) & 1)
+            for l in heads:
+                g = 1 << int(log2g[l])
+                assert l % g == 0 and np.all(log2g[l:l + g] == log2g[l])
+                if mode_max: res = float(np.max(m[l:l + g]))
+                else:
+                    mx = float(np.max(m[l:l + g]))
+                    res = -math.inf if mx == -math.inf else mx + math.log(float(np.sum(ssum[l:l + g] * np.exp(np.where(np.isneginf(m[l:l + g]), -np.inf, m[l:l + g] - mx)))))
+                x, kq, vec = int(pad[l] & NO_DST), int((pad[l] >> 20) & 63), int((pad[l] >> 18) & 3)
+                c = t - kq if backward else t - kMax + kq
+                if 0 <= c <= L:
+                    assert vec == c % NB                          # the node's own column's vector
+                    V[vec * NVs + x] = res
+                    if x < S:
+                        assert np.isnan(cells[L - c if backward else c, x])      # every cell exactly once
+                        cells[L - c if backward else c, x] = res
+            m[:] = -np.inf; ssum[:] = 0.0
+    assert not np.any(np.isnan(cells))
+    return cells
+
+
+def _machines():
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd import algebra as A
+    gen = Machine.fromJson({"state": [
+        {"id": "S", "trans": [{"to": "A"}, {"to": "B", "weight": 0.25}]},
+        {"id": "A", "trans": [{"to": "A", "out": "x", "weight": 0.5}, {"to": "B", "out": "y", "weight": 0.3}, {"to": "E", "weight": 0.2}]},
+        {"id": "B", "trans": [{"to": "A", "out": "y", "weight": 0.6}, {"to": "B", "out": "x", "weight": 0.1}, {"to": "E", "weight": 0.3}]},
+        {"id": "E"}]})
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm"))
+    comp = A.composeLeftToRight([h.truncated(2).machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
+    return {"tiny": EvaluatedMachine.fromMachine(gen, {}),
+            "fn3-10": EvaluatedMachine.fromMachine(h.truncated(10).machine(True), {}),
+            "composite-2": EvaluatedMachine.fromMachine(comp, None, useDefaults=True),
+            "random-40": random_machine(40, 0, 3, 7, density=2.0, silent_density=1.5, allow_inf=True),
+            "random-recogniser-25": random_machine(25, 2, 0, 11, density=1.5, silent_density=1.0, allow_inf=False)}
+
+
+@pytest.mark.parametrize("name", ["tiny", "fn3-10", "composite-2", "random-40", "random-recogniser-25"])
+@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_WIDE_RETIMED_PERIOD": "+2", "MB_WIDE_LANES": "256"}])
+def test_retimed_program_reproduces_the_oracle(name, knobs, monkeypatch, tmp_path):
+    from machineboss_amd import capi
+    from oracle import oracle
+    em = _machines()[name]
+    tape_out = em.nOutTok > 0
+    nt = em.nOutTok if tape_out else em.nInTok
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    for k, v in knobs.items():
+        if not v.startswith("+"): monkeypatch.setenv(k, v)
+    base = capi.debug_wide_retimed(em, str(tmp_path / "base.bin"), capi.MB_VITERBI, False)
+    if "MB_WIDE_RETIMED_PERIOD" in knobs: monkeypatch.setenv("MB_WIDE_RETIMED_PERIOD", str(base["period"] + int(knobs["MB_WIDE_RETIMED_PERIOD"])))
+    for mode, backward in ((capi.MB_VITERBI, False), (capi.MB_FORWARD, False), (capi.MB_FORWARD, True)):
+        prog = capi.debug_wide_retimed(em, str(tmp_path / "p.bin"), mode, backward)
+        assert prog["S"] == em.nStates and prog["inL2"] == (1 if "MB_WIDE_GLOBAL_VECTORS" in knobs else 0)
+        assert prog["lanes"] == (256 if knobs.get("MB_WIDE_LANES") == "256" or em.nStates < 192 else 1024)
+        # a stream runs on into the next rotation's (the kernel's prefetch ring reads 8 slots past a period)
+        assert np.array_equal(prog["tail"], prog["records"][0][:8])
+        for n in (0, 1, 9, 70 if prog["lanes"] * prog["slots"] <= 4096 else 20):      # 70: beyond the 64-column token window
+            seq = np.random.RandomState(n + 3).randint(1, nt + 1, size=n).astype(np.int32)
+            x, y = (z, seq) if tape_out else (seq, z)
+            got = simulate(prog, seq, backward, mode == capi.MB_VITERBI)
+            if mode == capi.MB_VITERBI: ref = om.viterbi(x, y)
+            else: ref = om.backward(x, y, oracle.SUM_EXACT) if backward else om.forward(x, y, oracle.SUM_EXACT)
+            ref = ref.reshape(n + 1, em.nStates)
+            if mode == capi.MB_VITERBI: assert np.array_equal(got, ref)
+            else:
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+
+
+def test_retimed_program_refuses_two_tape_machines(tmp_path):
+    from machineboss_amd import capi
+    em = random_machine(12, 2, 2, 5, density=1.5, silent_density=1.0, allow_inf=False)
+    with pytest.raises(RuntimeError):
+        capi.debug_wide_retimed(em, str(tmp_path / "never.bin"))
