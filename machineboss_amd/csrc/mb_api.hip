@@ -303,6 +303,7 @@ struct FastState {
   // large one-tape machines (mb_wide.hip): programs built on first use, rebuilt after a weight update
   WideProgram wFwd, wBwd, wVit;
   WideCountPlan wCnt;        // posterior counts of one-tape machines (any size): lane = transition
+  WideTbPlan wTb;            // Viterbi traceback of one-tape machines too large for the LDS edge tables of mb_generic.hip
   // machines with a handful of states (mb_small.cpp): lane = column, states in registers
   bool smallTried = false, smallOk = false;
   SmallProgram smF, smB;
@@ -880,7 +881,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt); medium_free(f->fwdTb);
-    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_counts_free(f->wCnt);
+    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_counts_free(f->wCnt); wide_traceback_free(f->wTb);
     small_free(f->smF); small_free(f->smB);
     delete f;
   }
@@ -1209,7 +1210,17 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
         if (!(d_path = (uint32_t *)ws_get(5, std::max<long long>(slot[np], 1) * sizeof(uint32_t)))) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
         if (tb) { if ((rc = launch_traceback_bytes(b->m, d_desc, np, b->d_in, b->d_out, (const unsigned char *)pool, Sb, d_ll, d_slot, d_path, d_len, g_stream))) break; }
-        else if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
+        else {
+          // one-tape machines beyond the LDS edge tables of the generic walkers: columns in LDS, one trip to memory per step
+          WideTbPlan *T = nullptr;
+          if (wide_applicable(b->m) && g_kernel_choice != 1 && b->m->nTrans > env_int("MB_ONETAPE_TRACEBACK_MIN_TRANS", 3584) && !b->hasEnv) {
+            FastState *f = fast_state(b->m);
+            if (!f->wTb.tried) (void)wide_traceback_build(b->m, f->wTb);
+            if (f->wTb.ok) T = &f->wTb;
+          }
+          if (T) { if ((rc = wide_traceback(b->m, *T, d_desc, np, b->m->nOut ? b->d_out : b->d_in, pool, d_slot, d_path, d_len, g_stream))) break; }
+          else if ((rc = launch_traceback(b->m, d_desc, np, b->d_in, b->d_out, pool, d_slot, d_path, d_len, g_stream))) break;
+        }
       }
       lap("launches (host side)");
       g_last_ms += tm.stop();

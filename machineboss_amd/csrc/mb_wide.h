@@ -179,4 +179,12 @@ void wide_counts_free(WideCountPlan &C);
 int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_tape,
                 const double *fwd, const double *bwd, double *d_counts, hipStream_t st);
 
+// Viterbi traceback of a one-tape machine (src/dpmatrix.defs.h:82-110 on a lattice of one column per symbol): one workgroup
+// per sequence, the walk by its first wavefront, the two columns a step can read in LDS (the others prefetch the next one)
+struct WideTbPlan { bool tried = false, ok = false; void *d_edges = nullptr; int *d_begin = nullptr; size_t ldsBytes = 0; };
+bool wide_traceback_build(const mb_machine *m, WideTbPlan &T);      // false: the machine does not fit (the generic walker takes it)
+void wide_traceback_free(WideTbPlan &T);
+int wide_traceback(const mb_machine *m, const WideTbPlan &T, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *d_pool,
+                   const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen, hipStream_t st);
+
 }  // namespace mb

@@ -1731,4 +1731,185 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
   return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Viterbi traceback of a one-tape machine
+// ------------------------------------------------------------------------------------------------------------
+// The generic walker (mb_generic.hip k_traceback) pays four to five dependent trips to memory per path step (CSR row offsets ->
+// edges -> cells -> edge id -> labels): 1.6 us a step, 6.4 ms for the 4 000 steps of a 2 kb sequence on the 20-node machine --
+// 60 % on top of the retimed fill.  Here one workgroup owns a sequence: the column of the position and the one before it --
+// every cell a step can read -- sit in LDS together with one offset per state, fifteen wavefronts fetch the columns ahead
+// while the first one walks, and a state's incoming edges (contiguous in the `incoming` view; id, source and label packed
+// in 8 bytes, weight beside them) come in ONE coalesced trip that hits the L2; the maximum is a butterfly over the values
+// alone and the winner the first lane that holds it.  Candidate order and tie-break are the reference's
+// (src/dpmatrix.defs.h:82-110): the emitting group before the silent one, position inside the group, first maximum wins.
+// The walk itself is ~0.3 us a step now; what is left is the re-read of the whole matrix, column by column (8 B per cell at
+// what 64 CUs keep in flight: 1.4 TB/s): 3.7 ms instead of 6.4 -- fill + paths 17.3 -> 14.5 ms at 64 x 2 kb.  One traceback
+// code per cell written by the fill would remove that read.
+struct OtTbEdge { uint32_t eid; uint16_t src; uint16_t key; };      // key: the token the transition emits (0: silent)
+
+__global__ __launch_bounds__(1024) void k_onetape_traceback(DevMachine m, const OtTbEdge *__restrict__ edges, const int *__restrict__ begin,
+                                                           const PairDesc *__restrict__ pairs, const int *__restrict__ tape,
+                                                           const double *__restrict__ pool, const long long *__restrict__ slotOff,
+                                                           uint32_t *__restrict__ pathBuf, long long *__restrict__ pathLen) {
+  extern __shared__ double tlds[];
+  const int S = m.S, tid = threadIdx.x, lane = tid & 63;
+  double *col = tlds;                                    // [3][S]: column c in buffer c % 3
+  int *sBeg = (int *)(tlds + 3 * (size_t)S);             // [S + 1]
+  int &done = sBeg[S + 1];                               // 1: the walk reached the start, 2: it failed (pathLen says how)
+  const long long p = blockIdx.x;
+  const PairDesc pd = pairs[p];
+  const bool inputTape = m.nOut == 0;
+  const int L = inputTape ? pd.inLen : pd.outLen;
+  const int *tok = tape + (inputTape ? pd.inBase : pd.outBase);
+  const double *cells = pool + pd.cellBase;              // column c at cells + c * S (the other tape is empty)
+  const long long slot0 = slotOff[p], cap = slotOff[p + 1] - slot0;
+  for (int k = tid; k <= S; k += 1024) sBeg[k] = begin[k];
+  for (int k = tid; k < S; k += 1024) {
+    col[(L % 3) * S + k] = cells[(long long)L * S + k];
+    if (L >= 1) col[((L - 1) % 3) * S + k] = cells[(long long)(L - 1) * S + k];
+  }
+  if (tid == 0) done = 0;
+  __syncthreads();
+  if (tid == 0 && !(col[(L % 3) * S + S - 1] > -INFINITY)) { pathLen[p] = -1; done = 2; }
+  __syncthreads();
+  int s = S - 1;
+  long long n = 0;
+  uint32_t held = 0;
+  typedef volatile __attribute__((address_space(3))) int lds_flag;      // (a read through a generic pointer would be a FLAT load)
+  lds_flag *doneFlag = (lds_flag *)(uintptr_t)(unsigned)(uintptr_t)&done;
+  // A column fresh from the fill comes from HBM, and 40 KB per column and workgroup is bound by what a CU keeps in flight
+  // (one batch of loads per round trip: 1.4 us, twice the walker's two steps): the loaders therefore run TWO columns ahead -- the
+  // loads of column o - 3 are issued before the barrier of iteration o and stay in flight across it (the barrier below waits
+  // for LDS traffic only), their values go to LDS one iteration later.
+  typedef double pair_t __attribute__((ext_vector_type(2)));
+  typedef pair_t pair_u __attribute__((aligned(8)));                     // 16-byte loads at 8-byte alignment (S may be odd)
+  struct Pair { double a, b; };
+  Pair r[4];
+  auto fetch = [&](int c) {
+    const double *src = cells + (long long)c * S;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 2 * (tid - 64) + j * 1920;
+      if (c >= 0 && k + 1 < S) { const pair_t v = __builtin_nontemporal_load((const pair_u *)(src + k)); r[j] = Pair{v.x, v.y}; }
+      else r[j] = Pair{(c >= 0 && k < S) ? __builtin_nontemporal_load(src + k) : 0.0, 0.0};
+    }
+  };
+  if (tid >= 64) fetch(L - 2);
+  for (int o = L; !*doneFlag; --o) {
+    if (tid >= 64) {
+      // the column two back, for the steps after the next emission
+      if (o >= 2) {
+        double *dst = col + ((o - 2) % 3) * S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = 2 * (tid - 64) + j * 1920; if (k < S) dst[k] = r[j].a; if (k + 1 < S) dst[k + 1] = r[j].b; }
+      }
+      fetch(o - 3);
+    } else {
+      const double *cur = col + (o % 3) * S, *prev = col + ((o + 2) % 3) * S;      // (o - 1) % 3
+      const int ot = o ? tok[o - 1] : 0;
+      for (;;) {
+        if (o == 0 && s == 0) { if (lane == 0) done = 1; break; }
+        int bestA = -1;
+        uint32_t bestEid = 0, bestSk = 0;                  // the winning edge travels with the maximum: no second trip for it
+        const int b0 = sBeg[s], b1 = sBeg[s + 1];
+        if (b1 - b0 <= 64) {
+          // the usual case, one candidate per lane: maximum by a butterfly over the values alone, then the first lane that
+          // holds it -- emitting group before silent; inside a group the edge list, hence the lanes, are in the reference's order
+          const int a = b0 + lane;
+          const bool valid = a < b1;
+          OtTbEdge e{0u, 0, 0};
+          double w = 0.0;
+          if (valid) { e = edges[a]; w = m.inW[a]; }
+          const int key = (int)e.key;
+          const bool emits = valid && o && key != 0 && key == ot, has = emits || (valid && key == 0);
+          // (a silent self-loop on state 0 is a genuine candidate of the reference's traceback: kept, as in k_traceback)
+          const double v = has ? (emits ? prev : cur)[e.src] + w : -INFINITY;
+          double mx = v;
+          wide_max_all<MB_VITERBI, 1>(mx); wide_max_all<MB_VITERBI, 2>(mx); wide_max_all<MB_VITERBI, 4>(mx);
+          wide_max_all<MB_VITERBI, 8>(mx); wide_max_all<MB_VITERBI, 16>(mx); wide_max_all<MB_VITERBI, 32>(mx);
+          const unsigned long long eqE = __ballot(emits && v == mx), eqS = __ballot(has && !emits && v == mx);
+          if (eqE | eqS) {
+            const int win = eqE ? __ffsll((long long)eqE) - 1 : __ffsll((long long)eqS) - 1;
+            bestA = b0 + win;
+            bestEid = (uint32_t)__builtin_amdgcn_readlane((int)e.eid, win);
+            bestSk = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)e.src | ((uint32_t)e.key << 16)), win);
+          }
+        } else {
+          double best = -INFINITY; int bestIdx = 0x7fffffff;
+          for (int a = b0 + lane; a < b1; a += 64) {
+            const OtTbEdge e = edges[a];
+            const int key = (int)e.key;
+            int grp; const double *sc;
+            if (key == 0) { grp = 1; sc = cur; }
+            else if (o && key == ot) { grp = 0; sc = prev; }
+            else continue;
+            const double v = sc[e.src] + m.inW[a];
+            const int idx = (grp << 24) | (a - b0);
+            if (bestA < 0 || v > best || (v == best && idx < bestIdx)) { best = v; bestIdx = idx; bestA = a; bestEid = e.eid; bestSk = (uint32_t)e.src | ((uint32_t)e.key << 16); }
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bestIdx, off), oa = __shfl_xor(bestA, off);
+            const uint32_t oe = (uint32_t)__shfl_xor((int)bestEid, off), ok = (uint32_t)__shfl_xor((int)bestSk, off);
+            const bool take = oa >= 0 && (bestA < 0 || ov > best || (ov == best && oi < bestIdx));
+            if (take) { best = ov; bestIdx = oi; bestA = oa; bestEid = oe; bestSk = ok; }
+          }
+        }
+        if (bestA < 0) { if (lane == 0) { pathLen[p] = -3; done = 2; } break; }
+        if (n >= cap) { if (lane == 0) { pathLen[p] = -2; done = 2; } break; }
+        const OtTbEdge be{bestEid, (uint16_t)(bestSk & 0xffffu), (uint16_t)(bestSk >> 16)};
+        if ((int)(n & 63) == lane) held = be.eid;      // one store per 64 steps (mb_generic.hip k_traceback)
+        ++n;
+        if ((n & 63) == 0) pathBuf[slot0 + cap - 1 - (n - 64 + lane)] = held;
+        s = (int)be.src;
+        if (be.key) break;                              // an emission: the position moves one column back
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS traffic only: the loaders' next column stays in flight
+  }
+  if (tid < 64 && done == 1) {
+    if ((n & ~63ll) + lane < n) pathBuf[slot0 + cap - 1 - ((n & ~63ll) + lane)] = held;
+    if (lane == 0) pathLen[p] = n;
+  }
+}
+
+bool wide_traceback_build(const mb_machine *m, WideTbPlan &T) {
+  T.tried = true; T.ok = false;
+  if ((m->nIn != 0) == (m->nOut != 0) || !env_int_w("MB_ONETAPE_TRACEBACK", 1)) return false;
+  const int S = m->S, K = (m->nIn + 1) * (m->nOut + 1);
+  T.ldsBytes = 3 * (size_t)S * sizeof(double) + (size_t)(S + 2) * sizeof(int);
+  if (T.ldsBytes > WIDE_LDS_MAX - 64 || S > 65535 || K > 65535) return false;
+  const bool inputTape = m->nOut == 0;
+  std::vector<OtTbEdge> edges((size_t)m->nTrans);
+  for (long long a = 0; a < m->nTrans; ++a) {
+    const uint32_t e = m->inPerm[a];
+    edges[a] = OtTbEdge{e, (uint16_t)m->src[e], (uint16_t)(inputTape ? m->inTok[e] : m->outTok[e])};
+  }
+  std::vector<int> begin((size_t)S + 1);
+  for (int st = 0; st <= S; ++st) begin[st] = m->inOff[(size_t)st * K];
+  if (!hip_ok(hipMalloc(&T.d_edges, std::max<size_t>(edges.size(), 1) * sizeof(OtTbEdge)), "hipMalloc(traceback edges)") ||
+      !hip_ok(hipMalloc((void **)&T.d_begin, begin.size() * sizeof(int)), "hipMalloc(traceback offsets)")) return false;
+  if ((!edges.empty() && !hip_ok(hipMemcpy(T.d_edges, edges.data(), edges.size() * sizeof(OtTbEdge), hipMemcpyHostToDevice), "H2D(traceback edges)")) ||
+      !hip_ok(hipMemcpy(T.d_begin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice), "H2D(traceback offsets)")) return false;
+  T.ok = true;
+  return true;
+}
+
+void wide_traceback_free(WideTbPlan &T) {
+  if (T.d_edges) (void)hipFree(T.d_edges);
+  if (T.d_begin) (void)hipFree(T.d_begin);
+  T = WideTbPlan();
+}
+
+int wide_traceback(const mb_machine *m, const WideTbPlan &T, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *d_pool,
+                   const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen, hipStream_t st) {
+  if (nPairs <= 0) return 0;
+  static bool attr = false;
+  if (!attr) { MB_HIP(hipFuncSetAttribute((const void *)k_onetape_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX)); attr = true; }
+  hipLaunchKernelGGL(k_onetape_traceback, dim3((unsigned)nPairs), dim3(1024), T.ldsBytes, st, m->dev, (const OtTbEdge *)T.d_edges, T.d_begin, d_pairs, d_tape,
+                     d_pool, d_slotOff, d_pathBuf, d_pathLen);
+  MB_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace mb

@@ -1098,6 +1098,7 @@ def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
     from machineboss_amd.evalmachine import EvaluatedMachine
     from machineboss_amd.hmmer import HmmerModel
     monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
+    monkeypatch.setenv("MB_ONETAPE_TRACEBACK_MIN_TRANS", "0")      # ... and the one-tape traceback walker (k_onetape_traceback) on every machine
     for k, v in knobs.items():
         if k != "MB_WIDE_RETIMED_PERIOD": monkeypatch.setenv(k, v)
     gen = Machine.fromJson({"state": [
