@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_wide_sweep(WideDev P1, const PairDesc 
           const int gWave = 1 << ((flags >> 26) & 7);
           if (gWave > 1) wide_group_reduce<MODE>(m, s, g, gWave);
           if ((dst & W_IDX_MASK) != W_NO_DST) {
-            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
+            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             V[((dst >> 29) & 1 ? extraOff : curOff) + (int)(dst & W_IDX_MASK)] = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
           const uint32_t x = dst & WIDE_RET_NO_DST, kq = (dst >> 20) & 63u;      // entry within its vector: the state (relays: >= S + 2)
           const int c = cBase + cSign * (int)kq;
           if (x != WIDE_RET_NO_DST && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
-            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)(__log2f(s) * 0.6931471805599453f) : -INFINITY);
+            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
             if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
