@@ -143,7 +143,8 @@ struct WideProgram {
   WideRec *d_ret = nullptr;
   WideRetDev ret{};
   size_t retLdsBytes = 0;
-  int retPeriod = 0, retTauMax = 0;
+  int retPeriod = 0, retTauMax = 0, retPeriodMin = 0;
+  bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };

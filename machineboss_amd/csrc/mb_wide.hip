@@ -1052,7 +1052,8 @@ bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int
 }  // namespace
 
 // hostOut: keep the record stream on the host instead of uploading it (mb_debug_wide_retimed: the planner without a device)
-static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr) {
+static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr,
+                           int keepPeriod = 0) {
   P.retOk = false;
   const int S = m->S, W = P.W;
   const int want = env_int_w("MB_WIDE_RETIMED", 1);
@@ -1088,11 +1089,14 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   std::vector<int> tau;
   const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
   auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau, work); };
-  const int forced = env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
+  // (a weight refresh keeps the period that was chosen: the schedule depends on the machine's structure, not on its weights)
+  const int forced = keepPeriod > 0 ? keepPeriod : env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
   int lo = 1, hi = 64;
-  if (!feasible(hi)) return true;
-  while (lo < hi) { const int mid = (lo + hi) / 2; if (feasible(mid)) hi = mid; else lo = mid + 1; }
-  const int pMin = lo;
+  if (keepPeriod <= 0) {
+    if (!feasible(hi)) return true;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (feasible(mid)) hi = mid; else lo = mid + 1; }
+  }
+  const int pMin = keepPeriod > 0 ? P.retPeriodMin : lo;
   // shape for one period length: ring depth, relays, nodes by residue; cost from the round planner
   struct Shape { int period = 0, NB = 0, NVs = 0, nRelay = 0, kMax = 0, tauMax = 0; bool gv = false; double cost = 1e300; std::vector<WNode> nd; };
   const bool forceGv = env_int_w("MB_WIDE_GLOBAL_VECTORS", 0) != 0, allowGv = env_int_w("MB_WIDE_RETIMED_L2", 1) != 0;
@@ -1214,7 +1218,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
   P.retGv = best.gv;
   P.retLdsBytes = ((best.gv ? 0 : (size_t)best.NB * best.NVs) + 2 * (size_t)P.ret.nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
-  P.retPeriod = best.period; P.retTauMax = best.tauMax;
+  P.retPeriod = best.period; P.retTauMax = best.tauMax; P.retPeriodMin = pMin;
+  P.slotsPerColumn = padded; P.candsPerColumn = T.candsPerColumn; P.nSync = T.nSync;
+  P.rounds = T.rounds;                                  // (planning tables: mb_machine_sweep_ops counts them)
   P.retOk = true;
   if (verbose)
     fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
@@ -1234,8 +1240,8 @@ bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram
 }
 
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {
-  const bool haveShape = P.ok;                     // a weight refresh keeps the shape that was chosen
-  const int keepStages = P.stages;
+  const bool haveShape = P.ok && P.shapeChosen;    // a weight refresh keeps the shape that was chosen
+  const int keepStages = P.stages, keepPeriod = (P.ok && P.retOk) ? P.retPeriod : 0, keepPeriodMin = P.retPeriodMin;
   wide_free(P);
   P.backward = backward; P.viterbi = viterbi;
   P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);      // 509 states: 48 G cells/s with 1024 lanes, 35 with 256
@@ -1243,6 +1249,24 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   long long nSilent = 0;
   for (long long e = 0; e < m->nTrans; ++e) nSilent += (m->inTok[e] == 0 && m->outTok[e] == 0);
   const long long pairCap = std::max<long long>(64 * (nSilent + S), 1 << 16);
+  const int want32 = env_int_w("MB_WIDE_FP32", -1);
+  // The retimed sweep first (from the LEVELLED nodes): a machine that has one needs no column-by-column program, and a
+  // weight refresh -- every EM iteration -- then costs one relaxation, one plan and one upload (20-node machine, two programs: 59 -> 5.6 ms on top of a 21 ms E-step; the first build 544 -> 51 ms).
+  if (env_int_w("MB_WIDE_RETIMED", 1) && want32 <= 0) {      // (MB_WIDE_FP32 = 1 asks for the fp32 kernel)
+    std::vector<WNode> levelled;
+    int xe = 0, xs = 0; long long xp = 0;
+    if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) {
+      P.retPeriodMin = keepPeriodMin;
+      if (!wide_ret_build(m, P, levelled, (m->nOut ? m->nOut : m->nIn) + 1, nullptr, keepPeriod)) return false;
+      if (P.retOk) {
+        P.NV = S + 2; P.NX = 1; P.stages = 0;
+        P.dev.S = S; P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
+        P.dev.resultIdx = backward ? 0 : S - 1; P.dev.backward = backward ? 1 : 0; P.dev.inputTape = m->nOut ? 0 : 1;
+        P.ok = true; P.dirty = false;
+        return true;
+      }
+    }
+  }
   std::vector<WNode> nodes, bestNodes;
   int nExtra = 0, nStages = 0, bestExtra = 0, bestStages = 0, bestK = 0;
   long long nPairs = 0, bestPairs = 0;
@@ -1293,7 +1317,6 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   // single precision relative to the column reference where it buys something: when two fp64 columns do not fit the LDS of
   // a CU (fp64 arithmetic is full rate on this chip: with both in LDS the fp64 kernel is the faster one, 39.9 vs 45.4 ms
   // on the 20-node profile machine).  MB_WIDE_FP32 = 1 / 0 forces it on / off.
-  const int want32 = env_int_w("MB_WIDE_FP32", -1);
   if (!viterbi && (want32 > 0 || (want32 < 0 && (size_t)(2 * P.NV + P.NX) * sizeof(double) > WIDE_LDS_MAX))) {
     std::vector<WideRec32> a32, b32;
     std::vector<unsigned long long> fw;
@@ -1318,15 +1341,6 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
     nRecs = P.segA.size() + P.segB.size();
     if (viterbi && !wide_vit_build(P, (m->nOut ? m->nOut : m->nIn) + 1)) return false;
   }
-  {
-    // the retimed program is built from the LEVELLED nodes, whatever closure shape / arithmetic the column-by-column kernel chose
-    std::vector<WNode> levelled;
-    int xe = 0, xs = 0; long long xp = 0;
-    const std::vector<WNode> *lv = &bestNodes;
-    if (bestK != 0 && env_int_w("MB_WIDE_RETIMED", 1)) { if (wide_nodes(m, backward, 0, P.W, pairCap, levelled, xe, xs, xp)) lv = &levelled; else lv = nullptr; }
-    else if (bestK != 0) lv = nullptr;
-    if (lv && want32 <= 0 && !wide_ret_build(m, P, *lv, (m->nOut ? m->nOut : m->nIn) + 1)) return false;      // (MB_WIDE_FP32 = 1 asks for the fp32 kernel)
-  }
   P.dev.segA = P.d_segA; P.dev.segB = P.d_segB;
   P.dev.NV = P.NV; P.dev.NX = P.NX; P.dev.W = P.W;
   std::vector<WideRec>().swap(P.recs); std::vector<uint32_t>().swap(P.dsts);
@@ -1334,7 +1348,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   P.dev.resultIdx = backward ? 0 : S - 1;
   P.dev.backward = backward ? 1 : 0;
   P.dev.inputTape = m->nOut ? 0 : 1;
-  P.ok = true; P.dirty = false;
+  P.ok = true; P.dirty = false; P.shapeChosen = true;
   if (verbose)
     fprintf(stderr, "[mbhip] wide %s%s program: %d stages, %zu rounds, %lld slots and %d barriers per column (%lld candidates = %.0f %% of the lane slots), %zu records, vectors %zu bytes\n",
             backward ? "backward" : "forward", viterbi ? " (max)" : "", bestK ? bestStages - 1 : 0, P.rounds.size(), P.slotsPerColumn, P.nSync, P.candsPerColumn,
