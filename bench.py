@@ -209,9 +209,11 @@ def extra_single_gpu(capi, np, hbm_peak):
         cells5 = b5.cells()
         ll5, t5 = timed(lambda: b5.forward(capi.MB_ROLLING), 2); k5 = capi.last_kernel_name()
         _, t5v = timed(lambda: b5.viterbi(paths=False), 1)
+        (_, _, e5), t5p = timed(lambda: b5.viterbi(), 1)
         (cnt5, s5, _), t5c = timed(lambda: b5.counts(), 1); k5c = capi.last_kernel_name()
         out["config5"] = {"workload": "fn3 profile (20 nodes) . simple_introns . translate . dnapsw: %d states, %d transitions, one tape; 64 sequences x 2000 nt" % (em5.nStates, em5.nTransitions),
                           "compose_s": round(tc, 2), "forward_rolling": round(cells5 / t5 / 1e9, 2), "viterbi_fill": round(cells5 / t5v / 1e9, 2),
+                          "viterbi_with_paths": round(cells5 / t5p / 1e9, 2), "path_edges": int(len(e5)),
                           "counts_lattice": round(cells5 / t5c / 1e9, 2), "unit": "Gcells/s", "counts_ms": round(t5c * 1e3, 1),
                           "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
