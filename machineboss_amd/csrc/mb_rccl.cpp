@@ -32,8 +32,20 @@ Rccl g_rccl;
 
 bool rccl_load() {
   if (g_rccl.lib) return true;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // RCCL must run on the HIP runtime THIS library runs on (it is handed our stream and our device buffers).  A process may
+  // hold two: PyTorch-ROCm preloads its own libamdhip64 by path, and when it is imported after this library has initialised
+  // the GPU on the system runtime, its copy never sees the device -- an RCCL bound to it fails ("no ROCm-capable device").  So
+  // the RCCL next to OUR runtime is tried first (dladdr on a HIP entry point tells which one that is), then the usual names.
+  std::string besideHip[2];
+  Dl_info info;
+  if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+    const std::string path(info.dli_fname);
+    const size_t slash = path.rfind('/');
+    if (slash != std::string::npos) { besideHip[0] = path.substr(0, slash) + "/librccl.so.1"; besideHip[1] = path.substr(0, slash) + "/librccl.so"; }
+  }
+  const char *names[] = {besideHip[0].c_str(), besideHip[1].c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char *n : names) {
+    if (!*n) continue;
     g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.lib) break;
   }
