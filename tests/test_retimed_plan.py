@@ -134,6 +134,29 @@ def test_retimed_program_reproduces_the_oracle(name, knobs, monkeypatch, tmp_pat
                 assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
 
 
+def test_retimed_program_of_the_config5_machine(tmp_path):
+    """BASELINE config 5's machine itself (20-node fn3 profile . simple_introns . translate . dnapsw, 5 063 states): period 10
+    where the machine's cycle allows 9, a ring of 3 vectors in LDS with some hundreds of relay entries, 37 columns in flight --
+    and the Viterbi cells of short sequences, bit for bit, from the record streams alone."""
+    from machineboss_amd import capi, algebra as A
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    from oracle import oracle
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).truncated(20)
+    em = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
+    assert em.nStates == 5063
+    prog = capi.debug_wide_retimed(em, str(tmp_path / "c5.bin"), capi.MB_VITERBI, False)
+    assert prog["lanes"] == 1024 and prog["inL2"] == 0 and prog["NB"] == 3 and 9 <= prog["period"] <= 12 and prog["NVs"] > 5065
+    assert (prog["NB"] * prog["NVs"] + 2 * prog["nPen"]) * 8 + 256 <= 160 * 1024       # ring + both penalty tables + token window in LDS
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    for n in (0, 4):
+        seq = np.random.RandomState(50 + n).randint(1, 5, size=n).astype(np.int32)
+        assert np.array_equal(simulate(prog, seq, False, True), om.viterbi(z, seq).reshape(n + 1, em.nStates))
+
+
 def test_retimed_program_refuses_two_tape_machines(tmp_path):
     from machineboss_amd import capi
     em = random_machine(12, 2, 2, 5, density=1.5, silent_density=1.0, allow_inf=False)
