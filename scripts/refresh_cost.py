@@ -7,12 +7,17 @@ from machineboss_amd.hmmer import HmmerModel
 from machineboss_amd.machine import Machine
 from machineboss_amd.evalmachine import EvaluatedMachine
 from machineboss_amd.seqgen import synth_batch
-nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 P = lambda n: Machine.fromFile("tests/golden/preset/%s.json" % n)
-h = HmmerModel.fromFile("tests/golden/hmmer/fn3.hmm").truncated(nodes)
-em = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
-dm = capi.DeviceMachine(em)
-b = capi.DeviceBatch(dm, *synth_batch(5, 64, 0, 2000, em.nInTok, em.nOutTok))
+if len(sys.argv) > 1 and not sys.argv[1].isdigit():      # a preset by name (two tapes): 64 pairs x 487 x 2000 (psw2dna), 1024 x 400 x 400 otherwise
+    em = EvaluatedMachine.fromMachine(P(sys.argv[1]), None, useDefaults=True)
+    dm = capi.DeviceMachine(em)
+    b = capi.DeviceBatch(dm, *(synth_batch(4, 64, 487, 2000, em.nInTok, em.nOutTok) if sys.argv[1] == "psw2dna" else synth_batch(3, 1024, 400, 400, em.nInTok, em.nOutTok)))
+else:
+    nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    h = HmmerModel.fromFile("tests/golden/hmmer/fn3.hmm").truncated(nodes)
+    em = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
+    dm = capi.DeviceMachine(em)
+    b = capi.DeviceBatch(dm, *synth_batch(5, 64, 0, 2000, em.nInTok, em.nOutTok))
 t0 = time.perf_counter(); b.counts(); print("first E-step (programs built): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 t0 = time.perf_counter(); b.counts(); print("E-step: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 lw = np.array(em.logWeight, dtype=np.float64)
