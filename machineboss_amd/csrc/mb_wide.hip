@@ -1034,10 +1034,9 @@ struct RetEdge { int src, dst, em, tok; double w; };
 
 // smallest tau >= 0 with tau(dst) >= tau(src) + 1 - em * period over all edges; false when some tau would exceed `bound` (the period
 // is shorter than a cycle of the machine needs, or the columns are deeper than the kernel's 6-bit lag)
-bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int bound, std::vector<int> &tau, long long &total) {
+bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int bound, std::vector<int> &tau) {
   tau.assign(nStates, 0);
-  long long work = 0;
-  total += 1;
+  long long work = 0;                                   // (a cap on the relaxation passes of one call: a pathological machine is refused, not waited for)
   for (;;) {
     bool moved = false;
     for (const RetEdge &e : edges) {
@@ -1085,10 +1084,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     if (a.em != b.em) return a.em < b.em;
     return P.backward ? a.dst > b.dst : a.dst < b.dst;
   });
-  long long work = 0;
   std::vector<int> tau;
   const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
-  auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau, work); };
+  auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau); };
   // (a weight refresh keeps the period that was chosen: the schedule depends on the machine's structure, not on its weights)
   const int forced = keepPeriod > 0 ? keepPeriod : env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
   int lo = 1, hi = 64;
