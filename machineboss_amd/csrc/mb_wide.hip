@@ -341,11 +341,18 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   for (int e = tid; e < nPen; e += W) { const int kt = e / rowLen; pen[e] = penalty(kt, e - kt * rowLen, 0); }
   __syncthreads();
   // one record stream per rotation of the ring (the newest column sits in vector t mod NB); a stream runs on into the next one
-  const size_t perStream = (size_t)Q.nSlots * W;
-  const WideRec *rec = Q.rec;
+  // (buffer loads: slot base in an SGPR offset, lane offset in one VGPR -- no 64-bit address arithmetic per slot)
+  typedef __attribute__((ext_vector_type(4))) unsigned int rec_u32x4;
+  const __amdgpu_buffer_rsrc_t recRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Q.rec, 0, 0x7fffffff, 0x00020000);
+  const int laneOff = tid * (int)sizeof(WideRec), slotBytes = W * (int)sizeof(WideRec), perStreamBytes = Q.nSlots * slotBytes;
+  auto ldrec = [&](int soff) -> WideRec {
+    const rec_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(recRsrc, laneOff, soff, 0);
+    WideRec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.src = r.z; o.pad = r.w;
+    return o;
+  };
   WideRec q[WIDE_RING];
 #pragma unroll
-  for (int k = 0; k < WIDE_RING; ++k) q[k] = (rec + (size_t)k * W)[tid];
+  for (int k = 0; k < WIDE_RING; ++k) q[k] = ldrec(k * slotBytes);
   const int nPer = L + 1 + Q.kMax;
   unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -367,14 +374,14 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
     for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; wide_lds_write(penNxt + (unsigned)e * 8u, penalty(kt, e - kt * rowLen, t + 1)); }
     const int cBase = P.backward ? t : t - Q.kMax;
     const char *rowPtr = (const char *)(P.lastOnly ? cells : cells + (long long)(P.backward ? L - t : t - Q.kMax) * S);
-    const WideRec *rcm = rec + (size_t)cm * perStream;
+    const int streamBase = cm * perStreamBytes;
     for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
       // (the slot after this period's last one belongs to the next period: its penalties are the other table's)
       const unsigned penHere = penCur, penLast = j0 + WIDE_RING == Q.nSlots ? penNxt : penCur;
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
-        q[k] = (rcm + (size_t)(j0 + WIDE_RING + k) * W)[tid];
+        q[k] = ldrec(streamBase + (j0 + WIDE_RING + k) * slotBytes);
         const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one just requested)
         const unsigned penN = k + 1 == WIDE_RING ? penLast : penHere;
         const double vNow = vAhead, pNow = pAhead;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             else wide_group_reduce_all<MODE>(m, s, gWave);
           }
           const uint32_t x = dst & WIDE_RET_NO_DST, kq = (dst >> 20) & 63u;      // entry within its vector: the state (relays: >= S + 2)
-          const int c = cBase + cSign * (int)kq;
+          const int c = cSign < 0 ? cBase - (int)kq : cBase + (int)kq;
           if (x != WIDE_RET_NO_DST && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
