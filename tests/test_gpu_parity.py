@@ -1402,20 +1402,35 @@ def test_boss_cli_hmmer_generator(capi, oracle_mod):
     assert got[0][2] == float("%.6g" % oracle_mod.OracleMachine(emg).viterbi(x, yg)[-1, -1, -1])
 
 
+_COMM_ONE = r"""
+import sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from machineboss_amd import capi
+counts = np.arange(7, dtype=np.float64) * 0.5
+ll = C.c_double(-3.25)
+assert capi.load().mb_allreduce_counts(None, counts.ctypes.data_as(C.POINTER(C.c_double)), counts.size, C.byref(ll)) == 0
+comm = capi.Comm(capi.Comm.unique_id(), 1, 0)
+try:
+    got, gl = comm.allreduce_counts(counts.copy(), -3.25)
+finally:
+    comm.close()
+assert np.array_equal(got, counts) and gl == -3.25
+"""
+
+
 def test_rccl_allreduce_entry_points(capi):
     """mb_comm_* / mb_allreduce_counts: the C-ABI route to the one collective of the path.  A one-rank communicator is all
     a single-GPU box can form -- the reduction is the identity there -- and a NULL communicator is a no-op; the N > 1
-    arithmetic is covered by the gloo world-size-2 tests of the Python route (tests/test_distributed.py)."""
-    import ctypes as C
-    counts = np.arange(7, dtype=np.float64) * 0.5
-    ll = C.c_double(-3.25)
-    assert capi.load().mb_allreduce_counts(None, counts.ctypes.data_as(C.POINTER(C.c_double)), counts.size, C.byref(ll)) == 0
-    comm = capi.Comm(capi.Comm.unique_id(), 1, 0)
-    try:
-        got, gl = comm.allreduce_counts(counts.copy(), -3.25)
-    finally:
-        comm.close()
-    assert np.array_equal(got, counts) and gl == -3.25
+    arithmetic is covered by the gloo world-size-2 tests of the Python route (tests/test_distributed.py).  In a process of
+    its own, as a C++ host would call it (and as test_rccl_allreduce_two_gpus does, one process per device): inside this
+    pytest process -- two HIP runtimes once PyTorch has been imported, hundreds of modules loaded -- ncclCommInitRank of the
+    image's RCCL aborted in one full-suite run out of two, taking every later test with it."""
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, "-c", _COMM_ONE, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
 
 
 _COMM_RANK = r"""
