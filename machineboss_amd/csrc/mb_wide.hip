@@ -1170,6 +1170,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   int nSlots = 0;
   for (const WideRound &R : T.rounds) nSlots += R.depth;
   const int padded = (nSlots + WIDE_RING - 1) / WIDE_RING * WIDE_RING;
+  if ((size_t)(best.NB * padded + WIDE_RING) * W * sizeof(WideRec) >= ((size_t)1 << 31)) return true;      // (the kernel's buffer loads carry 32-bit offsets)
   // one stream per rotation cm of the ring (newest column in vector cm): a record names its source by LDS byte address
   //   src = byte address << 14 | penalty entry;   pad (last slot) = flags | kq << 20 | vector << 18 | ring entry (see WideRetDev)
   const int NB = best.NB, NVs = best.NVs;
