@@ -617,3 +617,15 @@ def machineToJson(m: Machine, showParams: bool = False) -> dict:
             if m.cons.rate: cj["rate"] = m.cons.rate
             out["cons"] = cj
     return out
+
+
+def config4bMachine(presetDir: str) -> Machine:
+    """BASELINE config 4 read literally ("C4b"): protpsw . translate . dnapsw with dnapsw's parameter
+    constraints cleared -- with them the reference's compose aborts on the shared parameter names (src/machine.cpp:794-907).
+    482 states, 3095 transitions, 22 silent levels."""
+    import os
+    from .machine import Constraints
+    P = lambda n: Machine.fromFile(os.path.join(presetDir, n + ".json"))
+    d = P("dnapsw")
+    d.cons = Constraints()
+    return compose(compose(P("protpsw"), P("translate")), d)

@@ -387,9 +387,11 @@ static FastState *fast_state(mb_machine *m) {
         }
         return bestK;
       };
+      std::vector<int> cutsFwd; int KFwd = 0;   // the Forward program's closure: the count program's fill rounds use the same
       auto buildWith = [&](bool backward, MedProgram &P, MedGeom &geo) {
         std::vector<int> cuts;
         const int K = choose(backward, cuts);
+        if (!backward) { cutsFwd = cuts; KFwd = K; }
         medium_set_cuts(cuts);
         const bool okb = medium_build(m, backward, K, G, P, geo);
         medium_set_cuts({});
@@ -403,7 +405,7 @@ static FastState *fast_state(mb_machine *m) {
       if (ok && env_int("MB_MEDIUM_COUNTS", 1)) {
         int Gc = env_int("MB_MEDIUM_COUNT_G", 0);
         if (!medium_valid_G(Gc)) Gc = env_int("MB_MEDIUM_G", 0) ? G : medium_default_count_G(m->S);
-        f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt);
+        f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt, KFwd, cutsFwd);
       }
     } else if (wide_applicable(m) && m->S <= env_int("MB_WIDE_VITERBI_MIN_STATES", 2048) &&
                !(wide_build(m, false, true, f->wVit) && f->wVit.retOk)) {
@@ -1470,7 +1472,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   MedProgram P; MedGeom geo;
   if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
   if (mode == MED_MODE_COUNT) {
-    if (!medium_build_count_host(&m, G, P, geo)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
+    if (!medium_build_count_host(&m, G, P, geo, closure)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
   if (getenv("MB_MEDIUM_JIT_VERBOSE")) {
     long long c = 0; int syncs = 0;

@@ -55,7 +55,9 @@ struct MedProgDev {
 //          into VGPRs before the sweep;   LDS  copied into the LDS image next to the ring;   GLOBAL  fetched per step.
 enum { MED_PLACE_GLOBAL = 0, MED_PLACE_LDS = 1, MED_PLACE_REG = 2 };
 struct MedSlotInfo { int T; long long recBase; int place = MED_PLACE_GLOBAL; long long ldsOff = 0; };   // table (= vector it reads, = token kind), first record, placement, record offset in the LDS image
-struct MedRoundInfo { std::vector<MedSlotInfo> slots; bool sync = false, single = false; };
+struct MedRoundInfo { std::vector<MedSlotInfo> slots; bool sync = false, single = false;
+  bool flat = false;   // count programs: the usage pass behind the fill's rounds -- every record is ONE transition with its own source, destination and accumulator
+};
 
 struct MedJit {                 // one specialised kernel (per program and semiring)
   bool tried = false;
@@ -67,8 +69,11 @@ struct MedProgram {
   int G = 0, LPG = 0, NS = 0, Spad = 0, nChunks = 0, nRounds = 0;
   bool backward = false, closure = false;
   bool hasSplits = false;           // high-degree states were cut into parts + combining nodes (build_program)
-  bool counting = false;            // Forward fill + posterior counts program: the upper 16 bits of a record's srcOff hold
-                                    // the byte offset of its transition's accumulator in the LDS count array
+  bool counting = false;            // Forward fill + posterior counts program.  Levelled form (MB_MEDIUM_COUNT_FLAT=0): the exact program, the
+                                    // upper 16 bits of a record's srcOff hold the byte offset of its transition's accumulator in the LDS count
+                                    // array.  Flat form (default): the closure Forward program + one `flat` round of usage records
+                                    // {w, srcOff = source | destination << 16, dstOff = accumulator offset}, one per transition
+  bool flatCount = false;
   int accEntries = 0;               // counting: nTrans accumulators + LPG dummies (padding candidates, one per lane of a group)
   std::vector<int> desc;
   std::vector<MedRec> rec;
@@ -109,9 +114,10 @@ struct MedEnv { const int *d_start = nullptr, *d_end = nullptr, *h_start = nullp
 bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);   // closure: 0 levelled, K >= 1 closure in K stages
 bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, MedGeom &geo);
 bool medium_build_unsplit(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
-// exact Forward program whose records also name their transition's count accumulator (see MedProgram::counting)
-bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
-bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo);
+// Forward program whose sweep also accumulates posterior transition usage (see MedProgram::counting); closure / cuts: the staged
+// silent closure of its fill rounds (flat form only; what fast_state chose for the Forward program)
+bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo, int closure = 0, const std::vector<int> &cuts = std::vector<int>());
+bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo, int closure = 0, const std::vector<int> &cuts = std::vector<int>());
 // Forward fill of the chunk's matrices fused with MachineCounts accumulation (Backward matrices given); needs the
 // run-time specialised kernel: returns -1 (nothing launched) when it is unavailable, 0 ok, 1 error
 int medium_counts_materialised(const mb_machine *m, MedProgram &P, const MedGeom &geo, const PairDesc *d_pairs,

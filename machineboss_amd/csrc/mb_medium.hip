@@ -637,6 +637,12 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
       for (int id : rounds[r]) nsT[T] = std::max(nsT[T], sig(nodes[id])[T]);
       total += nsT[T];
     }
+    if (env_int_m("MB_MEDIUM_JIT_VERBOSE", 0) >= 2) {
+      int used = 0;
+      for (int id : rounds[r]) { const auto d = sig(nodes[id]); used += d[0] + d[1] + d[2] + d[3]; }
+      fprintf(stderr, "[mbhip]   round %d: stage %d, %zu of %d lanes, slots match/in/out/cur %d/%d/%d/%d, %d of %d lane-slots carry a candidate\n", r, nodes[rounds[r][0]].stage,
+              rounds[r].size(), LPG, nsT[0], nsT[1], nsT[2], nsT[3], used, total * LPG);
+    }
     bool single = (total == 1);
     for (int id : rounds[r]) { const auto d = sig(nodes[id]); if (d[0] + d[1] + d[2] + d[3] > 1) single = false; }
     if (total == 0) { nsT[3] = 1; total = 1; single = true; }   // a round of dead states still writes -inf through one padded slot
@@ -811,29 +817,93 @@ bool medium_build(const mb_machine *m, bool backward, int closure, int G, MedPro
   return medium_refresh_weights(m, P);
 }
 
-// Count program = the exact Forward program (one candidate per transition) + the accumulator offset of each
-// candidate's transition packed into the upper half of srcOff.  Geometry leaves room for one Backward supercell per
-// column and the count array in LDS, and keeps the workgroup at 8 wavefronts (256 VGPRs each).
-bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
-  build_program(m, false, false, G, P, /*allowSplit=*/false);   // counting terms need every candidate beside its real destination
-  P.counting = true; P.accEntries = (int)m->nTrans + P.LPG;   // + one dummy accumulator per lane of a group (padding candidates)
+// Count programs.  MachineCounts (src/counts.cpp:57-64, src/backward.cpp:58-87) adds exp(F(src cell, src) + w + B(dst cell, dst) - LL)
+// per transition and cell.  Two forms:
+//   LEVELLED (round 2/3, MB_MEDIUM_COUNT_FLAT=0): the exact Forward program, every candidate of its log-sum-exp is also a usage
+//     term of its transition; the accumulator offset rides in the upper half of srcOff.  The program is as deep as the machine's
+//     silent levels and its rounds are as wide as a level: psw2dna runs 17 rounds / 27 candidate slots per supercell with half
+//     of the lanes idle, although only ~276 of its 1684 transitions apply to a given cell (in-degree 1 for 254 of 271 states).
+//   FLAT (default): the fill is the staged-CLOSURE Forward program (the rounds of the log-likelihood sweep: 2 synchronisation
+//     points instead of 10 for psw2dna), and the usage terms follow in ONE more round without any dependency between lanes:
+//     the transitions that apply to a cell -- by table: match (input, output token), input-token, output-token, silent -- are
+//     dealt to the lanes of the column, ceil(n / LPG) slots per table, every record naming its own source (in the vector its
+//     table reads), destination (in the Backward supercell) and accumulator.  F(src) of EVERY state is final in the ring by
+//     then (closure programs finalise all S states), so the term is the reference's, with the Forward sweep's own rounding.
+static void append_flat_usage(const mb_machine *m, MedProgram &P) {
+  const int LPG = P.LPG, nIn = m->nIn, nOut = m->nOut, S = m->S;
+  const long long ntokT[4] = {(long long)(nIn + 1) * (nOut + 1), nIn + 1, nOut + 1, 1};
+  std::vector<std::vector<uint32_t>> byTok[4];
+  for (int T = 0; T < 4; ++T) byTok[T].resize((size_t)ntokT[T]);
+  for (long long e = 0; e < m->nTrans; ++e) {
+    const int it = m->inTok[e], ot = m->outTok[e];
+    const int T = (it && ot) ? 0 : (it ? 1 : (ot ? 2 : 3));
+    if (T == 3 && m->dst[e] <= m->src[e]) continue;   // the silent self-loop on state 0: no candidate of any fill (mb_machine.cpp)
+    const long long tok = T == 0 ? (long long)it * (nOut + 1) + ot : (T == 1 ? it : (T == 2 ? ot : 0));
+    byTok[T][(size_t)tok].push_back((uint32_t)e);
+  }
+  P.roundInfo.emplace_back();
+  MedRoundInfo &ri = P.roundInfo.back();
+  ri.flat = true;
+  for (int T = 0; T < 4; ++T) {
+    size_t mx = 0;
+    for (auto &l : byTok[T]) {
+      // lanes side by side read B(dst) (and mostly F(src)) of neighbouring states: no LDS bank is asked twice
+      std::stable_sort(l.begin(), l.end(), [&](uint32_t a, uint32_t b) { return m->dst[a] < m->dst[b]; });
+      mx = std::max(mx, l.size());
+    }
+    const int ns = (int)((mx + LPG - 1) / LPG);
+    for (int k = 0; k < ns; ++k) {
+      const size_t b0 = P.rec.size();
+      P.rec.resize(b0 + (size_t)ntokT[T] * LPG);
+      P.wref.resize(b0 + (size_t)ntokT[T] * LPG, -1);
+      ri.slots.push_back({T, (long long)b0});
+      for (long long tok = 0; tok < ntokT[T]; ++tok)
+        for (int ln = 0; ln < LPG; ++ln) {
+          MedRec &r = P.rec[b0 + (size_t)tok * LPG + ln];
+          const size_t j = (size_t)k * LPG + ln;
+          const std::vector<uint32_t> &l = byTok[T][(size_t)tok];
+          if (j < l.size()) {
+            const uint32_t e = l[j];
+            r.w = m->logW[e]; r.srcOff = (uint32_t)m->src[e] * 8u | ((uint32_t)m->dst[e] * 8u) << 16; r.dstOff = e * 8u;
+            P.wref[b0 + (size_t)tok * LPG + ln] = (int)e;
+          } else {   // padding: exp(-inf) = 0 into the lane's own dummy accumulator
+            r.w = -INFINITY; r.srcOff = (uint32_t)S * 8u | (P.dummyOff << 16); r.dstOff = (uint32_t)(m->nTrans + ln) * 8u;
+          }
+        }
+    }
+  }
+  if (ri.slots.empty()) P.roundInfo.pop_back();
+}
+
+// Geometry leaves room for one Backward supercell per column and the count array in LDS, and keeps the workgroup at 8 wavefronts.
+bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom &geo, int closure, const std::vector<int> &cuts) {
+  const bool flat = env_int_m("MB_MEDIUM_COUNT_FLAT", 1) != 0;
+  if (flat) {
+    medium_set_cuts(cuts);
+    build_program(m, false, closure, G, P);
+    medium_set_cuts({});
+  } else
+    build_program(m, false, 0, G, P, /*allowSplit=*/false);   // counting terms need every candidate beside its real destination
+  P.counting = true; P.flatCount = flat; P.accEntries = (int)m->nTrans + P.LPG;   // + one dummy accumulator per lane of a group (padding candidates)
   if (P.rec.size() >= (1u << 30) || P.Spad * 8 >= (1 << 16) || (m->nTrans + 64 + 2) * 8 >= (1 << 16)) return false;
   MedProgDev &d = P.dev;
   d.S = m->S; d.Spad = P.Spad; d.LPG = P.LPG; d.G = G; d.NS = P.NS; d.nChunks = P.nChunks;
   d.nIn = m->nIn; d.nOut = m->nOut; d.startNode = 0; d.endNode = m->S - 1;
+  if (flat) append_flat_usage(m, P);
   if (!medium_geometry(m, P, geo)) return false;
   medium_fit_records(m, P, geo);
-  for (size_t k = 0; k < P.rec.size(); ++k) {
-    const long long e = P.wref[k] >= 0 ? P.wref[k] : m->nTrans + (long long)(k % P.LPG);   // padding candidates add 0 to their lane's dummy accumulator
-    P.rec[k].srcOff = (P.rec[k].srcOff & 0xFFFFu) | ((uint32_t)(e * 8) << 16);
-  }
+  if (!flat)
+    for (size_t k = 0; k < P.rec.size(); ++k) {
+      const long long e = P.wref[k] >= 0 ? P.wref[k] : m->nTrans + (long long)(k % P.LPG);   // padding candidates add 0 to their lane's dummy accumulator
+      P.rec[k].srcOff = (P.rec[k].srcOff & 0xFFFFu) | ((uint32_t)(e * 8) << 16);
+    }
   medium_jit_plan(m, P, geo);
   medium_eval_weights(m, P);
   return true;
 }
 
-bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo) {
-  if (!medium_build_count_host(m, G, P, geo)) return false;
+bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo, int closure, const std::vector<int> &cuts) {
+  if (!medium_build_count_host(m, G, P, geo, closure, cuts)) return false;
   if (!up(P.d_desc, P.desc)) return false;
   P.dev.desc = P.d_desc;
   return medium_refresh_weights(m, P);

@@ -101,7 +101,8 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geoIn) {
     return true;
   };
   auto toReg = [&](MedRoundInfo &ri, size_t k) {
-    const int cost = 3 + (k == 0 ? 1 : 0) + (P.counting ? 1 : 0);   // count programs: + one fp32 usage accumulator per record
+    // count programs: + one fp32 usage accumulator per record that takes part in the counting (levelled form: all; flat form: the usage pass)
+    const int cost = ri.flat ? 4 : 3 + (k == 0 ? 1 : 0) + ((P.counting && !P.flatCount) ? 1 : 0);
     if (cost > regFree) return false;
     ri.slots[k].place = MED_PLACE_REG; regFree -= cost;
     return true;
@@ -143,9 +144,9 @@ long long medium_jit_spill_count(const std::string &code) {
 }
 
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int matKind) {
-  std::ostringstream defs, pre, body, post;
+  std::ostringstream defs, pre, body, post, flat;
   const int S = m->S;
-  const bool counting = mode == MED_MODE_COUNT, tbmode = mode == MED_MODE_TB, maxmode = mode == MB_VITERBI || tbmode;
+  const bool counting = mode == MED_MODE_COUNT && !P.flatCount, tbmode = mode == MED_MODE_TB, maxmode = mode == MB_VITERBI || tbmode;
   const bool materialise = matKind == MED_MAT_FULL;
   const int threads = geo.waves * 64;
   defs << "#define JS " << S << "\n#define JSPAD " << P.Spad << "\n#define JNS " << P.NS << "\n#define JG " << P.G
@@ -155,7 +156,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << matKind << "\n#define JTB " << (tbmode ? 1 : 0) << "\n#define JTBS " << tb_lds_stride(P) << "\n#define JSB " << medium_tb_stride(S)
        << "\n#define JNH " << P.haloStates.size() << "\n#define JNHP " << std::max<size_t>(P.haloStates.size(), 1)
        << "\n#define JNHR " << std::max<size_t>((P.haloStates.size() + threads - 1) / threads, 1) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
-       << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
+       << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
        << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
@@ -165,36 +166,87 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   defs << "};\n#define JHSTATE(k) jHaloState[k]\n";
   static const char *vec[4] = {"aDiag", "aLeft", "aDown", "aCur"};
   static const char *tok[4] = {"tokM16", "itOff16", "otOff16", "q16"};
+  // STAGES.  The rounds between two synchronisation points do not depend on one another (a round's same-cell candidates read
+  // what EARLIER stages wrote; build_program), but each ends with an LDS store to an address the compiler cannot tell from the
+  // next round's LDS loads, so straight-line "load, fold, store" per round runs the rounds of a stage one after the other -- a
+  // full LDS round trip + the log-sum-exp chain each (psw2dna's count sweep: 11 rounds in 3 stages, ~400 cycles per round of a
+  // 6 900-cycle step whose vector instructions need 1 500).  A stage is therefore emitted as: every load of every round (records
+  // placed in LDS, source values), then the folds, then the stores; rounds too long for that (> JIT_MAX_CANDS candidates) keep
+  // their running form and go between the loads and the folds of the others.  MB_JIT_STAGE_LOADS=0: round by round.
+  // A stage's loads are issued in batches of at most MB_JIT_STAGE_MAXLOADS source values (two VGPRs each until folded).
+  const bool stageLoads = env_int("MB_JIT_STAGE_LOADS", 1) != 0;
+  const int stageMaxLoads = std::max(1, env_int("MB_JIT_STAGE_MAXLOADS", 32));
+  int stagePending = 0;
+  std::ostringstream sLoad, sBig, sFold;
+  auto flushStage = [&]() {
+    stagePending = 0;
+    if (sLoad.str().empty() && sBig.str().empty() && sFold.str().empty()) return;
+    body << "      {\n" << sLoad.str() << sBig.str() << sFold.str() << "      }\n";
+    sLoad.str(""); sBig.str(""); sFold.str("");
+  };
   for (size_t r = 0; r < P.roundInfo.size(); ++r) {
     const MedRoundInfo &ri = P.roundInfo[r];
     const int n = (int)ri.slots.size();
-    body << "      {  // round " << r << ": " << n << " candidate slot(s)\n";
+    const std::string R = "_" + std::to_string(r);
+    const bool big = !tbmode && !ri.flat && n > JIT_MAX_CANDS;
     // name of the record of slot k; emits its load (loop-invariant ones go to the prologue)
+    std::ostringstream &out = ri.flat ? flat : (big ? sBig : sLoad);
     auto rec = [&](int k) {
       const MedSlotInfo &sl = ri.slots[k];
       const std::string name = "r" + std::to_string(r) + "_" + std::to_string(k);
       if (sl.place == MED_PLACE_REG)
         pre << "  const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ");\n";
       else if (sl.place == MED_PLACE_LDS)
-        body << "        const Rec " << name << " = ld_l(ldsRec, " << sl.ldsOff * 16 << "u + " << tok[sl.T] << ");\n";
+        out << "        const Rec " << name << " = ld_l(ldsRec, " << sl.ldsOff * 16 << "u + " << tok[sl.T] << ");\n";
       else if ((long long)P.rec.size() * 16 < (1ll << 31))   // buffer load: lane offset in a VGPR, slot base in an SGPR -> no loop-invariant 64-bit address per slot
-        body << "        const Rec " << name << " = ld_b(recRsrc, " << tok[sl.T] << ", " << sl.recBase * 16 << ");\n";
+        out << "        const Rec " << name << " = ld_b(recRsrc, " << tok[sl.T] << ", " << sl.recBase * 16 << ");\n";
       else
-        body << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
+        out << "        const Rec " << name << " = ld_g(grb + " << sl.recBase * 16 << "ull, " << tok[sl.T] << ");\n";
       return name;
     };
-    // count mode: usage term exp(v + bl) of candidate k.  A record that sits in VGPRs names the same transition for the
-    // whole sweep, so its usage is summed in a register (fp32, at most one tile of steps) and reaches the workgroup's
-    // LDS accumulator once, after the step loop; the others add to LDS per step (ds_add_f64).
-    auto countTerm = [&](const MedSlotInfo &sl, const std::string &name, int k) {
+    if (ri.flat) {
+      // usage pass of a flat count program (mb_medium.hip, append_flat_usage): every slot is one transition per lane,
+      // term = exp((F(src) + w) + (B(dst) - LL)); bvec holds B - LL.  Loop-invariant records sum in a register (fp32, one tile of
+      // steps) and reach the workgroup's LDS accumulator after the step loop -- their accumulator offset is read again there
+      // instead of living in a VGPR --, the others add to LDS per step.
+      flushStage();
+      std::vector<std::string> fn(n);
+      flat << "      if (JINSIDE) {  // usage pass: " << n << " slot(s); lanes of columns outside the lattice (stale ring values) sit it out\n";
+      for (int k = 0; k < n; ++k) fn[k] = rec(k);
+      for (int k = 0; k < n; ++k)
+        flat << "        const double x" << k << " = (med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)(" << fn[k] << ".srcOff & 0xFFFFu)) + " << fn[k] << ".w) + med_lds(ldsb, aB + (int)(" << fn[k] << ".srcOff >> 16));\n";
+      for (int k = 0; k < n; ++k) {
+        const MedSlotInfo &sl = ri.slots[k];
+        const std::string term = "ex2(x" + std::to_string(k) + ")";
+        if (sl.place == MED_PLACE_REG) {
+          pre << "  float acc_" << fn[k] << " = 0.0f;\n";
+          flat << "        acc_" << fn[k] << " += " << term << ";\n";
+          post << "  cnt_flush(ldsb, accBase + ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ").dstOff, acc_" << fn[k] << ");\n";
+        } else
+          flat << "        cnt_flush(ldsb, accBase + " << fn[k] << ".dstOff, " << term << ");\n";
+      }
+      flat << "      }\n";
+      continue;
+    }
+    // count mode (levelled form): usage term exp(v_k + bl) of candidate k, bl = B(dst) - logLike (src/backward.cpp:58-87).  The
+    // log-sum-exp of the state already formed e_k = exp(v_k - gM) for every candidate, so the usage is e_k * s with ONE more
+    // exponential per state (per group of JIT_MAX_CANDS on the running-max path), s = exp(max + bl) -- `term` is that product, or
+    // the lone candidate's own exp(v_0 + bl).  A record that sits in VGPRs names the same transition for the whole sweep, so its
+    // usage is summed in a register (fp32, at most one tile of steps) and reaches the workgroup's LDS accumulator once, after the
+    // step loop; the others add to LDS per step (ds_add_f64).
+    auto countTerm = [&](std::ostringstream &o, const MedSlotInfo &sl, const std::string &name, const std::string &term) {
       if (sl.place == MED_PLACE_REG) {
         pre << "  float acc_" << name << " = 0.0f;\n";
-        body << "        acc_" << name << " += ex2(v" << k << " + bl);\n";
+        o << "        acc_" << name << " += " << term << ";\n";
         post << "  cnt_flush(ldsb, accBase + (" << name << ".srcOff >> 16), acc_" << name << ");\n";
       } else
-        body << "        cnt_add(ldsb, accBase + (" << name << ".srcOff >> 16), v" << k << " + bl);\n";
+        o << "        cnt_flush(ldsb, accBase + (" << name << ".srcOff >> 16), " << term << ");\n";
     };
+    auto V = [&](int k) { return "v" + R + "_" + std::to_string(k); };
+    auto E = [&](int k) { return "e" + R + "_" + std::to_string(k); };
     std::vector<std::string> nm(n);
+    if (!big) { if (stagePending > 0 && stagePending + n > stageMaxLoads) flushStage(); stagePending += n; }
+    sFold << "        // round " << r << ": " << n << " candidate slot(s)\n";
     if (tbmode) {
       // max semiring with the index of the FIRST maximal candidate: slots come table by table (match, input-only, output-only,
       // same-cell) and inside a table in the reference's list order, which is its enumeration order (src/dpmatrix.defs.h:93-103);
@@ -202,68 +254,80 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       int perT[4] = {0, 0, 0, 0};
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
       for (int k = 0; k < n; ++k)
-        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
-      body << "        double res = v0; unsigned x = " << ((ri.slots[0].T << 6) | 0) << "u;\n";
+        sLoad << "        const double " << V(k) << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+      sFold << "        double res" << R << " = " << V(0) << "; unsigned x" << R << " = " << ((ri.slots[0].T << 6) | 0) << "u;\n";
       perT[ri.slots[0].T] = 1;
       for (int k = 1; k < n; ++k) {
         const int code = (ri.slots[k].T << 6) | perT[ri.slots[k].T]++;
-        body << "        { const bool g = v" << k << " > res; res = g ? v" << k << " : res; x = g ? " << code << "u : x; }\n";
+        sFold << "        { const bool g = " << V(k) << " > res" << R << "; res" << R << " = g ? " << V(k) << " : res" << R << "; x" << R << " = g ? " << code << "u : x" << R << "; }\n";
       }
-      body << "        const int dOff = (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF);\n";
-      body << "        *(double *)(ldsb + (aCur + dOff)) = JCLIP(res);\n";
-      body << "        tbCol[dOff >> 3] = (unsigned char)x;\n";
-    } else if (n <= JIT_MAX_CANDS) {
+      sFold << "        const int dOff" << R << " = (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF);\n";
+      sFold << "        *(double *)(ldsb + (aCur + dOff" << R << ")) = JCLIP(res" << R << ");\n";
+      sFold << "        tbCol[dOff" << R << " >> 3] = (unsigned char)x" << R << ";\n";
+    } else if (!big) {
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
       for (int k = 0; k < n; ++k)
-        body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+        sLoad << "        const double " << V(k) << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+      if (counting)   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
+        sLoad << "        const double bl" << R << " = med_lds(ldsb, aB + (int)(JINSIDE ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
       if (n == 1) {
-        body << "        const double res = v0;\n";
+        sFold << "        const double res" << R << " = " << V(0) << ";\n";
       } else {
-        body << "        double mx = dmax(v0, v1);\n";
-        for (int k = 2; k < n; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
-        if (maxmode) body << "        const double res = mx;\n";
+        sFold << "        double mx" << R << " = dmax(" << V(0) << ", " << V(1) << ");\n";
+        for (int k = 2; k < n; ++k) sFold << "        mx" << R << " = dmax(mx" << R << ", " << V(k) << ");\n";
+        if (maxmode) sFold << "        const double res" << R << " = mx" << R << ";\n";
         else {
-          body << "        const double gM = (mx == NEG_INF) ? 0.0 : mx;\n        const float sm = ex2(v0 - gM)";
-          for (int k = 1; k < n; ++k) body << " + ex2(v" << k << " - gM)";
-          body << ";\n        const double res = gM + (double)(__builtin_amdgcn_logf(sm) * MED_LN2);\n";
+          sFold << "        const double gM" << R << " = (mx" << R << " == NEG_INF) ? 0.0 : mx" << R << ";\n";
+          for (int k = 0; k < n; ++k) sFold << "        const float " << E(k) << " = ex2(" << V(k) << " - gM" << R << ");\n";
+          sFold << "        const float sm" << R << " = " << E(0);
+          for (int k = 1; k < n; ++k) sFold << " + " << E(k);
+          sFold << ";\n        const double res" << R << " = gM" << R << " + (double)(__builtin_amdgcn_logf(sm" << R << ") * MED_LN2);\n";
         }
       }
-      body << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
-      if (counting) {   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
-        body << "        const double bl = med_lds(ldsb, aB + (int)(JINSIDE ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
-        for (int k = 0; k < n; ++k) countTerm(ri.slots[k], nm[k], k);
+      sFold << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res" << R << ");\n";
+      if (counting) {
+        if (n == 1) countTerm(sFold, ri.slots[0], nm[0], "ex2(" + V(0) + " + bl" + R + ")");
+        else {
+          sFold << "        const float sB" << R << " = ex2(mx" << R << " + bl" << R << ");   // (mx, not gM: no candidate at all -> exp(-inf) = 0, whatever B - logLike is)\n";
+          for (int k = 0; k < n; ++k) countTerm(sFold, ri.slots[k], nm[k], E(k) + " * sB" + R);
+        }
       }
     } else {
       // many candidates: groups of JIT_MAX_CANDS folded into a running (max, scaled sum)
-      body << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
+      sBig << "        {  // round " << r << ": " << n << " candidate slot(s)\n";
+      sBig << "        double accM = NEG_INF; float accS = 0.0f; unsigned dstOff = 0xFFFFFFFFu;\n";
       for (int k0 = 0; k0 < n; k0 += JIT_MAX_CANDS) {
         const int k1 = std::min(n, k0 + JIT_MAX_CANDS);
-        body << "        {\n";
+        sBig << "        {\n";
         for (int k = k0; k < k1; ++k) nm[k] = rec(k);
-        if (k0 == 0) body << "        dstOff = " << nm[0] << ".dstOff;\n";
+        if (k0 == 0) sBig << "        dstOff = " << nm[0] << ".dstOff;\n";
         for (int k = k0; k < k1; ++k)
-          body << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
-        if (counting) {
-          body << "        const double bl = med_lds(ldsb, aB + (int)(JINSIDE ? dstOff : (unsigned)JDUMMYOFF)) + negLL;\n";
-          for (int k = k0; k < k1; ++k) countTerm(ri.slots[k], nm[k], k);
-        }
-        body << "        double mx = v" << k0 << ";\n";
-        for (int k = k0 + 1; k < k1; ++k) body << "        mx = dmax(mx, v" << k << ");\n";
-        if (maxmode) body << "        accM = dmax(accM, mx);\n";
+          sBig << "        const double v" << k << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
+        sBig << "        double mx = v" << k0 << ";\n";
+        for (int k = k0 + 1; k < k1; ++k) sBig << "        mx = dmax(mx, v" << k << ");\n";
+        if (maxmode) sBig << "        accM = dmax(accM, mx);\n";
         else {
-          body << "        const double nm = dmax(accM, mx), gM = (nm == NEG_INF) ? 0.0 : nm;\n        accS = accS * ex2(accM - gM)";
-          for (int k = k0; k < k1; ++k) body << " + ex2(v" << k << " - gM)";
-          body << ";\n        accM = nm;\n";
+          sBig << "        const double nm = dmax(accM, mx), gM = (nm == NEG_INF) ? 0.0 : nm;\n";
+          for (int k = k0; k < k1; ++k) sBig << "        const float e" << k << " = ex2(v" << k << " - gM);\n";
+          sBig << "        accS = accS * ex2(accM - gM)";
+          for (int k = k0; k < k1; ++k) sBig << " + e" << k;
+          sBig << ";\n        accM = nm;\n";
+          if (counting) {
+            sBig << "        const float sB = ex2(nm + (med_lds(ldsb, aB + (int)(JINSIDE ? dstOff : (unsigned)JDUMMYOFF)) + negLL));\n";
+            for (int k = k0; k < k1; ++k) countTerm(sBig, ri.slots[k], nm[k], "e" + std::to_string(k) + " * sB");
+          }
         }
-        body << "        }\n";
+        sBig << "        }\n";
       }
-      if (maxmode) body << "        const double res = accM;\n";
-      else body << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
-      body << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
+      if (maxmode) sBig << "        const double res = accM;\n";
+      else sBig << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
+      sBig << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
+      sBig << "        }\n";
     }
-    body << "      }\n";
+    if (ri.sync || !stageLoads) flushStage();
     if (ri.sync) body << "      med_wave_sync();\n";
   }
+  flushStage();
   std::string src = kMedJitSkeleton;
   auto replace = [&](const std::string &mark, const std::string &with) {
     const size_t p = src.find(mark);
@@ -272,6 +336,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   replace("/*@DEFS@*/", defs.str());
   replace("/*@PRE@*/", pre.str());
   replace("/*@BODY@*/", body.str());
+  replace("/*@FLAT@*/", flat.str());
   replace("/*@POST@*/", post.str());
   return src;
 }

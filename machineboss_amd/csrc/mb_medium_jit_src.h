@@ -157,7 +157,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
       ++jT;
 #endif
       (void)firstCand;
-#if JMODE == 2
+#if JMODE == 2 && !JFLAT
       {  // every chunk's slot-0 record names the lane's destination state
         const double bl = (lanesOn && (int)dstOff >= 0) ? (med_lds(ldsb, aB + (int)dstOff) + negLL) : NEG_INF;
         cnt_add(ldsb, accBase + (r.srcOff >> 16), v + bl);
@@ -343,7 +343,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     const int o0 = min(max(t0 - c, 0), outLen);
     const double *bs = cellPtrB(min(i, inLen), o0);
 #pragma unroll
-    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = bs[j]; }
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = JFLAT ? bs[j] + negLL : bs[j]; }   // JFLAT: bvec holds B - logLike
   }
 #else
   constexpr int aB = 0; constexpr unsigned accBase = 0; constexpr double negLL = 0.0;
@@ -410,21 +410,26 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       for (int k = 0; k < JBV; ++k) bpre[k] = bs[min(k * LPG + q, S - 1)];
     }
 #endif
+    // LDS byte addresses of the four vectors this lane's column reads / writes
+    const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
+    const unsigned otOff16 = (unsigned)(ot * LPG + q) * 16u;
+    const unsigned tokM16 = (unsigned)((it * (JNOUT + 1) + ot) * LPG + q) * 16u;
+    (void)aCur; (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
                                       P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff);
     } else {
-      // LDS byte addresses of the four vectors this lane's column reads / writes
-      const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
-      const unsigned otOff16 = (unsigned)(ot * LPG + q) * 16u;
-      const unsigned tokM16 = (unsigned)((it * (JNOUT + 1) + ot) * LPG + q) * 16u;
-      (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
 #if JTB
       unsigned char *tbCol = tbL + c * JTBS;
 #endif
 /*@BODY@*/
     }
     med_wave_sync();
+#if JMODE == 2 && JFLAT
+    // every state of this step's supercells is final: the usage of the transitions that apply to them (origin supercell included)
+/*@FLAT@*/
+    med_wave_sync();   // bvec is rewritten below
+#endif
     // everything loaded from global memory in this step is consumed here, BEFORE the step's global stores are issued:
     // vmcnt counts loads and stores in order on gfx9, so a wait placed after the stores would wait for them too
     if (wantTok) {
@@ -439,7 +444,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
 #if JMODE == 2
 #pragma unroll
-    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = bpre[k]; }
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = JFLAT ? bpre[k] + negLL : bpre[k]; }
 #endif
 #if JMAT == 2
     if (wantHalo) {
