@@ -46,6 +46,12 @@ struct ApiGuard {
   ApiGuard() : lk(g_api_mutex) { if (g_api_depth++ == 0) ws_begin_call(); }
   ~ApiGuard() { --g_api_depth; }
 };
+// the same lock without the "a new call begins" bookkeeping: option and introspection entry points (they touch the environment /
+// the planners' process-wide state, which guarded calls of other threads read)
+struct ApiLock {
+  std::lock_guard<std::recursive_mutex> lk;
+  ApiLock() : lk(g_api_mutex) {}
+};
 static int g_device = -1;   // device the library's stream and workspaces live on
 
 static int ensure_init() {
@@ -286,7 +292,8 @@ static int upload_chunk_descs(const mb_batch *b, const Chunk &c, PairDesc **d_ou
 // ---- kernel-family state attached to a machine ------------------------------------------------------------
 struct FastState {
   bool tried = false, mediumOk = false;
-  bool exactOk = false;      // one-tape machines: only the exact (levelled) tiled program is built, for Viterbi
+  bool exactOk = false;      // one-tape machines: only the exact (levelled) tiled program is built, for Viterbi (onetape_tiled_viterbi)
+  bool exactTried = false;
   int G = 0;
   // exact (leveled) programs: Viterbi and Forward with a custom start state; "sum" programs: Forward / Backward,
   // silent closure when it stays small, otherwise the exact program of that direction
@@ -407,16 +414,6 @@ static FastState *fast_state(mb_machine *m) {
         if (!medium_valid_G(Gc)) Gc = env_int("MB_MEDIUM_G", 0) ? G : medium_default_count_G(m->S);
         f->countOk = medium_build_count(m, Gc, f->fwdCnt, f->geoCnt, KFwd, cutsFwd);
       }
-    } else if (wide_applicable(m) && m->S <= env_int("MB_WIDE_VITERBI_MIN_STATES", 2048) &&
-               !(wide_build(m, false, true, f->wVit) && f->wVit.retOk)) {
-      // One-tape machine of moderate size whose max program has no retimed form (762 states: retimed 44 G cells/s, tiles 32;
-      // 1268 states: 73 vs 22): the log-sum-exp sweeps belong to the one-tape family, but its column-by-column Viterbi sweep
-      // walks the silent levels one record at a time (0.2 us per level), where the run-time specialised tile kernel has
-      // them as straight-line code (762 states: 32 vs 14.5 G cells/s, 1268 states: 22.8 vs 15.6).
-      int G = env_int("MB_MEDIUM_G", 0);
-      if (!medium_valid_G(G)) G = medium_default_G(m->S);
-      f->G = G;
-      f->exactOk = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
     }
   }
   return f;
@@ -464,6 +461,27 @@ static WideProgram *wide_program(mb_machine *m, int mode) {
   return &P;
 }
 
+// One-tape machine of moderate size whose max program has no retimed form (762 states: retimed 44 G cells/s, tiles 32; 1268
+// states: 73 vs 22): the log-sum-exp sweeps belong to the one-tape family, but its column-by-column Viterbi sweep walks the
+// silent levels one record at a time (0.2 us per level), where the run-time specialised tile kernel has them as straight-line
+// code (762 states: 32 vs 14.5 G cells/s, 1268 states: 22.8 vs 15.6).  Decided when a Viterbi fill asks, and again after a weight
+// update: which edges are -inf decides whether the retimed form exists (they leave the retiming graph), so a machine can gain or
+// lose it.  Callers that never run Viterbi build neither program.
+static bool onetape_tiled_viterbi(mb_machine *m) {
+  if (!wide_applicable(m) || g_kernel_choice == 1 || m->S > env_int("MB_WIDE_VITERBI_MIN_STATES", 2048)) return false;
+  FastState *f = fast_state(m);
+  WideProgram *W = wide_program(m, MB_VITERBI);      // (built on first use, rebuilt when the weights changed)
+  if (W && W->retOk) return false;
+  if (!f->exactTried) {
+    f->exactTried = true;
+    int G = env_int("MB_MEDIUM_G", 0);
+    if (!medium_valid_G(G)) G = medium_default_G(m->S);
+    f->G = G;
+    f->exactOk = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
+  }
+  return f->exactOk;
+}
+
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
                       const int *d_out, double *pool, int startState, const mb_batch *b) {
@@ -473,7 +491,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     for (const PairDesc &pd : hp) cells = std::max(cells, pd.cellBase + (long long)(pd.inLen + 1) * (pd.outLen + 1) * m->S);
     if (launch_fill_neg_inf(pool, cells, g_stream)) return 1;
   }
-  const bool tiledViterbi = !env && mode == MB_VITERBI && wide_applicable(m) && g_kernel_choice != 1 && fast_state(m)->exactOk;
+  const bool tiledViterbi = !env && mode == MB_VITERBI && onetape_tiled_viterbi(m);
   if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1 && !tiledViterbi) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
@@ -490,7 +508,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
     const int rc = medium_fill_materialised(m, P, geo, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD,
                                             (mode == MB_FORWARD && startState != 0) ? startState : -1, d_desc, hp, d_in, d_out, pool, g_stream, me);
     if (rc >= 0) {
-      g_last_kernel = medium_jit_ready(P, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, true) ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
+      g_last_kernel = medium_jit_ready(P, mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD, MED_MAT_FULL) ? "k_medium_jit" : (mode == MB_VITERBI ? "k_medium_tile<1>" : "k_medium_tile<0>");
       return rc;
     }
     // (-1: envelopes need the run-time specialised kernel and it is unavailable: the generic family takes the chunk)
@@ -832,6 +850,7 @@ int mb_machine_sweep_ops(mb_machine *m, double *expPerCell, double *logPerCell, 
 // Tuning knobs are read from the environment when a machine's programs / kernels are built (DESIGN.md section 4.4 lists
 // them); this is the same switchboard for a host that prefers calls to environment variables.
 int mb_set_option(const char *name, const char *value) {
+  ApiLock lock;
   if (!name || strncmp(name, "MB_", 3) != 0) { set_error("mb_set_option: option names start with MB_"); return 1; }
   const int rc = (value && *value) ? setenv(name, value, 1) : unsetenv(name);
   if (rc) { set_error("mb_set_option: cannot set option"); return 1; }
@@ -839,6 +858,7 @@ int mb_set_option(const char *name, const char *value) {
 }
 
 const char *mb_get_option(const char *name) {
+  ApiLock lock;
   if (!name || strncmp(name, "MB_", 3) != 0) return nullptr;
   return getenv(name);
 }
@@ -1457,6 +1477,7 @@ int mb_fill(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const int
 int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
                         const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int closure,
                         int G, const char *path) {
+  ApiLock lock;
   if (nStates <= 0 || nTrans < 0 || !path) { set_error("mb_debug_jit_source: bad argument"); return 1; }
   if (!medium_valid_G(G)) { set_error("mb_debug_jit_source: G must be a power of two in 1..64"); return 1; }
   mb_machine m;
@@ -1497,6 +1518,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
 // planner can be checked without a device (tests/test_retimed_plan.py simulates the stream and compares with the oracle).
 int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
                           const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, const char *path) {
+  ApiLock lock;
   if (nStates <= 0 || nTrans < 0 || !path || (nInTok != 0) == (nOutTok != 0)) { set_error("mb_debug_wide_retimed: bad argument (one-tape machines only)"); return 1; }
   mb_machine m;
   m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
@@ -1521,6 +1543,7 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
 int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
                           const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward,
                           int materialise, const char *path) {
+  ApiLock lock;
   if (nStates <= 0 || nTrans < 0 || !path || mode < 0 || mode >= SM_NMODE) { set_error("mb_debug_small_source: bad argument"); return 1; }
   mb_machine m;
   m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;

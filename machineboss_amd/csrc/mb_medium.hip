@@ -1062,7 +1062,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   if (roll) { A.colHalo = roll->halo; A.haloBase = roll->haloBase; A.bound = roll->bound; A.boundBase = roll->boundBase; A.tb = roll->tb; }
   const dim3 block(geo.waves * 64);
   hipEvent_t evStart = nullptr, evDone = nullptr;
-  bool streamsOk = true;
+  bool streamsOk = true, launchFailed = false;
   if (nG > 1) {      // the other streams start behind what `st` has queued (tile list, buffers) and hand back to it at the end
     streamsOk = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess &&
                 hipEventRecord(evStart, st) == hipSuccess;
@@ -1077,11 +1077,14 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
       const dim3 grid((unsigned)cnt[k]);
       hipStream_t sg = sgs[g];
       if (J && launch_jit(*J, grid, block, sg, dev, A)) continue;
+      // the ahead-of-time interpreter is the twin of the plain matrix kernels only: a failed launch of a specialised kernel without
+      // one (count sweep, traceback bytes, tiles without a matrix, envelopes) ends the sweep with an error
+      if (mode == MED_MODE_COUNT || mode == MED_MODE_TB || matKind != MED_MAT_FULL || geo.env) { launchFailed = true; streamsOk = false; break; }
       if (mode == MB_VITERBI) launch_tile<MB_VITERBI>(P.G, grid, block, geo.ldsBytes, sg, dev, A);
       else launch_tile<MB_FORWARD>(P.G, grid, block, geo.ldsBytes, sg, dev, A);
     }
   for (int g = 1; g < nG && streamsOk; ++g) streamsOk = hipEventRecord(evDone, sgs[g]) == hipSuccess && hipStreamWaitEvent(st, evDone, 0) == hipSuccess;
-  if (nG > 1 && !streamsOk) { for (int g = 1; g < nG; ++g) (void)hipStreamSynchronize(sgs[g]); set_error("tile sweep: stream synchronisation failed"); }
+  if (!streamsOk) { for (int g = 0; g < nG; ++g) (void)hipStreamSynchronize(sgs[g]); set_error(launchFailed ? "tile sweep: launch of the run-time specialised kernel failed" : "tile sweep: stream synchronisation failed"); }
   if (evStart) (void)hipEventDestroy(evStart);
   if (evDone) (void)hipEventDestroy(evDone);
   const bool ok = streamsOk && hip_ok(hipGetLastError(), "medium tile launch") && hip_ok(hipStreamSynchronize(st), "medium tile kernels");

@@ -410,7 +410,11 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
           s = 0.0f;
           if (flags & 0x40000000u) {
             __syncthreads();
-            vAhead = ring(nx.src);                             // (the penalties of a period were written a period ahead: what was fetched stands)
+            // both look-ups of the next slot again: its ring value may be stale, and so may its penalty -- the next period's table is
+            // written at the top of THIS period, and when this barrier is the period's only one and sits in its last slot (a plain
+            // HMM: period 1, slot count a multiple of WIDE_RING) nothing but timing ordered those writes before the read above
+            vAhead = ring(nx.src);
+            pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
           }
         }
       }
@@ -1573,7 +1577,7 @@ __global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEd
                                                         const unsigned short *__restrict__ waveLabel, int nWaves, int nEB,
                                                         const PairDesc *__restrict__ pairs, long long nUnits, int colSplit, int inputTape,
                                                         const int *__restrict__ tape, const double *__restrict__ fwd,
-                                                        const double *__restrict__ bwd, double *__restrict__ counts) {
+                                                        const double *__restrict__ bwd, double *__restrict__ counts, const float *__restrict__ norm) {
   const long long bid = blockIdx.x, slot = bid >> 3;
   const long long unit = (slot / nEB) * 8 + (bid & 7);
   const int eb = (int)(slot % nEB);
@@ -1599,16 +1603,58 @@ __global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEd
   auto term = [&](long long cs, long long cd) -> double {
     return (double)__builtin_amdgcn_exp2f((float)(F[cs * S + src] + (B[cd * S + dst] + wl)) * 1.44269504088896f);
   };
+  // norm: one over what the emitting terms of each column sum to (k_onetape_colnorm; see k_onetape_counts_lds), by global column
+  const float *nm = norm ? norm + pd.cellBase / S : nullptr;
   double acc = 0.0;
   if (y == 0) {
 #pragma unroll 4
-    for (int c = cA; c < cB; ++c) acc += term(c, c);
+    for (int c = cA; c < cB; ++c) acc += nm ? term(c, c) * (double)nm[c] : term(c, c);
   } else {
     const int cE = min(cB, L);
     for (int c = cA; c < cE; ++c)
-      if (tk[c] == y) acc += term(c, c + 1);
+      if (tk[c] == y) acc += nm ? term(c, c + 1) * (double)nm[c] : term(c, c + 1);
   }
   if (live && acc != 0.0) atomicAdd(&counts[m.outEid[pos]], acc);
+}
+
+// norm[global column] = 1 / (sum of the emitting terms that leave the column), the last column of a sequence: 1 / exp(F(L, end) -
+// logLike) -- the normaliser of k_onetape_counts_lds for the kernel above, whose edge blocks are workgroups of their own.  One
+// workgroup per sequence part, thread = source state (the outgoing view: row s * K + token).
+__global__ __launch_bounds__(256) void k_onetape_colnorm(DevMachine m, const PairDesc *__restrict__ pairs, int colSplit, int inputTape,
+                                                         const int *__restrict__ tape, const double *__restrict__ fwd,
+                                                         const double *__restrict__ bwd, float *__restrict__ norm) {
+  __shared__ float red[4];
+  const long long unit = blockIdx.x, p = unit / colSplit;
+  const int part = (int)(unit - p * colSplit), tid = threadIdx.x;
+  const PairDesc pd = pairs[p];
+  const int L = inputTape ? pd.inLen : pd.outLen;
+  const long long S = m.S;
+  const double *F = fwd + pd.cellBase, *B = bwd + pd.cellBase;
+  float *nm = norm + pd.cellBase / S;
+  const double ll = B[0];
+  const int per = (L + colSplit) / colSplit, cA = part * per, cB = min(L + 1, cA + per);
+  const int *tk = tape + (inputTape ? pd.inBase : pd.outBase);
+  for (int c = cA; c < cB; ++c) {
+    float z = 0.0f;
+    if (!(ll > -INFINITY)) z = 1.0f;
+    else if (c == L) z = __builtin_amdgcn_exp2f((float)(F[(long long)L * S + (S - 1)] - ll) * 1.44269504088896f);
+    else {
+      const int y = tk[c];
+      const double *Fc = F + (long long)c * S, *Bn = B + (long long)(c + 1) * S;
+      for (int s = tid; s < (int)S; s += 256) {
+        const double f = Fc[s] - ll;
+        const int row = s * m.K + y;
+        for (int a = m.outOff[row]; a < m.outOff[row + 1]; ++a) z += __builtin_amdgcn_exp2f((float)(f + (m.outW[a] + Bn[m.outDst[a]])) * 1.44269504088896f);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
+      __syncthreads();                                    // (the previous column's sums have been read)
+      if ((tid & 63) == 0) red[tid >> 6] = z;
+      __syncthreads();
+      z = red[0] + red[1] + red[2] + red[3];
+    }
+    if (tid == 0) nm[c] = (z > 0.0f && z < 3.0e38f) ? 1.0f / z : 1.0f;
+  }
 }
 
 // The same sum with the columns staged in LDS, for machines whose three state vectors F(c), B(c), B(c + 1) fit it (<= 6 800
@@ -1620,10 +1666,11 @@ template <int EPT>
 __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const OtEdge *__restrict__ edges, const unsigned short *__restrict__ waveLabel,
                                                             int nEdges, const PairDesc *__restrict__ pairs, int colSplit, int inputTape,
                                                             const int *__restrict__ tape, const double *__restrict__ fwd,
-                                                            const double *__restrict__ bwd, double *__restrict__ counts) {
+                                                            const double *__restrict__ bwd, double *__restrict__ counts, int normalise) {
   extern __shared__ double cl[];
   const int S = m.S, tid = threadIdx.x;
   double *Fl = cl, *Ba = cl + S, *Bb = cl + 2 * (long long)S;
+  float *zred = (float *)(cl + 3 * (long long)S);   // [16] per-wavefront sums of a column's emitting terms, two columns alternating
   const long long unit = blockIdx.x, p = unit / colSplit;
   const int part = (int)(unit - p * colSplit);
   const PairDesc pd = pairs[p];
@@ -1654,11 +1701,34 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
     for (int j = tid; j < S; j += 512) { Fl[j] = F[(long long)c * S + j]; Bcur[j] = B[(long long)c * S + j]; }
     __syncthreads();
     const int y = c < L ? tk[c] : -2;
+    // The terms of this column, and their NORMALISER.  In exact arithmetic the emitting transitions that leave column c sum to 1
+    // (every path crosses the boundary c | c + 1 exactly once: k_onetape_join) -- in the sweeps' arithmetic F(c, .) carries the
+    // rounding of c columns of log-sum-exp and B(c, .) of L - c, a random walk of ~1e-7 steps that reached 2e-4 per transition
+    // on 50 000 columns (test_baseline_config5_one_sequence_at_50kb_against_the_oracle) while the RATIOS inside a column stay
+    // good to 1e-7.  So every term of column c is divided by what its emitting terms sum to; the last column, which no
+    // transition leaves, by exp(F(L, end) - logLike), the same drift read off the end cell.
+    float t[EPT];
+    float zpart = 0.0f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (elab[k] == 0) acc[k] += (double)__builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bcur[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
-      else if (elab[k] == y) acc[k] += (double)__builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bnext[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
+      t[k] = 0.0f;
+      if (elab[k] == 0) t[k] = __builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bcur[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
+      else if (elab[k] == y) { t[k] = __builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bnext[esd[k] >> 16] + ewl[k])) * 1.44269504088896f); zpart += t[k]; }
     }
+    float inv;
+    if (normalise) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) zpart += __shfl_xor(zpart, off);
+      if ((tid & 63) == 0) zred[(c & 1) * 8 + (tid >> 6)] = zpart;
+      __syncthreads();
+      float z = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) z += zred[(c & 1) * 8 + w];
+      if (c == L) z = __builtin_amdgcn_exp2f((float)(Fl[S - 1] - ll) * 1.44269504088896f);
+      inv = (z > 0.0f && z < 3.0e38f) ? 1.0f / z : 1.0f;
+    } else inv = 1.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) acc[k] += (double)(t[k] * inv);
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
@@ -1670,11 +1740,12 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
 template <int EPT>
 static void launch_counts_lds(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, long long nUnits, int colSplit, bool inputTape,
                               const int *d_tape, const double *fwd, const double *bwd, double *d_counts, hipStream_t st) {
-  const size_t lds = (size_t)3 * m->S * sizeof(double);
+  const size_t lds = (size_t)3 * m->S * sizeof(double) + 16 * sizeof(float);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)&k_onetape_counts_lds<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_counts_lds<EPT>, dim3((unsigned)nUnits), dim3(512), lds, st, m->dev, (const OtEdge *)C.d_edges,
-                     (const unsigned short *)C.d_waveLabel, C.nWaves * 64, d_desc, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts);
+                     (const unsigned short *)C.d_waveLabel, C.nWaves * 64, d_desc, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts,
+                     env_int_w("MB_ONETAPE_COUNT_NORMALISE", 1));
 }
 
 bool wide_counts_build(const mb_machine *m, WideCountPlan &C) {
@@ -1746,8 +1817,18 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
   const int nEB = (C.nWaves + 3) / 4;
   const long long grid = ((nUnits + 7) / 8) * 8 * nEB;
   if (grid > 0x7fffffffll) { set_error("one-tape counts: launch too large"); return 1; }
+  float *d_norm = nullptr;
+  if (env_int_w("MB_ONETAPE_COUNT_NORMALISE", 1)) {
+    long long cols = 0;
+    for (const PairDesc &pd : hp) cols = std::max(cols, pd.cellBase / std::max(m->S, 1) + (inputTape ? pd.inLen : pd.outLen) + 1);
+    d_norm = (float *)ws_get(13, (size_t)std::max<long long>(cols, 1) * sizeof(float));
+    if (!d_norm) return 1;
+    int cs = 1;
+    while ((long long)hp.size() * cs < 1024 && (maxLen + 1) / (cs * 2) >= 16) cs *= 2;
+    hipLaunchKernelGGL(k_onetape_colnorm, dim3((unsigned)(hp.size() * cs)), dim3(256), 0, st, m->dev, d_desc, cs, inputTape ? 1 : 0, d_tape, fwd, bwd, d_norm);
+  }
   hipLaunchKernelGGL(k_onetape_counts, dim3((unsigned)grid), dim3(256), 0, st, m->dev, (const OtEdge *)C.d_edges,
-                     (const unsigned short *)C.d_waveLabel, C.nWaves, nEB, d_desc, nUnits, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts);
+                     (const unsigned short *)C.d_waveLabel, C.nWaves, nEB, d_desc, nUnits, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts, (const float *)d_norm);
   return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
 }
 

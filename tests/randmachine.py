@@ -45,3 +45,19 @@ def random_machine(S, nIn, nOut, seed, density=2.0, silent_density=1.2, dup=True
 
 def random_seq(rng, n, k):
     return rng.randint(1, k + 1, size=n).astype(np.int32) if k else np.zeros(0, np.int32)
+
+
+def plain_hmm(S, fan, nOut, seed):
+    """A generator in which every transition emits (a plain HMM: no silent level at all), `fan` transitions out of every
+    state but the last -- what gives the one-tape family's retimed sweep a period of ONE stage."""
+    rng = np.random.RandomState(seed)
+    edges = [(s, rng.randint(1, S), rng.randint(1, nOut + 1), float(np.log(rng.uniform(0.05, 1.0)))) for s in range(S - 1) for _ in range(fan)]
+    n = len(edges)
+    src = np.array([e[0] for e in edges], np.uint32); dst = np.array([e[1] for e in edges], np.uint32)
+    it = np.zeros(n, np.uint16); ot = np.array([e[2] for e in edges], np.uint16); lw = np.array([e[3] for e in edges], np.float64)
+    off = np.zeros(S + 1, np.int64)
+    for s in src:
+        off[s + 1] += 1
+    off = np.cumsum(off)
+    tidx = (np.arange(n) - off[src]).astype(np.uint32)
+    return EvaluatedMachine(S, Tokenizer([]), Tokenizer([chr(97 + k) for k in range(nOut)]), src, dst, it, ot, tidx, lw, off, [None] * S)
