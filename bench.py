@@ -194,6 +194,44 @@ def extra_single_gpu(capi, np, hbm_peak):
                       "loglike_sum": float(s4)}
     del b4c
 
+    # config 4 read LITERALLY ("C4b"): protpsw . translate . dnapsw with dnapsw's constraints cleared, composed
+    # here (482 states, 3095 transitions, 22 silent levels) -- the three modes on the config's own shape, each with its roofline
+    try:
+        from machineboss_amd import algebra as A4
+        t0 = time.perf_counter()
+        em4b = EvaluatedMachine.fromMachine(A4.config4bMachine(os.path.join(ROOT, "tests", "golden", "preset")), None, useDefaults=True)
+        tc4b = time.perf_counter() - t0
+        dm4b = capi.DeviceMachine(em4b)
+        bb = capi.DeviceBatch(dm4b, *synth_batch(4, 256, 487, 10000, em4b.nInTok, 3))      # DNA over {A,C,G}: no stop codons
+        cellsb = bb.cells()
+        llb, tfb = timed(lambda: bb.forward(capi.MB_MATERIALISE), 1); devfb = capi.last_device_ms(); kfb = capi.last_kernel_name()
+        _, trb = timed(lambda: bb.forward(capi.MB_ROLLING), 1)
+        del bb
+        bbv = capi.DeviceBatch(dm4b, *synth_batch(4, 64, 487, 10000, em4b.nInTok, 3))
+        cellsbv = bbv.cells()
+        (vb, offb, eb), tvb = timed(lambda: bbv.viterbi(paths=True), 1)
+        _, tvfb = timed(lambda: bbv.viterbi(paths=False), 1); devvfb = capi.last_device_ms()
+        del bbv
+        bbc = capi.DeviceBatch(dm4b, *synth_batch(4, 24, 487, 10000, em4b.nInTok, 3))      # two chunks of Backward matrices (18.8 GB each)
+        cellsbc = bbc.cells()
+        (cntb, sb, _), tcb = timed(lambda: bbc.counts(), 1); devcb = capi.last_device_ms()
+        del bbc
+        out["config4b"] = {"workload": "config 4 literally: protpsw . translate . dnapsw (dnapsw's constraints cleared; %d states, %d transitions), composed here in %.2f s; 256 / 64 / 24 pairs x 487 aa x 10000 nt" % (em4b.nStates, em4b.nTransitions, tc4b),
+                           "forward_materialised": round(cellsb / tfb / 1e9, 2), "forward_rolling": round(cellsb / trb / 1e9, 2), "unit": "Gcells/s",
+                           "viterbi_with_paths": round(cellsbv / tvb / 1e9, 2), "viterbi_fill": round(cellsbv / tvfb / 1e9, 2), "path_edges": int(offb[-1]),
+                           "counts_lattice": round(cellsbc / tcb / 1e9, 2), "loglike_checksum": float(np.sum(llb)), "viterbi_checksum": float(np.sum(vb)),
+                           "symbol_count_invariant": [float(cntb[np.asarray(em4b.inTok) != 0].sum()) / (24 * 487), float(cntb[np.asarray(em4b.outTok) != 0].sum()) / (24 * 10000)],
+                           "roofline": {"bound": "hbm", "achieved": round(8.0 * cellsb / (devfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
+                                        "frac": round(8.0 * cellsb / (devfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 8, "kernel": kfb, "what": "materialised Forward, 256 pairs"},
+                           "roofline_viterbi": {"bound": "valu", "achieved": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
+                                                "frac": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1},
+                           "roofline_counts": {"bound": "hbm", "achieved": round(16.0 * cellsbc / (devcb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
+                                               "frac": round(16.0 * cellsbc / (devcb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_lattice_cell": 16,
+                                               "note": "3 wavefronts per CU: the ring, one Backward supercell per column and 3095 accumulators leave 6 columns of LDS"}}
+        del dm4b
+    except Exception as e:
+        out["config4b"] = {"error": str(e)}
+
     # config 5: HMMER profile . simple_introns . translate . dnapsw assembled here (first 20 nodes of the fn3 profile: 5063
     # states, the "~5k states" of the config), a one-tape generator; 64 sequences x 2 kb (one workgroup per sequence)
     try:

@@ -339,9 +339,13 @@ static FastState *fast_state(mb_machine *m) {
       // machines whose silent sub-graph is deep and dense (protpsw.translate.dnapsw: 22 levels, 551 silent edges ->
       // 12 162 pairs) neither extreme is: the levels are closed in K groups, K chosen by a cost model
       // (candidate slots + 6 per synchronisation point), K = 0 meaning the levelled program.
-      auto cost = [](const MedProgram &P) {
+      // (round 4: a synchronisation point is priced at ONE slot, not six -- since the rounds of a stage issue their loads together
+      // (mb_medium_jit.cpp) the kernels are bound by vector issue, i.e. by candidates; measured on protpsw.translate.dnapsw: 12 level
+      // groups with 54 slots beat 5 with 75, rolling Forward 398 -> 432 G cells/s, psw2dna's choice does not change)
+      const int syncCost = env_int("MB_MEDIUM_SYNC_COST", 1), roundCost = env_int("MB_MEDIUM_ROUND_COST", 0);
+      auto cost = [syncCost, roundCost](const MedProgram &P) {
         long long c = 0;
-        for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + (ri.sync ? 6 : 0);
+        for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + roundCost + (ri.sync ? syncCost : 0);
         return c;
       };
       // Beyond even level groups: explicit stage boundaries, grown greedily -- the cut that lowers the cost most is added

@@ -141,7 +141,8 @@ inline int medium_default_G(int S) {   // measured with the specialised kernel: 
 // count sweep: LDS count atomics collide across the lanes of a wavefront that share a transition (few states: 16 columns
 // per wavefront, not 32); the Backward supercell per column in LDS caps the strip at 16 columns for psw2dna (271 states),
 // where 8 wavefronts x 2 columns (133 ms at 64 x 487 x 2 kb) beat 4 x 4 (150) and 16 x 1 (164)
-inline int medium_default_count_G(int S) { return S >= 128 ? std::min(medium_default_G(S), 2) : (S >= 24 ? medium_default_G(S) : 16); }
+// (round 4, flat count program: 482 states -- 6 columns of LDS whatever G is -- run 1 column per wavefront: 87 vs 76 G lattice-cells/s)
+inline int medium_default_count_G(int S) { return S >= 384 ? 1 : (S >= 128 ? std::min(medium_default_G(S), 2) : (S >= 24 ? medium_default_G(S) : 16)); }
 inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode == MED_MODE_COUNT ? 2 : (mode == MED_MODE_TB ? 3 : 0)); }
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
