@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--preset", default="psw2dna")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) measurements")
+    ap.add_argument("--extra-em-only", action="store_true", help="of the extras, only the EM iteration with its all-reduce (needs a rank group: N > 1 or MB_BENCH_FORCE_COMM=1)")
     return ap.parse_args(argv)
 
 
@@ -324,27 +325,24 @@ def main():
     args.gpus = world
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    # MB_BENCH_BACKEND=gloo MB_BENCH_SHARE_DEVICE=1: every rank on GPU 0 with the collectives on the host -- a dry run of
-    # the N > 1 code path on a one-GPU box (tests/test_gpu_parity.py); the real thing is "nccl" (= RCCL), one GPU per rank
-    backend = os.environ.get("MB_BENCH_BACKEND", "nccl")
-    if os.environ.get("MB_BENCH_SHARE_DEVICE") == "1":
-        local_rank = 0
-    cdev = "cuda" if backend == "nccl" else "cpu"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # The ranks (machineboss_amd/shard.py, RankGroup): ONE HIP runtime per process -- rendezvous, barriers and the max over ranks
+    # go over gloo on the host (torch never touches the GPU), the one data-path collective (E-step counts) over RCCL through the
+    # C-ABI on the library's own runtime and stream.  MB_BENCH_BACKEND: "rccl" (default), "nccl" (torch.distributed's NCCL
+    # backend = torch's RCCL on torch's runtime, the round-3 route), "gloo" + MB_BENCH_SHARE_DEVICE=1 (every rank on GPU 0, all
+    # collectives on the host: the dry run of the N > 1 path on a one-GPU box, tests/test_gpu_parity.py).
+    # MB_BENCH_FORCE_COMM=1: a one-rank RCCL communicator at N = 1 (bootstrap + collective exercised on one GPU).
+    from machineboss_amd.shard import RankGroup
+    grp = RankGroup.from_env(backend=os.environ.get("MB_BENCH_BACKEND"), force=os.environ.get("MB_BENCH_FORCE_COMM") == "1",
+                             share_device=os.environ.get("MB_BENCH_SHARE_DEVICE") == "1")
+    backend = grp.backend if grp else "none"
+    if grp:
+        local_rank = grp.local_rank
 
     from machineboss_amd import capi
     from machineboss_amd.machine import Machine
     from machineboss_amd.evalmachine import EvaluatedMachine
     from machineboss_amd.seqgen import synth_batch, synth_tokens
-    from machineboss_amd.shard import shard_range, lpt_assign, allreduce_counts
+    from machineboss_amd.shard import shard_range, lpt_assign
 
     capi.set_device(local_rank)
     m = Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", args.preset + ".json"))
@@ -371,10 +369,10 @@ def main():
     flags = capi.MB_MATERIALISE if args.mode == "materialise" else capi.MB_ROLLING
 
     def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        capi.synchronize()          # (hipDeviceSynchronize on the library's runtime: what torch.cuda.synchronize() is on torch's)
+        if grp:
+            grp.barrier()
+        capi.synchronize()
 
     ll = None
     for _ in range(args.warmup):
@@ -393,26 +391,24 @@ def main():
     kernel = capi.last_kernel_name()
     total_cells = cells_rank
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
+        dt = grp.all_reduce_float(dt, "max")
+        total_cells = grp.all_reduce_float(float(cells_rank), "sum")
     value = total_cells * args.steps / dt / 1e9
 
     extra = {}
     if world > 1:
         # every rank's share and clock: an imbalance (ragged shard, a slow device) shows as one rank's seconds standing out
-        rec = torch.tensor([float(rank), float(cells_rank), dt_rank, dev_ms / 1e3], dtype=torch.float64, device=cdev)
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        rows = sorted([[float(v) for v in r.tolist()] for r in allrec])
+        rows = sorted(grp.all_gather_floats([float(rank), float(cells_rank), dt_rank, dev_ms / 1e3]))
         extra["per_rank"] = [{"rank": int(r[0]), "cells_per_step": int(r[1]), "seconds": round(r[2], 4), "device_seconds": round(r[3], 4),
                               "gcells_per_s": round(r[1] * args.steps / max(r[2], 1e-12) / 1e9, 2)} for r in rows]
         slow = max(rows, key=lambda r: r[2])
         extra["slowest_rank"] = {"rank": int(slow[0]), "seconds": round(slow[2], 4), "over_mean": round(slow[2] / (sum(r[2] for r in rows) / world), 4)}
-    if world > 1 and not args.no_extra:
+        # what the sharding can deliver, per BASELINE config (pairs are independent units; nothing but --train's counts is exchanged)
+        extra["expected_scaling"] = {
+            "config 2-4 (batches of pairs, this line)": "weak scaling 1.0 per GPU by construction: every rank fills its own pairs, no data-path collective; strong scaling of 256 pairs over 8 GPUs leaves 32 pairs per GPU, whose tile wavefront still fills 256 CUs (672 live tiles per launch)",
+            "config 3 (--train)": "one all-reduce of nTransitions + 1 doubles (3.6 KB) per EM iteration: latency only",
+            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling 1.0x: a sequence is ONE workgroup (a one-tape lattice is serial along its columns), so 8 sequences per GPU take as long as 64 on one GPU (175 ms Forward); only a batch of more sequences than CUs scales (DESIGN.md 4.2b)"}
+    if grp and not args.no_extra:
         # the ONE collective of the path (--train): E-step on this rank's shard of config 3, then the all-reduce of
         # nTransitions + 1 doubles over RCCL (xGMI)
         mp = Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", "protpsw.json"))
@@ -421,21 +417,21 @@ def main():
         per = 1024
         bp = capi.DeviceBatch(dmp, *synth_batch(3, per, 400, 400, emp.nInTok, emp.nOutTok, first=rank * per))
         bp.counts()
-        seen = torch.ones(1, dtype=torch.float64, device=cdev); dist.all_reduce(seen)
+        seen = grp.all_reduce_float(1.0, "sum")
         sync(); t1 = time.perf_counter()
         its = 3
         for _ in range(its):
             cnt, s, _ = bp.counts()
             te = time.perf_counter()
-            cnt, s = allreduce_counts(cnt, s, cdev)
+            cnt, s = grp.allreduce_counts(cnt, s)
             tr = time.perf_counter() - te
         sync(); d1 = (time.perf_counter() - t1) / its
         nsym = float(cnt[np.asarray(emp.inTok) != 0].sum())
-        extra["em_iteration"] = {"workload": "config 3: protpsw --train E-step, %d x 400 x 400 aa per GPU + all-reduce of %d doubles (backend %s)" % (per, emp.nTransitions + 1, "nccl = RCCL" if backend == "nccl" else backend),
-                                 "ms_per_iteration": round(d1 * 1e3, 3), "allreduce_ms": round(tr * 1e3, 3), "n_ranks_seen": int(seen.item()),
+        extra["em_iteration"] = {"workload": "config 3: protpsw --train E-step, %d x 400 x 400 aa per GPU + all-reduce of %d doubles (backend %s)" % (per, emp.nTransitions + 1, {"rccl": "RCCL through the C-ABI", "nccl": "torch nccl = RCCL"}.get(backend, backend)),
+                                 "ms_per_iteration": round(d1 * 1e3, 3), "allreduce_ms": round(tr * 1e3, 3), "n_ranks_seen": int(round(seen)),
                                  "value": round(world * bp.cells() / d1 / 1e9, 2), "unit": "G lattice-cells/s over all ranks",
                                  "symbol_count_invariant": nsym / (world * per * 400)}
-    if world == 1 and rank == 0 and not args.no_extra:
+    if world == 1 and rank == 0 and not args.no_extra and not args.extra_em_only:
         other = capi.MB_ROLLING if flags == capi.MB_MATERIALISE else capi.MB_MATERIALISE
         _, d1 = timed(lambda: batch.forward(other))
         extra["rolling_gcells_per_gpu" if other == capi.MB_ROLLING else "materialised_gcells_per_gpu"] = round(cells_rank / d1 / 1e9, 3)
@@ -489,7 +485,7 @@ def main():
                "sample": "%d pairs (one per host core, concurrently) of %d aa x %d nt on %s (%.1f s wall), RollingOutputForwardMatrix restatement oracle/mb_oracle.c, table logsumexp"
                          % (cores, args.inlen, sample_out, args.preset, d2)}
 
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and not args.no_extra and not args.extra_em_only:
         extra.update(extra_single_gpu(capi, np, HBM_PEAK_GBS))
         nu = extra.get("nonuniform", {})
         emn, dmn = nu.pop("_em", None), nu.pop("_dm", None)
@@ -546,8 +542,8 @@ def main():
             "extra": extra,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if grp:
+        grp.close()
 
 
 if __name__ == "__main__":

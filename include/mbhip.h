@@ -52,6 +52,8 @@ enum {
 /* ---- process / device ------------------------------------------------------------------------------------ */
 int mb_device_count(void);        /* number of visible HIP devices (0 if none)                                 */
 int mb_set_device(int device);    /* one process drives one GPU (rank-local device)                            */
+int mb_synchronize(void);         /* wait for everything the library queued on its device (every compute entry point returns with its
+                                     results on the host already; this is the timing bracket of a multi-rank host, bench.py)   */
 const char *mb_last_error(void);  /* thread-local message of the last failing call                             */
 double mb_last_device_ms(void);   /* device time (HIP events on the library's stream) of the last batch call   */
 const char *mb_last_kernel_name(void); /* name of the dominant kernel of the last batch call (for profiles)     */

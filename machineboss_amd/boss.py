@@ -200,6 +200,9 @@ def collectData(args, machine: Machine, inferenceRequested: bool) -> List[SeqPai
     return data
 
 
+_GROUP = None      # shard.RankGroup of this process when launched as one rank of several (main() opens it)
+
+
 def _dist():
     try:
         import torch.distributed as dist
@@ -208,6 +211,16 @@ def _dist():
     except Exception:
         pass
     return None
+
+
+def _reduce_counts(counts, loglike):
+    """Sum of the E-step statistics over the ranks (MachineCounts::operator+=, src/counts.cpp:66-71): RCCL through the C-ABI when
+    main() opened the ranks (shard.RankGroup), torch.distributed's own group when a host program opened one."""
+    if _GROUP is not None:
+        return _GROUP.allreduce_counts(counts, loglike)
+    from .shard import allreduce_counts
+    import torch
+    return allreduce_counts(counts, loglike, "cuda" if (torch.cuda.is_available() and _dist().get_backend() == "nccl") else "cpu")
 
 
 def _shard(data: List[Any], machine, world: int) -> List[List[int]]:
@@ -266,17 +279,12 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
     from . import dp
     if args.train:
         from .fitter import MachineFitter, combineConstraints
-        from .shard import allreduce_counts
         if not ((args.constraints or not machine.cons.empty()) and (gotData or noIO)):
             raise MachineError("To fit parameters, please specify a constraints file and (for machines with input/output) a data file")
         fitter = MachineFitter(machine, constraints, funcs)
         sd = combineConstraints(machine.cons, constraints).defaultParams(); sd.update(seed)
         fitter.seed = sd
-        reduce = None
-        if world > 1:
-            import torch
-            dev = "cuda" if torch.cuda.is_available() else "cpu"
-            reduce = lambda counts, ll: allreduce_counts(counts, ll, dev)
+        reduce = _reduce_counts if world > 1 else None
         params = fitter.fit(mine, args.wiggle_room, reduce)
         emit("{" + ",".join('"%s":%s' % (escaped(k), fmtParam(params[k])) for k in sorted(params)) + "}\n")
     else:
@@ -294,9 +302,7 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
         ev = EvaluatedMachine.fromMachine(machine, params)
         counts = dp.MachineCounts(ev, mine)
         if world > 1:
-            import torch
-            from .shard import allreduce_counts
-            _, counts.loglike = allreduce_counts(counts._flat, counts.loglike, "cuda" if torch.cuda.is_available() else "cpu")
+            _, counts.loglike = _reduce_counts(counts._flat, counts.loglike)
         pc = counts.paramCounts(machine, params)
         emit("{" + ",".join('"%s":%s' % (escaped(k), "%g" % pc[k]) for k in sorted(pc)) + "}\n")
 
@@ -316,32 +322,17 @@ def run(argv: Optional[List[str]] = None, out=None) -> int:
 
 
 def _init_ranks():
-    """Launched under torchrun (WORLD_SIZE > 1): bind this rank to its GPU and open the process group BEFORE the first
-    GPU call, so that run() shards the pair list and reduces the counts (backend nccl = RCCL on GPUs, gloo without).
-    Returns the torch.distributed module if this call opened the group (the caller closes it), else None."""
+    """Launched under torchrun (WORLD_SIZE > 1): bind this rank to its GPU and open the ranks BEFORE the first GPU call, so that
+    run() shards the pair list and reduces the counts (shard.RankGroup: rendezvous over gloo, the count reduction over RCCL
+    through the C-ABI; MB_DIST_BACKEND = gloo puts several ranks on ONE GPU for the tests).  Returns the group if this call
+    opened it (the caller closes it), else None."""
+    global _GROUP
     import os
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or _dist() is not None:
         return None
-    import torch
-    import torch.distributed as dist
-    if dist.is_initialized():
-        return None
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    backend = os.environ.get("MB_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")   # gloo: several ranks on ONE GPU (tests)
-    if torch.cuda.is_available() and backend != "nccl":
-        from . import capi
-        capi.set_device(local)
-        dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world)
-    elif torch.cuda.is_available():
-        from . import capi
-        capi.set_device(local)
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=world, device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=world)
-    return dist
+    from .shard import RankGroup
+    _GROUP = RankGroup.from_env()
+    return _GROUP
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -354,7 +345,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         return 1
     finally:
         if opened is not None:
-            opened.destroy_process_group()
+            global _GROUP
+            opened.close(); _GROUP = None
 
 
 if __name__ == "__main__":

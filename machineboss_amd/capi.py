@@ -19,7 +19,7 @@ MB_MATERIALISE, MB_ROLLING = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SMALL, KERNEL_MEDIUM = 0, 1, 2, 3
 
 EXPORTS = [
-    "mb_device_count", "mb_set_device", "mb_last_error", "mb_last_device_ms", "mb_last_kernel_name", "mb_last_launch_count",
+    "mb_device_count", "mb_set_device", "mb_synchronize", "mb_last_error", "mb_last_device_ms", "mb_last_kernel_name", "mb_last_launch_count",
     "mb_machine_create", "mb_machine_set_weights", "mb_machine_destroy", "mb_machine_n_states", "mb_machine_n_trans",
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
@@ -158,8 +158,14 @@ def last_kernel_name() -> str:
     return load().mb_last_kernel_name().decode()
 
 
+def synchronize():
+    """Wait for everything the library queued on its device (the timing bracket of a multi-rank host)."""
+    _check(load().mb_synchronize())
+
+
 class Comm:
-    """RCCL communicator of the C-ABI (mb_comm*): the route a C++ host takes; Python hosts use torch.distributed (shard.py)."""
+    """RCCL communicator of the C-ABI (mb_comm*) on the library's own HIP runtime and stream: what a C++ host uses, and what
+    shard.RankGroup opens for the Python hosts (bench.py, boss.py)."""
 
     def __init__(self, unique_id: bytes, nRanks: int, rank: int):
         self.h = load().mb_comm_init(unique_id, nRanks, rank)

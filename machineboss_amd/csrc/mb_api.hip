@@ -52,6 +52,7 @@ struct ApiLock {
   std::lock_guard<std::recursive_mutex> lk;
   ApiLock() : lk(g_api_mutex) {}
 };
+bool g_deterministic = false;
 static int g_device = -1;   // device the library's stream and workspaces live on
 
 static int ensure_init() {
@@ -309,6 +310,8 @@ struct FastState {
   MedGeom geoCnt;
   // large one-tape machines (mb_wide.hip): programs built on first use, rebuilt after a weight update
   WideProgram wFwd, wBwd, wVit;
+  WideProgram wVitTb;        // ... the max program that keeps one traceback code per cell (`--align` without the fp64 matrix)
+  bool wVitTbTried = false;
   WideCountPlan wCnt;        // posterior counts of one-tape machines (any size): lane = transition
   WideTbPlan wTb;            // Viterbi traceback of one-tape machines too large for the LDS edge tables of mb_generic.hip
   // machines with a handful of states (mb_small.cpp): lane = column, states in registers
@@ -484,6 +487,23 @@ static bool onetape_tiled_viterbi(mb_machine *m) {
     f->exactOk = medium_build(m, false, 0, G, f->fwdExact, f->geoFE);
   }
   return f->exactOk;
+}
+
+// One-tape machines, `--viterbi / --align` with paths: the retimed max sweep keeping ONE traceback code per cell (mb_wide.hip,
+// WideProgram::tbCodes) -- nullptr when the machine has no such program (no retimed form, a fan-in beyond 256, more than 2^15
+// states or 2^16 transitions, a silent self-loop on state 0, MB_ONETAPE_TB=0): the fp64 matrix and its walkers take it then
+static WideProgram *wide_tb_program(mb_machine *m) {
+  if (g_kernel_choice == 1 || !wide_applicable(m) || !env_int("MB_ONETAPE_TB", 1)) return nullptr;
+  FastState *f = fast_state(m);
+  WideProgram &P = f->wVitTb;
+  if (!f->wVitTbTried || (P.ok && P.dirty)) {
+    f->wVitTbTried = true;
+    for (long long e = 0; e < m->nTrans; ++e)
+      if (m->inTok[e] == 0 && m->outTok[e] == 0 && m->dst[e] <= m->src[e]) return nullptr;      // (a candidate of the traceback but not of the fill)
+    P.tbCodes = true;
+    if (!wide_build(m, false, true, P)) return nullptr;
+  }
+  return (P.ok && P.retOk && P.tbOk) ? &P : nullptr;
 }
 
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
@@ -734,6 +754,12 @@ static int small_counts(mb_batch *b, double *counts, double *loglikeSum, double 
     if (nT && !hip_ok(hipMemcpy(hc.data(), d_rep, hc.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) { rc = 1; break; }
     if (!hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
     for (long long e = 0; e < nT; ++e) {
+      if (g_deterministic) {      // fixed point, 2^-36: the replicas add up as integers
+        long long tot = 0;
+        for (int r = 0; r < SMALL_COUNT_REPLICAS; ++r) { long long u; std::memcpy(&u, &hc[(size_t)r * nT + e], 8); tot += u; }
+        counts[e] += (double)tot / MB_DET_GLOBAL_SCALE;
+        continue;
+      }
       double s = 0.0;
       for (int r = 0; r < SMALL_COUNT_REPLICAS; ++r) s += hc[(size_t)r * nT + e];
       counts[e] += s;
@@ -795,6 +821,13 @@ int mb_set_device(int device) {
     return 1;
   }
   MB_HIP(hipSetDevice(device));
+  return 0;
+}
+
+int mb_synchronize(void) {
+  ApiGuard guard;
+  if (!g_init) return 0;      // nothing was ever queued
+  MB_HIP(hipDeviceSynchronize());
   return 0;
 }
 
@@ -896,7 +929,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
     if (f->countOk && !medium_refresh_weights(m, f->fwdCnt)) return 1;
     if (f->tbOk && !medium_refresh_weights(m, f->fwdTb)) return 1;
     if (f->smallOk && !(small_refresh_weights(m, f->smF) && small_refresh_weights(m, f->smB))) return 1;
-    f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = true;
+    f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = f->wVitTb.dirty = true;
   }
   return 0;
 }
@@ -907,7 +940,7 @@ void mb_machine_destroy(mb_machine *m) {
   if (m->fast) {
     FastState *f = (FastState *)m->fast;
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt); medium_free(f->fwdTb);
-    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_counts_free(f->wCnt); wide_traceback_free(f->wTb);
+    wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_free(f->wVitTb); wide_counts_free(f->wCnt); wide_traceback_free(f->wTb);
     small_free(f->smF); small_free(f->smB);
     delete f;
   }
@@ -1188,9 +1221,10 @@ int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen
 
 // ViterbiMatrix over a batch on the tiled / generic families.  tb: ONE traceback byte per cell instead of the fp64 matrix (tiled
 // family, run-time specialised kernel; returns -1 before anything was written when that kernel is unavailable).
-static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap, bool tb) {
+// tb: 0 = fp64 Viterbi matrices, 1 = the tiled family's traceback bytes, 2 = the one-tape family's traceback codes
+static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap, int tb) {
   const bool wantPaths = pathEdges != nullptr && pathOff != nullptr;
-  const int Sb = medium_tb_stride(b->m->S);
+  const int Sb = tb == 2 ? wide_tb_stride(b->m->S) : medium_tb_stride(b->m->S);
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, 1, chunks, tb ? (double)Sb / b->m->S + 0.01 : 0.0)) return 1;
   int rc = 0;
@@ -1213,7 +1247,12 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
       if (!hip_ok(sm_alloc((void **)&d_ll, np * sizeof(double)), "hipMalloc")) { rc = 1; break; }
       lap("chunk set-up");
       tm.start();
-      if (tb) {
+      if (tb == 2) {
+        WideProgram *W = wide_tb_program(b->m);
+        if (!W) { rc = c.p0 > 0 ? 1 : -1; if (rc > 0) set_error("one-tape traceback-code program became unavailable mid-batch"); break; }
+        if ((rc = wide_fill_tb(b->m, *W, d_desc, np, b->m->nOut ? b->d_out : b->d_in, (unsigned char *)pool, d_ll, g_stream))) break;
+        g_last_kernel = W->retGv ? "k_wide_retimed<1,L2,codes>" : "k_wide_retimed<1,codes>";
+      } else if (tb) {
         MedEnv me;
         if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
         if ((rc = launch_fill_neg_inf(d_ll, np, g_stream))) break;   // (a pair whose end cell lies in a tile that does not run)
@@ -1235,7 +1274,8 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
         if (!(d_len = (long long *)ws_get(4, np * sizeof(long long)))) { rc = 1; break; }
         if (!(d_path = (uint32_t *)ws_get(5, std::max<long long>(slot[np], 1) * sizeof(uint32_t)))) { rc = 1; break; }
         if (!hip_ok(hipMemcpyAsync(d_slot, slot.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
-        if (tb) { if ((rc = launch_traceback_bytes(b->m, d_desc, np, b->d_in, b->d_out, (const unsigned char *)pool, Sb, d_ll, d_slot, d_path, d_len, g_stream))) break; }
+        if (tb == 2) { if ((rc = wide_traceback_codes(b->m, *wide_tb_program(b->m), d_desc, np, (const unsigned char *)pool, d_ll, d_slot, d_path, d_len, g_stream))) break; }
+        else if (tb) { if ((rc = launch_traceback_bytes(b->m, d_desc, np, b->d_in, b->d_out, (const unsigned char *)pool, Sb, d_ll, d_slot, d_path, d_len, g_stream))) break; }
         else {
           // one-tape machines beyond the LDS edge tables of the generic walkers: columns in LDS, one trip to memory per step
           WideTbPlan *T = nullptr;
@@ -1301,12 +1341,24 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   MedGeom *tbGeo = nullptr;
   if (!wide_applicable(b->m) && use_medium(b->m) && env_int("MB_MEDIUM_TB", 1) && medium_tb_program(b->m, &tbGeo) &&
       traceback_bytes_lds(b->m, medium_tb_stride(b->m->S))) {
-    const int rc = viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, true);
+    const int rc = viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, 1);
     if (rc >= 0) return rc;
     g_last_ms = 0.0; g_last_launches = 0;
     if (pathOff) pathOff[0] = 0;
   }
-  return viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, false);
+  // one-tape family: one traceback code per cell when paths are wanted (a fill without paths keeps the leaner fp64 sweep)
+  // MB_ONETAPE_TB: 1 always, 0 never, unset: when the fp64 Viterbi matrices of the batch would take more than a quarter of the memory
+  // budget -- the code sweep is ~25 % slower than the plain max sweep (two more vector instructions per candidate, a (value, place)
+  // reduction), its walker 2 x faster than the fp64 walker, and it needs an eighth of the memory: 64 x 50 kb on the 5 063-state
+  // machine 373 vs 348 ms with 16 instead of 130 GB; the whole fn3 composite at that size (557 GB of fp64) runs only this way
+  const bool tbWanted = getenv("MB_ONETAPE_TB") ? env_int("MB_ONETAPE_TB", 1) != 0 : (double)b->totalCells * 8.0 > 0.25 * (double)budget_bytes();
+  if (pathEdges && pathOff && !b->hasEnv && tbWanted && wide_tb_program(b->m)) {
+    const int rc = viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, 2);
+    if (rc >= 0) return rc;
+    g_last_ms = 0.0; g_last_launches = 0;
+    pathOff[0] = 0;
+  }
+  return viterbi_chunks(b, loglike, pathOff, pathEdges, pathCap, 0);
 }
 
 // ---- Forward-Backward counts --------------------------------------------------------------------------------
@@ -1413,6 +1465,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
     if (nT && !hip_ok(hipMemcpy(hc.data(), d_counts, nT * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) rc = 1;
     if (!rc && !hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
     if (!rc) {
+      if (g_deterministic) for (long long e = 0; e < nT; ++e) { long long u; std::memcpy(&u, &hc[e], 8); hc[e] = (double)u / MB_DET_GLOBAL_SCALE; }   // fixed point, 2^-36
       for (long long e = 0; e < nT; ++e) counts[e] += hc[e];
       double s = 0;
       for (long long p = 0; p < b->nPairs; ++p) { s += hll[p]; if (loglike) loglike[p] = hll[p]; }  // loglike += forward.logLike()
@@ -1428,6 +1481,7 @@ int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *log
   if (!b || !counts) { set_error("null argument"); return 1; }
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
+  g_deterministic = env_int("MB_DETERMINISTIC", 0) != 0;
   if (b->nPairs == 0) return 0;
   if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF, b->hasEnv) && small_can_run(((FastState *)b->m->fast)->smB, SM_SUM, true, b->hasEnv))
     return small_counts(b, counts, loglikeSum, loglike);

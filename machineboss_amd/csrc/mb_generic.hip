@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_generic_counts(DevMachine m, const Pair
                                                         const int *__restrict__ inTok, const int *__restrict__ outTok,
                                                         const double *__restrict__ fwdPool,
                                                         const double *__restrict__ bwdPool, long long nTrans,
-                                                        int chunksPerPair, double *__restrict__ counts) {
+                                                        int chunksPerPair, double *__restrict__ counts, int det) {
+  // det (deterministic mode, mb_internal.h): both tables hold 64-bit fixed point at 2^-36 -- every term is below 1, integer adds commute
   __shared__ double lcount[MB_COUNTS_LDS_MAX];
   const bool useLds = nTrans <= MB_COUNTS_LDS_MAX;
   if (useLds) {
@@ -176,8 +177,9 @@ __global__ __launch_bounds__(256) void k_generic_counts(DevMachine m, const Pair
           const double tll = dc[m.outDst[a]] + m.outW[a];
           const double c = exp(logOdds + tll);
           if (c != 0.0) {
-            if (useLds) atomicAdd(&lcount[m.outEid[a]], c);
-            else atomicAdd(&counts[m.outEid[a]], c);
+            double *tab = useLds ? lcount : counts;
+            if (det) atomicAdd((unsigned long long *)tab + m.outEid[a], (unsigned long long)(c * 68719476736.0 + 0.5));
+            else atomicAdd(&tab[m.outEid[a]], c);
           }
         }
       }
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(256) void k_generic_counts(DevMachine m, const Pair
   if (useLds) {
     __syncthreads();
     for (int e = threadIdx.x; e < nTrans; e += blockDim.x)
-      if (lcount[e] != 0.0) atomicAdd(&counts[e], lcount[e]);
+      if (det ? ((const unsigned long long *)lcount)[e] != 0ull : lcount[e] != 0.0) {
+        if (det) atomicAdd((unsigned long long *)counts + e, ((const unsigned long long *)lcount)[e]);
+        else atomicAdd(&counts[e], lcount[e]);
+      }
   }
 }
 
@@ -473,7 +478,7 @@ int launch_generic_counts(const mb_machine *m, const PairDesc *d_pairs, long lon
   if (chunks > maxChunks) chunks = maxChunks;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(k_generic_counts, dim3((unsigned)(nPairs * chunks)), dim3(256), 0, st, m->dev, d_pairs, d_in, d_out,
-                     d_fwd, d_bwd, m->nTrans, (int)chunks, d_counts);
+                     d_fwd, d_bwd, m->nTrans, (int)chunks, d_counts, g_deterministic ? 1 : 0);
   return hip_ok(hipGetLastError(), "counts launch") ? 0 : 1;
 }
 

@@ -93,6 +93,14 @@ struct mb_batch {
 
 namespace mb {
 void set_error(const std::string &msg);
+// MB_DETERMINISTIC=1 (read when a count call begins): posterior counts are summed in 64-bit FIXED POINT wherever the order of the
+// additions depends on scheduling (LDS accumulators shared by wavefronts, global accumulators shared by tiles) -- integer addition
+// is associative, so `--counts / --train` reproduce bit for bit from run to run like the reference's serial loop
+// (src/counts.cpp:37-64).  Scales: 2^-44 inside a tile (a tile's partial sum stays below 2^11), 2^-36 in global memory (a count
+// below 1.3e8 per call); lane-private partial sums (registers, fixed shuffle trees) are deterministic as they are.
+extern bool g_deterministic;
+constexpr double MB_DET_TILE_SCALE = 17592186044416.0;   // 2^44
+constexpr double MB_DET_GLOBAL_SCALE = 68719476736.0;     // 2^36
 bool hip_ok(hipError_t e, const char *what);
 extern hipStream_t g_stream;
 extern thread_local long long g_last_launches;   // kernel launches of the dominant kernel in the last batch call

@@ -46,7 +46,7 @@ struct MedTileArgs {
   const long long *haloBase;  // rolling mode: per pair offset (in doubles) of its two buffers
   double *loglike;            // loglike[pairBase + blockIdx.y], written when the end cell is finalised (may be null)
   const int2 *tiles;          // materialised mode: (pair, strip) of workgroup tileBase + blockIdx.x
-  int C, TS, launch, rev, materialise, tileBase, pad0;
+  int C, TS, launch, rev, materialise, tileBase, det;   // det: specialised kernel, count mode: accumulators in 64-bit fixed point (g_deterministic)
   const double *poolB;        // count mode (specialised kernel only): Backward matrices, same layout and cellBase as pool
   double *counts;             // count mode: [nTrans] posterior transition counts, accumulated with fp64 atomics
   const int *envStart, *envEnd;   // restricted envelopes (specialised kernel, JENV variant): rows at PairDesc::envBase
@@ -1058,7 +1058,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
-  A.poolB = d_poolB; A.counts = d_counts; A.envStart = env.d_start; A.envEnd = env.d_end;
+  A.poolB = d_poolB; A.counts = d_counts; A.envStart = env.d_start; A.envEnd = env.d_end; A.det = g_deterministic ? 1 : 0;
   if (roll) { A.colHalo = roll->halo; A.haloBase = roll->haloBase; A.bound = roll->bound; A.boundBase = roll->boundBase; A.tb = roll->tb; }
   const dim3 block(geo.waves * 64);
   hipEvent_t evStart = nullptr, evDone = nullptr;

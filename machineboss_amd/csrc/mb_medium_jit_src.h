@@ -36,7 +36,7 @@ struct MedTileArgs {
   const long long *haloBase;
   double *loglike;
   const int2 *tiles;
-  int C, TS, launch, rev, materialise, tileBase, pad0;
+  int C, TS, launch, rev, materialise, tileBase, det;      // det: counts in 64-bit fixed point (MB_DETERMINISTIC, mb_internal.h)
   const double *poolB;
   double *counts;
   const int *envStart, *envEnd;
@@ -80,12 +80,13 @@ __device__ __forceinline__ Rec ld_l(const char *base, unsigned off) { return mk_
 __device__ __forceinline__ double med_lds(const char *ldsb, int off) { return *(const double *)(ldsb + off); }
 __device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((float)d * MED_L2E); }
 // count mode: add exp(x) to the LDS accumulator at byte offset off (ds_add_f64; lanes of one column never collide)
-__device__ __forceinline__ void cnt_add(const char *ldsb, unsigned off, double x) {
-  (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)ex2(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// deterministic mode (jdet = MedTileArgs::det in scope): the LDS accumulators hold 64-bit fixed point at 2^-44 -- integer adds commute
+#define cnt_flush(l, o, a) cnt_flush_(l, o, a, jdet)
+__device__ __forceinline__ void cnt_flush_(const char *ldsb, unsigned off, float acc, int jdet) {
+  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)(ldsb + off), (unsigned long long)((double)acc * 17592186044416.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void cnt_flush(const char *ldsb, unsigned off, float acc) {
-  (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+#define cnt_add(l, o, x) cnt_flush_(l, o, ex2(x), jdet)
 __device__ __forceinline__ void med_block_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
@@ -125,8 +126,8 @@ __device__ __forceinline__ void med_copy_out(double *dstp, const double *cur, in
 // generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
 __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
                                                 int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
-                                                unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL, int tbCol) {
-  double accM = NEG_INF; float accS = 0.0f;
+                                                unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL, int tbCol, int jdet) {
+  double accM = NEG_INF; float accS = 0.0f; (void)jdet;
   unsigned code = 0u, prevT = 99u, jT = 0u;   // JTB: (table << 6 | index in the table's list) of the first maximal candidate
   (void)code; (void)prevT; (void)jT; (void)tbCol;
   for (int ch = 0; ch < nChunks; ++ch) {
@@ -186,6 +187,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   constexpr int LPG = 64 / JG, S = JS, Spad = JSPAD, NS = JNS, C = JC, W = JTOKW, NT = JWAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane / LPG, q = lane - g * LPG;
+  const int jdet = A.det; (void)jdet;
   int pairIdx, a;
   bool prevDead = false;      // JMAT == 2 with envelopes: the block before this one holds no cell of the envelope and did not run
   if (JTILES) { const int2 tl = A.tiles[A.tileBase + blockIdx.x]; pairIdx = tl.x; a = tl.y & 0x3fffffff; prevDead = (tl.y >> 30) & 1; }
@@ -417,7 +419,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     (void)aCur; (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
     if (t == 0 && a == 0) {
       if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
-                                      P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff);
+                                      P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff, jdet);
     } else {
 #if JTB
       unsigned char *tbCol = tbL + c * JTBS;
@@ -511,6 +513,11 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   __syncthreads();
   // flush the workgroup's counts: one fp64 atomic per transition that was used in this tile
   for (int e = tid; e < JNTRANS; e += NT) {
+    if (jdet) {      // 2^-44 in the tile -> 2^-36 in global memory, rounded
+      const unsigned long long u = ((const unsigned long long *)accL)[e];
+      if (u) (void)__hip_atomic_fetch_add((unsigned long long *)A.counts + e, (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
     const double x = accL[e];
     if (x != 0.0) (void)__hip_atomic_fetch_add(A.counts + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

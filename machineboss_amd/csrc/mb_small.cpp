@@ -256,8 +256,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ void lds_add_f32(float *p, float x) {
   (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void lds_add_f64(double *p, double x) {
-  (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// the workgroup's count table: fp64, or -- deterministic mode (jdet in scope: bit 16 of SmallArgs::nRep, mb_internal.h
+// g_deterministic) -- 64-bit fixed point at 2^-44, whose additions commute
+#define lds_add_f64(p, x) lds_add_f64_(p, x, jdet)
+__device__ __forceinline__ void lds_add_f64_(double *p, double x, int jdet) {
+  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)(x * 17592186044416.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A) {
@@ -265,6 +269,7 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
   // the wavefront index is uniform inside a wavefront, which the compiler cannot see: taken through readfirstlane,
   // everything derived from it (the tile, its pair descriptor, every base address) lives in scalar registers
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jdet = A.nRep >> 16; (void)jdet;
   double *wL = lds;                                          // output-token and match weight tables
 #if JMODE == 3
   double *accT = lds + JLDSW;                                // posterior counts of this workgroup's tiles
@@ -395,8 +400,13 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
 #if JMODE == 3
   __syncthreads();
   {
-    double *rep = A.counts + (long long)(blockIdx.x % A.nRep) * JNTRANS;
+    double *rep = A.counts + (long long)(blockIdx.x % (A.nRep & 0xffff)) * JNTRANS;
     for (int e = tid; e < JNTRANS; e += 256) {
+      if (jdet) {      // 2^-44 in the workgroup -> 2^-36 in global memory, rounded
+        const unsigned long long u = ((const unsigned long long *)accT)[e];
+        if (u) (void)__hip_atomic_fetch_add((unsigned long long *)rep + e, (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       const double x = accT[e];
       if (x != 0.0) (void)__hip_atomic_fetch_add(rep + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -783,7 +793,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   const int4 *d_tiles = (const int4 *)tc.d_tiles;
   lap("tile list upload");
   SmallArgsHost A{};
-  A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1);
+  A.pairs = sw.d_pairs; A.inTok = sw.d_in; A.outTok = sw.d_out; A.tiles = d_tiles; A.TS = TS; A.nRep = std::max(sw.nRep, 1) | (g_deterministic ? 1 << 16 : 0);
   A.pool = sw.d_pool; A.tb = sw.d_tb; A.halo = sw.d_halo; A.bound = sw.d_bound; A.aux = sw.d_aux; A.loglike = sw.d_loglike;
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
   A.envStart = sw.d_envStart; A.envEnd = sw.d_envEnd;

@@ -144,6 +144,13 @@ struct WideProgram {
   WideRetDev ret{};
   size_t retLdsBytes = 0;
   int retPeriod = 0, retTauMax = 0, retPeriodMin = 0;
+  // Viterbi with ONE TRACEBACK CODE per cell instead of the fp64 cell (round 4; requested with tbCodes before wide_build): the
+  // retimed max sweep also keeps, per state, the PLACE of its first maximal candidate in the reference's enumeration order
+  // (emitting transitions, then silent ones, each in `incoming` order; src/dpmatrix.defs.h:93-103) and stores that byte;
+  // tbEntry[tbOff[state] + code] = position in the incoming view << 16 | emitting << 15 | source state (0xFFFFFFFF: the seed)
+  bool tbCodes = false, tbOk = false;
+  int *d_tbOff = nullptr; uint32_t *d_tbEntry = nullptr;
+  long long tbEntries = 0;
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
@@ -162,6 +169,15 @@ bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly = false);
 const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
+// ViterbiMatrix::fill keeping one traceback code per cell (P.tbOk): tb = bytes, wide_tb_stride(S) per column, PairDesc::cellBase =
+// BYTE offset of the sequence's first column; scores of the end cells in loglike
+inline int wide_tb_stride(int S) { return (S + 3) & ~3; }
+int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, unsigned char *tb,
+                 double *loglike, hipStream_t st);
+// ... and DPMatrix::traceBack over those codes: one workgroup per sequence, its first lane walks a window of code rows in LDS that
+// the other wavefronts refill ahead of it (and the decode table, when it fits beside the window)
+int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDesc *d_pairs, long long nPairs, const unsigned char *tb,
+                         const double *d_loglike, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen, hipStream_t st);
 // Two sweeps (e.g. Forward over one set of pairs, Backward over another) in ONE launch: workgroups 0..nA-1 run program A,
 // the rest program B, so both are on the chip together whatever the queue scheduler does with two streams.  Returns -1
 // (nothing launched) when the two programs do not share a kernel variant.

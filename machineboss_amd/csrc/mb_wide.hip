@@ -307,7 +307,27 @@ __device__ __forceinline__ void wide_lds_write(unsigned a, double v) { *(wide_ld
 
 // GV: the ring lives in an L2-resident scratch vector of the workgroup (machines whose ring exceeds the LDS: the whole fn3
 // profile composite, 21 761 states); penalties and the token window stay in LDS.  Records then carry ring ENTRIES (src >> 13).
-template <int MODE, bool GV>
+// lane-group reduction of (value, place): the maximum, and among equal maxima the SMALLEST place -- the first maximum of the
+// reference's enumeration (std::max_element, src/dpmatrix.defs.h:171-174); lanes of a group hold places slot * g + lane
+template <int H>
+__device__ __forceinline__ void wide_tb_step(double &m, uint32_t &key, int g) {
+  const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
+  const uint32_t ko = (uint32_t)wide_xor_lane<H>((int)key);
+  const bool take = (H < g) && (mo > m || (mo == m && ko < key));
+  m = take ? mo : m; key = take ? ko : key;
+}
+__device__ __forceinline__ void wide_group_reduce_tb(double &m, uint32_t &key, int g, int gWave) {
+  if (gWave > 1) wide_tb_step<1>(m, key, g);
+  if (gWave > 2) wide_tb_step<2>(m, key, g);
+  if (gWave > 4) wide_tb_step<4>(m, key, g);
+  if (gWave > 8) wide_tb_step<8>(m, key, g);
+  if (gWave > 16) wide_tb_step<16>(m, key, g);
+  if (gWave > 32) wide_tb_step<32>(m, key, g);
+}
+
+// TB (max sweep only): `pool` holds one traceback CODE per cell (bytes, wide_tb_stride(S) per column, PairDesc::cellBase = byte
+// offset) instead of the fp64 cell -- the place of the cell's first maximal candidate in its node's list (WideProgram::tbCodes)
+template <int MODE, bool GV, bool TB = false>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
   extern __shared__ double wlds[];
@@ -326,7 +346,11 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   __syncthreads();
   if (tid < NB) V[tid * NVs + S + 1] = 0.0;         // the seed's source, in every ring vector
   const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
-  double *cells = pool ? pool + pd.cellBase : nullptr;
+  double *cells = (pool && !TB) ? pool + pd.cellBase : nullptr;
+  unsigned char *codes = (pool && TB) ? (unsigned char *)pool + pd.cellBase : nullptr;
+  const int Sb = (S + 3) & ~3;
+  uint32_t bestSlot = 0u; int slotInRound = 0;                 // TB: slot of this lane's first maximal candidate within the round
+  (void)codes; (void)Sb; (void)bestSlot; (void)slotInRound;
   auto tokAt = [&](int c) -> int { return (c >= 1 && c <= L) ? (P.backward ? out[L - c] : out[c - 1]) : 0; };
   if (tid == 0) tokWin[1] = tokAt(1);
   int tokNext = tid == 0 ? tokAt(2) : 0;
@@ -374,6 +398,9 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
     for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; wide_lds_write(penNxt + (unsigned)e * 8u, penalty(kt, e - kt * rowLen, t + 1)); }
     const int cBase = P.backward ? t : t - Q.kMax;
     const char *rowPtr = (const char *)(P.lastOnly ? cells : cells + (long long)(P.backward ? L - t : t - Q.kMax) * S);
+    unsigned char *codeRow = TB ? codes + (long long)(t - Q.kMax) * Sb : nullptr;      // (forward sweeps only: column cBase = t - kMax)
+    (void)codeRow;
+    slotInRound = 0;      // (the padding slots behind the period's last round -- all -inf -- have been counted)
     const int streamBase = cm * perStreamBytes;
     for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
       // (the slot after this period's last one belongs to the next period: its penalties are the other table's)
@@ -388,12 +415,20 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
         vAhead = ring(nx.src);
         pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
         const double cand = vNow + (rc.w + pNow);              // w + 0.0 = w, w + -inf = -inf: the reference's one rounded add, or -inf
+        if (TB) { bestSlot = cand > m ? (uint32_t)slotInRound : bestSlot; ++slotInRound; }      // strict >: the first maximum
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
         else wide_fold<MODE>(m, s, cand, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
         if (flags & 0x80000000u) {
           const uint32_t dst = rc.pad;
           const int gWave = 1 << ((flags >> 26) & 7);
+          uint32_t key = 0u;
+          if (TB) {      // place in the node's list = slot * group + lane within the group (plan_stage deals candidate k to slot k / g, lane k % g)
+            const int lg = (int)((dst >> 26) & 7u);
+            key = (bestSlot << lg) | ((uint32_t)tid & ((1u << lg) - 1u));
+            if (gWave > 1) wide_group_reduce_tb(m, key, 1 << lg, gWave);
+            bestSlot = 0u; slotInRound = 0;
+          } else
           if (gWave > 1) {
             if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
             else wide_group_reduce_all<MODE>(m, s, gWave);
@@ -404,7 +439,8 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
-            if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
+            if (TB) { if (codes && x < (unsigned)S) codeRow[(long long)cSign * (long long)kq * Sb + x] = (unsigned char)key; }
+            else if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
           s = 0.0f;
@@ -561,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P1, const PairDes
 // host: program compiler
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-struct WCand { uint32_t src; double w; };
+struct WCand { uint32_t src; double w; uint32_t ref = 0xFFFFFFFFu; };      // ref: position of the transition in the machine's incoming view (levelled nodes)
 struct WNode { uint32_t dst; int stage; std::vector<std::vector<WCand>> t2; std::vector<WCand> t3; };
 inline uint32_t CUR(int i) { return (uint32_t)i; }
 inline uint32_t EXTRA(int i) { return (1u << 30) | (uint32_t)i; }
@@ -678,6 +714,8 @@ void wide_free(WideProgram &P) {
   for (int k = 0; k < 4; ++k) if (P.d_vit[k]) (void)hipFree(P.d_vit[k]);
   if (P.d_phase) (void)hipFree(P.d_phase);
   if (P.d_ret) (void)hipFree(P.d_ret);
+  if (P.d_tbOff) (void)hipFree(P.d_tbOff);
+  if (P.d_tbEntry) (void)hipFree(P.d_tbEntry);
   P = WideProgram();
 }
 
@@ -883,15 +921,16 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long lo
   auto other = [&](uint32_t e) { return (int)(backward ? m->dst[e] : m->src[e]); };
   // candidates of a state: emitting (by output token) and silent, in the reference's iteration order
   std::vector<std::vector<std::vector<WCand>>> emitC(S, std::vector<std::vector<WCand>>(nOut + 1));
-  std::vector<std::vector<std::pair<int, double>>> sil(S);
+  struct SilE { int first; double second; uint32_t ref; };
+  std::vector<std::vector<SilE>> sil(S);
   for (int x = 0; x < S; ++x)
     for (int tok = 0; tok <= nOut; ++tok) {
       const long long rw = (long long)x * (nOut + 1) + tok;      // row = (state * (nIn+1) + inTok) * (nOut+1) + outTok with one of the alphabets empty
       for (int a = off[rw]; a < off[rw + 1]; ++a) {
         const uint32_t e = perm[a];
         const int y = other(e);
-        if (tok) emitC[x][tok].push_back({PREV(y), m->logW[e]});
-        else if (backward ? y > x : y < x) sil[x].push_back({y, m->logW[e]});
+        if (tok) emitC[x][tok].push_back({PREV(y), m->logW[e], (uint32_t)a});
+        else if (backward ? y > x : y < x) sil[x].push_back({y, m->logW[e], (uint32_t)a});
       }
     }
   emitC[seedNode][0].push_back({PREV(S + 1), 0.0});
@@ -902,7 +941,7 @@ static bool wide_nodes(const mb_machine *m, bool backward, int K, int W, long lo
       for (const auto &l : emitC[x]) if (!l.empty()) any = true;
       if (!any) continue;
       WNode nd{CUR(x), lev[x], emitC[x], {}};
-      for (auto &pe : sil[x]) nd.t3.push_back({CUR(pe.first), pe.second});
+      for (auto &pe : sil[x]) nd.t3.push_back({CUR(pe.first), pe.second, pe.ref});
       nodes.push_back(std::move(nd));
     }
     nStages = nLev;
@@ -1041,7 +1080,7 @@ static bool up_w(T *&d, const std::vector<T> &h) {
 
 // ---- the retimed program of a levelled one-tape machine (see WideRetDev) --------------------------------------------------------
 namespace {
-struct RetEdge { int src, dst, em, tok; double w; };
+struct RetEdge { int src, dst, em, tok; double w; uint32_t ref; int rank; };      // ref / rank: incoming-view position, place in the destination's candidate list (reference order)
 
 // smallest tau >= 0 with tau(dst) >= tau(src) + 1 - em * period over all edges; false when some tau would exceed `bound` (the period
 // is shorter than a cycle of the machine needs, or the columns are deeper than the kernel's 6-bit lag)
@@ -1078,16 +1117,19 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   int seedState = -1; double seedW = 0.0;
   for (const WNode &nd : nodes) {
     const int x = (int)(nd.dst & W_IDX_MASK);
+    int rank = 0;      // the reference's traceback enumerates a cell's candidates emitting first, then silent, each in `incoming` order (src/dpmatrix.defs.h:93-103)
     for (int tok = 0; tok < (int)nd.t2.size(); ++tok)
       for (const WCand &cd : nd.t2[tok]) {
         const int y = (int)(cd.src & 0x3fffffffu);
         if (y == S + 1) { seedState = x; seedW = cd.w; continue; }      // the seed: no dependency
         if (y >= S || tok == 0) return true;                           // (cannot happen: token 0 of a levelled node holds the seed only)
-        if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 1, tok, cd.w});
+        if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 1, tok, cd.w, cd.ref, rank});
+        ++rank;
       }
     for (const WCand &cd : nd.t3) {
       const int y = (int)(cd.src & 0x3fffffffu);
-      if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 0, 0, cd.w});
+      if (live[y] && cd.w != -INFINITY) edges.push_back(RetEdge{y, x, 0, 0, cd.w, cd.ref, rank});
+      ++rank;
     }
   }
   // silent edges in sweep order first, so that one relaxation pass carries a change through a whole column
@@ -1095,6 +1137,14 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     if (a.em != b.em) return a.em < b.em;
     return P.backward ? a.dst > b.dst : a.dst < b.dst;
   });
+  // the order candidates enter their node's list: the relaxation's order, or -- traceback codes -- the reference's enumeration order
+  std::vector<RetEdge> byRank;
+  const std::vector<RetEdge> *edgeOrder = &edges;
+  if (P.tbCodes) {
+    byRank = edges;
+    std::stable_sort(byRank.begin(), byRank.end(), [](const RetEdge &a, const RetEdge &b) { return a.dst != b.dst ? a.dst < b.dst : a.rank < b.rank; });
+    edgeOrder = &byRank;
+  }
   std::vector<int> tau;
   const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
   auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau); };
@@ -1138,12 +1188,14 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       };
       auto dstWord = [&](int kt, int entry) { return ((uint32_t)kt << 20) | ((uint32_t)((NB - kt % NB) % NB) << 18) | (uint32_t)entry; };
       std::vector<std::vector<WCand>> cands(S);
-      if (seedState >= 0) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
-      for (const RetEdge &e : edges) {
+      if (seedState >= 0 && !P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
+      for (const RetEdge &e : *edgeOrder) {
         const int kt = tau[e.dst] / period, span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
         const int k = (span - 1) / hop;
-        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : e.src), e.w});
+        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : e.src), e.w, e.ref});
       }
+      // (traceback codes: a cell's code is the PLACE of its first maximal candidate in this list -- the reference's order, the seed last)
+      if (seedState >= 0 && P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
       sh.nd.clear();
       for (int x = 0; x < S; ++x) {      // (states nothing leads to are nodes too: their cells of the matrix are -inf)
         sh.nd.push_back(WNode{CUR(dstWord(tau[x] / period, x)), tau[x] % period, {}, std::move(cands[x])});
@@ -1232,6 +1284,27 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   P.slotsPerColumn = padded; P.candsPerColumn = T.candsPerColumn; P.nSync = T.nSync;
   P.rounds = T.rounds;                                  // (planning tables: mb_machine_sweep_ops counts them)
   P.retOk = true;
+  if (P.tbCodes && !hostOut) {
+    // decode tables of the traceback codes: the candidate lists of the state nodes, in the order the planner laid them out
+    std::vector<int> tbOff(S + 1, 0);
+    std::vector<std::vector<uint32_t>> ent(S);
+    bool fits = S < (1 << 15) && m->nTrans <= (1 << 16) && !P.backward && P.viterbi;
+    for (const WNode &nd : best.nd) {
+      const uint32_t x = nd.dst & WIDE_RET_NO_DST;
+      if (x >= (uint32_t)S) continue;                       // relays, constants
+      if (nd.t3.size() > 256) fits = false;
+      for (const WCand &cd : nd.t3) {
+        if (cd.ref == 0xFFFFFFFFu) { ent[x].push_back(0xFFFFFFFFu); continue; }      // the seed
+        const uint32_t e = m->inPerm[cd.ref];
+        ent[x].push_back((cd.ref << 16) | ((m->inTok[e] || m->outTok[e]) ? 1u << 15 : 0u) | m->src[e]);
+      }
+    }
+    std::vector<uint32_t> flat;
+    for (int x = 0; x < S; ++x) { tbOff[x] = (int)flat.size(); flat.insert(flat.end(), ent[x].begin(), ent[x].end()); }
+    tbOff[S] = (int)flat.size();
+    P.tbOk = fits && up_w(P.d_tbOff, tbOff) && up_w(P.d_tbEntry, flat);
+    P.tbEntries = (long long)flat.size();
+  }
   if (verbose)
     fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
             P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
@@ -1252,8 +1325,9 @@ bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {
   const bool haveShape = P.ok && P.shapeChosen;    // a weight refresh keeps the shape that was chosen
   const int keepStages = P.stages, keepPeriod = (P.ok && P.retOk) ? P.retPeriod : 0, keepPeriodMin = P.retPeriodMin;
+  const bool keepTb = P.tbCodes;
   wide_free(P);
-  P.backward = backward; P.viterbi = viterbi;
+  P.backward = backward; P.viterbi = viterbi; P.tbCodes = keepTb;
   P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);      // 509 states: 48 G cells/s with 1024 lanes, 35 with 256
   const int S = m->S, nLev = backward ? m->nLevB : m->nLevF;
   long long nSilent = 0;
@@ -1485,6 +1559,121 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   return rc;
 }
 
+int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, unsigned char *tb,
+                 double *loglike, hipStream_t st) {
+  (void)m;
+  if (!P.ok || !P.retOk || !P.tbOk || !P.viterbi || P.backward) { set_error("one-tape traceback-code program not built"); return 1; }
+  if (nPairs <= 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    attr = true;
+  }
+  double *ringScratch = nullptr;
+  if (P.retGv && !(ringScratch = (double *)ws_get(11, (size_t)nPairs * (size_t)P.ret.NB * P.ret.NVs * sizeof(double)))) return 1;
+  WideDev dev = P.dev; dev.lastOnly = 0;
+  if (P.retGv) hipLaunchKernelGGL((k_wide_retimed<MB_VITERBI, true, true>), dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_tape, (double *)tb, loglike, ringScratch);
+  else hipLaunchKernelGGL((k_wide_retimed<MB_VITERBI, false, true>), dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_tape, (double *)tb, loglike, ringScratch);
+  MB_HIP(hipGetLastError());
+  g_last_launches += 1;
+  return 0;
+}
+
+// ---- DPMatrix::traceBack over the codes (src/dpmatrix.defs.h:82-110) --------------------------------------------------------
+// One workgroup per sequence.  A step reads the code of (column, state), decodes it to (transition, source state, emitting?) and
+// moves -- a chain of dependent look-ups, so everything it touches sits in LDS: a WINDOW of code rows (the path goes back at
+// most one column per step) in two halves, one walked by the first lane while the other wavefronts fetch the rows below it,
+// and the decode tables when they fit beside the window (else they are read through L2).  The path is written backwards as
+// positions of the incoming view; a second kernel turns them into edge ids (off the walker's chain).
+struct WideTbWalk { const int *tbOff; const uint32_t *tbEntry; long long nEntries; int tablesInLds, rowsPerHalf; };      // (in LDS the offsets are 16-bit: nEntries < 65536 there)
+
+__global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, WideTbWalk Q, const PairDesc *__restrict__ pairs, int inputTape,
+                                                                const unsigned char *__restrict__ tb, const double *__restrict__ loglike,
+                                                                const long long *__restrict__ slotOff, uint32_t *__restrict__ pathBuf,
+                                                                long long *__restrict__ pathLen) {
+  extern __shared__ unsigned int twl[];
+  const long long p = blockIdx.x;
+  const PairDesc pd = pairs[p];
+  const int S = m.S, Sb = (S + 3) & ~3, L = inputTape ? pd.inLen : pd.outLen, tid = threadIdx.x;
+  const int R = Q.rowsPerHalf, rowW = Sb >> 2;
+  unsigned int *win = twl;                                         // [2][R][rowW]: half h holds columns hi(h) - R + 1 .. hi(h)
+  unsigned int *entL = twl + 2 * (size_t)R * rowW;                // decode tables (tablesInLds): entries, then 16-bit offsets
+  unsigned short *offL = (unsigned short *)(entL + Q.nEntries);
+  if (!(loglike[p] > -INFINITY)) { if (tid == 0) pathLen[p] = -1; return; }      // no path: src/dpmatrix.defs.h:84
+  if (Q.tablesInLds) {
+    for (int k = tid; k <= S; k += 256) offL[k] = (unsigned short)Q.tbOff[k];
+    for (long long k = tid; k < Q.nEntries; k += 256) entL[k] = Q.tbEntry[k];
+  }
+  const unsigned int *rows = (const unsigned int *)(tb + pd.cellBase);      // (cellBase and Sb are multiples of 4)
+  auto fill = [&](int half, int hi, int first, int nThreads) {    // columns hi - R + 1 .. hi (those that exist) into half `half`, by threads first .. first + nThreads - 1
+    const int lo = max(hi - R + 1, 0);
+    if (hi < 0) return;
+    const unsigned int *src = rows + (long long)lo * rowW;
+    unsigned int *dst = win + (size_t)half * R * rowW + (size_t)(lo - (hi - R + 1)) * rowW;
+    const int n = (hi - lo + 1) * rowW;
+    for (int k = tid - first; k < n; k += nThreads) dst[k] = src[k];
+  };
+  fill(0, L, 0, 256);
+  __syncthreads();
+  uint32_t *out = pathBuf + slotOff[p + 1];
+  const long long cap = slotOff[p + 1] - slotOff[p];
+  long long n = 0;
+  int c = L, s = S - 1, status = 0;                               // status: 0 walking, 1 done, -2 slot full, -3 dead end
+  for (int w = 0, hi = L; hi >= 0 && status == 0; ++w, hi -= R) {
+    const int half = w & 1;
+    if (tid >= 64) fill(half ^ 1, hi - R, 64, 192);                // the rows below this half, fetched while it is walked
+    else if (tid == 0) {
+      const unsigned char *hb = (const unsigned char *)(win + (size_t)half * R * rowW);
+      const int base = hi - R + 1;                                 // column of the half's first row
+      while (status == 0 && c >= base) {
+        if (c == 0 && s == 0) { status = 1; break; }
+        const unsigned int code = hb[(size_t)(c - base) * Sb + s];
+        const int o0 = Q.tablesInLds ? (int)offL[s] : Q.tbOff[s], o1 = Q.tablesInLds ? (int)offL[s + 1] : Q.tbOff[s + 1];
+        if ((int)code >= o1 - o0) { status = -3; break; }
+        const unsigned int e = Q.tablesInLds ? entL[o0 + code] : Q.tbEntry[o0 + code];
+        if (e == 0xFFFFFFFFu) { status = (c == 0) ? 1 : -3; break; }      // the seed: cell (0, start)
+        if (n >= cap) { status = -2; break; }
+        ++n;
+        out[-n] = e >> 16;                                         // position in the incoming view (edge ids: k_onetape_path_ids)
+        s = (int)(e & 0x7fffu);
+        if (e & 0x8000u) { if (c == 0) { status = -3; break; } --c; }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) pathLen[p] = status == 1 ? n : (status == 0 ? (c == 0 && s == 0 ? n : -3) : status);
+}
+
+__global__ __launch_bounds__(256) void k_onetape_path_ids(DevMachine m, const long long *__restrict__ slotOff, const long long *__restrict__ pathLen,
+                                                         uint32_t *__restrict__ pathBuf) {
+  const long long p = blockIdx.x, n = pathLen[p];
+  if (n <= 0) return;
+  uint32_t *q = pathBuf + slotOff[p + 1] - n;
+  for (long long k = threadIdx.x; k < n; k += 256) q[k] = m.inEid[q[k]];
+}
+
+int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDesc *d_pairs, long long nPairs, const unsigned char *tb,
+                         const double *d_loglike, const long long *d_slotOff, uint32_t *d_pathBuf, long long *d_pathLen, hipStream_t st) {
+  if (!P.tbOk) { set_error("one-tape traceback-code program not built"); return 1; }
+  if (nPairs <= 0) return 0;
+  const int S = m->S, Sb = wide_tb_stride(S);
+  const size_t tabBytes = (((size_t)(S + 1) * 2 + 3) & ~(size_t)3) + (size_t)P.tbEntries * 4;
+  WideTbWalk Q{P.d_tbOff, P.d_tbEntry, P.tbEntries, 0, 1};
+  const size_t budget = 150 * 1024;
+  // the window wants at least 2 x 2 rows; the tables go to LDS when 2 x 4 rows still fit beside them
+  if (tabBytes + (size_t)8 * Sb <= budget && P.tbEntries < 65536) Q.tablesInLds = 1;
+  const size_t forRows = budget - (Q.tablesInLds ? tabBytes : 0);
+  Q.rowsPerHalf = (int)std::max<size_t>(1, std::min<size_t>(forRows / (2 * (size_t)Sb), 32));
+  if ((size_t)2 * Q.rowsPerHalf * Sb > budget) { set_error("one-tape traceback codes: a code row exceeds the LDS"); return 1; }
+  const size_t lds = (size_t)2 * Q.rowsPerHalf * Sb + (Q.tablesInLds ? tabBytes : 0);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_onetape_traceback_codes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(k_onetape_traceback_codes, dim3((unsigned)nPairs), dim3(256), lds, st, m->dev, Q, d_pairs, m->nIn != 0 ? 1 : 0, tb, d_loglike, d_slotOff, d_pathBuf, d_pathLen);
+  hipLaunchKernelGGL(k_onetape_path_ids, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, d_slotOff, (const long long *)d_pathLen, d_pathBuf);
+  return hip_ok(hipGetLastError(), "one-tape traceback (codes) launch") ? 0 : 1;
+}
+
 int wide_fill2(const mb_machine *m, WideProgram &A, WideProgram &B, const PairDesc *d_descA, const PairDesc *d_descB, long long nA, long long nB,
                const int *d_tape, double *poolA, double *poolB, hipStream_t st, bool lastOnly) {
   (void)m;
@@ -1571,13 +1760,18 @@ int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, co
 // and a column whose token differs is skipped by a scalar branch.  The 2 x nStates doubles of a column are gathered by
 // every edge block of the sequence; blockIdx -> (sequence part, edge block) keeps the edge blocks of one part on ONE XCD
 // and next to each other in launch order, so they walk the columns together and the gathers hit that XCD's L2.
-struct OtEdge { uint32_t src, pos; };          // pos: position in the outgoing view (weight, destination, edge id); ~0u = padding
+struct OtEdge { uint32_t src, pos; };
+// one atomic per (transition, sequence part): fp64, or 64-bit fixed point at 2^-36 (deterministic mode, mb_internal.h)
+__device__ __forceinline__ void count_add(double *counts, uint32_t e, double x, int det) {
+  if (det) atomicAdd((unsigned long long *)counts + e, (unsigned long long)(x * 68719476736.0 + 0.5));
+  else atomicAdd(&counts[e], x);
+}          // pos: position in the outgoing view (weight, destination, edge id); ~0u = padding
 
 __global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEdge *__restrict__ edges,
                                                         const unsigned short *__restrict__ waveLabel, int nWaves, int nEB,
                                                         const PairDesc *__restrict__ pairs, long long nUnits, int colSplit, int inputTape,
                                                         const int *__restrict__ tape, const double *__restrict__ fwd,
-                                                        const double *__restrict__ bwd, double *__restrict__ counts, const float *__restrict__ norm) {
+                                                        const double *__restrict__ bwd, double *__restrict__ counts, const float *__restrict__ norm, int det) {
   const long long bid = blockIdx.x, slot = bid >> 3;
   const long long unit = (slot / nEB) * 8 + (bid & 7);
   const int eb = (int)(slot % nEB);
@@ -1614,7 +1808,7 @@ __global__ __launch_bounds__(256) void k_onetape_counts(DevMachine m, const OtEd
     for (int c = cA; c < cE; ++c)
       if (tk[c] == y) acc += nm ? term(c, c + 1) * (double)nm[c] : term(c, c + 1);
   }
-  if (live && acc != 0.0) atomicAdd(&counts[m.outEid[pos]], acc);
+  if (live && acc != 0.0) count_add(counts, m.outEid[pos], acc, det);
 }
 
 // norm[global column] = 1 / (sum of the emitting terms that leave the column), the last column of a sequence: 1 / exp(F(L, end) -
@@ -1666,7 +1860,7 @@ template <int EPT>
 __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const OtEdge *__restrict__ edges, const unsigned short *__restrict__ waveLabel,
                                                             int nEdges, const PairDesc *__restrict__ pairs, int colSplit, int inputTape,
                                                             const int *__restrict__ tape, const double *__restrict__ fwd,
-                                                            const double *__restrict__ bwd, double *__restrict__ counts, int normalise) {
+                                                            const double *__restrict__ bwd, double *__restrict__ counts, int normalise, int det) {
   extern __shared__ double cl[];
   const int S = m.S, tid = threadIdx.x;
   double *Fl = cl, *Ba = cl + S, *Bb = cl + 2 * (long long)S;
@@ -1733,7 +1927,7 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = tid + k * 512;
-    if (e < nEdges && acc[k] != 0.0) { const uint32_t pos = edges[e].pos; if (pos != 0xFFFFFFFFu) atomicAdd(&counts[m.outEid[pos]], acc[k]); }
+    if (e < nEdges && acc[k] != 0.0) { const uint32_t pos = edges[e].pos; if (pos != 0xFFFFFFFFu) count_add(counts, m.outEid[pos], acc[k], det); }
   }
 }
 
@@ -1745,7 +1939,7 @@ static void launch_counts_lds(const mb_machine *m, const WideCountPlan &C, const
   if (!attr) { (void)hipFuncSetAttribute((const void *)&k_onetape_counts_lds<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_counts_lds<EPT>, dim3((unsigned)nUnits), dim3(512), lds, st, m->dev, (const OtEdge *)C.d_edges,
                      (const unsigned short *)C.d_waveLabel, C.nWaves * 64, d_desc, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts,
-                     env_int_w("MB_ONETAPE_COUNT_NORMALISE", 1));
+                     env_int_w("MB_ONETAPE_COUNT_NORMALISE", 1), g_deterministic ? 1 : 0);
 }
 
 bool wide_counts_build(const mb_machine *m, WideCountPlan &C) {
@@ -1828,7 +2022,7 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
     hipLaunchKernelGGL(k_onetape_colnorm, dim3((unsigned)(hp.size() * cs)), dim3(256), 0, st, m->dev, d_desc, cs, inputTape ? 1 : 0, d_tape, fwd, bwd, d_norm);
   }
   hipLaunchKernelGGL(k_onetape_counts, dim3((unsigned)grid), dim3(256), 0, st, m->dev, (const OtEdge *)C.d_edges,
-                     (const unsigned short *)C.d_waveLabel, C.nWaves, nEB, d_desc, nUnits, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts, (const float *)d_norm);
+                     (const unsigned short *)C.d_waveLabel, C.nWaves, nEB, d_desc, nUnits, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts, (const float *)d_norm, g_deterministic ? 1 : 0);
   return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
 }
 

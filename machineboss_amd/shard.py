@@ -6,7 +6,8 @@ nTransitions posterior counts + 1 log-likelihood per EM iteration (MachineCounts
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -46,3 +47,100 @@ def allreduce_counts(counts: np.ndarray, loglike: float, backend_device: str = "
     host = buf.cpu().numpy()
     counts[:] = host[:-1]
     return counts, float(host[-1])
+
+
+class RankGroup:
+    """The ranks of a sharded run: one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, as
+    torch.distributed.run sets them).
+
+    ONE HIP runtime per process: rendezvous and the host-side odds and ends (barrier, max of a clock, gathering results in
+    order) go over torch.distributed's `gloo` backend on the CPU -- torch never touches the GPU -- and the ONE data-path
+    collective of the path, the sum of the E-step statistics (MachineCounts::operator+=, src/counts.cpp:66-71), goes over RCCL
+    through the C-ABI (mb_comm_unique_id -> broadcast of the 128 bytes -> mb_comm_init -> mb_allreduce_counts) on the
+    library's own runtime and stream, exactly as a C++ host would drive it (INTEGRATION.md).  Round 3 reduced through torch's
+    RCCL: two HIP runtimes in one process (PyTorch bundles its own), whose load order decided which RCCL could see the device.
+
+    backend: "rccl" (default on a GPU box) as above; "nccl": torch.distributed's NCCL backend (= torch's RCCL on torch's HIP
+    runtime: the round-3 route, kept for comparison); "gloo": everything on the host (CPU tests, several ranks on one GPU).
+    MB_DIST_BACKEND overrides the default."""
+
+    def __init__(self, dist, rank: int, world: int, local_rank: int, backend: str, comm=None, opened: bool = False):
+        self.dist, self.rank, self.world, self.local_rank, self.backend, self.comm, self._opened = dist, rank, world, local_rank, backend, comm, opened
+
+    @classmethod
+    def from_env(cls, backend: Optional[str] = None, force: bool = False, share_device: bool = False) -> Optional["RankGroup"]:
+        """None outside a multi-rank launch (force = True: a one-rank group all the same -- the bootstrap and the collective
+        exercised on a one-GPU box).  Binds the library to the rank's GPU BEFORE any GPU call."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1 and not force:
+            return None
+        rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        from . import capi
+        have_gpu = capi.device_count() > 0
+        backend = backend or os.environ.get("MB_DIST_BACKEND") or ("rccl" if have_gpu else "gloo")
+        if share_device:
+            local = 0
+        if have_gpu:
+            capi.set_device(local)
+        import torch.distributed as dist
+        opened = False
+        if not dist.is_initialized():
+            if backend == "nccl":
+                import torch
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            opened = True
+        grp = cls(dist, rank, world, local, backend, None, opened)
+        if backend == "rccl":
+            import torch
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                ident = torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8).clone()
+            if world > 1:
+                dist.broadcast(ident, src=0)
+            grp.comm = capi.Comm(bytes(ident.numpy().tobytes()), world, rank)
+        return grp
+
+    # ---- the data-path collective -----------------------------------------------------------------------------------------
+    def allreduce_counts(self, counts: np.ndarray, loglike: float):
+        """Sum of (posterior counts, log-likelihood) over the ranks, in place."""
+        if self.comm is not None:
+            return self.comm.allreduce_counts(counts, loglike)
+        if self.world == 1:
+            return counts, loglike
+        return allreduce_counts(counts, loglike, "cuda" if self.backend == "nccl" else "cpu")
+
+    # ---- host-side helpers (never on the data path) ------------------------------------------------------------------------
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def all_reduce_float(self, x: float, op: str = "sum") -> float:
+        if self.world == 1:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_gather_floats(self, row: Sequence[float]) -> List[List[float]]:
+        if self.world == 1:
+            return [[float(v) for v in row]]
+        import torch
+        rec = torch.tensor([float(v) for v in row], dtype=torch.float64, device=self._dev())
+        out = [torch.zeros_like(rec) for _ in range(self.world)]
+        self.dist.all_gather(out, rec)
+        return [[float(v) for v in r.tolist()] for r in out]
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close(); self.comm = None
+        if self._opened and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+            self._opened = False

@@ -31,6 +31,9 @@ def tm(f, name):
 llr = tm(lambda: b.forward(capi.MB_ROLLING), "forward rolling") if "r" in modes else None
 llm = tm(lambda: b.forward(capi.MB_MATERIALISE), "forward materialised") if "m" in modes else None
 v = tm(lambda: b.viterbi(paths=False), "viterbi fill") if "v" in modes else None
+if "p" in modes:
+    r = tm(lambda: b.viterbi(), "viterbi with paths")
+    print("  device %.1f ms, %d path edges" % (capi.last_device_ms(), len(r[2])), flush=True)
 if "c" in modes:
     b.counts()
     t0 = time.perf_counter(); cnt, lls, _ = b.counts(); dt = time.perf_counter() - t0

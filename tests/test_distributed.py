@@ -117,3 +117,33 @@ def test_cli_results_gathered_in_input_order_world2():
     assert [1] in owned                                            # the long pair alone on one rank, the six short ones on the other
     for rank, _, got in res:
         assert got == ["pair%d" % k for k in range(7)]
+
+
+def _group_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from machineboss_amd.shard import RankGroup
+    grp = RankGroup.from_env()                       # no GPU here: everything over gloo (on a GPU box: RCCL through the C-ABI)
+    counts = np.arange(5, dtype=np.float64) * (rank + 1)
+    counts, ll = grp.allreduce_counts(counts, -1.5 * (rank + 1))
+    grp.barrier()
+    q.put((rank, grp.backend, counts.copy(), ll, grp.all_reduce_float(float(rank + 1), "max"), grp.all_reduce_float(2.0, "sum"),
+           grp.all_gather_floats([rank, 10.0 * rank])))
+    grp.close()
+
+
+def test_rank_group_world2():
+    """shard.RankGroup, the ranks of bench.py and boss.py: environment as torch.distributed.run sets it, rendezvous over gloo,
+    the count reduction and the host-side helpers (max of a clock, gather of per-rank rows) -- two processes, no GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, backend, counts, ll, mx, sm, rows in res:
+        assert backend == "gloo" and np.array_equal(counts, np.arange(5) * 3.0) and ll == -4.5 and mx == 2.0 and sm == 4.0
+        assert sorted(rows) == [[0.0, 0.0], [1.0, 10.0]]
