@@ -38,6 +38,38 @@ TRANSCENDENTAL_PEAK_T = 157.0 / 2 / 4   # v_exp_f32 / v_log_f32 per second (x 1e
 BYTES_PER_CELL = 8      # materialised Forward: one fp64 store per cell (w = 8)
 
 
+def recorded(name):
+    """A committed measurement under profiles/ (None when absent): PMC traffic and the vector-issue model are recorded constants
+    of the round's profile run (scripts/profile_r04.sh), labelled as such wherever the bench line quotes them."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def valu_issue(model, keys, cells_per_s):
+    """Vector-issue fraction of a mode: issue slots per cell of its kernels' step loops, from their gfx950 ISA
+    (scripts/valu_model.py: plain VALU 1, fp64 / transcendental 2, one slot = 2 cycles of a SIMD-32) x the measured rate /
+    (256 CUs x 4 SIMDs x 2.4 GHz / 2).  None when the model has no entry for a kernel."""
+    if not model:
+        return None
+    try:
+        per_cell = sum(model["kernels"][k]["issue_slots_per_cell"] for k in keys)
+        return {"valu_issue_frac": round(cells_per_s * per_cell / model["peak_issue_slots_per_s"], 4), "issue_slots_per_cell": round(per_cell, 4),
+                "at_full_issue_gcells": round(model["peak_issue_slots_per_s"] / per_cell / 1e9, 1), "kernels": list(keys),
+                "source": "profiles/r04_valu_model.json (ISA of the generated kernels, scripts/valu_model.py; recorded, not re-derived in this run)"}
+    except KeyError:
+        return None
+
+
+def pmc_traffic(name, units):
+    """HBM bytes per call of a non-headline mode from its committed PMC passes (profiles/<name>), scaled to this run's units."""
+    p = recorded(name)
+    if not p:
+        return None, None
+    return round(p["hbm_bytes_per_cell"] * units), "profiles/%s (%.2f B per cell, separate --pmc WRITE_SIZE / FETCH_SIZE passes; recorded, not re-measured in this run)" % (name, p["hbm_bytes_per_cell"])
+
+
 def host_cores() -> int:
     """CPU threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container can see
     256 CPUs and be throttled to 8) and by one socket's worth (the north-star compares with a single socket)."""
@@ -131,17 +163,22 @@ def extra_single_gpu(capi, np, hbm_peak):
         cnt, s3, _ = b3.counts(); dev.append(capi.last_device_ms())
     wall = (time.perf_counter() - t0) / 5
     ach = 16.0 * cells3 / (sum(dev) / len(dev) / 1e3) / 1e9
+    model = recorded("r04_valu_model.json")
+    tr3, tr3src = pmc_traffic("r04_counts_pmc_hbm.json", cells3)
     nsym = float(cnt[np.asarray(em1.inTok) != 0].sum()), float(cnt[np.asarray(em1.outTok) != 0].sum())
     out["counts"] = {"workload": "config 3 per GPU: protpsw (8 states, 450 transitions), 1024 pairs x 400 x 400 aa, Backward + Forward/count sweep (MachineCounts)",
                      "value": round(cells3 / wall / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(wall * 1e3, 3),
                      "device_ms": round(sum(dev) / len(dev), 3),
                      "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(ach / hbm_peak, 4),
-                                  "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_small_sum_bwd + " + capi.last_kernel_name(), "traffic": None},
+                                  "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_small_sum_bwd + " + capi.last_kernel_name(), "traffic": tr3, "traffic_source": tr3src,
+                                  "issue": valu_issue(model, ["protpsw.m0.mat.bwd.hip", "protpsw.m3.roll.fwd.hip"], cells3 / (sum(dev) / len(dev) / 1e3))},
                      "symbol_count_invariant": [nsym[0] / (1024 * 400), nsym[1] / (1024 * 400)], "loglike_sum": float(s3)}
     mfw, tf = timed(lambda: b3.forward(capi.MB_MATERIALISE), 5); devf = capi.last_device_ms()
     out["forward_config3"] = {"workload": "protpsw 1024 x 400 x 400, materialised Forward", "value": round(cells3 / tf / 1e9, 2), "unit": "Gcells/s",
                               "roofline": {"bound": "hbm", "achieved": round(8.0 * cells3 / (devf / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
-                                           "frac": round(8.0 * cells3 / (devf / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name()}}
+                                           "frac": round(8.0 * cells3 / (devf / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name(),
+                                           "traffic": pmc_traffic("r04_forward3_pmc_hbm.json", cells3)[0],
+                                           "issue": valu_issue(model, ["protpsw.m0.mat.fwd.hip"], cells3 / (devf / 1e3))}}
     del b3
 
     # config 2: dnapsw, 1024 x 1 kb x 1 kb: Viterbi with traceback (1 algorithmic byte per cell: the traceback pointer), Forward
@@ -180,7 +217,9 @@ def extra_single_gpu(capi, np, hbm_peak):
                        "device_ms": round(devv4, 3), "fill_device_ms": round(devvf4, 3), "path_edges": int(off4[-1]), "loglike_sum": float(v4.sum()),
                        "roofline": {"bound": "valu", "note": "1 traceback byte per cell (+ boundary records and halo rows: profiles/r03_viterbi4_pmc_hbm.json); the max sweep is bound by vector instruction issue, not by HBM",
                                     "achieved": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
-                                    "frac": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1, "kernel": kv4}}
+                                    "frac": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1, "kernel": kv4,
+                                    "traffic": pmc_traffic("r04_viterbi4_pmc_hbm.json", cells4)[0],
+                                    "issue": valu_issue(model, ["psw2dna.tb.tiles.fwd.exact.hip"], cells4 / (devvf4 / 1e3))}}
     del b4
     nc4 = 63      # three chunks of Backward matrices (21 pairs of 10.6 GB each fit the 80 % budget of a 288 GB GPU)
     b4c = capi.DeviceBatch(dm4, *synth_batch(4, nc4, 487, 10000, em4.nInTok, em4.nOutTok))
@@ -190,7 +229,9 @@ def extra_single_gpu(capi, np, hbm_peak):
     out["counts4"] = {"workload": "config 4: psw2dna, %d pairs x 487 aa x 10000 nt, Backward fill + Forward/count sweep without a Forward matrix (MachineCounts)" % nc4,
                       "value": round(cells4c / tc4 / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(tc4 * 1e3, 2), "device_ms": round(devc4, 2),
                       "roofline": {"bound": "hbm", "achieved": round(ach4, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(ach4 / hbm_peak, 4),
-                                   "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_medium_jit (Backward fill) + k_medium_jit (count sweep)", "traffic": None},
+                                   "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_medium_jit (Backward fill) + k_medium_jit (count sweep: closure Forward rounds + flat usage pass)",
+                                   "traffic": pmc_traffic("r04_counts4_pmc_hbm.json", cells4c)[0], "traffic_source": pmc_traffic("r04_counts4_pmc_hbm.json", cells4c)[1],
+                                   "issue": valu_issue(model, ["psw2dna.sum.mat.bwd.clos.hip", "psw2dna.cnt.tiles.fwd.clos.hip"], cells4c / (devc4 / 1e3))},
                       "symbol_count_invariant": [float(cnt4[np.asarray(em4.inTok) != 0].sum()) / (nc4 * 487), float(cnt4[np.asarray(em4.outTok) != 0].sum()) / (nc4 * 10000)],
                       "loglike_sum": float(s4)}
     del b4c
@@ -223,7 +264,9 @@ def extra_single_gpu(capi, np, hbm_peak):
                            "counts_lattice": round(cellsbc / tcb / 1e9, 2), "loglike_checksum": float(np.sum(llb)), "viterbi_checksum": float(np.sum(vb)),
                            "symbol_count_invariant": [float(cntb[np.asarray(em4b.inTok) != 0].sum()) / (24 * 487), float(cntb[np.asarray(em4b.outTok) != 0].sum()) / (24 * 10000)],
                            "roofline": {"bound": "hbm", "achieved": round(8.0 * cellsb / (devfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
-                                        "frac": round(8.0 * cellsb / (devfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 8, "kernel": kfb, "what": "materialised Forward, 256 pairs"},
+                                        "frac": round(8.0 * cellsb / (devfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 8, "kernel": kfb, "what": "materialised Forward, 256 pairs",
+                                        "traffic": pmc_traffic("r04_forward4b_pmc_hbm.json", cellsb)[0],
+                                        "issue": valu_issue(model, ["c4b.sum.mat.fwd.clos.hip"], cellsb / (devfb / 1e3))},
                            "roofline_viterbi": {"bound": "valu", "achieved": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                                 "frac": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1},
                            "roofline_counts": {"bound": "hbm", "achieved": round(16.0 * cellsbc / (devcb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
@@ -442,6 +485,7 @@ def main():
             extra["rolling_rate"] = {"exp_per_cell": round(ops["exp_per_cell"], 3), "log_per_cell": round(ops["log_per_cell"], 3), "family": ops["family"],
                                      "achieved_transcendental_per_s": round(tr / 1e12, 3), "peak": TRANSCENDENTAL_PEAK_T, "unit": "T v_exp/v_log per s",
                                      "frac": round(tr / 1e12 / TRANSCENDENTAL_PEAK_T, 4),
+                                     "issue": valu_issue(recorded("r04_valu_model.json"), ["psw2dna_strip.sum.roll.fwd.clos.hip"], cells_rank / d1),
                                      "note": "quarter-rate fp32 transcendentals: 157 TFLOP/s fp32 / 2 / 4 (MI355X_MICROARCH.md); the sweep is bound by total vector issue (fp64 add / max at half rate), of which these are a part"}
             extra["rolling_note"] = "boss --loglike mode: no matrix in HBM, bound by vector instruction issue (fp64 add/max, v_exp_f32/v_log_f32), not by HBM; the HBM fraction is not meaningful for it"
 
@@ -511,7 +555,7 @@ def main():
         ach = BYTES_PER_CELL * cells_rank * args.steps / (dev_ms / 1e3) / 1e9 if (dev_ms > 0 and flags == capi.MB_MATERIALISE) else 0.0
         traffic = None
         traffic_src = None
-        for tag in ("r03", "r02", "r01"):   # HBM bytes per launch from the committed PMC passes (profiles/): a recorded constant, valid for the default workload only
+        for tag in ("r04", "r03", "r02", "r01"):   # HBM bytes per launch from the committed PMC passes (profiles/): a recorded constant, valid for the default workload only
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")))
                 if pmc["kernel"] == kernel and pmc["cells_per_step"] == cells_rank and flags == capi.MB_MATERIALISE:
@@ -536,7 +580,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(BYTES_PER_CELL * cells_rank * args.steps / max(launches, 1)) if flags == capi.MB_MATERIALISE else 0,
                          "launches_per_step": launches // max(args.steps, 1),
                          "avg_launch_us": round(dev_ms * 1e3 / max(launches, 1), 2),
-                         "device_ms_per_step": round(dev_ms / args.steps, 3)},
+                         "device_ms_per_step": round(dev_ms / args.steps, 3),
+                         "issue": valu_issue(recorded("r04_valu_model.json"), ["psw2dna.sum.mat.fwd.clos.hip" if flags == capi.MB_MATERIALISE else "psw2dna_strip.sum.roll.fwd.clos.hip"],
+                                             cells_rank * args.steps / max(dev_ms / 1e3, 1e-9)) if args.preset == "psw2dna" else None},
             "cpu_baseline": cpu,
             "loglike_checksum": float(np.sum(ll)),
             "extra": extra,

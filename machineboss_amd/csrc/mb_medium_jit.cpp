@@ -49,9 +49,11 @@ static size_t halo_bytes(const MedProgram &P, const MedGeom &geo) { return (size
 static int tb_lds_stride(const MedProgram &P) { return (P.Spad + 15) & ~15; }
 static size_t tb_bytes(const MedProgram &P, const MedGeom &geo, int mode) { return mode == MED_MODE_TB ? (size_t)geo.C * tb_lds_stride(P) + 16 : 0; }
 
-size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode) {
-  return ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo) + tb_bytes(P, geo, mode);
+// (+ 128 bytes behind everything else: the per-wavefront step counters of the neighbour synchronisation, JNBSYNC)
+static size_t lds_payload_bytes(const MedProgram &P, const MedGeom &geo, int mode) {
+  return (ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo) + tb_bytes(P, geo, mode) + 15) & ~(size_t)15;
 }
+size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode) { return lds_payload_bytes(P, geo, mode) + 128; }
 
 // Traceback bytes: code = table << 6 | index of the candidate in its table's list, so a state may have at most 64
 // candidates per table (any machine with a larger fan-in keeps the fp64 Viterbi matrix); a silent self-loop on state 0 --
@@ -87,7 +89,7 @@ void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geoIn) {
   const int LPG = P.LPG;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
   // (the traceback-byte vectors of MED_MODE_TB share the plan of the program's other kernels: reserved whenever they could be used)
-  long long ldsFree = 160 * 1024 - 64 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo) - (long long)halo_bytes(P, geo)
+  long long ldsFree = 160 * 1024 - 256 - (long long)ring_bytes(P, geo) - (long long)tok_bytes(P, geo) - (long long)count_bytes(P, geo) - (long long)halo_bytes(P, geo)
                       - ((!P.closure && !P.backward && !P.counting) ? (long long)tb_bytes(P, geo, MED_MODE_TB) : 0);
   int regFree = P.regBudget;                               // VGPRs for loop-invariant records (3 per record, +1 per round)
   if (P.Spad * 8 >= (1 << 16)) regFree = 0;
@@ -156,6 +158,12 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JENV " << (geo.env ? 1 : 0) << "\n#define JMAT " << matKind << "\n#define JTB " << (tbmode ? 1 : 0) << "\n#define JTBS " << tb_lds_stride(P) << "\n#define JSB " << medium_tb_stride(S)
        << "\n#define JNH " << P.haloStates.size() << "\n#define JNHP " << std::max<size_t>(P.haloStates.size(), 1)
        << "\n#define JNHR " << std::max<size_t>((P.haloStates.size() + threads - 1) / threads, 1) << "\n#define JHALOT " << (materialise ? geo.haloSteps : 0)
+       // NEIGHBOUR SYNCHRONISATION instead of a workgroup barrier per step (tiles without a matrix whose halo rows one wavefront moves):
+       // see the skeleton.  Measured on psw2dna 64 x 487 x 2 kb: log-likelihood tiles 1 124 -> 1 188 G cells/s, traceback-byte Viterbi
+       // 593 -> 617, the count sweep 224 -> 220 (its step is paced by the Backward loads, not by the barrier): off for that one
+       << "\n#define JNBSYNC " << ((env_int("MB_JIT_NEIGHBOUR_SYNC", mode == MED_MODE_COUNT ? 0 : 1) && matKind == MED_MAT_ROLL && P.haloStates.size() <= 64 && geo.waves > 1 && geo.waves <= 16) ? 1 : 0)
+       << "\n#define JFLAGOFF " << lds_payload_bytes(P, geo, mode)
+       << "\n#define JDBG " << env_int("MB_JIT_DEBUG", 0)      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
        << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow

@@ -280,6 +280,17 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
 
   for (int j = tid; j < NS * (C + 1) * Spad; j += NT) lds[j] = NEG_INF;
+#if JNBSYNC
+  // NEIGHBOUR SYNCHRONISATION.  A step of column c reads what column c - 1 held one step earlier, and overwrites the ring slot
+  // column c + 1 read one step earlier: a wavefront depends on its two NEIGHBOUR wavefronts only (and the halo rows are moved by
+  // wavefront 0 alone), so the workgroup barrier that ended every step -- all wavefronts of a SIMD then stall and issue in
+  // lock-step: the vector ALUs ran at a quarter of their issue rate (profiles/r04_valu_model.json, r04_counts4_pmc_sq.txt) -- is
+  // replaced by one step counter per wavefront in LDS: wavefront w starts step t once w - 1 and w + 1 have finished step t - 1.
+  // All wavefronts of a workgroup are resident, the dependencies run along a chain: the slowest wavefront can always proceed.
+  // A real barrier remains at the end of every token window (its double buffer is refilled co-operatively) and of the tile.
+  volatile int *stepDone = (volatile int *)((char *)lds + JFLAGOFF);
+  if (tid < JWAVES) stepDone[tid] = 0;
+#endif
   {  // candidate records placed in LDS (16 B each)
     const u32x4 *img = (const u32x4 *)P.ldsImage;
     u32x4 *dst = (u32x4 *)ldsRec;
@@ -386,6 +397,14 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
     const int sCur = slotCur * slotStride, sPrev = slotPrev * slotStride, sPrev2 = slotPrev2 * slotStride;
+#if JNBSYNC
+    {  // both neighbours have finished the step before this one (counters hold the number of steps finished since t0)
+      const int need = t - t0;
+      if (wv > 0) while (__builtin_amdgcn_readfirstlane(stepDone[wv - 1]) < need) __builtin_amdgcn_s_sleep(1);
+      if (wv + 1 < JWAVES) while (__builtin_amdgcn_readfirstlane(stepDone[wv + 1]) < need) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+#endif
     // halo supercell (i0-1, t+1) for the next step.  The load is UNCONDITIONAL (clamped to a valid address when there
     // is no halo): a conditionally initialised register would make the compiler wait for every outstanding memory
     // operation -- the previous step's stores included -- before overwriting it.
@@ -393,7 +412,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #if JMAT == 2
     double hvr[JNHR];
 #pragma unroll
-    for (int k = 0; k < JNHR; ++k) hvr[k] = haloIn[(long long)min(t + 1, outLen) * JNHP + min(tid + k * NT, JNHP - 1)];
+    for (int k = 0; k < JNHR; ++k) hvr[k] = (JDBG & 2) ? -1.0 : haloIn[(long long)min(t + 1, outLen) * JNHP + min(tid + k * NT, JNHP - 1)];
 #elif JHALOT == 0
     double hv[JHALO];
     {
@@ -409,7 +428,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     {
       const double *bs = cellPtrB(min(i, inLen), min(max(o + 1, 0), outLen));
 #pragma unroll
-      for (int k = 0; k < JBV; ++k) bpre[k] = bs[min(k * LPG + q, S - 1)];
+      for (int k = 0; k < JBV; ++k) bpre[k] = (JDBG & 1) ? -1.0 : bs[min(k * LPG + q, S - 1)];
     }
 #endif
     // LDS byte addresses of the four vectors this lane's column reads / writes
@@ -493,7 +512,13 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
       if (i == inLen && o == outLen && q == 0 && A.loglike) A.loglike[pairIdx] = cur[JENDNODE];
     }
+#if JNBSYNC
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // this step's LDS writes are done before the counter says so
+    if (lane == 0) stepDone[wv] = t - t0 + 1;
+    if (((t + 1) % W) == 0 || t + 1 == t1) med_block_sync();      // end of a token window (the next step rewrites the other buffer) / of the tile
+#else
     med_block_sync();
+#endif
     slotCur = (slotCur + 1) % NS;
   }
 #if JMAT == 2
