@@ -362,6 +362,17 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   constexpr int aB = 0; constexpr unsigned accBase = 0; constexpr double negLL = 0.0;
   (void)aB; (void)accBase; (void)negLL;
 #endif
+#if JMODE == 2 && JBDIST == 2
+  // The Backward supercells are fetched TWO steps ahead (round 4: with one step of distance a fifth of the count sweep was the
+  // latency of these loads, MB_JIT_DEBUG experiment in DESIGN.md 4.1c): bnext holds B(o + 1) across the step, the loads of B(o + 2)
+  // are issued at its top, and the step ends with bvec <- bnext, bnext <- what arrived.
+  double bnext[JBV];
+  {
+    const double *bs = cellPtrB(min(i, inLen), min(max(t0 - c + 1, 0), outLen));
+#pragma unroll
+    for (int k = 0; k < JBV; ++k) bnext[k] = bs[min(k * LPG + q, S - 1)];
+  }
+#endif
 #if JTB
   const int tbColOff = (int)((const char *)tbL - ldsb) + c * JTBS;
 #else
@@ -426,7 +437,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     // Backward supercell (i, o+1) of the next step: registers now, LDS after this step's counting (clamped, unconditional)
     double bpre[JBV];
     {
-      const double *bs = cellPtrB(min(i, inLen), min(max(o + 1, 0), outLen));
+      const double *bs = cellPtrB(min(i, inLen), min(max(o + JBDIST, 0), outLen));
 #pragma unroll
       for (int k = 0; k < JBV; ++k) bpre[k] = (JDBG & 1) ? -1.0 : bs[min(k * LPG + q, S - 1)];
     }
@@ -465,7 +476,13 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
 #if JMODE == 2
 #pragma unroll
+#if JBDIST == 2
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = JFLAT ? bnext[k] + negLL : bnext[k]; }
+#pragma unroll
+    for (int k = 0; k < JBV; ++k) bnext[k] = bpre[k];
+#else
     for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = JFLAT ? bpre[k] + negLL : bpre[k]; }
+#endif
 #endif
 #if JMAT == 2
     if (wantHalo) {

@@ -1846,6 +1846,24 @@ def test_deterministic_counts_reproduce_bit_for_bit(capi, oracle_mod, machines, 
     dm.close()
 
 
+def test_counts_when_pytorch_is_imported_first(capi):
+    """A host that imports PyTorch before this library makes libmbhip.so bind to the HIP runtime and hiprtc that PyTorch bundles
+    (ROCm 7.0 here, /opt/rocm is 7.2): every kernel is then generated by another compiler.  Round 4 found the one place that
+    mattered -- that compiler reports three AGPR-parked registers of the 482-state count kernel as spilled at every budget, the
+    re-planning loop ran out of attempts and left the placement one step ahead of the code: counts of 1e19 -- in a full `pytest
+    tests` run only (tests/test_distributed.py imports torch at collection).  In a process of its own: torch first, then the
+    C4b count sweep against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "torch_first_probe.py")], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, MB_JIT_CACHE="0"), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if "hiprtc |" in l][-1]
+    errs = [float(tok.split()[-1]) for tok in line.split("|")[1:3]]
+    assert max(errs) < 1e-5, line
+
+
 def test_workspace_eviction_between_modes(capi, machines):
     """the memory budget counts cached workspaces as reclaimable, so a call that needs a big slot must be able to
     evict the pools earlier calls left behind.  Alternate Forward (pool 0), counts (pools 0 + 1) and Viterbi under an
