@@ -163,7 +163,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        // 593 -> 617, the count sweep 224 -> 220 (its step is paced by the Backward loads, not by the barrier): off for that one
        << "\n#define JNBSYNC " << ((env_int("MB_JIT_NEIGHBOUR_SYNC", mode == MED_MODE_COUNT ? 0 : 1) && matKind == MED_MAT_ROLL && P.haloStates.size() <= 64 && geo.waves > 1 && geo.waves <= 16) ? 1 : 0)
        << "\n#define JFLAGOFF " << lds_payload_bytes(P, geo, mode)
-       << "\n#define JBDIST " << (env_int("MB_JIT_B_DISTANCE", 2) == 2 ? 2 : 1)      // count sweep: steps the Backward supercells are fetched ahead
+       << "\n#define JBDIST " << (env_int("MB_JIT_B_DISTANCE", 1) == 2 ? 2 : 1)      // count sweep: steps the Backward supercells are fetched ahead (2: measured 218 vs 221 G lattice-cells/s -- the loads cost issue and LDS writes, not exposed latency)
        << "\n#define JDBG " << env_int("MB_JIT_DEBUG", 0)      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
        << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode

@@ -363,9 +363,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   (void)aB; (void)accBase; (void)negLL;
 #endif
 #if JMODE == 2 && JBDIST == 2
-  // The Backward supercells are fetched TWO steps ahead (round 4: with one step of distance a fifth of the count sweep was the
-  // latency of these loads, MB_JIT_DEBUG experiment in DESIGN.md 4.1c): bnext holds B(o + 1) across the step, the loads of B(o + 2)
-  // are issued at its top, and the step ends with bvec <- bnext, bnext <- what arrived.
+  // MB_JIT_B_DISTANCE=2 (experiment, round 4): the Backward supercells fetched TWO steps ahead -- bnext holds B(o + 1) across the
+  // step, the loads of B(o + 2) are issued at its top, and the step ends with bvec <- bnext, bnext <- what arrived.  No gain: what
+  // the loads cost the count sweep (a fifth of it, MB_JIT_DEBUG experiment in DESIGN.md 4.1c) is their issue, not their latency.
   double bnext[JBV];
   {
     const double *bs = cellPtrB(min(i, inLen), min(max(t0 - c + 1, 0), outLen));
