@@ -105,14 +105,20 @@ int mb_batch_forward(mb_batch *b, int flags, double *loglike);
  * loglike[nPairs]; pathOff[nPairs+1] (output) delimits each pair's start->end list of global edge ids in
  * pathEdges[pathCap].  A pair whose end cell is -inf gets an empty path (the reference refuses to trace it,
  * src/dpmatrix.defs.h:84, target/boss.cpp:831).  pathEdges may be NULL to skip tracebacks.
- * mb_viterbi_path_bound gives a sufficient pathCap contribution for one pair. */
+ * mb_viterbi_path_bound gives a sufficient pathCap contribution for one pair.
+ * With paths the fill keeps ONE traceback byte per cell instead of the fp64 cell wherever the machine's family can (small and
+ * tiled families always; one-tape family when the fp64 matrices would take a quarter of the memory budget, option MB_ONETAPE_TB);
+ * scores and paths are the reference's either way (first maximum in its enumeration order, src/dpmatrix.defs.h:93-103,171-174). */
 int64_t mb_viterbi_path_bound(const mb_machine *m, int64_t inLen, int64_t outLen);
 int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap);
 
 /* MachineCounts(eval, seqPairList): E-step                        src/counts.cpp:37-64, src/backward.cpp:58-87
  * counts[nTrans] += posterior expected usage of every transition, summed over the batch;
  * *loglikeSum += sum of forward.logLike() (MachineCounts::loglike); loglike[nPairs] optional (may be NULL).
- * Pairs with a -inf likelihood contribute nothing to counts (the reference would produce NaN there). */
+ * Pairs with a -inf likelihood contribute nothing to counts (the reference would produce NaN there).
+ * The reference's loop is serial and reproduces bit for bit; here the order of some additions follows the scheduling (counts agree
+ * to ~1e-10 from run to run).  Option MB_DETERMINISTIC=1 (mb_set_option or the environment, read when the call begins) puts every
+ * such accumulator into 64-bit fixed point: repeated calls return identical counts, below 1.3e8 per transition and call. */
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike);
 
 /* One full matrix back to the host, for DPMatrix::cell()/writeJson() (src/dpmatrix.defs.h:39-53), the golden
