@@ -587,6 +587,17 @@ def main():
             "loglike_checksum": float(np.sum(ll)),
             "extra": extra,
         }
+        # the figures of `extra` that other documents quote, once more at the END of the line (a reader that keeps only the tail of a
+        # long line still sees them): mode -> [rate, HBM-roofline fraction or None]
+        if extra:
+            def _rf(k, rate_key="value", roof="roofline"):
+                v = extra.get(k) or {}
+                return [v.get(rate_key), (v.get(roof) or {}).get("frac")] if rate_key in v else None
+            out["summary"] = {"headline": [out["value"], out["roofline"]["frac"]], "rolling_gcells": extra.get("rolling_gcells_per_gpu"),
+                              "counts4": _rf("counts4"), "viterbi4_with_paths": _rf("viterbi4"), "counts_config3": _rf("counts"), "forward_config3": _rf("forward_config3"),
+                              "config4b_forward_materialised": _rf("config4b", "forward_materialised"), "config4b_counts": _rf("config4b", "counts_lattice", "roofline_counts"),
+                              "config5_50kb_forward_viterbi": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill")],
+                              "unit": "G cells/s (counts: G lattice-cells/s), fraction of 8 TB/s at the mode's algorithmic bytes"}
         print(json.dumps(out))
     if grp:
         grp.close()
