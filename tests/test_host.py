@@ -202,3 +202,43 @@ def test_logsumexp_header_compiles(tmp_path):
     subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "cxx"), str(src), "-o", exe,
                            "-L", libdir, "-lmbhip", "-Wl,-rpath," + libdir])
     assert subprocess.run([exe]).returncode == 0
+
+
+def test_count_programs_of_the_tiled_family_generate(tmp_path, monkeypatch):
+    """Host only (mb_debug_jit_source needs no device): the two count programs of the tiled family for psw2dna.  FLAT (round 4): the
+    closure Forward rounds carry no usage terms, ONE usage pass follows them whose slots cover the transitions that apply to a
+    cell (input-token 1280 / 20, output-token 258 / 4, silent 146 over 32 lanes: 2 + 3 + 5), every transition of the machine sits
+    in exactly one usage record.  LEVELLED (MB_MEDIUM_COUNT_FLAT=0): the exact program, usage terms from the log-sum-exp's own
+    exponentials times one exp(max + B - LL) per state."""
+    from machineboss_amd import capi
+    m = Machine.fromFile(golden_path("preset", "psw2dna.json"))
+    em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    flat = str(tmp_path / "flat.hip")
+    capi.debug_jit_source(em, flat, mode=3 + 16, closure=2, G=2)
+    src = open(flat).read()
+    assert "#define JFLAT 1" in src and "usage pass: 10 slot(s)" in src and "sB_" not in src
+    body = src[src.index("usage pass: 10 slot(s)"):]
+    assert body.count("ex2(x") == 10                                   # one exponential per usage slot, none in the fill rounds' count path
+    monkeypatch.setenv("MB_MEDIUM_COUNT_FLAT", "0")
+    lev = str(tmp_path / "lev.hip")
+    capi.debug_jit_source(em, lev, mode=3 + 16, closure=2, G=2)
+    src0 = open(lev).read()
+    assert "#define JFLAT 0" in src0 and "usage pass" not in src0 and "sB_" in src0 and "ex2(mx_" in src0
+
+
+def test_vector_issue_model_runs_on_a_generated_kernel(tmp_path):
+    """scripts/valu_model.py end to end without a GPU: generate the rolling-Forward tile kernel of psw2dna,
+    cross-compile it to gfx950 ISA, count the step loop -- a few hundred vector instructions for 4 x 271 cells, i.e. a quarter of
+    an issue slot per cell (profiles/r04_valu_model.json: 0.26)."""
+    import json
+    import subprocess
+    import sys
+    from machineboss_amd import capi
+    m = Machine.fromFile(golden_path("preset", "psw2dna.json"))
+    em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    d = tmp_path / "jit"; d.mkdir()
+    capi.debug_jit_source(em, str(d / "psw2dna.sum.tiles.fwd.clos.hip"), mode=16, closure=2, G=4)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "valu_model.py"), str(d), str(d / "model.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    k = json.load(open(d / "model.json"))["kernels"]["psw2dna.sum.tiles.fwd.clos.hip"]
+    assert k["cells_per_loop"] == 4 * 271 and 150 <= k["loop"]["valu"] <= 400 and 0.15 <= k["issue_slots_per_cell"] <= 0.45
