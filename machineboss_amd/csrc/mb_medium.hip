@@ -506,7 +506,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   bool anySplit = false, anySplitCur = false;
   int extraStages = 0;
   {
-    const int splitAt = allowSplit ? env_int_m("MB_MEDIUM_SPLIT_DEGREE", 8) : 0, part = 8;
+    const int splitAt = allowSplit ? env_int_m("MB_MEDIUM_SPLIT_DEGREE", 8) : 0, part = std::max(2, env_int_m("MB_MEDIUM_SPLIT_PART", 8));
     const int seedStage = closure ? 0 : lev[startNode];
     std::vector<Node> outNodes;
     for (Node &n : nodes) {
