@@ -25,12 +25,15 @@ long long jit_cache_hits() { return g_jit_hits; }
 static const char *kOpts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics"};
 static const int kNOpts = 5;
 // MB_JIT_EXTRA_OPTS: further space-separated hiprtc options (compiler experiments: "-mllvm -amdgpu-..."); part of the cache key
+// + what the caller asks for the compiles that follow (jit_more_opts; same role in the key)
+static std::string g_moreOpts;
+void jit_more_opts(const char *opts) { g_moreOpts = opts ? opts : ""; }
 static std::vector<std::string> extra_opts() {
   std::vector<std::string> v;
   const char *e = getenv("MB_JIT_EXTRA_OPTS");
-  if (!e) return v;
+  const std::string all = std::string(e ? e : "") + " " + g_moreOpts;
   std::string cur;
-  for (const char *p = e;; ++p) {
+  for (const char *p = all.c_str();; ++p) {
     if (*p == ' ' || *p == 0) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; }
     else cur += *p;
   }

@@ -12,6 +12,11 @@ namespace mb {
 // are read on every compile); a directory that is a symlink, belongs to someone else or is group/world-writable is not used.  *fromCache tells which happened.
 bool jit_compile(const std::string &src, const char *name, std::string &code, std::string *log, bool *fromCache);
 
+// Further space-separated hiprtc options for the compiles (and cache lookups, evictions) that follow, until called again with
+// nullptr.  One use: a kernel that ends up with scratch memory is compiled again with "-mllvm -amdgpu-spill-vgpr-to-agpr=0"
+// (mb_medium_jit.cpp: round 4 met a kernel of 600+ spilled VGPRs whose AGPR spill slots came back wrong under ROCm 7.2).
+void jit_more_opts(const char *opts);
+
 // Removes the cached code object of `src` (a cached file that hipModuleLoadData rejects -- truncated, or written by another
 // compiler build behind the same version number -- must not latch an error: the caller evicts it and compiles again).
 void jit_evict(const std::string &src);

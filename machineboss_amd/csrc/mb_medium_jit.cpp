@@ -219,20 +219,28 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       // steps) and reach the workgroup's LDS accumulator after the step loop -- their accumulator offset is read again there
       // instead of living in a VGPR --, the others add to LDS per step.
       flushStage();
+      // The slots go in batches of MB_JIT_FLAT_CHUNK (24): the loads of a batch are in flight together, and a program of a hundred
+      // slots (16 columns per wavefront on a dense machine) no longer keeps every record and term live at once (600+ spilled VGPRs).
       std::vector<std::string> fn(n);
+      const int chunk = env_int("MB_JIT_FLAT_CHUNK", 24) > 0 ? env_int("MB_JIT_FLAT_CHUNK", 24) : n;
       flat << "      if (JINSIDE) {  // usage pass: " << n << " slot(s); lanes of columns outside the lattice (stale ring values) sit it out\n";
-      for (int k = 0; k < n; ++k) fn[k] = rec(k);
-      for (int k = 0; k < n; ++k)
-        flat << "        const double x" << k << " = (med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)(" << fn[k] << ".srcOff & 0xFFFFu)) + " << fn[k] << ".w) + med_lds(ldsb, aB + (int)(" << fn[k] << ".srcOff >> 16));\n";
-      for (int k = 0; k < n; ++k) {
-        const MedSlotInfo &sl = ri.slots[k];
-        const std::string term = "ex2(x" + std::to_string(k) + ")";
-        if (sl.place == MED_PLACE_REG) {
-          pre << "  float acc_" << fn[k] << " = 0.0f;\n";
-          flat << "        acc_" << fn[k] << " += " << term << ";\n";
-          post << "  cnt_flush(ldsb, accBase + ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ").dstOff, acc_" << fn[k] << ");\n";
-        } else
-          flat << "        cnt_flush(ldsb, accBase + " << fn[k] << ".dstOff, " << term << ");\n";
+      for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int k1 = std::min(n, k0 + chunk);
+        if (n > chunk) flat << "        {\n";
+        for (int k = k0; k < k1; ++k) fn[k] = rec(k);
+        for (int k = k0; k < k1; ++k)
+          flat << "        const double x" << k << " = (med_lds(ldsb, " << vec[ri.slots[k].T] << " + (int)(" << fn[k] << ".srcOff & 0xFFFFu)) + " << fn[k] << ".w) + med_lds(ldsb, aB + (int)(" << fn[k] << ".srcOff >> 16));\n";
+        for (int k = k0; k < k1; ++k) {
+          const MedSlotInfo &sl = ri.slots[k];
+          const std::string term = "ex2(x" + std::to_string(k) + ")";
+          if (sl.place == MED_PLACE_REG) {
+            pre << "  float acc_" << fn[k] << " = 0.0f;\n";
+            flat << "        acc_" << fn[k] << " += " << term << ";\n";
+            post << "  cnt_flush(ldsb, accBase + ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ").dstOff, acc_" << fn[k] << ");\n";
+          } else
+            flat << "        cnt_flush(ldsb, accBase + " << fn[k] << ".dstOff, " << term << ");\n";
+        }
+        if (n > chunk) flat << "        }\n";
       }
       flat << "      }\n";
       continue;
@@ -404,6 +412,18 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
       if (O.module) (void)hipModuleUnload((hipModule_t)O.module);
       O = MedJit();
     }
+  }
+  // A kernel that keeps scratch memory at the last budget is compiled once more with the VGPR -> AGPR spill path of the compiler
+  // switched off.  Round 4, ROCm 7.2: the 126-slot usage pass of a flat count program as ONE batch (618 spilled VGPRs, 512 registers
+  // in use) lost the Backward values of one group of four states -- same source right at -O1 and with this option, wrong at -O3;
+  // in the ISA the value travels a248 -> a219 through v_accvgpr_mov between its spill and its reload.  The pass is batched now
+  // (MB_JIT_FLAT_CHUNK) and no kernel of the test suite or the bench ends here; MB_JIT_AGPR_SPILLS=1 keeps the compiler's default.
+  struct MoreOpts { bool on; explicit MoreOpts(bool o) : on(o) { if (on) jit_more_opts("-mllvm -amdgpu-spill-vgpr-to-agpr=0"); } ~MoreOpts() { if (on) jit_more_opts(nullptr); } };
+  const MoreOpts noAgprSpills(jit_kernel_meta(code, ".private_segment_fixed_size") > 0 && env_int("MB_JIT_AGPR_SPILLS", 0) == 0);
+  if (noAgprSpills.on) {
+    std::string log;
+    if (!jit_compile(src, "mb_medium_jit.hip", code, &log, &fromCache)) return false;
+    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit: scratch memory at the last budget -- compiled again without AGPR spill slots (scratch %lld bytes)\n", jit_kernel_meta(code, ".private_segment_fixed_size"));
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;

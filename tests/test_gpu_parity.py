@@ -408,6 +408,32 @@ def test_tiled_family_128_step_tiles_and_both_count_programs(capi, oracle_mod, m
     assert close(counts, ref_c, 1e-5, 1e-7)
 
 
+def test_flat_count_program_of_a_hundred_slots(capi, oracle_mod):
+    """16 columns per wavefront on a dense 100-state machine: four lanes per column, so the usage pass of the flat count program
+    has 126 slots.  Emitted as one batch it kept every record and term live at once (600-800 spilled VGPRs) and the sweep lost the
+    Backward values of one group of four states (knob fuzz, seed 46000 case 19: counts of 27 transitions wrong by up to 7.7); the
+    pass now goes in batches of MB_JIT_FLAT_CHUNK slots (mb_medium_jit.cpp).  Oracle: src/backward.cpp:58-87."""
+    from randmachine import random_machine, random_seq
+    em = random_machine(100, 1, 2, 46019, density=2.5, silent_density=1.5)
+    rng = np.random.RandomState(7)
+    pairs = [(random_seq(rng, il, 1), random_seq(rng, ol, 2)) for il, ol in ((31, 36), (29, 50), (0, 9), (17, 0), (40, 140), (33, 31), (8, 61))]
+    om = oracle_mod.OracleMachine(em)
+    pairs = [(x, y) for x, y in pairs if om.loglike(x, y, oracle_mod.SUM_EXACT) > -math.inf]     # (the oracle's counts of an impossible pair are NaN)
+    assert len(pairs) >= 3
+    ref = np.zeros(em.nTransitions); lls = [om.counts_add(x, y, ref, oracle_mod.SUM_EXACT) for x, y in pairs]
+    got = {}
+    for G in ("16", "8"):
+        capi.set_option("MB_MEDIUM_G", G)
+        try:
+            dm = capi.DeviceMachine(em)
+            cnt, s, cll = capi.DeviceBatch.from_pairs(dm, pairs).counts(); assert capi.last_kernel_name() == "k_medium_jit"
+            dm.close()
+        finally:
+            capi.set_option("MB_MEDIUM_G", None)
+        assert close(cll, lls, FAST_REL, FAST_ABS)
+        assert close(cnt, ref, 1e-5, 1e-7), (G, float(np.abs(cnt - ref).max()))
+
+
 def _ram_gb():
     import psutil
     return psutil.virtual_memory().available / 1e9

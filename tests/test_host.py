@@ -226,6 +226,34 @@ def test_count_programs_of_the_tiled_family_generate(tmp_path, monkeypatch):
     assert "#define JFLAT 0" in src0 and "usage pass" not in src0 and "sB_" in src0 and "ex2(mx_" in src0
 
 
+def test_flat_usage_pass_goes_in_batches(tmp_path, monkeypatch):
+    """A dense 100-state machine at 16 columns per wavefront (four lanes per column): 122 usage slots, emitted in batches of
+    MB_JIT_FLAT_CHUNK (24) so that a batch's records and terms are what is live, not the whole pass (mb_medium_jit.cpp; as ONE batch
+    the kernel spilled 600-800 VGPRs and its counts were wrong on the device, tests/test_gpu_parity.py).  The cross-compiled kernel
+    of the batched pass keeps within the register file of a one-wavefront workgroup."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from randmachine import random_machine
+    from machineboss_amd import capi
+    em = random_machine(100, 1, 2, 46019, density=2.5, silent_density=1.5)
+    monkeypatch.setenv("MB_JIT_REGBUDGET", "0")
+    one = str(tmp_path / "batched.hip")
+    capi.debug_jit_source(em, one, mode=3, closure=8, G=16)
+    src = open(one).read()
+    assert "usage pass: 122 slot(s)" in src
+    body = src[src.index("usage pass: 122 slot(s)"):]
+    assert body.count("ex2(x") == 122 and body.count("\n        {\n") == 6
+    asm = str(tmp_path / "batched.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-munsafe-fp-atomics", "-include", "hip/hip_runtime.h",
+                           "-x", "hip", "--cuda-device-only", "-S", "-o", asm, one], stderr=subprocess.DEVNULL, timeout=600)
+    spill = [ln for ln in open(asm) if ".vgpr_spill_count" in ln]
+    assert spill and int(spill[0].split(":")[1]) == 0, spill
+    monkeypatch.setenv("MB_JIT_FLAT_CHUNK", "0")
+    capi.debug_jit_source(em, one, mode=3, closure=8, G=16)
+    assert open(one).read().count("\n        {\n") == 0
+
+
 def test_vector_issue_model_runs_on_a_generated_kernel(tmp_path):
     """scripts/valu_model.py end to end without a GPU: generate the rolling-Forward tile kernel of psw2dna,
     cross-compile it to gfx950 ISA, count the step loop -- a few hundred vector instructions for 4 x 271 cells, i.e. a quarter of
