@@ -928,7 +928,7 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   if (maxCols < P.G) return false;
   // one or two lanes per supercell (machines with a handful of states): a 512-column strip wastes half its steps on
   // the skewed start/end of a 1 kb sweep; 8 wavefronts (256 columns) measured best on dnapsw / protpsw
-  int waves = (int)std::min<long long>(maxCols / P.G, (P.counting || P.LPG <= 2) ? 8 : 16);
+  int waves = (int)std::min<long long>(maxCols / P.G, P.counting ? std::max(1, std::min(16, env_int_m("MB_MEDIUM_COUNT_MAXWAVES", 8))) : (P.LPG <= 2 ? 8 : 16));
   // S must be covered by 4 halo registers per thread
   while (waves < 16 && (long long)waves * 64 * 4 < m->S && (long long)(waves + 1) * P.G <= maxCols) ++waves;
   if ((long long)waves * 64 * 4 < m->S || (long long)waves * P.G > maxCols) return false;

@@ -309,20 +309,34 @@ __device__ __forceinline__ void wide_lds_write(unsigned a, double v) { *(wide_ld
 // profile composite, 21 761 states); penalties and the token window stay in LDS.  Records then carry ring ENTRIES (src >> 13).
 // lane-group reduction of (value, place): the maximum, and among equal maxima the SMALLEST place -- the first maximum of the
 // reference's enumeration (std::max_element, src/dpmatrix.defs.h:171-174); lanes of a group hold places slot * g + lane
+// Two butterflies: the maximum first (the plain max reduction), then -- lanes that hold the maximum keep their place, the others take
+// 0xFFFFFFFF -- the minimum of the places (one v_min_u32 per step instead of two fp64 compares and three selects on a pair).
 template <int H>
-__device__ __forceinline__ void wide_tb_step(double &m, uint32_t &key, int g) {
-  const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
+__device__ __forceinline__ void wide_key_step(uint32_t &key, int g) {
   const uint32_t ko = (uint32_t)wide_xor_lane<H>((int)key);
-  const bool take = (H < g) && (mo > m || (mo == m && ko < key));
-  m = take ? mo : m; key = take ? ko : key;
+  if (H < g) key = min(key, ko);
+}
+template <int H>
+__device__ __forceinline__ void wide_rawmax_step(double &m, int g) {
+  const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
+  const double mx = wide_max_raw(m, mo);
+  m = (H < g) ? mx : m;
 }
 __device__ __forceinline__ void wide_group_reduce_tb(double &m, uint32_t &key, int g, int gWave) {
-  if (gWave > 1) wide_tb_step<1>(m, key, g);
-  if (gWave > 2) wide_tb_step<2>(m, key, g);
-  if (gWave > 4) wide_tb_step<4>(m, key, g);
-  if (gWave > 8) wide_tb_step<8>(m, key, g);
-  if (gWave > 16) wide_tb_step<16>(m, key, g);
-  if (gWave > 32) wide_tb_step<32>(m, key, g);
+  const double own = m;
+  if (gWave > 1) wide_rawmax_step<1>(m, g);
+  if (gWave > 2) wide_rawmax_step<2>(m, g);
+  if (gWave > 4) wide_rawmax_step<4>(m, g);
+  if (gWave > 8) wide_rawmax_step<8>(m, g);
+  if (gWave > 16) wide_rawmax_step<16>(m, g);
+  if (gWave > 32) wide_rawmax_step<32>(m, g);
+  key = (own == m) ? key : 0xFFFFFFFFu;              // (a maximum is one of its operands, bit for bit; -inf == -inf: place 0 of the first lane wins)
+  if (gWave > 1) wide_key_step<1>(key, g);
+  if (gWave > 2) wide_key_step<2>(key, g);
+  if (gWave > 4) wide_key_step<4>(key, g);
+  if (gWave > 8) wide_key_step<8>(key, g);
+  if (gWave > 16) wide_key_step<16>(key, g);
+  if (gWave > 32) wide_key_step<32>(key, g);
 }
 
 // TB (max sweep only): `pool` holds one traceback CODE per cell (bytes, wide_tb_stride(S) per column, PairDesc::cellBase = byte
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
-            if (TB) { if (codes && x < (unsigned)S) codeRow[(long long)cSign * (long long)kq * Sb + x] = (unsigned char)key; }
+            if (TB) { if (codes && x < (unsigned)S) codeRow[__umul24(kq, (unsigned)Sb) + x] = (unsigned char)key; }      // (traceback codes: forward sweeps only, cSign = 1)
             else if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -1586,8 +1600,13 @@ int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, lo
 // most one column per step) in two halves, one walked by the first lane while the other wavefronts fetch the rows below it,
 // and the decode tables when they fit beside the window (else they are read through L2).  The path is written backwards as
 // positions of the incoming view; a second kernel turns them into edge ids (off the walker's chain).
-struct WideTbWalk { const int *tbOff; const uint32_t *tbEntry; long long nEntries; int tablesInLds, rowsPerHalf; };      // (in LDS the offsets are 16-bit: nEntries < 65536 there)
+struct WideTbWalk { const int *tbOff; const uint32_t *tbEntry; long long nEntries; int tablesInLds, rowsPerHalf, fast; };      // (in LDS the offsets are 16-bit: nEntries < 65536 there)
 
+// `fast` (tables in LDS and 8 more bytes per state fit beside them): the low halves -- emitting << 15 | source state -- of a state's
+// first FOUR entries sit in one 8-byte LDS word, read together with the code, so the chain from one step to the next is ONE LDS
+// round trip (code and word in parallel, a shift) instead of two (code, then entry); the entry itself is still read -- its high half
+// is the position the path records -- but one step late, together with the next step's reads, off the chain.  A code >= 4, the seed
+// and a full slot take the plain step below.
 __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, WideTbWalk Q, const PairDesc *__restrict__ pairs, int inputTape,
                                                                 const unsigned char *__restrict__ tb, const double *__restrict__ loglike,
                                                                 const long long *__restrict__ slotOff, uint32_t *__restrict__ pathBuf,
@@ -1598,12 +1617,21 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
   const int S = m.S, Sb = (S + 3) & ~3, L = inputTape ? pd.inLen : pd.outLen, tid = threadIdx.x;
   const int R = Q.rowsPerHalf, rowW = Sb >> 2;
   unsigned int *win = twl;                                         // [2][R][rowW]: half h holds columns hi(h) - R + 1 .. hi(h)
-  unsigned int *entL = twl + 2 * (size_t)R * rowW;                // decode tables (tablesInLds): entries, then 16-bit offsets
+  const size_t winWords = (2 * (size_t)R * rowW + 1) & ~(size_t)1;
+  unsigned long long *fastL = (unsigned long long *)(twl + winWords);   // (fast) [S]: 4 x 16 bits, 0xFFFF = no such entry / the seed
+  unsigned int *entL = twl + winWords + (Q.fast ? 2 * (size_t)S : 0);   // decode tables (tablesInLds): entries, then 16-bit offsets
   unsigned short *offL = (unsigned short *)(entL + Q.nEntries);
   if (!(loglike[p] > -INFINITY)) { if (tid == 0) pathLen[p] = -1; return; }      // no path: src/dpmatrix.defs.h:84
   if (Q.tablesInLds) {
     for (int k = tid; k <= S; k += 256) offL[k] = (unsigned short)Q.tbOff[k];
     for (long long k = tid; k < Q.nEntries; k += 256) entL[k] = Q.tbEntry[k];
+    if (Q.fast)
+      for (int k = tid; k < S; k += 256) {
+        const int o0 = Q.tbOff[k], cnt = Q.tbOff[k + 1] - o0;
+        unsigned long long w = 0ull;
+        for (int j = 0; j < 4; ++j) w |= (unsigned long long)(j < cnt ? (Q.tbEntry[o0 + j] & 0xFFFFu) : 0xFFFFu) << (16 * j);
+        fastL[k] = w;
+      }
   }
   const unsigned int *rows = (const unsigned int *)(tb + pd.cellBase);      // (cellBase and Sb are multiples of 4)
   auto fill = [&](int half, int hi, int first, int nThreads) {    // columns hi - R + 1 .. hi (those that exist) into half `half`, by threads first .. first + nThreads - 1
@@ -1620,6 +1648,7 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
   const long long cap = slotOff[p + 1] - slotOff[p];
   long long n = 0;
   int c = L, s = S - 1, status = 0;                               // status: 0 walking, 1 done, -2 slot full, -3 dead end
+  int pend = -1;                                                   // fast: index of the entry whose position out[-n] is still owed
   for (int w = 0, hi = L; hi >= 0 && status == 0; ++w, hi -= R) {
     const int half = w & 1;
     if (tid >= 64) fill(half ^ 1, hi - R, 64, 192);                // the rows below this half, fetched while it is walked
@@ -1629,6 +1658,19 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
       while (status == 0 && c >= base) {
         if (c == 0 && s == 0) { status = 1; break; }
         const unsigned int code = hb[(size_t)(c - base) * Sb + s];
+        if (Q.fast) {
+          const unsigned long long fw = fastL[s];
+          const int o0f = (int)offL[s];
+          const unsigned int owed = entL[max(pend, 0)];             // last step's entry, read beside this step's code and word
+          if (pend >= 0) { out[-n] = owed >> 16; pend = -1; }
+          const unsigned int f16 = code < 4u ? (unsigned int)(fw >> (16 * code)) & 0xFFFFu : 0xFFFFu;
+          if (f16 != 0xFFFFu && n < cap && !((f16 & 0x8000u) && c == 0)) {
+            ++n; pend = o0f + (int)code;
+            s = (int)(f16 & 0x7fffu);
+            c -= (int)(f16 >> 15);
+            continue;
+          }
+        }
         const int o0 = Q.tablesInLds ? (int)offL[s] : Q.tbOff[s], o1 = Q.tablesInLds ? (int)offL[s + 1] : Q.tbOff[s + 1];
         if ((int)code >= o1 - o0) { status = -3; break; }
         const unsigned int e = Q.tablesInLds ? entL[o0 + code] : Q.tbEntry[o0 + code];
@@ -1639,6 +1681,7 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
         s = (int)(e & 0x7fffu);
         if (e & 0x8000u) { if (c == 0) { status = -3; break; } --c; }
       }
+      if (pend >= 0) { out[-n] = entL[pend] >> 16; pend = -1; }      // (a half ends, or the walk does: nothing is owed across the barrier)
     }
     __syncthreads();
   }
@@ -1658,15 +1701,17 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
   if (!P.tbOk) { set_error("one-tape traceback-code program not built"); return 1; }
   if (nPairs <= 0) return 0;
   const int S = m->S, Sb = wide_tb_stride(S);
-  const size_t tabBytes = (((size_t)(S + 1) * 2 + 3) & ~(size_t)3) + (size_t)P.tbEntries * 4;
-  WideTbWalk Q{P.d_tbOff, P.d_tbEntry, P.tbEntries, 0, 1};
+  size_t tabBytes = (((size_t)(S + 1) * 2 + 3) & ~(size_t)3) + (size_t)P.tbEntries * 4;
+  WideTbWalk Q{P.d_tbOff, P.d_tbEntry, P.tbEntries, 0, 1, 0};
   const size_t budget = 150 * 1024;
-  // the window wants at least 2 x 2 rows; the tables go to LDS when 2 x 4 rows still fit beside them
+  // the window wants at least 2 x 2 rows; the tables go to LDS when 2 x 4 rows still fit beside them, the fast words (8 bytes per
+  // state) when they do too
   if (tabBytes + (size_t)8 * Sb <= budget && P.tbEntries < 65536) Q.tablesInLds = 1;
+  if (Q.tablesInLds && tabBytes + (size_t)S * 8 + 8 + (size_t)8 * Sb <= budget && env_int_w("MB_ONETAPE_TB_FAST", 1) != 0) { Q.fast = 1; tabBytes += (size_t)S * 8 + 8; }
   const size_t forRows = budget - (Q.tablesInLds ? tabBytes : 0);
   Q.rowsPerHalf = (int)std::max<size_t>(1, std::min<size_t>(forRows / (2 * (size_t)Sb), 32));
   if ((size_t)2 * Q.rowsPerHalf * Sb > budget) { set_error("one-tape traceback codes: a code row exceeds the LDS"); return 1; }
-  const size_t lds = (size_t)2 * Q.rowsPerHalf * Sb + (Q.tablesInLds ? tabBytes : 0);
+  const size_t lds = (size_t)2 * Q.rowsPerHalf * Sb + 8 + (Q.tablesInLds ? tabBytes : 0);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_onetape_traceback_codes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_traceback_codes, dim3((unsigned)nPairs), dim3(256), lds, st, m->dev, Q, d_pairs, m->nIn != 0 ? 1 : 0, tb, d_loglike, d_slotOff, d_pathBuf, d_pathLen);

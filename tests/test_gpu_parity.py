@@ -1245,7 +1245,7 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}, {"MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_ONETAPE_TB": "1"}, {"MB_ONETAPE_TB": "1", "MB_WIDE_GLOBAL_VECTORS": "1"}])
+@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}, {"MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_ONETAPE_TB": "0"}, {"MB_ONETAPE_TB": "0", "MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_ONETAPE_TB_FAST": "0"}])
 def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
     """The retimed sweep of the one-tape family (mb_wide.hip k_wide_retimed: every state on its own column, a period of a
     few wide rounds instead of one round per silent level): Viterbi matrices bit for bit, Forward / Backward matrices and
@@ -1288,9 +1288,9 @@ def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
         b = capi.DeviceBatch.from_pairs(dm, pairs)
         ll = b.forward(capi.MB_ROLLING); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
         vll, off, edges = b.viterbi()
-        # (paths: the fp64 matrix and its walkers, or -- MB_ONETAPE_TB=1, round 4; by itself only for batches whose fp64 matrices would
-        # take a quarter of the device memory -- one traceback CODE per cell kept by the max sweep, walked by k_onetape_traceback_codes)
-        assert ("codes" in capi.last_kernel_name()) == ("MB_ONETAPE_TB" in knobs)
+        # (paths: one traceback CODE per cell kept by the max sweep, walked by k_onetape_traceback_codes -- round 4, the default since the
+        # code sweep's reduction became two butterflies -- or, MB_ONETAPE_TB=0, the fp64 matrix and its walkers)
+        assert ("codes" in capi.last_kernel_name()) == (knobs.get("MB_ONETAPE_TB") != "0")
         counts, s, _ = b.counts()
         assert close(counts, ref, 1e-5, 1e-7)
         for k, (x, y) in enumerate(pairs):
