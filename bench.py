@@ -317,11 +317,16 @@ def extra_single_gpu(capi, np, hbm_peak):
         cells5f = b5f.cells()
         ll5f, t5f = timed(lambda: b5f.forward(capi.MB_ROLLING), 1); k5f = capi.last_kernel_name()
         (v5f, _, _), t5vf = timed(lambda: b5f.viterbi(paths=False), 1); k5vf = capi.last_kernel_name()
-        out["config5"]["full_size"] = {"workload": "the same machine, 64 sequences x 50000 nt (BASELINE config 5 as stated, all on one GPU)", "cells": int(cells5f),
+        # --align at that size: one traceback code per cell (16 GB where the fp64 Viterbi matrices would be 130), the paths on the host
+        (v5p, o5p, e5p), t5pf = timed(lambda: b5f.viterbi(), 1); k5pf = capi.last_kernel_name()
+        out["config5"]["full_size"] = {"viterbi_with_paths": round(cells5f / t5pf / 1e9, 2), "viterbi_with_paths_ms": round(t5pf * 1e3, 1), "path_edges": int(len(e5p)),
+                                       "paths_kernel": k5pf, "paths_score_equals_fill": bool(np.array_equal(v5p, v5f)),
+                                       "note_paths": "the paths are oracle-checked bit for bit at this length in tests/test_gpu_parity.py (test_baseline_config5_one_sequence_at_50kb_against_the_oracle)"}
+        out["config5"]["full_size"].update({"workload": "the same machine, 64 sequences x 50000 nt (BASELINE config 5 as stated, all on one GPU)", "cells": int(cells5f),
                                        "forward_rolling": round(cells5f / t5f / 1e9, 2), "forward_ms": round(t5f * 1e3, 1), "viterbi_fill": round(cells5f / t5vf / 1e9, 2),
                                        "viterbi_ms": round(t5vf * 1e3, 1), "unit": "Gcells/s", "kernels": [k5f, k5vf], "loglike_sum": float(np.sum(ll5f)),
-                                       "viterbi_le_forward": bool(np.all(v5f <= ll5f + 1e-6 * np.abs(ll5f)))}
-        del b5f
+                                       "viterbi_le_forward": bool(np.all(v5f <= ll5f + 1e-6 * np.abs(ll5f)))})
+        del b5f, e5p
     except Exception as e:   # the extras never take the headline down
         out["config5"] = {"error": str(e)}
 
@@ -599,7 +604,7 @@ def main():
             out["summary"] = {"headline": [out["value"], out["roofline"]["frac"]], "rolling_gcells": extra.get("rolling_gcells_per_gpu"),
                               "counts4": _rf("counts4"), "viterbi4_with_paths": _rf("viterbi4"), "counts_config3": _rf("counts"), "forward_config3": _rf("forward_config3"),
                               "config4b_forward_materialised": _rf("config4b", "forward_materialised"), "config4b_counts": _rf("config4b", "counts_lattice", "roofline_counts"),
-                              "config5_50kb_forward_viterbi": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill")],
+                              "config5_50kb_forward_viterbi_withpaths": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill", "viterbi_with_paths")],
                               "unit": "G cells/s (counts: G lattice-cells/s), fraction of 8 TB/s at the mode's algorithmic bytes"}
         print(json.dumps(out))
     if grp:

@@ -63,12 +63,20 @@ __device__ __forceinline__ int wide_xor_lane(int v) {
   return __shfl_xor(v, H, 64);
 }
 
+// v_max_f64 as is: the operands here are sums of finite weights or -inf, never NaN, so the quieting moves the compiler puts
+// in front of fmax() (one v_max_f64 x, x per operand) buy nothing
+__device__ __forceinline__ double wide_max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // lane-group reduction, all lanes of the group end with the group's result: butterfly over the maxima, one rescale of
 // the lane's own sum to the group maximum, butterfly over the sums
 template <int MODE, int H>
 __device__ __forceinline__ void wide_max_step(double &m, int g) {
   const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
-  if (H < g) m = (MODE == MB_VITERBI) ? dmax(m, mo) : __builtin_fmax(m, mo);
+  if (MODE == MB_VITERBI) { const double mx = wide_max_raw(m, mo); m = (H < g) ? mx : m; }      // (one v_max_f64 + selects; a compare-and-select maximum is two more)
+  else if (H < g) m = __builtin_fmax(m, mo);
 }
 template <int H>
 __device__ __forceinline__ void wide_sum_step(float &s, int g) {
@@ -266,13 +274,6 @@ __global__ __launch_bounds__(1024) void k_wide_viterbi(WideDev P, WideVitDev Q, 
 }
 
 // ---- retimed programs: a period of rounds, every node on its own column (see WideRetDev) ---------------------------------------
-// v_max_f64 as is: the operands here are sums of finite weights or -inf, never NaN, so the quieting moves the compiler puts
-// in front of fmax() (one v_max_f64 x, x per operand) buy nothing
-__device__ __forceinline__ double wide_max_raw(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 // lane-group reduction of a wavefront whose groups all have gWave lanes: no per-lane masks
 template <int MODE, int H>
 __device__ __forceinline__ void wide_max_all(double &m) {

@@ -35,7 +35,11 @@ c1 = e["config1_latency"]; row("1", "one 50 x 50 pair, `--loglike`", "small", c1
 c5 = e.get("config5", {})
 if "full_size" in c5:
     fs = c5["full_size"]
-    row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
+    if "viterbi_with_paths" in fs:
+        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill / with paths (traceback codes)", "one-tape", "%s / %s / %s" % (fs["forward_rolling"], fs["viterbi_fill"], fs["viterbi_with_paths"]), "G cells/s", None,
+            "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
+    else:
+        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
     row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
 cpu = b.get("cpu_baseline") or {}
 txt = ["Source: `profiles/%s_bench.json` (one `python3 bench.py` on the MI355X box; `frac` = algorithmic bytes / device time / 8 TB/s; `issue` = vector-issue fraction from the kernels' ISA, `profiles/r04_valu_model.json`, section 5).  Boxes of the pool differ by +-5 %%." % tag, "",
