@@ -1349,7 +1349,7 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
   // one-tape family: one traceback code per cell when paths are wanted (a fill without paths keeps the leaner fp64 sweep).
   // MB_ONETAPE_TB=0 forbids it (the walker then re-evaluates candidates on the fp64 Viterbi matrix).  The code sweep costs 13 % over
   // the plain max sweep (a compare and a select per candidate, a second butterfly over the places), its walker half of the fp64
-  // walker, and it moves an eighth of the bytes: 64 x 50 kb on the 5 063-state machine 328 vs 346 ms with 16 instead of 130 GB,
+  // walker, and it moves an eighth of the bytes: 64 x 50 kb on the 5 063-state machine 315 vs 346 ms with 16 instead of 130 GB,
   // 256 x 4 kb 28 vs 42 ms, 64 x 2 kb 13.3 vs 14.2, the whole fn3 composite (L2-resident ring) 158 vs 171 -- and 557 GB of fp64 for
   // that machine at 64 x 50 kb could not be resident at all.  (Until the reduction was split into two butterflies the sweep cost
   // 29 % and the route was taken only when memory asked for it.)

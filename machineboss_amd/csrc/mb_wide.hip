@@ -1640,9 +1640,23 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
     if (hi < 0) return;
     const unsigned int *src = rows + (long long)lo * rowW;
     unsigned int *dst = win + (size_t)half * R * rowW + (size_t)(lo - (hi - R + 1)) * rowW;
-    const int n = (hi - lo + 1) * rowW;
-    for (int k = tid - first; k < n; k += nThreads) dst[k] = src[k];
+    const int n = (hi - lo + 1) * rowW, nv = n >> 2;
+    // 16 bytes per lane and load, eight loads in flight per lane: with single dwords, four at a time, a half of four 5 KB rows was
+    // seven round trips to memory one after the other (3 us) -- THAT was the walker's time, not its walk (rows are 4-byte aligned:
+    // global_load_dwordx4 takes that, the LDS side is written dword by dword)
+    typedef unsigned int u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    for (int k0 = tid - first; k0 < nv; k0 += nThreads * 8) {
+      u32x4a4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * nThreads; if (k < nv) v[u] = ((const u32x4a4 *)src)[k]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int k = k0 + u * nThreads; if (k < nv) ((u32x4a4 *)dst)[k] = v[u]; }
+    }
+    for (int k = (nv << 2) + tid - first; k < n; k += nThreads) dst[k] = src[k];
   };
+  // two words behind everything else: the walk's status after half w, in word w & 1 (every thread leaves the loop with it)
+  int *flag = (int *)(Q.tablesInLds ? (char *)offL + ((((size_t)S + 1) * 2 + 3) & ~(size_t)3) : (char *)(twl + winWords));
+  if (tid < 2) flag[tid] = 0;
   fill(0, L, 0, 256);
   __syncthreads();
   uint32_t *out = pathBuf + slotOff[p + 1];
@@ -1650,42 +1664,55 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
   long long n = 0;
   int c = L, s = S - 1, status = 0;                               // status: 0 walking, 1 done, -2 slot full, -3 dead end
   int pend = -1;                                                   // fast: index of the entry whose position out[-n] is still owed
-  for (int w = 0, hi = L; hi >= 0 && status == 0; ++w, hi -= R) {
+  // The walk belongs to the first wavefront, ALL of its lanes: its state is uniform, every look-up comes back through
+  // readfirstlane, so position, state, counters and branches live on the scalar unit (a dependent scalar instruction issues every
+  // cycle or two, a dependent vector one every four to eight, and a branch needs no exec mask) -- only the LDS addresses and the
+  // value lane 0 stores pass through vector registers.  (As one lane's vector code a step was ~60 instructions and 8 masked branches.)
+#define RFL(x) ((unsigned int)__builtin_amdgcn_readfirstlane((int)(x)))
+  for (int w = 0, hi = L; hi >= 0; ++w, hi -= R) {
     const int half = w & 1;
-    if (tid >= 64) fill(half ^ 1, hi - R, 64, 192);                // the rows below this half, fetched while it is walked
-    else if (tid == 0) {
+    if (RFL(tid >> 6) != 0u) fill(half ^ 1, hi - R, 64, 192);      // the rows below this half, fetched while it is walked (a UNIFORM branch: the walk's state must not meet a per-thread join)
+    else {
       const unsigned char *hb = (const unsigned char *)(win + (size_t)half * R * rowW);
       const int base = hi - R + 1;                                 // column of the half's first row
       while (status == 0 && c >= base) {
         if (c == 0 && s == 0) { status = 1; break; }
-        const unsigned int code = hb[(size_t)(c - base) * Sb + s];
+        const unsigned int codeV = hb[(c - base) * Sb + s];        // (every look-up of the step is requested before the first one is awaited)
+        unsigned int code;
         if (Q.fast) {
           const unsigned long long fw = fastL[s];
-          const int o0f = (int)offL[s];
-          const unsigned int owed = entL[max(pend, 0)];             // last step's entry, read beside this step's code and word
-          if (pend >= 0) { out[-n] = owed >> 16; pend = -1; }
-          const unsigned int f16 = code < 4u ? (unsigned int)(fw >> (16 * code)) & 0xFFFFu : 0xFFFFu;
+          const unsigned int offV = offL[s];
+          const unsigned int owedV = entL[max(pend, 0)];            // last step's entry, read beside this step's code and word
+          code = RFL(codeV);
+          const unsigned int fwLo = RFL((unsigned int)fw), fwHi = RFL((unsigned int)(fw >> 32));
+          const int o0f = (int)RFL(offV);
+          const unsigned int owed = RFL(owedV);
+          if (pend >= 0) { if (tid == 0) out[-n] = owed >> 16; pend = -1; }
+          const unsigned int f16 = code < 4u ? (((code & 2u) ? fwHi : fwLo) >> (16u * (code & 1u))) & 0xFFFFu : 0xFFFFu;
           if (f16 != 0xFFFFu && n < cap && !((f16 & 0x8000u) && c == 0)) {
             ++n; pend = o0f + (int)code;
             s = (int)(f16 & 0x7fffu);
             c -= (int)(f16 >> 15);
             continue;
           }
-        }
-        const int o0 = Q.tablesInLds ? (int)offL[s] : Q.tbOff[s], o1 = Q.tablesInLds ? (int)offL[s + 1] : Q.tbOff[s + 1];
+        } else code = RFL(codeV);
+        const int o0 = (int)RFL(Q.tablesInLds ? (int)offL[s] : Q.tbOff[s]), o1 = (int)RFL(Q.tablesInLds ? (int)offL[s + 1] : Q.tbOff[s + 1]);
         if ((int)code >= o1 - o0) { status = -3; break; }
-        const unsigned int e = Q.tablesInLds ? entL[o0 + code] : Q.tbEntry[o0 + code];
+        const unsigned int e = RFL(Q.tablesInLds ? entL[o0 + code] : Q.tbEntry[o0 + code]);
         if (e == 0xFFFFFFFFu) { status = (c == 0) ? 1 : -3; break; }      // the seed: cell (0, start)
         if (n >= cap) { status = -2; break; }
         ++n;
-        out[-n] = e >> 16;                                         // position in the incoming view (edge ids: k_onetape_path_ids)
+        if (tid == 0) out[-n] = e >> 16;                           // position in the incoming view (edge ids: k_onetape_path_ids)
         s = (int)(e & 0x7fffu);
         if (e & 0x8000u) { if (c == 0) { status = -3; break; } --c; }
       }
-      if (pend >= 0) { out[-n] = entL[pend] >> 16; pend = -1; }      // (a half ends, or the walk does: nothing is owed across the barrier)
+      if (pend >= 0) { const unsigned int e = RFL(entL[pend]); if (tid == 0) out[-n] = e >> 16; pend = -1; }      // (a half ends, or the walk does: nothing is owed across the barrier)
+      if (tid == 0) flag[half] = status;
     }
     __syncthreads();
+    if (flag[half] != 0) break;                                    // (word w & 1 is written again two halves on, behind the next barrier)
   }
+#undef RFL
   if (tid == 0) pathLen[p] = status == 1 ? n : (status == 0 ? (c == 0 && s == 0 ? n : -3) : status);
 }
 
@@ -1712,7 +1739,7 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
   const size_t forRows = budget - (Q.tablesInLds ? tabBytes : 0);
   Q.rowsPerHalf = (int)std::max<size_t>(1, std::min<size_t>(forRows / (2 * (size_t)Sb), 32));
   if ((size_t)2 * Q.rowsPerHalf * Sb > budget) { set_error("one-tape traceback codes: a code row exceeds the LDS"); return 1; }
-  const size_t lds = (size_t)2 * Q.rowsPerHalf * Sb + 8 + (Q.tablesInLds ? tabBytes : 0);
+  const size_t lds = (size_t)2 * Q.rowsPerHalf * Sb + 8 + (Q.tablesInLds ? tabBytes : 0) + 16;      // (+ two status words)
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_onetape_traceback_codes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_traceback_codes, dim3((unsigned)nPairs), dim3(256), lds, st, m->dev, Q, d_pairs, m->nIn != 0 ? 1 : 0, tb, d_loglike, d_slotOff, d_pathBuf, d_pathLen);
