@@ -41,6 +41,13 @@ static const size_t WIDE_LDS_MAX = 160 * 1024;
 // ------------------------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------------------------
+// v_max_f64 as is: the operands here are sums of finite weights or -inf, never NaN, so the quieting moves the compiler puts
+// in front of fmax() (one v_max_f64 x, x per operand) buy nothing
+__device__ __forceinline__ double wide_max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // one candidate folded into a lane's running (max, sum of exp relative to max): exactly one of the two exponentials of
 // the usual online update is exp(0), so a single v_exp_f32 of -|v - m| serves both cases
 template <int MODE>
@@ -49,7 +56,7 @@ __device__ __forceinline__ void wide_fold(double &m, float &s, double v, float s
   const float e = __expf(-fabsf((float)(v - m)));
   const bool up = v > m;
   s = __fmaf_rn(up ? s : sv, e, up ? sv : s);
-  m = __builtin_fmax(m, v);
+  m = wide_max_raw(m, v);      // (fmax() costs two more v_max_f64 per fold: half of the maxima of the Forward sweep's ISA were x = max(x, x))
 }
 
 // value of lane (l ^ H) of the lane group: H = 1, 2 quad permutes, H = 4, 8 half-row / row mirrors (equivalent to the
@@ -63,20 +70,13 @@ __device__ __forceinline__ int wide_xor_lane(int v) {
   return __shfl_xor(v, H, 64);
 }
 
-// v_max_f64 as is: the operands here are sums of finite weights or -inf, never NaN, so the quieting moves the compiler puts
-// in front of fmax() (one v_max_f64 x, x per operand) buy nothing
-__device__ __forceinline__ double wide_max_raw(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 // lane-group reduction, all lanes of the group end with the group's result: butterfly over the maxima, one rescale of
 // the lane's own sum to the group maximum, butterfly over the sums
 template <int MODE, int H>
 __device__ __forceinline__ void wide_max_step(double &m, int g) {
   const double mo = __hiloint2double(wide_xor_lane<H>(__double2hiint(m)), wide_xor_lane<H>(__double2loint(m)));
   if (MODE == MB_VITERBI) { const double mx = wide_max_raw(m, mo); m = (H < g) ? mx : m; }      // (one v_max_f64 + selects; a compare-and-select maximum is two more)
-  else if (H < g) m = __builtin_fmax(m, mo);
+  else if (H < g) m = wide_max_raw(m, mo);
 }
 template <int H>
 __device__ __forceinline__ void wide_sum_step(float &s, int g) {
