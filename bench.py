@@ -301,8 +301,8 @@ def extra_single_gpu(capi, np, hbm_peak):
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
                           "roofline": {"bound": "valu + barriers", "note": "one workgroup per sequence on 64 of 256 CUs (Forward, cut in two: 128); the retimed sweep (DESIGN.md 4.2b) turns a column's 366 dependent silent levels into a period of 10 barrier-separated rounds with 37 columns in flight; no HBM or MFMA bound applies",
                                        "issue": {"what": "SQ_INSTS_VALU of the 64 x 50 kb dispatches / (SIMDs of the occupied CUs x cycles at 2.4 GHz) x 2 cycles per wave64 instruction on a SIMD-32, unweighted (fp64 at half rate: about 1.5 x)",
-                                                 "viterbi_fill": round(24506836032 * 2 / (64 * 4 * 0.254 * 2.4e9), 3), "forward_cut_in_two": round(21037251008 * 2 / (128 * 4 * 0.1736 * 2.4e9), 3),
-                                                 "SQ_WAIT_ANY": [0.437, 0.375], "source": "profiles/r04_onetape_pmc_sq.txt, r04_onetape_kernel_stats.csv (recorded, not re-measured in this run)"}}}
+                                                 "viterbi_fill": round(24209015808 * 2 / (64 * 4 * 0.2505 * 2.4e9), 3), "forward_cut_in_two": round(20143165376 * 2 / (128 * 4 * 0.1738 * 2.4e9), 3),
+                                                 "SQ_WAIT_ANY": [0.423, 0.402], "source": "profiles/r04_onetape_pmc_sq.txt, r04_onetape_kernel_stats.csv (recorded, not re-measured in this run)"}}}
         del b5
         # ... with every CU busy: 256 sequences x 4 kb
         b5w = capi.DeviceBatch(dm5, *synth_batch(5, 256, 0, 4000, em5.nInTok, em5.nOutTok))
