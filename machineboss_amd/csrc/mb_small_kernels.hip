@@ -182,23 +182,33 @@ __global__ __launch_bounds__(256) void k_small_traceback_wave(SmTbTables T, int 
     a = i >> 6; tTop = t; cRight = c; iA = i; oA = o;
     __builtin_amdgcn_wave_barrier();
     const uint32_t *base = words + ((long long)a * Te * 64) * NW;
-    constexpr int PER = WIN / 64, BLK = 8;                        // loads per lane, issued 8 at a time before the first is awaited
-    static_assert(WIN % (64 * BLK) == 0, "window size");
+    // 16 bytes per lane and load (a window row is WC x NW = 32 ... 64 contiguous dwords, 4-byte aligned: global_load_dwordx4 takes
+    // that), 8 loads in flight: a 16 KB window is two round trips to memory instead of eight (round 4; the one-tape code walker's
+    // window taught it).  Entries left of lane 0 or above step 0 are never looked up, so whatever a vector brings
+    // for them stays; only a vector that would START before the pair's first byte (strip 0, step 0) is read element by element.
+    constexpr int PER = WIN / 256, BLK = PER < 8 ? PER : 8;       // 16-byte loads per lane
+    static_assert(WIN % 256 == 0 && (WC * NW) % 4 == 0 && PER % BLK == 0, "window size");
+    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
     const int c0 = cRight - WC + 1;                               // first lane of the window's rows
     const int tiv = inLen > 0 ? in[max(iA - 1 - lane, 0)] : 0, tov = outLen > 0 ? out[max(oA - 1 - lane, 0)] : 0;   // requested with the block (clamped indices)
 #pragma unroll 1
     for (int k0 = 0; k0 < PER; k0 += BLK) {
-      uint32_t v[BLK];
+      u32x4a4 v[BLK];
 #pragma unroll
       for (int k = 0; k < BLK; ++k) {
-        const int idx = (k0 + k) * 64 + lane, dt = idx / (WC * NW), rem = idx - dt * (WC * NW);
-        const int tt = tTop - dt, cc = c0 + rem / NW;
-        const bool ok = tt >= 0 && cc >= 0;
-        v[k] = base[ok ? ((long long)tt * 64 + c0) * NW + rem : 0];   // unconditional (clamped) so that the loads stay in flight together
-        v[k] = ok ? v[k] : 0u;
+        const int idx = ((k0 + k) * 64 + lane) * 4, dt = idx / (WC * NW), rem = idx - dt * (WC * NW);
+        const int tt = tTop - dt;
+        const long long off = ((long long)tt * 64 + c0) * NW + rem;
+        if (tt >= 0 && (off >= 0 || a > 0)) v[k] = *(const u32x4a4 *)(base + off);
+        else {
+          u32x4a4 z;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const bool ok = tt >= 0 && c0 + (rem + j) / NW >= 0; const uint32_t x = base[ok ? off + j : 0]; z[j] = ok ? x : 0u; }
+          v[k] = z;
+        }
       }
 #pragma unroll
-      for (int k = 0; k < BLK; ++k) win[(k0 + k) * 64 + lane] = v[k];
+      for (int k = 0; k < BLK; ++k) *(u32x4a4 *)(win + ((k0 + k) * 64 + lane) * 4) = v[k];
     }
     static_assert(WC <= 64 && WT <= 64, "token windows are one load per lane");
     if (lane < WC) tokI[lane] = (iA - 1 - lane >= 0) ? tiv : 0;
