@@ -1162,7 +1162,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!hip_ok(hipMemcpyAsync(d_hb, hb.data(), b->nPairs * sizeof(long long), hipMemcpyHostToDevice, g_stream), "H2D")) { rc = 1; break; }
       tm.start();
       rc = medium_forward_rolling(m, f->fwdSum, f->geoFS, b->d_pairs, b->pairs, b->d_in, b->d_out, d_halo, d_hb, d_ll, g_stream);
-      g_last_kernel = medium_jit_ready(f->fwdSum, MB_FORWARD, false) ? "k_medium_jit" : "k_medium_tile<0>";
+      g_last_kernel = (medium_jit_ready(f->fwdSum, MB_FORWARD, MED_MAT_NONE) || medium_jit_ready(f->fwdSum, MB_FORWARD, MED_MAT_ROLL)) ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "rolling forward kernel")) rc = 1;
     } while (0);
@@ -1180,7 +1180,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     else {
       tm.start();
       rc = medium_forward_pipelined(m, f->fwdSum, f->geoFS, b->pairs, b->d_in, b->d_out, pool, (long long)(g_ws[0].bytes / 8), d_ll, g_stream);
-      g_last_kernel = medium_jit_ready(f->fwdSum, MB_FORWARD, true) ? "k_medium_jit" : "k_medium_tile<0>";
+      g_last_kernel = medium_jit_ready(f->fwdSum, MB_FORWARD, MED_MAT_FULL) ? "k_medium_jit" : "k_medium_tile<0>";
       g_last_ms += tm.stop();
     }
   } else {
