@@ -1605,8 +1605,8 @@ struct WideTbWalk { const int *tbOff; const uint32_t *tbEntry; long long nEntrie
 
 // `fast` (tables in LDS and 8 more bytes per state fit beside them): the low halves -- emitting << 15 | source state -- of a state's
 // first FOUR entries sit in one 8-byte LDS word, read together with the code, so the chain from one step to the next is ONE LDS
-// round trip (code and word in parallel, a shift) instead of two (code, then entry); the entry itself is still read -- its high half
-// is the position the path records -- but one step late, together with the next step's reads, off the chain.  A code >= 4, the seed
+// round trip (code and word in parallel, a shift) instead of two (code, then entry); the walk records the entry's INDEX, which
+// k_onetape_path_ids turns into the edge id afterwards, in parallel, off the chain.  A code >= 4, the seed
 // and a full slot take the plain step below.
 __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, WideTbWalk Q, const PairDesc *__restrict__ pairs, int inputTape,
                                                                 const unsigned char *__restrict__ tb, const double *__restrict__ loglike,
@@ -1663,7 +1663,6 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
   const long long cap = slotOff[p + 1] - slotOff[p];
   long long n = 0;
   int c = L, s = S - 1, status = 0;                               // status: 0 walking, 1 done, -2 slot full, -3 dead end
-  int pend = -1;                                                   // fast: index of the entry whose position out[-n] is still owed
   // The walk belongs to the first wavefront, ALL of its lanes: its state is uniform, every look-up comes back through
   // readfirstlane, so position, state, counters and branches live on the scalar unit (a dependent scalar instruction issues every
   // cycle or two, a dependent vector one every four to eight, and a branch needs no exec mask) -- only the LDS addresses and the
@@ -1682,15 +1681,13 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
         if (Q.fast) {
           const unsigned long long fw = fastL[s];
           const unsigned int offV = offL[s];
-          const unsigned int owedV = entL[max(pend, 0)];            // last step's entry, read beside this step's code and word
           code = RFL(codeV);
           const unsigned int fwLo = RFL((unsigned int)fw), fwHi = RFL((unsigned int)(fw >> 32));
           const int o0f = (int)RFL(offV);
-          const unsigned int owed = RFL(owedV);
-          if (pend >= 0) { if (tid == 0) out[-n] = owed >> 16; pend = -1; }
           const unsigned int f16 = code < 4u ? (((code & 2u) ? fwHi : fwLo) >> (16u * (code & 1u))) & 0xFFFFu : 0xFFFFu;
           if (f16 != 0xFFFFu && n < cap && !((f16 & 0x8000u) && c == 0)) {
-            ++n; pend = o0f + (int)code;
+            ++n;
+            if (tid == 0) out[-n] = (uint32_t)(o0f + (int)code);    // the ENTRY's index: k_onetape_path_ids turns it into the edge id, off the walk
             s = (int)(f16 & 0x7fffu);
             c -= (int)(f16 >> 15);
             continue;
@@ -1702,11 +1699,10 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
         if (e == 0xFFFFFFFFu) { status = (c == 0) ? 1 : -3; break; }      // the seed: cell (0, start)
         if (n >= cap) { status = -2; break; }
         ++n;
-        if (tid == 0) out[-n] = e >> 16;                           // position in the incoming view (edge ids: k_onetape_path_ids)
+        if (tid == 0) out[-n] = (uint32_t)(o0 + (int)code);        // the entry's index (edge ids: k_onetape_path_ids)
         s = (int)(e & 0x7fffu);
         if (e & 0x8000u) { if (c == 0) { status = -3; break; } --c; }
       }
-      if (pend >= 0) { const unsigned int e = RFL(entL[pend]); if (tid == 0) out[-n] = e >> 16; pend = -1; }      // (a half ends, or the walk does: nothing is owed across the barrier)
       if (tid == 0) flag[half] = status;
     }
     __syncthreads();
@@ -1716,12 +1712,13 @@ __global__ __launch_bounds__(256) void k_onetape_traceback_codes(DevMachine m, W
   if (tid == 0) pathLen[p] = status == 1 ? n : (status == 0 ? (c == 0 && s == 0 ? n : -3) : status);
 }
 
-__global__ __launch_bounds__(256) void k_onetape_path_ids(DevMachine m, const long long *__restrict__ slotOff, const long long *__restrict__ pathLen,
-                                                         uint32_t *__restrict__ pathBuf) {
+// entry index -> position in the incoming view (the entry's high half) -> edge id
+__global__ __launch_bounds__(256) void k_onetape_path_ids(DevMachine m, const uint32_t *__restrict__ tbEntry, const long long *__restrict__ slotOff,
+                                                         const long long *__restrict__ pathLen, uint32_t *__restrict__ pathBuf) {
   const long long p = blockIdx.x, n = pathLen[p];
   if (n <= 0) return;
   uint32_t *q = pathBuf + slotOff[p + 1] - n;
-  for (long long k = threadIdx.x; k < n; k += 256) q[k] = m.inEid[q[k]];
+  for (long long k = threadIdx.x; k < n; k += 256) q[k] = m.inEid[tbEntry[q[k]] >> 16];
 }
 
 int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDesc *d_pairs, long long nPairs, const unsigned char *tb,
@@ -1743,7 +1740,7 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_onetape_traceback_codes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_traceback_codes, dim3((unsigned)nPairs), dim3(256), lds, st, m->dev, Q, d_pairs, m->nIn != 0 ? 1 : 0, tb, d_loglike, d_slotOff, d_pathBuf, d_pathLen);
-  hipLaunchKernelGGL(k_onetape_path_ids, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, d_slotOff, (const long long *)d_pathLen, d_pathBuf);
+  hipLaunchKernelGGL(k_onetape_path_ids, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, P.d_tbEntry, d_slotOff, (const long long *)d_pathLen, d_pathBuf);
   return hip_ok(hipGetLastError(), "one-tape traceback (codes) launch") ? 0 : 1;
 }
 
