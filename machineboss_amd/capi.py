@@ -212,23 +212,35 @@ def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, mat
                                         mode, int(backward), int(materialise) | (2 if envelopes else 0), path.encode()))
 
 
-def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = False) -> dict:
+def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = False, tb_codes: bool = False) -> dict:
     """The retimed program of a one-tape machine as the kernel reads it (host only, no GPU needed): the header fields and
-    the record streams, one per rotation of the ring, as a structured array [stream][slot][lane] of (w, src, pad)."""
+    the record streams, one per rotation of the ring, as a structured array [stream][slot][lane] of (w, src, pad).
+    tb_codes (forward max program only): the program that keeps one traceback code per cell, with its decode tables
+    `tbOff` [S + 1], `tbEntry` (position in the incoming view << 16 | emitting << 15 | source state; 0xFFFFFFFF: the seed)
+    and `inEid` (incoming view position -> global edge id)."""
     a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
          np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
          np.ascontiguousarray(em.logWeight, np.float64)]
     _check(load().mb_debug_wide_retimed(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
                                         _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
-                                        mode, int(backward), path.encode()))
+                                        mode | (16 if tb_codes else 0), int(backward), path.encode()))
     head = np.fromfile(path, np.int32, 12)
     assert head[0] == 0x52455431
     keys = ("lanes", "slots", "NB", "NVs", "kMax", "rowLen", "nPen", "period", "S", "inL2", "streams")
     out = {k: int(v) for k, v in zip(keys, head[1:])}
-    rec = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), offset=48)
-    assert rec.size == (out["NB"] * out["slots"] + 8) * out["lanes"]
+    nrec = (out["NB"] * out["slots"] + 8) * out["lanes"]
+    rec = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), count=nrec, offset=48)
+    assert rec.size == nrec
     out["records"] = rec[:out["NB"] * out["slots"] * out["lanes"]].reshape(out["NB"], out["slots"], out["lanes"])
     out["tail"] = rec[out["NB"] * out["slots"] * out["lanes"]:].reshape(8, out["lanes"])
+    rest = np.fromfile(path, np.uint32, offset=48 + 16 * nrec)
+    if tb_codes:
+        pos = 0
+        for k in ("tbOff", "tbEntry", "inEid"):
+            n = int(rest[pos]); out[k] = rest[pos + 1:pos + 1 + n].copy(); pos += 1 + n
+        assert pos == rest.size and out["tbOff"].size == em.nStates + 1 and out["inEid"].size == em.nTransitions
+    else:
+        assert rest.size == 0
     return out
 
 

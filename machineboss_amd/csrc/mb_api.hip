@@ -1589,11 +1589,23 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
   WideProgram P;
   std::vector<WideRec> stream;
-  if (!wide_ret_host(&m, backward != 0, mode == MB_VITERBI, P, stream)) { set_error("machine has no retimed program"); return 1; }
+  // mode + 16 (with MB_VITERBI, forward): the program that keeps one traceback CODE per cell; its decode tables and the incoming
+  // view's edge ids follow the record streams: int32 count + tbOff, int32 count + tbEntry, int32 count + inEid
+  const bool tbCodes = (mode & 16) != 0;
+  mode &= 15;
+  if (tbCodes && (mode != MB_VITERBI || backward)) { set_error("mb_debug_wide_retimed: traceback codes belong to the forward max program"); return 1; }
+  if (!wide_ret_host(&m, backward != 0, mode == MB_VITERBI, P, stream, tbCodes)) { set_error("machine has no retimed program"); return 1; }
+  if (tbCodes && !P.tbOk) { set_error("machine does not qualify for traceback codes"); return 1; }
   FILE *f = fopen(path, "wb");
   if (!f) { set_error("mb_debug_wide_retimed: cannot open output file"); return 1; }
   const int32_t head[12] = {0x52455431, P.W, P.ret.nSlots, P.ret.NB, P.ret.NVs, P.ret.kMax, P.ret.rowLen, P.ret.nPen, P.retPeriod, nStates, P.retGv ? 1 : 0, P.ret.NB};
-  const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(stream.data(), sizeof(WideRec), stream.size(), f) == stream.size();
+  bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(stream.data(), sizeof(WideRec), stream.size(), f) == stream.size();
+  if (ok && tbCodes) {
+    const int32_t n0 = (int32_t)P.h_tbOff.size(), n1 = (int32_t)P.h_tbEntry.size(), n2 = (int32_t)m.inPerm.size();
+    ok = fwrite(&n0, 4, 1, f) == 1 && fwrite(P.h_tbOff.data(), 4, (size_t)n0, f) == (size_t)n0 &&
+         fwrite(&n1, 4, 1, f) == 1 && fwrite(P.h_tbEntry.data(), 4, (size_t)n1, f) == (size_t)n1 &&
+         fwrite(&n2, 4, 1, f) == 1 && fwrite(m.inPerm.data(), 4, (size_t)n2, f) == (size_t)n2;
+  }
   fclose(f);
   if (!ok) { set_error("mb_debug_wide_retimed: short write"); return 1; }
   return 0;

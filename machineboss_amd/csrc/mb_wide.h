@@ -150,6 +150,7 @@ struct WideProgram {
   // tbEntry[tbOff[state] + code] = position in the incoming view << 16 | emitting << 15 | source state (0xFFFFFFFF: the seed)
   bool tbCodes = false, tbOk = false;
   int *d_tbOff = nullptr; uint32_t *d_tbEntry = nullptr;
+  std::vector<int> h_tbOff; std::vector<uint32_t> h_tbEntry;      // host copies (the debug dump)
   long long tbEntries = 0;
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
@@ -163,7 +164,7 @@ bool wide_applicable(const mb_machine *m);
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P);
 void wide_free(WideProgram &P);
 // the retimed program of a machine, planned and linearised on the host only (no device): P.ret / P.retGv / P.retPeriod + the record stream
-bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream);
+bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes = false);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,

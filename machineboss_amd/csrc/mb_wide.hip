@@ -1299,8 +1299,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   P.slotsPerColumn = padded; P.candsPerColumn = T.candsPerColumn; P.nSync = T.nSync;
   P.rounds = T.rounds;                                  // (planning tables: mb_machine_sweep_ops counts them)
   P.retOk = true;
-  if (P.tbCodes && !hostOut) {
+  if (P.tbCodes) {
     // decode tables of the traceback codes: the candidate lists of the state nodes, in the order the planner laid them out
+    // (kept on the host as well: mb_debug_wide_retimed hands them to the device-free simulation of tests/test_retimed_plan.py)
     std::vector<int> tbOff(S + 1, 0);
     std::vector<std::vector<uint32_t>> ent(S);
     bool fits = S < (1 << 15) && m->nTrans <= (1 << 16) && !P.backward && P.viterbi;
@@ -1317,8 +1318,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     std::vector<uint32_t> flat;
     for (int x = 0; x < S; ++x) { tbOff[x] = (int)flat.size(); flat.insert(flat.end(), ent[x].begin(), ent[x].end()); }
     tbOff[S] = (int)flat.size();
-    P.tbOk = fits && up_w(P.d_tbOff, tbOff) && up_w(P.d_tbEntry, flat);
+    P.tbOk = fits && (hostOut || (up_w(P.d_tbOff, tbOff) && up_w(P.d_tbEntry, flat)));
     P.tbEntries = (long long)flat.size();
+    P.h_tbOff = tbOff; P.h_tbEntry = flat;
   }
   if (verbose)
     fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
@@ -1327,9 +1329,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   return true;
 }
 
-bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream) {
+bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes) {
   P = WideProgram();
-  P.backward = backward; P.viterbi = viterbi;
+  P.backward = backward; P.viterbi = viterbi; P.tbCodes = tbCodes;
   P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);
   std::vector<WNode> nodes;
   int nExtra = 0, nStages = 0; long long nPairs = 0;

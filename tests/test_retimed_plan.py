@@ -19,14 +19,20 @@ from randmachine import random_machine
 NO_DST = 0x3ffff
 
 
-def simulate(prog, seq, backward, mode_max):
-    """cells[column][state] of one sequence from the record streams (the kernel's data flow, slot by slot)."""
+def simulate(prog, seq, backward, mode_max, tb=False):
+    """cells[column][state] of one sequence from the record streams (the kernel's data flow, slot by slot).
+    tb (forward max program built for traceback codes): also codes[column][state] -- the place of the cell's first maximal
+    candidate in its node's list, as k_wide_retimed<1,.,codes> keeps it: a lane remembers the slot of its first strictly greater
+    candidate within the round, the place is slot * group + lane within the group, and among the lanes that hold the group's
+    maximum the smallest place wins."""
     W, NB, NVs, kMax, rowLen, S, inL2 = (prog[k] for k in ("lanes", "NB", "NVs", "kMax", "rowLen", "S", "inL2"))
     L = len(seq)
     V = np.full(NB * NVs, -np.inf)
     for b in range(NB):
         V[b * NVs + S + 1] = 0.0
     cells = np.full((L + 1, S), np.nan)
+    codes = np.full((L + 1, S), -1, np.int64)
+    best = np.zeros(W, np.int64)
     tok_at = lambda c: (int(seq[L - c]) if backward else int(seq[c - 1])) if 1 <= c <= L else 0
     lanes = np.arange(W)
     for t in range(L + 1 + kMax):
@@ -39,11 +45,13 @@ def simulate(prog, seq, backward, mode_max):
             if c >= 1 and 0 < tok_at(c) < rowLen - 1: pen[kt, tok_at(c)] = 0.0
         pen = pen.reshape(-1)
         m = np.full(W, -np.inf); ssum = np.zeros(W)
+        slot_in_round = 0
         for rec in prog["records"][cm]:
             src = rec["src"].astype(np.int64)
             entry = (src >> 13) if inL2 else ((src >> 14) >> 3)
             assert inL2 or np.all(((src >> 14) & 7) == 0)
             cand = (V[entry] + rec["w"]) + pen[src & 0x1fff]
+            if tb: best = np.where(cand > m, slot_in_round, best); slot_in_round += 1      # strict >: the first maximum
             if mode_max: m = np.maximum(m, cand)
             else:      # max and sum of exp relative to it, as the kernel keeps them (in fp64 here)
                 new = np.maximum(m, cand)
@@ -65,7 +73,10 @@ def simulate(prog, seq, backward, mode_max):
                 g = 1 << int(log2g[l])
                 assert l % g == 0 and np.all(log2g[l:l + g] == log2g[l])
                 if mode_max: res = float(np.max(m[l:l + g]))
-                else:
+                if tb:
+                    place = (best[l:l + g] << int(log2g[l])) | (lanes[l:l + g] & (g - 1))
+                    code = int(np.min(place[m[l:l + g] == res]))
+                if not mode_max:
                     mx = float(np.max(m[l:l + g]))
                     res = -math.inf if mx == -math.inf else mx + math.log(float(np.sum(ssum[l:l + g] * np.exp(np.where(np.isneginf(m[l:l + g]), -np.inf, m[l:l + g] - mx)))))
                 x, kq, vec = int(pad[l] & NO_DST), int((pad[l] >> 20) & 63), int((pad[l] >> 18) & 3)
@@ -76,9 +87,32 @@ def simulate(prog, seq, backward, mode_max):
                     if x < S:
                         assert np.isnan(cells[L - c if backward else c, x])      # every cell exactly once
                         cells[L - c if backward else c, x] = res
+                        if tb: assert 0 <= code < 256; codes[c, x] = code
             m[:] = -np.inf; ssum[:] = 0.0
+            best[:] = 0; slot_in_round = 0
     assert not np.any(np.isnan(cells))
-    return cells
+    return (cells, codes) if tb else cells
+
+
+def walk_codes(prog, codes, L):
+    """k_onetape_traceback_codes restated: from (L, end state) back to (0, start state) through the decode tables; the path as
+    global edge ids, start -> end."""
+    S = prog["S"]; off, ent, eid = prog["tbOff"], prog["tbEntry"], prog["inEid"]
+    c, s, path = L, S - 1, []
+    while not (c == 0 and s == 0):
+        code = int(codes[c, s]); o0, o1 = int(off[s]), int(off[s + 1])
+        assert 0 <= code < o1 - o0, "dead end"
+        e = int(ent[o0 + code])
+        if e == 0xFFFFFFFF:
+            assert c == 0
+            break
+        path.append(int(eid[e >> 16]))
+        s = e & 0x7fff
+        if e & 0x8000:
+            assert c > 0
+            c -= 1
+        assert len(path) <= (L + 1) * (S + 1)
+    return np.asarray(path[::-1], np.int64)
 
 
 def _machines():
@@ -132,6 +166,40 @@ def test_retimed_program_reproduces_the_oracle(name, knobs, monkeypatch, tmp_pat
             else:
                 fin = np.isfinite(ref)
                 assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["tiny", "fn3-10", "composite-2", "random-40", "random-recogniser-25"])
+@pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_WIDE_LANES": "256"}])
+def test_retimed_traceback_codes_reproduce_the_oracle_paths(name, knobs, monkeypatch, tmp_path):
+    """One traceback code per cell (round 4, `--align` on one-tape machines without the fp64 matrix; DPMatrix::traceBack,
+    src/dpmatrix.defs.h:82-110), WITHOUT a device: the forward max program built for codes (candidate lists in the reference's
+    enumeration order, the seed last) still yields the oracle's Viterbi cells bit for bit, the codes the kernel's bookkeeping
+    would store decode -- `tbEntry[tbOff[state] + code]` -- to the oracle's path transition for transition, ties included
+    (uniform weights tie most choices), and every code addresses an entry of its state."""
+    from machineboss_amd import capi
+    from oracle import oracle
+    em = _machines()[name]
+    tape_out = em.nOutTok > 0
+    nt = em.nOutTok if tape_out else em.nInTok
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    prog = capi.debug_wide_retimed(em, str(tmp_path / "tb.bin"), capi.MB_VITERBI, False, tb_codes=True)
+    ent = prog["tbEntry"]; real = ent[ent != 0xFFFFFFFF]
+    pos = np.sort(real >> 16)
+    assert pos.size and np.all(np.diff(pos) > 0) and pos[-1] < em.nTransitions      # a transition is the candidate of one state, once (those of weight -inf and the silent self-loop on state 0 are none)
+    assert np.all((real & 0x7fff) == np.asarray(em.src)[prog["inEid"][real >> 16]])
+    walked = 0
+    for n in (0, 1, 9, 33, 70 if prog["lanes"] * prog["slots"] <= 4096 else 20):
+        seq = np.random.RandomState(n + 5).randint(1, nt + 1, size=n).astype(np.int32)
+        x, y = (z, seq) if tape_out else (seq, z)
+        cells, codes = simulate(prog, seq, False, True, tb=True)
+        V = om.viterbi(x, y)
+        assert np.array_equal(cells, V.reshape(n + 1, em.nStates))
+        if V.reshape(-1)[-1] > -math.inf:
+            assert np.array_equal(walk_codes(prog, codes, n), om.traceback(x, y, V))
+            walked += 1
+    assert walked >= 3
 
 
 def test_retimed_program_of_the_config5_machine(tmp_path):
