@@ -206,7 +206,10 @@ int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
  * written to `path`: 12 int32 -- magic 0x52455431, lanes, slots per period, ring depth NB, doubles per ring vector, largest
  * lag, penalty row length, penalty entries, period, states, 1 = ring in L2 (records name entries, not LDS addresses),
  * streams -- then (NB * slots + 8) * lanes records of 16 bytes (fp64 weight, source word, end-of-round word).
- * mode MB_FORWARD = sum semiring, MB_VITERBI = max.  Host only: the planner can be checked without a device. */
+ * mode MB_FORWARD = sum semiring, MB_VITERBI = max; MB_VITERBI + 16 (forward only) = the max program that keeps one traceback
+ * code per cell (the default route of --align on one-tape machines), followed by its decode tables: int32 count + tbOff
+ * [states + 1], int32 count + tbEntry (position in the incoming view << 16 | emitting << 15 | source state; 0xFFFFFFFF the
+ * seed), int32 count + the incoming view's global edge ids.  Host only: the planner can be checked without a device. */
 int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                           const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
                           int mode, int backward, const char *path);
