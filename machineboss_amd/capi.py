@@ -201,6 +201,24 @@ def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = Fal
                                       mode, int(backward), int(closure), G, path.encode()))
 
 
+def debug_medium_program(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: int = 1, G: int = 2) -> dict:
+    """The tiled family's PROGRAM for this machine as the kernels read it (host only, no GPU needed): chunk descriptors `desc`
+    [nChunks][8], records `rec` (w, srcOff, dstOff), the usage slots `flat` [(table, first record)] of a flat count program, and
+    the scalars S, Spad, LPG, G, nIn, nOut, seedOff, dummyOff, backward, closure, counting, flatCount (mb_api.hip,
+    mb_debug_jit_source with mode + 32; the semantics are med_slow_supercell's, mb_medium.hip)."""
+    debug_jit_source(em, path, mode=mode | 32, backward=backward, closure=closure, G=G)
+    head = np.fromfile(path, np.int32, 16)
+    assert head[0] == 0x4D454431
+    keys = ("S", "Spad", "LPG", "G", "nChunks", "nIn", "nOut", "seedOff", "dummyOff", "nRec", "nFlat", "backward", "closure", "counting", "flatCount")
+    out = {k: int(v) for k, v in zip(keys, head[1:])}
+    off = 64
+    out["desc"] = np.fromfile(path, np.int32, out["nChunks"] * 8, offset=off).reshape(out["nChunks"], 8); off += out["nChunks"] * 32
+    out["rec"] = np.fromfile(path, np.dtype([("w", "<f8"), ("srcOff", "<u4"), ("dstOff", "<u4")]), out["nRec"], offset=off); off += out["nRec"] * 16
+    out["flat"] = np.fromfile(path, np.int32, out["nFlat"] * 2, offset=off).reshape(out["nFlat"], 2)
+    assert os.path.getsize(path) == off + out["nFlat"] * 8
+    return out
+
+
 def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, materialise: bool = True, envelopes: bool = False):
     """Write the HIP source of the small-machine family's sweep for this machine (host only, no GPU needed).
     mode: 0 sum, 1 max (fp64 cells), 2 max (traceback bytes), 3 Forward fused with posterior counts."""

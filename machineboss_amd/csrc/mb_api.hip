@@ -1547,8 +1547,10 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   m.logW.assign(logWeight, logWeight + nTrans);
   std::string err;
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
-  // mode: MB_FORWARD sum, MB_VITERBI max, 3 count, 4 max with traceback bytes; + 16: tiles without a matrix (MED_MAT_ROLL; implied by 4)
+  // mode: MB_FORWARD sum, MB_VITERBI max, 3 count, 4 max with traceback bytes; + 16: tiles without a matrix (MED_MAT_ROLL; implied by 4);
+  // + 32: the PROGRAM instead of the source (see below)
   const int matKind = ((mode & 16) || (mode & 15) == MED_MODE_TB) ? MED_MAT_ROLL : MED_MAT_FULL;
+  const bool dumpProgram = (mode & 32) != 0;
   mode &= 15;
   MedProgram P; MedGeom geo;
   if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
@@ -1559,6 +1561,25 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     long long c = 0; int syncs = 0;
     for (const MedRoundInfo &ri : P.roundInfo) { c += (long long)ri.slots.size() + (ri.sync ? 6 : 0); syncs += ri.sync; }
     fprintf(stderr, "[mbhip] program cost %lld (rounds %zu, syncs %d, pairs %d, levels %d)\n", c, P.roundInfo.size(), syncs, P.nPairs, backward ? m.nLevB : m.nLevF);
+  }
+  if (dumpProgram) {
+    // The program as the kernels read it -- descriptors + records, what med_slow_supercell (mb_medium.hip) interprets chunk by chunk
+    // and the run-time generator unrolls --, for a device-free replay (tests/test_tiled_plan.py): 16 int32 (magic 0x4D454431, S, Spad,
+    // LPG, G, nChunks, nIn, nOut, seedOff, dummyOff, records, usage slots of a flat count program, 1 = backward, closure stages,
+    // 1 = counting, 1 = flat), nChunks x 8 int32 descriptors, the records (fp64 weight, srcOff, dstOff), the usage slots (int32
+    // table, int32 first record)
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
+    std::vector<int32_t> flatSlots;
+    for (const MedRoundInfo &ri : P.roundInfo) if (ri.flat) for (const MedSlotInfo &sl : ri.slots) { flatSlots.push_back(sl.T); flatSlots.push_back((int32_t)sl.recBase); }
+    const int32_t head[16] = {0x4D454431, m.S, P.Spad, P.LPG, P.G, P.nChunks, m.nIn, m.nOut, (int32_t)P.dev.seedOff, (int32_t)P.dummyOff, (int32_t)P.rec.size(),
+                              (int32_t)(flatSlots.size() / 2), P.backward ? 1 : 0, closure, P.counting ? 1 : 0, P.flatCount ? 1 : 0};
+    const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(P.desc.data(), 4, (size_t)P.nChunks * MED_DESC_WORDS, f) == (size_t)P.nChunks * MED_DESC_WORDS &&
+                    fwrite(P.rec.data(), sizeof(MedRec), P.rec.size(), f) == P.rec.size() &&
+                    (flatSlots.empty() || fwrite(flatSlots.data(), 4, flatSlots.size(), f) == flatSlots.size());
+    fclose(f);
+    if (!ok) { set_error("mb_debug_jit_source: short write"); return 1; }
+    return 0;
   }
   if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
   if (mode == MED_MODE_TB && !medium_tb_eligible(&m, P)) { set_error("machine does not qualify for traceback bytes on the tiled family"); return 1; }
