@@ -200,7 +200,10 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
                         int mode, int backward, int closure, int G, const char *path);
 
 /* The same for the small-machine family (machines of <= 16 states: lane = column, states in registers); mode 0 = sum
- * semiring, 1 = max with fp64 cells, 2 = max with one traceback byte per cell, 3 = Forward fused with posterior counts. */
+ * semiring, 1 = max with fp64 cells, 2 = max with one traceback byte per cell, 3 = Forward fused with posterior counts;
+ * mode + 32 writes the PROGRAM the generator unrolls instead: 20 int32 (magic 0x534D5031, S, nIn, nOut, backward, seed and end
+ * state, table entries, off[4], nTab[4], candidates, 3 x 0), the evaluation order, decOff [S + 1], the candidates (T, src, dup,
+ * tab) in the reference's enumeration order, w[] (fp64), eid[] (int32) -- tests/test_small_plan.py replays it. */
 int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                           const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
                           int mode, int backward, int materialise, const char *path);

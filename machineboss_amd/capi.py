@@ -230,6 +230,26 @@ def debug_small_source(em, path: str, mode: int = 0, backward: bool = False, mat
                                         mode, int(backward), int(materialise) | (2 if envelopes else 0), path.encode()))
 
 
+def debug_small_program(em, path: str, backward: bool = False) -> dict:
+    """The small-machine family's PROGRAM for this machine (host only, no GPU needed; mb_debug_small_source with mode + 32): the
+    evaluation order of the states, per state its candidates (T, src, dup, tab) in the reference's enumeration order (`decOff` [S + 1]
+    delimits them), and the weight / edge-id tables `w`, `eid` with their layout (`off`, `nTab` by kind T: 0 match, 1 input-only,
+    2 output-only, 3 silent)."""
+    debug_small_source(em, path, mode=32, backward=backward)
+    head = np.fromfile(path, np.int32, 20)
+    assert head[0] == 0x534D5031
+    out = {k: int(v) for k, v in zip(("S", "nIn", "nOut", "backward", "seedState", "endState", "nEntries"), head[1:8])}
+    out["off"] = [int(v) for v in head[8:12]]; out["nTab"] = [int(v) for v in head[12:16]]
+    nc, S, pos = int(head[16]), out["S"], 80
+    out["order"] = np.fromfile(path, np.int32, S, offset=pos); pos += 4 * S
+    out["decOff"] = np.fromfile(path, np.int32, S + 1, offset=pos); pos += 4 * (S + 1)
+    out["cand"] = np.fromfile(path, np.int32, 4 * nc, offset=pos).reshape(nc, 4); pos += 16 * nc
+    out["w"] = np.fromfile(path, np.float64, out["nEntries"], offset=pos); pos += 8 * out["nEntries"]
+    out["eid"] = np.fromfile(path, np.int32, out["nEntries"], offset=pos); pos += 4 * out["nEntries"]
+    assert os.path.getsize(path) == pos and out["decOff"][-1] == nc
+    return out
+
+
 def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = False, tb_codes: bool = False) -> dict:
     """The retimed program of a one-tape machine as the kernel reads it (host only, no GPU needed): the header fields and
     the record streams, one per rotation of the ring, as a structured array [stream][slot][lane] of (w, src, pad).

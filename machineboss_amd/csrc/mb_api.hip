@@ -1637,6 +1637,8 @@ int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
                           const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward,
                           int materialise, const char *path) {
   ApiLock lock;
+  const bool dumpProgram = (mode & 32) != 0;      // the PROGRAM instead of the source (see below)
+  mode &= 31;
   if (nStates <= 0 || nTrans < 0 || !path || mode < 0 || mode >= SM_NMODE) { set_error("mb_debug_small_source: bad argument"); return 1; }
   mb_machine m;
   m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
@@ -1647,6 +1649,23 @@ int mb_debug_small_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
   if (!compile_machine(&m, &err)) { set_error(err); return 1; }
   SmallProgram P;
   if (!small_build_host(&m, backward != 0, P)) { set_error("machine does not qualify for the small-machine family"); return 1; }
+  if (dumpProgram) {
+    // what the generator unrolls, for a device-free replay (tests/test_small_plan.py): 20 int32 (magic 0x534D5031, S, nIn, nOut,
+    // backward, seed state, end state, table entries, off[0..3], nTab[0..3], candidates, 3 x 0), the evaluation order [S], decOff
+    // [S + 1], the candidates (T, src, dup, tab) in the reference's enumeration order, then w[] (fp64) and eid[] (int32)
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("mb_debug_small_source: cannot open output file"); return 1; }
+    std::vector<int32_t> cands;
+    for (int d = 0; d < P.S; ++d) for (const SmSlot &sl : P.cand[d]) { cands.push_back(sl.T); cands.push_back(sl.src); cands.push_back(sl.dup); cands.push_back(sl.tab); }
+    const int32_t head[20] = {0x534D5031, P.S, P.nIn, P.nOut, P.backward ? 1 : 0, P.seedState, P.endState, (int32_t)P.nEntries, (int32_t)P.off[0], (int32_t)P.off[1],
+                              (int32_t)P.off[2], (int32_t)P.off[3], P.nTab[0], P.nTab[1], P.nTab[2], P.nTab[3], (int32_t)(cands.size() / 4), 0, 0, 0};
+    const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(P.order.data(), 4, P.order.size(), f) == P.order.size() &&
+                    fwrite(P.decOff.data(), 4, P.decOff.size(), f) == P.decOff.size() && fwrite(cands.data(), 4, cands.size(), f) == cands.size() &&
+                    fwrite(P.w.data(), 8, P.w.size(), f) == P.w.size() && fwrite(P.eid.data(), 4, P.eid.size(), f) == P.eid.size();
+    fclose(f);
+    if (!ok) { set_error("mb_debug_small_source: short write"); return 1; }
+    return 0;
+  }
   const std::string code = small_jit_source(P, mode, (materialise & 1) != 0, (materialise & 2) != 0);   // bit 1: the restricted-envelope variant
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_small_source: cannot open output file"); return 1; }
