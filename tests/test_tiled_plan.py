@@ -175,3 +175,39 @@ def test_count_programs_reproduce_the_oracle(name, flat, tmp_path, monkeypatch):
             fwd = om.forward(x, y, oracle.SUM_EXACT); fin = np.isfinite(fwd)
             assert np.array_equal(np.isneginf(cells), np.isneginf(fwd)) and np.allclose(cells[fin], fwd[fin], rtol=1e-11, atol=1e-11)
         assert np.allclose(got, ref, rtol=1e-9, atol=1e-12), (name, G, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_planner_fuzz_without_a_device(seed, tmp_path, monkeypatch):
+    """Random machines under random planner knobs (node splits at small degrees, part sizes, closure stage counts and cost weights,
+    1 ... 32 columns per wavefront): the closure fill program, the Viterbi program and the flat count program each reproduce the
+    oracle.  The device-side twin of this sweep is scripts/fuzz_knobs.sh; this one needs no GPU and runs with the CPU suite."""
+    from machineboss_amd import capi
+    from oracle import oracle
+    rng = np.random.RandomState(1000 + seed)
+    S = int(rng.choice([17, 24, 40, 64, 100, 150]))
+    nIn, nOut = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+    em = random_machine(S, nIn, nOut, 2000 + seed, density=float(rng.uniform(0.8, 3.0)), silent_density=float(rng.uniform(0.3, 2.5)), allow_inf=bool(seed % 3 == 0))
+    knobs = {"MB_MEDIUM_SPLIT_DEGREE": str(int(rng.choice([3, 5, 8, 12, 100000]))), "MB_MEDIUM_SPLIT_PART": str(int(rng.choice([2, 4, 8]))),
+             "MB_MEDIUM_SYNC_COST": str(int(rng.choice([1, 6]))), "MB_MEDIUM_ROUND_COST": str(int(rng.choice([0, 1, 3])))}
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    G = int(rng.choice([1, 2, 4, 8, 16, 32])); K = int(rng.choice([1, 2, 3, 4, 7, 11]))
+    om = oracle.OracleMachine(em)
+    pairs = [(random_seq(rng, int(rng.randint(0, 7)), nIn), random_seq(rng, int(rng.randint(0, 9)), nOut)) for _ in range(3)]
+    progF = capi.debug_medium_program(em, str(tmp_path / "f.bin"), mode=capi.MB_FORWARD, closure=K, G=G)
+    progV = capi.debug_medium_program(em, str(tmp_path / "v.bin"), mode=capi.MB_VITERBI, closure=0, G=G)
+    try:
+        progC = capi.debug_medium_program(em, str(tmp_path / "c.bin"), mode=3, closure=K, G=G)
+    except capi.MbError as e:
+        assert "does not qualify" in str(e)
+        progC = None
+    ref_c = np.zeros(em.nTransitions); got_c = np.zeros(em.nTransitions)
+    for x, y in pairs:
+        assert np.array_equal(replay(progV, x, y, True), om.viterbi(x, y)), (knobs, G)
+        F = om.forward(x, y, oracle.SUM_EXACT); fin = np.isfinite(F)
+        got = replay(progF, x, y, False)
+        assert np.array_equal(np.isneginf(got), np.isneginf(F)) and np.allclose(got[fin], F[fin], rtol=1e-10, atol=1e-10), (knobs, G, K)
+        if progC is not None and F.reshape(-1)[-1] > -math.inf:
+            ll = om.counts_add(x, y, ref_c, oracle.SUM_EXACT)
+            got_c += replay(progC, x, y, False, bwd=om.backward(x, y, oracle.SUM_EXACT), ll=ll, n_trans=em.nTransitions)[1]
+    assert np.allclose(got_c, ref_c, rtol=1e-8, atol=1e-11), (knobs, G, K, float(np.abs(got_c - ref_c).max()))
