@@ -193,7 +193,7 @@ const char *mb_get_option(const char *name);
  * wavefront, 1 ... 64) to `path`.  mode + 32 writes the PROGRAM instead of the source, as the kernels read it: 16 int32 (magic
  * 0x4D454431, S, Spad, LPG, G, chunks, nIn, nOut, seedOff, dummyOff, records, usage slots, backward, closure, counting, flat),
  * chunks x 8 int32 descriptors, records of 16 bytes (fp64 weight, srcOff, dstOff), usage slots (int32 table, int32 first
- * record) -- tests/test_tiled_plan.py replays it against the oracle.  Host only: works without a GPU, so the generated kernel
+ * record), one int32 per record (the transition it stands for, -1 padding) -- tests/test_tiled_plan.py replays it against the oracle.  Host only: works without a GPU, so the generated kernel
  * can be inspected / cross-compiled offline. */
 int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                         const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,

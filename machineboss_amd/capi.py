@@ -214,8 +214,9 @@ def debug_medium_program(em, path: str, mode: int = MB_FORWARD, backward: bool =
     off = 64
     out["desc"] = np.fromfile(path, np.int32, out["nChunks"] * 8, offset=off).reshape(out["nChunks"], 8); off += out["nChunks"] * 32
     out["rec"] = np.fromfile(path, np.dtype([("w", "<f8"), ("srcOff", "<u4"), ("dstOff", "<u4")]), out["nRec"], offset=off); off += out["nRec"] * 16
-    out["flat"] = np.fromfile(path, np.int32, out["nFlat"] * 2, offset=off).reshape(out["nFlat"], 2)
-    assert os.path.getsize(path) == off + out["nFlat"] * 8
+    out["flat"] = np.fromfile(path, np.int32, out["nFlat"] * 2, offset=off).reshape(out["nFlat"], 2); off += out["nFlat"] * 8
+    out["wref"] = np.fromfile(path, np.int32, out["nRec"], offset=off)      # per record: >= 0 its transition, -1 padding, <= -2 a closure pair
+    assert os.path.getsize(path) == off + out["nRec"] * 4
     return out
 
 

@@ -1567,7 +1567,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     // and the run-time generator unrolls --, for a device-free replay (tests/test_tiled_plan.py): 16 int32 (magic 0x4D454431, S, Spad,
     // LPG, G, nChunks, nIn, nOut, seedOff, dummyOff, records, usage slots of a flat count program, 1 = backward, closure stages,
     // 1 = counting, 1 = flat), nChunks x 8 int32 descriptors, the records (fp64 weight, srcOff, dstOff), the usage slots (int32
-    // table, int32 first record)
+    // table, int32 first record), one int32 per record: the transition it stands for
     FILE *f = fopen(path, "wb");
     if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
     std::vector<int32_t> flatSlots;
@@ -1576,7 +1576,8 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
                               (int32_t)(flatSlots.size() / 2), P.backward ? 1 : 0, closure, P.counting ? 1 : 0, P.flatCount ? 1 : 0};
     const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(P.desc.data(), 4, (size_t)P.nChunks * MED_DESC_WORDS, f) == (size_t)P.nChunks * MED_DESC_WORDS &&
                     fwrite(P.rec.data(), sizeof(MedRec), P.rec.size(), f) == P.rec.size() &&
-                    (flatSlots.empty() || fwrite(flatSlots.data(), 4, flatSlots.size(), f) == flatSlots.size());
+                    (flatSlots.empty() || fwrite(flatSlots.data(), 4, flatSlots.size(), f) == flatSlots.size()) &&
+                    fwrite(P.wref.data(), 4, P.wref.size(), f) == P.wref.size();      // per record: >= 0 its transition, -1 padding, <= -2 a closure pair
     fclose(f);
     if (!ok) { set_error("mb_debug_jit_source: short write"); return 1; }
     return 0;

@@ -7,7 +7,7 @@ import numpy as np
 from machineboss_amd import capi
 from oracle import oracle
 from randmachine import random_machine, random_seq
-from test_tiled_plan import replay
+from test_tiled_plan import replay, walk_chosen
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 tmp = tempfile.mkdtemp(); bad = 0; t0 = time.time()
@@ -31,7 +31,9 @@ for c in range(n):
     except capi.MbError: progC = None
     ref_c = np.zeros(em.nTransitions); got_c = np.zeros(em.nTransitions); ok = True
     for x, y in pairs:
-        ok &= np.array_equal(replay(progV, x, y, True), om.viterbi(x, y))
+        V = om.viterbi(x, y); gotV, chosen = replay(progV, x, y, True, edges=True)
+        ok &= np.array_equal(gotV, V)
+        if V.reshape(-1)[-1] > -math.inf: ok &= np.array_equal(walk_chosen(em, chosen, x, y), om.traceback(x, y, V))      # the path the program's candidate order chooses
         R = om.backward(x, y, oracle.SUM_EXACT) if bwd else om.forward(x, y, oracle.SUM_EXACT)
         got = replay(progF, x[::-1], y[::-1], False)[::-1, ::-1] if bwd else replay(progF, x, y, False)
         fin = np.isfinite(R)

@@ -20,8 +20,10 @@ from conftest import golden_path
 from randmachine import random_machine, random_seq
 
 
-def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0):
-    """cells[i][o][0:S] of one pair from the program (med_slow_supercell's data flow); count programs also return the usage sums."""
+def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0, edges=False):
+    """cells[i][o][0:S] of one pair from the program (med_slow_supercell's data flow); count programs also return the usage sums.
+    edges (max programs): also, per cell and state, the transition of its FIRST maximal candidate in slot order -- through the parts
+    of a split node: the first maximal part's first maximal candidate -- i.e. what a traceback over this program's order chooses."""
     S, Spad, LPG, nOut, seedOff, dummy = (prog[k] for k in ("S", "Spad", "LPG", "nOut", "seedOff", "dummyOff"))
     desc, rec, flat = prog["desc"], prog["rec"], prog["flat"]
     counting, flatc = bool(prog["counting"]), bool(prog["flatCount"])
@@ -31,6 +33,8 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0):
     outside = np.full(Spad, -np.inf)
     lanes = np.arange(LPG)
     acc = np.zeros(n_trans + LPG)
+    wref = prog["wref"]
+    chosen = np.full((nI + 1, nO + 1, Spad), -1, np.int64)
     for i in range(nI + 1):
         for o in range(nO + 1):
             cur = cells[i, o]
@@ -52,6 +56,11 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0):
                             accM = np.where(seed, 0.0, -np.inf); accS = np.where(seed, 1.0, 0.0)
                     so = r["srcOff"].astype(np.int64)
                     v = vec[(so & 0xFFFF if counting else so) >> 3] + r["w"]
+                    if edges:
+                        ridx = base + k * int(dp[4])
+                        if k == 0 and first: best_rec = np.full(LPG, -1, np.int64)
+                        better = v > accM                               # strict: the first maximum (accM is the maximum so far; -inf never wins)
+                        best_rec = np.where(better, ridx, best_rec)
                     if levelled_counts:      # usage of the candidate's transition: exp(v + B(dst) - LL) into the accumulator its record names
                         with np.errstate(invalid="ignore"):
                             t = v + bl[np.minimum(dst >> 3, Spad - 1)]
@@ -66,6 +75,11 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0):
                     ok = dst < 0x80000000
                     assert np.all(dst[ok] % 8 == 0) and np.all(dst[ok] < Spad * 8)
                     cur[dst[ok] >> 3] = res[ok]
+                    if edges:
+                        for ln in np.nonzero(ok & (best_rec >= 0))[0]:
+                            rr = int(best_rec[ln]); e = int(wref[rr])
+                            # a candidate without a transition of its own and a finite weight reads a PART of this state in the same cell
+                            chosen[i, o, dst[ln] >> 3] = e if e >= 0 else chosen[i, o, int(rec[rr]["srcOff"]) >> 3]
             assert cur[S] == -np.inf                                   # the -inf sentinel padding candidates read is never written
             if flatc:
                 for T, b0 in flat:
@@ -75,7 +89,19 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0):
                     t = (vecs[T][(so & 0xFFFF) >> 3] + r["w"]) + bl[so >> 19]
                     np.add.at(acc, r["dstOff"].astype(np.int64) >> 3, np.where(np.isneginf(t), 0.0, np.exp(np.where(np.isfinite(t), t, 0.0))))
     cells = cells[:, :, :S].transpose(1, 0, 2)      # [output][input][state] like the oracle's
+    if edges: return cells, chosen[:, :, :S]
     return (cells, acc[:n_trans]) if counting else cells
+
+
+def walk_chosen(em, chosen, x, y):
+    """DPMatrix::traceBack over the transitions `replay(..., edges=True)` chose: global edge ids, start -> end."""
+    src, it, ot = np.asarray(em.src), np.asarray(em.inTok), np.asarray(em.outTok)
+    i, o, s, path = len(x), len(y), em.nStates - 1, []
+    while i > 0 or o > 0 or s != 0:
+        e = int(chosen[i, o, s]); assert e >= 0
+        path.append(e); s = int(src[e]); i -= int(it[e] != 0); o -= int(ot[e] != 0)
+        assert i >= 0 and o >= 0 and len(path) <= (len(x) + 1) * (len(y) + 1) * em.nStates
+    return np.asarray(path[::-1], np.int64)
 
 
 def _machines():
@@ -120,12 +146,15 @@ def test_fill_programs_reproduce_the_oracle(name, tmp_path):
             ran += 1
             assert prog["S"] == em.nStates and prog["LPG"] == 64 // G and not prog["counting"]
             for x, y in pairs:
-                got = replay(prog, x, y, mode == capi.MB_VITERBI)
-                if mode == capi.MB_VITERBI:
-                    assert np.array_equal(got, om.viterbi(x, y)), (name, G)
-                else:
-                    ref = om.forward(x, y, oracle.SUM_EXACT); fin = np.isfinite(ref)
-                    assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-11, atol=1e-11), (name, G, closure)
+                if mode == capi.MB_VITERBI:      # cells bit for bit, and the path the program's candidate order chooses is the reference's (first maximum, ties included)
+                    got, chosen = replay(prog, x, y, True, edges=True)
+                    V = om.viterbi(x, y)
+                    assert np.array_equal(got, V), (name, G)
+                    if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_chosen(em, chosen, x, y), om.traceback(x, y, V)), (name, G)
+                    continue
+                got = replay(prog, x, y, False)
+                ref = om.forward(x, y, oracle.SUM_EXACT); fin = np.isfinite(ref)
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-11, atol=1e-11), (name, G, closure)
     assert ran >= 5
     # Backward programs (the transposed machine in the reversed frame: cell (i', o') of the sweep is BackwardMatrix cell
     # (inLen - i', outLen - o'), src/backward.cpp:18-46), levelled and closure
@@ -203,7 +232,10 @@ def test_planner_fuzz_without_a_device(seed, tmp_path, monkeypatch):
         progC = None
     ref_c = np.zeros(em.nTransitions); got_c = np.zeros(em.nTransitions)
     for x, y in pairs:
-        assert np.array_equal(replay(progV, x, y, True), om.viterbi(x, y)), (knobs, G)
+        V = om.viterbi(x, y)
+        gotV, chosen = replay(progV, x, y, True, edges=True)
+        assert np.array_equal(gotV, V), (knobs, G)
+        if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_chosen(em, chosen, x, y), om.traceback(x, y, V)), (knobs, G)
         F = om.forward(x, y, oracle.SUM_EXACT); fin = np.isfinite(F)
         got = replay(progF, x, y, False)
         assert np.array_equal(np.isneginf(got), np.isneginf(F)) and np.allclose(got[fin], F[fin], rtol=1e-10, atol=1e-10), (knobs, G, K)
