@@ -102,6 +102,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) measurements")
     ap.add_argument("--extra-em-only", action="store_true", help="of the extras, only the EM iteration with its all-reduce (needs a rank group: N > 1 or MB_BENCH_FORCE_COMM=1)")
+    ap.add_argument("--dropin-only", action="store_true", help="only extra.dropin (the reference's call sites through the C++ classes); prints that block")
+    ap.add_argument("--quick", action="store_true", help="with --dropin-only: small batches")
     return ap.parse_args(argv)
 
 
@@ -365,6 +367,54 @@ def extra_single_gpu(capi, np, hbm_peak):
     return out
 
 
+def extra_dropin(capi, np, quick=False):
+    """The boundary as the REFERENCE'S OWN CALLERS drive it: tests/cxx/dropin.cpp runs the `--loglike` loop of
+    target/boss.cpp:796-800 and the `--viterbi / --align` loop of :826-833 exactly as written there -- one matrix object per pair --
+    through machineboss_amd/cxx/mb_dp.hpp, (a) unchanged, (b) with the ONE line INTEGRATION.md 2b adds in front of each loop
+    (MachineBossHIP::prefetch), (c) next to the batch C-ABI.  A child process (C++): this process's cached workspaces are released first.
+    Host buffers in, host results out: these rates include tokenising, H2D, D2H and building MachinePath objects."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "cxx"))
+    import casefile
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.seqgen import synth_tokens
+    capi.release_workspace()
+    out = {"what": "pairs/s and G cells/s THROUGH the drop-in C++ classes for loops shaped like target/boss.cpp:796-800 (RollingOutputForwardMatrix per pair) and :826-833 (ViterbiMatrix per pair: logLike() + path(machine)); matrix_fills = fp64 matrices that crossed PCIe (0: none)"}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = casefile.build_exe(tmp, "dropin", "-O2")
+        for key, preset, cfg, n, il, ol, reps in (("config2", "dnapsw", 2, 64 if quick else 1024, 1000, 1000, 2), ("config4", "psw2dna", 4, 2 if quick else 8, 487, 10000, 2)):
+            em = casefile.file_weights(EvaluatedMachine.fromMachine(Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", preset + ".json")), None, useDefaults=True))
+            pairs = [synth_tokens(1000 * cfg + k, il, ol, em.nInTok, em.nOutTok) for k in range(n)]
+            case = os.path.join(tmp, key + ".txt")
+            casefile.write_case(case, em, ["s%d" % s for s in range(em.nStates)], pairs)
+            env = {k: v for k, v in os.environ.items() if k != "MB_ROLLING_MIN_PAIRS"}
+            r = subprocess.run([exe, case, "time", str(reps)], capture_output=True, text=True, env=env, timeout=1500)
+            rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or len(rows) != 3:
+                out[key] = {"error": (r.stdout + r.stderr)[-500:]}
+                continue
+            blk = {"workload": "%s, %d pairs x %d x %d through the C++ classes (mock of the reference's host types)" % (preset, n, il, ol)}
+            for row in rows:
+                blk[row["variant"]] = {"loglike_pairs_per_s": round(n / row["loglike_s"], 1), "loglike_gcells": row["loglike_gcells"],
+                                       "align_pairs_per_s": round(n / row["align_s"], 1), "align_gcells": row["align_gcells"], "matrix_fills": row["matrix_fills"],
+                                       "ll_sum": row["ll_sum"], "vit_sum": row["vit_sum"], "path_transitions": row["path_transitions"],
+                                       "loglike_s": row["loglike_s"], "align_s": row["align_s"], "inside_prefetch_s": [row["prefetch_loglike_s"], row["prefetch_align_s"]],
+                                       "inside_path_objects_s": row["path_objects_s"]}
+            a, b, c = (blk[k] for k in ("unchanged_loop", "unchanged_loop_prefetch", "batch_c_abi"))
+            # unchanged loop + the one added line against the batch C-ABI fed from the same SeqPairList (tokenising included on both sides);
+            # for --align the loop additionally builds the reference's MachinePath objects (std::list<MachineTransition>: host work of the
+            # reference's own types that no batch caller of edge ids does) -- quoted with and without that share
+            blk["prefetch_over_batch_time"] = {"loglike": round(b["loglike_s"] / c["loglike_s"], 3), "align": round(b["align_s"] / c["align_s"], 3),
+                                               "align_without_path_objects": round((b["align_s"] - b["inside_path_objects_s"]) / c["align_s"], 3),
+                                               "added_line_alone": [round(b["inside_prefetch_s"][0] / c["loglike_s"], 3), round(b["inside_prefetch_s"][1] / c["align_s"], 3)],
+                                               "note": "loop time outside the added line is host work of the reference's own types per pair: eval.canTokenize (two std::map look-ups per symbol), MachinePath = std::list<MachineTransition> built and destroyed (config 2: 3 734 transitions per pair)"}
+            blk["same_results"] = bool(a["vit_sum"] == b["vit_sum"] == c["vit_sum"] and a["path_transitions"] == b["path_transitions"] == c["path_transitions"]
+                                       and abs(a["ll_sum"] - b["ll_sum"]) <= 1e-8 * abs(b["ll_sum"]) and abs(c["ll_sum"] - b["ll_sum"]) <= 1e-8 * abs(b["ll_sum"]))
+            out[key] = blk
+    return out
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -396,6 +446,9 @@ def main():
     from machineboss_amd.shard import shard_range, lpt_assign
 
     capi.set_device(local_rank)
+    if args.dropin_only:
+        print(json.dumps(extra_dropin(capi, np, args.quick)))
+        return
     m = Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", args.preset + ".json"))
     em = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
     dm = capi.DeviceMachine(em)
@@ -539,6 +592,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extra and not args.extra_em_only:
         extra.update(extra_single_gpu(capi, np, HBM_PEAK_GBS))
+        try:
+            extra["dropin"] = extra_dropin(capi, np)
+        except Exception as e:
+            extra["dropin"] = {"error": str(e)}
         nu = extra.get("nonuniform", {})
         emn, dmn = nu.pop("_em", None), nu.pop("_dm", None)
         if emn is not None and not args.no_cpu:

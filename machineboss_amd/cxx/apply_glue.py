@@ -13,6 +13,11 @@ What it does to ``src/``:
   members up to ``writeParamCountsJson``/``paramCounts`` (src/counts.cpp:23-106) go -- the shim's MachineCounts carries them;
 * ``hipdp.h``, ``mb_dp.hpp``, ``mbhip.h`` are added.
 
+``--prefetch`` additionally adds ONE line in front of each of the two per-pair loops of ``target/boss.cpp`` (``--loglike``,
+:796; ``--viterbi / --align``, :826): ``MachineBossHIP::prefetch (eval, data.seqPairs, ...)`` runs the whole SeqPairList as one
+batched device call, and the matrices the unchanged loops then construct pair by pair pick their results up (mb_dp.hpp).
+Without it every pair is a device call of its own (correct, and latency-bound).
+
 ``--overlay`` builds the result as a directory of symlinks to the original files plus the generated headers, so a read-only
 tree can be checked: the compiler resolves ``#include "x.h"`` next to the including file's path as named, i.e. inside the
 overlay.  Nothing of the original tree is copied except the text of counts.h minus one struct, and only into the overlay.
@@ -68,6 +73,29 @@ def patched_counts_cpp(text: str) -> str:
     return text[:a] + "// MachineCounts members: in hipdp.h / mb_dp.hpp (HIP engine)\n\n" + text[b:]
 
 
+PREFETCH_SITES = (   # (the `if` that opens the block, what the loop reads)
+    ('if (vm.count("loglike")) {', "MachineBossHIP::PrefetchLogLike"),
+    ('if (vm.count("align") || vm.count("viterbi")) {', "MachineBossHIP::PrefetchViterbi"),
+)
+EVAL_LINE = "const EvaluatedMachine eval (machine, params);"
+
+
+def patched_boss_cpp(text: str) -> str:
+    """target/boss.cpp with the prefetch line behind the `const EvaluatedMachine eval (machine, params);` of the --loglike block
+    (target/boss.cpp:793-794) and of the --viterbi / --align block (:819-822).  Nothing else changes."""
+    for opener, what in PREFETCH_SITES:
+        a = text.find(opener)
+        if a < 0:
+            raise SystemExit("boss.cpp: block '%s' not found" % opener)
+        b = text.find(EVAL_LINE, a)
+        if b < 0 or b - a > 400:
+            raise SystemExit("boss.cpp: '%s' not found behind '%s'" % (EVAL_LINE, opener))
+        eol = text.index("\n", b)
+        indent = text[text.rfind("\n", 0, b) + 1:b]
+        text = text[:eol + 1] + indent + "MachineBossHIP::prefetch (eval, data.seqPairs, %s);   // HIP engine: one batched device call for the loop below\n" % what + text[eol + 1:]
+    return text
+
+
 def generated(src: str) -> dict:
     out = {n: replaced_header(n) for n in REPLACED}
     out["counts.h"] = patched_counts_h(open(os.path.join(src, "counts.h")).read())
@@ -78,7 +106,7 @@ def generated(src: str) -> dict:
     return out
 
 
-def overlay(tree: str, dest: str) -> str:
+def overlay(tree: str, dest: str, prefetch: bool = False) -> str:
     """A view of `tree` with the glue applied: symlinks + generated files.  Returns dest."""
     tree = os.path.abspath(tree)
     if os.path.exists(dest):
@@ -98,11 +126,21 @@ def overlay(tree: str, dest: str) -> str:
             fh.write(text)
     if os.path.isdir(os.path.join(tree, "ext")):
         os.symlink(os.path.join(tree, "ext"), os.path.join(dest, "ext"))
+    boss = os.path.join(tree, "target", "boss.cpp")
+    if prefetch and os.path.exists(boss):
+        os.remove(os.path.join(dest, "target", "boss.cpp"))
+        with open(os.path.join(dest, "target", "boss.cpp"), "w") as fh:
+            fh.write(patched_boss_cpp(open(boss).read()))
     return dest
 
 
-def in_place(tree: str) -> None:
+def in_place(tree: str, prefetch: bool = False) -> None:
     src = os.path.join(tree, "src")
+    boss = os.path.join(tree, "target", "boss.cpp")
+    if prefetch and os.path.exists(boss):
+        text = patched_boss_cpp(open(boss).read())
+        with open(boss, "w") as fh:
+            fh.write(text)
     for f, text in generated(src).items():
         with open(os.path.join(src, f), "w") as fh:
             fh.write(text)
@@ -117,11 +155,12 @@ def main(argv=None) -> int:
     g = ap.add_mutually_exclusive_group(required=True)
     g.add_argument("--overlay", metavar="DIR")
     g.add_argument("--in-place", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="also add the one-line batch prefetch in front of the --loglike and --viterbi/--align loops of target/boss.cpp")
     a = ap.parse_args(argv)
     if a.in_place:
-        in_place(a.tree)
+        in_place(a.tree, a.prefetch)
     else:
-        print(overlay(a.tree, a.overlay))
+        print(overlay(a.tree, a.overlay, a.prefetch))
     return 0
 
 

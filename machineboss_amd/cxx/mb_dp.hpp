@@ -6,6 +6,17 @@
 // MachineCounts::count; errors are std::runtime_error carrying the library message (the reference throws
 // runtime_error("Abort") after printing, src/util.cpp:39-48).
 //
+// What a constructor computes is what the reference's CALLERS read (target/boss.cpp:796-800,826-833, src/api.cpp:31-66):
+//  * ViterbiMatrix: the score and the path, through the kernel family's traceback-byte / traceback-code sweep
+//    (mb_batch_viterbi on the one pair) -- logLike() and path(machine) answer from those;
+//  * ForwardMatrix: the log-likelihood, through the rolling sweep (mb_batch_forward, MB_ROLLING);
+//  * BackwardMatrix: nothing yet.
+// The fp64 MATRIX (8 bytes per cell over PCIe: 64 MB for a 1 kb x 1 kb dnapsw pair, 10.6 GB for a 487 aa x 10 kb psw2dna
+// pair) is fetched with mb_fill_env LAZILY, by the first cell() / writeJson / selector-traceBack / getCounts(forward, ...)
+// that needs it; matrixFills() counts those fetches.  prefetch(eval, seqPairs, what) runs ONE batched device call for a
+// whole SeqPairList and lets the matrices constructed afterwards in the caller's unchanged `for (seqPair : data.seqPairs)`
+// loop pick their results up.
+//
 // Two layers:
 //  * neutral types -- FlatMachine (struct-of-arrays EvaluatedMachine), TokSeqPair, Envelope, and the classes DPMatrix /
 //    ForwardMatrix / BackwardMatrix / ViterbiMatrix / RollingOutputForwardMatrix / MachineCounts over them.  The fills run
@@ -51,6 +62,28 @@ typedef size_t TransIndex;               // EvaluatedMachineState::TransIndex, s
 inline void check(int rc) { if (rc) throw std::runtime_error(mb_last_error()); }
 inline double negInf() { return -std::numeric_limits<double>::infinity(); }
 
+// fp64 matrices fetched from the device so far by this process (mb_fill_env calls of the lazy DP classes): a caller -- or a
+// test -- can tell that a loop of logLike() / path(machine) calls moved no matrix over PCIe
+inline long &matrixFillCounter() { static long n = 0; return n; }
+inline long matrixFills() { return matrixFillCounter(); }
+
+// Results of one batched device call, waiting for the matrices a caller's loop constructs pair by pair (prefetch(), below).
+// Keyed by the ADDRESS of the caller's SeqPair (the loop variable of `for (const auto& seqPair : data.seqPairs)` is a
+// reference to the list element); an entry is used only if the pair at that address still tokenises to the same sequences
+// and has the same envelope.
+enum { PrefetchLogLike = 1, PrefetchViterbi = 2 };
+struct PrefetchedPair {
+  std::vector<int> in, out;
+  uint64_t fingerprint = 0;         // of the caller's symbol sequences (template layer): the pair at this address is still the pair that was prefetched
+  std::vector<int32_t> envStart, envEnd;
+  double ll = 0;
+  std::vector<uint32_t> edges;      // Viterbi path as global edge ids, start -> end
+};
+struct PrefetchStore {
+  std::map<const void *, PrefetchedPair> loglike, viterbi;
+  void clear() { loglike.clear(); viterbi.clear(); }
+};
+
 // Flattened EvaluatedMachine (src/eval.h:59-98): struct-of-arrays over global transition ids
 // e = transOffset[src] + transIndex, the order EvaluatedMachine::init visits them (src/eval.cpp:47-69).
 struct FlatMachine {
@@ -65,6 +98,11 @@ struct FlatMachine {
   // rows sorted by the other endpoint, then by insertion order -- what the nested map / multimap iterate
   mutable std::vector<uint32_t> inEdge, outEdge;
   mutable std::vector<size_t> inOff, outOff;
+  mutable PrefetchStore prefetched;                   // results of prefetch() for THESE weights
+  // single-character alphabets (DNA, protein: every preset) tokenise through a 256-entry table instead of the caller's
+  // std::map<string, Token> (src/eval.h:29-41: two map look-ups per symbol); anything else goes to the caller's tokenizer
+  struct CharTable { bool usable = false; int tok[256]; };
+  CharTable inChars, outChars;
 
   size_t nTransitions() const { return src.size(); }
   StateIndex startState() const { return 0; }
@@ -112,6 +150,7 @@ struct FlatMachine {
   }
   void setLogWeights(const std::vector<double> &lw) {     // per EM iteration (src/fitter.cpp:28-29)
     logWeight = lw;
+    prefetched.clear();
     if (dev) check(mb_machine_set_weights(dev, logWeight.data()));
   }
   ~FlatMachine() { if (dev) mb_machine_destroy(dev); }
@@ -161,6 +200,13 @@ struct Envelope {
   }
   bool contains(long x, long y) const { return y >= 0 && y <= outLen && x >= inStart[y] && x < inEnd[y]; }
   bool fits(const TokSeqPair &sp) const { return inLen == (long)sp.input.size() && outLen == (long)sp.output.size(); }
+  static bool overlapping(long s1, long e1, long s2, long e2) { return !(s1 >= e2 || s2 >= e1); }
+  bool connected() const {                       // src/seqpair.cpp:188-193
+    if ((long)inStart.size() != outLen + 1 || (long)inEnd.size() != outLen + 1) return false;
+    bool conn = overlapping(inStart[0], inEnd[0], 0, 1);
+    for (long y = 1; conn && y <= outLen; ++y) conn = conn && overlapping(inStart[y - 1], inEnd[y - 1] + 1, inStart[y], inEnd[y]);
+    return conn && overlapping(inStart[outLen], inEnd[outLen], inLen, inLen + 1);
+  }
   bool isFull() const {
     for (long y = 0; y <= outLen; ++y) if (inStart[y] != 0 || inEnd[y] != inLen + 1) return false;
     return true;
@@ -169,6 +215,55 @@ struct Envelope {
     std::vector<long long> r(1, 0);
     for (long y = 0; y <= outLen; ++y) r.push_back(r.back() + inEnd[y] - inStart[y]);
     return r;
+  }
+};
+
+// A tokenised SeqPairList resident on the device (mb_batch), with the envelopes of its pairs: what every class below runs its
+// sweeps on, one pair or a whole list alike.  envelopes: empty = all full; otherwise one per pair.
+class DeviceBatch {
+  mb_batch *b = nullptr;
+  const FlatMachine &flat;
+  std::vector<int64_t> bound;
+public:
+  DeviceBatch(const FlatMachine &m, const std::vector<const TokSeqPair *> &pairs, const std::vector<const Envelope *> &envelopes) : flat(m) {
+    std::vector<InputToken> in; std::vector<OutputToken> out;
+    std::vector<int64_t> inOff(1, 0), outOff(1, 0);
+    for (const TokSeqPair *sp : pairs) {
+      in.insert(in.end(), sp->input.begin(), sp->input.end()); out.insert(out.end(), sp->output.begin(), sp->output.end());
+      inOff.push_back((int64_t)in.size()); outOff.push_back((int64_t)out.size());
+      bound.push_back(mb_viterbi_path_bound(m.device(), (int64_t)sp->input.size(), (int64_t)sp->output.size()));
+    }
+    if (in.empty()) in.push_back(0);
+    if (out.empty()) out.push_back(0);
+    b = mb_batch_create(m.device(), (int64_t)pairs.size(), in.data(), inOff.data(), out.data(), outOff.data());
+    if (!b) throw std::runtime_error(mb_last_error());
+    if (!envelopes.empty()) {
+      if (envelopes.size() != pairs.size()) { mb_batch_destroy(b); throw std::runtime_error("Envelope/training set mismatch"); }
+      std::vector<int64_t> envOff(1, 0); std::vector<int32_t> st, en;
+      for (const Envelope *e : envelopes) {
+        if (!e->isFull()) { st.insert(st.end(), e->inStart.begin(), e->inStart.end()); en.insert(en.end(), e->inEnd.begin(), e->inEnd.end()); }
+        envOff.push_back((int64_t)st.size());
+      }
+      if (!st.empty() && mb_batch_set_envelopes(b, envOff.data(), st.data(), en.data())) { mb_batch_destroy(b); throw std::runtime_error(mb_last_error()); }
+    }
+  }
+  DeviceBatch(const DeviceBatch &) = delete;
+  DeviceBatch &operator=(const DeviceBatch &) = delete;
+  ~DeviceBatch() { if (b) mb_batch_destroy(b); }
+  size_t size() const { return bound.size(); }
+  std::vector<double> forward(int flags) { std::vector<double> ll(size(), 0.0); check(mb_batch_forward(b, flags, ll.data())); return ll; }
+  // scores, and the paths as global edge ids: pair p owns edges[off[p] .. off[p+1])
+  void viterbi(std::vector<double> &ll, std::vector<int64_t> &off, std::vector<uint32_t> &edges) {
+    int64_t cap = 0;
+    for (int64_t n : bound) cap += n;
+    ll.assign(size(), 0.0); off.assign(size() + 1, 0); edges.resize((size_t)std::max<int64_t>(cap, 1));
+    check(mb_batch_viterbi(b, ll.data(), off.data(), edges.data(), cap));
+    edges.resize((size_t)off[size()]);
+  }
+  std::vector<double> counts(std::vector<double> &flatCounts, double &loglikeSum) {
+    std::vector<double> ll(size(), 0.0);
+    check(mb_batch_counts(b, flatCounts.data(), &loglikeSum, ll.data()));
+    return ll;
   }
 };
 
@@ -188,6 +283,18 @@ struct PathOf {
   typedef MachinePathT<Transition> type;
 };
 
+// a result of prefetch() for the (already tokenised) pair at `key`, if it is still about these sequences and this envelope
+inline const PrefetchedPair *prefetchedFor(const std::map<const void *, PrefetchedPair> &store, const void *key, const std::vector<InputToken> &in,
+                                           const std::vector<OutputToken> &out, const Envelope &env) {
+  if (!key || store.empty()) return nullptr;
+  const auto it = store.find(key);
+  if (it == store.end()) return nullptr;
+  const PrefetchedPair &pp = it->second;
+  const bool full = env.isFull();
+  if (pp.in != in || pp.out != out || (full ? !pp.envStart.empty() : (pp.envStart != env.inStart || pp.envEnd != env.inEnd))) return nullptr;
+  return &pp;
+}
+
 // ---- DPMatrix<IdentityIndexMapper> (src/dpmatrix.h:64-163) over neutral types -----------------------------------------------
 class DPMatrixCore {
 public:
@@ -198,16 +305,36 @@ public:
   typedef std::function<size_t(const std::vector<double> &)> TransSelector;
 
 protected:
-  std::vector<double> cellStorage;
+  mutable std::vector<double> cellStorage;      // the fp64 matrix, fetched from the device by the first reader (ensureMatrix)
+  mutable bool haveMatrix = false;
   const FlatMachine &flat;
-  void fill(int mode, int startState) {
-    cellStorage.resize((size_t)(inLen + 1) * (outLen + 1) * nStates);
-    TokSeqPair tsp{input, output};
-    if (!env.fits(tsp)) throw std::runtime_error("Envelope/sequence mismatch");      // DPMatrix::alloc, src/dpmatrix.defs.h:31
-    const bool full = env.isFull();
-    check(mb_fill_env(flat.device(), mode, input.data(), inLen, output.data(), outLen, startState,
-                      full ? nullptr : env.inStart.data(), full ? nullptr : env.inEnd.data(), cellStorage.data()));
+  const int fillMode;                           // MB_FORWARD / MB_VITERBI / MB_BACKWARD
+  const int fillStartState;
+  // DPMatrix::alloc's assertions (src/dpmatrix.defs.h:31-32) hold at construction, whether or not a matrix is ever fetched
+  void checkEnvelope() const {
+    if (env.inLen != inLen || env.outLen != outLen) throw std::runtime_error("Envelope/sequence mismatch");
+    if (!env.connected()) throw std::runtime_error("Envelope is not connected");
   }
+  void ensureMatrix() const {
+    if (haveMatrix) return;
+    cellStorage.resize((size_t)(inLen + 1) * (outLen + 1) * nStates);
+    const bool full = env.isFull();
+    check(mb_fill_env(flat.device(), fillMode, input.data(), inLen, output.data(), outLen, fillStartState,
+                      full ? nullptr : env.inStart.data(), full ? nullptr : env.inEnd.data(), cellStorage.data()));
+    ++matrixFillCounter();
+    haveMatrix = true;
+  }
+  // the one pair as a device batch (scores, paths and log-likelihoods without the matrix)
+  std::unique_ptr<DeviceBatch> onePairBatch() const {
+    pairView.input = input; pairView.output = output;
+    std::vector<const TokSeqPair *> ps(1, &pairView);
+    std::vector<const Envelope *> es;
+    if (!env.isFull()) es.push_back(&env);
+    return std::unique_ptr<DeviceBatch>(new DeviceBatch(flat, ps, es));
+  }
+private:
+  mutable TokSeqPair pairView;
+protected:
   // DPMatrix::iterate over one label group (src/dpmatrix.h:101-115): candidates in multimap order
   void pathIterate(const TransVisitor &visit, bool incoming, StateIndex state, InputToken inTok, OutputToken outTok, InputIndex inPos, OutputIndex outPos) const {
     flat.buildOrders();
@@ -229,15 +356,16 @@ public:
   const StateIndex nStates;
   Envelope env;     // Envelope(seqPair): the path envelope of an aligned pair, else full (quirk Q1: src/dpmatrix.defs.h:16-17)
 
-  DPMatrixCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out)
-      : flat(m), input(in), output(out), inLen((long)in.size()), outLen((long)out.size()), nStates(m.nStates) { env.initFull(inLen, outLen); }
-  DPMatrixCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
-      : flat(m), input(in), output(out), inLen((long)in.size()), outLen((long)out.size()), nStates(m.nStates), env(e) {}
+  DPMatrixCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, int mode = MB_FORWARD, int startState = 0)
+      : flat(m), fillMode(mode), fillStartState(startState), input(in), output(out), inLen((long)in.size()), outLen((long)out.size()), nStates(m.nStates), env(e) { checkEnvelope(); }
+  bool matrixFetched() const { return haveMatrix; }
 
   const FlatMachine &flatMachine() const { return flat; }
   // the const accessor of the reference: -inf outside the envelope (src/dpmatrix.h:142-144)
   double cell(InputIndex inPos, OutputIndex outPos, StateIndex state) const {
-    return env.contains(inPos, outPos) ? cellStorage[((size_t)outPos * (inLen + 1) + inPos) * nStates + state] : negInf();
+    if (!env.contains(inPos, outPos)) return negInf();
+    ensureMatrix();
+    return cellStorage[((size_t)outPos * (inLen + 1) + inPos) * nStates + state];
   }
   double startCell() const { return cell(0, 0, flat.startState()); }
   double endCell() const { return cell(inLen, outLen, flat.endState()); }
@@ -365,10 +493,20 @@ public:
 };
 
 class ForwardCore : public DPMatrixCore {      // src/forward.h:19-27
+  double ll = 0;
+  bool haveLL = false;
 public:
-  ForwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, StateIndex startState = 0)
-      : DPMatrixCore(m, in, out, e) { fill(MB_FORWARD, (int)startState); }
-  double logLike() const { return endCell(); }
+  // pre: this pair's result of prefetch(), if there is one
+  ForwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, StateIndex startState = 0, const PrefetchedPair *pre = nullptr)
+      : DPMatrixCore(m, in, out, e, MB_FORWARD, (int)startState) {
+    if (startState != 0) return;       // a caller-chosen start state (src/forward.h:24) exists on the matrix route only: logLike() fetches it
+    if (pre) ll = pre->ll;
+    else ll = onePairBatch()->forward(MB_ROLLING)[0];
+    haveLL = true;
+  }
+  // the rolling sweep's value (src/forward.defs.h:51-55 reads the end cell of the same recursion; the two agree to ~1e-9
+  // relative when the sweep sums in another order than the materialised fill)
+  double logLike() const { return haveLL ? ll : endCell(); }
   // stochastic traceback (src/forward.cpp:17-23)
   template <class MachineT, class Generator>
   typename PathOf<MachineT>::type samplePath(const MachineT &m, Generator &rng) const { return traceBack(m, randomTransSelector(rng)); }
@@ -377,26 +515,33 @@ public:
 };
 
 class ViterbiCore : public DPMatrixCore {      // src/viterbi.h:9-18
+  double score = 0;
+  std::vector<uint32_t> pathEdges;             // the fill's own arg-max chain, traced on the device: global edge ids, start -> end
 public:
-  ViterbiCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
-      : DPMatrixCore(m, in, out, e) { fill(MB_VITERBI, 0); }
-  double logLike() const { return endCell(); }
+  ViterbiCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, const PrefetchedPair *pre = nullptr)
+      : DPMatrixCore(m, in, out, e, MB_VITERBI, 0) {
+    if (pre) { score = pre->ll; pathEdges = pre->edges; return; }
+    std::vector<double> l; std::vector<int64_t> off;
+    onePairBatch()->viterbi(l, off, pathEdges);
+    score = l[0];
+  }
+  double logLike() const { return score; }     // = endCell(), bit for bit (the max semiring is exact in every kernel family)
+  // src/viterbi.cpp:49-51: traceBack(m) with selectMaxTrans -- the first maximum in the reference's enumeration order is what
+  // the device's traceback bytes / codes record, so the path is answered without the matrix
   template <class MachineT>
-  typename PathOf<MachineT>::type path(const MachineT &m) const { return traceBack(m); }      // src/viterbi.cpp:49-51
-  // the same path traced on the device (one traceback byte per cell or the matrix, whichever the machine's kernel family
-  // keeps), as (state, transIndex) steps -- what a batch caller uses through mb_viterbi_batch
-  std::vector<PathStep> path() const {
-    if (!(endCell() > negInf())) throw std::runtime_error("Can't do traceback: no finite-weight paths");
-    const int64_t inOff[2] = {0, inLen}, outOff[2] = {0, outLen};
-    const int64_t cap = mb_viterbi_path_bound(flat.device(), inLen, outLen);
-    std::vector<uint32_t> edges((size_t)cap);
-    int64_t off[2] = {0, 0};
-    double ll = 0;
-    check(mb_viterbi_batch(flat.device(), 1, input.data(), inOff, output.data(), outOff, &ll, off, edges.data(), cap));
-    std::vector<PathStep> p;
-    for (int64_t k = 0; k < off[1]; ++k) p.push_back({flat.src[edges[k]], flat.transIndex[edges[k]]});
+  typename PathOf<MachineT>::type path(const MachineT &m) const {
+    typename PathOf<MachineT>::type p;
+    for (const PathStep &st : path()) p.trans.push_back(m.state[st.src].getTransition(st.transIndex));
     return p;
   }
+  std::vector<PathStep> path() const {         // as (state, transIndex) steps
+    if (!(score > negInf())) throw std::runtime_error("Can't do traceback: no finite-weight paths");      // src/dpmatrix.defs.h:84
+    std::vector<PathStep> p;
+    p.reserve(pathEdges.size());
+    for (const uint32_t e : pathEdges) p.push_back({flat.src[e], flat.transIndex[e]});
+    return p;
+  }
+  const std::vector<uint32_t> &pathEdgeIds() const { return pathEdges; }
 };
 
 class BackwardCore : public DPMatrixCore {     // src/backward.h:10-59
@@ -410,9 +555,9 @@ public:
   static BackTransVisitor transitionSorter(PostTransQueue &ptq) {
     return [&](StateIndex s, TransIndex ti, InputIndex ip, OutputIndex op, double postProb) { ptq.push(PostTrans{ip, op, s, ti, postProb}); };
   }
-  BackwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e)
-      : DPMatrixCore(m, in, out, e) { fill(MB_BACKWARD, 0); }
-  double logLike() const { return startCell(); }
+  BackwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, const PrefetchedPair * = nullptr)
+      : DPMatrixCore(m, in, out, e, MB_BACKWARD, 0) {}
+  double logLike() const { return startCell(); }      // fetches the matrix: the reference's callers of BackwardMatrix all walk it (src/counts.cpp:57-61 is MachineCounts here)
 
   // BackwardMatrix::getCounts with a visitor (src/backward.cpp:62-87): every cell, every outgoing transition, in the
   // reference's order; the position handed to the visitor is the transition's DESTINATION cell (:77-83)
@@ -470,8 +615,8 @@ inline Envelope fullEnvelope(const TokSeqPair &sp) { Envelope e; e.initFull((lon
 class ForwardMatrix : public ForwardCore {
 public:
   const FlatMachine &machine; const TokSeqPair &seqPair;
-  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, fullEnvelope(sp), startState), machine(m), seqPair(sp) {}
-  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, e, startState), machine(m), seqPair(sp) {}
+  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, fullEnvelope(sp), startState, prefetchedFor(m.prefetched.loglike, &sp, sp.input, sp.output, fullEnvelope(sp))), machine(m), seqPair(sp) {}
+  ForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e, StateIndex startState = 0) : ForwardCore(m, sp.input, sp.output, e, startState, prefetchedFor(m.prefetched.loglike, &sp, sp.input, sp.output, e)), machine(m), seqPair(sp) {}
 };
 class BackwardMatrix : public BackwardCore {
 public:
@@ -482,20 +627,55 @@ public:
 class ViterbiMatrix : public ViterbiCore {
 public:
   const FlatMachine &machine; const TokSeqPair &seqPair;
-  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp) : ViterbiCore(m, sp.input, sp.output, fullEnvelope(sp)), machine(m), seqPair(sp) {}
-  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : ViterbiCore(m, sp.input, sp.output, e), machine(m), seqPair(sp) {}
+  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp) : ViterbiCore(m, sp.input, sp.output, fullEnvelope(sp), prefetchedFor(m.prefetched.viterbi, &sp, sp.input, sp.output, fullEnvelope(sp))), machine(m), seqPair(sp) {}
+  ViterbiMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope &e) : ViterbiCore(m, sp.input, sp.output, e, prefetchedFor(m.prefetched.viterbi, &sp, sp.input, sp.output, e)), machine(m), seqPair(sp) {}
 };
 
 // RollingOutputForwardMatrix (src/forward.h:29, dpmatrix.h:46-58): log-likelihood only, no matrix in HBM
 class RollingOutputForwardMatrix {
   double ll;
 public:
-  RollingOutputForwardMatrix(const FlatMachine &m, const TokSeqPair &sp) {
-    const int64_t inOff[2] = {0, (int64_t)sp.input.size()}, outOff[2] = {0, (int64_t)sp.output.size()};
-    check(mb_forward_batch(m.device(), 1, sp.input.data(), inOff, sp.output.data(), outOff, MB_ROLLING, &ll));
+  RollingOutputForwardMatrix(const FlatMachine &m, const TokSeqPair &sp, const Envelope *env = nullptr) {
+    const bool full = !env || env->isFull();
+    if (const PrefetchedPair *pp = prefetchedFor(m.prefetched.loglike, &sp, sp.input, sp.output, env ? *env : fullEnvelope(sp))) { ll = pp->ll; return; }
+    std::vector<const TokSeqPair *> ps(1, &sp);
+    std::vector<const Envelope *> es;
+    if (!full) es.push_back(env);
+    ll = DeviceBatch(m, ps, es).forward(MB_ROLLING)[0];
   }
   double logLike() const { return ll; }
 };
+
+// prefetch over neutral types: ONE batched device call for the whole list; keys[p] = the address the matrices of pair p will
+// be constructed from (see the template form below, which is what a boss.cpp-style caller uses)
+inline void prefetchPairs(const FlatMachine &m, const std::vector<const TokSeqPair *> &pairs, const std::vector<const Envelope *> &envelopes,
+                          const std::vector<const void *> &keys, int what, const std::vector<uint64_t> *fingerprints = nullptr) {
+  m.prefetched.clear();
+  if (pairs.empty()) return;
+  bool anyEnv = false;
+  for (const Envelope *e : envelopes) anyEnv = anyEnv || !e->isFull();
+  DeviceBatch batch(m, pairs, anyEnv ? envelopes : std::vector<const Envelope *>());
+  auto entry = [&](size_t p) {
+    PrefetchedPair pp;
+    pp.in = pairs[p]->input; pp.out = pairs[p]->output;
+    if (fingerprints) pp.fingerprint = (*fingerprints)[p];
+    if (!envelopes.empty() && !envelopes[p]->isFull()) { pp.envStart = envelopes[p]->inStart; pp.envEnd = envelopes[p]->inEnd; }
+    return pp;
+  };
+  if (what & PrefetchLogLike) {
+    const std::vector<double> ll = batch.forward(MB_ROLLING);
+    for (size_t p = 0; p < pairs.size(); ++p) { PrefetchedPair pp = entry(p); pp.ll = ll[p]; m.prefetched.loglike[keys[p]] = std::move(pp); }
+  }
+  if (what & PrefetchViterbi) {
+    std::vector<double> ll; std::vector<int64_t> off; std::vector<uint32_t> edges;
+    batch.viterbi(ll, off, edges);
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      PrefetchedPair pp = entry(p);
+      pp.ll = ll[p]; pp.edges.assign(edges.begin() + off[p], edges.begin() + off[p + 1]);
+      m.prefetched.viterbi[keys[p]] = std::move(pp);
+    }
+  }
+}
 
 // MachineCounts (src/counts.h:11-25): E-step over a list of pairs in ONE device call
 struct MachineCounts {
@@ -511,30 +691,13 @@ struct MachineCounts {
   }
   // envelopes: empty = all full; otherwise one per pair (MachineCounts(eval, seqPairList, envelopes), src/counts.cpp:37-43)
   std::vector<double> add(const FlatMachine &m, const std::vector<TokSeqPair> &pairs, const std::vector<Envelope> &envelopes = {}) {
-    std::vector<InputToken> in; std::vector<OutputToken> out;
-    std::vector<int64_t> inOff(1, 0), outOff(1, 0);
-    for (const TokSeqPair &sp : pairs) {
-      in.insert(in.end(), sp.input.begin(), sp.input.end()); out.insert(out.end(), sp.output.begin(), sp.output.end());
-      inOff.push_back((int64_t)in.size()); outOff.push_back((int64_t)out.size());
-    }
-    std::vector<double> flat(m.nTransitions(), 0.0), ll(pairs.size(), 0.0);
+    if (!envelopes.empty() && envelopes.size() != pairs.size()) throw std::runtime_error("Envelope/training set mismatch");
+    std::vector<const TokSeqPair *> ps; std::vector<const Envelope *> es;
+    for (const TokSeqPair &sp : pairs) ps.push_back(&sp);
+    for (const Envelope &e : envelopes) es.push_back(&e);
+    std::vector<double> flat(m.nTransitions(), 0.0);
     double s = 0;
-    mb_batch *b = mb_batch_create(m.device(), (int64_t)pairs.size(), in.data(), inOff.data(), out.data(), outOff.data());
-    if (!b) throw std::runtime_error(mb_last_error());
-    int rc = 0;
-    if (!envelopes.empty()) {
-      if (envelopes.size() != pairs.size()) { mb_batch_destroy(b); throw std::runtime_error("Envelope/training set mismatch"); }
-      std::vector<int64_t> envOff(1, 0); std::vector<int32_t> st, en;
-      for (const Envelope &e : envelopes) {
-        if (!e.isFull()) { st.insert(st.end(), e.inStart.begin(), e.inStart.end()); en.insert(en.end(), e.inEnd.begin(), e.inEnd.end()); }
-        envOff.push_back((int64_t)st.size());
-      }
-      if (st.empty()) { st.push_back(0); en.push_back(0); }
-      rc = mb_batch_set_envelopes(b, envOff.data(), st.data(), en.data());
-    }
-    if (!rc) rc = mb_batch_counts(b, flat.data(), &s, ll.data());
-    mb_batch_destroy(b);
-    check(rc);
+    const std::vector<double> ll = DeviceBatch(m, ps, es).counts(flat, s);
     for (size_t e = 0; e < flat.size(); ++e) count[m.src[e]][m.transIndex[e]] += flat[e];
     loglike += s;
     return ll;
@@ -581,17 +744,69 @@ void flattenEvaluated(const EvalT &eval, FlatMachine &flat) {
 // target/boss.cpp:796,826) share it, new weights at the same address (an EM loop re-evaluating in place) are re-sent with
 // mb_machine_set_weights, a different topology rebuilds it.  forgetEvaluated() drops the entry when `eval` dies.
 inline std::map<const void *, std::shared_ptr<FlatMachine>> &flatRegistry() { static std::map<const void *, std::shared_ptr<FlatMachine>> r; return r; }
+inline void buildCharTable(const std::vector<std::string> &tok2sym, FlatMachine::CharTable &t) {
+  for (int &x : t.tok) x = -1;
+  t.usable = tok2sym.size() > 1;
+  for (size_t k = 1; k < tok2sym.size(); ++k) {
+    if (tok2sym[k].size() != 1) { t.usable = false; return; }
+    t.tok[(unsigned char)tok2sym[k][0]] = (int)k;
+  }
+}
+template <class SymbolT> void buildCharTable(const std::vector<SymbolT> &, FlatMachine::CharTable &t) { t.usable = false; }
+// Tokenizer::tokenize (src/eval.h:29-41); a symbol the table does not know goes to the caller's tokenizer, which throws its own message
+template <class TokenizerT>
+std::vector<int> tokenizeWith(const FlatMachine::CharTable &t, const TokenizerT &tk, const std::vector<std::string> &seq) {
+  if (!t.usable) return tk.tokenize(seq);
+  std::vector<int> out(seq.size());
+  for (size_t i = 0; i < seq.size(); ++i) {
+    const int v = seq[i].size() == 1 ? t.tok[(unsigned char)seq[i][0]] : -1;
+    if (v <= 0) return tk.tokenize(seq);
+    out[i] = v;
+  }
+  return out;
+}
+template <class TokenizerT, class SymbolT>
+std::vector<int> tokenizeWith(const FlatMachine::CharTable &, const TokenizerT &tk, const std::vector<SymbolT> &seq) { return tk.tokenize(seq); }
+
+// does `flat` still describe `eval`?  (same walk as flattenEvaluated, nothing allocated); sameWeights tells whether only the weights moved
+template <class EvalT>
+bool sameTopology(const EvalT &eval, const FlatMachine &flat, bool &sameWeights) {
+  sameWeights = true;
+  if (flat.nStates != (int)eval.state.size() || flat.nInTok != (int)eval.inputTokenizer.tok2sym.size() - 1 || flat.nOutTok != (int)eval.outputTokenizer.tok2sym.size() - 1) return false;
+  for (StateIndex s = 0; s < eval.state.size(); ++s) {
+    const size_t n = eval.state[s].logTransWeight.size(), base = flat.transOffset[s];
+    if (flat.transOffset[s + 1] - base != n) return false;
+    size_t seen = 0;
+    for (const auto &iost : eval.state[s].outgoing)
+      for (const auto &ost : iost.second)
+        for (const auto &st : ost.second) {
+          const size_t e = base + st.second.transIndex;
+          if (st.second.transIndex >= n || flat.dst[e] != (uint32_t)st.first || flat.inTok[e] != (uint16_t)iost.first || flat.outTok[e] != (uint16_t)ost.first) return false;
+          ++seen;
+        }
+    if (seen != n) return false;
+    for (size_t ti = 0; ti < n; ++ti) if (!(flat.logWeight[base + ti] == eval.state[s].logTransWeight[ti])) sameWeights = false;
+  }
+  return true;
+}
+
 template <class EvalT>
 std::shared_ptr<FlatMachine> flatOf(const EvalT &eval) {
-  std::shared_ptr<FlatMachine> fresh = std::make_shared<FlatMachine>();
-  flattenEvaluated(eval, *fresh);
   std::shared_ptr<FlatMachine> &slot = flatRegistry()[(const void *)&eval];
-  if (slot && slot->nStates == fresh->nStates && slot->nInTok == fresh->nInTok && slot->nOutTok == fresh->nOutTok && slot->src == fresh->src &&
-      slot->dst == fresh->dst && slot->inTok == fresh->inTok && slot->outTok == fresh->outTok) {
-    if (slot->logWeight != fresh->logWeight) slot->setLogWeights(fresh->logWeight);
+  bool sameWeights = false;
+  if (slot && sameTopology(eval, *slot, sameWeights)) {
+    if (!sameWeights) {
+      std::vector<double> lw;
+      lw.reserve(slot->nTransitions());
+      for (StateIndex s = 0; s < eval.state.size(); ++s) lw.insert(lw.end(), eval.state[s].logTransWeight.begin(), eval.state[s].logTransWeight.end());
+      slot->setLogWeights(lw);
+    }
     return slot;
   }
-  slot = fresh;
+  slot = std::make_shared<FlatMachine>();
+  flattenEvaluated(eval, *slot);
+  buildCharTable(eval.inputTokenizer.tok2sym, slot->inChars);
+  buildCharTable(eval.outputTokenizer.tok2sym, slot->outChars);
   return slot;
 }
 template <class EvalT>
@@ -610,13 +825,63 @@ Envelope envelopeOf(const SeqPairT &sp) {
   return e;
 }
 
+// FNV-1a over the symbols of both tapes: the cheap proof that the SeqPair at a prefetched address is still the same pair
+inline uint64_t fnvSeq(uint64_t h, const std::vector<std::string> &seq) {
+  for (const std::string &sym : seq) {
+    for (const char c : sym) { h ^= (unsigned char)c; h *= 1099511628211ull; }
+    h ^= 0xFF; h *= 1099511628211ull;
+  }
+  return h;
+}
+template <class SymbolT> uint64_t fnvSeq(uint64_t h, const std::vector<SymbolT> &seq) {
+  for (const SymbolT &sym : seq) { h ^= (uint64_t)std::hash<SymbolT>()(sym); h *= 1099511628211ull; }
+  return h;
+}
+template <class SeqPairT> uint64_t fingerprintOf(const SeqPairT &sp) {
+  uint64_t h = fnvSeq(14695981039346656037ull, sp.input.seq);
+  h ^= 0xFE; h *= 1099511628211ull;
+  return fnvSeq(h, sp.output.seq);
+}
+
+// What a matrix of the caller's types is constructed from: the device machine, the pair's tokens and Envelope(seqPair) -- and,
+// if prefetch() ran for this SeqPair object and it has not changed since, its result (tokens are then taken from it)
+struct Prepared {
+  std::shared_ptr<FlatMachine> flat;
+  std::vector<InputToken> in;
+  std::vector<OutputToken> out;
+  Envelope env;
+  const PrefetchedPair *pre = nullptr;
+};
+template <class EvalT, class SeqPairT>
+Prepared prepare(const EvalT &m, const SeqPairT &sp, int what) {
+  Prepared p;
+  p.flat = flatOf(m);
+  p.env = envelopeOf(sp);
+  const std::map<const void *, PrefetchedPair> *store = what == PrefetchLogLike ? &p.flat->prefetched.loglike : what == PrefetchViterbi ? &p.flat->prefetched.viterbi : nullptr;
+  if (store && !store->empty()) {
+    const auto it = store->find((const void *)&sp);
+    if (it != store->end()) {
+      const PrefetchedPair &pp = it->second;
+      const bool full = p.env.isFull();
+      if (pp.in.size() == sp.input.seq.size() && pp.out.size() == sp.output.seq.size() && pp.fingerprint == fingerprintOf(sp) &&
+          (full ? pp.envStart.empty() : (pp.envStart == p.env.inStart && pp.envEnd == p.env.inEnd))) {
+        p.in = pp.in; p.out = pp.out; p.pre = &pp;
+        return p;
+      }
+    }
+  }
+  p.in = tokenizeWith(p.flat->inChars, m.inputTokenizer, sp.input.seq);
+  p.out = tokenizeWith(p.flat->outChars, m.outputTokenizer, sp.output.seq);
+  return p;
+}
+
 template <class EvalT, class SeqPairT, class Core>
 class MatrixT : public Core {
 protected:
   std::shared_ptr<FlatMachine> flatPtr;
   template <class... Extra>
-  MatrixT(std::shared_ptr<FlatMachine> f, const EvalT &m, const SeqPairT &sp, Extra... extra)
-      : Core(*f, m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq), envelopeOf(sp), extra...), flatPtr(f), machine(m), seqPair(sp) {}
+  MatrixT(const EvalT &m, const SeqPairT &sp, const Prepared &p, Extra... extra)
+      : Core(*p.flat, p.in, p.out, p.env, extra..., p.pre), flatPtr(p.flat), machine(m), seqPair(sp) {}
 public:
   const EvalT &machine;       // the public members of the reference's DPMatrix (src/dpmatrix.h:125-131)
   const SeqPairT &seqPair;
@@ -632,16 +897,16 @@ template <class EvalT, class SeqPairT>
 class ForwardMatrixT : public MatrixT<EvalT, SeqPairT, ForwardCore> {
   typedef MatrixT<EvalT, SeqPairT, ForwardCore> Base;
 public:
-  ForwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp, (StateIndex)0) {}
-  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp, (StateIndex)0) {}
-  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &, StateIndex startState) : Base(flatOf(m), m, sp, startState) {}
+  ForwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(m, sp, prepare(m, sp, PrefetchLogLike), (StateIndex)0) {}
+  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(m, sp, prepare(m, sp, PrefetchLogLike), (StateIndex)0) {}
+  template <class EnvT> ForwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &, StateIndex startState) : Base(m, sp, prepare(m, sp, startState ? 0 : PrefetchLogLike), startState) {}
 };
 template <class EvalT, class SeqPairT>
 class BackwardMatrixT : public MatrixT<EvalT, SeqPairT, BackwardCore> {
   typedef MatrixT<EvalT, SeqPairT, BackwardCore> Base;
 public:
-  BackwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp) {}
-  template <class EnvT> BackwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp) {}
+  BackwardMatrixT(const EvalT &m, const SeqPairT &sp) : Base(m, sp, prepare(m, sp, 0)) {}
+  template <class EnvT> BackwardMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(m, sp, prepare(m, sp, 0)) {}
   using BackwardCore::getCounts;
   template <class CountsT> static BackwardCore::BackTransVisitor transitionCounter(CountsT &counts) {      // src/backward.h:13-19
     return [&counts](StateIndex s, TransIndex ti, long, long, double postProb) { counts.count[s][ti] += postProb; };
@@ -655,20 +920,47 @@ template <class EvalT, class SeqPairT>
 class ViterbiMatrixT : public MatrixT<EvalT, SeqPairT, ViterbiCore> {
   typedef MatrixT<EvalT, SeqPairT, ViterbiCore> Base;
 public:
-  ViterbiMatrixT(const EvalT &m, const SeqPairT &sp) : Base(flatOf(m), m, sp) {}
-  template <class EnvT> ViterbiMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(flatOf(m), m, sp) {}
+  ViterbiMatrixT(const EvalT &m, const SeqPairT &sp) : Base(m, sp, prepare(m, sp, PrefetchViterbi)) {}
+  template <class EnvT> ViterbiMatrixT(const EvalT &m, const SeqPairT &sp, const EnvT &) : Base(m, sp, prepare(m, sp, PrefetchViterbi)) {}
 };
 template <class EvalT, class SeqPairT>
 class RollingOutputForwardMatrixT {        // MappedForwardMatrix<RollingOutputIndexMapper> (src/forward.h:29): logLike() only
   double ll;
 public:
   RollingOutputForwardMatrixT(const EvalT &m, const SeqPairT &sp) {
-    const std::shared_ptr<FlatMachine> f = flatOf(m);
-    const TokSeqPair tsp{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)};
-    ll = RollingOutputForwardMatrix(*f, tsp).logLike();
+    const Prepared p = prepare(m, sp, PrefetchLogLike);
+    if (p.pre) { ll = p.pre->ll; return; }
+    const TokSeqPair tsp{p.in, p.out};
+    ll = RollingOutputForwardMatrix(*p.flat, tsp, &p.env).logLike();      // quirk Q1: Envelope(seqPair)
   }
   double logLike() const { return ll; }
 };
+
+// prefetch(eval, data.seqPairs, what): ONE batched device call over the pairs a caller is about to loop over; the
+// ViterbiMatrix / ForwardMatrix / RollingOutputForwardMatrix objects it then constructs from the SAME SeqPair objects (the
+// `for (const auto& seqPair : data.seqPairs)` loops of target/boss.cpp:796,826 bind references to the list's elements) take
+// their score, path or log-likelihood from it instead of running one device call each.  what: PrefetchLogLike (rolling
+// Forward), PrefetchViterbi (score + path), or both.  Pairs the machine cannot tokenise are skipped, as the loops skip them
+// (`eval.canTokenize (seqPair)`).  New weights or another prefetch for the same EvaluatedMachine drop the old results.
+template <class EvalT, class SeqPairsT>
+void prefetch(const EvalT &eval, const SeqPairsT &seqPairs, int what) {
+  const std::shared_ptr<FlatMachine> f = flatOf(eval);
+  std::list<TokSeqPair> toks; std::list<Envelope> envs;
+  std::vector<const TokSeqPair *> ps; std::vector<const Envelope *> es; std::vector<const void *> keys; std::vector<uint64_t> fps;
+  for (const auto &sp : seqPairs) {
+    // (the table tokenizer says no exactly when eval.canTokenize (sp) does -- two std::map look-ups per symbol, src/eval.h:23-28 --
+    //  and then asks the caller's tokenizer, which throws)
+    try { toks.push_back(TokSeqPair{tokenizeWith(f->inChars, eval.inputTokenizer, sp.input.seq), tokenizeWith(f->outChars, eval.outputTokenizer, sp.output.seq)}); }
+    catch (const std::exception &) { continue; }
+    envs.push_back(envelopeOf(sp));
+    bool usable = envs.back().fits(toks.back()) && envs.back().connected();
+    for (const int t : toks.back().input) usable = usable && t > 0;       // (an empty symbol tokenises to epsilon: the device rejects it)
+    for (const int t : toks.back().output) usable = usable && t > 0;
+    if (!usable) { toks.pop_back(); envs.pop_back(); continue; }          // the matrix constructor will throw for this one, as it would without a prefetch
+    ps.push_back(&toks.back()); es.push_back(&envs.back()); keys.push_back((const void *)&sp); fps.push_back(fingerprintOf(sp));
+  }
+  prefetchPairs(*f, ps, es, keys, what, &fps);
+}
 
 // MachineCounts with the reference's whole surface (src/counts.h:11-25).  A SeqPairList goes to the device as ONE batch.
 // PolicyT names the caller's weight algebra and string helper for the three members that never touch the DP
@@ -685,7 +977,7 @@ struct MachineCountsT : MachineCounts {
   void init(const EvalT &m) { MachineCounts::init(*flatOf(m)); }
   double add(const EvalT &m, const SeqPairT &sp) {
     const std::shared_ptr<FlatMachine> f = flatOf(m);
-    const TokSeqPair tsp{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)};
+    const TokSeqPair tsp{tokenizeWith(f->inChars, m.inputTokenizer, sp.input.seq), tokenizeWith(f->outChars, m.outputTokenizer, sp.output.seq)};
     return MachineCounts::add(*f, {tsp}, {envelopeOf(sp)})[0];
   }
   template <class EnvT> double add(const EvalT &m, const SeqPairT &sp, const EnvT &) { return add(m, sp); }
@@ -693,7 +985,7 @@ struct MachineCountsT : MachineCounts {
     const std::shared_ptr<FlatMachine> f = flatOf(m);
     std::vector<TokSeqPair> pairs; std::vector<Envelope> envs;
     for (const auto &sp : l.seqPairs) {
-      pairs.push_back(TokSeqPair{m.inputTokenizer.tokenize(sp.input.seq), m.outputTokenizer.tokenize(sp.output.seq)});
+      pairs.push_back(TokSeqPair{tokenizeWith(f->inChars, m.inputTokenizer, sp.input.seq), tokenizeWith(f->outChars, m.outputTokenizer, sp.output.seq)});
       envs.push_back(envelopeOf(sp));
     }
     (void)MachineCounts::add(*f, pairs, envs);

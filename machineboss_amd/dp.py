@@ -126,8 +126,14 @@ class _DPMatrix:
     The fill runs on the GPU (mb_fill); the path functions below (traceBack / traceForward and their selectors and
     terminators, src/dpmatrix.defs.h:61-186) walk the finished matrix on the host exactly as the reference does --
     they visit O(path length x in-degree) cells and are only used by Machine::downsample / stochasticDownsample and
-    ForwardMatrix::samplePath.  The Viterbi path of a batch (the hot use) is traced on the device instead."""
+    ForwardMatrix::samplePath.  The Viterbi path of a batch (the hot use) is traced on the device instead.
+
+    The fp64 matrix is fetched LAZILY, by the first cell() / cells() / writeJson / walker that reads it (``matrix_fills``
+    counts the fetches): what the reference's callers read from a ViterbiMatrix or a ForwardMatrix -- logLike(), path(m)
+    (target/boss.cpp:826-833, src/api.cpp:31-66) -- comes from the matrix-free sweeps the constructors run (mb_dp.hpp, the
+    C++ twin of this module, does the same)."""
     _mode = capi.MB_FORWARD
+    matrix_fills = 0          # class-wide count of fp64 matrices fetched from the device
 
     def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None, startState: int = 0):
         self.machine, self.seqPair = machine, seqPair
@@ -140,10 +146,29 @@ class _DPMatrix:
         self.env = Envelope(seqPair)
         if not self.env.connected():                                     # DPMatrix::alloc, src/dpmatrix.defs.h:31-32
             raise MachineError("Envelope is not connected:\n%s\n" % self.env.writeJson())
+        if not self.env.fits(seqPair):
+            raise MachineError("Envelope/sequence mismatch")
         self._dm = _device_machine(machine)
-        full = self.env.isFull()
-        self._cells = self._dm.fill(self._mode, self.input, self.output, startState,
-                                    None if full else self.env.inStart, None if full else self.env.inEnd)  # [o][i][s]
+        self._startState = startState
+        self._matrix = None
+
+    @property
+    def _cells(self) -> np.ndarray:
+        if self._matrix is None:
+            full = self.env.isFull()
+            self._matrix = self._dm.fill(self._mode, self.input, self.output, self._startState,
+                                         None if full else self.env.inStart, None if full else self.env.inEnd)  # [o][i][s]
+            _DPMatrix.matrix_fills += 1
+        return self._matrix
+
+    def matrixFetched(self) -> bool:
+        return self._matrix is not None
+
+    def _onePairBatch(self) -> "capi.DeviceBatch":
+        b = capi.DeviceBatch.from_pairs(self._dm, [(self.input, self.output)])
+        if not self.env.isFull():      # Envelope(seqPair), quirk Q1
+            b.set_envelopes([(self.env.inStart, self.env.inEnd)])
+        return b
 
     def cell(self, inPos: int, outPos: int, state: int) -> float:
         if 0 <= outPos <= self.outLen and 0 <= inPos <= self.inLen:
@@ -269,11 +294,19 @@ class _DPMatrix:
 
 
 class ForwardMatrix(_DPMatrix):
-    """src/forward.h:19-27."""
+    """src/forward.h:19-27.  The constructor runs the rolling sweep (log-likelihood only); the matrix comes on demand."""
     _mode = capi.MB_FORWARD
 
+    def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None, startState: int = 0):
+        super().__init__(machine, seqPair, envelope, startState)
+        self._ll = None
+        if startState == 0:            # a caller-chosen start state (src/forward.h:24) exists on the matrix route only
+            b = self._onePairBatch()
+            self._ll = float(b.forward(capi.MB_ROLLING)[0])
+            b.close()
+
     def logLike(self) -> float:
-        return self.endCell()
+        return self.endCell() if self._ll is None else self._ll
 
     def samplePath(self, m: Machine, rng, s: Optional[int] = None) -> MachinePath:
         """Stochastic traceback with exp(candidate) weights (src/forward.cpp:17-23)."""
@@ -362,20 +395,21 @@ class ViterbiMatrix(_DPMatrix):
 
     def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None):
         super().__init__(machine, seqPair, envelope, 0)
+        # score + the fill's own arg-max chain through the family's traceback-byte / traceback-code sweep: no fp64 matrix
+        b = self._onePairBatch()
+        ll, off, edges = b.viterbi(paths=True)
+        b.close()
+        self._score = float(ll[0])
+        self._edges = np.array(edges[off[0]:off[1]], copy=True)
 
     def logLike(self) -> float:
-        return self.endCell()
+        return self._score          # = endCell(), bit for bit (the max semiring is exact in every kernel family)
 
     def path(self, m: Machine) -> MachinePath:
-        """traceBack(m) (src/viterbi.cpp:49-51, dpmatrix.defs.h:61-110), run on the device."""
-        if not (self.endCell() > -math.inf):
+        """traceBack(m) (src/viterbi.cpp:49-51, dpmatrix.defs.h:61-110), traced on the device by the constructor."""
+        if not (self._score > -math.inf):
             raise MachineError("Can't do traceback: no finite-weight paths")
-        b = capi.DeviceBatch.from_pairs(self._dm, [(self.input, self.output)])
-        if not self.env.isFull():      # the matrix was filled inside Envelope(seqPair) (quirk Q1): the traceback must stay inside it too
-            b.set_envelopes([(self.env.inStart, self.env.inEnd)])
-        _, off, edges = b.viterbi(paths=True)
-        b.close()
-        return edgesToPath(self.machine, m, edges)
+        return edgesToPath(self.machine, m, self._edges)
 
 
 def edgesToPath(em: EvaluatedMachine, m: Machine, edges: Sequence[int]) -> MachinePath:

@@ -82,6 +82,10 @@ struct Tokenizer {                       // src/eval.h:11-50
     for (Token tok = 0; tok < (Token)tok2sym.size(); ++tok) sym2tok[tok2sym[tok]] = tok;
   }
   static Token emptyToken() { return 0; }
+  bool canTokenize(const std::vector<Symbol> &symSeq) const {          // src/eval.h:23-28
+    for (const auto &sym : symSeq) if (!sym2tok.count(sym)) return false;
+    return true;
+  }
   std::vector<Token> tokenize(const std::vector<Symbol> &symSeq) const {
     std::vector<Token> tokSeq;
     for (const auto &sym : symSeq) {
@@ -136,6 +140,9 @@ struct EvaluatedMachine {                // src/eval.h:77-98, init as src/eval.c
   StateIndex nStates() const { return state.size(); }
   StateIndex startState() const { return 0; }
   StateIndex endState() const { return nStates() - 1; }
+  template <class SeqPairT> bool canTokenize(const SeqPairT &sp) const {   // src/eval.cpp:218-220
+    return inputTokenizer.canTokenize(sp.input.seq) && outputTokenizer.canTokenize(sp.output.seq);
+  }
 };
 
 template <typename Symbol>

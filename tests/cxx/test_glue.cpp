@@ -76,6 +76,15 @@ int main(int argc, char **argv) {
       if (viterbi.logLike() > -numeric_limits<double>::infinity()) printPath("align", viterbi.path(machine));
     }
 
+    // the same two loops behind the ONE added line of INTEGRATION.md section 2b: one batched device call, then the unchanged loop
+    MachineBossHIP::prefetch(eval, data.seqPairs, MachineBossHIP::PrefetchLogLike | MachineBossHIP::PrefetchViterbi);
+    for (const auto &sp : data.seqPairs) {
+      RollingOutputForwardMatrix roll(eval, sp);
+      ViterbiMatrix viterbi(eval, sp);
+      cout << "ppair " << setprecision(17) << roll.logLike() << " " << viterbi.logLike() << endl;
+      if (viterbi.logLike() > -numeric_limits<double>::infinity()) printPath("palign", viterbi.path(machine));
+    }
+
     // target/boss.cpp:813, src/api.cpp:48-58 (--counts)
     MachineCounts counts(eval, data);
     cout << "counts " << setprecision(17) << counts.loglike;

@@ -63,6 +63,33 @@ def test_reference_callers_compile_against_real_headers_with_the_glue(tmp_path, 
     assert "MachineObjective::MachineObjective" in cc and "MachineCounts::add" not in cc and "MachineCounts::paramCounts" not in cc
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "target")), reason="reference tree not present (it never travels to the GPU box)")
+def test_prefetch_option_adds_one_line_per_loop_of_boss_cpp(tmp_path):
+    """apply_glue.py --prefetch: target/boss.cpp gains exactly one line behind the `const EvaluatedMachine eval (machine, params);` of
+    the --loglike block (target/boss.cpp:793-796) and of the --viterbi / --align block (:819-826); everything else is the reference's
+    text.  (boss.cpp itself cannot be parsed here -- it includes Boost; the call it gains is parsed against the real headers in
+    test_glue.cpp -DMB_GLUE_REAL above and runs in tests/test_dropin.py.)"""
+    import difflib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "machineboss_amd", "cxx"))
+    import apply_glue
+    ov = apply_glue.overlay(REFERENCE, str(tmp_path / "overlay"), prefetch=True)
+    old = open(os.path.join(REFERENCE, "target", "boss.cpp")).read().splitlines()
+    new = open(os.path.join(ov, "target", "boss.cpp")).read().splitlines()
+    ops = [op for op in difflib.SequenceMatcher(None, old, new, autojunk=False).get_opcodes() if op[0] != "equal"]
+    assert [op[0] for op in ops] == ["insert", "insert"] and all(op[4] - op[3] == 1 for op in ops)
+    added = [new[op[3]].strip() for op in ops]
+    assert added[0].startswith("MachineBossHIP::prefetch (eval, data.seqPairs, MachineBossHIP::PrefetchLogLike);")
+    assert added[1].startswith("MachineBossHIP::prefetch (eval, data.seqPairs, MachineBossHIP::PrefetchViterbi);")
+    for op in ops:      # each sits right behind the block's EvaluatedMachine and in front of its loop
+        assert new[op[3] - 1].strip() == "const EvaluatedMachine eval (machine, params);"
+        assert any("for (const auto& seqPair: data.seqPairs)" in l for l in new[op[3]:op[3] + 8])
+    assert not os.path.islink(os.path.join(ov, "target", "boss.cpp"))
+    # without the option boss.cpp is the reference's own file
+    ov2 = apply_glue.overlay(REFERENCE, str(tmp_path / "overlay2"))
+    assert os.path.islink(os.path.join(ov2, "target", "boss.cpp"))
+
+
 def _write_case(path, em, names, pairs, seed):
     """Machine + pairs in the text form tests/cxx/test_glue.cpp reads (weights as exp(logWeight), 17 digits)."""
     insym = [None] + list(em.inputTokenizer.tok2sym[1:]) if hasattr(em.inputTokenizer, "tok2sym") else None
@@ -170,7 +197,9 @@ def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed, dag):
                 assert cells[k].rstrip(",") == '  { "inPos": %d, "outPos": %d, "state": "s%d", "logLike": %s }' % (i, o, s, txt), cells[k]
                 k += 1
     ll = get("loglike")[0].split()
-    assert float(ll[1]) == F[-1, -1, -1] and float(ll[2]) == B[0, 0, 0] and ll[4:7] == [str(len(x)), str(len(y)), str(S)] and ll[-1] == "-inf"
+    # ForwardMatrix::logLike() is the rolling sweep's value (the matrix is fetched lazily, by writeJson above): equal to the end cell up to summation order
+    same_ll = lambda a, b: a == b or abs(a - b) <= 1e-9 * abs(b)
+    assert same_ll(float(ll[1]), F[-1, -1, -1]) and float(ll[2]) == B[0, 0, 0] and ll[4:7] == [str(len(x)), str(len(y)), str(S)] and ll[-1] == "-inf"
     # --loglike / --viterbi / --align per pair
     pl = get("pair"); al = get("align"); ai = 0
     for k, (a, b) in enumerate(pairs):
@@ -180,6 +209,12 @@ def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed, dag):
         assert v == Vk[-1, -1, -1] and (abs(r - ref) <= 2e-6 * abs(ref) + 2e-5 if math.isfinite(ref) else r == ref)
         if Vk[-1, -1, -1] > -math.inf:
             same_path(al[ai], om.traceback(a, b, Vk)); ai += 1
+    # ... and the same through prefetch(): identical scores and paths, log-likelihoods up to summation order
+    ppl = get("ppair"); pal = get("palign")
+    assert len(ppl) == len(pl) and [l.split()[1:] for l in pal] == [l.split()[1:] for l in al]
+    for a, b in zip(pl, ppl):
+        (r1, v1), (r2, v2) = [float(t) for t in a.split()[1:]], [float(t) for t in b.split()[1:]]
+        assert v1 == v2 and (r1 == r2 or abs(r1 - r2) <= 1e-9 * abs(r1))
     # MachineCounts over the list, the api.h wrappers, getCounts(forward, counts) on the host against the device sweep
     cl = [float(t) for t in get("counts")[0].split()[1:]]
     ref_c = np.zeros(em.nTransitions); ref_s = 0.0
@@ -195,7 +230,7 @@ def test_glue_runs_like_the_reference(tmp_path, oracle_mod, S, seed, dag):
     assert "\n".join(cj).replace("e-0", "e-").replace("e+0", "e+") == ("[" + ",\n ".join(rows) + "]").replace("e-0", "e-").replace("e+0", "e+")
     assert get("paramcounts")[0] == "paramcounts {}"      # the mock's weights carry no parameters
     cv = get("counts_visitor_vs_device")[0].split()
-    assert float(cv[1]) < 1e-6 and float(cv[3]) == F[-1, -1, -1] and float(cv[4]) == V[-1, -1, -1]
+    assert float(cv[1]) < 1e-6 and same_ll(float(cv[3]), F[-1, -1, -1]) and float(cv[4]) == V[-1, -1, -1]
     if V[-1, -1, -1] > -math.inf:
         same_path(get("apialign")[0], om.traceback(x, y, V))
     if F[-1, -1, -1] > -math.inf:
