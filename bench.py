@@ -38,36 +38,110 @@ TRANSCENDENTAL_PEAK_T = 157.0 / 2 / 4   # v_exp_f32 / v_log_f32 per second (x 1e
 BYTES_PER_CELL = 8      # materialised Forward: one fp64 store per cell (w = 8)
 
 
+PROFILE_TAG = "r05"      # profiles/<tag>_*: the recorded constants this bench line may quote
+DUMP_DIR = None          # generated kernel sources of THIS run (MB_MEDIUM_JIT_DUMP / MB_SMALL_JIT_DUMP), hashed against profiles/<tag>_kernel_sha.json
+REFUSED = {}             # recorded figure -> why it was not quoted
+
+
 def recorded(name):
-    """A committed measurement under profiles/ (None when absent): PMC traffic and the vector-issue model are recorded constants
-    of the round's profile run (scripts/profile_r04.sh), labelled as such wherever the bench line quotes them."""
+    """A committed measurement under profiles/ (None when absent)."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
 
 
-def valu_issue(model, keys, cells_per_s):
+def dump_kernels_as(tag):
+    """From here on the library writes the source of every kernel it generates to DUMP_DIR/<tag>.<kind>.hip (read when a kernel is built)."""
+    if DUMP_DIR:
+        os.environ["MB_MEDIUM_JIT_DUMP"] = os.path.join(DUMP_DIR, tag)
+        os.environ["MB_SMALL_JIT_DUMP"] = os.path.join(DUMP_DIR, tag)
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def kernel_sha_now():
+    """sha256[:16] of every generated kernel source of this run, and of the ahead-of-time one-tape kernels' source files."""
+    out = {}
+    if DUMP_DIR and os.path.isdir(DUMP_DIR):
+        for f in sorted(os.listdir(DUMP_DIR)):
+            if f.endswith(".hip"):
+                out[f[:-4]] = _sha16(os.path.join(DUMP_DIR, f))
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mb_wide.hip", "mb_wide.h"):
+        h.update(open(os.path.join(ROOT, "machineboss_amd", "csrc", f), "rb").read())
+    out["aot:mb_wide"] = h.hexdigest()[:16]
+    return out
+
+
+def kernels_unchanged(what, kernels):
+    """True when every kernel a recorded figure was measured on still has the source it had when profiles/<tag>_kernel_sha.json was
+    written (by `python bench.py --write-kernel-sha`, in the round's profile run): a recorded PMC traffic / issue figure is quoted
+    only then -- otherwise the line carries null and REFUSED says why (constants must not go stale silently)."""
+    ref = recorded(PROFILE_TAG + "_kernel_sha.json")
+    if not ref:
+        REFUSED[what] = "no profiles/%s_kernel_sha.json" % PROFILE_TAG
+        return False
+    now = kernel_sha_now()
+    for k in kernels:
+        if k not in now:
+            REFUSED[what] = "kernel %s was not generated in this run" % k
+            return False
+        if ref.get("kernels", {}).get(k) != now[k]:
+            REFUSED[what] = "kernel %s changed since profiles/%s_* were recorded (%s -> %s)" % (k, PROFILE_TAG, ref.get("kernels", {}).get(k), now[k])
+            return False
+    return True
+
+
+def valu_issue(keys, cells_per_s):
     """Vector-issue fraction of a mode: issue slots per cell of its kernels' step loops, from their gfx950 ISA
     (scripts/valu_model.py: plain VALU 1, fp64 / transcendental 2, one slot = 2 cycles of a SIMD-32) x the measured rate /
-    (256 CUs x 4 SIMDs x 2.4 GHz / 2).  None when the model has no entry for a kernel."""
+    (256 CUs x 4 SIMDs x 2.4 GHz / 2).  None when the model has no entry for a kernel or a kernel changed since it was recorded."""
+    model = recorded(PROFILE_TAG + "_valu_model.json")
     if not model:
+        REFUSED["issue:" + "+".join(keys)] = "no profiles/%s_valu_model.json" % PROFILE_TAG
+        return None
+    if not kernels_unchanged("issue:" + "+".join(keys), [k[:-4] if k.endswith(".hip") else k for k in keys]):
         return None
     try:
         per_cell = sum(model["kernels"][k]["issue_slots_per_cell"] for k in keys)
         return {"valu_issue_frac": round(cells_per_s * per_cell / model["peak_issue_slots_per_s"], 4), "issue_slots_per_cell": round(per_cell, 4),
                 "at_full_issue_gcells": round(model["peak_issue_slots_per_s"] / per_cell / 1e9, 1), "kernels": list(keys),
-                "source": "profiles/r04_valu_model.json (ISA of the generated kernels, scripts/valu_model.py; recorded, not re-derived in this run)"}
+                "source": "profiles/%s_valu_model.json (ISA of the generated kernels, scripts/valu_model.py; recorded -- kernel sources verified unchanged by hash)" % PROFILE_TAG}
     except KeyError:
         return None
 
 
-def pmc_traffic(name, units):
-    """HBM bytes per call of a non-headline mode from its committed PMC passes (profiles/<name>), scaled to this run's units."""
-    p = recorded(name)
+def pmc_traffic(name, units, kernels):
+    """HBM bytes per call of a mode from its committed PMC passes (profiles/<tag>_<name>), scaled to this run's units -- or (None, why)."""
+    full = PROFILE_TAG + "_" + name
+    p = recorded(full)
     if not p:
+        REFUSED["traffic:" + name] = "no profiles/" + full
         return None, None
-    return round(p["hbm_bytes_per_cell"] * units), "profiles/%s (%.2f B per cell, separate --pmc WRITE_SIZE / FETCH_SIZE passes; recorded, not re-measured in this run)" % (name, p["hbm_bytes_per_cell"])
+    if not kernels_unchanged("traffic:" + name, kernels):
+        return None, REFUSED["traffic:" + name]
+    return round(p["hbm_bytes_per_cell"] * units), "profiles/%s (%.2f B per cell, separate --pmc WRITE_SIZE / FETCH_SIZE passes; recorded -- kernel sources verified unchanged by hash)" % (full, p["hbm_bytes_per_cell"])
+
+
+def onetape_issue():
+    """Issue fraction of the one-tape sweeps at 64 x 50 kb from the round's SQ passes (profiles/<tag>_onetape_sq.json, written by
+    scripts/profile_onetape.sh + summarize): SQ_INSTS_VALU of the dispatches / (SIMDs of the occupied CUs x cycles at 2.4 GHz) x 2 cycles
+    per wave64 instruction -- quoted only while mb_wide.hip is the file it was measured on (no pasted literals)."""
+    p = recorded(PROFILE_TAG + "_onetape_sq.json")
+    if not p:
+        REFUSED["issue:onetape"] = "no profiles/%s_onetape_sq.json" % PROFILE_TAG
+        return None
+    if not kernels_unchanged("issue:onetape", ["aot:mb_wide"]):
+        return None
+    out = {"what": p.get("what"), "source": "profiles/%s_onetape_sq.json (recorded -- mb_wide.hip verified unchanged by hash)" % PROFILE_TAG}
+    for k, v in p.get("sweeps", {}).items():
+        out[k] = {"valu_issue_frac_unweighted": round(v["SQ_INSTS_VALU"] * 2 / (v["cus"] * 4 * v["seconds"] * 2.4e9), 3), "SQ_WAIT_ANY": v.get("SQ_WAIT_ANY")}
+    return out
 
 
 def host_cores() -> int:
@@ -102,6 +176,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-headline) measurements")
     ap.add_argument("--extra-em-only", action="store_true", help="of the extras, only the EM iteration with its all-reduce (needs a rank group: N > 1 or MB_BENCH_FORCE_COMM=1)")
+    ap.add_argument("--write-kernel-sha", metavar="FILE", help="write the hashes of this run's generated kernel sources (profiles/<tag>_kernel_sha.json: what recorded PMC / issue figures are checked against)")
     ap.add_argument("--dropin-only", action="store_true", help="only extra.dropin (the reference's call sites through the C++ classes); prints that block")
     ap.add_argument("--quick", action="store_true", help="with --dropin-only: small batches")
     return ap.parse_args(argv)
@@ -145,6 +220,7 @@ def extra_single_gpu(capi, np, hbm_peak):
 
     # config 1: protpsw, ONE 50-aa pair: cold start = machine upload + program build + kernel JIT (or disk-cache hit) + run
     em1 = machine("protpsw")
+    dump_kernels_as("protpsw")
     t0 = time.perf_counter()
     dm1 = capi.DeviceMachine(em1)
     b1 = capi.DeviceBatch(dm1, *synth_batch(1, 1, 50, 50, em1.nInTok, em1.nOutTok))
@@ -165,26 +241,26 @@ def extra_single_gpu(capi, np, hbm_peak):
         cnt, s3, _ = b3.counts(); dev.append(capi.last_device_ms())
     wall = (time.perf_counter() - t0) / 5
     ach = 16.0 * cells3 / (sum(dev) / len(dev) / 1e3) / 1e9
-    model = recorded("r04_valu_model.json")
-    tr3, tr3src = pmc_traffic("r04_counts_pmc_hbm.json", cells3)
+    tr3, tr3src = pmc_traffic("counts_pmc_hbm.json", cells3, ["protpsw.m0.mat.bwd", "protpsw.m3.roll.fwd"])
     nsym = float(cnt[np.asarray(em1.inTok) != 0].sum()), float(cnt[np.asarray(em1.outTok) != 0].sum())
     out["counts"] = {"workload": "config 3 per GPU: protpsw (8 states, 450 transitions), 1024 pairs x 400 x 400 aa, Backward + Forward/count sweep (MachineCounts)",
                      "value": round(cells3 / wall / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(wall * 1e3, 3),
                      "device_ms": round(sum(dev) / len(dev), 3),
                      "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(ach / hbm_peak, 4),
                                   "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_small_sum_bwd + " + capi.last_kernel_name(), "traffic": tr3, "traffic_source": tr3src,
-                                  "issue": valu_issue(model, ["protpsw.m0.mat.bwd.hip", "protpsw.m3.roll.fwd.hip"], cells3 / (sum(dev) / len(dev) / 1e3))},
+                                  "issue": valu_issue(["protpsw.m0.mat.bwd.hip", "protpsw.m3.roll.fwd.hip"], cells3 / (sum(dev) / len(dev) / 1e3))},
                      "symbol_count_invariant": [nsym[0] / (1024 * 400), nsym[1] / (1024 * 400)], "loglike_sum": float(s3)}
     mfw, tf = timed(lambda: b3.forward(capi.MB_MATERIALISE), 5); devf = capi.last_device_ms()
     out["forward_config3"] = {"workload": "protpsw 1024 x 400 x 400, materialised Forward", "value": round(cells3 / tf / 1e9, 2), "unit": "Gcells/s",
                               "roofline": {"bound": "hbm", "achieved": round(8.0 * cells3 / (devf / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                            "frac": round(8.0 * cells3 / (devf / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name(),
-                                           "traffic": pmc_traffic("r04_forward3_pmc_hbm.json", cells3)[0],
-                                           "issue": valu_issue(model, ["protpsw.m0.mat.fwd.hip"], cells3 / (devf / 1e3))}}
+                                           "traffic": pmc_traffic("forward3_pmc_hbm.json", cells3, ["protpsw.m0.mat.fwd"])[0],
+                                           "issue": valu_issue(["protpsw.m0.mat.fwd.hip"], cells3 / (devf / 1e3))}}
     del b3
 
     # config 2: dnapsw, 1024 x 1 kb x 1 kb: Viterbi with traceback (1 algorithmic byte per cell: the traceback pointer), Forward
     em2 = machine("dnapsw")
+    dump_kernels_as("dnapsw")
     dm2 = capi.DeviceMachine(em2)
     b2 = capi.DeviceBatch(dm2, *synth_batch(2, 1024, 1000, 1000, em2.nInTok, em2.nOutTok))
     cells2 = b2.cells()
@@ -208,6 +284,7 @@ def extra_single_gpu(capi, np, hbm_peak):
     # traceback byte per cell (1 B), `--train`'s E-step keeps no Forward matrix (16 B per lattice cell: the
     # Backward matrix written once and read once)
     em4 = machine("psw2dna")
+    dump_kernels_as("psw2dna")
     dm4 = capi.DeviceMachine(em4)
     nv = 256
     b4 = capi.DeviceBatch(dm4, *synth_batch(4, nv, 487, 10000, em4.nInTok, em4.nOutTok))
@@ -220,8 +297,8 @@ def extra_single_gpu(capi, np, hbm_peak):
                        "roofline": {"bound": "valu", "note": "1 traceback byte per cell (+ boundary records and halo rows: profiles/r03_viterbi4_pmc_hbm.json); the max sweep is bound by vector instruction issue, not by HBM",
                                     "achieved": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                     "frac": round(1.0 * cells4 / (devvf4 / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1, "kernel": kv4,
-                                    "traffic": pmc_traffic("r04_viterbi4_pmc_hbm.json", cells4)[0],
-                                    "issue": valu_issue(model, ["psw2dna.tb.tiles.fwd.exact.hip"], cells4 / (devvf4 / 1e3))}}
+                                    "traffic": pmc_traffic("viterbi4_pmc_hbm.json", cells4, ["psw2dna.tb.tiles.fwd.exact"])[0],
+                                    "issue": valu_issue(["psw2dna.tb.tiles.fwd.exact.hip"], cells4 / (devvf4 / 1e3))}}
     del b4
     nc4 = 63      # three chunks of Backward matrices (21 pairs of 10.6 GB each fit the 80 % budget of a 288 GB GPU)
     b4c = capi.DeviceBatch(dm4, *synth_batch(4, nc4, 487, 10000, em4.nInTok, em4.nOutTok))
@@ -232,8 +309,9 @@ def extra_single_gpu(capi, np, hbm_peak):
                       "value": round(cells4c / tc4 / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(tc4 * 1e3, 2), "device_ms": round(devc4, 2),
                       "roofline": {"bound": "hbm", "achieved": round(ach4, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(ach4 / hbm_peak, 4),
                                    "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_medium_jit (Backward fill) + k_medium_jit (count sweep: closure Forward rounds + flat usage pass)",
-                                   "traffic": pmc_traffic("r04_counts4_pmc_hbm.json", cells4c)[0], "traffic_source": pmc_traffic("r04_counts4_pmc_hbm.json", cells4c)[1],
-                                   "issue": valu_issue(model, ["psw2dna.sum.mat.bwd.clos.hip", "psw2dna.cnt.tiles.fwd.clos.hip"], cells4c / (devc4 / 1e3))},
+                                   "traffic": pmc_traffic("counts4_pmc_hbm.json", cells4c, ["psw2dna.sum.mat.bwd.clos", "psw2dna.cnt.tiles.fwd.clos"])[0],
+                                   "traffic_source": pmc_traffic("counts4_pmc_hbm.json", cells4c, ["psw2dna.sum.mat.bwd.clos", "psw2dna.cnt.tiles.fwd.clos"])[1],
+                                   "issue": valu_issue(["psw2dna.sum.mat.bwd.clos.hip", "psw2dna.cnt.tiles.fwd.clos.hip"], cells4c / (devc4 / 1e3))},
                       "symbol_count_invariant": [float(cnt4[np.asarray(em4.inTok) != 0].sum()) / (nc4 * 487), float(cnt4[np.asarray(em4.outTok) != 0].sum()) / (nc4 * 10000)],
                       "loglike_sum": float(s4)}
     del b4c
@@ -245,6 +323,7 @@ def extra_single_gpu(capi, np, hbm_peak):
         t0 = time.perf_counter()
         em4b = EvaluatedMachine.fromMachine(A4.config4bMachine(os.path.join(ROOT, "tests", "golden", "preset")), None, useDefaults=True)
         tc4b = time.perf_counter() - t0
+        dump_kernels_as("c4b")
         dm4b = capi.DeviceMachine(em4b)
         bb = capi.DeviceBatch(dm4b, *synth_batch(4, 256, 487, 10000, em4b.nInTok, 3))      # DNA over {A,C,G}: no stop codons
         cellsb = bb.cells()
@@ -267,13 +346,14 @@ def extra_single_gpu(capi, np, hbm_peak):
                            "symbol_count_invariant": [float(cntb[np.asarray(em4b.inTok) != 0].sum()) / (24 * 487), float(cntb[np.asarray(em4b.outTok) != 0].sum()) / (24 * 10000)],
                            "roofline": {"bound": "hbm", "achieved": round(8.0 * cellsb / (devfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                         "frac": round(8.0 * cellsb / (devfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 8, "kernel": kfb, "what": "materialised Forward, 256 pairs",
-                                        "traffic": pmc_traffic("r04_forward4b_pmc_hbm.json", cellsb)[0],
-                                        "issue": valu_issue(model, ["c4b.sum.mat.fwd.clos.hip"], cellsb / (devfb / 1e3))},
+                                        "traffic": pmc_traffic("forward4b_pmc_hbm.json", cellsb, ["c4b.sum.mat.fwd.clos"])[0],
+                                        "issue": valu_issue(["c4b.sum.mat.fwd.clos.hip"], cellsb / (devfb / 1e3))},
                            "roofline_viterbi": {"bound": "valu", "achieved": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                                 "frac": round(1.0 * cellsbv / (devvfb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1},
                            "roofline_counts": {"bound": "hbm", "achieved": round(16.0 * cellsbc / (devcb / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                                "frac": round(16.0 * cellsbc / (devcb / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_lattice_cell": 16,
-                                               "note": "3 wavefronts per CU: the ring, one Backward supercell per column and 3095 accumulators leave 6 columns of LDS"}}
+                                               "traffic": pmc_traffic("c4b_counts_pmc_hbm.json", cellsbc, ["c4b.sum.mat.bwd.clos", "c4b.cnt.tiles.fwd.clos"])[0],
+                                               "issue": valu_issue(["c4b.sum.mat.bwd.clos.hip", "c4b.cnt.tiles.fwd.clos.hip"], cellsbc / (devcb / 1e3))}}
         del dm4b
     except Exception as e:
         out["config4b"] = {"error": str(e)}
@@ -288,6 +368,7 @@ def extra_single_gpu(capi, np, hbm_peak):
         h = HmmerModel.fromFile(os.path.join(ROOT, "tests", "golden", "hmmer", "fn3.hmm")).truncated(20)
         em5 = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
         tc = time.perf_counter() - t0
+        dump_kernels_as("config5")
         dm5 = capi.DeviceMachine(em5)
         b5 = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 2000, em5.nInTok, em5.nOutTok))
         cells5 = b5.cells()
@@ -302,9 +383,7 @@ def extra_single_gpu(capi, np, hbm_peak):
                           "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
                           "roofline": {"bound": "valu + barriers", "note": "one workgroup per sequence on 64 of 256 CUs (Forward, cut in two: 128); the retimed sweep (DESIGN.md 4.2b) turns a column's 366 dependent silent levels into a period of 10 barrier-separated rounds with 37 columns in flight; no HBM or MFMA bound applies",
-                                       "issue": {"what": "SQ_INSTS_VALU of the 64 x 50 kb dispatches / (SIMDs of the occupied CUs x cycles at 2.4 GHz) x 2 cycles per wave64 instruction on a SIMD-32, unweighted (fp64 at half rate: about 1.5 x)",
-                                                 "viterbi_fill": round(24209015808 * 2 / (64 * 4 * 0.2505 * 2.4e9), 3), "forward_cut_in_two": round(20143165376 * 2 / (128 * 4 * 0.1738 * 2.4e9), 3),
-                                                 "SQ_WAIT_ANY": [0.423, 0.402], "source": "profiles/r04_onetape_pmc_sq.txt, r04_onetape_kernel_stats.csv (recorded, not re-measured in this run)"}}}
+                                       "issue": onetape_issue()}}
         del b5
         # ... with every CU busy: 256 sequences x 4 kb
         b5w = capi.DeviceBatch(dm5, *synth_batch(5, 256, 0, 4000, em5.nInTok, em5.nOutTok))
@@ -349,6 +428,7 @@ def extra_single_gpu(capi, np, hbm_peak):
         tfit = time.perf_counter() - t0
         allp = dict(m4.funcs); allp.update(params)
         emn = EvaluatedMachine.fromMachine(m4, allp)
+        dump_kernels_as("psw2dna_fitted")
         dmn = capi.DeviceMachine(emn)
         bn = capi.DeviceBatch(dmn, *synth_batch(4, 32, 487, 10000, emn.nInTok, emn.nOutTok))
         cellsn = bn.cells()
@@ -446,6 +526,11 @@ def main():
     from machineboss_amd.shard import shard_range, lpt_assign
 
     capi.set_device(local_rank)
+    global DUMP_DIR
+    if rank == 0 and world == 1:
+        import tempfile
+        DUMP_DIR = tempfile.mkdtemp(prefix="mb_bench_kernels_")
+        dump_kernels_as(args.preset)
     if args.dropin_only:
         print(json.dumps(extra_dropin(capi, np, args.quick)))
         return
@@ -457,6 +542,7 @@ def main():
         # every rank gets `pairs` pairs; rank r takes pairs [r*pairs, (r+1)*pairs) of the global list
         total_pairs = args.pairs * world
         first, count = shard_range(total_pairs, world, rank)
+        mine = list(range(first, first + count))
         inTok, inOff, outTok, outOff = synth_batch(4, count, args.inlen, args.outlen, em.nInTok, em.nOutTok, first=first)
     else:
         # the stated batch (256 pairs) split over the ranks: longest-processing-time-first by DP cell count
@@ -502,9 +588,25 @@ def main():
     extra = {}
     if world > 1:
         # every rank's share and clock: an imbalance (ragged shard, a slow device) shows as one rank's seconds standing out
-        rows = sorted(grp.all_gather_floats([float(rank), float(cells_rank), dt_rank, dev_ms / 1e3]))
+        # ... and its log-likelihood checksum beside the committed per-pair values of the same synthetic pairs (profiles/<tag>_loglike_per_pair.json,
+        # written on one GPU by scripts/loglike_reference.py): a rank that computed on the wrong device, the wrong shard or with a broken
+        # communicator shows here, on first contact with a multi-GPU node
+        ref = recorded(PROFILE_TAG + "_loglike_per_pair.json")
+        ref_ok = bool(ref) and ref.get("preset") == args.preset and ref.get("inlen") == args.inlen and ref.get("outlen") == args.outlen and (max(mine) if mine else 0) < len(ref.get("loglike", []))
+        ref_sum = float(sum(ref["loglike"][k] for k in mine)) if ref_ok else float("nan")
+        rows = sorted(grp.all_gather_floats([float(rank), float(cells_rank), dt_rank, dev_ms / 1e3, float(np.sum(ll)), ref_sum, float(len(mine))]))
         extra["per_rank"] = [{"rank": int(r[0]), "cells_per_step": int(r[1]), "seconds": round(r[2], 4), "device_seconds": round(r[3], 4),
-                              "gcells_per_s": round(r[1] * args.steps / max(r[2], 1e-12) / 1e9, 2)} for r in rows]
+                              "gcells_per_s": round(r[1] * args.steps / max(r[2], 1e-12) / 1e9, 2), "pairs": int(r[6]), "loglike_checksum": r[4],
+                              "loglike_reference": (None if r[5] != r[5] else r[5])} for r in rows]
+        cells_expected = total_pairs * (args.inlen + 1) * (args.outlen + 1) * em.nStates
+        checks = {"n_ranks_seen": len(rows), "ranks_distinct": len({int(r[0]) for r in rows}) == world,
+                  "cells_all_ranks": int(sum(r[1] for r in rows)), "cells_expected": int(cells_expected), "pairs_all_ranks": int(sum(r[6] for r in rows)), "pairs_expected": int(total_pairs),
+                  "loglike_checksum_all_ranks": float(sum(r[4] for r in rows)),
+                  "loglike_reference": ("profiles/%s_loglike_per_pair.json" % PROFILE_TAG) if all(r[5] == r[5] for r in rows) else None,
+                  "loglike_max_rel_dev_from_reference": (max(abs(r[4] - r[5]) / max(abs(r[5]), 1e-300) for r in rows) if all(r[5] == r[5] for r in rows) else None)}
+        checks["ok"] = bool(checks["n_ranks_seen"] == world and checks["ranks_distinct"] and checks["cells_all_ranks"] == checks["cells_expected"] and checks["pairs_all_ranks"] == checks["pairs_expected"]
+                            and all(np.isfinite(r[4]) for r in rows) and (checks["loglike_max_rel_dev_from_reference"] is None or checks["loglike_max_rel_dev_from_reference"] <= 1e-8))
+        extra["checks"] = checks
         slow = max(rows, key=lambda r: r[2])
         extra["slowest_rank"] = {"rank": int(slow[0]), "seconds": round(slow[2], 4), "over_mean": round(slow[2] / (sum(r[2] for r in rows) / world), 4)}
         # what the sharding can deliver, per BASELINE config (pairs are independent units; nothing but --train's counts is exchanged)
@@ -546,7 +648,7 @@ def main():
             extra["rolling_rate"] = {"exp_per_cell": round(ops["exp_per_cell"], 3), "log_per_cell": round(ops["log_per_cell"], 3), "family": ops["family"],
                                      "achieved_transcendental_per_s": round(tr / 1e12, 3), "peak": TRANSCENDENTAL_PEAK_T, "unit": "T v_exp/v_log per s",
                                      "frac": round(tr / 1e12 / TRANSCENDENTAL_PEAK_T, 4),
-                                     "issue": valu_issue(recorded("r04_valu_model.json"), ["psw2dna_strip.sum.roll.fwd.clos.hip"], cells_rank / d1),
+                                     "issue": valu_issue(["psw2dna.sum.roll.fwd.clos.hip"], cells_rank / d1),
                                      "note": "quarter-rate fp32 transcendentals: 157 TFLOP/s fp32 / 2 / 4 (MI355X_MICROARCH.md); the sweep is bound by total vector issue (fp64 add / max at half rate), of which these are a part"}
             extra["rolling_note"] = "boss --loglike mode: no matrix in HBM, bound by vector instruction issue (fp64 add/max, v_exp_f32/v_log_f32), not by HBM; the HBM fraction is not meaningful for it"
 
@@ -620,22 +722,22 @@ def main():
         ach = BYTES_PER_CELL * cells_rank * args.steps / (dev_ms / 1e3) / 1e9 if (dev_ms > 0 and flags == capi.MB_MATERIALISE) else 0.0
         traffic = None
         traffic_src = None
-        for tag in ("r04", "r03", "r02", "r01"):   # HBM bytes per launch from the committed PMC passes (profiles/): a recorded constant, valid for the default workload only
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")))
-                if pmc["kernel"] == kernel and pmc["cells_per_step"] == cells_rank and flags == capi.MB_MATERIALISE:
-                    traffic = round(pmc["hbm_bytes_per_cell"] * cells_rank * args.steps / max(launches, 1))
-                    traffic_src = "profiles/%s_pmc_hbm.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command, not re-measured in this run)" % tag
-                    break
-            except Exception:
-                pass
+        pmc = recorded(PROFILE_TAG + "_pmc_hbm.json")      # HBM bytes per launch from the committed PMC passes: a recorded constant, valid for the default workload and the kernel it was measured on
+        if pmc and pmc.get("kernel") == kernel and pmc.get("cells_per_step") == cells_rank and flags == capi.MB_MATERIALISE:
+            if kernels_unchanged("traffic:headline", ["psw2dna.sum.mat.fwd.clos"]):
+                traffic = round(pmc["hbm_bytes_per_cell"] * cells_rank * args.steps / max(launches, 1))
+                traffic_src = "profiles/%s_pmc_hbm.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command; recorded -- kernel source verified unchanged by hash)" % PROFILE_TAG
+            else:
+                traffic_src = REFUSED.get("traffic:headline")
+        elif flags == capi.MB_MATERIALISE:
+            traffic_src = "no PMC passes recorded for this workload (profiles/%s_pmc_hbm.json)" % PROFILE_TAG
         out = {
             "metric": "Giga DP-cells/sec (Forward) on composed protpsw machine",
             "value": round(value, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4a: %s (%d states, %d transitions), %d pairs%s x %d aa x %d nt, Forward %s, --use-defaults params"
-                                   % (args.preset, em.nStates, em.nTransitions, args.pairs, "/GPU" if args.scaling == "weak" else " in total", args.inlen, args.outlen, args.mode),
+            "config": {"workload": "C4a: %s (%d states, %d transitions), %d pairs%s x %d aa x %d nt, Forward %s, --use-defaults params; inputs resident in HBM when the clock starts (tokens: %.1f MB of H2D per GPU, not timed), log-likelihoods copied back inside the timed region"
+                                   % (args.preset, em.nStates, em.nTransitions, args.pairs, "/GPU" if args.scaling == "weak" else " in total", args.inlen, args.outlen, args.mode, (len(inTok) + len(outTok)) * 4 / 1e6),
                        "parallelism": "pairs sharded over %d GPU(s), no data-path collective" % world,
                        "cells_per_gpu_per_step": int(cells_rank),
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MB_")}},
@@ -646,12 +748,16 @@ def main():
                          "launches_per_step": launches // max(args.steps, 1),
                          "avg_launch_us": round(dev_ms * 1e3 / max(launches, 1), 2),
                          "device_ms_per_step": round(dev_ms / args.steps, 3),
-                         "issue": valu_issue(recorded("r04_valu_model.json"), ["psw2dna.sum.mat.fwd.clos.hip" if flags == capi.MB_MATERIALISE else "psw2dna_strip.sum.roll.fwd.clos.hip"],
+                         "issue": valu_issue(["psw2dna.sum.mat.fwd.clos.hip" if flags == capi.MB_MATERIALISE else "psw2dna.sum.roll.fwd.clos.hip"],
                                              cells_rank * args.steps / max(dev_ms / 1e3, 1e-9)) if args.preset == "psw2dna" else None},
             "cpu_baseline": cpu,
-            "loglike_checksum": float(np.sum(ll)),
+            "loglike_checksum": float(np.sum(ll)),      # this rank's (rank 0); all ranks: extra.checks.loglike_checksum_all_ranks
+            "recorded_constants": {"tag": PROFILE_TAG, "refused": dict(REFUSED), "kernel_sha": kernel_sha_now()},
             "extra": extra,
         }
+        if args.write_kernel_sha:
+            with open(args.write_kernel_sha, "w") as fh:
+                json.dump({"written_by": "python bench.py --write-kernel-sha (the round's profile run)", "kernels": kernel_sha_now()}, fh, indent=1, sort_keys=True)
         # the figures of `extra` that other documents quote, once more at the END of the line (a reader that keeps only the tail of a
         # long line still sees them): mode -> [rate, HBM-roofline fraction or None]
         if extra:
@@ -664,8 +770,15 @@ def main():
                               "config5_50kb_forward_viterbi_withpaths": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill", "viterbi_with_paths")],
                               "unit": "G cells/s (counts: G lattice-cells/s), fraction of 8 TB/s at the mode's algorithmic bytes"}
         print(json.dumps(out))
+        sys.stdout.flush()
+    failed = rank == 0 and world > 1 and not (extra.get("checks") or {}).get("ok", False)
+    if grp and not args.no_extra and world > 1 and rank == 0 and (extra.get("em_iteration") or {}).get("n_ranks_seen") != world:
+        failed = True
     if grp:
         grp.close()
+    if failed:
+        sys.stderr.write("bench.py: the multi-rank consistency checks FAILED (extra.checks / em_iteration.n_ranks_seen): the line above is not a valid measurement\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -324,6 +324,15 @@ static int env_int(const char *name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
+// what the closure chooser minimises (fast_state) and what MB_MEDIUM_JIT_VERBOSE prints (mb_debug_jit_source): candidate slots + the
+// price of a round and of a synchronisation point in slots (MB_MEDIUM_ROUND_COST, default 0; MB_MEDIUM_SYNC_COST, default 1)
+static long long medium_program_cost(const MedProgram &P) {
+  const int syncCost = env_int("MB_MEDIUM_SYNC_COST", 1), roundCost = env_int("MB_MEDIUM_ROUND_COST", 0);
+  long long c = 0;
+  for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + roundCost + (ri.sync ? syncCost : 0);
+  return c;
+}
+
 static FastState *fast_state(mb_machine *m) {
   if (!m->fast) m->fast = new FastState();
   FastState *f = (FastState *)m->fast;
@@ -345,12 +354,7 @@ static FastState *fast_state(mb_machine *m) {
       // (round 4: a synchronisation point is priced at ONE slot, not six -- since the rounds of a stage issue their loads together
       // (mb_medium_jit.cpp) the kernels are bound by vector issue, i.e. by candidates; measured on protpsw.translate.dnapsw: 12 level
       // groups with 54 slots beat 5 with 75, rolling Forward 398 -> 432 G cells/s, psw2dna's choice does not change)
-      const int syncCost = env_int("MB_MEDIUM_SYNC_COST", 1), roundCost = env_int("MB_MEDIUM_ROUND_COST", 0);
-      auto cost = [syncCost, roundCost](const MedProgram &P) {
-        long long c = 0;
-        for (const MedRoundInfo &ri : P.roundInfo) c += (long long)ri.slots.size() + roundCost + (ri.sync ? syncCost : 0);
-        return c;
-      };
+      auto cost = [](const MedProgram &P) { return medium_program_cost(P); };
       // Beyond even level groups: explicit stage boundaries, grown greedily -- the cut that lowers the cost most is added
       // until none does (protpsw.translate.dnapsw, 22 levels: even K = 3 costs 86 slots, cuts at levels 7 and 14 cost 73;
       // psw2dna Backward: 96 -> 80 with one cut at level 2).  Returns K (0 = levelled) and fills `cuts` when cuts win.
@@ -491,17 +495,23 @@ static bool onetape_tiled_viterbi(mb_machine *m) {
 
 // One-tape machines, `--viterbi / --align` with paths: the retimed max sweep keeping ONE traceback code per cell (mb_wide.hip,
 // WideProgram::tbCodes) -- nullptr when the machine has no such program (no retimed form, a fan-in beyond 256, more than 2^15
-// states or 2^16 transitions, a silent self-loop on state 0, MB_ONETAPE_TB=0): the fp64 matrix and its walkers take it then
+// states or 2^16 transitions, a silent transition i -> j with j <= i -- the self-loop on state 0 is the one the reference lets
+// through: a candidate of its traceback but not of the fill --, MB_ONETAPE_TB=0): the fp64 matrix and its walkers take it then.
+// Decided at the first call and AGAIN after every weight update (which edges are -inf decides whether a retimed form exists,
+// see onetape_tiled_viterbi): a failed build is retried then, not latched; a program without a retimed form or without codes is
+// freed at once (its column-by-column twin would never run).
 static WideProgram *wide_tb_program(mb_machine *m) {
   if (g_kernel_choice == 1 || !wide_applicable(m) || !env_int("MB_ONETAPE_TB", 1)) return nullptr;
   FastState *f = fast_state(m);
   WideProgram &P = f->wVitTb;
-  if (!f->wVitTbTried || (P.ok && P.dirty)) {
+  if (!f->wVitTbTried || P.dirty) {
     f->wVitTbTried = true;
+    P.dirty = false;      // (this set of weights has been looked at, whatever comes of it)
     for (long long e = 0; e < m->nTrans; ++e)
-      if (m->inTok[e] == 0 && m->outTok[e] == 0 && m->dst[e] <= m->src[e]) return nullptr;      // (a candidate of the traceback but not of the fill)
+      if (m->inTok[e] == 0 && m->outTok[e] == 0 && m->dst[e] <= m->src[e]) { if (P.ok) wide_free(P); return nullptr; }
     P.tbCodes = true;
-    if (!wide_build(m, false, true, P)) return nullptr;
+    const bool built = wide_build(m, false, true, P);
+    if (!built || !(P.ok && P.retOk && P.tbOk)) { wide_free(P); P.dirty = false; return nullptr; }
   }
   return (P.ok && P.retOk && P.tbOk) ? &P : nullptr;
 }
@@ -755,9 +765,11 @@ static int small_counts(mb_batch *b, double *counts, double *loglikeSum, double 
     if (!hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
     for (long long e = 0; e < nT; ++e) {
       if (g_deterministic) {      // fixed point, 2^-36: the replicas add up as integers
-        long long tot = 0;
-        for (int r = 0; r < SMALL_COUNT_REPLICAS; ++r) { long long u; std::memcpy(&u, &hc[(size_t)r * nT + e], 8); tot += u; }
-        counts[e] += (double)tot / MB_DET_GLOBAL_SCALE;
+        unsigned long long tot = 0; bool inRange = true;
+        for (int r = 0; r < SMALL_COUNT_REPLICAS; ++r) { unsigned long long u; std::memcpy(&u, &hc[(size_t)r * nT + e], 8); inRange = inRange && u < (1ull << 62); tot += u; }
+        double c;
+        if (!det_to_double(tot, c) || !inRange) { set_error("MB_DETERMINISTIC: a posterior count left the fixed-point range (6.7e7 per transition and call): split the batch or use the floating-point mode"); rc = 1; break; }
+        counts[e] += c;
         continue;
       }
       double s = 0.0;
@@ -1467,7 +1479,12 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
     if (nT && !hip_ok(hipMemcpy(hc.data(), d_counts, nT * sizeof(double), hipMemcpyDeviceToHost), "D2H counts")) rc = 1;
     if (!rc && !hip_ok(hipMemcpy(hll.data(), d_ll, b->nPairs * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) rc = 1;
     if (!rc) {
-      if (g_deterministic) for (long long e = 0; e < nT; ++e) { long long u; std::memcpy(&u, &hc[e], 8); hc[e] = (double)u / MB_DET_GLOBAL_SCALE; }   // fixed point, 2^-36
+      if (g_deterministic)
+        for (long long e = 0; e < nT && !rc; ++e) {      // fixed point, 2^-36
+          unsigned long long u; std::memcpy(&u, &hc[e], 8);
+          if (!det_to_double(u, hc[e])) { set_error("MB_DETERMINISTIC: a posterior count left the fixed-point range (6.7e7 per transition and call): split the batch or use the floating-point mode"); rc = 1; }
+        }
+      if (rc) { sm_free(d_counts); sm_free(d_ll); return 1; }
       for (long long e = 0; e < nT; ++e) counts[e] += hc[e];
       double s = 0;
       for (long long p = 0; p < b->nPairs; ++p) { s += hll[p]; if (loglike) loglike[p] = hll[p]; }  // loglike += forward.logLike()
@@ -1558,8 +1575,8 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     if (!medium_build_count_host(&m, G, P, geo, closure)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
   if (getenv("MB_MEDIUM_JIT_VERBOSE")) {
-    long long c = 0; int syncs = 0;
-    for (const MedRoundInfo &ri : P.roundInfo) { c += (long long)ri.slots.size() + (ri.sync ? 6 : 0); syncs += ri.sync; }
+    const long long c = medium_program_cost(P); int syncs = 0;
+    for (const MedRoundInfo &ri : P.roundInfo) syncs += ri.sync;
     fprintf(stderr, "[mbhip] program cost %lld (rounds %zu, syncs %d, pairs %d, levels %d)\n", c, P.roundInfo.size(), syncs, P.nPairs, backward ? m.nLevB : m.nLevF);
   }
   if (dumpProgram) {

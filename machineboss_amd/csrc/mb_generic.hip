@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_generic_counts(DevMachine m, const Pair
           const double c = exp(logOdds + tll);
           if (c != 0.0) {
             double *tab = useLds ? lcount : counts;
-            if (det) atomicAdd((unsigned long long *)tab + m.outEid[a], (unsigned long long)(c * 68719476736.0 + 0.5));
+            if (det) atomicAdd((unsigned long long *)tab + m.outEid[a], (unsigned long long)fmin(fmax(c * 68719476736.0 + 0.5, 0.0), 4611686018427387904.0));
             else atomicAdd(&tab[m.outEid[a]], c);
           }
         }

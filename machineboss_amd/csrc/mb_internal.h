@@ -97,10 +97,14 @@ void set_error(const std::string &msg);
 // additions depends on scheduling (LDS accumulators shared by wavefronts, global accumulators shared by tiles) -- integer addition
 // is associative, so `--counts / --train` reproduce bit for bit from run to run like the reference's serial loop
 // (src/counts.cpp:37-64).  Scales: 2^-44 inside a tile (a tile's partial sum stays below 2^11), 2^-36 in global memory (a count
-// below 1.3e8 per call); lane-private partial sums (registers, fixed shuffle trees) are deterministic as they are.
+// below 6.7e7 per call; beyond it the call fails, det_to_double); lane-private partial sums (registers, fixed shuffle trees) are deterministic as they are.
 extern bool g_deterministic;
 constexpr double MB_DET_TILE_SCALE = 17592186044416.0;   // 2^44
 constexpr double MB_DET_GLOBAL_SCALE = 68719476736.0;     // 2^36
+// A global fixed-point accumulator as a count.  The device clamps every term to [0, 2^62] before its cast (a NaN, a negative or a
+// huge value saturates), so an accumulator that reaches 2^62 -- a count beyond 6.7e7, or a saturated term -- says "out of range":
+// the call then FAILS instead of returning wrapped garbage with rc = 0.
+inline bool det_to_double(unsigned long long u, double &out) { out = (double)u / MB_DET_GLOBAL_SCALE; return u < (1ull << 62); }
 bool hip_ok(hipError_t e, const char *what);
 extern hipStream_t g_stream;
 extern thread_local long long g_last_launches;   // kernel launches of the dominant kernel in the last batch call

@@ -12,6 +12,7 @@
 // a step waits (through the in-order vmcnt counter of gfx9) for the previous step's global stores to be acknowledged.
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <sstream>
 #include <string>
@@ -31,6 +32,17 @@ static const int JIT_MAX_CANDS = std::max(2, env_int_early("MB_JIT_MAXCANDS", 12
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
+}
+// MB_JIT_DEBUG (kernels with switched-off loads: WRONG results by design) exists only in a library built with
+// -DMB_EXPERIMENTS; a product build ignores the variable, so a stray environment cannot corrupt counts or likelihoods
+static int jit_debug_bits() {
+#ifdef MB_EXPERIMENTS
+  const int v = env_int("MB_JIT_DEBUG", 0);
+  if (v & 3) { static bool told = false; if (!told) { told = true; fprintf(stderr, "[mbhip] WARNING: MB_JIT_DEBUG=%d -- tile kernels skip loads, results are WRONG by design\n", v); } }
+  return v;
+#else
+  return 0;
+#endif
 }
 
 static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) {   // rounded up to 16 bytes: the record image follows
@@ -164,7 +176,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JNBSYNC " << ((env_int("MB_JIT_NEIGHBOUR_SYNC", mode == MED_MODE_COUNT ? 0 : 1) && matKind == MED_MAT_ROLL && P.haloStates.size() <= 64 && geo.waves > 1 && geo.waves <= 16) ? 1 : 0)
        << "\n#define JFLAGOFF " << lds_payload_bytes(P, geo, mode)
        << "\n#define JBDIST " << (env_int("MB_JIT_B_DISTANCE", 1) == 2 ? 2 : 1)      // count sweep: steps the Backward supercells are fetched ahead (2: measured 218 vs 221 G lattice-cells/s -- the loads cost issue and LDS writes, not exposed latency)
-       << "\n#define JDBG " << env_int("MB_JIT_DEBUG", 0)      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
+       << "\n#define JDBG " << jit_debug_bits()      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
        << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
@@ -397,7 +409,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
     // kernel at every budget -- and cost nothing.
     long long spills = medium_jit_spill_count(code);
     if (jit_kernel_meta(code, ".private_segment_fixed_size") == 0) spills = 0;
-    if (attempt == 0 && (env_int("MB_JIT_DEBUG", 0) & 4)) spills = 3;      // experiments: force one re-plan
+    if (attempt == 0 && (jit_debug_bits() & 4)) spills = 3;      // experiments: force one re-plan
     if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs (scratch %lld bytes)\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : (mode == MED_MODE_TB ? "max+tb" : "sum")), P.regBudget, spills, jit_kernel_meta(code, ".private_segment_fixed_size"));
     // (the LAST attempt keeps what it compiled: re-planning behind it would leave the placement -- the LDS image, the record tables
     // the host refreshes -- one step ahead of the code; round 4 found exactly that, counts of 1e19, when a kernel never stopped spilling)

@@ -83,7 +83,9 @@ __device__ __forceinline__ float ex2(double d) { return __builtin_amdgcn_exp2f((
 // deterministic mode (jdet = MedTileArgs::det in scope): the LDS accumulators hold 64-bit fixed point at 2^-44 -- integer adds commute
 #define cnt_flush(l, o, a) cnt_flush_(l, o, a, jdet)
 __device__ __forceinline__ void cnt_flush_(const char *ldsb, unsigned off, float acc, int jdet) {
-  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)(ldsb + off), (unsigned long long)((double)acc * 17592186044416.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (clamped to [0, 2^62] before the cast: a NaN, a negative or a huge term saturates instead of being undefined behaviour, and the host
+  //  reads an accumulator >= 2^62 as "overflowed" -- ADVICE r4)
+  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)(ldsb + off), (unsigned long long)__builtin_fmin(__builtin_fmax((double)acc * 17592186044416.0, 0.0), 4611686018427387904.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else (void)__hip_atomic_fetch_add((double *)(ldsb + off), (double)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 #define cnt_add(l, o, x) cnt_flush_(l, o, ex2(x), jdet)
@@ -557,7 +559,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   for (int e = tid; e < JNTRANS; e += NT) {
     if (jdet) {      // 2^-44 in the tile -> 2^-36 in global memory, rounded
       const unsigned long long u = ((const unsigned long long *)accL)[e];
-      if (u) (void)__hip_atomic_fetch_add((unsigned long long *)A.counts + e, (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u) (void)__hip_atomic_fetch_add((unsigned long long *)A.counts + e, u >= (1ull << 62) ? (1ull << 62) : (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a saturated tile stays saturated
       continue;
     }
     const double x = accL[e];

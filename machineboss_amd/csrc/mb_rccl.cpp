@@ -8,8 +8,13 @@
 // and calls mb_comm_init everywhere; a Python host uses torch.distributed instead (machineboss_amd/shard.py).
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "mb_internal.h"
 
@@ -81,14 +86,40 @@ int mb_comm_unique_id(char id[128]) {
   return 0;
 }
 
+// ncclCommInitRank returns when ALL nRanks ranks have called it; a rank that never arrives (it crashed before this point, it
+// was handed another id, its device is gone) would leave the others waiting for ever.  The wait is therefore BOUNDED
+// (MB_COMM_TIMEOUT_S, default 180 s): the bootstrap runs on a helper thread bound to this thread's device; if it has not come
+// back in time this call fails with a message naming the rank, and the host is expected to print mb_last_error() and EXIT with
+// a non-zero code -- never to re-exec or retry in a process that has touched the GPU (bench.py, boss.py and shard.RankGroup do
+// exactly that; the helper thread is abandoned with the process).
 mb_comm *mb_comm_init(const char id[128], int nRanks, int rank) {
   if (!id || nRanks < 1 || rank < 0 || rank >= nRanks) { mb::set_error("mb_comm_init: bad argument"); return nullptr; }
   if (!rccl_load()) return nullptr;
   UniqueId u;
   std::memcpy(u.internal, id, 128);
-  void *comm = nullptr;
-  if (!rccl_ok(g_rccl.commInitRank(&comm, nRanks, u, rank), "ncclCommInitRank")) return nullptr;
-  return (mb_comm *)comm;
+  int dev = 0;
+  if (!mb::hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+  const char *ts = getenv("MB_COMM_TIMEOUT_S");
+  const double timeout = (ts && *ts) ? atof(ts) : 180.0;
+  struct Result { void *comm = nullptr; int rc = 0; bool deviceOk = true; };
+  auto prom = std::make_shared<std::promise<Result>>();      // shared: the helper may outlive this call
+  std::future<Result> fut = prom->get_future();
+  const CommInitRankFn initFn = g_rccl.commInitRank;
+  std::thread([prom, initFn, u, nRanks, rank, dev]() {
+    Result r;
+    r.deviceOk = hipSetDevice(dev) == hipSuccess;      // the device binding is per thread
+    if (r.deviceOk) r.rc = initFn(&r.comm, nRanks, u, rank);
+    prom->set_value(r);
+  }).detach();
+  if (timeout > 0 && fut.wait_for(std::chrono::duration<double>(timeout)) != std::future_status::ready) {
+    mb::set_error("mb_comm_init: rank " + std::to_string(rank) + " of " + std::to_string(nRanks) + " (device " + std::to_string(dev) + "): the RCCL communicator was not formed within " +
+                  std::to_string((int)timeout) + " s -- not every rank reached ncclCommInitRank with this id (MB_COMM_TIMEOUT_S); exit, do not retry in this process");
+    return nullptr;
+  }
+  const Result r = fut.get();
+  if (!r.deviceOk) { mb::set_error("mb_comm_init: rank " + std::to_string(rank) + ": hipSetDevice(" + std::to_string(dev) + ") failed on the bootstrap thread"); return nullptr; }
+  if (!rccl_ok(r.rc, ("ncclCommInitRank (rank " + std::to_string(rank) + " of " + std::to_string(nRanks) + ", device " + std::to_string(dev) + ")").c_str())) return nullptr;
+  return (mb_comm *)r.comm;
 }
 
 void mb_comm_destroy(mb_comm *comm) {

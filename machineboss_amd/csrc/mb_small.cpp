@@ -260,7 +260,7 @@ __device__ __forceinline__ void lds_add_f32(float *p, float x) {
 // g_deterministic) -- 64-bit fixed point at 2^-44, whose additions commute
 #define lds_add_f64(p, x) lds_add_f64_(p, x, jdet)
 __device__ __forceinline__ void lds_add_f64_(double *p, double x, int jdet) {
-  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)(x * 17592186044416.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (jdet) (void)__hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)__builtin_fmin(__builtin_fmax(x * 17592186044416.0, 0.0), 4611686018427387904.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -404,7 +404,7 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     for (int e = tid; e < JNTRANS; e += 256) {
       if (jdet) {      // 2^-44 in the workgroup -> 2^-36 in global memory, rounded
         const unsigned long long u = ((const unsigned long long *)accT)[e];
-        if (u) (void)__hip_atomic_fetch_add((unsigned long long *)rep + e, (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (u) (void)__hip_atomic_fetch_add((unsigned long long *)rep + e, u >= (1ull << 62) ? (1ull << 62) : (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a saturated table entry stays saturated
         continue;
       }
       const double x = accT[e];

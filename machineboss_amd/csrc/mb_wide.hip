@@ -1835,7 +1835,7 @@ int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, co
 struct OtEdge { uint32_t src, pos; };
 // one atomic per (transition, sequence part): fp64, or 64-bit fixed point at 2^-36 (deterministic mode, mb_internal.h)
 __device__ __forceinline__ void count_add(double *counts, uint32_t e, double x, int det) {
-  if (det) atomicAdd((unsigned long long *)counts + e, (unsigned long long)(x * 68719476736.0 + 0.5));
+  if (det) atomicAdd((unsigned long long *)counts + e, (unsigned long long)fmin(fmax(x * 68719476736.0 + 0.5, 0.0), 4611686018427387904.0));      // saturates (NaN -> 0): the host reads >= 2^62 as overflow
   else atomicAdd(&counts[e], x);
 }          // pos: position in the outgoing view (weight, destination, edge id); ~0u = padding
 

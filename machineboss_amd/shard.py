@@ -7,6 +7,7 @@ nTransitions posterior counts + 1 log-likelihood per EM iteration (MachineCounts
 from __future__ import annotations
 
 import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -81,6 +82,8 @@ class RankGroup:
         backend = backend or os.environ.get("MB_DIST_BACKEND") or ("rccl" if have_gpu else "gloo")
         if share_device:
             local = 0
+        elif have_gpu and backend == "gloo" and local >= capi.device_count():
+            local %= capi.device_count()      # all-host collectives: several ranks may share a GPU (a one-GPU box under torchrun --nproc-per-node 2)
         if have_gpu:
             capi.set_device(local)
         import torch.distributed as dist
@@ -101,7 +104,14 @@ class RankGroup:
                 ident = torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8).clone()
             if world > 1:
                 dist.broadcast(ident, src=0)
-            grp.comm = capi.Comm(bytes(ident.numpy().tobytes()), world, rank)
+            try:
+                grp.comm = capi.Comm(bytes(ident.numpy().tobytes()), world, rank)      # bounded wait inside (mb_comm_init, MB_COMM_TIMEOUT_S)
+            except Exception as e:
+                # first contact gone wrong: say which rank and LEAVE -- the launcher (torch.distributed.run / bench.py's parent) reports the
+                # failing rank and ends the others; a process that has touched the GPU is never re-exec'd or retried
+                sys.stderr.write("[machineboss_amd] rank %d of %d (local rank %d): RCCL bootstrap failed: %s\n" % (rank, world, local, e))
+                sys.stderr.flush()
+                os._exit(17)
         return grp
 
     # ---- the data-path collective -----------------------------------------------------------------------------------------

@@ -1631,6 +1631,39 @@ def test_rccl_allreduce_entry_points(capi):
     assert p.returncode == 0, p.stderr[-2000:]
 
 
+_COMM_LONE = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from machineboss_amd import capi
+capi.set_device(0)
+uid = capi.Comm.unique_id()
+t0 = time.time()
+try:
+    capi.Comm(uid, 2, 0)              # rank 1 never comes
+    print("FORMED")
+except Exception as e:
+    print("ERROR %.1f %s" % (time.time() - t0, e))
+sys.stdout.flush()
+os._exit(0)                           # the abandoned bootstrap thread goes with the process
+"""
+
+
+@pytest.mark.gpu
+def test_comm_init_gives_up_when_a_rank_never_arrives(capi):
+    """First-contact hardening: mb_comm_init waits a BOUNDED time (MB_COMM_TIMEOUT_S) for the other ranks.
+    One process asks for a two-rank communicator and nobody else ever calls in: the call must come back with an error that names
+    the rank instead of hanging the job (shard.RankGroup then prints it and exits non-zero; nothing is retried in a process that has
+    touched the GPU)."""
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MB_COMM_TIMEOUT_S="4")
+    p = subprocess.run([sys.executable, "-c", _COMM_LONE, ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith(("ERROR", "FORMED"))][-1]
+    assert line.startswith("ERROR") and "rank 0 of 2" in line and "not formed within 4 s" in line, line
+    assert 3.0 <= float(line.split()[1]) <= 60.0
+
+
 _COMM_RANK = r"""
 import os, sys, time
 import numpy as np
@@ -1792,6 +1825,17 @@ def test_bench_two_ranks_dry_run(capi, scaling):
     assert abs(d["value"] - pairs_total * 488 * 701 * 271 / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-3 * d["value"]
     em = d["extra"]["em_iteration"]
     assert em["n_ranks_seen"] == 2 and abs(em["symbol_count_invariant"] - 1.0) < 1e-4
+    # first-contact assertions of the N > 1 line, here over gloo on the one GPU: every rank seen once, the shards
+    # add up to the batch, and the gathered log-likelihood checksum is the single-process one of the same synthetic pairs
+    ck = d["extra"]["checks"]
+    assert ck["ok"] and ck["n_ranks_seen"] == 2 and ck["ranks_distinct"] and ck["cells_all_ranks"] == ck["cells_expected"] == pairs_total * 488 * 701 * 271
+    assert ck["pairs_all_ranks"] == ck["pairs_expected"] == pairs_total
+    assert sorted(r["rank"] for r in d["extra"]["per_rank"]) == [0, 1] and sum(r["pairs"] for r in d["extra"]["per_rank"]) == pairs_total
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    emm = EvaluatedMachine.fromMachine(Machine.fromFile(golden_path("preset", "psw2dna.json")), None, useDefaults=True)
+    single = capi.DeviceBatch(capi.DeviceMachine(emm), *synth_batch(4, pairs_total, 487, 700, emm.nInTok, emm.nOutTok)).forward(capi.MB_MATERIALISE)
+    assert abs(ck["loglike_checksum_all_ranks"] - float(np.sum(single))) <= 1e-9 * abs(float(np.sum(single)))
 
 
 def _bench_json(args, env_extra, timeout=900):
@@ -1831,6 +1875,17 @@ def test_bench_two_ranks_over_rccl(capi, backend):
     assert sum(r["cells_per_step"] for r in d["extra"]["per_rank"]) == 12 * 488 * 701 * 271
     em = d["extra"]["em_iteration"]
     assert em["n_ranks_seen"] == 2 and abs(em["symbol_count_invariant"] - 1.0) < 1e-4
+    # first-contact assertions of the N > 1 line, here over gloo on the one GPU: every rank seen once, the shards
+    # add up to the batch, and the gathered log-likelihood checksum is the single-process one of the same synthetic pairs
+    ck = d["extra"]["checks"]
+    assert ck["ok"] and ck["n_ranks_seen"] == 2 and ck["ranks_distinct"] and ck["cells_all_ranks"] == ck["cells_expected"] == pairs_total * 488 * 701 * 271
+    assert ck["pairs_all_ranks"] == ck["pairs_expected"] == pairs_total
+    assert sorted(r["rank"] for r in d["extra"]["per_rank"]) == [0, 1] and sum(r["pairs"] for r in d["extra"]["per_rank"]) == pairs_total
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    emm = EvaluatedMachine.fromMachine(Machine.fromFile(golden_path("preset", "psw2dna.json")), None, useDefaults=True)
+    single = capi.DeviceBatch(capi.DeviceMachine(emm), *synth_batch(4, pairs_total, 487, 700, emm.nInTok, emm.nOutTok)).forward(capi.MB_MATERIALISE)
+    assert abs(ck["loglike_checksum_all_ranks"] - float(np.sum(single))) <= 1e-9 * abs(float(np.sum(single)))
 
 
 @pytest.mark.parametrize("family", ["small", "tiled", "onetape", "generic"])
