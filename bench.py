@@ -407,6 +407,15 @@ def extra_single_gpu(capi, np, hbm_peak):
                                        "forward_rolling": round(cells5f / t5f / 1e9, 2), "forward_ms": round(t5f * 1e3, 1), "viterbi_fill": round(cells5f / t5vf / 1e9, 2),
                                        "viterbi_ms": round(t5vf * 1e3, 1), "unit": "Gcells/s", "kernels": [k5f, k5vf], "loglike_sum": float(np.sum(ll5f)),
                                        "viterbi_le_forward": bool(np.all(v5f <= ll5f + 1e-6 * np.abs(ll5f)))})
+        # ... and the E-step at that size (two fp64 matrices of 130 GB each: the library cuts the batch into chunks that fit; fills with the fp64
+        # correction term, sequences being >= 10 000 symbols)
+        try:
+            (cnt5f, s5cf, _), t5cf = timed(lambda: b5f.counts(), 1)
+            out["config5"]["full_size"].update({"counts_lattice": round(cells5f / t5cf / 1e9, 2), "counts_ms": round(t5cf * 1e3, 1), "counts_device_ms": round(capi.last_device_ms(), 1),
+                                                "counts_kernel": capi.last_kernel_name(), "counts_symbol_invariant": float(cnt5f[np.asarray(em5.outTok) != 0].sum()) / (64 * 50000),
+                                                "counts_note": "Forward + Backward fills (k_wide_retimed, fp64 log-sum-exp correction term: sequences >= 10 000 symbols) + k_onetape_counts, G lattice-cells/s"})
+        except Exception as e:
+            out["config5"]["full_size"]["counts_error"] = str(e)
         del b5f, e5p
     except Exception as e:   # the extras never take the headline down
         out["config5"] = {"error": str(e)}

@@ -1407,6 +1407,14 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
       // sequences than CUs leaves most of the chip idle, so the two run side by side on two streams (64 sequences: 64 + 64
       // CUs); the count kernel waits for both.
       bool fwdDone = false;
+      // One-tape E-step over LONG sequences: the fills carry their log-sum-exp correction term in fp64 (mb_wide.hip, wide_exp64): the
+      // fp32 term's per-column error repeats in stationary states and grows linearly with the length (7.6e-5 per transition at 50 000
+      // columns).  MB_ONETAPE_COUNT_FP64: 1 always, 0 never, default: sequences of >= MB_ONETAPE_COUNT_FP64_MIN_LEN (10 000) symbols.
+      struct AccurateFills { bool on; explicit AccurateFills(bool o) : on(o) { if (on) wide_set_accurate(true); } ~AccurateFills() { if (on) wide_set_accurate(false); } };
+      int longest = 0;
+      for (const PairDesc &pd : hp) longest = std::max(longest, std::max(pd.inLen, pd.outLen));
+      const int accMode = env_int("MB_ONETAPE_COUNT_FP64", -1);
+      const AccurateFills accurateFills(wide_applicable(b->m) && (accMode == 1 || (accMode != 0 && longest >= env_int("MB_ONETAPE_COUNT_FP64_MIN_LEN", 10000))));
       if (!roll && !b->hasEnv && wide_applicable(b->m) && g_kernel_choice != 1 && env_int("MB_ONETAPE_CONCURRENT_FILLS", 1)) {
         WideProgram *WB = wide_program(b->m, MB_BACKWARD), *WF = wide_program(b->m, MB_FORWARD);
         hipStream_t s2 = second_stream();

@@ -163,6 +163,7 @@ bool wide_applicable(const mb_machine *m);
 // (re)build the program of one direction/semiring from the machine's current weights and upload it
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P);
 void wide_free(WideProgram &P);
+void wide_set_accurate(bool on);      // the next retimed sum fills carry their log-sum-exp correction term in fp64 (E-step of long sequences)
 // the retimed program of a machine, planned and linearised on the host only (no device): P.ret / P.retGv / P.retPeriod + the record stream
 bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes = false);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather

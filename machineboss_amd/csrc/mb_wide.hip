@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <type_traits>
 
 #include "mb_wide.h"
 #include "mb_device_math.h"
@@ -50,10 +51,16 @@ __device__ __forceinline__ double wide_max_raw(double a, double b) {
 }
 // one candidate folded into a lane's running (max, sum of exp relative to max): exactly one of the two exponentials of
 // the usual online update is exp(0), so a single v_exp_f32 of -|v - m| serves both cases
+// exp(x) of an fp64 difference x <= 0 through v_exp_f32: the multiplication by log2(e) is done in fp64, BEFORE the conversion.  __expf
+// multiplies in fp32 by a log2(e) that is 1.3e-8 too small, i.e. returns exp(x (1 - 1.3e-8)): a relative BIAS of 1.3e-8 |x| on every
+// non-dominant term of a log-sum-exp.  A bias does not average out -- it accumulates at a rate that differs between states (a
+// chain of self-loop dominated states gathers less of it than the match states beside it): at 50 000 columns the posterior counts
+// of whole groups of transitions sat 7.6e-5 from the exact oracle (round 5, scripts/count_accuracy_onetape.py).
+__device__ __forceinline__ float wide_exp_diff(double x) { return __builtin_amdgcn_exp2f((float)(x * 1.4426950408889634)); }
 template <int MODE>
 __device__ __forceinline__ void wide_fold(double &m, float &s, double v, float sv) {
   if (MODE == MB_VITERBI) { m = dmax(m, v); return; }
-  const float e = __expf(-fabsf((float)(v - m)));
+  const float e = wide_exp_diff(-fabs(v - m));
   const bool up = v > m;
   s = __fmaf_rn(up ? s : sv, e, up ? sv : s);
   m = wide_max_raw(m, v);      // (fmax() costs two more v_max_f64 per fold: half of the maxima of the Forward sweep's ISA were x = max(x, x))
@@ -93,7 +100,7 @@ __device__ __forceinline__ void wide_group_reduce(double &m, float &s, int g, in
   if (gWave > 16) wide_max_step<MODE, 16>(m, g);
   if (gWave > 32) wide_max_step<MODE, 32>(m, g);
   if (MODE == MB_VITERBI) return;
-  s *= __expf((float)(own - m));                    // own <= m; an empty lane (own = W_NEG_BIG, s = 0) stays 0
+  s *= wide_exp_diff(own - m);                      // own <= m; an empty lane (own = W_NEG_BIG, s = 0) stays 0
   if (gWave > 1) wide_sum_step<1>(s, g);
   if (gWave > 2) wide_sum_step<2>(s, g);
   if (gWave > 4) wide_sum_step<4>(s, g);
@@ -292,7 +299,7 @@ __device__ __forceinline__ void wide_group_reduce_all(double &m, float &s, int g
   if (gWave > 16) wide_max_all<MODE, 16>(m);
   if (gWave > 32) wide_max_all<MODE, 32>(m);
   if (MODE == MB_VITERBI) return;
-  s *= __expf((float)(own - m));
+  s *= wide_exp_diff(own - m);
   wide_sum_all<1>(s);
   if (gWave > 2) wide_sum_all<2>(s);
   if (gWave > 4) wide_sum_all<4>(s);
@@ -305,6 +312,76 @@ __device__ __forceinline__ void wide_group_reduce_all(double &m, float &s, int g
 typedef __attribute__((address_space(3))) double wide_lds_f64;
 __device__ __forceinline__ double wide_lds_read(unsigned a) { return *(const wide_lds_f64 *)(uintptr_t)a; }
 __device__ __forceinline__ void wide_lds_write(unsigned a, double v) { *(wide_lds_f64 *)(uintptr_t)a = v; }
+
+// ---- the log-sum-exp correction term in fp64 (ACC variants of the retimed sum sweep: the fills of a one-tape E-step over long
+// sequences).  With v_exp_f32 / v_log_f32 a state's per-column error is ~6e-8 -- and NOT random: a state that sits in a stationary
+// regime (an intron's self-loop chain, the flanking states) sees nearly the same arguments column after column, so the same
+// rounding repeats and the error grows LINEARLY, at a rate that differs between groups of states; the per-column normaliser of the
+// count kernel removes only what a column's states share.  Measured at 50 000 columns under --use-defaults parameters: 7.6e-5 per
+// transition against the exact oracle, whole groups of transitions sitting at that value (round 5).
+// exp(x), x <= 0: 2^(k/64) from a 64-entry table in LDS times a degree-4 polynomial of the remainder (|r| <= ln 2 / 128: 4e-14).
+__device__ __forceinline__ double wide_exp64(double x, unsigned tab) {
+  x = wide_max_raw(x, -740.0);                                        // (-inf and the -1e300 stand-in: ~0)
+  const double kf = __builtin_rint(x * 92.33248261689366);           // 64 / ln 2
+  const double r = __builtin_fma(kf, -0.010830424696249145, x);      // x - k ln 2 / 64
+  const int k = (int)kf;
+  const double p = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(r, 0.041666666666666664, 0.16666666666666666), r, 0.5), r, 1.0), r, 1.0);
+  return __builtin_ldexp(wide_lds_read(tab + ((unsigned)(k & 63) << 3)) * p, k >> 6);
+}
+// log(s), s >= 1: v_log_f32 as the seed, one Newton step through the exponential above (second order kept)
+__device__ __forceinline__ double wide_log64(double s, unsigned tab) {
+  const double t0 = (double)__log2f((float)s) * 0.6931471805599453;
+  const double d = __builtin_fma(s, wide_exp64(-t0, tab), -1.0);
+  return t0 + __builtin_fma(-0.5 * d, d, d);
+}
+template <int MODE>
+__device__ __forceinline__ void wide_fold(double &m, double &s, double v, double sv, unsigned tab) {
+  const double e = wide_exp64(-fabs(v - m), tab);
+  const bool up = v > m;
+  s = __builtin_fma(up ? s : sv, e, up ? sv : s);
+  m = wide_max_raw(m, v);
+}
+template <int H>
+__device__ __forceinline__ void wide_sum_step(double &s, int g) {
+  const double so = __hiloint2double(wide_xor_lane<H>(__double2hiint(s)), wide_xor_lane<H>(__double2loint(s)));
+  if (H < g) s += so;
+}
+template <int H>
+__device__ __forceinline__ void wide_sum_all(double &s) { s += __hiloint2double(wide_xor_lane<H>(__double2hiint(s)), wide_xor_lane<H>(__double2loint(s))); }
+template <int MODE>
+__device__ __forceinline__ void wide_group_reduce(double &m, double &s, int g, int gWave, unsigned tab) {
+  const double own = m;
+  if (gWave > 1) wide_max_step<MODE, 1>(m, g);
+  if (gWave > 2) wide_max_step<MODE, 2>(m, g);
+  if (gWave > 4) wide_max_step<MODE, 4>(m, g);
+  if (gWave > 8) wide_max_step<MODE, 8>(m, g);
+  if (gWave > 16) wide_max_step<MODE, 16>(m, g);
+  if (gWave > 32) wide_max_step<MODE, 32>(m, g);
+  s *= wide_exp64(own - m, tab);
+  if (gWave > 1) wide_sum_step<1>(s, g);
+  if (gWave > 2) wide_sum_step<2>(s, g);
+  if (gWave > 4) wide_sum_step<4>(s, g);
+  if (gWave > 8) wide_sum_step<8>(s, g);
+  if (gWave > 16) wide_sum_step<16>(s, g);
+  if (gWave > 32) wide_sum_step<32>(s, g);
+}
+template <int MODE>
+__device__ __forceinline__ void wide_group_reduce_all(double &m, double &s, int gWave, unsigned tab) {
+  const double own = m;
+  wide_max_all<MODE, 1>(m);
+  if (gWave > 2) wide_max_all<MODE, 2>(m);
+  if (gWave > 4) wide_max_all<MODE, 4>(m);
+  if (gWave > 8) wide_max_all<MODE, 8>(m);
+  if (gWave > 16) wide_max_all<MODE, 16>(m);
+  if (gWave > 32) wide_max_all<MODE, 32>(m);
+  s *= wide_exp64(own - m, tab);
+  wide_sum_all<1>(s);
+  if (gWave > 2) wide_sum_all<2>(s);
+  if (gWave > 4) wide_sum_all<4>(s);
+  if (gWave > 8) wide_sum_all<8>(s);
+  if (gWave > 16) wide_sum_all<16>(s);
+  if (gWave > 32) wide_sum_all<32>(s);
+}
 
 // GV: the ring lives in an L2-resident scratch vector of the workgroup (machines whose ring exceeds the LDS: the whole fn3
 // profile composite, 21 761 states); penalties and the token window stay in LDS.  Records then carry ring ENTRIES (src >> 13).
@@ -342,7 +419,9 @@ __device__ __forceinline__ void wide_group_reduce_tb(double &m, uint32_t &key, i
 
 // TB (max sweep only): `pool` holds one traceback CODE per cell (bytes, wide_tb_stride(S) per column, PairDesc::cellBase = byte
 // offset) instead of the fp64 cell -- the place of the cell's first maximal candidate in its node's list (WideProgram::tbCodes)
-template <int MODE, bool GV, bool TB = false>
+// ACC (sum sweep only): the log-sum-exp correction term in fp64 (wide_exp64 / wide_log64 above) instead of v_exp_f32 / v_log_f32; the
+// 64-entry table of 2^(j/64) sits in the last 512 bytes of the launch's LDS
+template <int MODE, bool GV, bool TB = false, bool ACC = false>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
   extern __shared__ double wlds[];
@@ -356,6 +435,9 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   double *V = GV ? scratch + (size_t)bid * (size_t)nVec : wlds;
   double *pen = GV ? wlds : wlds + nVec;             // [2][nPen]: this period's penalties and the next one's
   int *tokWin = (int *)(pen + 2 * nPen);             // token of column c in entry c & 63, written two periods ahead
+  const unsigned expTab = (unsigned)(((GV ? 0u : (unsigned)nVec * 8u) + 2u * (unsigned)nPen * 8u + (unsigned)WIDE_RET_TOKWIN * 4u + 7u) & ~7u);      // ACC: 2^(j/64), j = 0..63
+  if (ACC && tid < 64) wide_lds_write(expTab + (unsigned)tid * 8u, exp2((double)tid * 0.015625));
+  (void)expTab;
   for (int k = tid; k < nVec; k += W) V[k] = -INFINITY;
   if (tid < WIDE_RET_TOKWIN) tokWin[tid] = 0;
   __syncthreads();
@@ -395,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   const int nPer = L + 1 + Q.kMax;
   unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
-  float s = 0.0f;
+  typename std::conditional<ACC, double, float>::type s = 0;
   const bool storeAll = cells && !P.lastOnly, storeLast = cells && P.lastOnly;
   // a node's lag comes as kq = kMax - ktau (ktau for a backward sweep): its column is cBase + cSign * kq, its matrix row starts
   // kq * rowS doubles behind rowPtr
@@ -432,6 +514,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
         const double cand = vNow + (rc.w + pNow);              // w + 0.0 = w, w + -inf = -inf: the reference's one rounded add, or -inf
         if (TB) { bestSlot = cand > m ? (uint32_t)slotInRound : bestSlot; ++slotInRound; }      // strict >: the first maximum
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
+        else if constexpr (ACC) wide_fold<MODE>(m, s, cand, 1.0, expTab);
         else wide_fold<MODE>(m, s, cand, 1.0f);
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.pad);
         if (flags & 0x80000000u) {
@@ -445,20 +528,28 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             bestSlot = 0u; slotInRound = 0;
           } else
           if (gWave > 1) {
-            if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
-            else wide_group_reduce_all<MODE>(m, s, gWave);
+            if constexpr (ACC) {
+              if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave, expTab);
+              else wide_group_reduce_all<MODE>(m, s, gWave, expTab);
+            } else {
+              if (flags & 0x20000000u) wide_group_reduce<MODE>(m, s, 1 << ((dst >> 26) & 7), gWave);
+              else wide_group_reduce_all<MODE>(m, s, gWave);
+            }
           }
           const uint32_t x = dst & WIDE_RET_NO_DST, kq = (dst >> 20) & 63u;      // entry within its vector: the state (relays: >= S + 2)
           const int c = cSign < 0 ? cBase - (int)kq : cBase + (int)kq;
           if (x != WIDE_RET_NO_DST && (unsigned)c <= (unsigned)L) {      // (lanes without a node carry x = all ones)
-            const double res = (MODE == MB_VITERBI) ? m : (s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY);      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
+            double res;
+            if (MODE == MB_VITERBI) res = m;
+            else if constexpr (ACC) res = s >= 0.5 ? m + (s == 1.0 ? 0.0 : wide_log64(s, expTab)) : -INFINITY;      // (a lone candidate: exact, as on the fp32 route)
+            else res = s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY;      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
             if (TB) { if (codes && x < (unsigned)S) codeRow[__umul24(kq, (unsigned)Sb) + x] = (unsigned char)key; }      // (traceback codes: forward sweeps only, cSign = 1)
             else if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
           }
           m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
-          s = 0.0f;
+          s = 0;
           if (flags & 0x40000000u) {
             __syncthreads();
             // both look-ups of the next slot again: its ring value may be stale, and so may its penalty -- the next period's table is
@@ -1512,6 +1603,11 @@ const char *wide_kernel_name(const WideProgram &P) {
   return "k_wide_sweep<0>";
 }
 
+// the next sum-semiring fills of retimed programs use the fp64 correction term (k_wide_retimed<.., ACC>): set by the E-step of long
+// sequences (mb_api.hip, counts_chunks) around its two fills
+static bool g_wide_accurate = false;
+void wide_set_accurate(bool on) { g_wide_accurate = on; }
+
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly) {
   (void)m;
@@ -1529,11 +1625,21 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
       MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
       MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
       MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+      MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_FORWARD, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
       attr = true;
     }
     double *ringScratch = nullptr;
     if (P.retGv && !(ringScratch = (double *)ws_get(scratchSlot, (size_t)nPairs * (size_t)P.ret.NB * P.ret.NVs * sizeof(double)))) return 1;
     WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+    const size_t accLds = ((P.retLdsBytes + 7) & ~(size_t)7) + 512;      // + the table of 2^(j/64)
+    if (g_wide_accurate && !P.viterbi && accLds <= WIDE_LDS_MAX) {
+      if (P.retGv) hipLaunchKernelGGL((k_wide_retimed<MB_FORWARD, true, false, true>), dim3((unsigned)nPairs), dim3(P.W), accLds, st, dev, P.ret, d_desc, d_out, pool, loglike, ringScratch);
+      else hipLaunchKernelGGL((k_wide_retimed<MB_FORWARD, false, false, true>), dim3((unsigned)nPairs), dim3(P.W), accLds, st, dev, P.ret, d_desc, d_out, pool, loglike, ringScratch);
+      MB_HIP(hipGetLastError());
+      g_last_launches += 1;
+      return 0;
+    }
 #define WIDE_RET_GO(M, G) hipLaunchKernelGGL((k_wide_retimed<M, G>), dim3((unsigned)nPairs), dim3(P.W), P.retLdsBytes, st, dev, P.ret, d_desc, d_out, pool, loglike, ringScratch)
     if (P.viterbi) { if (P.retGv) WIDE_RET_GO(MB_VITERBI, true); else WIDE_RET_GO(MB_VITERBI, false); }
     else { if (P.retGv) WIDE_RET_GO(MB_FORWARD, true); else WIDE_RET_GO(MB_FORWARD, false); }

@@ -23,8 +23,11 @@ FAST_ABS = 2e-5
 ABS_TABLE = 1e-4    # vs the reference's table build: the table drops terms >= 10 nats below the running max and
 REL_TABLE = 1e-4    # interpolates at step 1e-4 (src/logsumexp.h:20-21,48-70); 1e-4 relative is the north-star tolerance
 COUNT_TOL = 1e-9
-COUNT50_REL = 1e-4  # posterior counts of a 50 000-column one-tape sweep, PER TRANSITION against the exact oracle: measured 7.6e-5 (the reference's
-                    # own default build, table-interpolated log-sum-exp, is 9.6e-2 from it); before the per-column normaliser of round 4: 2.3e-4
+COUNT50_REL = 5e-6  # posterior counts of a 50 000-column one-tape sweep, PER TRANSITION against the exact oracle.  Round 5: the fills of an E-step over
+                    # sequences of >= 10 000 symbols carry their log-sum-exp correction term in fp64 (mb_wide.hip wide_exp64): measured 5.4e-7 on four
+                    # sequences / two parameter sets (scripts/count_accuracy_onetape.py).  With the fp32 term (MB_ONETAPE_COUNT_FP64=0, round 4) 6.4e-5 - 7.7e-5:
+                    # a per-column error that REPEATS in stationary states and grows linearly, not a random walk; the reference's own default build
+                    # (table-interpolated log-sum-exp) is 9.6e-2 from the exact oracle
 
 
 @pytest.fixture(scope="module")
@@ -535,6 +538,34 @@ def test_baseline_config5_one_sequence_at_50kb_against_the_oracle(capi, oracle_m
     print("config 5 at 50 kb: largest per-transition count deviation %.3g (relative, counts below 1e-3 taken as 1e-3)" % dev.max())
     assert close(counts, ref_c, COUNT50_REL, 1e-3 * COUNT50_REL)
     dm.close()
+
+
+@pytest.mark.parametrize("L,seed,params", [(50000, 7, "random"), (20000, 11, "uniform"), (12000, 3, "random"), (9000, 5, "uniform")])
+def test_one_tape_counts_of_long_sequences_against_the_oracle(capi, oracle_mod, L, seed, params):
+    """the per-transition comparison of the one-tape E-step with the EXACT oracle on more than one sequence and
+    on a NON-UNIFORM parameter set (every norm group a random point of its simplex, every prob in (0.05, 0.95): no ties, another
+    dynamic range), at 50 kb and at shorter lengths either side of the 10 000-symbol threshold from which the fills carry their
+    correction term in fp64 (src/backward.cpp:58-87, src/logsumexp.h:72-90).  The bound is 5e-6 (1e-4 asked; measured 5.4e-7 with
+    the fp64 term, <= 4.9e-5 below the threshold with the fp32 term at 9 000 symbols -- bound 1e-4 there)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import count_accuracy_onetape as cao
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    if _ram_gb() < 14 and L > 20000: pytest.skip("host memory: two oracle matrices of 2 GB each")
+    m = cao.profile_machine(20)
+    em = EvaluatedMachine.fromMachine(m, cao.random_params(m, 99)) if params == "random" else EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    x = np.zeros(0, np.int32); y = np.random.RandomState(seed).randint(1, 4, size=L).astype(np.int32)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+    counts, s, ll = b.counts()
+    ref = np.zeros(em.nTransitions); llo = om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+    dev = np.abs(counts - ref) / np.maximum(np.abs(ref), 1e-3)
+    print("one-tape E-step, L = %d, %s parameters: largest per-transition count deviation %.3g, log-likelihood %.3g relative" % (L, params, dev.max(), abs(ll[0] - llo) / abs(llo)))
+    bound = COUNT50_REL if L >= 10000 else 1e-4
+    assert close(counts, ref, bound, 1e-3 * bound) and abs(ll[0] - llo) <= (1e-12 if L >= 10000 else 1e-7) * abs(llo)
+    assert abs(counts[np.asarray(em.outTok) != 0].sum() / L - 1.0) < 1e-6
+    b.close(); dm.close()
 
 
 def test_tiled_family_byte_sweep_under_envelopes(capi, oracle_mod, machines):
