@@ -204,7 +204,8 @@ def debug_jit_source(em, path: str, mode: int = MB_FORWARD, backward: bool = Fal
 def debug_medium_program(em, path: str, mode: int = MB_FORWARD, backward: bool = False, closure: int = 1, G: int = 2) -> dict:
     """The tiled family's PROGRAM for this machine as the kernels read it (host only, no GPU needed): chunk descriptors `desc`
     [nChunks][8], records `rec` (w, srcOff, dstOff), the usage slots `flat` [(table, first record)] of a flat count program, and
-    the scalars S, Spad, LPG, G, nIn, nOut, seedOff, dummyOff, backward, closure, counting, flatCount (mb_api.hip,
+    the scalars S, Spad, LPG, G, nIn, nOut, seedOff, dummyOff, backward, closure, counting, flatCount, fusedEmit, twoTables, the fused emit slots
+    `fused` and the loop-time accumulator map `accMap` of a flat count program (mb_api.hip,
     mb_debug_jit_source with mode + 32; the semantics are med_slow_supercell's, mb_medium.hip)."""
     debug_jit_source(em, path, mode=mode | 32, backward=backward, closure=closure, G=G)
     head = np.fromfile(path, np.int32, 16)
@@ -214,9 +215,14 @@ def debug_medium_program(em, path: str, mode: int = MB_FORWARD, backward: bool =
     off = 64
     out["desc"] = np.fromfile(path, np.int32, out["nChunks"] * 8, offset=off).reshape(out["nChunks"], 8); off += out["nChunks"] * 32
     out["rec"] = np.fromfile(path, np.dtype([("w", "<f8"), ("srcOff", "<u4"), ("dstOff", "<u4")]), out["nRec"], offset=off); off += out["nRec"] * 16
-    out["flat"] = np.fromfile(path, np.int32, out["nFlat"] * 2, offset=off).reshape(out["nFlat"], 2); off += out["nFlat"] * 8
-    out["wref"] = np.fromfile(path, np.int32, out["nRec"], offset=off)      # per record: >= 0 its transition, -1 padding, <= -2 a closure pair
-    assert os.path.getsize(path) == off + out["nRec"] * 4
+    flags = out["flatCount"]
+    out["flatCount"], out["fusedEmit"], out["twoTables"] = flags & 1, (flags >> 1) & 1, (flags >> 2) & 1
+    out["flat"] = np.fromfile(path, np.int32, out["nFlat"] * 3, offset=off).reshape(out["nFlat"], 3); off += out["nFlat"] * 12      # (table, first record, placement: 2 = VGPRs)
+    out["wref"] = np.fromfile(path, np.int32, out["nRec"], offset=off); off += out["nRec"] * 4      # per record: >= 0 its transition, -1 padding, <= -2 a closure pair
+    nFused, nLoop = (int(v) for v in np.fromfile(path, np.int32, 2, offset=off)); off += 8
+    out["fused"] = np.fromfile(path, np.int32, nFused * 3, offset=off).reshape(nFused, 3); off += nFused * 12                        # emit slots of the fill rounds that also add usage
+    out["accMap"] = np.fromfile(path, np.int32, nLoop, offset=off); off += nLoop * 4                                                  # loop-time accumulator entry -> transition
+    assert os.path.getsize(path) == off
     return out
 
 

@@ -1591,18 +1591,29 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     // The program as the kernels read it -- descriptors + records, what med_slow_supercell (mb_medium.hip) interprets chunk by chunk
     // and the run-time generator unrolls --, for a device-free replay (tests/test_tiled_plan.py): 16 int32 (magic 0x4D454431, S, Spad,
     // LPG, G, nChunks, nIn, nOut, seedOff, dummyOff, records, usage slots of a flat count program, 1 = backward, closure stages,
-    // 1 = counting, 1 = flat), nChunks x 8 int32 descriptors, the records (fp64 weight, srcOff, dstOff), the usage slots (int32
-    // table, int32 first record), one int32 per record: the transition it stands for
+    // 1 = counting, flags: 1 flat | 2 emitting usage fused into the fill rounds | 4 two accumulator tables), nChunks x 8 int32
+    // descriptors, the records (fp64 weight, srcOff, dstOff), the usage slots (int32 table, first record, placement), one int32 per
+    // record: the transition it stands for, then int32 fused slots, int32 loop-time accumulators, the fused slots (table, first
+    // record, placement) and the loop-time table's transitions
     FILE *f = fopen(path, "wb");
     if (!f) { set_error("mb_debug_jit_source: cannot open output file"); return 1; }
-    std::vector<int32_t> flatSlots;
-    for (const MedRoundInfo &ri : P.roundInfo) if (ri.flat) for (const MedSlotInfo &sl : ri.slots) { flatSlots.push_back(sl.T); flatSlots.push_back((int32_t)sl.recBase); }
+    // usage slots: (table, first record, placement 2 = VGPRs: summed in a register, set down in the after-the-loop table; else: the
+    // loop-time table) -- the usage pass of a flat count program, then the fused emit slots of its fill rounds (MedProgram::fusedEmit)
+    std::vector<int32_t> flatSlots, fusedSlots;
+    for (const MedRoundInfo &ri : P.roundInfo)
+      for (const MedSlotInfo &sl : ri.slots) {
+        if (ri.flat) { flatSlots.push_back(sl.T); flatSlots.push_back((int32_t)sl.recBase); flatSlots.push_back(sl.place); }
+        else if (ri.fused && sl.T < 3) { fusedSlots.push_back(sl.T); fusedSlots.push_back((int32_t)sl.recBase); fusedSlots.push_back(sl.place); }
+      }
     const int32_t head[16] = {0x4D454431, m.S, P.Spad, P.LPG, P.G, P.nChunks, m.nIn, m.nOut, (int32_t)P.dev.seedOff, (int32_t)P.dummyOff, (int32_t)P.rec.size(),
-                              (int32_t)(flatSlots.size() / 2), P.backward ? 1 : 0, closure, P.counting ? 1 : 0, P.flatCount ? 1 : 0};
+                              (int32_t)(flatSlots.size() / 3), P.backward ? 1 : 0, closure, P.counting ? 1 : 0, (P.flatCount ? 1 : 0) | (P.fusedEmit ? 2 : 0) | (P.accAllEntries ? 4 : 0)};
+    const int32_t tail[2] = {(int32_t)(fusedSlots.size() / 3), (int32_t)P.accMap.size()};
     const bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(P.desc.data(), 4, (size_t)P.nChunks * MED_DESC_WORDS, f) == (size_t)P.nChunks * MED_DESC_WORDS &&
                     fwrite(P.rec.data(), sizeof(MedRec), P.rec.size(), f) == P.rec.size() &&
                     (flatSlots.empty() || fwrite(flatSlots.data(), 4, flatSlots.size(), f) == flatSlots.size()) &&
-                    fwrite(P.wref.data(), 4, P.wref.size(), f) == P.wref.size();      // per record: >= 0 its transition, -1 padding, <= -2 a closure pair
+                    fwrite(P.wref.data(), 4, P.wref.size(), f) == P.wref.size() &&      // per record: >= 0 its transition, -1 padding, <= -2 a closure pair
+                    fwrite(tail, sizeof(tail), 1, f) == 1 && (fusedSlots.empty() || fwrite(fusedSlots.data(), 4, fusedSlots.size(), f) == fusedSlots.size()) &&
+                    (P.accMap.empty() || fwrite(P.accMap.data(), 4, P.accMap.size(), f) == P.accMap.size());      // loop-time accumulator entry -> transition
     fclose(f);
     if (!ok) { set_error("mb_debug_jit_source: short write"); return 1; }
     return 0;

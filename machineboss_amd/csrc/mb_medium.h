@@ -47,6 +47,7 @@ struct MedProgDev {
   const int *desc;
   const MedRec *rec;
   const MedRec *ldsImage;   // those records, in the order the specialised kernel addresses them
+  const int *accMap;        // count programs with a compact loop-time accumulator table: entry -> transition (MedProgram::accMap)
 };
 
 // structure of the program, kept for the run-time code generator (mb_medium_jit.cpp)
@@ -57,6 +58,7 @@ enum { MED_PLACE_GLOBAL = 0, MED_PLACE_LDS = 1, MED_PLACE_REG = 2 };
 struct MedSlotInfo { int T; long long recBase; int place = MED_PLACE_GLOBAL; long long ldsOff = 0; };   // table (= vector it reads, = token kind), first record, placement, record offset in the LDS image
 struct MedRoundInfo { std::vector<MedSlotInfo> slots; bool sync = false, single = false;
   bool flat = false;   // count programs: the usage pass behind the fill's rounds -- every record is ONE transition with its own source, destination and accumulator
+  bool fused = false;  // count programs (MedProgram::fusedEmit): the round's emitting candidates (tables 0-2) are real transitions whose usage term is added right here
 };
 
 struct MedJit {                 // one specialised kernel (per program and semiring)
@@ -74,7 +76,19 @@ struct MedProgram {
                                     // array.  Flat form (default): the closure Forward program + one `flat` round of usage records
                                     // {w, srcOff = source | destination << 16, dstOff = accumulator offset}, one per transition
   bool flatCount = false;
-  int accEntries = 0;               // counting: nTrans accumulators + LPG dummies (padding candidates, one per lane of a group)
+  // Round 5 (flat form): the EMITTING transitions' usage is FUSED into the fill's emit rounds -- v = F(src) + w is in a register there and
+  // every candidate of a lane shares one destination, so the term costs one B look-up per round instead of a record + two look-ups
+  // per transition, and the usage pass keeps the silent transitions only (the 482-state machine: 4 output-token slots = 20 KB of LDS
+  // records less).  A fused record carries its accumulator offset in the upper half of srcOff, and slot 0 of a lane the byte offset
+  // of its real destination state in the Backward supercell in the upper half of dstOff.  Not when emitting candidate lists are split.
+  bool fusedEmit = false;
+  // ... and the accumulators are TWO tables: a compact one that lives through the step loop, for the transitions whose usage records
+  // are not loop-invariant (token-selected ones: ds_add per step), and one entry per transition that exists only AFTER the loop, laid
+  // over the ring (dead by then), which takes the register sums of the loop-invariant records.  The 482-state machine: 25 KB -> 8 KB.
+  std::vector<int> accMap;          // loop-time table: entry -> transition
+  int *d_accMap = nullptr;
+  int accAllEntries = 0;            // flat count programs: nTrans + LPG entries of the after-the-loop table (0: one table, accEntries)
+  int accEntries = 0;               // counting: entries of the loop-time accumulator table + LPG dummies (padding candidates, one per lane of a group); levelled form: nTrans + LPG
   std::vector<int> desc;
   std::vector<MedRec> rec;
   std::vector<int> wref;            // per record: >= 0 global edge id, -1 padding (-inf), <= -2 closure pair -2-id
@@ -147,6 +161,8 @@ inline int medium_jit_index(int mode) { return mode == MB_VITERBI ? 1 : (mode ==
 void medium_eval_weights(const mb_machine *m, MedProgram &P);
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);
+void medium_count_layout(const mb_machine *m, MedProgram &P);      // flat count programs, after every medium_jit_plan: accumulator offsets of the usage records by placement
+int medium_jit_max_cands();
 long long medium_jit_spill_count(const std::string &codeObject);
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode = MB_FORWARD);
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int matKind);

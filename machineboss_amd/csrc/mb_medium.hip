@@ -389,7 +389,7 @@ static double host_lse(double a, double b) {
 // closure = 0: levelled (exact) program; K >= 1: silent closure in K stages -- the silent levels 1..nLev-1 are cut into K
 // consecutive groups, every group is closed transitively over (a) the states finalised by earlier groups and (b) the
 // emit-only parts of its own emit-fed states, and costs ONE synchronisation point.  K = 1 is the full closure.
-static void build_program(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, bool allowSplit = true) {
+static void build_program(const mb_machine *m, bool backward, int closure, int G, MedProgram &P, bool allowSplit = true, bool countFuse = false) {
   const int S = m->S, LPG = 64 / G, nIn = m->nIn, nOut = m->nOut;
   P = MedProgram();
   P.G = G; P.LPG = LPG; P.backward = backward; P.closure = closure != 0;
@@ -568,6 +568,9 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   // aligned; with one or two lanes per supercell the lanes of a wavefront read DIFFERENT columns at the same state
   // offset, and an odd length (stride of 2 x odd LDS banks) makes those reads conflict-free.
   P.hasSplits = anySplit || anySplitCur;
+  // count programs (flat form): the usage of the emitting transitions can ride on the fill's emit rounds when every emitting candidate
+  // sits in the node of its real destination state (no parts of split candidate lists) -- decided here, finished below once the rounds exist
+  bool fuse = countFuse && !backward && !anySplit;
   P.Spad = (S + 1 + nExtra + 1 + 1) & ~1;
   if (LPG <= 2) P.Spad |= 1;
   P.dummyOff = (uint32_t)(S + 1 + nExtra) * 8u;
@@ -649,6 +652,8 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
     P.roundInfo.emplace_back();
     P.roundInfo.back().sync = sync[r] != 0;
     P.roundInfo.back().single = single;
+    P.roundInfo.back().fused = fuse && (nsT[0] + nsT[1] + nsT[2] > 0);
+    if (P.roundInfo.back().fused && total > medium_jit_max_cands()) fuse = false;      // (the generator's running-form rounds carry no usage terms: decided for the whole program below)
     struct Ch { int T, j0, n; };
     std::vector<Ch> chs;
     for (int T = 0; T < 4; ++T)
@@ -677,7 +682,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
           candsOf(n, c.T, tok, tmp);
           for (int k = 0; k < c.n; ++k) {
             const size_t idx = b0 + (size_t)k * stride + (size_t)tok * LPG + ln;
-            if (k == 0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u;
+            if (k == 0) P.rec[idx].dstOff = (uint32_t)n.dst * 8u | ((countFuse && n.emitOf >= 0) ? ((uint32_t)n.emitOf * 8u) << 16 : 0u);      // (upper half: the real state's place in the Backward supercell)
             const int j = c.j0 + k;
             if (j < (int)tmp.size()) {
               P.rec[idx].srcOff = (uint32_t)tmp[j].src * 8u; P.wref[idx] = tmp[j].wref;
@@ -690,6 +695,9 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   }
   std::sort(P.haloStates.begin(), P.haloStates.end());
   P.haloStates.erase(std::unique(P.haloStates.begin(), P.haloStates.end()), P.haloStates.end());
+  P.fusedEmit = fuse;
+  if (!fuse) for (MedRoundInfo &ri : P.roundInfo) ri.fused = false;
+  if (countFuse && !fuse) for (MedRec &r : P.rec) r.dstOff &= 0xFFFFu;
   P.nChunks = (int)(P.desc.size() / DW);
   // where the seed goes: the stage-1 destination of the start node
   P.dev.seedOff = 0;
@@ -745,6 +753,7 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
   for (size_t k = 0; k < img.size(); ++k) img[k] = P.rec[P.ldsImageIdx[k]];
   if (!up(P.d_ldsImage, img)) return false;
   P.dev.ldsImage = P.d_ldsImage;
+  if (P.counting) { if (!up(P.d_accMap, P.accMap)) return false; P.dev.accMap = P.d_accMap; }
   return true;
 }
 
@@ -784,7 +793,7 @@ void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) 
     const long long perRec = P.counting ? 5 : 4;
     const long long inReg = std::max<long long>(0, regBudget / perRec - slotsT[1]);      // token-independent records the VGPRs can hold
     const long long need = (slotsT[2] * ntokT[2] + std::max<long long>(0, slotsT[3] - inReg)) * P.LPG * 16 + (long long)haloStepsFor(geo.C) * m->S * 8;
-    const long long ring = (long long)(P.NS + (P.counting ? 1 : 0)) * (geo.C + 1) * P.Spad * 8 + (P.counting ? (long long)(m->nTrans + 66) * 8 : 0);
+    const long long ring = (long long)(P.NS + (P.counting ? 1 : 0)) * (geo.C + 1) * P.Spad * 8 + (P.counting ? (long long)(P.accEntries + 2) * 8 : 0);
     if (ring + need + 2048 <= 160 * 1024 || geo.waves <= minWaves) break;
     --geo.waves; geo.C = geo.waves * P.G;
   }
@@ -845,6 +854,7 @@ static void append_flat_usage(const mb_machine *m, MedProgram &P) {
   MedRoundInfo &ri = P.roundInfo.back();
   ri.flat = true;
   for (int T = 0; T < 4; ++T) {
+    if (P.fusedEmit && T < 3) continue;      // their usage terms ride on the fill's emit rounds
     size_t mx = 0;
     for (auto &l : byTok[T]) {
       // lanes side by side read B(dst) (and mostly F(src)) of neighbouring states: no LDS bank is asked twice
@@ -880,7 +890,7 @@ bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom 
   const bool flat = env_int_m("MB_MEDIUM_COUNT_FLAT", 1) != 0;
   if (flat) {
     medium_set_cuts(cuts);
-    build_program(m, false, closure, G, P);
+    build_program(m, false, closure, G, P, /*allowSplit=*/true, /*countFuse=*/env_int_m("MB_MEDIUM_COUNT_FUSE", 1) != 0);
     medium_set_cuts({});
   } else
     build_program(m, false, 0, G, P, /*allowSplit=*/false);   // counting terms need every candidate beside its real destination
@@ -898,8 +908,63 @@ bool medium_build_count_host(const mb_machine *m, int G, MedProgram &P, MedGeom 
       P.rec[k].srcOff = (P.rec[k].srcOff & 0xFFFFu) | ((uint32_t)(e * 8) << 16);
     }
   medium_jit_plan(m, P, geo);
+  medium_count_layout(m, P);
+  if (flat && env_int_m("MB_MEDIUM_COUNT_COMPACT", 1)) {
+    // the placement says which usage records are loop-invariant: only the others need an accumulator that lives through the step loop.
+    // With that (smaller) table the geometry is taken again -- more columns -- and the placement with it.
+    MedGeom geo2;
+    if (medium_geometry(m, P, geo2)) {
+      medium_fit_records(m, P, geo2);
+      geo = geo2;
+      P.planC = 0; P.planHalo = 0; P.planWaves = 0; P.regBudget = -1;
+      medium_jit_plan(m, P, geo);
+      medium_count_layout(m, P);
+    }
+  }
   medium_eval_weights(m, P);
   return true;
+}
+
+// Accumulator offsets of a flat count program's usage records, by placement (after every medium_jit_plan).  A usage record held in
+// VGPRs sums in a register over a tile and reaches an accumulator AFTER the step loop: entry e of the all-transition table laid over
+// the dead ring.  Every other usage record adds per step (ds_add): entry compact(e) of the loop-time table, compact ids dealt in
+// order of first appearance (accMap: entry -> transition).  Flat records carry the offset in dstOff, fused emit records in the
+// upper half of srcOff.  MB_MEDIUM_COUNT_COMPACT=0: one table of nTrans + LPG entries for both, as in round 4.
+void medium_count_layout(const mb_machine *m, MedProgram &P) {
+  if (!P.counting || !P.flatCount) return;
+  const bool compact = env_int_m("MB_MEDIUM_COUNT_COMPACT", 1) != 0;
+  const int LPG = P.LPG;
+  const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
+  std::vector<int> compactOf((size_t)m->nTrans, -1);
+  P.accMap.clear();
+  auto isUsage = [&](const MedRoundInfo &ri, const MedSlotInfo &sl) { return ri.flat || (ri.fused && sl.T < 3); };
+  if (compact)
+    for (const MedRoundInfo &ri : P.roundInfo)
+      for (const MedSlotInfo &sl : ri.slots) {
+        if (!isUsage(ri, sl) || sl.place == MED_PLACE_REG) continue;
+        for (long long k = 0; k < ntokT[sl.T] * LPG; ++k) {
+          const int e = P.wref[(size_t)(sl.recBase + k)];
+          if (e >= 0 && compactOf[(size_t)e] < 0) { compactOf[(size_t)e] = (int)P.accMap.size(); P.accMap.push_back(e); }
+        }
+      }
+  else
+    for (long long e = 0; e < m->nTrans; ++e) { compactOf[(size_t)e] = (int)e; P.accMap.push_back((int)e); }
+  const int nLoop = (int)P.accMap.size();
+  P.accEntries = nLoop + LPG;
+  P.accAllEntries = compact ? (int)m->nTrans + LPG : 0;
+  for (const MedRoundInfo &ri : P.roundInfo)
+    for (const MedSlotInfo &sl : ri.slots) {
+      if (!isUsage(ri, sl)) continue;
+      const bool inReg = compact && sl.place == MED_PLACE_REG;
+      for (long long k = 0; k < ntokT[sl.T] * LPG; ++k) {
+        MedRec &r = P.rec[(size_t)(sl.recBase + k)];
+        const int e = P.wref[(size_t)(sl.recBase + k)];
+        const int ln = (int)(k % LPG);
+        const uint32_t off = (uint32_t)(e >= 0 ? (inReg ? e : compactOf[(size_t)e]) : (inReg ? (int)m->nTrans : nLoop) + ln) * 8u;      // padding: the lane's dummy entry
+        if (ri.flat) r.dstOff = off;
+        else r.srcOff = (r.srcOff & 0xFFFFu) | (off << 16);
+      }
+    }
 }
 
 bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo, int closure, const std::vector<int> &cuts) {
@@ -911,7 +976,7 @@ bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo,
 
 void medium_free(MedProgram &P) {
   medium_jit_free(P);
-  void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage};
+  void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage, P.d_accMap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   P = MedProgram();
 }
@@ -921,7 +986,7 @@ bool medium_geometry(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
   // count programs keep one Backward supercell per column and the count array next to the ring
   const size_t perCol = (size_t)(P.NS + (P.counting ? 1 : 0)) * P.Spad * sizeof(double);
   const size_t progBytes = 0;
-  const size_t fixed = 512 + (P.counting ? (size_t)(m->nTrans + 64 + 2) * sizeof(double) + 1024 : 0);
+  const size_t fixed = 512 + (P.counting ? (size_t)(std::max(P.accEntries, P.LPG) + 2) * sizeof(double) + 1024 : 0);
   if (fixed + 2 * perCol > 160 * 1024) return false;
   const size_t budget = 160 * 1024 - fixed;
   long long maxCols = (long long)(budget / perCol) - 1;   // one extra column for the halo

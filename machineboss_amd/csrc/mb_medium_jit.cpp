@@ -33,6 +33,7 @@ static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
+int medium_jit_max_cands() { return JIT_MAX_CANDS; }
 // MB_JIT_DEBUG (kernels with switched-off loads: WRONG results by design) exists only in a library built with
 // -DMB_EXPERIMENTS; a product build ignores the variable, so a stray environment cannot corrupt counts or likelihoods
 static int jit_debug_bits() {
@@ -50,7 +51,13 @@ static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) {   // rounded
 }
 static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 3 * 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }   // output tokens + the envelope rows (start, end) of the same window
 
-// count programs: one Backward supercell per column + the count accumulators
+// count programs: one Backward supercell per column + the loop-time count accumulators.  A flat program's all-transition table (one
+// entry per transition + LPG dummies) exists only AFTER the step loop and is laid over the start of the LDS (ring, records, tokens,
+// Backward supercells: all dead by then); the loop-time table must not lie under it, so it starts no earlier than that table ends
+static size_t acc_offset(const MedProgram &P, const MedGeom &geo) {
+  const size_t natural = ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + (size_t)geo.C * P.Spad * sizeof(double);
+  return std::max(natural, ((size_t)P.accAllEntries * sizeof(double) + 15) & ~(size_t)15);
+}
 static size_t count_bytes(const MedProgram &P, const MedGeom &geo) {
   return P.counting ? ((size_t)geo.C * P.Spad + (size_t)P.accEntries) * sizeof(double) : 0;
 }
@@ -63,6 +70,7 @@ static size_t tb_bytes(const MedProgram &P, const MedGeom &geo, int mode) { retu
 
 // (+ 128 bytes behind everything else: the per-wavefront step counters of the neighbour synchronisation, JNBSYNC)
 static size_t lds_payload_bytes(const MedProgram &P, const MedGeom &geo, int mode) {
+  if (P.counting) return (acc_offset(P, geo) + (size_t)P.accEntries * sizeof(double) + halo_bytes(P, geo) + 15) & ~(size_t)15;
   return (ring_bytes(P, geo) + P.ldsImageIdx.size() * sizeof(MedRec) + tok_bytes(P, geo) + count_bytes(P, geo) + halo_bytes(P, geo) + tb_bytes(P, geo, mode) + 15) & ~(size_t)15;
 }
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode) { return lds_payload_bytes(P, geo, mode) + 128; }
@@ -178,6 +186,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JBDIST " << (env_int("MB_JIT_B_DISTANCE", 1) == 2 ? 2 : 1)      // count sweep: steps the Backward supercells are fetched ahead (2: measured 218 vs 221 G lattice-cells/s -- the loads cost issue and LDS writes, not exposed latency)
        << "\n#define JDBG " << jit_debug_bits()      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
        << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
+       << "\n#define JNALL " << P.accAllEntries << "\n#define JNLOOP " << std::max(0, P.accEntries - P.LPG) << "\n#define JACCOFF " << (P.counting ? acc_offset(P, geo) : 0)
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
        << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
@@ -248,7 +257,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
           if (sl.place == MED_PLACE_REG) {
             pre << "  float acc_" << fn[k] << " = 0.0f;\n";
             flat << "        acc_" << fn[k] << " += " << term << ";\n";
-            post << "  cnt_flush(ldsb, accBase + ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ").dstOff, acc_" << fn[k] << ");\n";
+            post << "  cnt_flush(ldsb, accBase2 + ld_g(grb + " << sl.recBase * 16 << "ull, " << (sl.T == 1 ? "itOff16" : "q16") << ").dstOff, acc_" << fn[k] << ");\n";
           } else
             flat << "        cnt_flush(ldsb, accBase + " << fn[k] << ".dstOff, " << term << ");\n";
         }
@@ -267,7 +276,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       if (sl.place == MED_PLACE_REG) {
         pre << "  float acc_" << name << " = 0.0f;\n";
         o << "        acc_" << name << " += " << term << ";\n";
-        post << "  cnt_flush(ldsb, accBase + (" << name << ".srcOff >> 16), acc_" << name << ");\n";
+        post << "  cnt_flush(ldsb, accBase2 + (" << name << ".srcOff >> 16), acc_" << name << ");\n";
       } else
         o << "        cnt_flush(ldsb, accBase + (" << name << ".srcOff >> 16), " << term << ");\n";
     };
@@ -298,7 +307,9 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       for (int k = 0; k < n; ++k)
         sLoad << "        const double " << V(k) << " = med_lds(ldsb, " << vec[ri.slots[k].T] << " + SRCOFF(" << nm[k] << ".srcOff)) + " << nm[k] << ".w;\n";
       if (counting)   // posterior usage of every candidate's transition: exp(F(src) + w + B(dst) - LL), src/backward.cpp:58-87
-        sLoad << "        const double bl" << R << " = med_lds(ldsb, aB + (int)(JINSIDE ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
+        sLoad << "        const double bl" << R << " = med_lds(ldsb, aB + (int)(JINSIDE ? DSTOFF(" << nm[0] << ".dstOff) : (unsigned)JDUMMYOFF)) + negLL;   // the dummy entry of bvec holds -inf\n";
+      if (ri.fused)   // flat count program: the round's emitting candidates are real transitions into the lane's state -- B(state) - LL once per round (bvec holds B - LL)
+        sLoad << "        const double bf" << R << " = med_lds(ldsb, aB + (int)(JINSIDE ? (" << nm[0] << ".dstOff >> 16) : (unsigned)JDUMMYOFF));\n";
       if (n == 1) {
         sFold << "        const double res" << R << " = " << V(0) << ";\n";
       } else {
@@ -313,7 +324,19 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
           sFold << ";\n        const double res" << R << " = gM" << R << " + (double)(__builtin_amdgcn_logf(sm" << R << ") * MED_LN2);\n";
         }
       }
-      sFold << "        *(double *)(ldsb + (aCur + (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res" << R << ");\n";
+      sFold << "        *(double *)(ldsb + (aCur + (int)(active ? DSTOFF(" << nm[0] << ".dstOff) : (unsigned)JDUMMYOFF))) = JCLIP(res" << R << ");\n";
+      if (ri.fused)
+        for (int k = 0; k < n; ++k) {
+          const MedSlotInfo &sl = ri.slots[k];
+          if (sl.T >= 3) continue;
+          const std::string term = "ex2(" + V(k) + " + bf" + R + ")";
+          if (sl.place == MED_PLACE_REG) {      // the same transition for the whole sweep of the column: summed in a register, set down after the step loop
+            pre << "  float acc_" << nm[k] << " = 0.0f;\n";
+            sFold << "        acc_" << nm[k] << " += " << term << ";\n";
+            post << "  cnt_flush(ldsb, accBase2 + (" << nm[k] << ".srcOff >> 16), acc_" << nm[k] << ");\n";
+          } else
+            sFold << "        cnt_flush(ldsb, accBase + (" << nm[k] << ".srcOff >> 16), " << term << ");\n";
+        }
       if (counting) {
         if (n == 1) countTerm(sFold, ri.slots[0], nm[0], "ex2(" + V(0) + " + bl" + R + ")");
         else {
@@ -342,7 +365,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
           for (int k = k0; k < k1; ++k) sBig << " + e" << k;
           sBig << ";\n        accM = nm;\n";
           if (counting) {
-            sBig << "        const float sB = ex2(nm + (med_lds(ldsb, aB + (int)(JINSIDE ? dstOff : (unsigned)JDUMMYOFF)) + negLL));\n";
+            sBig << "        const float sB = ex2(nm + (med_lds(ldsb, aB + (int)(JINSIDE ? DSTOFF(dstOff) : (unsigned)JDUMMYOFF)) + negLL));\n";
             for (int k = k0; k < k1; ++k) countTerm(sBig, ri.slots[k], nm[k], "e" + std::to_string(k) + " * sB");
           }
         }
@@ -350,7 +373,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       }
       if (maxmode) sBig << "        const double res = accM;\n";
       else sBig << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
-      sBig << "        *(double *)(ldsb + (aCur + (int)(active ? dstOff : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
+      sBig << "        *(double *)(ldsb + (aCur + (int)(active ? DSTOFF(dstOff) : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
       sBig << "        }\n";
     }
     if (ri.sync || !stageLoads) flushStage();
@@ -417,7 +440,11 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.
     P.regBudget = std::max(0, std::min(P.regBudget, P.regUsed) - std::max(9, (int)spills + 3));   // cut from what the plan really spent
+    // (flat count programs: which usage records are loop-invariant changes with the placement, and with it the size of the loop-time
+    //  accumulator table the placement has to leave room for -- planned once against the largest table, then against the real one)
+    if (P.counting && P.flatCount) { P.accEntries = (int)m->nTrans + P.LPG; medium_jit_plan(m, P, geoIn); medium_count_layout(m, P); }
     medium_jit_plan(m, P, geoIn);
+    medium_count_layout(m, P);
     if (!medium_refresh_weights(m, P)) return false;
     for (MedJit &O : P.jit) {
       if (&O == &J) continue;

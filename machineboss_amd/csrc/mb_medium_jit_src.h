@@ -27,6 +27,7 @@ struct MedProgDev {
   const int *desc;
   const MedRec *rec;
   const MedRec *ldsImage;
+  const int *accMap;
 };
 struct MedTileArgs {
   const PairDesc *pairs;
@@ -59,8 +60,10 @@ struct MedTileArgs {
 #endif
 #if JMODE == 2
 #define SRCOFF(x) ((int)((x) & 0xFFFFu))
+#define DSTOFF(x) ((x) & 0xFFFFu)      // (upper half of a fused emit round's slot-0 record: the real state's place in the Backward supercell)
 #else
 #define SRCOFF(x) ((int)(x))
+#define DSTOFF(x) (x)
 #endif
 typedef const __attribute__((address_space(4))) int *cdesc_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -147,7 +150,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
       const Rec r = mk_rec(grec[idx0 + k * dp[4]]);
       bool firstCand = false;
       if (k == 0) {
-        dstOff = r.dstOff;
+        dstOff = DSTOFF(r.dstOff);
         if (first) {
           const bool seed = origin && dstOff == seedOff;
           accM = seed ? 0.0 : NEG_INF; accS = seed ? 1.0f : 0.0f;
@@ -252,7 +255,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #if JMODE == 2
   // count mode: the Backward supercell of every column (this step's) and the count accumulators of the workgroup
   double *bvec = (double *)(tokWin + 6 * (W + C));
-  double *accL = bvec + (long long)C * Spad;
+  double *accL = (double *)((char *)lds + JACCOFF);      // the loop-time accumulators: behind the Backward supercells, and behind what the after-the-loop table will cover
   const double *cellsB = A.poolB + pd.cellBase;
   auto cellPtrB = [&](int ci, int co) -> const double * { return cellsB + ((long long)co * I + ci) * S; };
   const double bLL = cellsB[0];                                   // BackwardMatrix::logLike() = cell(0,0,start), src/backward.cpp:48-50,66
@@ -553,17 +556,36 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #endif
 #if JMODE == 2
   // usage summed in registers over the tile's steps (records held in VGPRs) -> the workgroup's LDS accumulators
+#if JNALL > 0
+  // ... which, for a flat program, is a table of its own: one entry per transition, laid over the start of the LDS now that the ring,
+  // the records and the Backward supercells are dead (the loop-time table, JNLOOP entries for the token-selected usage records, lies behind it)
+  __syncthreads();
+  for (int j = tid; j < JNALL; j += NT) lds[j] = 0.0;
+  __syncthreads();
+  const unsigned accBase2 = 0u;
+#else
+  const unsigned accBase2 = accBase;
+#endif
+  (void)accBase2;
 /*@POST@*/
   __syncthreads();
   // flush the workgroup's counts: one fp64 atomic per transition that was used in this tile
+#if JNALL > 0
+  for (int e = tid; e < JNTRANS + JNLOOP; e += NT) {
+    const bool loop = e >= JNTRANS;
+    const double *tab = loop ? accL : lds;
+    const int j = loop ? e - JNTRANS : e, tr = loop ? P.accMap[j] : e;
+#else
   for (int e = tid; e < JNTRANS; e += NT) {
+    const double *tab = accL; const int j = e, tr = e;
+#endif
     if (jdet) {      // 2^-44 in the tile -> 2^-36 in global memory, rounded
-      const unsigned long long u = ((const unsigned long long *)accL)[e];
-      if (u) (void)__hip_atomic_fetch_add((unsigned long long *)A.counts + e, u >= (1ull << 62) ? (1ull << 62) : (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a saturated tile stays saturated
+      const unsigned long long u = ((const unsigned long long *)tab)[j];
+      if (u) (void)__hip_atomic_fetch_add((unsigned long long *)A.counts + tr, u >= (1ull << 62) ? (1ull << 62) : (u + 128ull) >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a saturated tile stays saturated
       continue;
     }
-    const double x = accL[e];
-    if (x != 0.0) (void)__hip_atomic_fetch_add(A.counts + e, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double x = tab[j];
+    if (x != 0.0) (void)__hip_atomic_fetch_add(A.counts + tr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #endif
 }

@@ -1565,7 +1565,9 @@ def test_baseline_config5_at_its_stated_length(capi, monkeypatch):
     # every symbol is emitted exactly once (round 3: to 2e-4 at this length -- the rounding of 50 000 columns of log-sum-exp in F and B;
     # round 4 divides every column's terms by what its emitting terms sum to, k_onetape_counts_lds)
     counts, s, cll = b2.counts()
-    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 1e-6 * 2 * L and close(cll, llp[:2], 1e-8)
+    # (the E-step's fills carry their correction term in fp64 at this length: their log-likelihood is the exact one to 1e-14, the rolling
+    #  sweep's fp32 term is 1.1e-8 away from it -- test_baseline_config5_one_sequence_at_50kb_against_the_oracle has both against the oracle)
+    assert abs(counts[np.asarray(em.outTok) != 0].sum() - 2 * L) <= 1e-6 * 2 * L and close(cll, llp[:2], 5e-8)
 
 
 def test_pipelined_forward_matches_plain(capi, machines):

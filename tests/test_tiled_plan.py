@@ -32,8 +32,19 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0, edges=False):
     cells = np.full((nI + 1, nO + 1, Spad), -np.inf)
     outside = np.full(Spad, -np.inf)
     lanes = np.arange(LPG)
-    acc = np.zeros(n_trans + LPG)
+    acc = np.zeros(n_trans + LPG)              # levelled form: one table; flat form: the after-the-loop table (register sums of loop-invariant records)
+    acc_loop = np.zeros(len(prog.get("accMap", ())) + LPG)      # flat form: the loop-time table (token-selected records), entry -> transition in accMap
+    two = bool(prog.get("twoTables", 0))
     wref = prog["wref"]
+    # fused emit slots of the fill rounds (round 5): record -> placement (2 = VGPRs); such a record's upper srcOff half is its accumulator
+    # offset, and slot 0's upper dstOff half the real state's place in the Backward supercell
+    ntokT = ((prog["nIn"] + 1) * (nOut + 1), prog["nIn"] + 1, nOut + 1, 1)
+    fused_place = {}
+    for T, b0, place in prog.get("fused", ()):
+        for k in range(ntokT[int(T)] * LPG): fused_place[int(b0) + k] = int(place)
+    def add_usage(place, off_bytes, val):
+        tab = acc if (not two or place == 2) else acc_loop
+        np.add.at(tab, off_bytes >> 3, val)
     chosen = np.full((nI + 1, nO + 1, Spad), -1, np.int64)
     for i in range(nI + 1):
         for o in range(nO + 1):
@@ -51,6 +62,8 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0, edges=False):
                     r = rec[base + k * int(dp[4])]
                     if k == 0:
                         dst = r["dstOff"].astype(np.int64)
+                        bdst = dst >> 16                      # (count programs with fused emit usage: the real state, in bytes)
+                        if counting: dst = dst & 0xFFFF
                         if first:
                             seed = (dst == seedOff) if (i == 0 and o == 0) else np.zeros(LPG, bool)
                             accM = np.where(seed, 0.0, -np.inf); accS = np.where(seed, 1.0, 0.0)
@@ -65,6 +78,11 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0, edges=False):
                         with np.errstate(invalid="ignore"):
                             t = v + bl[np.minimum(dst >> 3, Spad - 1)]
                         np.add.at(acc, so >> 19, np.where(np.isnan(t) | np.isneginf(t), 0.0, np.exp(np.where(np.isfinite(t), t, 0.0))))
+                    ridx0 = int(base[0]) + k * int(dp[4])
+                    if flatc and ridx0 in fused_place:      # the emitting candidates of this round are real transitions into the lane's state: exp(v + B(state) - LL)
+                        with np.errstate(invalid="ignore"):
+                            t = v + bl[np.minimum(bdst >> 3, Spad - 1)]
+                        add_usage(fused_place[ridx0], so >> 16, np.where(np.isnan(t) | np.isneginf(t), 0.0, np.exp(np.where(np.isfinite(t), t, 0.0))))
                     if mode_max: accM = np.maximum(accM, v)
                     else:
                         nm = np.maximum(accM, v); g = np.where(np.isneginf(nm), 0.0, nm)
@@ -82,14 +100,18 @@ def replay(prog, x, y, mode_max, bwd=None, ll=None, n_trans=0, edges=False):
                             chosen[i, o, dst[ln] >> 3] = e if e >= 0 else chosen[i, o, int(rec[rr]["srcOff"]) >> 3]
             assert cur[S] == -np.inf                                   # the -inf sentinel padding candidates read is never written
             if flatc:
-                for T, b0 in flat:
+                for T, b0, place in flat:
                     tok = (it * (nOut + 1) + ot, it, ot, 0)[T]
                     r = rec[int(b0) + tok * LPG + lanes]
                     so = r["srcOff"].astype(np.int64)
                     t = (vecs[T][(so & 0xFFFF) >> 3] + r["w"]) + bl[so >> 19]
-                    np.add.at(acc, r["dstOff"].astype(np.int64) >> 3, np.where(np.isneginf(t), 0.0, np.exp(np.where(np.isfinite(t), t, 0.0))))
+                    add_usage(int(place), r["dstOff"].astype(np.int64), np.where(np.isneginf(t), 0.0, np.exp(np.where(np.isfinite(t), t, 0.0))))
     cells = cells[:, :, :S].transpose(1, 0, 2)      # [output][input][state] like the oracle's
     if edges: return cells, chosen[:, :, :S]
+    if counting and two:      # the kernel's flush: the after-the-loop table entry e, plus the loop-time table through accMap
+        tot = acc[:n_trans].copy()
+        np.add.at(tot, np.asarray(prog["accMap"], np.int64), acc_loop[:len(prog["accMap"])])
+        return cells, tot
     return (cells, acc[:n_trans]) if counting else cells
 
 
@@ -189,11 +211,14 @@ def test_count_programs_reproduce_the_oracle(name, flat, tmp_path, monkeypatch):
         assert prog["counting"] and prog["flatCount"] == int(flat) and (prog["nFlat"] > 0) == (flat == "1")
         if flat == "1":      # every transition that is a candidate of some cell sits in exactly one usage record
             named = []
-            for T, b0 in prog["flat"]:
+            for T, b0, place in list(prog["flat"]) + list(prog["fused"]):      # the usage pass, and the emit slots of the fill rounds that carry usage terms
                 ntok = ((em.nInTok + 1) * (em.nOutTok + 1), em.nInTok + 1, em.nOutTok + 1, 1)[T]
-                r = prog["rec"][int(b0):int(b0) + ntok * prog["LPG"]]
-                named.append((r["dstOff"][np.isfinite(r["w"])] >> 3).astype(np.int64))
+                w = prog["wref"][int(b0):int(b0) + ntok * prog["LPG"]]
+                named.append(w[(w >= 0) & np.isfinite(prog["rec"]["w"][int(b0):int(b0) + ntok * prog["LPG"]])].astype(np.int64))
             named = np.sort(np.concatenate(named))
+            if not prog["fusedEmit"]: assert len(prog["fused"]) == 0
+            if prog["twoTables"]:      # loop-time entries: the transitions of the usage records that are not held in VGPRs, each once
+                am = np.asarray(prog["accMap"]); assert len(np.unique(am)) == len(am)
             live = np.isfinite(np.asarray(em.logWeight)) & ~((np.asarray(em.inTok) == 0) & (np.asarray(em.outTok) == 0) & (np.asarray(em.dst) <= np.asarray(em.src)))
             assert np.all(np.diff(named) > 0) and np.array_equal(named, np.nonzero(live)[0])
         ref = np.zeros(em.nTransitions); got = np.zeros(em.nTransitions)
