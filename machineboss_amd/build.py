@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for s in sources():
         o = os.path.join(bdir, s + ".o")
-        cmd = [_hipcc(), "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o, "-I", os.path.join(ROOT, "include"), "-I", CSRC] + FLAGS
+        cmd = [_hipcc(), "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o, "-I", os.path.join(ROOT, "include"), "-I", CSRC] + FLAGS + os.environ.get("MB_BUILD_EXTRA_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd)))

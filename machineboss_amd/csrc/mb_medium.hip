@@ -779,6 +779,7 @@ void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) 
   const char *e = getenv("MB_MEDIUM_MAXWAVES");
   if (e && atoi(e) > 0 && atoi(e) < geo.waves) { geo.waves = atoi(e); geo.C = geo.waves * P.G; }
   if (getenv("MB_MEDIUM_FIT_RECORDS") && atoi(getenv("MB_MEDIUM_FIT_RECORDS")) == 0) return;
+  if (P.counting && env_int_m("MB_MEDIUM_COUNT_FIT", 1) == 0) return;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
   long long slotsT[4] = {0, 0, 0, 0};
   for (const MedRoundInfo &ri : P.roundInfo) for (const MedSlotInfo &sl : ri.slots) ++slotsT[sl.T];

@@ -181,7 +181,8 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        // NEIGHBOUR SYNCHRONISATION instead of a workgroup barrier per step (tiles without a matrix whose halo rows one wavefront moves):
        // see the skeleton.  Measured on psw2dna 64 x 487 x 2 kb: log-likelihood tiles 1 124 -> 1 188 G cells/s, traceback-byte Viterbi
        // 593 -> 617, the count sweep 224 -> 220 (its step is paced by the Backward loads, not by the barrier): off for that one
-       << "\n#define JNBSYNC " << ((env_int("MB_JIT_NEIGHBOUR_SYNC", mode == MED_MODE_COUNT ? 0 : 1) && matKind == MED_MAT_ROLL && P.haloStates.size() <= 64 && geo.waves > 1 && geo.waves <= 16) ? 1 : 0)
+       // (round 5: on for the count sweep too when a wavefront is ONE column -- the 482-state machine: 87 -> 90 G lattice-cells/s)
+       << "\n#define JNBSYNC " << ((env_int("MB_JIT_NEIGHBOUR_SYNC", (mode == MED_MODE_COUNT && P.G != 1) ? 0 : 1) && matKind == MED_MAT_ROLL && P.haloStates.size() <= 64 && geo.waves > 1 && geo.waves <= 16) ? 1 : 0)
        << "\n#define JFLAGOFF " << lds_payload_bytes(P, geo, mode)
        << "\n#define JBDIST " << (env_int("MB_JIT_B_DISTANCE", 1) == 2 ? 2 : 1)      // count sweep: steps the Backward supercells are fetched ahead (2: measured 218 vs 221 G lattice-cells/s -- the loads cost issue and LDS writes, not exposed latency)
        << "\n#define JDBG " << jit_debug_bits()      // experiments only (wrong results): 1 = no Backward loads, 2 = no halo loads
@@ -244,7 +245,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       // slots (16 columns per wavefront on a dense machine) no longer keeps every record and term live at once (600+ spilled VGPRs).
       std::vector<std::string> fn(n);
       const int chunk = env_int("MB_JIT_FLAT_CHUNK", 24) > 0 ? env_int("MB_JIT_FLAT_CHUNK", 24) : n;
-      flat << "      if (JINSIDE) {  // usage pass: " << n << " slot(s); lanes of columns outside the lattice (stale ring values) sit it out\n";
+      flat << "      if (JINSIDE && !(JDBG & 8)) {  // usage pass: " << n << " slot(s); lanes of columns outside the lattice (stale ring values) sit it out\n";
       for (int k0 = 0; k0 < n; k0 += chunk) {
         const int k1 = std::min(n, k0 + chunk);
         if (n > chunk) flat << "        {\n";
@@ -325,7 +326,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         }
       }
       sFold << "        *(double *)(ldsb + (aCur + (int)(active ? DSTOFF(" << nm[0] << ".dstOff) : (unsigned)JDUMMYOFF))) = JCLIP(res" << R << ");\n";
-      if (ri.fused)
+      if (ri.fused && !(jit_debug_bits() & 16))
         for (int k = 0; k < n; ++k) {
           const MedSlotInfo &sl = ri.slots[k];
           if (sl.T >= 3) continue;

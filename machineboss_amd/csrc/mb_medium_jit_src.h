@@ -486,7 +486,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #pragma unroll
     for (int k = 0; k < JBV; ++k) bnext[k] = bpre[k];
 #else
-    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S) bvec[c * Spad + j] = JFLAT ? bpre[k] + negLL : bpre[k]; }
+    for (int k = 0; k < JBV; ++k) { const int j = k * LPG + q; if (j < S && !(JDBG & 32)) bvec[c * Spad + j] = JFLAT ? bpre[k] + negLL : bpre[k]; }
 #endif
 #endif
 #if JMAT == 2

@@ -6,12 +6,13 @@
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp
+REPS=${MODE_REPS:-3}
 for MODE in "$@"; do
   OUT=$(pwd)/gpurun_out/prof_${TAG}_$MODE
   rm -rf "$OUT"; mkdir -p "$OUT"
-  python3 scripts/bench_mode.py $MODE 3 > "$OUT/plain.json" 2> "$OUT/plain.err"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 scripts/bench_mode.py $MODE 3 > "$OUT/stats.json" 2> "$OUT/stats.err"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/bench_mode.py $MODE 3 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 scripts/bench_mode.py $MODE 3 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+  python3 scripts/bench_mode.py $MODE $REPS > "$OUT/plain.json" 2> "$OUT/plain.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 scripts/bench_mode.py $MODE $REPS > "$OUT/stats.json" 2> "$OUT/stats.err"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/bench_mode.py $MODE $REPS > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 scripts/bench_mode.py $MODE $REPS > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
   python3 scripts/summarize_modes.py "$TAG" "$MODE" "$OUT" "$OUT/summary" || true
 done

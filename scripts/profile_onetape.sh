@@ -35,5 +35,31 @@ with open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag), "w") as g
         for k in sorted(best): g.write("%-24s %16.0f  %6.1f %% of SQ_WAVE_CYCLES\n" % (k, best[k], 100 * best[k] / wc))
         g.write("\n")
 print(open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag)).read())
+# the figures bench.py quotes for config 5 (issue fraction of the occupied CUs): profiles/<tag>_onetape_sq.json
+import json
+dur = {}
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "k_wide_retimed" not in n: continue
+        key = "viterbi_fill" if "<1" in n.replace("(mb::", "<") or "1, " in n[:60] and "k_wide_retimed<1" in n else None
+        key = "viterbi_fill" if "k_wide_retimed<1" in n else "forward_cut_in_two"
+        d = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+        dur[key] = max(dur.get(key, 0.0), d)
+sweeps = {}
+for mode, key, cus in (("v", "viterbi_fill", 64), ("r", "forward_cut_in_two", 128)):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for sub in ("pmc_", "pmc2_"):
+        for f in glob.glob(os.path.join(out, sub + mode, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_wide_retimed" in r["Kernel_Name"]: per[sub][r["Counter_Name"]] += float(r["Counter_Value"])
+    if not per or key not in dur: continue
+    # counters summed over the run's k_wide_retimed dispatches (the run calls the sweep twice: first call + timed call), time likewise
+    ndisp = 2
+    sweeps[key] = {"SQ_INSTS_VALU": per["pmc2_"].get("SQ_INSTS_VALU", 0.0) / ndisp, "cus": cus, "seconds": dur[key],
+                   "SQ_WAIT_ANY": round(per["pmc_"].get("SQ_WAIT_ANY", 0.0) / max(per["pmc_"].get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
+json.dump({"what": "SQ_INSTS_VALU of one 64 x %s nt sweep / (SIMDs of the occupied CUs x cycles at 2.4 GHz) x 2 cycles per wave64 instruction on a SIMD-32, unweighted (fp64 at half rate: about 1.5 x); separate rocprofv3 --pmc passes, durations from the kernel trace" % os.environ.get("ONETAPE_LEN", "2000"),
+           "sweeps": sweeps}, open(os.path.join(out, "summary", "%s_onetape_sq.json" % tag), "w"), indent=1)
+print(json.dumps(sweeps))
 PY
 grep -E "forward|viterbi fill" "$OUT/stats.log"

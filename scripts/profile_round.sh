@@ -11,7 +11,7 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 bench.py --write-kernel-sha "$OUT/summary_kernel_sha.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu --no-extra > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --no-cpu --no-extra --steps 1 --warmup 0 > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --no-cpu --no-extra --steps 1 --warmup 0 > "$OUT/pmc_fetch.log" 2>&1

@@ -23,7 +23,7 @@ def pmc(sub, counter):
 
 w, r = pmc("pmc_write", "WRITE_SIZE"), pmc("pmc_fetch", "FETCH_SIZE")
 calls = plain["calls"]; cells = plain["cells_per_call"]
-per = {"counts": 16, "viterbi": 1, "forward3": 8, "forward2": 8, "counts4": 16, "viterbi4": 1, "forward4b": 8}[mode]
+per = {"counts": 16, "viterbi": 1, "forward3": 8, "forward2": 8, "counts4": 16, "viterbi4": 1, "forward4b": 8, "c4b_counts": 16}[mode]
 kern = {}
 for k in sorted(set(w) | set(r)):
     if not (k.startswith("k_small") or "traceback" in k or "k_medium" in k):
