@@ -1,9 +1,9 @@
 """The "current numbers" table of DESIGN.md section 4.3, generated from the last full bench line (profiles/<tag>_bench.json), so that
-the document quotes ONE figure per mode and says where it comes from.  usage: python scripts/design_numbers.py [tag=r04] [--write]
+the document quotes ONE figure per mode and says where it comes from.  usage: python scripts/design_numbers.py [tag=r05] [--write]
 --write replaces the text between <!-- NUMBERS:BEGIN --> and <!-- NUMBERS:END --> in DESIGN.md."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
 b = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench.json")))
 e = b["extra"]
 rows = []
@@ -19,14 +19,14 @@ def row(cfg, mode, fam, val, unit, frac, bound, issue, note=""):
 
 
 rf = b["roofline"]
-row("4a (headline)", "materialised Forward, 256 x 487 x 10 kb", "tiled", b["value"], "G cells/s", rf["frac"], "HBM, 8 B/cell", iss(rf), "%.0f us per launch, %d launches per step; traffic %.2f B/cell (recorded)" % (rf["avg_launch_us"], rf["launches_per_step"], (rf["traffic"] or 0) / max(rf["algorithmic_bytes_per_launch"], 1) * 8))
+row("4a (headline)", "materialised Forward, 256 x 487 x 10 kb", "tiled", b["value"], "G cells/s", rf["frac"], "HBM, 8 B/cell", iss(rf), "%.0f us per launch, %d launches per step; traffic %s" % (rf["avg_launch_us"], rf["launches_per_step"], ("%.2f B/cell (recorded, kernel hash verified)" % (rf["traffic"] / max(rf["algorithmic_bytes_per_launch"], 1) * 8)) if rf.get("traffic") else "not quoted (see recorded_constants.refused)"))
 row("4a", "rolling Forward (`--loglike`), same batch", "tiled", e.get("rolling_gcells_per_gpu"), "G cells/s", None, "latency at 2 wavefronts per SIMD", iss(e.get("rolling_rate")), "no matrix")
 v4 = e["viterbi4"]; row("4a", "Viterbi fill / with the paths on the host, 256 pairs", "tiled", "%s / %s" % (v4["fill_only"], v4["value"]), "G cells/s", v4["roofline"]["frac"], "1 B/cell; latency", iss(v4["roofline"]), "one traceback byte per cell")
 c4 = e["counts4"]; row("4a", "Backward fill + count sweep (`--train` E-step), 63 pairs", "tiled", c4["value"], "G lattice-cells/s", c4["roofline"]["frac"], "HBM, 16 B/lattice cell", iss(c4["roofline"]), "%.0f ms device" % c4["device_ms"])
 cb = e.get("config4b", {})
 if "forward_materialised" in cb:
     row("4b (literal composition, 482 states)", "materialised Forward 256 pairs / rolling", "tiled", "%s / %s" % (cb["forward_materialised"], cb["forward_rolling"]), "G cells/s", cb["roofline"]["frac"], "HBM, 8 B/cell", iss(cb["roofline"]), "composed on the box")
-    row("4b", "Viterbi fill / with paths (64 pairs); counts (24 pairs)", "tiled", "%s / %s; %s" % (cb["viterbi_fill"], cb["viterbi_with_paths"], cb["counts_lattice"]), "G (lattice-)cells/s", cb["roofline_counts"]["frac"], "counts: 16 B/lattice cell", "--", "counts: 3 wavefronts per CU")
+    row("4b", "Viterbi fill / with paths (64 pairs); counts (24 pairs)", "tiled", "%s / %s; %s" % (cb["viterbi_fill"], cb["viterbi_with_paths"], cb["counts_lattice"]), "G (lattice-)cells/s", cb["roofline_counts"]["frac"], "counts: 16 B/lattice cell", iss(cb["roofline_counts"]), "counts: 7 columns = 7 wavefronts per CU (4.1d)")
 c3 = e["counts"]; row("3", "Backward fill + count sweep, 1024 x 400 x 400 (per GPU)", "small", c3["value"], "G lattice-cells/s", c3["roofline"]["frac"], "HBM, 16 B", iss(c3["roofline"]), "%.2f ms device" % c3["device_ms"])
 f3 = e["forward_config3"]; row("3", "materialised Forward", "small", f3["value"], "G cells/s", f3["roofline"]["frac"], "HBM, 8 B", iss(f3["roofline"]))
 v2 = e["viterbi"]; row("2", "Viterbi fill / with paths, 1024 x 1 kb x 1 kb", "small", "%s / %s" % (v2["fill_only"], v2["value"]), "G cells/s", v2["roofline"]["frac"], "1 B/cell; issue", "--")
@@ -40,9 +40,19 @@ if "full_size" in c5:
             "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
     else:
         row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
+    if "counts_lattice" in fs:
+        row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "vector issue on 128 of 256 CUs", "--", "%.0f ms" % fs["counts_ms"])
     row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
+dr = e.get("dropin", {})
+for key, name in (("config4", "4a through the reference's call sites (8 pairs)"), ("config2", "2 through the reference's call sites (1024 pairs)")):
+    d = dr.get(key) or {}
+    if "unchanged_loop" in d:
+        u, pf, bc = d["unchanged_loop"], d["unchanged_loop_prefetch"], d["batch_c_abi"]
+        row(name, "`--loglike` / `--align` loops of boss.cpp through the C++ classes: unchanged / + the prefetch line / batch C-ABI", "--",
+            "%s, %s / %s, %s / %s, %s" % (u["loglike_pairs_per_s"], u["align_pairs_per_s"], pf["loglike_pairs_per_s"], pf["align_pairs_per_s"], bc["loglike_pairs_per_s"], bc["align_pairs_per_s"]),
+            "pairs/s", None, "host buffers in, host objects out", "--", "no fp64 matrix over PCIe (fetches: %d)" % (u["matrix_fills"] + pf["matrix_fills"]))
 cpu = b.get("cpu_baseline") or {}
-txt = ["Source: `profiles/%s_bench.json` (one `python3 bench.py` on the MI355X box; `frac` = algorithmic bytes / device time / 8 TB/s; `issue` = vector-issue fraction from the kernels' ISA, `profiles/r04_valu_model.json`, section 5).  Boxes of the pool differ by +-5 %%." % tag, "",
+txt = ["Source: `profiles/%s_bench.json` (one `python3 bench.py` on the MI355X box; `frac` = algorithmic bytes / device time / 8 TB/s; `issue` = vector-issue fraction from the kernels' ISA, `profiles/%s_valu_model.json`, section 5; recorded constants are quoted only while the kernel sources' hashes match `profiles/%s_kernel_sha.json`).  Boxes of the pool differ by +-5 %%." % (tag, tag, tag), "",
        "| Config | Mode | Family | Rate | HBM frac | Bound | Issue | Note |", "|---|---|---|---|---|---|---|---|"] + rows
 if cpu:
     txt += ["", "CPU baseline of the same run: %s %s on %d host cores (%s)." % (cpu["value"], cpu["unit"], cpu["cores"], cpu["kind"])]
