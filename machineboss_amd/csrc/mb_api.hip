@@ -909,6 +909,11 @@ int mb_set_option(const char *name, const char *value) {
 const char *mb_get_option(const char *name) {
   ApiLock lock;
   if (!name || strncmp(name, "MB_", 3) != 0) return nullptr;
+  if (strcmp(name, "MB_INFO_INPLACE_RING_KERNELS") == 0) {      // (read-only: kernel kinds that took the in-place ring so far, for tests)
+    static thread_local std::string v;
+    v = std::to_string(medium_inplace_kernels());
+    return v.c_str();
+  }
   return getenv(name);
 }
 
@@ -1576,6 +1581,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   // + 32: the PROGRAM instead of the source (see below)
   const int matKind = ((mode & 16) || (mode & 15) == MED_MODE_TB) ? MED_MAT_ROLL : MED_MAT_FULL;
   const bool dumpProgram = (mode & 32) != 0;
+  const bool compactRing = (mode & 64) != 0;      // + 64: the matrix-free kernel with the COMPACT ring (as many wavefronts as its LDS allows, at most 12)
   mode &= 15;
   MedProgram P; MedGeom geo;
   if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
@@ -1619,6 +1625,14 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
     return 0;
   }
   if (matKind == MED_MAT_ROLL) geo.haloSteps = 0;
+  if (compactRing) {
+    if (matKind != MED_MAT_ROLL || P.recC.empty()) { set_error("mb_debug_jit_source: no compact ring for this kernel kind"); return 1; }
+    geo.compact = true; geo.haloSteps = 0;
+    for (geo.waves = 12; geo.waves > 1; --geo.waves) {
+      geo.C = geo.waves * P.G;
+      if (medium_jit_lds_bytes(P, geo, mode == MED_MODE_TB ? MED_MODE_TB : MB_FORWARD) <= 160 * 1024 - 512) break;
+    }
+  }
   if (mode == MED_MODE_TB && !medium_tb_eligible(&m, P)) { set_error("machine does not qualify for traceback bytes on the tiled family"); return 1; }
   const std::string code = medium_jit_source(&m, P, geo, mode == MED_MODE_COUNT ? MED_MODE_COUNT : (mode == MED_MODE_TB ? MED_MODE_TB : (mode == MB_VITERBI ? MB_VITERBI : MB_FORWARD)), matKind);
   FILE *f = fopen(path, "w");

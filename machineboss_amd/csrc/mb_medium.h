@@ -107,6 +107,20 @@ struct MedProgram {
   int planC = 0, planHalo = 0, planWaves = 0;   // geometry the placement is made for (the program's own: its widest strips)
   int tokWindow = 64;                   // steps per output-token window kept in LDS by the specialised kernel
   std::vector<int> haloStates;          // states whose values another strip reads (sources of input-consuming candidates), ascending
+  // IN-PLACE RING (round 5).  What a step reads from EARLIER steps is (a) its own column's cells of the step before -- the sources of
+  // output-token candidates, which in a closure program all sit in the emit rounds of stage 0 -- and (b) the left column's cells of
+  // one / two steps before, but only the sources of input-consuming candidates (haloStates: 3 of psw2dna's 271 states).  So the
+  // matrix-free sum kernels keep per column ONE full vector, read as "the step before" by the emit rounds -- every load of stage 0 is
+  // issued before its first store -- and overwritten in place by this step's cells, + NS SHORT vectors of the halo states (this step's
+  // copy being written, the NS - 1 before it read by the right neighbour): 2.3 instead of 4.4 KB per column for psw2dna, 12 instead of
+  // 8 wavefronts per CU.  recC = rec with the input-consuming tables' source offsets renamed into the short vector (padding: its own
+  // -inf entry) and, in the upper half of slot 0's dstOff, 8 x (place of the destination in the short vector + 1) or 0.
+  std::vector<unsigned char> recT;      // table of each record
+  std::vector<MedRec> recC;
+  MedRec *d_recC = nullptr, *d_ldsImageC = nullptr;
+  bool inPlaceOk = false;               // every emit round precedes the first synchronisation point, none in the running form, few enough slots
+  signed char compactState[24 * 2] = {0};   // per kernel kind (medium_jit_slot / MED_GEOM_LEVELS): 0 untried, 1 compact ring in use, -1 not
+  int compactWaves[24 * 2] = {0};
   int *d_desc = nullptr;
   MedRec *d_rec = nullptr, *d_ldsImage = nullptr;
   MedProgDev dev{};
@@ -118,7 +132,9 @@ struct MedProgram {
 // haloSteps > 0: the materialised kernel loads the halo supercells of a whole tile (at most haloSteps steps) into LDS in
 // its prologue, so its step loop issues NO vector-memory load (machines with few states, where a step is shorter than
 // the time the previous step's stores need to be acknowledged)
-struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; int level = 0; bool env = false; };   // env: the kernel variant that clips to the pairs' envelopes
+struct MedGeom { int waves = 0, C = 0; size_t ldsBytes = 0; int haloSteps = 0; int level = 0; bool env = false;   // env: the kernel variant that clips to the pairs' envelopes
+  bool compact = false;   // the IN-PLACE RING of the matrix-free sum kernels (round 5, MedProgram::inPlaceOk): more columns in the same LDS
+};
 
 // restricted envelopes of the pairs (PairDesc::envBase rows of the batch's inStart / inEnd arrays): device copies for the
 // kernel, host copies for the tile lists (tiles outside every envelope row are not launched); all null = full envelopes
@@ -163,6 +179,7 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P);
 void medium_jit_plan(const mb_machine *m, MedProgram &P, const MedGeom &geo);
 void medium_count_layout(const mb_machine *m, MedProgram &P);      // flat count programs, after every medium_jit_plan: accumulator offsets of the usage records by placement
 int medium_jit_max_cands();
+long long medium_inplace_kernels();      // kernel kinds that took the in-place ring so far (introspection)
 long long medium_jit_spill_count(const std::string &codeObject);
 size_t medium_jit_lds_bytes(const MedProgram &P, const MedGeom &geo, int mode = MB_FORWARD);
 std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const MedGeom &geo, int mode, int matKind);
@@ -179,8 +196,12 @@ int medium_fill_materialised(const mb_machine *m, MedProgram &P, const MedGeom &
                              const PairDesc *d_pairs, const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out,
                              double *d_pool, hipStream_t st, const MedEnv &env = MedEnv());
 // run-time specialisation (mb_medium_jit.cpp): returns false if hiprtc is unavailable or the program does not qualify
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int matKind);
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geo, int mode, int matKind, bool allowReplan = true);
 inline int medium_jit_slot(int mode, int matKind, int level, bool env = false) { return ((3 * medium_jit_index(mode) + matKind) * 2 + (env ? 1 : 0)) * MED_GEOM_LEVELS + level; }
+inline int medium_compact_len(const MedProgram &P) { return ((int)P.haloStates.size() + 2) & ~1; }      // halo states + the -inf entry, even
+// geometry of a matrix-free sweep: the compact ring's (tried once per kernel kind: its kernel must compile into the registers its
+// wavefront count leaves, without touching the program's placement) or the plain one
+MedGeom medium_roll_geometry(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const std::vector<PairDesc> &pairs, int mode, int matKind, bool env, bool materialiseRule);
 inline bool medium_jit_ready(const MedProgram &P, int mode, int matKind) {
   for (int h = 0; h < MED_GEOM_LEVELS; ++h) if (P.jit[medium_jit_slot(mode, matKind, h, false)].func || P.jit[medium_jit_slot(mode, matKind, h, true)].func) return true;
   return false;

@@ -673,6 +673,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
       P.desc[db + 4] = stride;
       P.rec.resize(b0 + (size_t)c.n * stride, padRec);
       P.wref.resize(b0 + (size_t)c.n * stride, -1);
+      P.recT.resize(b0 + (size_t)c.n * stride, (unsigned char)c.T);
       for (int k = 0; k < c.n; ++k) {
         P.roundInfo.back().slots.push_back({c.T, (long long)b0 + (long long)k * stride});
       }
@@ -695,6 +696,18 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
   }
   std::sort(P.haloStates.begin(), P.haloStates.end());
   P.haloStates.erase(std::unique(P.haloStates.begin(), P.haloStates.end()), P.haloStates.end());
+  {   // in-place ring (mb_medium.h): the emit rounds must all lie in the first stage, in the straight-line form, and be few
+    int firstSync = -1, lastEmit = -1; long long slots0 = 0; bool anyBig = false;
+    for (size_t r = 0; r < P.roundInfo.size(); ++r) {
+      const MedRoundInfo &ri = P.roundInfo[r];
+      bool emit = false;
+      for (const MedSlotInfo &sl : ri.slots) emit = emit || sl.T < 3;
+      if (emit) { lastEmit = (int)r; if ((int)ri.slots.size() > medium_jit_max_cands()) anyBig = true; }
+      if (firstSync < 0) { slots0 += (long long)ri.slots.size(); if (ri.sync) firstSync = (int)r; }
+    }
+    if (firstSync < 0) firstSync = (int)P.roundInfo.size() - 1;
+    P.inPlaceOk = closure != 0 && lastEmit >= 0 && lastEmit <= firstSync && !anyBig && slots0 <= env_int_m("MB_MEDIUM_INPLACE_MAXSLOTS", 48);
+  }
   P.fusedEmit = fuse;
   if (!fuse) for (MedRoundInfo &ri : P.roundInfo) ri.fused = false;
   if (countFuse && !fuse) for (MedRec &r : P.rec) r.dstOff &= 0xFFFFu;
@@ -743,6 +756,21 @@ void medium_eval_weights(const mb_machine *m, MedProgram &P) {
     const int r = P.wref[k];
     P.rec[k].w = r >= 0 ? m->logW[r] : (r == -1 ? -INFINITY : pairW[-2 - r]);
   }
+  // the in-place ring's copy (MedProgram::recC): sources of the input-consuming tables by their place in the short vector (padding: the
+  // short vector's own -inf entry), the destination's place + 1 in the upper half of dstOff
+  P.recC.clear();
+  if (!P.counting && P.inPlaceOk && P.Spad * 8 < (1 << 16) && P.recT.size() == P.rec.size()) {
+    std::vector<int> place((size_t)P.Spad + 2, -1);
+    for (size_t k = 0; k < P.haloStates.size(); ++k) place[(size_t)P.haloStates[k]] = (int)k;
+    const uint32_t KH = (uint32_t)P.haloStates.size();
+    P.recC = P.rec;
+    for (size_t k = 0; k < P.recC.size(); ++k) {
+      MedRec &r = P.recC[k];
+      if (P.recT[k] < 2) { const uint32_t st = r.srcOff >> 3; r.srcOff = ((st < place.size() && place[st] >= 0) ? (uint32_t)place[st] : KH) * 8u; }
+      const uint32_t d = r.dstOff >> 3;
+      if (d < place.size() && place[d] >= 0) r.dstOff |= ((uint32_t)(place[d] + 1) * 8u) << 16;
+    }
+  }
 }
 
 bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
@@ -754,6 +782,12 @@ bool medium_refresh_weights(const mb_machine *m, MedProgram &P) {
   if (!up(P.d_ldsImage, img)) return false;
   P.dev.ldsImage = P.d_ldsImage;
   if (P.counting) { if (!up(P.d_accMap, P.accMap)) return false; P.dev.accMap = P.d_accMap; }
+  if (!P.recC.empty()) {
+    if (!up(P.d_recC, P.recC)) return false;
+    std::vector<MedRec> imgC(P.ldsImageIdx.size());
+    for (size_t k = 0; k < imgC.size(); ++k) imgC[k] = P.recC[P.ldsImageIdx[k]];
+    if (!up(P.d_ldsImageC, imgC)) return false;
+  }
   return true;
 }
 
@@ -867,6 +901,7 @@ static void append_flat_usage(const mb_machine *m, MedProgram &P) {
       const size_t b0 = P.rec.size();
       P.rec.resize(b0 + (size_t)ntokT[T] * LPG);
       P.wref.resize(b0 + (size_t)ntokT[T] * LPG, -1);
+      P.recT.resize(b0 + (size_t)ntokT[T] * LPG, (unsigned char)T);
       ri.slots.push_back({T, (long long)b0});
       for (long long tok = 0; tok < ntokT[T]; ++tok)
         for (int ln = 0; ln < LPG; ++ln) {
@@ -977,7 +1012,7 @@ bool medium_build_count(const mb_machine *m, int G, MedProgram &P, MedGeom &geo,
 
 void medium_free(MedProgram &P) {
   medium_jit_free(P);
-  void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage, P.d_accMap};
+  void *ptrs[] = {P.d_desc, P.d_rec, P.d_ldsImage, P.d_accMap, P.d_recC, P.d_ldsImageC};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   P = MedProgram();
 }
@@ -1121,6 +1156,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
   if ((mode == MED_MODE_COUNT || mode == MED_MODE_TB || matKind == MED_MAT_ROLL || geo.env) && !J) { sm_free(d_tiles); return -1; }   // no ahead-of-time kernel for these
   MedProgDev dev = devIn;
   dev.rec = P.dev.rec; dev.ldsImage = P.dev.ldsImage; dev.ldsImageRecs = (int)P.ldsImageIdx.size();
+  if (geo.compact) { dev.rec = P.d_recC; dev.ldsImage = P.d_ldsImageC; }
   MedTileArgs A{};
   A.pairs = d_pairs; A.inTok = d_in; A.outTok = d_out; A.pool = d_pool; A.colHalo = nullptr; A.haloBase = nullptr;
   A.loglike = d_loglike; A.tiles = d_tiles; A.C = C; A.TS = TS; A.rev = P.backward ? 1 : 0; A.materialise = 1;
@@ -1189,6 +1225,60 @@ MedGeom medium_pick_geometry(const MedProgram &P, const MedGeom &geo, const std:
   return best;
 }
 
+// The in-place ring's geometry (MedProgram::inPlaceOk): as many wavefronts as its LDS footprint allows (MB_MEDIUM_COMPACT_MAXWAVES, 12),
+// decided ONCE per kernel kind by compiling the kernel: it must fit the registers that wavefront count leaves WITHOUT a re-plan (the
+// placement is shared with the program's other kernels; the traceback-byte program, whose only other kernel serves mb_fill, may
+// re-plan), else the kind keeps the plain ring.  OFF unless MB_MEDIUM_INPLACE_RING=1: psw2dna's rolling sweeps run 1 128-1 190 G cells/s at 12
+// wavefronts against 1 200-1 319 at the plain ring's 8 (9 wavefronts: 1 000) -- a SIMD's time grows with the wavefronts on it.
+static long long g_inplace_kernels = 0;
+long long medium_inplace_kernels() { return g_inplace_kernels; }
+MedGeom medium_roll_geometry(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const std::vector<PairDesc> &pairs, int mode, int matKind, bool env, bool materialiseRule) {
+  const int kind = (3 * medium_jit_index(mode) + matKind) * 2 + (env ? 1 : 0);
+  auto plain = [&]() { MedGeom g = medium_pick_geometry(P, geoIn, pairs, materialiseRule); g.env = env; g.haloSteps = 0; return g; };
+  if (matKind == MED_MAT_FULL || mode != MB_FORWARD || P.counting || P.recC.empty() || !P.d_recC || P.LPG <= 2 || env_int_m("MB_MEDIUM_INPLACE_RING", 0) == 0) return plain();      // (off by default: measured, it does not pay -- DESIGN.md 4.1d)
+  if (P.compactState[kind] < 0) return plain();
+  if (P.compactState[kind] == 0) {
+    P.compactState[kind] = -1;
+    const int KC = medium_compact_len(P);
+    if ((long long)P.Spad + (long long)P.NS * KC >= (long long)P.NS * P.Spad) return plain();      // nothing to gain (nearly every state is read across columns)
+    MedGeom g = geoIn;
+    g.compact = true; g.env = env; g.haloSteps = 0; g.level = 0;
+    const int maxWaves = std::min(16, env_int_m("MB_MEDIUM_COMPACT_MAXWAVES", 12));
+    for (g.waves = maxWaves; g.waves > geoIn.waves; --g.waves) {
+      g.C = g.waves * P.G;
+      g.ldsBytes = (size_t)(g.C + 1) * (size_t)(P.Spad + P.NS * KC) * sizeof(double);
+      if (medium_jit_lds_bytes(P, g, mode) <= 160 * 1024 - 512) break;
+    }
+    if (g.waves <= geoIn.waves) return plain();
+    MedJit &J = P.jit[medium_jit_slot(mode, matKind, 0, env)];
+    if (J.tried && !J.func) return plain();                                                       // (the kind has no specialised kernel at all)
+    if (J.module) (void)hipModuleUnload((hipModule_t)J.module);
+    J = MedJit();
+    // (9 ... 12 wavefronts leave a wavefront the same 168 registers, 5 ... 8 the same 256: at most two attempts -- the most wavefronts
+    //  the LDS allows, then 8 when that is still more than the plain ring's)
+    bool ok = medium_jit_get(m, P, g, mode, matKind, /*allowReplan=*/false);
+    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring (mode %d, matrix kind %d%s): %zu of %d states per short vector, %d wavefronts -> %s\n", mode, matKind, env ? ", envelopes" : "",
+                                                  P.haloStates.size(), m->S, g.waves, ok ? "in use" : "does not fit its registers");
+    if (!ok && g.waves > 8 && geoIn.waves < 8) {
+      J = MedJit();
+      g.waves = 8; g.C = g.waves * P.G;
+      g.ldsBytes = (size_t)(g.C + 1) * (size_t)(P.Spad + P.NS * KC) * sizeof(double);
+      ok = medium_jit_get(m, P, g, mode, matKind, /*allowReplan=*/false);
+      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring: 8 wavefronts -> %s\n", ok ? "in use" : "does not fit its registers: plain ring");
+    }
+    if (!ok) { J = MedJit(); return plain(); }
+    P.compactState[kind] = 1;
+    P.compactWaves[kind] = g.waves;
+    ++g_inplace_kernels;
+  }
+  MedGeom base = geoIn;
+  base.compact = true; base.waves = P.compactWaves[kind]; base.C = base.waves * P.G;
+  MedGeom g = medium_pick_geometry(P, base, pairs, materialiseRule);
+  g.compact = true; g.env = env; g.haloSteps = 0;
+  g.ldsBytes = (size_t)(g.C + 1) * (size_t)(P.Spad + P.NS * medium_compact_len(P)) * sizeof(double);
+  return g;
+}
+
 static int max_out_len(const std::vector<PairDesc> &pairs) {
   int mx = 0;
   for (const PairDesc &pd : pairs) mx = std::max(mx, pd.outLen);
@@ -1234,7 +1324,7 @@ static int roll_buffers(const MedProgram &P, const MedGeom &geo, const std::vect
     const long long NA = (pairs[p].inLen + geo.C) / geo.C;
     base[p] = haloD; base[n + p] = boundD;
     haloD += NA * (pairs[p].outLen + 1) * H;
-    boundD += NA * (P.NS - 1) * geo.C * P.dev.S;
+    boundD += NA * ((P.NS - 1) * geo.C * P.dev.S + (geo.compact ? (long long)(geo.C * (P.dev.S + (P.NS - 1) * medium_compact_len(P))) : 0));      // (in-place ring: the full vectors of the last step + the short ones)
   }
   if (!hip_ok(sm_alloc((void **)d_bases, 2 * n * sizeof(long long)), "hipMalloc(roll bases)")) return 1;
   if (!hip_ok(hipMemcpyAsync(*d_bases, base.data(), 2 * n * sizeof(long long), hipMemcpyHostToDevice, st), "H2D roll bases") ||
@@ -1254,8 +1344,7 @@ int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, 
                       const int *d_in, const int *d_out, unsigned char *d_tb, double *d_loglike, hipStream_t st, const MedEnv &env) {
   if (pairsIn.empty()) return 0;
   if (!medium_tb_eligible(m, P)) return -1;
-  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
-  geo.env = env.d_start != nullptr; geo.haloSteps = 0;
+  MedGeom geo = medium_roll_geometry(m, P, geoIn, pairsIn, MED_MODE_TB, MED_MAT_ROLL, env.d_start != nullptr, true);
   // the byte vectors of a step (one per column) need LDS the widest strip does not leave: columns are given up, one wavefront
   // at a time, until they fit (psw2dna: 32 -> 28 columns); the same rule for every batch, so a strip level maps to one kernel
   while (geo.waves > 1 && medium_jit_lds_bytes(P, geo, MED_MODE_TB) > 160 * 1024) { --geo.waves; geo.C = geo.waves * P.G; }
@@ -1278,9 +1367,13 @@ int medium_viterbi_tb(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, 
 int medium_forward_rolltiles(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, const PairDesc *d_pairs, const std::vector<PairDesc> &pairsIn,
                              const int *d_in, const int *d_out, double *d_loglike, hipStream_t st, const MedEnv &env) {
   if (pairsIn.empty()) return 0;
-  MedGeom geo = medium_pick_geometry(P, geoIn, pairsIn, true);
-  geo.env = env.d_start != nullptr; geo.haloSteps = 0;
-  if (P.counting || !medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_ROLL)) return -1;
+  if (P.counting) return -1;
+  MedGeom geo = medium_roll_geometry(m, P, geoIn, pairsIn, MB_FORWARD, MED_MAT_ROLL, env.d_start != nullptr, true);
+  if (!medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_ROLL)) {
+    if (!geo.compact) return -1;
+    geo = medium_pick_geometry(P, geoIn, pairsIn, true); geo.env = env.d_start != nullptr; geo.haloSteps = 0;      // (a narrower strip level whose compact kernel does not build)
+    if (!medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_ROLL)) return -1;
+  }
   std::vector<PairDesc> pairs = pairsIn;
   for (PairDesc &pd : pairs) pd.launch0 = 0;
   MedRoll R; long long *d_bases = nullptr;
@@ -1382,7 +1475,8 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
                            const std::vector<PairDesc> &pairs, const int *d_in, const int *d_out, double *d_colHalo,
                            const long long *d_haloBase, double *d_loglike, hipStream_t st) {
   if (pairs.empty()) return 0;
-  const MedGeom geo = medium_pick_geometry(P, geoIn, pairs, false);
+  MedGeom geo = medium_roll_geometry(m, P, geoIn, pairs, MB_FORWARD, MED_MAT_NONE, false, false);
+  if (geo.compact && !medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_NONE)) { geo = medium_pick_geometry(P, geoIn, pairs, false); }      // (the ahead-of-time twin knows the plain ring only)
   set_lds_attr();
   int maxIn = 0, maxOut = 0;
   for (const PairDesc &pd : pairs) { maxIn = std::max(maxIn, pd.inLen); maxOut = std::max(maxOut, pd.outLen); }
@@ -1394,6 +1488,7 @@ int medium_forward_rolling(const mb_machine *m, MedProgram &P, const MedGeom &ge
   const MedJit *J = medium_jit_get(m, P, geo, MB_FORWARD, MED_MAT_NONE) ? &P.jit[medium_jit_slot(MB_FORWARD, MED_MAT_NONE, geo.level)] : nullptr;
   MedProgDev dev = P.dev;
   dev.ldsImageRecs = (int)P.ldsImageIdx.size();
+  if (geo.compact) { dev.rec = P.d_recC; dev.ldsImage = P.d_ldsImageC; }
   for (int a = 0; a < NA; ++a) {
     A.launch = a;
     ++g_last_launches;

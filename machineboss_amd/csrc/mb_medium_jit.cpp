@@ -46,9 +46,11 @@ static int jit_debug_bits() {
 #endif
 }
 
-static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) {   // rounded up to 16 bytes: the record image follows
-  return ((((size_t)P.NS * (geo.C + 1) * P.Spad + 1) & ~(size_t)1)) * sizeof(double);
+static size_t ring_doubles(const MedProgram &P, const MedGeom &geo) {   // even: the record image follows, 16-byte aligned
+  const size_t perCol = geo.compact ? (size_t)P.Spad + (size_t)P.NS * medium_compact_len(P) : (size_t)P.NS * P.Spad;      // compact ring: one full vector + NS short ones
+  return (perCol * (geo.C + 1) + 1) & ~(size_t)1;
 }
+static size_t ring_bytes(const MedProgram &P, const MedGeom &geo) { return ring_doubles(P, geo) * sizeof(double); }
 static size_t tok_bytes(const MedProgram &P, const MedGeom &geo) { return 3 * 2ull * (size_t)(P.tokWindow + geo.C) * sizeof(int); }   // output tokens + the envelope rows (start, end) of the same window
 
 // count programs: one Backward supercell per column + the loop-time count accumulators.  A flat program's all-transition table (one
@@ -189,6 +191,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
        << "\n#define JFLAT " << (P.flatCount ? 1 : 0) << "\n#define JNACC " << P.accEntries << "\n#define JNTRANS " << m->nTrans
        << "\n#define JNALL " << P.accAllEntries << "\n#define JNLOOP " << std::max(0, P.accEntries - P.LPG) << "\n#define JACCOFF " << (P.counting ? acc_offset(P, geo) : 0)
        << "\n#define JNOUT " << m->nOut << "\n#define JENDNODE " << P.dev.endNode
+       << "\n#define JCR " << (geo.compact ? 1 : 0) << "\n#define JKC " << medium_compact_len(P) << "\n#define JRINGD " << ring_doubles(P, geo)
        << "\n#define JLDSRECS " << (long long)P.ldsImageIdx.size() << "\n#define JTOKW " << P.tokWindow
        << "\n#define JTOKN " << (P.tokWindow + geo.C - 1 + threads - 1) / threads
        << "\n#define JDUMMYOFF " << P.dummyOff << "\n#define JHALO " << (S + threads - 1) / threads << "\n";
@@ -208,6 +211,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   const bool stageLoads = env_int("MB_JIT_STAGE_LOADS", 1) != 0;
   const int stageMaxLoads = std::max(1, env_int("MB_JIT_STAGE_MAXLOADS", 32));
   int stagePending = 0;
+  bool firstStageDone = false;
   std::ostringstream sLoad, sBig, sFold;
   auto flushStage = [&]() {
     stagePending = 0;
@@ -284,7 +288,9 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
     auto V = [&](int k) { return "v" + R + "_" + std::to_string(k); };
     auto E = [&](int k) { return "e" + R + "_" + std::to_string(k); };
     std::vector<std::string> nm(n);
-    if (!big) { if (stagePending > 0 && stagePending + n > stageMaxLoads) flushStage(); stagePending += n; }
+    // (in-place ring: the first stage's emit rounds read the column's vector as "the step before" and overwrite it -- every load of the stage
+    //  goes in front of its first store, whatever the batch size; MedProgram::inPlaceOk bounds the stage's slots)
+    if (!big) { if (stagePending > 0 && stagePending + n > stageMaxLoads && !(geo.compact && !firstStageDone)) flushStage(); stagePending += n; }
     sFold << "        // round " << r << ": " << n << " candidate slot(s)\n";
     if (tbmode) {
       // max semiring with the index of the FIRST maximal candidate: slots come table by table (match, input-only, output-only,
@@ -300,8 +306,10 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
         const int code = (ri.slots[k].T << 6) | perT[ri.slots[k].T]++;
         sFold << "        { const bool g = " << V(k) << " > res" << R << "; res" << R << " = g ? " << V(k) << " : res" << R << "; x" << R << " = g ? " << code << "u : x" << R << "; }\n";
       }
-      sFold << "        const int dOff" << R << " = (int)(active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF);\n";
+      sFold << "        const unsigned dW" << R << " = active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF;\n";
+      sFold << "        const int dOff" << R << " = (int)DSTOFF(dW" << R << ");\n";
       sFold << "        *(double *)(ldsb + (aCur + dOff" << R << ")) = JCLIP(res" << R << ");\n";
+      sFold << "        JCSTORE(dW" << R << ", JCLIP(res" << R << "));\n";
       sFold << "        tbCol[dOff" << R << " >> 3] = (unsigned char)x" << R << ";\n";
     } else if (!big) {
       for (int k = 0; k < n; ++k) nm[k] = rec(k);
@@ -325,7 +333,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
           sFold << ";\n        const double res" << R << " = gM" << R << " + (double)(__builtin_amdgcn_logf(sm" << R << ") * MED_LN2);\n";
         }
       }
-      sFold << "        *(double *)(ldsb + (aCur + (int)(active ? DSTOFF(" << nm[0] << ".dstOff) : (unsigned)JDUMMYOFF))) = JCLIP(res" << R << ");\n";
+      sFold << "        { const unsigned dW = active ? " << nm[0] << ".dstOff : (unsigned)JDUMMYOFF; *(double *)(ldsb + (aCur + (int)DSTOFF(dW))) = JCLIP(res" << R << "); JCSTORE(dW, JCLIP(res" << R << ")); }\n";
       if (ri.fused && !(jit_debug_bits() & 16))
         for (int k = 0; k < n; ++k) {
           const MedSlotInfo &sl = ri.slots[k];
@@ -374,11 +382,11 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
       }
       if (maxmode) sBig << "        const double res = accM;\n";
       else sBig << "        const double res = ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);\n";
-      sBig << "        *(double *)(ldsb + (aCur + (int)(active ? DSTOFF(dstOff) : (unsigned)JDUMMYOFF))) = JCLIP(res);\n";
+      sBig << "        { const unsigned dW = active ? dstOff : (unsigned)JDUMMYOFF; *(double *)(ldsb + (aCur + (int)DSTOFF(dW))) = JCLIP(res); JCSTORE(dW, JCLIP(res)); }\n";
       sBig << "        }\n";
     }
-    if (ri.sync || !stageLoads) flushStage();
-    if (ri.sync) body << "      med_wave_sync();\n";
+    if (ri.sync || (!stageLoads && !(geo.compact && !firstStageDone))) flushStage();
+    if (ri.sync) { body << "      med_wave_sync();\n"; firstStageDone = true; }
   }
   flushStage();
   std::string src = kMedJitSkeleton;
@@ -394,7 +402,7 @@ std::string medium_jit_source(const mb_machine *m, const MedProgram &P, const Me
   return src;
 }
 
-bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, int mode, int matKind) {
+bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, int mode, int matKind, bool allowReplan) {
   MedGeom geo = geoIn;
   if (matKind != MED_MAT_FULL) geo.haloSteps = 0;   // only the matrix kernel pre-loads a tile's halo supercells
   const bool materialise = matKind == MED_MAT_FULL;
@@ -437,6 +445,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
     if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs (scratch %lld bytes)\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : (mode == MED_MODE_TB ? "max+tb" : "sum")), P.regBudget, spills, jit_kernel_meta(code, ".private_segment_fixed_size"));
     // (the LAST attempt keeps what it compiled: re-planning behind it would leave the placement -- the LDS image, the record tables
     // the host refreshes -- one step ahead of the code; round 4 found exactly that, counts of 1e19, when a kernel never stopped spilling)
+    if (spills > 0 && !allowReplan) return false;      // (a trial build that must not touch the program's placement: medium_roll_geometry)
     if (spills <= 0 || P.regBudget == 0 || attempt == 7) break;
     // the compiler ran out of VGPRs: move records from registers to LDS / global and regenerate.  The placement is
     // shared by both semirings of this program, so a kernel already built for the other one is dropped.

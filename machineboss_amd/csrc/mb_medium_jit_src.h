@@ -61,9 +61,22 @@ struct MedTileArgs {
 #if JMODE == 2
 #define SRCOFF(x) ((int)((x) & 0xFFFFu))
 #define DSTOFF(x) ((x) & 0xFFFFu)      // (upper half of a fused emit round's slot-0 record: the real state's place in the Backward supercell)
+#elif JCR
+#define SRCOFF(x) ((int)(x))
+#define DSTOFF(x) ((x) & 0xFFFFu)      // (upper half: 8 x (the state's place in the column's short vector + 1), 0 = not one of its states)
 #else
 #define SRCOFF(x) ((int)(x))
 #define DSTOFF(x) (x)
+#endif
+// IN-PLACE RING (JCR, mb_medium.h MedProgram::inPlaceOk): per column ONE full vector -- the cells of the step before when the emit rounds
+// of stage 0 read it (aDown = aCur: all their loads are issued before the stage's first store), this step's cells afterwards -- and JNS
+// short vectors of the halo states (JNH: the sources of input-consuming candidates, all a neighbouring column ever reads):
+// [cells: JSPAD][short 0: JKC] ... [short JNS-1: JKC]; step t writes short vector t % JNS beside the full one, the column to the right
+// reads (t - 1) % JNS (aLeft) and (t - 2) % JNS (aDiag)
+#if JCR
+#define JCSTORE(d, v) do { if ((d) >> 16) *(double *)(ldsb + (aCompW + (int)((d) >> 16) - 8)) = (v); } while (0)
+#else
+#define JCSTORE(d, v) do { } while (0)
 #endif
 typedef const __attribute__((address_space(4))) int *cdesc_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -129,9 +142,10 @@ __device__ __forceinline__ void med_copy_out(double *dstp, const double *cur, in
 }
 
 // generic evaluation of one supercell from the descriptors (origin supercell only; same as the AOT slow path)
-__device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int myColBase,
-                                                int sCur, int sPrev, int sPrev2, int colStride, int it, int ot, int q,
+__device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int nChunks, const char *ldsb, int aDiag, int aLeft, int aDown, int aCur, int aCompW,
+                                                int it, int ot, int q,
                                                 unsigned seedOff, bool origin, bool lanesOn, int aB, unsigned accBase, double negLL, int tbCol, int jdet) {
+  (void)aCompW;
   double accM = NEG_INF; float accS = 0.0f; (void)jdet;
   unsigned code = 0u, prevT = 99u, jT = 0u;   // JTB: (table << 6 | index in the table's list) of the first maximal candidate
   (void)code; (void)prevT; (void)jT; (void)tbCol;
@@ -140,8 +154,9 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
     const int hdr = dp[0];
     const int ns = hdr & 15;
     const bool first = (hdr >> 4) & 1, last = (hdr >> 5) & 1, sync = (hdr >> 6) & 1;
-    unsigned dstOff = 0xFFFFFFFFu;
-    const int vecBase = myColBase + med_vofs((unsigned)dp[3] >> 24, sCur, sPrev, sPrev2, colStride);
+    unsigned dstOff = 0xFFFFFFFFu, dstW = 0u;
+    const unsigned vsel = (unsigned)dp[3] >> 24;
+    const int vecBase = vsel == 3 ? aCur : (vsel == 0 ? aDiag : (vsel == 1 ? aLeft : aDown));
     const int idx0 = (int)__umul24(it, dp[2]) + (int)__umul24(ot, dp[3] & 0xFFFFFF) + dp[1] + q;
     const unsigned Tsel = (unsigned)dp[3] >> 24;
     if (first || Tsel != prevT) jT = 0u;
@@ -150,7 +165,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
       const Rec r = mk_rec(grec[idx0 + k * dp[4]]);
       bool firstCand = false;
       if (k == 0) {
-        dstOff = DSTOFF(r.dstOff);
+        dstOff = r.dstOff == 0xFFFFFFFFu ? r.dstOff : DSTOFF(r.dstOff); dstW = r.dstOff;
         if (first) {
           const bool seed = origin && dstOff == seedOff;
           accM = seed ? 0.0 : NEG_INF; accS = seed ? 1.0f : 0.0f;
@@ -178,7 +193,7 @@ __device__ __noinline__ void med_slow_supercell(cdesc_t desc, grec_t grec, int n
     }
     if (last) {
       const double res = (JMODE == 1) ? accM : ((accM == NEG_INF) ? 0.0 : accM) + (double)(__builtin_amdgcn_logf(accS) * MED_LN2);
-      if (lanesOn && (int)dstOff >= 0) *(double *)(ldsb + (myColBase + sCur + (int)dstOff)) = res;
+      if (lanesOn && (int)dstOff >= 0) { *(double *)(ldsb + (aCur + (int)dstOff)) = res; JCSTORE(dstW, res); }
 #if JTB
       if (lanesOn && (int)dstOff >= 0) *(unsigned char *)(ldsb + (tbCol + (int)(dstOff >> 3))) = (unsigned char)code;
 #endif
@@ -228,11 +243,16 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     haloIn = hb + (long long)max(a - 1, 0) * hsz;
     haloOut = hb + (long long)a * hsz;
   }
+#if JCR
+  double *bnd = A.bound + A.boundBase[pairIdx] + (long long)a * ((NS - 1) * C * S + C * (S + (NS - 1) * JKC));      // (in-place ring: full vectors of the last step + the short ones; sized by roll_buffers)
+#else
   double *bnd = A.bound + A.boundBase[pairIdx] + (long long)a * ((NS - 1) * C * S);
+#endif
   // the states this thread moves between a halo row and column 0 of the ring: entries tid, tid + NT, ... of the row
   int myHS[JNHR];
 #pragma unroll
   for (int k = 0; k < JNHR; ++k) myHS[k] = JHSTATE(min(tid + k * NT, JNHP - 1));
+  (void)myHS;
 #endif
 #if JTB
   unsigned char *tbPair = A.tb + pd.cellBase;
@@ -241,8 +261,14 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     const long long ri = rev ? inLen - ci : ci, ro = rev ? outLen - co : co;
     return cells + (ro * I + ri) * S;
   };
+#if JCR
+  constexpr int KCV = JKC, COLD = Spad + NS * JKC;      // doubles per short vector / per column
+  auto curOf = [&](int col) -> double * { return lds + (long long)col * COLD; };                              // ring column `col` (0 = the strip's left neighbour): this step's cells
+  auto shortOf = [&](int slot, int col) -> double * { return lds + (long long)col * COLD + Spad + slot * KCV; };   // ... its short vector of step parity `slot`
+#else
   auto ring = [&](int slot, int col) -> double * { return lds + ((long long)slot * (C + 1) + col) * Spad; };
-  char *ldsRec = (char *)(lds + (((long long)NS * (C + 1) * Spad + 1) & ~1ll));   // 16-byte aligned
+#endif
+  char *ldsRec = (char *)(lds + JRINGD);   // 16-byte aligned
   // output tokens of the sweep, kept in LDS one window of W steps at a time (double buffered): window k holds the
   // tokens of o in [k*W - C + 1, k*W + W - 1]; the token of column c at step t sits at index (t % W) + (C - 1 - c).
   int *tokWin = (int *)(ldsRec + (long long)JLDSRECS * 16);
@@ -284,7 +310,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
 #endif
 
-  for (int j = tid; j < NS * (C + 1) * Spad; j += NT) lds[j] = NEG_INF;
+  for (int j = tid; j < JRINGD; j += NT) lds[j] = NEG_INF;
 #if JNBSYNC
   // NEIGHBOUR SYNCHRONISATION.  A step of column c reads what column c - 1 held one step earlier, and overwrites the ring slot
   // column c + 1 read one step earlier: a wavefront depends on its two NEIGHBOUR wavefronts only (and the halo rows are moved by
@@ -311,6 +337,32 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   __syncthreads();
   // ring state of steps t0-1 (and t0-2 when match edges exist); flat index over (column, state) so that machines with
   // few states still use every thread
+#if JCR
+  // in-place ring: what earlier steps hand over is, per column of the strip, the full vector of step t0 - 1 and the short vectors of
+  // steps t0 - 1 (and t0 - 2) -- JMAT 2: from the boundary record of block b - 1 --, and for column 0 (the strip to the left) the short
+  // vectors from its halo column
+#if JMAT == 2
+  if (b > 0 && !prevDead) {
+    for (int idx = tid; idx < C * S; idx += NT) { const int cc = idx / S, j = idx - cc * S; curOf(cc + 1)[j] = bnd[idx]; }
+    for (int dt = 1; dt < NS; ++dt) {
+      const int slot = (((t0 - dt) % NS) + NS) % NS;
+      for (int idx = tid; idx < C * JNHP; idx += NT) { const int cc = idx / JNHP, k = idx - cc * JNHP; shortOf(slot, cc + 1)[k] = bnd[(long long)C * S + (long long)(dt - 1) * C * JNHP + idx]; }
+    }
+  }
+#endif
+  for (int dt = 1; dt < NS; ++dt) {
+    const int tp = t0 - dt;
+    const int slot = ((tp % NS) + NS) % NS;
+    const int co = tp + 1;      // ring column 0 is one step ahead: at step tp it holds output position tp + 1
+    if (i0 > 0 && co >= 0 && co <= outLen) {
+#if JMAT == 0
+      for (int k = tid; k < JNH; k += NT) shortOf(slot, 0)[k] = haloIn[(long long)co * S + JHSTATE(k)];
+#else
+      for (int k = tid; k < JNH; k += NT) shortOf(slot, 0)[k] = haloIn[(long long)co * JNHP + k];
+#endif
+    }
+  }
+#else
   for (int dt = 1; dt < NS; ++dt) {
     const int tp = t0 - dt;
     const int slot = ((tp % NS) + NS) % NS;
@@ -340,13 +392,19 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
 #endif
   }
+#endif
   __syncthreads();
 
   cdesc_t desc = (cdesc_t)P.desc;
   grec_t grec = (grec_t)P.rec;
   gbytes_t grb = (gbytes_t)P.rec;
   const char *ldsb = (const char *)lds;
+#if JCR
+  constexpr int colStride = COLD * 8, slotStride = 0;      // compact ring: column-major, a column's vectors side by side
+#else
   constexpr int colStride = Spad * 8, slotStride = (C + 1) * colStride;
+#endif
+  (void)slotStride;
   const int myColBase = (c + 1) * colStride;
   const unsigned q16 = (unsigned)q * 16u;
   const unsigned itOff16 = (unsigned)(it * LPG + q) * 16u;
@@ -412,7 +470,9 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       }
     }
     const int slotPrev = (slotCur + NS - 1) % NS, slotPrev2 = (slotCur + NS - 2) % NS;
+#if !JCR
     const int sCur = slotCur * slotStride, sPrev = slotPrev * slotStride, sPrev2 = slotPrev2 * slotStride;
+#endif
 #if JNBSYNC
     {  // both neighbours have finished the step before this one (counters hold the number of steps finished since t0)
       const int need = t - t0;
@@ -429,6 +489,13 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     double hvr[JNHR];
 #pragma unroll
     for (int k = 0; k < JNHR; ++k) hvr[k] = (JDBG & 2) ? -1.0 : haloIn[(long long)min(t + 1, outLen) * JNHP + min(tid + k * NT, JNHP - 1)];
+#elif JCR
+    double hvc[JNHR];      // (JMAT 0, in-place ring: only the halo states of the halo supercell)
+    {
+      const double *hs = haloIn + (long long)min(t + 1, outLen) * S;
+#pragma unroll
+      for (int k = 0; k < JNHR; ++k) hvc[k] = hs[JHSTATE(min(tid + k * NT, JNHP - 1))];
+    }
 #elif JHALOT == 0
     double hv[JHALO];
     {
@@ -448,12 +515,19 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
     }
 #endif
     // LDS byte addresses of the four vectors this lane's column reads / writes
+#if JCR
+    const int aCur = myColBase, aCompW = myColBase + (Spad + slotCur * KCV) * 8, aDown = aCur;      // (in place: the emit rounds read the cells of the step before out of the vector they overwrite)
+    const int aLeft = myColBase - colStride + (Spad + slotPrev * KCV) * 8, aDiag = myColBase - colStride + (Spad + slotPrev2 * KCV) * 8;
+    (void)aCompW;
+#else
     const int aCur = myColBase + sCur, aDown = myColBase + sPrev, aLeft = aDown - colStride, aDiag = myColBase + sPrev2 - colStride;
+    constexpr int aCompW = 0; (void)aCompW;
+#endif
     const unsigned otOff16 = (unsigned)(ot * LPG + q) * 16u;
     const unsigned tokM16 = (unsigned)((it * (JNOUT + 1) + ot) * LPG + q) * 16u;
     (void)aCur; (void)aDiag; (void)tokM16; (void)otOff16; (void)aLeft; (void)aDown;
     if (t == 0 && a == 0) {
-      if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, myColBase, sCur, sPrev, sPrev2, colStride, it, ot, q,
+      if (wv == 0) med_slow_supercell(desc, grec, P.nChunks, ldsb, aDiag, aLeft, aDown, aCur, aCompW, it, ot, q,
                                       P.seedOff, active && i == 0 && o == 0, active, aB, accBase, negLL, tbColOff, jdet);
     } else {
 #if JTB
@@ -492,7 +566,17 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
 #if JMAT == 2
     if (wantHalo) {
 #pragma unroll
+#if JCR
+      for (int k = 0; k < JNHR; ++k) if (tid + k * NT < JNH) shortOf(slotCur, 0)[tid + k * NT] = hvr[k];
+#else
       for (int k = 0; k < JNHR; ++k) if (tid + k * NT < JNH) ring(slotCur, 0)[myHS[k]] = hvr[k];
+#endif
+    }
+#elif JCR
+    if (wantHalo) {
+      double *hd = shortOf(slotCur, 0);
+#pragma unroll
+      for (int k = 0; k < JNHR; ++k) if (tid + k * NT < JNH) hd[tid + k * NT] = hvc[k];
     }
 #else
     if (wantHalo) {
@@ -508,7 +592,7 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
       }
     }
 #endif
-    const double *cur = (const double *)(ldsb + (myColBase + sCur));
+    const double *cur = (const double *)(ldsb + aCur);
     if (active) {
 #if JMAT == 1
       {
@@ -548,10 +632,15 @@ extern "C" __global__ __launch_bounds__(JWAVES * 64) void k_medium_jit(MedProgDe
   if (t1 < T)
     for (int dt = 1; dt < NS; ++dt) {
       const int slot = (((t1 - dt) % NS) + NS) % NS;
+#if JCR
+      if (dt == 1) for (int idx = tid; idx < C * S; idx += NT) { const int cc = idx / S, j = idx - cc * S; bnd[idx] = curOf(cc + 1)[j]; }      // the cells of step t1 - 1
+      for (int idx = tid; idx < C * JNHP; idx += NT) { const int cc = idx / JNHP, k = idx - cc * JNHP; bnd[(long long)C * S + (long long)(dt - 1) * C * JNHP + idx] = shortOf(slot, cc + 1)[k]; }
+#else
       for (int idx = tid; idx < C * S; idx += NT) {
         const int cc = idx / S, j = idx - cc * S;
         bnd[(long long)(dt - 1) * C * S + idx] = ring(slot, cc + 1)[j];
       }
+#endif
     }
 #endif
 #if JMODE == 2

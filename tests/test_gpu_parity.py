@@ -568,6 +568,44 @@ def test_one_tape_counts_of_long_sequences_against_the_oracle(capi, oracle_mod, 
     b.close(); dm.close()
 
 
+@pytest.mark.parametrize("name", ["psw2dna", "random150", "random257"])
+def test_in_place_ring_of_the_matrix_free_sum_kernels(capi, oracle_mod, machines, monkeypatch, name):
+    """MB_MEDIUM_INPLACE_RING=1 (built and measured in round 5; off by default because it does not pay): the
+    matrix-free sum kernels keep ONE full vector per column -- read as the step before by the emit rounds of stage 0, whose loads all
+    precede the stage's first store, and overwritten in place -- plus short vectors of the halo states, and run as many wavefronts
+    as that leaves room for.  Log-likelihoods through the tile pipeline (few pairs, blocks of 64 steps: boundary records) and
+    through the strip sweep, full and restricted envelopes, against the oracle and against the plain ring, bit for bit."""
+    from randmachine import random_machine
+    from machineboss_amd.seqpair import Envelope, SeqPair
+    if name == "psw2dna":
+        m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+    else:
+        em = random_machine(int(name[6:]), 3, 3, 77 + int(name[6:]), density=1.6, silent_density=1.2)
+    om = oracle_mod.OracleMachine(em)
+    rng = np.random.RandomState(5)
+    shapes = [(70, 150), (33, 95), (0, 40), (64, 1), (90, 130)] if name == "psw2dna" else [(40, 90), (17, 70), (0, 30), (50, 2)]
+    pairs = [(rng.randint(1, em.nInTok + 1, size=il).astype(np.int32), rng.randint(1, em.nOutTok + 1, size=ol).astype(np.int32)) for il, ol in shapes]
+    ref = np.array([om.loglike(x, y, oracle_mod.SUM_EXACT) for x, y in pairs])
+    got = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("MB_MEDIUM_INPLACE_RING", ring)
+        monkeypatch.setenv("MB_MEDIUM_TS", "64")
+        dm = capi.DeviceMachine(em)
+        b = capi.DeviceBatch.from_pairs(dm, pairs)
+        monkeypatch.setenv("MB_ROLLING_MIN_PAIRS", "100000")      # few pairs: tiles without a matrix (boundary records between blocks of 64 steps)
+        tiles = b.forward(capi.MB_ROLLING); k1 = capi.last_kernel_name()
+        monkeypatch.setenv("MB_ROLLING_MIN_PAIRS", "0")           # the strip sweep
+        strips = b.forward(capi.MB_ROLLING)
+        assert k1 == "k_medium_jit"
+        got[ring] = (tiles, strips)
+        if ring == "1": n_inplace = int(capi.load().mb_get_option(b"MB_INFO_INPLACE_RING_KERNELS") or 0)
+        for v in (tiles, strips):
+            assert close(v, ref, FAST_REL, FAST_ABS)
+        b.close(); dm.close()
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])      # same rounds, same arithmetic: same bits
+    assert n_inplace >= (2 if name == "psw2dna" else 0)      # (psw2dna: both kinds took it -- 3 halo states of 271; a dense random machine may read most states across columns)
+
+
 def test_tiled_family_byte_sweep_under_envelopes(capi, oracle_mod, machines):
     """The same two sweeps with restricted envelopes: tiles without a cell of the envelope do not run (their halo rows read
     -inf, the next block of the strip starts from -inf instead of a boundary record), among them a gapless stretch that
