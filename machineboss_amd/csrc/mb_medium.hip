@@ -1244,12 +1244,12 @@ MedGeom medium_roll_geometry(const mb_machine *m, MedProgram &P, const MedGeom &
     MedGeom g = geoIn;
     g.compact = true; g.env = env; g.haloSteps = 0; g.level = 0;
     const int maxWaves = std::min(16, env_int_m("MB_MEDIUM_COMPACT_MAXWAVES", 12));
-    for (g.waves = maxWaves; g.waves > geoIn.waves; --g.waves) {
+    for (g.waves = maxWaves; g.waves >= geoIn.waves; --g.waves) {      // (the same wavefront count is allowed: the in-place ring also drops an address add per candidate)
       g.C = g.waves * P.G;
       g.ldsBytes = (size_t)(g.C + 1) * (size_t)(P.Spad + P.NS * KC) * sizeof(double);
       if (medium_jit_lds_bytes(P, g, mode) <= 160 * 1024 - 512) break;
     }
-    if (g.waves <= geoIn.waves) return plain();
+    if (g.waves < geoIn.waves) return plain();
     MedJit &J = P.jit[medium_jit_slot(mode, matKind, 0, env)];
     if (J.tried && !J.func) return plain();                                                       // (the kind has no specialised kernel at all)
     if (J.module) (void)hipModuleUnload((hipModule_t)J.module);
