@@ -84,6 +84,8 @@ def load():
                                         C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_debug_wide_retimed.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                         C.c_int, C.c_int, C.c_char_p]
+    L.mb_debug_wide_parts.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_log_sum_exp.argtypes = [C.c_double, C.c_double]; L.mb_log_sum_exp.restype = C.c_double
     L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
     L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
@@ -286,6 +288,35 @@ def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = F
         assert pos == rest.size and out["tbOff"].size == em.nStates + 1 and out["inEid"].size == em.nTransitions
     else:
         assert rest.size == 0
+    return out
+
+
+def debug_wide_parts(em, path: str, k: int, lanes: int = 256, mode: int = MB_VITERBI, backward: bool = False, tb_codes: bool = False) -> dict:
+    """The k-part form of the retimed program (k workgroups per sequence; host only): {"nExp": exchange columns, "S": states,
+    "parts": [per part the fields of debug_wide_retimed + Sloc, nImp, expBase, expIdx0, nExp, resultEntry, gmap, impIdx]}."""
+    a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+         np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+         np.ascontiguousarray(em.logWeight, np.float64)]
+    _check(load().mb_debug_wide_parts(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                      _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
+                                      mode | (16 if tb_codes else 0), int(backward), int(k), int(lanes), path.encode()))
+    head = np.fromfile(path, np.int32, 4)
+    assert head[0] == 0x52455432
+    out = {"nExp": int(head[2]), "S": int(head[3]), "parts": []}
+    pos = 16
+    keys = ("lanes", "slots", "NB", "NVs", "kMax", "rowLen", "nPen", "period", "Sloc", "nImp", "expBase", "expIdx0", "nExp", "resultEntry", "nTab")
+    for _ in range(int(head[1])):
+        ph = np.fromfile(path, np.int32, 16, offset=pos); pos += 64
+        part = {k_: int(v) for k_, v in zip(keys, ph)}
+        tab = np.fromfile(path, np.uint32, part["nTab"], offset=pos); pos += 4 * part["nTab"]
+        part["gmap"], part["impIdx"] = tab[:part["Sloc"]].astype(np.int64), tab[part["Sloc"]:].astype(np.int64)
+        assert part["impIdx"].size == part["nImp"]
+        nrec = (part["NB"] * part["slots"] + 8) * part["lanes"]
+        rec = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), count=nrec, offset=pos); pos += 16 * nrec
+        part["records"] = rec[:part["NB"] * part["slots"] * part["lanes"]].reshape(part["NB"], part["slots"], part["lanes"])
+        part["inL2"] = 0
+        out["parts"].append(part)
+    assert os.path.getsize(path) == pos
     return out
 
 

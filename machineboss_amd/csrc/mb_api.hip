@@ -516,6 +516,9 @@ static WideProgram *wide_tb_program(mb_machine *m) {
   return (P.ok && P.retOk && P.tbOk) ? &P : nullptr;
 }
 
+// (the count sweep of a one-tape machine runs its two fills side by side: each may count on half of the CUs)
+static int g_fill_share = 1;
+
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
                       const int *d_out, double *pool, int startState, const mb_batch *b) {
@@ -529,8 +532,9 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
   if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1 && !tiledViterbi) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
+    const int rcW = wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream, false, hp.data(), device_cus() / g_fill_share);
     g_last_kernel = wide_kernel_name(*W);
-    return wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream);
+    return rcW;
   }
   if ((use_medium(m) && !(env && wide_applicable(m))) || tiledViterbi) {
     FastState *f = fast_state(m);
@@ -1128,17 +1132,20 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
         tm.start();
         if (hipEventCreateWithFlags(&evStart, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDone, hipEventDisableTiming) != hipSuccess ||
             hipEventRecord(evStart, g_stream) != hipSuccess || hipStreamWaitEvent(s2, evStart, 0) != hipSuccess) { set_error("one-tape split: stream set-up failed"); rc = 1; break; }
-        const int fusedFill = wide_fill2(m, *W, *WB, d_pre, d_suf, n, n, tape, vec, vec + n * S, g_stream, true);   // both sweeps in ONE launch
+        // (with CUs to spare both halves run k workgroups per sequence, each launch on a stream of its own)
+        const bool parts = wide_parts_for(m, *W, n, device_cus() / 2) > 1 && wide_parts_for(m, *WB, n, device_cus() / 2) > 1;
+        const int fusedFill = parts ? -1 : wide_fill2(m, *W, *WB, d_pre, d_suf, n, n, tape, vec, vec + n * S, g_stream, true);   // both sweeps in ONE launch
         if (fusedFill > 0) { rc = 1; break; }
         if (fusedFill < 0) {                        // (programs of different kernel variants: two launches on two streams)
-          if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true))) break;
-          if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true))) break;
+          if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true, parts ? pre.data() : nullptr, device_cus() / 2))) break;
+          if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true, parts ? suf.data() : nullptr, device_cus() / 2))) break;
           if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
         }
         if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
         { static thread_local std::string nm; nm = std::string(wide_kernel_name(*W)) + " x2 + k_onetape_join"; g_last_kernel = nm.c_str(); }
         g_last_ms += tm.stop();
         if (!hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernels")) rc = 1;
+        if (!rc && wide_parts_failed()) rc = 1;
       } while (0);
       if (rc) { (void)hipStreamSynchronize(g_stream); (void)hipStreamSynchronize(second_stream()); }
       if (evStart) (void)hipEventDestroy(evStart);
@@ -1146,10 +1153,11 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       sm_free(d_pre); sm_free(d_suf);
     } else {
       tm.start();
-      rc = wide_fill(m, *W, b->d_pairs, b->nPairs, m->nOut ? b->d_out : b->d_in, nullptr, d_ll, g_stream);
+      rc = wide_fill(m, *W, b->d_pairs, b->nPairs, m->nOut ? b->d_out : b->d_in, nullptr, d_ll, g_stream, false, b->pairs.data(), device_cus());
       g_last_kernel = wide_kernel_name(*W);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernel")) rc = 1;
+      if (!rc && wide_parts_failed()) rc = 1;
     }
   } else if (mode == MB_FORWARD && (flags & MB_ROLLING) && use_medium(m) && !wide_applicable(m) && env_int("MB_MEDIUM_ROLLTILES", 1) &&
              (b->nPairs < env_int("MB_ROLLING_MIN_PAIRS", 192) || b->hasEnv) && rolltiles_ok) {
@@ -1213,6 +1221,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       if (!rc) rc = launch_gather_loglike(d_desc, c.p1 - c.p0, pool, m->S, 0, d_ll + c.p0, g_stream);
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+      if (!rc && wide_parts_failed()) rc = 1;
       sm_free(d_desc);
       if (rc) break;
     }
@@ -1267,8 +1276,8 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
       if (tb == 2) {
         WideProgram *W = wide_tb_program(b->m);
         if (!W) { rc = c.p0 > 0 ? 1 : -1; if (rc > 0) set_error("one-tape traceback-code program became unavailable mid-batch"); break; }
-        if ((rc = wide_fill_tb(b->m, *W, d_desc, np, b->m->nOut ? b->d_out : b->d_in, (unsigned char *)pool, d_ll, g_stream))) break;
-        g_last_kernel = W->retGv ? "k_wide_retimed<1,L2,codes>" : "k_wide_retimed<1,codes>";
+        if ((rc = wide_fill_tb(b->m, *W, d_desc, np, b->m->nOut ? b->d_out : b->d_in, (unsigned char *)pool, d_ll, g_stream, hp.data(), device_cus()))) break;
+        g_last_kernel = wide_last_parts() > 1 ? wide_kernel_name(*W) : (W->retGv ? "k_wide_retimed<1,L2,codes>" : "k_wide_retimed<1,codes>");
       } else if (tb) {
         MedEnv me;
         if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }
@@ -1308,6 +1317,7 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
       lap("launches (host side)");
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "viterbi kernels")) { rc = 1; break; }
+      if (wide_parts_failed()) { rc = 1; break; }
       lap("kernels");
       if (!hip_ok(hipMemcpy(hll.data(), d_ll, np * sizeof(double), hipMemcpyDeviceToHost), "D2H loglike")) { rc = 1; break; }
       std::memcpy(loglike + c.p0, hll.data(), np * sizeof(double));
@@ -1424,7 +1434,9 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         WideProgram *WB = wide_program(b->m, MB_BACKWARD), *WF = wide_program(b->m, MB_FORWARD);
         hipStream_t s2 = second_stream();
         if (!WB || !WF) { rc = 1; break; }
-        const int fusedFill = wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch
+        // (with CUs to spare each fill runs k workgroups per sequence, on a stream of its own)
+        const bool parts = s2 && wide_parts_for(b->m, *WF, np, device_cus() / 2) > 1 && wide_parts_for(b->m, *WB, np, device_cus() / 2) > 1;
+        const int fusedFill = parts ? -1 : wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch
         if (fusedFill > 0) { rc = 1; break; }
         if (fusedFill == 0) { fwdDone = true; g_last_kernel = wide_kernel_name(*WF); }
         else if (s2) {                              // (programs of different kernel variants: two launches on two streams)
@@ -1433,8 +1445,8 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
           bool ok = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess;
           ok = ok && hipEventRecord(evStart, g_stream) == hipSuccess && hipStreamWaitEvent(s2, evStart, 0) == hipSuccess;   // s2 starts after what g_stream has queued (descriptors)
           if (ok) {
-            rc = wide_fill(b->m, *WF, d_desc, np, tape, fwd, nullptr, s2);
-            if (!rc) rc = wide_fill(b->m, *WB, d_desc, np, tape, bwd, nullptr, g_stream);
+            rc = wide_fill(b->m, *WF, d_desc, np, tape, fwd, nullptr, s2, false, parts ? hp.data() : nullptr, device_cus() / 2);
+            if (!rc) rc = wide_fill(b->m, *WB, d_desc, np, tape, bwd, nullptr, g_stream, false, parts ? hp.data() : nullptr, device_cus() / 2);
             ok = hipEventRecord(evDone, s2) == hipSuccess && hipStreamWaitEvent(g_stream, evDone, 0) == hipSuccess;
           }
           if (evStart) (void)hipEventDestroy(evStart);
@@ -1482,6 +1494,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
       }
       g_last_ms += tm.stop();
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
+      if (wide_parts_failed()) { rc = 1; break; }
     } while (0);
     sm_free(d_desc);
     if (rc) break;
@@ -1553,6 +1566,7 @@ int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const
   if (!rc && env_int("MB_DEBUG_POISON", 0)) (void)hipMemsetAsync(pool, 0xFF, n * sizeof(double), g_stream);
   if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, b);
   if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+  if (!rc && wide_parts_failed()) rc = 1;
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
   mb_batch_destroy(b);
   return rc;
@@ -1680,6 +1694,41 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
   }
   fclose(f);
   if (!ok) { set_error("mb_debug_wide_retimed: short write"); return 1; }
+  return 0;
+}
+
+// the k-part form of the retimed program (k workgroups per sequence, WidePartDev), planned on the host only: int32 magic 0x52455432,
+// parts, exchange columns, states; then per part 16 int32 (lanes, slots, NB, NVs, kMax, rowLen, nPen, period, own states, imports,
+// first export entry, first exchange column, exports, result entry, table words, 0), the table (machine state of every own state, then the
+// exchange column of every import) and the record streams as in mb_debug_wide_retimed
+int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                        const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int k, int lanes, const char *path) {
+  ApiLock lock;
+  if (nStates <= 0 || nTrans < 0 || !path || (nInTok != 0) == (nOutTok != 0)) { set_error("mb_debug_wide_parts: bad argument (one-tape machines only)"); return 1; }
+  mb_machine m;
+  m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
+  m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);
+  m.inTok.assign(inTok, inTok + nTrans); m.outTok.assign(outTok, outTok + nTrans);
+  m.logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  const bool tbCodes = (mode & 16) != 0;
+  mode &= 15;
+  std::vector<WidePartHost> parts;
+  int nExpTot = 0;
+  if (!wide_parts_host(&m, backward != 0, mode == MB_VITERBI, tbCodes, k, lanes, parts, nExpTot)) { set_error("machine has no k-part retimed program"); return 1; }
+  FILE *f = fopen(path, "wb");
+  if (!f) { set_error("mb_debug_wide_parts: cannot open output file"); return 1; }
+  const int32_t head[4] = {0x52455432, (int32_t)parts.size(), nExpTot, nStates};
+  bool ok = fwrite(head, sizeof(head), 1, f) == 1;
+  for (const WidePartHost &H : parts) {
+    const int32_t ph[16] = {lanes, H.h.ret.nSlots, H.h.ret.NB, H.h.ret.NVs, H.h.ret.kMax, H.h.ret.rowLen, H.h.ret.nPen, H.period, H.h.Sloc, H.h.nImp,
+                            H.h.expBase, H.h.expIdx0, H.h.nExp, H.h.resultEntry, (int32_t)H.tab.size(), 0};
+    ok = ok && fwrite(ph, sizeof(ph), 1, f) == 1 && fwrite(H.tab.data(), 4, H.tab.size(), f) == H.tab.size() &&
+         fwrite(H.stream.data(), sizeof(WideRec), H.stream.size(), f) == H.stream.size();
+  }
+  fclose(f);
+  if (!ok) { set_error("mb_debug_wide_parts: short write"); return 1; }
   return 0;
 }
 

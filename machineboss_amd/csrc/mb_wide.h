@@ -109,6 +109,50 @@ struct WideRetDev {
   int rowLen, nPen;            // penalty table: rowLen = tokens + 2 entries (silent, each token, seed) per ktau, nPen entries in all
 };
 
+// ---- k WORKGROUPS PER SEQUENCE (round 5; k_wide_retimed_parts) -----------------------------------------------------------------
+// One workgroup per sequence leaves most of the chip idle when a batch has fewer sequences than the device has CUs (BASELINE config 5:
+// 64 sequences, 256 CUs -- and 8 per GPU when the batch is split over eight).  The states of the machine are cut into k PARTS along a
+// topological order of the strongly connected components of its transition graph (emitting transitions included, in the direction of
+// the sweep): no cycle crosses a cut, so values flow from part p to parts > p only, and a consumer may lag its producer by any number
+// of columns.  Every part is a retimed program of its own (own period, own ring, own record stream) over
+//     its own states | the two constants | IMPORT nodes | EXPORT nodes | relays.
+// An export node is a silent copy (x + 0.0) of a state some later part reads; its result goes to the EXCHANGE buffer
+// X[sequence][column][export] (fp64, one 8-byte store of agent scope) instead of the matrix.  An import node's only candidate is
+// `0.0 + (0.0 + X[column][export])`: the value enters through the PENALTY TABLE -- the table of a period is written one period ahead by
+// the workgroup's first lanes; its last lanes append one entry per import -- so the record format and the slot loop are those of the
+// one-workgroup sweep.  There are no flags: X is preset to all-ones (a NaN no cell ever holds) and a consumer lane re-reads its entry until
+// it is something else (issued a period ahead, so the wait is normally over when it is looked at).  Workgroup ids are part-major: a
+// consumer waits only for workgroups with lower ids, which the dispatcher starts first -- no deadlock even when the grid exceeds the chip --
+// and every wait is bounded (WidePartArgs::timeoutTicks: the kernel raises *err, stops waiting and the host fails the call).
+// Cells, traceback codes and log-likelihoods are those of the one-workgroup program, bit for bit in the max semiring (same candidates in
+// the same order; the two copies add 0.0).
+struct WidePartDev {
+  WideRetDev ret;              // nPen: the (ktau, token) entries only; the imports' entries follow them
+  const uint32_t *gmap;        // [Sloc]: machine state of local state x (column of its matrix cell / traceback code)
+  const uint32_t *impIdx;      // [nImp]: exchange column of import i
+  int Sloc, nImp;              // own states (ring entries 0 .. Sloc - 1; Sloc, Sloc + 1: -inf and 0.0); imports
+  int expBase, expIdx0, nExp;  // ring entries >= expBase are exports: entry expBase + j is exchange column expIdx0 + j
+  int resultEntry;             // ring entry of the state whose last-column value is the log-likelihood, -1: another part has it
+};
+struct WidePartArgs {
+  const WidePartDev *parts;
+  int nSeq, nExpTot;           // workgroup = part * nSeq + sequence; exchange columns per sequence column
+  double *X;                   // [xOff[seq] + column][nExpTot]
+  const long long *xOff;       // first exchange row of every sequence
+  unsigned *err;               // raised by a lane whose wait ran out
+  long long timeoutTicks;      // of wall_clock64() (100 MHz)
+};
+struct WidePartSet {
+  bool ok = false;
+  int kWanted = 0, k = 0, W = 0, nExpTot = 0;
+  size_t ldsBytes = 0;                       // largest part (with the fp64 correction term's table)
+  std::vector<WideRec *> d_rec;
+  std::vector<uint32_t *> d_tab;             // gmap + impIdx of every part, one allocation each
+  WidePartDev *d_parts = nullptr;
+  std::vector<WidePartDev> h_parts;          // (device pointers inside)
+  std::vector<int> period, slots, nSync;     // per part, for the log
+};
+
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
 struct WideSecond { unsigned nFirst; const PairDesc *pairs; double *pool; void *scratch; };
 
@@ -153,6 +197,7 @@ struct WideProgram {
   std::vector<int> h_tbOff; std::vector<uint32_t> h_tbEntry;      // host copies (the debug dump)
   long long tbEntries = 0;
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
+  std::vector<WidePartSet> partSets; // k workgroups per sequence: one set per k that was asked for (built on first use)
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };
@@ -166,16 +211,25 @@ void wide_free(WideProgram &P);
 void wide_set_accurate(bool on);      // the next retimed sum fills carry their log-sum-exp correction term in fp64 (E-step of long sequences)
 // the retimed program of a machine, planned and linearised on the host only (no device): P.ret / P.retGv / P.retPeriod + the record stream
 bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes = false);
+// ... and its k-part form: the record stream, geometry and tables of every part (a part's `h` holds HOST pointers into tabs[part]:
+// gmap [Sloc], then impIdx [nImp]); false when the machine's graph has no cut
+struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0; size_t ldsBytes = 0; };
+bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
+// h_desc (host copy of d_desc) + cus (CUs this launch may count on): with fewer sequences than CUs the sweep runs k workgroups per
+// sequence when the machine's graph can be cut (see WidePartDev); without them, or when it cannot, one workgroup per sequence
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
-              double *loglike, hipStream_t st, bool lastOnly = false);
+              double *loglike, hipStream_t st, bool lastOnly = false, const PairDesc *h_desc = nullptr, int cus = 0);
+int wide_last_parts();      // k of the last launch of this family (1: one workgroup per sequence)
+int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus);      // k such a launch would use (builds the parts)
+bool wide_parts_failed();   // after the streams were synchronised: a bounded wait ran out (error set, flag cleared)
 const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
 // ViterbiMatrix::fill keeping one traceback code per cell (P.tbOk): tb = bytes, wide_tb_stride(S) per column, PairDesc::cellBase =
 // BYTE offset of the sequence's first column; scores of the end cells in loglike
 inline int wide_tb_stride(int S) { return (S + 3) & ~3; }
 int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, unsigned char *tb,
-                 double *loglike, hipStream_t st);
+                 double *loglike, hipStream_t st, const PairDesc *h_desc = nullptr, int cus = 0);
 // ... and DPMatrix::traceBack over those codes: one workgroup per sequence, its first lane walks a window of code rows in LDS that
 // the other wavefronts refill ahead of it (and the decode table, when it fits beside the window)
 int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDesc *d_pairs, long long nPairs, const unsigned char *tb,

@@ -25,7 +25,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <numeric>
+#include <queue>
 #include <type_traits>
 
 #include "mb_wide.h"
@@ -421,23 +423,51 @@ __device__ __forceinline__ void wide_group_reduce_tb(double &m, uint32_t &key, i
 // offset) instead of the fp64 cell -- the place of the cell's first maximal candidate in its node's list (WideProgram::tbCodes)
 // ACC (sum sweep only): the log-sum-exp correction term in fp64 (wide_exp64 / wide_log64 above) instead of v_exp_f32 / v_log_f32; the
 // 64-entry table of 2^(j/64) sits in the last 512 bytes of the launch's LDS
-template <int MODE, bool GV, bool TB = false, bool ACC = false>
-__global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
-                                                       double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
+// PART (k workgroups per sequence, see WidePartDev): `pp` is this workgroup's part, `A` the exchange buffer; the ring entries below
+// pp->Sloc are the part's own states (matrix column pp->gmap[x]), imports enter through the penalty table, exports leave for A.X
+constexpr unsigned long long WIDE_X_EMPTY = ~0ull;      // what the exchange buffer is preset to: a NaN no cell holds
+__device__ __forceinline__ unsigned long long wide_x_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double wide_x_wait(const unsigned long long *p, unsigned *err, long long timeoutTicks) {
+  const long long t0 = (long long)wall_clock64();
+  for (;;) {
+    const unsigned long long b = wide_x_load(p);
+    if (b != WIDE_X_EMPTY) return __longlong_as_double((long long)b);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -INFINITY;      // some wait ran out: the call has failed, drain
+    if ((long long)wall_clock64() - t0 > timeoutTicks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -INFINITY; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+template <int MODE, bool GV, bool TB, bool ACC, bool PART>
+__device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRetDev &Q, const PairDesc pd, const unsigned bid, const int *__restrict__ outTok,
+                                                  double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch,
+                                                  const WidePartDev &part, const WidePartArgs &A) {
+  static_assert(!(PART && GV), "the parts of a machine keep their rings in LDS");
   extern __shared__ double wlds[];
   // the records carry raw LDS byte addresses: the dynamic array is this kernel's only LDS, so it starts at 0
   if ((unsigned)(uintptr_t)wlds != 0u) __builtin_trap();
-  const unsigned bid = blockIdx.x;
-  const PairDesc pd = pairs[bid];
-  const int tid = threadIdx.x, W = P.W, S = P.S;
+  const int tid = threadIdx.x, W = P.W;
+  // (the part's fields in registers: loads from `part` behind the exchange's atomics would be issued again in every round epilogue)
+  const int pSloc = part.Sloc, pImp = part.nImp, pExpBase = part.expBase, pExpIdx0 = part.expIdx0, pExp = part.nExp, pResult = part.resultEntry;
+  const int S = PART ? pSloc : P.S, Sg = P.S;      // S: ring entries below it are cells of the matrix (S, S + 1: the constants); Sg: states of the machine
   const int L = P.inputTape ? pd.inLen : pd.outLen;
   const int NVs = Q.NVs, NB = Q.NB, nVec = NB * NVs, nPen = Q.nPen, rowLen = Q.rowLen;
+  const int nImp = PART ? pImp : 0, nPenAll = nPen + nImp;
   double *V = GV ? scratch + (size_t)bid * (size_t)nVec : wlds;
-  double *pen = GV ? wlds : wlds + nVec;             // [2][nPen]: this period's penalties and the next one's
-  int *tokWin = (int *)(pen + 2 * nPen);             // token of column c in entry c & 63, written two periods ahead
-  const unsigned expTab = (unsigned)(((GV ? 0u : (unsigned)nVec * 8u) + 2u * (unsigned)nPen * 8u + (unsigned)WIDE_RET_TOKWIN * 4u + 7u) & ~7u);      // ACC: 2^(j/64), j = 0..63
+  double *pen = GV ? wlds : wlds + nVec;             // [2][nPenAll]: this period's penalties (and imports) and the next one's
+  int *tokWin = (int *)(pen + 2 * nPenAll);          // token of column c in entry c & 63, written two periods ahead
+  const unsigned expTab = (unsigned)(((GV ? 0u : (unsigned)nVec * 8u) + 2u * (unsigned)nPenAll * 8u + (unsigned)WIDE_RET_TOKWIN * 4u + 7u) & ~7u);      // ACC: 2^(j/64), j = 0..63
   if (ACC && tid < 64) wide_lds_write(expTab + (unsigned)tid * 8u, exp2((double)tid * 0.015625));
   (void)expTab;
+  const unsigned gmapOff = expTab + 512u;            // PART: machine state of every own state (32-bit)
+  const size_t xStride = PART ? (size_t)A.nExpTot : 0;
+  unsigned long long *xRow = PART ? (unsigned long long *)A.X + (size_t)A.xOff[bid] * xStride : nullptr;      // [column][exchange column] of this sequence
+  const bool impLane = PART && tid >= W - nImp;      // the last lanes of the workgroup: one import each
+  const int impI = tid - (W - nImp);
+  const unsigned long long *impPtr = impLane ? xRow + part.impIdx[impI] : nullptr;
+  unsigned long long impAhead = WIDE_X_EMPTY;
+  if (PART && pool) for (int k = tid; k < S; k += W) *(unsigned *)((char *)wlds + gmapOff + 4u * (unsigned)k) = part.gmap[k];
+  (void)gmapOff; (void)xRow; (void)impI; (void)impPtr; (void)impAhead; (void)Sg; (void)pExpBase; (void)pExpIdx0; (void)pExp; (void)pResult;
   for (int k = tid; k < nVec; k += W) V[k] = -INFINITY;
   if (tid < WIDE_RET_TOKWIN) tokWin[tid] = 0;
   __syncthreads();
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   const int *out = outTok + (P.inputTape ? pd.inBase : pd.outBase);
   double *cells = (pool && !TB) ? pool + pd.cellBase : nullptr;
   unsigned char *codes = (pool && TB) ? (unsigned char *)pool + pd.cellBase : nullptr;
-  const int Sb = (S + 3) & ~3;
+  const int Sb = (Sg + 3) & ~3;
   uint32_t bestSlot = 0u; int slotInRound = 0;                 // TB: slot of this lane's first maximal candidate within the round
   (void)codes; (void)Sb; (void)bestSlot; (void)slotInRound;
   auto tokAt = [&](int c) -> int { return (c >= 1 && c <= L) ? (P.backward ? out[L - c] : out[c - 1]) : 0; };
@@ -460,6 +490,10 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   };
   __syncthreads();
   for (int e = tid; e < nPen; e += W) { const int kt = e / rowLen; pen[e] = penalty(kt, e - kt * rowLen, 0); }
+  if (impLane) {      // column 0 of the imports; column 1 is asked for now and looked at in the first period
+    pen[nPen + impI] = wide_x_wait(impPtr, A.err, A.timeoutTicks);
+    if (L >= 1) impAhead = wide_x_load(impPtr + xStride);
+  }
   __syncthreads();
   // one record stream per rotation of the ring (the newest column sits in vector t mod NB); a stream runs on into the next one
   // (buffer loads: slot base in an SGPR offset, lane offset in one VGPR -- no 64-bit address arithmetic per slot)
@@ -473,15 +507,15 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
   };
   WideRec q[WIDE_RING];
 #pragma unroll
-  for (int k = 0; k < WIDE_RING; ++k) q[k] = ldrec(k * slotBytes);
+  for (int k = 0; k < WIDE_RING; ++k) { q[k] = ldrec(k * slotBytes); __builtin_amdgcn_sched_barrier(0); }      // (in this order: the waits inside the loop count the loads behind a record)
   const int nPer = L + 1 + Q.kMax;
-  unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPen * 8u;
+  unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPenAll * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
   typename std::conditional<ACC, double, float>::type s = 0;
   const bool storeAll = cells && !P.lastOnly, storeLast = cells && P.lastOnly;
   // a node's lag comes as kq = kMax - ktau (ktau for a backward sweep): its column is cBase + cSign * kq, its matrix row starts
   // kq * rowS doubles behind rowPtr
-  const int cSign = P.backward ? -1 : 1, rowS = P.lastOnly ? 0 : S;
+  const int cSign = P.backward ? -1 : 1, rowS = P.lastOnly ? 0 : Sg;
   int cm = 0;
   auto ring = [&](uint32_t src) -> double { return GV ? *(const double *)((const char *)V + ((size_t)(src >> 13) << 3)) : wide_lds_read(src >> 14); };
   // the ring reads of a slot are issued one slot ahead (behind a barrier they are issued again: what they fetched may be stale)
@@ -493,8 +527,14 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
     }
     if (tid < nPen) wide_lds_write(penNxt + (unsigned)tid * 8u, penalty(myKt, myCol, t + 1));
     for (int e = tid + W; e < nPen; e += W) { const int kt = e / rowLen; wide_lds_write(penNxt + (unsigned)e * 8u, penalty(kt, e - kt * rowLen, t + 1)); }
+    if (impLane) {      // the next period's newest column is t + 1: its value was asked for a period ago; the one after it is asked for now
+      double v = -INFINITY;
+      if (t + 1 <= L) v = impAhead != WIDE_X_EMPTY ? __longlong_as_double((long long)impAhead) : wide_x_wait(impPtr + (size_t)(t + 1) * xStride, A.err, A.timeoutTicks);
+      wide_lds_write(penNxt + (unsigned)(nPen + impI) * 8u, v);
+      if (t + 2 <= L) impAhead = wide_x_load(impPtr + (size_t)(t + 2) * xStride);
+    }
     const int cBase = P.backward ? t : t - Q.kMax;
-    const char *rowPtr = (const char *)(P.lastOnly ? cells : cells + (long long)(P.backward ? L - t : t - Q.kMax) * S);
+    const char *rowPtr = (const char *)(P.lastOnly ? cells : cells + (long long)(P.backward ? L - t : t - Q.kMax) * Sg);
     unsigned char *codeRow = TB ? codes + (long long)(t - Q.kMax) * Sb : nullptr;      // (forward sweeps only: column cBase = t - kMax)
     (void)codeRow;
     slotInRound = 0;      // (the padding slots behind the period's last round -- all -inf -- have been counted)
@@ -505,8 +545,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
 #pragma unroll
       for (int k = 0; k < WIDE_RING; ++k) {
         const WideRec rc = q[k];
-        q[k] = ldrec(streamBase + (j0 + WIDE_RING + k) * slotBytes);
-        const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one just requested)
+        const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one requested at the end of this group's first slot)
         const unsigned penN = k + 1 == WIDE_RING ? penLast : penHere;
         const double vNow = vAhead, pNow = pAhead;
         vAhead = ring(nx.src);
@@ -545,6 +584,16 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             else res = s > 0.0f ? m + (double)__log2f(s) * 0.6931471805599453 : -INFINITY;      // (ln 2 in fp64: as a float it is 2.7e-9 too large, a bias that a column of hundreds of levels adds up)
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
+            if constexpr (PART) {
+              if (x - (unsigned)pExpBase < (unsigned)pExp) {      // an export (relay entries follow them): one 8-byte store that the consumers' lanes wait for (a NaN would read as "not yet": none is stored as all-ones)
+                const unsigned long long bits = res == res ? (unsigned long long)__double_as_longlong(res) : 0x7ff8000000000000ull;
+                __hip_atomic_store(xRow + (size_t)c * xStride + (size_t)(pExpIdx0 + (int)(x - (unsigned)pExpBase)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              if (x < (unsigned)S) {
+                if (TB) { if (codes) codeRow[__umul24(kq, (unsigned)Sb) + *(const unsigned *)((const char *)wlds + gmapOff + 4u * x)] = (unsigned char)key; }
+                else if (storeAll | (storeLast & (c == L))) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + *(const unsigned *)((const char *)wlds + gmapOff + 4u * x)) << 3)) = res;
+              }
+            } else
             if (TB) { if (codes && x < (unsigned)S) codeRow[__umul24(kq, (unsigned)Sb) + x] = (unsigned char)key; }      // (traceback codes: forward sweeps only, cSign = 1)
             else if ((storeAll | (storeLast & (c == L))) && x < (unsigned)S) *(double *)(rowPtr + ((size_t)(__umul24(kq, (unsigned)rowS) + x) << 3)) = res;
           }
@@ -559,12 +608,47 @@ __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, 
             pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
           }
         }
+        // the record of this slot one ring ahead, requested when the slot is done with its own: the load lands in the registers the old
+        // record occupied (requested at the top of the slot it needs registers of its own, and the copies at the loop's back edge made
+        // the compiler wait for ALL eight loads in flight there -- the prefetch ring was drained every eight slots)
+        __builtin_amdgcn_sched_barrier(0);
+        q[k] = ldrec(streamBase + (j0 + WIDE_RING + k) * slotBytes);
       }
     }
     cm = cm + 1 == NB ? 0 : cm + 1;
     const unsigned sw = penCur; penCur = penNxt; penNxt = sw;
   }
-  if (loglike && tid == 0) loglike[bid] = V[(L % NB) * NVs + P.resultIdx];
+  if (PART) { if (loglike && tid == 0 && pResult >= 0) loglike[bid] = V[(L % NB) * NVs + pResult]; }
+  else if (loglike && tid == 0) loglike[bid] = V[(L % NB) * NVs + P.resultIdx];
+}
+
+template <int MODE, bool GV, bool TB = false, bool ACC = false>
+__global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
+                                                       double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
+  wide_retimed_body<MODE, GV, TB, ACC, false>(P, Q, pairs[blockIdx.x], blockIdx.x, outTok, pool, loglike, scratch, WidePartDev{}, WidePartArgs{});
+}
+
+// first exchange row of every sequence (a handful of sequences: one lane)
+__global__ void k_wide_part_rows(const PairDesc *__restrict__ pairs, int nSeq, int inputTape, long long *__restrict__ xOff) {
+  long long rows = 0;
+  for (int p = 0; p < nSeq; ++p) { xOff[p] = rows; rows += (long long)(inputTape ? pairs[p].inLen : pairs[p].outLen) + 1; }
+}
+
+// k workgroups per sequence: workgroup = part * nSeq + sequence (a part waits for lower parts only, and those are dispatched first)
+template <int MODE, bool TB, bool ACC>
+__global__ __launch_bounds__(1024) void k_wide_retimed_parts(WideDev P, WidePartArgs A, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
+                                                             double *__restrict__ pool, double *__restrict__ loglike) {
+  const unsigned part = blockIdx.x / (unsigned)A.nSeq, seq = blockIdx.x - part * (unsigned)A.nSeq;
+  // the part's descriptor, in scalar registers (it is the same for every lane; the record stream's buffer descriptor is built from it)
+  const WidePartDev g = A.parts[part];
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto uniPtr = [&](const void *q) { const unsigned long long b = (unsigned long long)(uintptr_t)q; return (const void *)(uintptr_t)(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned)uni((int)b)); };
+  WidePartDev pd;
+  pd.ret.rec = (const WideRec *)uniPtr(g.ret.rec); pd.ret.nSlots = uni(g.ret.nSlots); pd.ret.NB = uni(g.ret.NB); pd.ret.NVs = uni(g.ret.NVs); pd.ret.kMax = uni(g.ret.kMax);
+  pd.ret.rowLen = uni(g.ret.rowLen); pd.ret.nPen = uni(g.ret.nPen);
+  pd.gmap = (const uint32_t *)uniPtr(g.gmap); pd.impIdx = (const uint32_t *)uniPtr(g.impIdx);
+  pd.Sloc = uni(g.Sloc); pd.nImp = uni(g.nImp); pd.expBase = uni(g.expBase); pd.expIdx0 = uni(g.expIdx0); pd.nExp = uni(g.nExp); pd.resultEntry = uni(g.resultEntry);
+  wide_retimed_body<MODE, false, TB, ACC, true>(P, pd.ret, pairs[seq], seq, outTok, pool, loglike, nullptr, pd, A);
 }
 
 // ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
@@ -822,6 +906,11 @@ void wide_free(WideProgram &P) {
   if (P.d_ret) (void)hipFree(P.d_ret);
   if (P.d_tbOff) (void)hipFree(P.d_tbOff);
   if (P.d_tbEntry) (void)hipFree(P.d_tbEntry);
+  for (WidePartSet &ps : P.partSets) {
+    for (WideRec *r : ps.d_rec) if (r) (void)hipFree(r);
+    for (uint32_t *t : ps.d_tab) if (t) (void)hipFree(t);
+    if (ps.d_parts) (void)hipFree(ps.d_parts);
+  }
   P = WideProgram();
 }
 
@@ -1206,15 +1295,25 @@ bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int
 }
 }  // namespace
 
+// One PART of a machine cut for k workgroups per sequence (see WidePartDev): the nodes handed to wide_ret_build are LOCAL -- vertices
+// 0 .. nOwn - 1 the part's own states, then nImp import vertices (no candidates of their own: their value comes through the penalty
+// table), then nExp export vertices (one silent candidate each: the exported state, weight 0.0); the seed's source is vertex count + 1
+struct RetPart { int nOwn = 0, nImp = 0, nExp = 0; };
+
 // hostOut: keep the record stream on the host instead of uploading it (mb_debug_wide_retimed: the planner without a device)
 static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr,
-                           int keepPeriod = 0) {
+                           int keepPeriod = 0, const RetPart *part = nullptr) {
   P.retOk = false;
-  const int S = m->S, W = P.W;
+  const int W = P.W;
+  // S: vertices of the retiming graph; SC: ring entry of the -inf constant (entries below it are the cells the matrix keeps)
+  const int S = part ? part->nOwn + part->nImp + part->nExp : m->S, SC = part ? part->nOwn : m->S;
+  const int nImp = part ? part->nImp : 0;
+  auto entryOf = [&](int v) { return v < SC ? v : v + 2; };      // (the two constants sit between the own states and the other vertices)
   const int want = env_int_w("MB_WIDE_RETIMED", 1);
   if (want == 0) return true;
   const int rowLen = nTok + 1;                                 // penalty columns: silent, tokens 1 .. nTok - 1, the seed
   if (S + 2 >= (int)WIDE_RET_NO_DST || rowLen > 64) return true;
+  if (part && (hostOut == nullptr || nImp > W)) return true;
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   // the levelled nodes as a graph over states: t2[tok] = emitting candidates (source in the column before), t3 = silent ones
   std::vector<char> live(S, 0);
@@ -1284,30 +1383,40 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       for (int x = 0; x < S; ++x) { relayBase[x] = nRelay; nRelay += nHops[x]; kMax = std::max(kMax, (tau[x] + nHops[x] * hop) / period); }
       const int NVs = S + 2 + nRelay, nPen = (kMax + 1) * rowLen;
       if (kMax > kLimit) continue;
-      const size_t ldsPen = 2 * (size_t)nPen * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int), ldsAll = ldsPen + (size_t)NB * NVs * sizeof(double);
+      const size_t ldsPen = 2 * (size_t)(nPen + nImp) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int) + (part ? 512 + 4 * (size_t)SC : 0),
+                   ldsAll = ldsPen + (size_t)NB * NVs * sizeof(double);
       const bool inLds = ldsAll <= WIDE_LDS_MAX && !forceGv;
       if ((pass == 0) != inLds) continue;
-      if ((!inLds && (ldsPen > WIDE_LDS_MAX || !allowGv)) || (size_t)NB * NVs >= (1u << 19) || NVs >= (int)WIDE_RET_NO_DST || nPen > 0x2000) continue;
+      if (part && !inLds) continue;                            // (parts keep their ring in LDS: that is what they are cut for)
+      if ((!inLds && (ldsPen > WIDE_LDS_MAX || !allowGv)) || (size_t)NB * NVs >= (1u << 19) || NVs >= (int)WIDE_RET_NO_DST || nPen + nImp > 0x2000) continue;
       auto srcWord = [&](int ktDst, int em, int col, int entry) {      // penalty entry << 19 | ring entry for rotation 0
         const int back = (ktDst + em) % NB;
         return ((uint32_t)(ktDst * rowLen + col) << 19) | (uint32_t)(((NB - back) % NB) * NVs + entry);
       };
       auto dstWord = [&](int kt, int entry) { return ((uint32_t)kt << 20) | ((uint32_t)((NB - kt % NB) % NB) << 18) | (uint32_t)entry; };
       std::vector<std::vector<WCand>> cands(S);
-      if (seedState >= 0 && !P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
+      if (seedState >= 0 && !P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, SC + 1), seedW});
       for (const RetEdge &e : *edgeOrder) {
         const int kt = tau[e.dst] / period, span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
         const int k = (span - 1) / hop;
-        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : e.src), e.w, e.ref});
+        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : entryOf(e.src)), e.w, e.ref});
       }
       // (traceback codes: a cell's code is the PLACE of its first maximal candidate in this list -- the reference's order, the seed last)
-      if (seedState >= 0 && P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, S + 1), seedW});
+      if (seedState >= 0 && P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, SC + 1), seedW});
+      // an import: 0.0 (the constant) + (0.0 + its entry of the penalty table, behind the (ktau, token) entries) -- nothing leads to an
+      // import vertex, so it sits in the period's newest column (ktau 0), which is the column its entry is loaded for
+      bool importsNewest = true;
+      for (int i = 0; i < nImp; ++i) {
+        importsNewest = importsNewest && tau[SC + i] < period;
+        cands[SC + i].push_back(WCand{((uint32_t)(nPen + i) << 19) | (uint32_t)(SC + 1), 0.0});
+      }
+      if (!importsNewest) continue;
       sh.nd.clear();
       for (int x = 0; x < S; ++x) {      // (states nothing leads to are nodes too: their cells of the matrix are -inf)
-        sh.nd.push_back(WNode{CUR(dstWord(tau[x] / period, x)), tau[x] % period, {}, std::move(cands[x])});
+        sh.nd.push_back(WNode{CUR(dstWord(tau[x] / period, entryOf(x))), tau[x] % period, {}, std::move(cands[x])});
         for (int k = 1; k <= nHops[x]; ++k) {
           const int tr = tau[x] + k * hop, kr = tr / period, entry = S + 2 + relayBase[x] + k - 1;
-          sh.nd.push_back(WNode{CUR(dstWord(kr, entry)), tr % period, {}, {WCand{srcWord(kr, 0, 0, k == 1 ? x : entry - 1), 0.0}}});
+          sh.nd.push_back(WNode{CUR(dstWord(kr, entry)), tr % period, {}, {WCand{srcWord(kr, 0, 0, k == 1 ? entryOf(x) : entry - 1), 0.0}}});
         }
       }
       sh.period = period; sh.NB = NB; sh.NVs = NVs; sh.nRelay = nRelay; sh.kMax = kMax; sh.tauMax = tauMax; sh.gv = !inLds;
@@ -1326,7 +1435,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   if (best.cost >= 1e300) return true;
   // rounds (one stage per residue) -> one stream of [slot][lane] records
   WideProgram T;
-  T.W = W; T.dev.S = S;
+  T.W = W; T.dev.S = SC;
   wide_plan(best.nd, best.period - 1, 1, W, true, &T, 280.0);
   if (T.rounds.empty()) return true;
   int nSlots = 0;
@@ -1340,7 +1449,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   st.reserve((size_t)(NB * padded + WIDE_RING) * W);
   for (int cm = 0; cm < NB; ++cm) {
     const bool gv = best.gv;                                   // records name ring entries (L2 ring) or LDS byte addresses
-    const WideRec padRec{-INFINITY, gv ? (uint32_t)S << 13 : (uint32_t)(S * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
+    const WideRec padRec{-INFINITY, gv ? (uint32_t)SC << 13 : (uint32_t)(SC * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
     const size_t start = st.size();
     for (const WideRound &R : T.rounds)
       for (int j = 0; j < R.depth; ++j) {
@@ -1385,12 +1494,12 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
   P.retGv = best.gv;
-  P.retLdsBytes = ((best.gv ? 0 : (size_t)best.NB * best.NVs) + 2 * (size_t)P.ret.nPen) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
+  P.retLdsBytes = ((best.gv ? 0 : (size_t)best.NB * best.NVs) + 2 * (size_t)(P.ret.nPen + nImp)) * sizeof(double) + WIDE_RET_TOKWIN * sizeof(int);
   P.retPeriod = best.period; P.retTauMax = best.tauMax; P.retPeriodMin = pMin;
   P.slotsPerColumn = padded; P.candsPerColumn = T.candsPerColumn; P.nSync = T.nSync;
   P.rounds = T.rounds;                                  // (planning tables: mb_machine_sweep_ops counts them)
   P.retOk = true;
-  if (P.tbCodes) {
+  if (P.tbCodes && !part) {      // (the parts of a machine write the codes of its one-workgroup program: same lists, same order)
     // decode tables of the traceback codes: the candidate lists of the state nodes, in the order the planner laid them out
     // (kept on the host as well: mb_debug_wide_retimed hands them to the device-free simulation of tests/test_retimed_plan.py)
     std::vector<int> tbOff(S + 1, 0);
@@ -1428,6 +1537,155 @@ bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram
   int nExtra = 0, nStages = 0; long long nPairs = 0;
   if (!wide_nodes(m, backward, 0, P.W, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
   return wide_ret_build(m, P, nodes, (m->nOut ? m->nOut : m->nIn) + 1, &stream) && P.retOk;
+}
+
+// ---- k workgroups per sequence: the cut (see WidePartDev in mb_wide.h) -------------------------------------------------------------
+namespace {
+// strongly connected components of a graph in CSR form (Tarjan, explicit stack); returns their number, comp[v] = component of v
+int scc_of(int n, const std::vector<int> &off, const std::vector<int> &adj, std::vector<int> &comp) {
+  comp.assign(n, -1);
+  std::vector<int> idx(n, -1), low(n, 0), stack, it(n, 0), call;
+  std::vector<char> onStack(n, 0);
+  int counter = 0, nComp = 0;
+  for (int r = 0; r < n; ++r) {
+    if (idx[r] >= 0) continue;
+    call.push_back(r); idx[r] = low[r] = counter++; stack.push_back(r); onStack[r] = 1;
+    while (!call.empty()) {
+      const int v = call.back();
+      if (it[v] < off[v + 1] - off[v]) {
+        const int w = adj[off[v] + it[v]++];
+        if (idx[w] < 0) { idx[w] = low[w] = counter++; stack.push_back(w); onStack[w] = 1; call.push_back(w); }
+        else if (onStack[w]) low[v] = std::min(low[v], idx[w]);
+      } else {
+        call.pop_back();
+        if (!call.empty()) low[call.back()] = std::min(low[call.back()], low[v]);
+        if (low[v] == idx[v]) {
+          for (;;) { const int w = stack.back(); stack.pop_back(); onStack[w] = 0; comp[w] = nComp; if (w == v) break; }
+          ++nComp;
+        }
+      }
+    }
+  }
+  return nComp;
+}
+}  // namespace
+
+bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot) {
+  parts.clear(); nExpTot = 0;
+  const int S = m->S, nTok = (m->nOut ? m->nOut : m->nIn) + 1;
+  if (k < 2 || S < 2 * k) return false;
+  const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
+  std::vector<WNode> nodes;
+  int nExtra = 0, nStages = 0; long long nPairs = 0;
+  if (!wide_nodes(m, backward, 0, W, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
+  // the dependency graph of the sweep: source -> node, for every candidate the retimed program keeps (finite weight, a source that has
+  // candidates itself)
+  std::vector<char> live(S, 0);
+  std::vector<int> nodeOf(S, -1);
+  for (size_t i = 0; i < nodes.size(); ++i) { const int x = (int)(nodes[i].dst & W_IDX_MASK); live[x] = 1; nodeOf[x] = (int)i; }
+  auto forCands = [&](const WNode &nd, const std::function<void(const WCand &)> &f) {
+    for (const auto &l : nd.t2) for (const WCand &cd : l) f(cd);
+    for (const WCand &cd : nd.t3) f(cd);
+  };
+  auto srcOf = [&](const WCand &cd) { return (int)(cd.src & 0x3fffffffu); };
+  auto kept = [&](const WCand &cd) { const int y = srcOf(cd); return y < S && live[y] && cd.w != -INFINITY; };
+  std::vector<int> off(S + 1, 0), adj, weight(S, 3);
+  for (const WNode &nd : nodes) forCands(nd, [&](const WCand &cd) { if (kept(cd)) off[srcOf(cd) + 1]++; });
+  for (int v = 0; v < S; ++v) off[v + 1] += off[v];
+  adj.resize(off[S]);
+  { std::vector<int> fillAt(off.begin(), off.end() - 1);
+    for (const WNode &nd : nodes) { const int x = (int)(nd.dst & W_IDX_MASK); forCands(nd, [&](const WCand &cd) { if (kept(cd)) { adj[fillAt[srcOf(cd)]++] = x; weight[x]++; } }); } }
+  std::vector<int> comp;
+  const int nComp = scc_of(S, off, adj, comp);
+  // a topological order of the components that follows the sweep's own order of states where it can (Kahn, the ready component with
+  // the earliest state first), cut where the running weight (candidates + a round's share per state) passes i / k of the total
+  std::vector<int> key(nComp, backward ? -1 : S), indeg(nComp, 0);
+  std::vector<long long> cw(nComp, 0);
+  for (int v = 0; v < S; ++v) { key[comp[v]] = backward ? std::max(key[comp[v]], v) : std::min(key[comp[v]], v); cw[comp[v]] += weight[v]; }
+  std::vector<std::vector<int>> cadj(nComp);
+  for (int v = 0; v < S; ++v)
+    for (int a = off[v]; a < off[v + 1]; ++a) if (comp[adj[a]] != comp[v]) cadj[comp[v]].push_back(comp[adj[a]]);
+  for (auto &l : cadj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); for (int c : l) indeg[c]++; }
+  auto later = [&](int a, int b) { return backward ? key[a] < key[b] : key[a] > key[b]; };      // (priority_queue: the top is the one that is not "later")
+  std::priority_queue<int, std::vector<int>, decltype(later)> ready(later);
+  for (int c = 0; c < nComp; ++c) if (!indeg[c]) ready.push(c);
+  long long total = 0, run = 0;
+  for (long long w : cw) total += w;
+  std::vector<int> partOfComp(nComp, 0);
+  int cur = 0, seen = 0;
+  while (!ready.empty()) {
+    const int c = ready.top(); ready.pop(); ++seen;
+    if (cur + 1 < k && run > 0 && run + cw[c] / 2 >= total * (cur + 1) / k) ++cur;
+    partOfComp[c] = cur; run += cw[c];
+    for (int d : cadj[c]) if (!--indeg[d]) ready.push(d);
+  }
+  if (seen != nComp) return false;
+  const int K = cur + 1;
+  if (K < 2) return false;
+  std::vector<int> partOf(S), expIdx(S, -1), loc(S, -1);
+  for (int v = 0; v < S; ++v) partOf[v] = partOfComp[comp[v]];
+  std::vector<char> exported(S, 0);
+  for (int v = 0; v < S; ++v)
+    for (int a = off[v]; a < off[v + 1]; ++a) {
+      if (partOf[adj[a]] < partOf[v]) return false;      // (cannot happen: the order is topological)
+      if (partOf[adj[a]] > partOf[v]) exported[v] = 1;
+    }
+  std::vector<int> expIdx0(K + 1, 0);
+  for (int p = 0; p < K; ++p) {
+    expIdx0[p] = nExpTot;
+    for (int v = 0; v < S; ++v) if (partOf[v] == p && exported[v]) expIdx[v] = nExpTot++;
+  }
+  expIdx0[K] = nExpTot;
+  parts.resize(K);
+  const int resultState = backward ? 0 : S - 1;
+  for (int p = 0; p < K; ++p) {
+    std::vector<int> own, imps, exps;
+    for (int v = 0; v < S; ++v) if (partOf[v] == p) { loc[v] = (int)own.size(); own.push_back(v); if (exported[v]) exps.push_back(v); }
+    for (int v : own) if (nodeOf[v] >= 0) forCands(nodes[nodeOf[v]], [&](const WCand &cd) { if (kept(cd) && partOf[srcOf(cd)] != p) imps.push_back(srcOf(cd)); });
+    std::sort(imps.begin(), imps.end()); imps.erase(std::unique(imps.begin(), imps.end()), imps.end());
+    RetPart spec; spec.nOwn = (int)own.size(); spec.nImp = (int)imps.size(); spec.nExp = (int)exps.size();
+    const int SV = spec.nOwn + spec.nImp + spec.nExp;
+    auto localOf = [&](const WCand &cd, WCand &out) -> bool {      // false: a candidate the program drops anyway (its source never holds a value)
+      const int y = srcOf(cd);
+      out = cd;
+      if (y == S + 1) { out.src = (cd.src & 0xC0000000u) | (uint32_t)(SV + 1); return true; }
+      if (y >= S || !live[y] || cd.w == -INFINITY) return false;
+      const int v = partOf[y] == p ? loc[y] : spec.nOwn + (int)(std::lower_bound(imps.begin(), imps.end(), y) - imps.begin());
+      out.src = (cd.src & 0xC0000000u) | (uint32_t)v;
+      return true;
+    };
+    std::vector<WNode> ln;
+    for (int v : own) {
+      if (nodeOf[v] < 0) continue;
+      const WNode &nd = nodes[nodeOf[v]];
+      WNode o{CUR(loc[v]), 0, {}, {}};
+      o.t2.resize(nd.t2.size());
+      WCand c2;
+      for (size_t t = 0; t < nd.t2.size(); ++t) for (const WCand &cd : nd.t2[t]) if (localOf(cd, c2)) o.t2[t].push_back(c2);
+      for (const WCand &cd : nd.t3) if (localOf(cd, c2)) o.t3.push_back(c2);
+      ln.push_back(std::move(o));
+    }
+    for (int i = 0; i < spec.nImp; ++i) ln.push_back(WNode{CUR(spec.nOwn + i), 0, {}, {}});
+    for (int j = 0; j < spec.nExp; ++j) ln.push_back(WNode{CUR(spec.nOwn + spec.nImp + j), 0, {}, {WCand{CUR(loc[exps[j]]), 0.0}}});
+    WideProgram T;
+    T.backward = backward; T.viterbi = viterbi; T.tbCodes = tbCodes; T.W = W;
+    WidePartHost &H = parts[p];
+    if (!wide_ret_build(m, T, ln, nTok, &H.stream, 0, &spec) || !T.retOk || T.retGv) { parts.clear(); return false; }
+    H.h = WidePartDev{};
+    H.h.ret = T.ret; H.h.ret.rec = nullptr;
+    H.h.Sloc = spec.nOwn; H.h.nImp = spec.nImp; H.h.expBase = spec.nOwn + spec.nImp + 2; H.h.expIdx0 = expIdx0[p]; H.h.nExp = spec.nExp;
+    H.h.resultEntry = partOf[resultState] == p ? loc[resultState] : -1;
+    H.tab.clear();
+    for (int v : own) H.tab.push_back((uint32_t)v);
+    for (int y : imps) H.tab.push_back((uint32_t)expIdx[y]);
+    H.period = T.retPeriod;
+    H.ldsBytes = ((T.retLdsBytes + 7) & ~(size_t)7) + 512 + 4 * (size_t)spec.nOwn;
+    if (verbose)
+      fprintf(stderr, "[mbhip] wide retimed part %d of %d: %d states, %d imports, %d exports, period %d, %d slots per period, %d columns in flight, ring %d x %d, LDS %zu bytes\n",
+              p, K, spec.nOwn, spec.nImp, spec.nExp, T.retPeriod, T.ret.nSlots, T.ret.kMax + 1, T.ret.NB, T.ret.NVs, H.ldsBytes);
+    for (int v : own) loc[v] = -1;
+  }
+  return true;
 }
 
 bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P) {
@@ -1596,7 +1854,13 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
   return 0;
 }
 
+static int g_last_parts = 1;
 const char *wide_kernel_name(const WideProgram &P) {
+  if (P.retOk && g_last_parts > 1) {      // (asked after the launch)
+    static thread_local char nm[64];
+    snprintf(nm, sizeof(nm), "k_wide_retimed<%s> in %d parts", P.viterbi ? (P.tbCodes ? "1,codes" : "1") : "0", g_last_parts);
+    return nm;
+  }
   if (P.retOk) return P.retGv ? (P.viterbi ? "k_wide_retimed<1,L2>" : "k_wide_retimed<0,L2>") : (P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>");
   if (P.f32) return "k_wide_sum32";
   if (P.viterbi) return P.vitOk ? "k_wide_viterbi" : "k_wide_sweep<1>";
@@ -1608,9 +1872,112 @@ const char *wide_kernel_name(const WideProgram &P) {
 static bool g_wide_accurate = false;
 void wide_set_accurate(bool on) { g_wide_accurate = on; }
 
+// ---- k workgroups per sequence: program sets and launches ------------------------------------------------------------------------
+int wide_last_parts() { return g_last_parts; }
+static bool g_parts_pending = false;        // a partitioned launch since the status was last read
+static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for an exchange value ran out (sticky until wide_parts_failed looks)
+
+// k for a launch of nPairs sequences that may count on `cus` CUs: as many parts as fit, at most MB_ONETAPE_PARTS (default 4; 0 or 1:
+// off).  Measured on the 5 063-state machine: a part's period is bound by its chain of stages, not by its width -- 4 parts
+// of 512 lanes are the best cut for every mode, 8 and 16 parts no better; two parts (of 1 024 lanes) pay for the sum sweeps only.
+static int wide_parts_k(const WideProgram &P, long long nPairs, int cus) {
+  if (!P.retOk || nPairs <= 0 || cus <= 0) return 1;
+  const int maxK = env_int_w("MB_ONETAPE_PARTS", 4);
+  const long long k = std::min<long long>(maxK, cus / nPairs);
+  if (k < 2 || (k == 2 && P.viterbi && !getenv("MB_ONETAPE_PARTS"))) return 1;
+  return (int)k;
+}
+
+static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
+  int lanes = env_int_w("MB_ONETAPE_PART_LANES", k <= 2 ? 1024 : 512);
+  if (lanes < 64 || lanes > 1024 || lanes % 64) lanes = 512;
+  for (WidePartSet &ps : P.partSets) if (ps.kWanted == k && ps.W == lanes) return ps.ok ? &ps : nullptr;
+  P.partSets.emplace_back();
+  WidePartSet &ps = P.partSets.back();
+  ps.kWanted = k;
+  ps.W = lanes;
+  std::vector<WidePartHost> hp;
+  if (!wide_parts_host(m, P.backward, P.viterbi, P.tbCodes, k, ps.W, hp, ps.nExpTot)) return nullptr;
+  ps.k = (int)hp.size();
+  ps.d_rec.assign(ps.k, nullptr); ps.d_tab.assign(ps.k, nullptr);
+  ps.h_parts.resize(ps.k);
+  for (int p = 0; p < ps.k; ++p) {
+    if (!up_w(ps.d_rec[p], hp[p].stream) || !up_w(ps.d_tab[p], hp[p].tab)) return nullptr;
+    WidePartDev d = hp[p].h;
+    d.ret.rec = ps.d_rec[p]; d.gmap = ps.d_tab[p]; d.impIdx = ps.d_tab[p] + d.Sloc;
+    ps.h_parts[p] = d;
+    ps.ldsBytes = std::max(ps.ldsBytes, hp[p].ldsBytes);
+    ps.period.push_back(hp[p].period); ps.slots.push_back(d.ret.nSlots);
+  }
+  if (!up_w(ps.d_parts, ps.h_parts)) return nullptr;
+  if (!g_part_err) {
+    if (!hip_ok(hipMalloc((void **)&g_part_err, 256), "hipMalloc(part status)") || !hip_ok(hipMemset(g_part_err, 0, 256), "hipMemset(part status)")) { g_part_err = nullptr; return nullptr; }
+  }
+  ps.ok = true;
+  return &ps;
+}
+
+// after the stream(s) of partitioned launches have been synchronised: did a wait run out?  (the flag is cleared)
+bool wide_parts_failed() {
+  if (!g_part_err || !g_parts_pending) return false;
+  g_parts_pending = false;
+  unsigned e = 0;
+  if (hipMemcpy(&e, g_part_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) { set_error("one-tape parts: status unreadable"); return true; }
+  if (!e) return false;
+  (void)hipMemset(g_part_err, 0, sizeof(e));
+  set_error("one-tape sweep with k workgroups per sequence: a workgroup waited longer than MB_ONETAPE_PART_TIMEOUT_S for a value of another part (results discarded)");
+  return true;
+}
+
+// mode: 0 fp64 cells / log-likelihood only, 1 traceback codes
+static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps, const PairDesc *d_desc, const PairDesc *h_desc, long long nPairs, const int *d_tape,
+                           double *pool, double *loglike, hipStream_t st, bool lastOnly, bool tb) {
+  // exchange rows: one per column of every sequence; the buffer starts with the sequences' first rows (filled in on the device)
+  long long rows = 0;
+  for (long long p = 0; p < nPairs; ++p) rows += (long long)(m->nOut ? h_desc[p].outLen : h_desc[p].inLen) + 1;
+  const size_t headBytes = ((size_t)nPairs * sizeof(long long) + 255) & ~(size_t)255, xBytes = (size_t)rows * (size_t)ps.nExpTot * sizeof(double);
+  char *buf = (char *)ws_get(P.backward ? 14 : 13, headBytes + std::max<size_t>(xBytes, 8));
+  if (!buf) return 1;
+  hipLaunchKernelGGL(k_wide_part_rows, dim3(1), dim3(1), 0, st, d_desc, (int)nPairs, m->nOut ? 0 : 1, (long long *)buf);
+  MB_HIP(hipMemsetAsync(buf + headBytes, 0xFF, std::max<size_t>(xBytes, 8), st));
+  WidePartArgs A{};
+  A.parts = ps.d_parts; A.nSeq = (int)nPairs; A.nExpTot = ps.nExpTot; A.X = (double *)(buf + headBytes); A.xOff = (const long long *)buf;
+  A.err = g_part_err; A.timeoutTicks = (long long)std::max(1, env_int_w("MB_ONETAPE_PART_TIMEOUT_S", 20)) * 100000000ll;
+  WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0; dev.W = ps.W;
+  // one workgroup per CU: a part's LDS is padded beyond half a CU's (the parts of a sequence are meant to run side by side on CUs of their own)
+  size_t lds = ps.ldsBytes;
+  if (env_int_w("MB_ONETAPE_PART_EXCLUSIVE", 1)) lds = std::max<size_t>(lds, 82 * 1024);
+  if (lds > WIDE_LDS_MAX) { set_error("one-tape parts: LDS"); return 1; }
+  static bool attr = false;
+  if (!attr) {
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_VITERBI, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_VITERBI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_FORWARD, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_FORWARD, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
+    attr = true;
+  }
+  const dim3 grid((unsigned)(nPairs * ps.k)), block((unsigned)ps.W);
+  if (P.viterbi) {
+    if (tb) hipLaunchKernelGGL((k_wide_retimed_parts<MB_VITERBI, true, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
+    else hipLaunchKernelGGL((k_wide_retimed_parts<MB_VITERBI, false, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
+  } else if (g_wide_accurate) hipLaunchKernelGGL((k_wide_retimed_parts<MB_FORWARD, false, true>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
+  else hipLaunchKernelGGL((k_wide_retimed_parts<MB_FORWARD, false, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
+  MB_HIP(hipGetLastError());
+  g_last_launches += 1;
+  g_last_parts = ps.k;
+  g_parts_pending = true;
+  return 0;
+}
+
+int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus) {
+  const int k = wide_parts_k(P, nPairs, cus);
+  if (k < 2) return 1;
+  WidePartSet *ps = wide_parts_get(m, P, k);
+  return ps ? ps->k : 1;
+}
+
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
-              double *loglike, hipStream_t st, bool lastOnly) {
-  (void)m;
+              double *loglike, hipStream_t st, bool lastOnly, const PairDesc *h_desc, int cus) {
   const int *d_out = d_tape;       // the token array of the machine's one tape (outputs of a generator, inputs of a recogniser)
   if (!P.ok) { set_error("wide program not built"); return 1; }
   if (nPairs <= 0) return 0;
@@ -1618,6 +1985,12 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   // sweep direction, so that a Forward and a Backward sweep may run side by side on two streams); nothing here waits for
   // the device
   const int scratchSlot = P.backward ? 12 : 11;
+  g_last_parts = 1;
+  if (P.retOk && h_desc) {
+    const int k = wide_parts_k(P, nPairs, cus);
+    WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
+    if (ps) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, pool, loglike, st, lastOnly, false);
+  }
   if (P.retOk) {
     static bool attr = false;
     if (!attr) {
@@ -1683,10 +2056,15 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
 }
 
 int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, unsigned char *tb,
-                 double *loglike, hipStream_t st) {
-  (void)m;
+                 double *loglike, hipStream_t st, const PairDesc *h_desc, int cus) {
   if (!P.ok || !P.retOk || !P.tbOk || !P.viterbi || P.backward) { set_error("one-tape traceback-code program not built"); return 1; }
   if (nPairs <= 0) return 0;
+  g_last_parts = 1;
+  if (h_desc) {
+    const int k = wide_parts_k(P, nPairs, cus);
+    WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
+    if (ps) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true);
+  }
   static bool attr = false;
   if (!attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));

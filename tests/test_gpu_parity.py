@@ -20,6 +20,12 @@ pytestmark = pytest.mark.gpu
 REL_EXACT = 1e-11   # device exp/log1p vs libm, accumulated over the lattice
 FAST_REL = 2e-6     # tiled families: fp32 exp/log correction term, ~1e-7 abs per cell, accumulated along the lattice
 FAST_ABS = 2e-5
+
+
+def _one_wg(name):
+    """kernel name without the ' in k parts' of a sweep that ran k workgroups per sequence"""
+    import re
+    return re.sub(r" in \d+ parts", "", name)
 ABS_TABLE = 1e-4    # vs the reference's table build: the table drops terms >= 10 nats below the running max and
 REL_TABLE = 1e-4    # interpolates at step 1e-4 (src/logsumexp.h:20-21,48-70); 1e-4 relative is the north-star tolerance
 COUNT_TOL = 1e-9
@@ -511,7 +517,7 @@ def test_baseline_config5_one_sequence_at_50kb_against_the_oracle(capi, oracle_m
     finally:
         capi.set_option("MB_ONETAPE_SPLIT", None)
     llm = b.forward(capi.MB_MATERIALISE)
-    assert k1 == "k_wide_retimed<0> x2 + k_onetape_join" and k2 == "k_wide_retimed<0>"
+    assert _one_wg(k1) == "k_wide_retimed<0> x2 + k_onetape_join" and _one_wg(k2) == "k_wide_retimed<0>"
     assert close([llr[0], llp[0], llm[0]], [ref] * 3, FAST_REL, FAST_ABS)
     assert close(llr, [om.loglike(x, y, oracle_mod.SUM_TABLE)], REL_TABLE, ABS_TABLE)
     V = om.viterbi(x, y)
@@ -1348,7 +1354,7 @@ def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
         pairs = [(z, q) if tape else (q, z) for q in seqs]
         ref = np.zeros(em.nTransitions)
         for x, y in pairs:
-            V = dm.fill(capi.MB_VITERBI, x, y); assert capi.last_kernel_name() == ("k_wide_retimed<1,L2>" if "MB_WIDE_GLOBAL_VECTORS" in knobs else "k_wide_retimed<1>")
+            V = dm.fill(capi.MB_VITERBI, x, y); assert _one_wg(capi.last_kernel_name()) == ("k_wide_retimed<1,L2>" if "MB_WIDE_GLOBAL_VECTORS" in knobs else "k_wide_retimed<1>")
             F = dm.fill(capi.MB_FORWARD, x, y); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
             B = dm.fill(capi.MB_BACKWARD, x, y)
             assert np.array_equal(V, om.viterbi(x, y))
@@ -1498,6 +1504,79 @@ def test_one_tape_split_forward(capi, oracle_mod, monkeypatch):
     assert close(llr, [orr.loglike(xx, np.zeros(0, np.int32), oracle_mod.SUM_EXACT) for xx in xs], FAST_REL, FAST_ABS)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"MB_ONETAPE_PARTS": "7", "MB_ONETAPE_PART_LANES": "128"}, {"MB_ONETAPE_PARTS": "2"}, {"MB_ONETAPE_PARTS": "3", "MB_ONETAPE_PART_LANES": "1024", "MB_ONETAPE_PART_EXCLUSIVE": "0"}])
+def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs):
+    """k workgroups per sequence (k_wide_retimed_parts): with fewer sequences than CUs the machine is cut into parts along
+    a topological order of its strongly connected components, one retimed program and one workgroup per part, values crossing through
+    an exchange buffer.  Against the ONE-workgroup sweep (MB_ONETAPE_PARTS=1) and the oracle, on config 5's literal composition with a
+    3-node profile (762 states) and ragged lengths (an empty sequence among them): Viterbi matrices, scores and paths bit for bit --
+    through fp64 cells and through traceback codes --, Forward / Backward matrices to 1e-9 (the same candidates, summed by other lane
+    groups), rolling log-likelihoods (cut in two on top) and counts within the fast-path tolerance of the oracle;
+    default cut, seven parts of two wavefronts, two parts, three parts sharing CUs."""
+    m, em = _profile_machine(3)
+    om = oracle_mod.OracleMachine(em)
+    rng = np.random.RandomState(11)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (0, 1, 63, 200, 129, 64)]
+    pairs = [(x, y) for y in ys]
+    monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
+    monkeypatch.setenv("MB_ONETAPE_TRACEBACK_MIN_TRANS", "0")
+    def run(dm):
+        b = capi.DeviceBatch.from_pairs(dm, pairs)
+        out = {"names": []}
+        def note(): out["names"].append(capi.last_kernel_name())
+        out["roll"] = b.forward(capi.MB_ROLLING); note()
+        out["mat"] = b.forward(capi.MB_MATERIALISE); note()
+        out["vit"] = b.viterbi(); note()
+        monkeypatch.setenv("MB_ONETAPE_TB", "0")
+        out["vit64"] = b.viterbi(); note()
+        monkeypatch.delenv("MB_ONETAPE_TB")
+        out["cnt"] = b.counts(); note()
+        y = ys[3]
+        out["V"] = dm.fill(capi.MB_VITERBI, x, y); note()
+        out["F"] = dm.fill(capi.MB_FORWARD, x, y); note()
+        out["B"] = dm.fill(capi.MB_BACKWARD, x, y); note()
+        return out
+    monkeypatch.setenv("MB_ONETAPE_PARTS", "1")
+    dm1 = capi.DeviceMachine(em)
+    one = run(dm1)
+    assert not any("parts" in n for n in one["names"])
+    monkeypatch.delenv("MB_ONETAPE_PARTS")
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    dmk = capi.DeviceMachine(em)
+    got = run(dmk)
+    want = int(knobs.get("MB_ONETAPE_PARTS", "4"))
+    sweeps = [n for n in got["names"] if "k_wide_retimed" in n]
+    assert sweeps and all(" parts" in n for n in sweeps if not (want == 2 and "<1" in n and "MB_ONETAPE_PARTS" not in knobs)), got["names"]
+    assert any("in %d parts" % want in n for n in sweeps) or want > 4, got["names"]      # (a cut may come out with fewer parts than asked for)
+    # bit for bit against the one-workgroup sweep
+    assert np.array_equal(got["V"], one["V"])
+    for key in ("F", "B", "mat"):      # (other lane groups: another order of the same sum, and other fp32 roundings of its correction term)
+        d = np.abs(np.asarray(got[key]) - np.asarray(one[key])); d = d[np.isfinite(d)]
+        assert np.array_equal(np.isneginf(got[key]), np.isneginf(one[key])) and (d.size == 0 or d.max() < 1e-6), (key, float(d.max()))
+    for key in ("vit", "vit64"):
+        for a, b_ in zip(got[key], one[key]): assert np.array_equal(np.asarray(a), np.asarray(b_)), key
+    assert close(got["roll"], one["roll"], 1e-8, 1e-9) and close(got["cnt"][0], one["cnt"][0], 1e-6, 1e-9)
+    # ... and against the oracle
+    y = ys[3]
+    assert np.array_equal(got["V"], om.viterbi(x, y))
+    assert close(got["F"], om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(got["B"], om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+    vll, off, edges = got["vit"]
+    ref = np.zeros(em.nTransitions)
+    for k, (xx, yy) in enumerate(pairs):
+        Vo = om.viterbi(xx, yy)
+        assert vll[k] == Vo[-1, -1, -1] and close([got["roll"][k]], [om.loglike(xx, yy, oracle_mod.SUM_EXACT)], FAST_REL, FAST_ABS)
+        if Vo[-1, -1, -1] > -math.inf:
+            assert np.array_equal(edges[off[k]:off[k + 1]], om.traceback(xx, yy, Vo))
+            om.counts_add(xx, yy, ref, oracle_mod.SUM_EXACT)
+    assert close(got["cnt"][0], ref, 1e-5, 1e-7)
+    # a weight update rebuilds the parts
+    lw = np.array(em.logWeight, dtype=np.float64) - 0.0625
+    dmk.set_weights(lw); om.set_weights(lw)
+    assert np.array_equal(dmk.fill(capi.MB_VITERBI, x, y), om.viterbi(x, y)) and " parts" in capi.last_kernel_name()
+    dm1.close(); dmk.close()
+
+
 @pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])
 def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, nodes, nSeq, L):
     """BASELINE config 5 at the sizes that select the one-tape family's DEFAULT paths (no environment forcing): the 20-node
@@ -1515,7 +1594,7 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     llr = b.forward(capi.MB_ROLLING)
     kern = capi.last_kernel_name()
-    assert kern.startswith("k_wide_retimed<0>" if nodes == 20 else "k_wide_retimed<0,L2>")   # (+ " x2 + k_onetape_join": few sequences are cut in two)
+    assert kern.startswith("k_wide_retimed<0>" if nodes == 20 else "k_wide_retimed<0> in 4 parts")      # (21 761 states: one workgroup keeps its ring in L2, the four parts of eight sequences keep theirs in LDS)   # (+ " x2 + k_onetape_join": few sequences are cut in two)
     nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
     bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
     llm = bm.forward(capi.MB_MATERIALISE)
@@ -1573,11 +1652,11 @@ def test_baseline_config5_at_its_stated_length(capi, monkeypatch):
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     assert b.cells() == nSeq * (L + 1) * 5063
     llr = b.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() == "k_wide_retimed<0> x2 + k_onetape_join"     # 2 x 64 workgroups <= 256 CUs: cut in two
+    assert _one_wg(capi.last_kernel_name()) == "k_wide_retimed<0> x2 + k_onetape_join"     # 2 x 64 workgroups <= 256 CUs: cut in two
     assert np.all(np.isfinite(llr)) and llr[0] == llr[1] == llr[63]
     monkeypatch.setenv("MB_ONETAPE_SPLIT", "0")
     llp = b.forward(capi.MB_ROLLING)
-    assert capi.last_kernel_name() == "k_wide_retimed<0>" and close(llr, llp, 1e-8) and llp[0] == llp[1] == llp[63]
+    assert _one_wg(capi.last_kernel_name()) == "k_wide_retimed<0>" and close(llr, llp, 1e-8) and llp[0] == llp[1] == llp[63]
     monkeypatch.delenv("MB_ONETAPE_SPLIT")
     b2 = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:2]])                # 2 x 2.03 GB matrices
     llm = b2.forward(capi.MB_MATERIALISE)

@@ -19,19 +19,29 @@ from randmachine import random_machine
 NO_DST = 0x3ffff
 
 
-def simulate(prog, seq, backward, mode_max, tb=False):
+def simulate(prog, seq, backward, mode_max, tb=False, part=None):
     """cells[column][state] of one sequence from the record streams (the kernel's data flow, slot by slot).
+    part = (X, cells, codes): `prog` is one PART of a machine cut for k workgroups per sequence (capi.debug_wide_parts): its imports
+    come from the exchange array X[column][exchange column] through the penalty table's tail (the kernel's wait for a value is the
+    assertion that an earlier part has written it), its exports go there, its own states' cells go to their machine columns.
     tb (forward max program built for traceback codes): also codes[column][state] -- the place of the cell's first maximal
     candidate in its node's list, as k_wide_retimed<1,.,codes> keeps it: a lane remembers the slot of its first strictly greater
     candidate within the round, the place is slot * group + lane within the group, and among the lanes that hold the group's
     maximum the smallest place wins."""
-    W, NB, NVs, kMax, rowLen, S, inL2 = (prog[k] for k in ("lanes", "NB", "NVs", "kMax", "rowLen", "S", "inL2"))
+    W, NB, NVs, kMax, rowLen, inL2 = (prog[k] for k in ("lanes", "NB", "NVs", "kMax", "rowLen", "inL2"))
+    S = prog["Sloc"] if part else prog["S"]
     L = len(seq)
     V = np.full(NB * NVs, -np.inf)
     for b in range(NB):
         V[b * NVs + S + 1] = 0.0
-    cells = np.full((L + 1, S), np.nan)
-    codes = np.full((L + 1, S), -1, np.int64)
+    if part:
+        X, cells, codes = part
+        gmap = prog["gmap"]
+        assert prog["nPen"] == (kMax + 1) * rowLen and prog["nImp"] <= W and prog["expBase"] == S + prog["nImp"] + 2
+    else:
+        cells = np.full((L + 1, S), np.nan)
+        codes = np.full((L + 1, S), -1, np.int64)
+        gmap = np.arange(S)
     best = np.zeros(W, np.int64)
     tok_at = lambda c: (int(seq[L - c]) if backward else int(seq[c - 1])) if 1 <= c <= L else 0
     lanes = np.arange(W)
@@ -44,6 +54,10 @@ def simulate(prog, seq, backward, mode_max, tb=False):
             if c == 0: pen[kt, rowLen - 1] = 0.0
             if c >= 1 and 0 < tok_at(c) < rowLen - 1: pen[kt, tok_at(c)] = 0.0
         pen = pen.reshape(-1)
+        if part:      # the imports of the period's newest column, behind the (ktau, token) entries
+            imp = X[t, prog["impIdx"]] if t <= L else np.full(prog["nImp"], -np.inf)
+            assert not np.any(np.isnan(imp)), "an import is read before an earlier part wrote it"
+            pen = np.concatenate([pen, imp])
         m = np.full(W, -np.inf); ssum = np.zeros(W)
         slot_in_round = 0
         for rec in prog["records"][cm]:
@@ -84,13 +98,37 @@ def simulate(prog, seq, backward, mode_max, tb=False):
                 if 0 <= c <= L:
                     assert vec == c % NB                          # the node's own column's vector
                     V[vec * NVs + x] = res
+                    if part and prog["expBase"] <= x < prog["expBase"] + prog["nExp"]:      # (relay entries follow the exports)
+                        e = prog["expIdx0"] + x - prog["expBase"]
+                        assert np.isnan(X[c, e])
+                        X[c, e] = res
                     if x < S:
-                        assert np.isnan(cells[L - c if backward else c, x])      # every cell exactly once
-                        cells[L - c if backward else c, x] = res
-                        if tb: assert 0 <= code < 256; codes[c, x] = code
+                        assert np.isnan(cells[L - c if backward else c, gmap[x]])      # every cell exactly once
+                        cells[L - c if backward else c, gmap[x]] = res
+                        if tb: assert 0 <= code < 256; codes[c, gmap[x]] = code
             m[:] = -np.inf; ssum[:] = 0.0
             best[:] = 0; slot_in_round = 0
+    if part: return None
     assert not np.any(np.isnan(cells))
+    return (cells, codes) if tb else cells
+
+
+def simulate_parts(pp, seq, backward, mode_max, tb=False):
+    """The k parts of one machine, one after the other in the order their workgroups are numbered (a part reads what LOWER parts
+    export): cells (and codes) of the whole machine."""
+    L = len(seq)
+    X = np.full((L + 1, max(pp["nExp"], 1)), np.nan)
+    cells = np.full((L + 1, pp["S"]), np.nan)
+    codes = np.full((L + 1, pp["S"]), -1, np.int64)
+    owners = np.concatenate([p["gmap"] for p in pp["parts"]])
+    assert np.array_equal(np.sort(owners), np.arange(pp["S"]))            # every state belongs to exactly one part
+    assert sum(p["nExp"] for p in pp["parts"]) == pp["nExp"] and sum(p["resultEntry"] >= 0 for p in pp["parts"]) == 1
+    for p in pp["parts"]:
+        assert np.all(p["impIdx"] < p["expIdx0"])                         # imports come from lower parts only
+        simulate(p, seq, backward, mode_max, tb, part=(X, cells, codes))
+    assert not np.any(np.isnan(cells)) and not np.any(np.isnan(X[:, :pp["nExp"]]))
+    res = [p for p in pp["parts"] if p["resultEntry"] >= 0][0]
+    assert res["gmap"][res["resultEntry"]] == (0 if backward else pp["S"] - 1)
     return (cells, codes) if tb else cells
 
 
@@ -223,6 +261,56 @@ def test_retimed_program_of_the_config5_machine(tmp_path):
     for n in (0, 4):
         seq = np.random.RandomState(50 + n).randint(1, 5, size=n).astype(np.int32)
         assert np.array_equal(simulate(prog, seq, False, True), om.viterbi(z, seq).reshape(n + 1, em.nStates))
+
+
+@pytest.mark.parametrize("name", ["fn3-10", "composite-2", "random-40", "random-recogniser-25"])
+@pytest.mark.parametrize("k,lanes", [(2, 256), (3, 64), (4, 1024)])
+def test_k_part_programs_reproduce_the_oracle(name, k, lanes, tmp_path):
+    """k workgroups per sequence (round 5, BASELINE config 5 on a chip with more CUs than sequences): the machine's graph cut along a
+    topological order of its strongly connected components, every part a retimed program of its own, values crossing through an
+    exchange array.  WITHOUT a device: replaying the parts' record streams gives the oracle's Viterbi cells bit for bit (and the
+    traceback codes decode to the oracle's paths through the ONE-workgroup program's tables), Forward / Backward cells to 1e-12."""
+    from machineboss_amd import capi
+    from oracle import oracle
+    em = _machines()[name]
+    tape_out = em.nOutTok > 0
+    nt = em.nOutTok if tape_out else em.nInTok
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    try:
+        pv = capi.debug_wide_parts(em, str(tmp_path / "pv.bin"), k, lanes, capi.MB_VITERBI, False)
+    except RuntimeError as e:
+        assert name.startswith("random") and "no k-part" in str(e)      # (a random machine may be one component)
+        pytest.skip("the machine's graph has no cut")
+    assert 2 <= len(pv["parts"]) <= k
+    for mode, backward in ((capi.MB_VITERBI, False), (capi.MB_FORWARD, False), (capi.MB_FORWARD, True)):
+        pp = capi.debug_wide_parts(em, str(tmp_path / "p.bin"), k, lanes, mode, backward)
+        for n in (0, 1, 9, 70 if max(p["lanes"] * p["slots"] for p in pp["parts"]) <= 4096 else 20):
+            seq = np.random.RandomState(n + 3).randint(1, nt + 1, size=n).astype(np.int32)
+            x, y = (z, seq) if tape_out else (seq, z)
+            got = simulate_parts(pp, seq, backward, mode == capi.MB_VITERBI)
+            if mode == capi.MB_VITERBI: ref = om.viterbi(x, y)
+            else: ref = om.backward(x, y, oracle.SUM_EXACT) if backward else om.forward(x, y, oracle.SUM_EXACT)
+            ref = ref.reshape(n + 1, em.nStates)
+            if mode == capi.MB_VITERBI: assert np.array_equal(got, ref)
+            else:
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+    # traceback codes: the parts write the codes of the one-workgroup program
+    try:
+        one = capi.debug_wide_retimed(em, str(tmp_path / "tb.bin"), capi.MB_VITERBI, False, tb_codes=True)
+    except RuntimeError:
+        return
+    pt = capi.debug_wide_parts(em, str(tmp_path / "pt.bin"), k, lanes, capi.MB_VITERBI, False, tb_codes=True)
+    for n in (9, 33):
+        seq = np.random.RandomState(n + 5).randint(1, nt + 1, size=n).astype(np.int32)
+        x, y = (z, seq) if tape_out else (seq, z)
+        cells, codes = simulate_parts(pt, seq, False, True, tb=True)
+        V = om.viterbi(x, y)
+        assert np.array_equal(cells, V.reshape(n + 1, em.nStates))
+        cells1, codes1 = simulate(one, seq, False, True, tb=True)
+        assert np.array_equal(codes, codes1)
+        if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_codes(one, codes, n), om.traceback(x, y, V))
 
 
 def test_retimed_program_refuses_two_tape_machines(tmp_path):
