@@ -382,7 +382,7 @@ def extra_single_gpu(capi, np, hbm_peak):
                           "counts_lattice": round(cells5 / t5c / 1e9, 2), "unit": "Gcells/s", "counts_ms": round(t5c * 1e3, 1),
                           "kernels": [k5, k5c], "loglike_sum": float(np.sum(ll5)),
                           "symbol_count_invariant": float(cnt5[np.asarray(em5.outTok) != 0].sum()) / (64 * 2000),
-                          "roofline": {"bound": "valu + barriers", "note": "one workgroup per sequence on 64 of 256 CUs (Forward, cut in two: 128); the retimed sweep (DESIGN.md 4.2b) turns a column's 366 dependent silent levels into a period of 10 barrier-separated rounds with 37 columns in flight; no HBM or MFMA bound applies",
+                          "roofline": {"bound": "valu + barriers", "note": "k workgroups per sequence (DESIGN.md 4.2d: 64 sequences x 4 parts, or cut in two x 2 parts -- every CU holds one workgroup); the retimed sweep (4.2b) turns a column's 366 dependent silent levels into a period of 9-10 barrier-separated rounds; the period is bound by that chain of stages; no HBM or MFMA bound applies",
                                        "issue": onetape_issue()}}
         del b5
         # ... with every CU busy: 256 sequences x 4 kb
@@ -417,6 +417,23 @@ def extra_single_gpu(capi, np, hbm_peak):
         except Exception as e:
             out["config5"]["full_size"]["counts_error"] = str(e)
         del b5f, e5p
+        # ... and what ONE GPU holds when the config is split over eight: 8 sequences x 50 kb.  A sequence is serial along its columns, so the
+        # only parallelism left is inside a column: k workgroups per sequence, against one workgroup per sequence
+        b5e = capi.DeviceBatch(dm5, *synth_batch(5, 8, 0, 50000, em5.nInTok, em5.nOutTok))
+        eight = {"workload": "the same machine, 8 sequences x 50000 nt (one GPU's share of config 5 split over 8 GPUs)"}
+        for label, env in (("k_workgroups_per_sequence", None), ("one_workgroup_per_sequence", "1")):
+            if env is None: os.environ.pop("MB_ONETAPE_PARTS", None)
+            else: os.environ["MB_ONETAPE_PARTS"] = env
+            _, te = timed(lambda: b5e.forward(capi.MB_ROLLING), 1); ke = capi.last_kernel_name()
+            _, tve = timed(lambda: b5e.viterbi(paths=False), 1); kve = capi.last_kernel_name()
+            _, tpe = timed(lambda: b5e.viterbi(), 1)
+            eight[label] = {"forward_ms": round(te * 1e3, 1), "viterbi_ms": round(tve * 1e3, 1), "viterbi_with_paths_ms": round(tpe * 1e3, 1), "kernels": [ke, kve]}
+        os.environ.pop("MB_ONETAPE_PARTS", None)
+        fs = out["config5"]["full_size"]
+        eight["strong_scaling_ceiling_over_8_gpus"] = {k: round(fs[k] / eight["k_workgroups_per_sequence"][k], 2) for k in ("forward_ms", "viterbi_ms", "viterbi_with_paths_ms")}
+        eight["note"] = "ceiling = time of 64 sequences on one GPU / time of 8 sequences on one GPU (no communication: the shards are independent)"
+        out["config5"]["eight_per_gpu"] = eight
+        del b5e
     except Exception as e:   # the extras never take the headline down
         out["config5"] = {"error": str(e)}
 
@@ -622,7 +639,7 @@ def main():
         extra["expected_scaling"] = {
             "config 2-4 (batches of pairs, this line)": "weak scaling 1.0 per GPU by construction: every rank fills its own pairs, no data-path collective; strong scaling of 256 pairs over 8 GPUs leaves 32 pairs per GPU, whose tile wavefront still fills 256 CUs (672 live tiles per launch)",
             "config 3 (--train)": "one all-reduce of nTransitions + 1 doubles (3.6 KB) per EM iteration: latency only",
-            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling 1.0x: a sequence is ONE workgroup (a one-tape lattice is serial along its columns), so 8 sequences per GPU take as long as 64 on one GPU (175 ms Forward); only a batch of more sequences than CUs scales (DESIGN.md 4.2b)"}
+            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling ~1.0-1.2x for the 5 063-state machine: a one-tape lattice is serial along its columns, a sequence is k <= 4 workgroups (DESIGN.md 4.2d: the period is bound by its chain of stages, more workgroups per sequence do not shorten it), so 8 sequences per GPU take almost as long as 64 on one GPU (extra.config5.eight_per_gpu of the N = 1 line measures it); only a batch of more sequences than CUs scales.  The whole fn3 profile (21 761 states, ring beyond one CU's LDS) does scale with workgroups per sequence: 64 -> 16 -> 4 sequences x 3 kb take 30 -> 17 -> 16 ms (Viterbi fill)"}
     if grp and not args.no_extra:
         # the ONE collective of the path (--train): E-step on this rank's shard of config 3, then the all-reduce of
         # nTransitions + 1 doubles over RCCL (xGMI)

@@ -1133,12 +1133,16 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
         if (hipEventCreateWithFlags(&evStart, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDone, hipEventDisableTiming) != hipSuccess ||
             hipEventRecord(evStart, g_stream) != hipSuccess || hipStreamWaitEvent(s2, evStart, 0) != hipSuccess) { set_error("one-tape split: stream set-up failed"); rc = 1; break; }
         // (with CUs to spare both halves run k workgroups per sequence, each launch on a stream of its own)
-        const bool parts = wide_parts_for(m, *W, n, device_cus() / 2) > 1 && wide_parts_for(m, *WB, n, device_cus() / 2) > 1;
+        // (a machine whose ring lives in L2 and whose parts fit the LDS only when a sweep has the whole chip: one half after the other)
+        bool parts = wide_parts_for(m, *W, n, device_cus() / 2) > 1 && wide_parts_for(m, *WB, n, device_cus() / 2) > 1;
+        const bool oneByOne = !parts && (W->retGv || WB->retGv) && wide_parts_for(m, *W, n, device_cus()) > 1 && wide_parts_for(m, *WB, n, device_cus()) > 1;
+        parts = parts || oneByOne;
+        const int share = oneByOne ? 1 : 2;
         const int fusedFill = parts ? -1 : wide_fill2(m, *W, *WB, d_pre, d_suf, n, n, tape, vec, vec + n * S, g_stream, true);   // both sweeps in ONE launch
         if (fusedFill > 0) { rc = 1; break; }
         if (fusedFill < 0) {                        // (programs of different kernel variants: two launches on two streams)
-          if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, s2, true, parts ? pre.data() : nullptr, device_cus() / 2))) break;
-          if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true, parts ? suf.data() : nullptr, device_cus() / 2))) break;
+          if ((rc = wide_fill(m, *W, d_pre, n, tape, vec, nullptr, oneByOne ? g_stream : s2, true, parts ? pre.data() : nullptr, device_cus() / share))) break;
+          if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true, parts ? suf.data() : nullptr, device_cus() / share))) break;
           if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
         }
         if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
@@ -1435,7 +1439,11 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         hipStream_t s2 = second_stream();
         if (!WB || !WF) { rc = 1; break; }
         // (with CUs to spare each fill runs k workgroups per sequence, on a stream of its own)
-        const bool parts = s2 && wide_parts_for(b->m, *WF, np, device_cus() / 2) > 1 && wide_parts_for(b->m, *WB, np, device_cus() / 2) > 1;
+        // (a machine whose ring lives in L2 and whose parts fit the LDS only when a fill has the whole chip: one fill after the other)
+        bool parts = s2 && wide_parts_for(b->m, *WF, np, device_cus() / 2) > 1 && wide_parts_for(b->m, *WB, np, device_cus() / 2) > 1;
+        const bool oneByOne = s2 && !parts && (WF->retGv || WB->retGv) && wide_parts_for(b->m, *WF, np, device_cus()) > 1 && wide_parts_for(b->m, *WB, np, device_cus()) > 1;
+        parts = parts || oneByOne;
+        const int share = oneByOne ? 1 : 2;
         const int fusedFill = parts ? -1 : wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch
         if (fusedFill > 0) { rc = 1; break; }
         if (fusedFill == 0) { fwdDone = true; g_last_kernel = wide_kernel_name(*WF); }
@@ -1445,8 +1453,8 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
           bool ok = hipEventCreateWithFlags(&evStart, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&evDone, hipEventDisableTiming) == hipSuccess;
           ok = ok && hipEventRecord(evStart, g_stream) == hipSuccess && hipStreamWaitEvent(s2, evStart, 0) == hipSuccess;   // s2 starts after what g_stream has queued (descriptors)
           if (ok) {
-            rc = wide_fill(b->m, *WF, d_desc, np, tape, fwd, nullptr, s2, false, parts ? hp.data() : nullptr, device_cus() / 2);
-            if (!rc) rc = wide_fill(b->m, *WB, d_desc, np, tape, bwd, nullptr, g_stream, false, parts ? hp.data() : nullptr, device_cus() / 2);
+            rc = wide_fill(b->m, *WF, d_desc, np, tape, fwd, nullptr, oneByOne ? g_stream : s2, false, parts ? hp.data() : nullptr, device_cus() / share);
+            if (!rc) rc = wide_fill(b->m, *WB, d_desc, np, tape, bwd, nullptr, g_stream, false, parts ? hp.data() : nullptr, device_cus() / share);
             ok = hipEventRecord(evDone, s2) == hipSuccess && hipStreamWaitEvent(g_stream, evDone, 0) == hipSuccess;
           }
           if (evStart) (void)hipEventDestroy(evStart);

@@ -1877,19 +1877,22 @@ int wide_last_parts() { return g_last_parts; }
 static bool g_parts_pending = false;        // a partitioned launch since the status was last read
 static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for an exchange value ran out (sticky until wide_parts_failed looks)
 
-// k for a launch of nPairs sequences that may count on `cus` CUs: as many parts as fit, at most MB_ONETAPE_PARTS (default 4; 0 or 1:
-// off).  Measured on the 5 063-state machine: a part's period is bound by its chain of stages, not by its width -- 4 parts
-// of 512 lanes are the best cut for every mode, 8 and 16 parts no better; two parts (of 1 024 lanes) pay for the sum sweeps only.
+// k for a launch of nPairs sequences that may count on `cus` CUs: as many parts as fit, at most MB_ONETAPE_PARTS (0 or 1: off).
+// Measured.  A machine whose ring fits the LDS of ONE CU (5 063 states): a part's period is bound by its chain of stages,
+// not by its width -- 4 parts of 512 lanes are the best cut for every mode (+5...12 %), 8 and 16 parts no better, two parts (of 1 024
+// lanes) pay for the sum sweeps only: default at most 4.  A machine whose ring lives in L2 (21 761 states): the parts bring it into
+// LDS -- 16 sequences: Viterbi fill 160 -> 17 ms with 16 parts, log-likelihoods 79 -> 12.5 ms with 8 -- default at most 16.
 static int wide_parts_k(const WideProgram &P, long long nPairs, int cus) {
   if (!P.retOk || nPairs <= 0 || cus <= 0) return 1;
-  const int maxK = env_int_w("MB_ONETAPE_PARTS", 4);
+  const int maxK = env_int_w("MB_ONETAPE_PARTS", P.retGv ? 16 : 4);
   const long long k = std::min<long long>(maxK, cus / nPairs);
-  if (k < 2 || (k == 2 && P.viterbi && !getenv("MB_ONETAPE_PARTS"))) return 1;
+  if (k < 2 || (k == 2 && P.viterbi && !P.retGv && !getenv("MB_ONETAPE_PARTS"))) return 1;
   return (int)k;
 }
 
 static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
-  int lanes = env_int_w("MB_ONETAPE_PART_LANES", k <= 2 ? 1024 : 512);
+  // lanes per part: about 0.4 per state (5 063 states: 2 parts x 1 024, 4 x 512; 21 761 states: 4 x 1 024, 8 and 16 x 512)
+  int lanes = env_int_w("MB_ONETAPE_PART_LANES", m->S / k >= 2500 ? 1024 : 512);
   if (lanes < 64 || lanes > 1024 || lanes % 64) lanes = 512;
   for (WidePartSet &ps : P.partSets) if (ps.kWanted == k && ps.W == lanes) return ps.ok ? &ps : nullptr;
   P.partSets.emplace_back();

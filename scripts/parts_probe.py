@@ -14,7 +14,7 @@ nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 outlen = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 modes = sys.argv[4] if len(sys.argv) > 4 else "rvp"
-variants = [tuple(int(x) for x in a.split(",")) for a in sys.argv[5:]] or [(0, 256)]
+variants = [tuple(int(x) for x in a.split(",")) for a in sys.argv[5:]] or [(0, 0)]      # 0: the library's own choice
 P = lambda n: Machine.fromFile("tests/golden/preset/%s.json" % n)
 h = HmmerModel.fromFile("tests/golden/hmmer/fn3.hmm").truncated(nodes)
 m = A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])
@@ -42,7 +42,8 @@ for mode in modes:
 for k, lanes in variants:
     if k: os.environ["MB_ONETAPE_PARTS"] = str(k)
     else: os.environ.pop("MB_ONETAPE_PARTS", None)
-    os.environ["MB_ONETAPE_PART_LANES"] = str(lanes)
+    if lanes: os.environ["MB_ONETAPE_PART_LANES"] = str(lanes)
+    else: os.environ.pop("MB_ONETAPE_PART_LANES", None)
     for mode in modes:
         r, dt, kn = timed(mode)
         ref = base[mode]

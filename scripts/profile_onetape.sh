@@ -42,12 +42,13 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recurs
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "k_wide_retimed" not in n: continue
-        key = "viterbi_fill" if "<1" in n.replace("(mb::", "<") or "1, " in n[:60] and "k_wide_retimed<1" in n else None
-        key = "viterbi_fill" if "k_wide_retimed<1" in n else "forward_cut_in_two"
+        key = "viterbi_fill" if ("k_wide_retimed<1" in n or "k_wide_retimed_parts<1" in n) else "forward_cut_in_two"
         d = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
         dur[key] = max(dur.get(key, 0.0), d)
 sweeps = {}
-for mode, key, cus in (("v", "viterbi_fill", 64), ("r", "forward_cut_in_two", 128)):
+# (round 5: k workgroups per sequence -- 64 sequences x 4 parts, or 2 halves x 2 parts: every CU holds one workgroup; MB_ONETAPE_PARTS=1: 64 / 128)
+one_wg = os.environ.get("MB_ONETAPE_PARTS") == "1"
+for mode, key, cus in (("v", "viterbi_fill", 64 if one_wg else 256), ("r", "forward_cut_in_two", 128 if one_wg else 256)):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for sub in ("pmc_", "pmc2_"):
         for f in glob.glob(os.path.join(out, sub + mode, "**", "*counter_collection.csv"), recursive=True):
