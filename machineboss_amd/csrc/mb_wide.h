@@ -141,6 +141,7 @@ struct WidePartArgs {
   const long long *xOff;       // first exchange row of every sequence
   unsigned *err;               // raised by a lane whose wait ran out
   long long timeoutTicks;      // of wall_clock64() (100 MHz)
+  int dropExports;             // test hook (MB_ONETAPE_PART_TEST_DROP_EXPORTS=1): nothing is exported, every consumer's wait runs out, the call fails
 };
 struct WidePartSet {
   bool ok = false;

@@ -585,7 +585,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
             if constexpr (PART) {
-              if (x - (unsigned)pExpBase < (unsigned)pExp) {      // an export (relay entries follow them): one 8-byte store that the consumers' lanes wait for (a NaN would read as "not yet": none is stored as all-ones)
+              if (x - (unsigned)pExpBase < (unsigned)pExp && !A.dropExports) {      // an export (relay entries follow them): one 8-byte store that the consumers' lanes wait for (a NaN would read as "not yet": none is stored as all-ones)
                 const unsigned long long bits = res == res ? (unsigned long long)__double_as_longlong(res) : 0x7ff8000000000000ull;
                 __hip_atomic_store(xRow + (size_t)c * xStride + (size_t)(pExpIdx0 + (int)(x - (unsigned)pExpBase)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
@@ -1946,6 +1946,7 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   WidePartArgs A{};
   A.parts = ps.d_parts; A.nSeq = (int)nPairs; A.nExpTot = ps.nExpTot; A.X = (double *)(buf + headBytes); A.xOff = (const long long *)buf;
   A.err = g_part_err; A.timeoutTicks = (long long)std::max(1, env_int_w("MB_ONETAPE_PART_TIMEOUT_S", 20)) * 100000000ll;
+  A.dropExports = env_int_w("MB_ONETAPE_PART_TEST_DROP_EXPORTS", 0) ? 1 : 0;      // (fails the call loudly, never a wrong result: tests/test_gpu_parity.py)
   WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0; dev.W = ps.W;
   // one workgroup per CU: a part's LDS is padded beyond half a CU's (the parts of a sequence are meant to run side by side on CUs of their own)
   size_t lds = ps.ldsBytes;

@@ -7,6 +7,7 @@ posterior counts agree to COUNT_TOL (summation order differs: fp64 atomics).
 """
 import json
 import math
+import time
 import os
 
 import numpy as np
@@ -1575,6 +1576,30 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     dmk.set_weights(lw); om.set_weights(lw)
     assert np.array_equal(dmk.fill(capi.MB_VITERBI, x, y), om.viterbi(x, y)) and " parts" in capi.last_kernel_name()
     dm1.close(); dmk.close()
+
+
+def test_one_tape_parts_fail_the_call_when_a_value_never_arrives(capi, monkeypatch):
+    """The exchange between the parts of a sequence has no way to hang: a lane waits a bounded time for another part's value, then raises
+    the launch's status word, every other waiter stops, the kernel drains and the host FAILS the call.  Provoked with the test hook that
+    makes every part keep its exports to itself; the next call (hook off) works again."""
+    m, em = _profile_machine(3)
+    x = np.zeros(0, np.int32)
+    ys = [np.random.RandomState(3 + n).randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (80, 120)]
+    dm = capi.DeviceMachine(em)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    good = b.viterbi(paths=False)[0]
+    assert " parts" in capi.last_kernel_name()
+    monkeypatch.setenv("MB_ONETAPE_PART_TEST_DROP_EXPORTS", "1")
+    monkeypatch.setenv("MB_ONETAPE_PART_TIMEOUT_S", "1")
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="waited longer"):
+        b.viterbi(paths=False)
+    assert time.perf_counter() - t0 < 30
+    with pytest.raises(RuntimeError, match="waited longer"):
+        b.forward(capi.MB_ROLLING)
+    monkeypatch.delenv("MB_ONETAPE_PART_TEST_DROP_EXPORTS")
+    assert np.array_equal(b.viterbi(paths=False)[0], good)
+    dm.close()
 
 
 @pytest.mark.parametrize("nodes,nSeq,L", [(20, 64, 2000), (86, 8, 300)])

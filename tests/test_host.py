@@ -216,9 +216,16 @@ def test_count_programs_of_the_tiled_family_generate(tmp_path, monkeypatch):
     flat = str(tmp_path / "flat.hip")
     capi.debug_jit_source(em, flat, mode=3 + 16, closure=2, G=2)
     src = open(flat).read()
-    assert "#define JFLAT 1" in src and "usage pass: 10 slot(s)" in src and "sB_" not in src
-    body = src[src.index("usage pass: 10 slot(s)"):]
-    assert body.count("ex2(x") == 10                                   # one exponential per usage slot, none in the fill rounds' count path
+    # round 5: the emitting transitions' usage is FUSED into the fill's emit rounds (same candidates, already in registers); the pass
+    # that follows the fill keeps the silent transitions' 5 slots
+    assert "#define JFLAT 1" in src and "usage pass: 5 slot(s)" in src and "sB_" not in src
+    body = src[src.index("usage pass: 5 slot(s)"):]
+    assert body.count("ex2(x") == 5                                    # one exponential per usage slot
+    monkeypatch.setenv("MB_MEDIUM_COUNT_FUSE", "0")                    # round 4's form: every transition in the usage pass (2 + 3 + 5 slots)
+    capi.debug_jit_source(em, flat, mode=3 + 16, closure=2, G=2)
+    src = open(flat).read()
+    assert "usage pass: 10 slot(s)" in src and src[src.index("usage pass: 10 slot(s)"):].count("ex2(x") == 10
+    monkeypatch.delenv("MB_MEDIUM_COUNT_FUSE")
     monkeypatch.setenv("MB_MEDIUM_COUNT_FLAT", "0")
     lev = str(tmp_path / "lev.hip")
     capi.debug_jit_source(em, lev, mode=3 + 16, closure=2, G=2)
@@ -238,6 +245,7 @@ def test_flat_usage_pass_goes_in_batches(tmp_path, monkeypatch):
     from machineboss_amd import capi
     em = random_machine(100, 1, 2, 46019, density=2.5, silent_density=1.5)
     monkeypatch.setenv("MB_JIT_REGBUDGET", "0")
+    monkeypatch.setenv("MB_MEDIUM_COUNT_FUSE", "0")      # every transition in the usage pass (round 4's form: the longest pass; round 5 fuses the emitting ones into the fill)
     one = str(tmp_path / "batched.hip")
     capi.debug_jit_source(em, one, mode=3, closure=8, G=16)
     src = open(one).read()
