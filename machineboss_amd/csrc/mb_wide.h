@@ -31,6 +31,7 @@ struct WideRound {
 // the lanes); in the last slot of a round, per lane: bit 29 = destination is an extra entry, bits 28..26 = log2 of the
 // lane-group size, bits 25..0 = destination index (all ones: this lane stores nothing).
 constexpr int WIDE_RING = 8;
+constexpr int WIDE_PART_RING = 8;      // ... of the parts of a machine cut for k workgroups per sequence (4 -- a period of 9 one-slot rounds padded to 12 slots instead of 16 -- was measured: Viterbi 40.8 -> 42.8 ms, the others within 3 % either way)
 struct WideDev {
   const WideRec *segA, *segB;
   long long strideA;   // records per token table of segment A (= nA * W)
@@ -103,7 +104,7 @@ constexpr int WIDE_RET_TOKWIN = 64;
 constexpr uint32_t WIDE_RET_NO_DST = 0x3ffffu;
 struct WideRetDev {
   const WideRec *rec;          // [nSlots + WIDE_RING][W]: the rounds of one period, then its first WIDE_RING slots again
-  int nSlots;                  // multiple of WIDE_RING
+  int nSlots;                  // multiple of WIDE_RING (WIDE_PART_RING for a part)
   int NB, NVs;                 // ring depth, doubles per ring vector (S + 2 + relays)
   int kMax;                    // largest ktau: a sequence of L columns takes L + 1 + kMax periods
   int rowLen, nPen;            // penalty table: rowLen = tokens + 2 entries (silent, each token, seed) per ktau, nPen entries in all

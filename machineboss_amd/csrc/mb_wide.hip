@@ -438,7 +438,7 @@ __device__ __forceinline__ double wide_x_wait(const unsigned long long *p, unsig
   }
 }
 
-template <int MODE, bool GV, bool TB, bool ACC, bool PART>
+template <int MODE, bool GV, bool TB, bool ACC, bool PART, int RING>
 __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRetDev &Q, const PairDesc pd, const unsigned bid, const int *__restrict__ outTok,
                                                   double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch,
                                                   const WidePartDev &part, const WidePartArgs &A) {
@@ -505,9 +505,9 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
     WideRec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.src = r.z; o.pad = r.w;
     return o;
   };
-  WideRec q[WIDE_RING];
+  WideRec q[RING];
 #pragma unroll
-  for (int k = 0; k < WIDE_RING; ++k) { q[k] = ldrec(k * slotBytes); __builtin_amdgcn_sched_barrier(0); }      // (in this order: the waits inside the loop count the loads behind a record)
+  for (int k = 0; k < RING; ++k) { q[k] = ldrec(k * slotBytes); __builtin_amdgcn_sched_barrier(0); }      // (in this order: the waits inside the loop count the loads behind a record)
   const int nPer = L + 1 + Q.kMax;
   unsigned penCur = GV ? 0u : (unsigned)nVec * 8u, penNxt = penCur + (unsigned)nPenAll * 8u;
   double m = (MODE == MB_VITERBI) ? -INFINITY : W_NEG_BIG;
@@ -539,14 +539,14 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
     (void)codeRow;
     slotInRound = 0;      // (the padding slots behind the period's last round -- all -inf -- have been counted)
     const int streamBase = cm * perStreamBytes;
-    for (int j0 = 0; j0 < Q.nSlots; j0 += WIDE_RING) {
+    for (int j0 = 0; j0 < Q.nSlots; j0 += RING) {
       // (the slot after this period's last one belongs to the next period: its penalties are the other table's)
-      const unsigned penHere = penCur, penLast = j0 + WIDE_RING == Q.nSlots ? penNxt : penCur;
+      const unsigned penHere = penCur, penLast = j0 + RING == Q.nSlots ? penNxt : penCur;
 #pragma unroll
-      for (int k = 0; k < WIDE_RING; ++k) {
+      for (int k = 0; k < RING; ++k) {
         const WideRec rc = q[k];
-        const WideRec &nx = q[(k + 1) % WIDE_RING];          // the next slot's record (k = 7: the one requested at the end of this group's first slot)
-        const unsigned penN = k + 1 == WIDE_RING ? penLast : penHere;
+        const WideRec &nx = q[(k + 1) % RING];          // the next slot's record (k = 7: the one requested at the end of this group's first slot)
+        const unsigned penN = k + 1 == RING ? penLast : penHere;
         const double vNow = vAhead, pNow = pAhead;
         vAhead = ring(nx.src);
         pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
@@ -603,7 +603,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
             __syncthreads();
             // both look-ups of the next slot again: its ring value may be stale, and so may its penalty -- the next period's table is
             // written at the top of THIS period, and when this barrier is the period's only one and sits in its last slot (a plain
-            // HMM: period 1, slot count a multiple of WIDE_RING) nothing but timing ordered those writes before the read above
+            // HMM: period 1, slot count a multiple of RING) nothing but timing ordered those writes before the read above
             vAhead = ring(nx.src);
             pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
           }
@@ -612,7 +612,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
         // record occupied (requested at the top of the slot it needs registers of its own, and the copies at the loop's back edge made
         // the compiler wait for ALL eight loads in flight there -- the prefetch ring was drained every eight slots)
         __builtin_amdgcn_sched_barrier(0);
-        q[k] = ldrec(streamBase + (j0 + WIDE_RING + k) * slotBytes);
+        q[k] = ldrec(streamBase + (j0 + RING + k) * slotBytes);
       }
     }
     cm = cm + 1 == NB ? 0 : cm + 1;
@@ -625,7 +625,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
 template <int MODE, bool GV, bool TB = false, bool ACC = false>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
-  wide_retimed_body<MODE, GV, TB, ACC, false>(P, Q, pairs[blockIdx.x], blockIdx.x, outTok, pool, loglike, scratch, WidePartDev{}, WidePartArgs{});
+  wide_retimed_body<MODE, GV, TB, ACC, false, WIDE_RING>(P, Q, pairs[blockIdx.x], blockIdx.x, outTok, pool, loglike, scratch, WidePartDev{}, WidePartArgs{});
 }
 
 // first exchange row of every sequence (a handful of sequences: one lane)
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(1024) void k_wide_retimed_parts(WideDev P, WidePart
   pd.ret.rowLen = uni(g.ret.rowLen); pd.ret.nPen = uni(g.ret.nPen);
   pd.gmap = (const uint32_t *)uniPtr(g.gmap); pd.impIdx = (const uint32_t *)uniPtr(g.impIdx);
   pd.Sloc = uni(g.Sloc); pd.nImp = uni(g.nImp); pd.expBase = uni(g.expBase); pd.expIdx0 = uni(g.expIdx0); pd.nExp = uni(g.nExp); pd.resultEntry = uni(g.resultEntry);
-  wide_retimed_body<MODE, false, TB, ACC, true>(P, pd.ret, pairs[seq], seq, outTok, pool, loglike, nullptr, pd, A);
+  wide_retimed_body<MODE, false, TB, ACC, true, WIDE_PART_RING>(P, pd.ret, pairs[seq], seq, outTok, pool, loglike, nullptr, pd, A);
 }
 
 // ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
@@ -1440,7 +1440,9 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   if (T.rounds.empty()) return true;
   int nSlots = 0;
   for (const WideRound &R : T.rounds) nSlots += R.depth;
-  const int padded = (nSlots + WIDE_RING - 1) / WIDE_RING * WIDE_RING;
+  // (the kernel keeps `ring` records in flight and takes its slots in groups of that many)
+  const int ring = part ? WIDE_PART_RING : WIDE_RING;
+  const int padded = (nSlots + ring - 1) / ring * ring;
   if ((size_t)(best.NB * padded + WIDE_RING) * W * sizeof(WideRec) >= ((size_t)1 << 31)) return true;      // (the kernel's buffer loads carry 32-bit offsets)
   // one stream per rotation cm of the ring (newest column in vector cm): a record names its source by LDS byte address
   //   src = byte address << 14 | penalty entry;   pad (last slot) = flags | kq << 20 | vector << 18 | ring entry (see WideRetDev)
