@@ -223,8 +223,10 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
 /* The same program cut for k WORKGROUPS PER SEQUENCE (batches of fewer sequences than the device has CUs): int32
  * magic 0x52455432, parts, exchange columns, states; then per part 16 int32 (lanes, slots per period, NB, doubles per ring vector,
  * largest lag, penalty row length, penalty entries, period, own states, imports, first export entry, first exchange column,
- * exports, result entry or -1, table words, 0), the table (machine state of every own state, then the exchange column of every
- * import) and (NB * slots + 8) * lanes records.  Fails when the machine's transition graph has no cut. */
+ * exports, result entry or -1, table words, byte offset of the second weights or 0), the table (machine state of every own state,
+ * then the exchange column of every import), (NB * slots + 8) * lanes records and -- parts with two-transition candidates (DESIGN
+ * 4.2d) -- as many doubles, the candidates' second weights.  lanes = 0: the library's own choice.  Fails when the machine's
+ * transition graph has no cut. */
 int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                         const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
                         int mode, int backward, int k, int lanes, const char *path);

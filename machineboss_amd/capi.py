@@ -293,7 +293,8 @@ def debug_wide_retimed(em, path: str, mode: int = MB_VITERBI, backward: bool = F
 
 def debug_wide_parts(em, path: str, k: int, lanes: int = 256, mode: int = MB_VITERBI, backward: bool = False, tb_codes: bool = False) -> dict:
     """The k-part form of the retimed program (k workgroups per sequence; host only): {"nExp": exchange columns, "S": states,
-    "parts": [per part the fields of debug_wide_retimed + Sloc, nImp, expBase, expIdx0, nExp, resultEntry, gmap, impIdx]}."""
+    "parts": [per part the fields of debug_wide_retimed + Sloc, nImp, expBase, expIdx0, nExp, resultEntry, gmap, impIdx]}; tb_codes:
+    + the decode tables of the parts' candidate lists, joined over the machine's states (tbOff, tbEntry, inEid)."""
     a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
          np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
          np.ascontiguousarray(em.logWeight, np.float64)]
@@ -304,7 +305,7 @@ def debug_wide_parts(em, path: str, k: int, lanes: int = 256, mode: int = MB_VIT
     assert head[0] == 0x52455432
     out = {"nExp": int(head[2]), "S": int(head[3]), "parts": []}
     pos = 16
-    keys = ("lanes", "slots", "NB", "NVs", "kMax", "rowLen", "nPen", "period", "Sloc", "nImp", "expBase", "expIdx0", "nExp", "resultEntry", "nTab")
+    keys = ("lanes", "slots", "NB", "NVs", "kMax", "rowLen", "nPen", "period", "Sloc", "nImp", "expBase", "expIdx0", "nExp", "resultEntry", "nTab", "w2Offset")
     for _ in range(int(head[1])):
         ph = np.fromfile(path, np.int32, 16, offset=pos); pos += 64
         part = {k_: int(v) for k_, v in zip(keys, ph)}
@@ -312,10 +313,21 @@ def debug_wide_parts(em, path: str, k: int, lanes: int = 256, mode: int = MB_VIT
         part["gmap"], part["impIdx"] = tab[:part["Sloc"]].astype(np.int64), tab[part["Sloc"]:].astype(np.int64)
         assert part["impIdx"].size == part["nImp"]
         nrec = (part["NB"] * part["slots"] + 8) * part["lanes"]
-        rec = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), count=nrec, offset=pos); pos += 16 * nrec
+        rec16 = np.fromfile(path, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4")]), count=nrec, offset=pos); pos += 16 * nrec
+        rec = np.zeros(nrec, np.dtype([("w", "<f8"), ("src", "<u4"), ("pad", "<u4"), ("w2", "<f8")]))
+        for f in ("w", "src", "pad"): rec[f] = rec16[f]
+        if part["w2Offset"]:      # two-transition candidates: the second weights, one per record, behind the records
+            assert part["w2Offset"] == 16 * nrec
+            rec["w2"] = np.fromfile(path, "<f8", count=nrec, offset=pos); pos += 8 * nrec
         part["records"] = rec[:part["NB"] * part["slots"] * part["lanes"]].reshape(part["NB"], part["slots"], part["lanes"])
         part["inL2"] = 0
         out["parts"].append(part)
+    if tb_codes:
+        rest = np.fromfile(path, np.uint32, offset=pos); q = 0
+        for k_ in ("tbOff", "tbEntry", "inEid"):
+            n = int(rest[q]); out[k_] = rest[q + 1:q + 1 + n].copy(); q += 1 + n
+        assert q == rest.size and out["tbOff"].size == em.nStates + 1 and out["inEid"].size == em.nTransitions
+        pos += 4 * rest.size
     assert os.path.getsize(path) == pos
     return out
 

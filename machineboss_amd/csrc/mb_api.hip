@@ -1707,8 +1707,9 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
 
 // the k-part form of the retimed program (k workgroups per sequence, WidePartDev), planned on the host only: int32 magic 0x52455432,
 // parts, exchange columns, states; then per part 16 int32 (lanes, slots, NB, NVs, kMax, rowLen, nPen, period, own states, imports,
-// first export entry, first exchange column, exports, result entry, table words, 0), the table (machine state of every own state, then the
-// exchange column of every import) and the record streams as in mb_debug_wide_retimed
+// first export entry, first exchange column, exports, result entry, table words, byte offset of the second weights or 0), the table (machine
+// state of every own state, then the exchange column of every import), the record streams as in mb_debug_wide_retimed and -- parts with
+// two-transition candidates -- one double per record: the candidate's second weight
 int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
                         const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int k, int lanes, const char *path) {
   ApiLock lock;
@@ -1724,16 +1725,26 @@ int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   mode &= 15;
   std::vector<WidePartHost> parts;
   int nExpTot = 0;
-  if (!wide_parts_host(&m, backward != 0, mode == MB_VITERBI, tbCodes, k, lanes, parts, nExpTot)) { set_error("machine has no k-part retimed program"); return 1; }
+  std::vector<int> tbOff; std::vector<uint32_t> tbEntry;
+  if (tbCodes && (mode != MB_VITERBI || backward)) { set_error("mb_debug_wide_parts: traceback codes belong to the forward max program"); return 1; }
+  int lanesChosen = lanes, ringChosen = 8;
+  if (!wide_parts_host(&m, backward != 0, mode == MB_VITERBI, tbCodes, k, lanes, parts, nExpTot, &tbOff, &tbEntry, nullptr, &lanesChosen, &ringChosen)) { set_error("machine has no k-part retimed program"); return 1; }
+  lanes = lanesChosen;
   FILE *f = fopen(path, "wb");
   if (!f) { set_error("mb_debug_wide_parts: cannot open output file"); return 1; }
   const int32_t head[4] = {0x52455432, (int32_t)parts.size(), nExpTot, nStates};
   bool ok = fwrite(head, sizeof(head), 1, f) == 1;
   for (const WidePartHost &H : parts) {
     const int32_t ph[16] = {lanes, H.h.ret.nSlots, H.h.ret.NB, H.h.ret.NVs, H.h.ret.kMax, H.h.ret.rowLen, H.h.ret.nPen, H.period, H.h.Sloc, H.h.nImp,
-                            H.h.expBase, H.h.expIdx0, H.h.nExp, H.h.resultEntry, (int32_t)H.tab.size(), 0};
+                            H.h.expBase, H.h.expIdx0, H.h.nExp, H.h.resultEntry, (int32_t)H.tab.size(), H.h.w2Offset};
     ok = ok && fwrite(ph, sizeof(ph), 1, f) == 1 && fwrite(H.tab.data(), 4, H.tab.size(), f) == H.tab.size() &&
          fwrite(H.stream.data(), sizeof(WideRec), H.stream.size(), f) == H.stream.size();
+  }
+  if (ok && tbCodes) {      // the joined decode tables of the parts' candidate lists, and the incoming view's edge ids
+    const int32_t n0 = (int32_t)tbOff.size(), n1 = (int32_t)tbEntry.size(), n2 = (int32_t)m.inPerm.size();
+    ok = fwrite(&n0, 4, 1, f) == 1 && fwrite(tbOff.data(), 4, (size_t)n0, f) == (size_t)n0 &&
+         fwrite(&n1, 4, 1, f) == 1 && fwrite(tbEntry.data(), 4, (size_t)n1, f) == (size_t)n1 &&
+         fwrite(&n2, 4, 1, f) == 1 && fwrite(m.inPerm.data(), 4, (size_t)n2, f) == (size_t)n2;
   }
   fclose(f);
   if (!ok) { set_error("mb_debug_wide_parts: short write"); return 1; }

@@ -31,7 +31,6 @@ struct WideRound {
 // the lanes); in the last slot of a round, per lane: bit 29 = destination is an extra entry, bits 28..26 = log2 of the
 // lane-group size, bits 25..0 = destination index (all ones: this lane stores nothing).
 constexpr int WIDE_RING = 8;
-constexpr int WIDE_PART_RING = 8;      // ... of the parts of a machine cut for k workgroups per sequence (4 -- a period of 9 one-slot rounds padded to 12 slots instead of 16 -- was measured: Viterbi 40.8 -> 42.8 ms, the others within 3 % either way)
 struct WideDev {
   const WideRec *segA, *segB;
   long long strideA;   // records per token table of segment A (= nA * W)
@@ -104,7 +103,7 @@ constexpr int WIDE_RET_TOKWIN = 64;
 constexpr uint32_t WIDE_RET_NO_DST = 0x3ffffu;
 struct WideRetDev {
   const WideRec *rec;          // [nSlots + WIDE_RING][W]: the rounds of one period, then its first WIDE_RING slots again
-  int nSlots;                  // multiple of WIDE_RING (WIDE_PART_RING for a part)
+  int nSlots;                  // multiple of WIDE_RING (of a part's own ring depth, 4 or 8)
   int NB, NVs;                 // ring depth, doubles per ring vector (S + 2 + relays)
   int kMax;                    // largest ktau: a sequence of L columns takes L + 1 + kMax periods
   int rowLen, nPen;            // penalty table: rowLen = tokens + 2 entries (silent, each token, seed) per ktau, nPen entries in all
@@ -127,13 +126,17 @@ struct WideRetDev {
 // and every wait is bounded (WidePartArgs::timeoutTicks: the kernel raises *err, stops waiting and the host fails the call).
 // Cells, traceback codes and log-likelihoods are those of the one-workgroup program, bit for bit in the max semiring (same candidates in
 // the same order; the two copies add 0.0).
+// A part WITH TWO-TRANSITION CANDIDATES (ret_merge in mb_wide.hip: silent transitions merged into their successors' candidate lists
+// halve the stages of a period) has a second stream behind its records, w2Offset bytes into `ret.rec`: one double per lane and slot, the
+// SECOND weight of the candidate (0.0 for a one-transition candidate) -- `(V(u) + (w + penalty)) + w2`.
 struct WidePartDev {
-  WideRetDev ret;              // nPen: the (ktau, token) entries only; the imports' entries follow them
+  WideRetDev ret;              // nPen: the (ktau, token) entries only; the imports' entries follow them; rec: [slot][lane] of 32 bytes
   const uint32_t *gmap;        // [Sloc]: machine state of local state x (column of its matrix cell / traceback code)
   const uint32_t *impIdx;      // [nImp]: exchange column of import i
   int Sloc, nImp;              // own states (ring entries 0 .. Sloc - 1; Sloc, Sloc + 1: -inf and 0.0); imports
   int expBase, expIdx0, nExp;  // ring entries >= expBase are exports: entry expBase + j is exchange column expIdx0 + j
   int resultEntry;             // ring entry of the state whose last-column value is the log-likelihood, -1: another part has it
+  int w2Offset;                // byte offset of the second weights' stream (parts with two-transition candidates)
 };
 struct WidePartArgs {
   const WidePartDev *parts;
@@ -144,15 +147,22 @@ struct WidePartArgs {
   long long timeoutTicks;      // of wall_clock64() (100 MHz)
   int dropExports;             // test hook (MB_ONETAPE_PART_TEST_DROP_EXPORTS=1): nothing is exported, every consumer's wait runs out, the call fails
 };
+// what a build of a cut chose -- lanes, ring depth, the two-transition candidates of every part (indices into the part's edge list, with its
+// length as a check) -- kept by the program across weight updates: the choice depends on the machine's graph, not on its weights
+struct WidePartHint { bool valid = false, merge = true; int kWanted = 0, lanesAsked = 0, ringAsked = 0, W = 0, ring = 8; std::vector<std::vector<int>> merged; std::vector<size_t> nEdges; };
 struct WidePartSet {
   bool ok = false;
-  int kWanted = 0, k = 0, W = 0, nExpTot = 0;
+  int kWanted = 0, lanesAsked = 0, ringAsked = 0;      // what was asked for (0: the builder's choice)
+  int k = 0, W = 0, nExpTot = 0, ring = WIDE_RING;
+  bool merge = false;                        // the parts carry two-transition candidates (kernel variant with the second weights' stream)
   size_t ldsBytes = 0;                       // largest part (with the fp64 correction term's table)
   std::vector<WideRec *> d_rec;
   std::vector<uint32_t *> d_tab;             // gmap + impIdx of every part, one allocation each
   WidePartDev *d_parts = nullptr;
   std::vector<WidePartDev> h_parts;          // (device pointers inside)
   std::vector<int> period, slots, nSync;     // per part, for the log
+  // traceback-code programs: the decode tables of the parts' own candidate lists (two-transition candidates change the places), joined
+  int *d_tbOff = nullptr; uint32_t *d_tbEntry = nullptr; long long tbEntries = 0;
 };
 
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
@@ -168,6 +178,8 @@ struct WideProgram {
   int nSync = 0;
   std::vector<WideRound> rounds;     // planning tables (host only)
   std::vector<WideRec> recs;
+  std::vector<double> recs2;         // wantW2 (the parts of a machine): second weight of every record (0.0: a one-transition candidate)
+  bool wantW2 = false;
   std::vector<uint32_t> dsts;
   std::vector<WideRec> segA, segB;   // linearised streams
   int NV = 0, NX = 0;
@@ -189,6 +201,7 @@ struct WideProgram {
   WideRec *d_ret = nullptr;
   WideRetDev ret{};
   size_t retLdsBytes = 0;
+  long long retW2Offset = 0;         // a part with two-transition candidates: byte offset of the second weights behind the records
   int retPeriod = 0, retTauMax = 0, retPeriodMin = 0;
   // Viterbi with ONE TRACEBACK CODE per cell instead of the fp64 cell (round 4; requested with tbCodes before wide_build): the
   // retimed max sweep also keeps, per state, the PLACE of its first maximal candidate in the reference's enumeration order
@@ -198,8 +211,10 @@ struct WideProgram {
   int *d_tbOff = nullptr; uint32_t *d_tbEntry = nullptr;
   std::vector<int> h_tbOff; std::vector<uint32_t> h_tbEntry;      // host copies (the debug dump)
   long long tbEntries = 0;
+  int tbFromSet = -1;                // the last traceback-code fill ran through partSets[tbFromSet] (its codes decode with that set's tables)
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
   std::vector<WidePartSet> partSets; // k workgroups per sequence: one set per k that was asked for (built on first use)
+  std::vector<WidePartHint> partHints;
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }
   size_t vecBytes() const { return (size_t)(2 * NV + NX) * sizeof(double); }
 };
@@ -216,7 +231,9 @@ bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram
 // ... and its k-part form: the record stream, geometry and tables of every part (a part's `h` holds HOST pointers into tabs[part]:
 // gmap [Sloc], then impIdx [nImp]); false when the machine's graph has no cut
 struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0; size_t ldsBytes = 0; };
-bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot);
+// W = 0: the lanes per part (and the ring depth) are searched; hint: the choice of an earlier build of the same cut (in / out)
+bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot,
+                     std::vector<int> *tbOff = nullptr, std::vector<uint32_t> *tbEntry = nullptr, WidePartHint *hint = nullptr, int *Wout = nullptr, int *ringOut = nullptr);
 // sweep every pair of the chunk; pool != nullptr: materialise the matrix (reference layout); loglike != nullptr: gather
 // the log-likelihood of each pair.  d_desc/hp describe the same pairs (cellBase relative to pool).
 // h_desc (host copy of d_desc) + cus (CUs this launch may count on): with fewer sequences than CUs the sweep runs k workgroups per

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <numeric>
 #include <queue>
@@ -438,7 +439,7 @@ __device__ __forceinline__ double wide_x_wait(const unsigned long long *p, unsig
   }
 }
 
-template <int MODE, bool GV, bool TB, bool ACC, bool PART, int RING>
+template <int MODE, bool GV, bool TB, bool ACC, bool PART, int RING, bool W2>
 __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRetDev &Q, const PairDesc pd, const unsigned bid, const int *__restrict__ outTok,
                                                   double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch,
                                                   const WidePartDev &part, const WidePartArgs &A) {
@@ -499,13 +500,22 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
   // (buffer loads: slot base in an SGPR offset, lane offset in one VGPR -- no 64-bit address arithmetic per slot)
   typedef __attribute__((ext_vector_type(4))) unsigned int rec_u32x4;
   const __amdgpu_buffer_rsrc_t recRsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Q.rec, 0, 0x7fffffff, 0x00020000);
+  // (W2 -- a part with two-transition candidates: the second weights are a stream of their own behind the records, [slot][lane] doubles)
+  struct Rec2 { double w; uint32_t src, pad; double w2; };
+  typedef typename std::conditional<W2, Rec2, WideRec>::type RecT;
   const int laneOff = tid * (int)sizeof(WideRec), slotBytes = W * (int)sizeof(WideRec), perStreamBytes = Q.nSlots * slotBytes;
-  auto ldrec = [&](int soff) -> WideRec {
+  const int w2Base = W2 ? part.w2Offset + tid * 8 : 0;
+  auto ldrec = [&](int soff) -> RecT {
     const rec_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(recRsrc, laneOff, soff, 0);
-    WideRec o; o.w = __hiloint2double((int)r.y, (int)r.x); o.src = r.z; o.pad = r.w;
+    RecT o; o.w = __hiloint2double((int)r.y, (int)r.x); o.src = r.z; o.pad = r.w;
+    if constexpr (W2) {
+      typedef __attribute__((ext_vector_type(2))) unsigned int rec_u32x2;
+      const rec_u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(recRsrc, w2Base, soff >> 1, 0);      // (8 of the record's 16 bytes per lane and slot)
+      o.w2 = __hiloint2double((int)r2.y, (int)r2.x);
+    }
     return o;
   };
-  WideRec q[RING];
+  RecT q[RING];
 #pragma unroll
   for (int k = 0; k < RING; ++k) { q[k] = ldrec(k * slotBytes); __builtin_amdgcn_sched_barrier(0); }      // (in this order: the waits inside the loop count the loads behind a record)
   const int nPer = L + 1 + Q.kMax;
@@ -544,13 +554,14 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
       const unsigned penHere = penCur, penLast = j0 + RING == Q.nSlots ? penNxt : penCur;
 #pragma unroll
       for (int k = 0; k < RING; ++k) {
-        const WideRec rc = q[k];
-        const WideRec &nx = q[(k + 1) % RING];          // the next slot's record (k = 7: the one requested at the end of this group's first slot)
+        const RecT rc = q[k];
+        const RecT &nx = q[(k + 1) % RING];          // the next slot's record (k = 7: the one requested at the end of this group's first slot)
         const unsigned penN = k + 1 == RING ? penLast : penHere;
         const double vNow = vAhead, pNow = pAhead;
         vAhead = ring(nx.src);
         pAhead = wide_lds_read(((nx.src & 0x1fffu) << 3) + penN);
-        const double cand = vNow + (rc.w + pNow);              // w + 0.0 = w, w + -inf = -inf: the reference's one rounded add, or -inf
+        double cand = vNow + (rc.w + pNow);                    // w + 0.0 = w, w + -inf = -inf: the reference's one rounded add, or -inf
+        if constexpr (W2) cand = cand + rc.w2;                 // (a two-transition candidate: the second transition's rounded add; + 0.0 otherwise)
         if (TB) { bestSlot = cand > m ? (uint32_t)slotInRound : bestSlot; ++slotInRound; }      // strict >: the first maximum
         if (MODE == MB_VITERBI) m = wide_max_raw(m, cand);
         else if constexpr (ACC) wide_fold<MODE>(m, s, cand, 1.0, expTab);
@@ -625,7 +636,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
 template <int MODE, bool GV, bool TB = false, bool ACC = false>
 __global__ __launch_bounds__(1024) void k_wide_retimed(WideDev P, WideRetDev Q, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                        double *__restrict__ pool, double *__restrict__ loglike, double *__restrict__ scratch) {
-  wide_retimed_body<MODE, GV, TB, ACC, false, WIDE_RING>(P, Q, pairs[blockIdx.x], blockIdx.x, outTok, pool, loglike, scratch, WidePartDev{}, WidePartArgs{});
+  wide_retimed_body<MODE, GV, TB, ACC, false, WIDE_RING, false>(P, Q, pairs[blockIdx.x], blockIdx.x, outTok, pool, loglike, scratch, WidePartDev{}, WidePartArgs{});
 }
 
 // first exchange row of every sequence (a handful of sequences: one lane)
@@ -635,7 +646,7 @@ __global__ void k_wide_part_rows(const PairDesc *__restrict__ pairs, int nSeq, i
 }
 
 // k workgroups per sequence: workgroup = part * nSeq + sequence (a part waits for lower parts only, and those are dispatched first)
-template <int MODE, bool TB, bool ACC>
+template <int MODE, bool TB, bool ACC, bool W2>
 __global__ __launch_bounds__(1024) void k_wide_retimed_parts(WideDev P, WidePartArgs A, const PairDesc *__restrict__ pairs, const int *__restrict__ outTok,
                                                              double *__restrict__ pool, double *__restrict__ loglike) {
   const unsigned part = blockIdx.x / (unsigned)A.nSeq, seq = blockIdx.x - part * (unsigned)A.nSeq;
@@ -648,7 +659,8 @@ __global__ __launch_bounds__(1024) void k_wide_retimed_parts(WideDev P, WidePart
   pd.ret.rowLen = uni(g.ret.rowLen); pd.ret.nPen = uni(g.ret.nPen);
   pd.gmap = (const uint32_t *)uniPtr(g.gmap); pd.impIdx = (const uint32_t *)uniPtr(g.impIdx);
   pd.Sloc = uni(g.Sloc); pd.nImp = uni(g.nImp); pd.expBase = uni(g.expBase); pd.expIdx0 = uni(g.expIdx0); pd.nExp = uni(g.nExp); pd.resultEntry = uni(g.resultEntry);
-  wide_retimed_body<MODE, false, TB, ACC, true, WIDE_PART_RING>(P, pd.ret, pairs[seq], seq, outTok, pool, loglike, nullptr, pd, A);
+  pd.w2Offset = uni(g.w2Offset);
+  wide_retimed_body<MODE, false, TB, ACC, true, WIDE_RING, W2>(P, pd.ret, pairs[seq], seq, outTok, pool, loglike, nullptr, pd, A);
 }
 
 // ---- single precision relative to a per-column reference (log-sum-exp programs) ------------------------------------
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(1024) void k_wide_sum32(WideDev32 P1, const PairDes
 // host: program compiler
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-struct WCand { uint32_t src; double w; uint32_t ref = 0xFFFFFFFFu; };      // ref: position of the transition in the machine's incoming view (levelled nodes)
+struct WCand { uint32_t src; double w; uint32_t ref = 0xFFFFFFFFu; double w2 = 0.0; };      // ref: position of the transition in the machine's incoming view (levelled nodes); w2: second transition of a two-transition candidate (parts, see ret_merge)
 struct WNode { uint32_t dst; int stage; std::vector<std::vector<WCand>> t2; std::vector<WCand> t3; };
 inline uint32_t CUR(int i) { return (uint32_t)i; }
 inline uint32_t EXTRA(int i) { return (1u << 30) | (uint32_t)i; }
@@ -859,6 +871,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
     R.tokStride = t2 ? depth * W : 0;
     const WideRec padRec{-INFINITY, PREV(P->dev.S), 0};
     P->recs.resize(P->recs.size() + (size_t)nTab * depth * W, padRec);
+    if (P->wantW2) P->recs2.resize(P->recs.size(), 0.0);
     P->dsts.resize(P->dsts.size() + W, W_NO_DST);     // idle lanes: group of one, no destination
     int lane = 0;
     for (int q = pos; q < e; ++q) {
@@ -874,6 +887,7 @@ double plan_stage(const std::vector<const WNode *> &nodes, int nTokTables, int W
           const int j = k / g, sub = k % g;
           WideRec &rc = P->recs[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + lane + sub];
           rc.w = cd.w; rc.src = cd.src;
+          if (P->wantW2) P->recs2[(size_t)R.recBase + (size_t)t * R.tokStride + (size_t)j * W + lane + sub] = cd.w2;
           if (t == nTab - 1) P->candsPerColumn++;
         }
       }
@@ -910,6 +924,8 @@ void wide_free(WideProgram &P) {
     for (WideRec *r : ps.d_rec) if (r) (void)hipFree(r);
     for (uint32_t *t : ps.d_tab) if (t) (void)hipFree(t);
     if (ps.d_parts) (void)hipFree(ps.d_parts);
+    if (ps.d_tbOff) (void)hipFree(ps.d_tbOff);
+    if (ps.d_tbEntry) (void)hipFree(ps.d_tbEntry);
   }
   P = WideProgram();
 }
@@ -1274,8 +1290,19 @@ static bool up_w(T *&d, const std::vector<T> &h) {
 }
 
 // ---- the retimed program of a levelled one-tape machine (see WideRetDev) --------------------------------------------------------
+// One PART of a machine cut for k workgroups per sequence (see WidePartDev): the nodes handed to wide_ret_build are LOCAL -- vertices
+// 0 .. nOwn - 1 the part's own states, then nImp import vertices (no candidates of their own: their value comes through the penalty
+// table), then nExp export vertices (one silent candidate each: the exported state, weight 0.0); the seed's source is vertex count + 1
+struct RetPart {
+  int nOwn = 0, nImp = 0, nExp = 0, ring = WIDE_RING;
+  bool useMerge = true;       // two-transition candidates (off: the part's LDS is tight -- they lengthen the spans, the relays push the period up)
+  // the two-transition candidates of this part, chosen once (they depend on the graph, not on the lanes or the weights): indices into
+  // the part's edge list in construction order, and that list's length as a check
+  bool mergeKnown = false; std::vector<int> merged; size_t nEdges = 0;
+};
+
 namespace {
-struct RetEdge { int src, dst, em, tok; double w; uint32_t ref; int rank; };      // ref / rank: incoming-view position, place in the destination's candidate list (reference order)
+struct RetEdge { int src, dst, em, tok; double w; uint32_t ref; int rank; double w2 = 0.0; int orig = -1; };      // ref / rank: incoming-view position, place in the destination's candidate list (reference order); w2 / orig: see ret_merge
 
 // smallest tau >= 0 with tau(dst) >= tau(src) + 1 - em * period over all edges; false when some tau would exceed `bound` (the period
 // is shorter than a cycle of the machine needs, or the columns are deeper than the kernel's 6-bit lag)
@@ -1293,12 +1320,103 @@ bool ret_offsets(const std::vector<RetEdge> &edges, int nStates, int period, int
     if (work > 400000000ll) return false;
   }
 }
-}  // namespace
 
-// One PART of a machine cut for k workgroups per sequence (see WidePartDev): the nodes handed to wide_ret_build are LOCAL -- vertices
-// 0 .. nOwn - 1 the part's own states, then nImp import vertices (no candidates of their own: their value comes through the penalty
-// table), then nExp export vertices (one silent candidate each: the exported state, weight 0.0); the seed's source is vertex count + 1
-struct RetPart { int nOwn = 0, nImp = 0, nExp = 0; };
+// the relaxation of ret_offsets at a period the edges do not allow: the edges (indices) of a cycle that gains time, empty when the
+// offsets settle or only the depth bound was passed (predecessor pointers; their graph is checked for a cycle after every pass)
+std::vector<int> ret_cycle(const std::vector<RetEdge> &edges, int nStates, int period, int bound) {
+  std::vector<int> tau(nStates, 0), pred(nStates, -1), stamp(nStates, -1);
+  for (int pass = 0; pass < 4 * nStates + 8; ++pass) {
+    bool moved = false, over = false;
+    for (int k = 0; k < (int)edges.size(); ++k) {
+      const RetEdge &e = edges[k];
+      const int t = tau[e.src] + 1 - (e.em ? period : 0);
+      if (t > tau[e.dst]) { tau[e.dst] = t; pred[e.dst] = k; moved = true; over = over || t > bound; }
+    }
+    if (!moved) return {};
+    for (int v0 = 0; v0 < nStates; ++v0) {
+      if (stamp[v0] >= 0 || pred[v0] < 0) continue;
+      int v = v0;
+      while (v >= 0 && pred[v] >= 0 && stamp[v] < 0) { stamp[v] = v0; v = edges[pred[v]].src; }
+      if (v >= 0 && pred[v] >= 0 && stamp[v] == v0) {      // walked into its own trail: a cycle through v
+        std::vector<int> cyc;
+        int u = v;
+        do { cyc.push_back(pred[u]); u = edges[pred[u]].src; } while (u != v);
+        std::reverse(cyc.begin(), cyc.end());
+        return cyc;
+      }
+    }
+    std::fill(stamp.begin(), stamp.end(), -1);
+    if (over) return {};
+  }
+  return {};
+}
+
+// TWO-TRANSITION CANDIDATES (the parts of a machine cut for k workgroups per sequence).  A part's period is a chain of
+// stages, one per transition of the machine's tightest cycle per emitted symbol (9 for the config-5 composite), and a stage costs the
+// same whatever its width.  A silent transition v -> x is MERGED: x takes, instead of the candidate V(v) + w2, one candidate
+// (V(u) + w1) + w2 per candidate u of v -- max over them = (max_u (V(u) + w1)) + w2 = V(v) + w2 bit for bit (rounding is monotone), a
+// sum the same sum in another order -- so x no longer waits for v and the cycle is one stage shorter.  v keeps its own node (its cell
+// is part of the matrix), a traceback code of x that falls into the merged block decodes to the transition v -> x, and the walker
+// finds v's own code where it always was.  Merged: silent transitions only (an emitting second transition would need the source two
+// columns back), never into a state that is itself read through a merge nor out of one (no three-transition candidates), not out
+// of the seed's state, fan-ins bounded.  Chosen greedily along the cycles that forbid the next shorter period, until `target`.
+void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState, int target, int bound, bool backward, bool verbose, RetPart *cache) {
+  std::vector<RetEdge> orig = edges;
+  for (size_t i = 0; i < orig.size(); ++i) orig[i].orig = (int)i;
+  edges = orig;
+  std::vector<char> merged(orig.size(), 0), isSrc(nStates, 0), isTgt(nStates, 0);
+  std::vector<std::vector<int>> inOf(nStates);
+  std::vector<int> fanIn(nStates, 0);
+  for (size_t i = 0; i < orig.size(); ++i) { inOf[orig[i].dst].push_back((int)i); fanIn[orig[i].dst]++; }
+  for (auto &l : inOf) std::stable_sort(l.begin(), l.end(), [&](int a, int b) { return orig[a].rank < orig[b].rank; });
+  auto order = [&](std::vector<RetEdge> &ev) {
+    std::stable_sort(ev.begin(), ev.end(), [&](const RetEdge &a, const RetEdge &b) { if (a.em != b.em) return a.em < b.em; return backward ? a.dst > b.dst : a.dst < b.dst; });
+  };
+  auto rebuild = [&]() {
+    edges.clear();
+    for (size_t i = 0; i < orig.size(); ++i) {
+      if (!merged[i]) { edges.push_back(orig[i]); continue; }
+      for (int f : inOf[orig[i].src]) edges.push_back(RetEdge{orig[f].src, orig[i].dst, orig[f].em, orig[f].tok, orig[f].w, orig[i].ref, orig[i].rank, orig[i].w, -1});
+    }
+    order(edges);
+  };
+  std::vector<int> tau;
+  auto pMinOf = [&]() {
+    int lo = 1, hi = 64;
+    if (!ret_offsets(edges, nStates, hi, bound + 64, tau)) return 65;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (ret_offsets(edges, nStates, mid, 62 * mid + mid - 1, tau)) hi = mid; else lo = mid + 1; }
+    return lo;
+  };
+  int nMerged = 0, p0 = -1, p = -1;
+  if (cache && cache->mergeKnown && cache->nEdges == orig.size()) {      // chosen before (another lane count, a weight update): apply
+    for (int i : cache->merged) if (i >= 0 && i < (int)orig.size()) merged[i] = 1;
+    if (!cache->merged.empty()) rebuild();
+    return;
+  }
+  for (int iter = 0; iter < 4000; ++iter) {
+    p = pMinOf();
+    if (p0 < 0) p0 = p;
+    if (p <= target || p > 64) break;
+    const std::vector<int> cyc = ret_cycle(edges, nStates, p - 1, 62 * (p - 1) + p - 2);
+    if (verbose && getenv("MB_WIDE_VERBOSE_MERGE")) fprintf(stderr, "[mbhip]   merge iteration %d: period %d, cycle of %zu edges\n", iter, p, cyc.size());
+    if (cyc.empty()) break;
+    int picked = 0;
+    for (int k : cyc) {
+      const RetEdge &ce = edges[k];
+      if (ce.orig < 0 || ce.em || merged[ce.orig]) continue;
+      const int v = ce.src, x = ce.dst;
+      if (v >= nOwn || x >= nOwn || v == seedState || isTgt[v] || isSrc[x] || inOf[v].empty()) continue;
+      if ((int)inOf[v].size() > 8 || fanIn[x] + (int)inOf[v].size() - 1 > 48) continue;
+      merged[ce.orig] = 1; isSrc[v] = 1; isTgt[x] = 1; fanIn[x] += (int)inOf[v].size() - 1;
+      ++picked; ++nMerged;
+    }
+    if (!picked) break;
+    rebuild();
+  }
+  if (cache) { cache->mergeKnown = true; cache->nEdges = orig.size(); cache->merged.clear(); for (size_t i = 0; i < orig.size(); ++i) if (merged[i]) cache->merged.push_back((int)i); }
+  if (verbose) fprintf(stderr, "[mbhip] wide retimed part: %d silent transitions merged into two-transition candidates, shortest period %d -> %d (%zu -> %zu candidates)\n", nMerged, p0, p, orig.size(), edges.size());
+}
+}  // namespace
 
 // hostOut: keep the record stream on the host instead of uploading it (mb_debug_wide_retimed: the planner without a device)
 static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr,
@@ -1342,6 +1460,17 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     if (a.em != b.em) return a.em < b.em;
     return P.backward ? a.dst > b.dst : a.dst < b.dst;
   });
+  const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
+  // parts: two-transition candidates until the period is about half the machine's own (MB_ONETAPE_PART_MERGE=0: none; n > 1: until period n)
+  const int mergeTo = (part && part->useMerge) ? env_int_w("MB_ONETAPE_PART_MERGE", 1) : 0;
+  if (mergeTo > 0) {
+    int target = mergeTo;
+    if (mergeTo == 1 && !part->mergeKnown) {
+      std::vector<int> t0; int lo = 1, hi = 64;
+      if (ret_offsets(edges, S, hi, kLimit * hi + hi - 1, t0)) { while (lo < hi) { const int mid = (lo + hi) / 2; if (ret_offsets(edges, S, mid, kLimit * mid + mid - 1, t0)) hi = mid; else lo = mid + 1; } target = (lo + 1) / 2; }
+    }
+    if (target >= 1) ret_merge(edges, S, SC, seedState, target, kLimit * 64 + 63, P.backward, verbose, const_cast<RetPart *>(part));
+  }
   // the order candidates enter their node's list: the relaxation's order, or -- traceback codes -- the reference's enumeration order
   std::vector<RetEdge> byRank;
   const std::vector<RetEdge> *edgeOrder = &edges;
@@ -1351,7 +1480,6 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
     edgeOrder = &byRank;
   }
   std::vector<int> tau;
-  const int kLimit = WIDE_RET_TOKWIN - 2;                      // largest lag the token window serves
   auto feasible = [&](int period) { return ret_offsets(edges, S, period, kLimit * period + period - 1, tau); };
   // (a weight refresh keeps the period that was chosen: the schedule depends on the machine's structure, not on its weights)
   const int forced = keepPeriod > 0 ? keepPeriod : env_int_w("MB_WIDE_RETIMED_PERIOD", 0);
@@ -1399,7 +1527,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       for (const RetEdge &e : *edgeOrder) {
         const int kt = tau[e.dst] / period, span = tau[e.dst] + (e.em ? period : 0) - tau[e.src];
         const int k = (span - 1) / hop;
-        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : entryOf(e.src)), e.w, e.ref});
+        cands[e.dst].push_back(WCand{srcWord(kt, e.em, e.tok, k ? S + 2 + relayBase[e.src] + k - 1 : entryOf(e.src)), e.w, e.ref, e.w2});
       }
       // (traceback codes: a cell's code is the PLACE of its first maximal candidate in this list -- the reference's order, the seed last)
       if (seedState >= 0 && P.tbCodes) cands[seedState].push_back(WCand{srcWord(tau[seedState] / period, 0, rowLen - 1, SC + 1), seedW});
@@ -1435,20 +1563,22 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   if (best.cost >= 1e300) return true;
   // rounds (one stage per residue) -> one stream of [slot][lane] records
   WideProgram T;
-  T.W = W; T.dev.S = SC;
+  T.W = W; T.dev.S = SC; T.wantW2 = part && part->useMerge;
   wide_plan(best.nd, best.period - 1, 1, W, true, &T, 280.0);
   if (T.rounds.empty()) return true;
   int nSlots = 0;
   for (const WideRound &R : T.rounds) nSlots += R.depth;
   // (the kernel keeps `ring` records in flight and takes its slots in groups of that many)
-  const int ring = part ? WIDE_PART_RING : WIDE_RING;
+  const int ring = part ? part->ring : WIDE_RING;
   const int padded = (nSlots + ring - 1) / ring * ring;
-  if ((size_t)(best.NB * padded + WIDE_RING) * W * sizeof(WideRec) >= ((size_t)1 << 31)) return true;      // (the kernel's buffer loads carry 32-bit offsets)
+  const bool withW2 = part && part->useMerge;                  // a second stream behind the records: the second weights, [slot][lane] doubles
+  if ((size_t)(best.NB * padded + WIDE_RING) * W * sizeof(WideRec) * (withW2 ? 2 : 1) >= ((size_t)1 << 31)) return true;      // (the kernel's buffer loads carry 32-bit offsets)
   // one stream per rotation cm of the ring (newest column in vector cm): a record names its source by LDS byte address
   //   src = byte address << 14 | penalty entry;   pad (last slot) = flags | kq << 20 | vector << 18 | ring entry (see WideRetDev)
   const int NB = best.NB, NVs = best.NVs;
   std::vector<WideRec> st;
-  st.reserve((size_t)(NB * padded + WIDE_RING) * W);
+  st.reserve((size_t)(NB * padded + WIDE_RING) * W * (withW2 ? 2 : 1));
+  std::vector<double> st2;
   for (int cm = 0; cm < NB; ++cm) {
     const bool gv = best.gv;                                   // records name ring entries (L2 ring) or LDS byte addresses
     const WideRec padRec{-INFINITY, gv ? (uint32_t)SC << 13 : (uint32_t)(SC * 8) << 14, 0};      // entry S of vector 0 (-inf), penalty entry 0 (0.0)
@@ -1458,6 +1588,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
         const bool last = j + 1 == R.depth;
         for (int l = 0; l < W; ++l) {
           WideRec rc = T.recs[(size_t)R.recBase + (size_t)j * W + l];
+          const double w2 = (withW2 && rc.w != -INFINITY) ? T.recs2[(size_t)R.recBase + (size_t)j * W + l] : 0.0;
           if (rc.w == -INFINITY) rc = padRec;                    // (the planner's own padding)
           else {
             const uint32_t a0 = rc.src & 0x7ffffu, penIdx = rc.src >> 19;      // shape(): entry for rotation 0, penalty entry
@@ -1480,11 +1611,18 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
             }
           }
           st.push_back(rc);
+          if (withW2) st2.push_back(w2);
         }
       }
     st.resize(start + (size_t)padded * W, padRec);
+    if (withW2) st2.resize(st.size(), 0.0);
   }
   st.insert(st.end(), st.begin(), st.begin() + (size_t)WIDE_RING * W);      // the ring reads one ring of slots into the next period
+  if (withW2) {      // ... and the second weights behind them (two to a WideRec), read at half the records' byte offset
+    st2.insert(st2.end(), st2.begin(), st2.begin() + (size_t)WIDE_RING * W);
+    P.retW2Offset = (long long)st.size() * (long long)sizeof(WideRec);
+    for (size_t q = 0; q < st2.size(); q += 2) { WideRec two; two.w = st2[q]; const double hi = q + 1 < st2.size() ? st2[q + 1] : 0.0; std::memcpy(&two.src, &hi, 8); st.push_back(two); }
+  } else P.retW2Offset = 0;
   if (verbose)
     for (const WideRound &R : T.rounds) {
       int hist[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1501,15 +1639,15 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   P.slotsPerColumn = padded; P.candsPerColumn = T.candsPerColumn; P.nSync = T.nSync;
   P.rounds = T.rounds;                                  // (planning tables: mb_machine_sweep_ops counts them)
   P.retOk = true;
-  if (P.tbCodes && !part) {      // (the parts of a machine write the codes of its one-workgroup program: same lists, same order)
+  if (P.tbCodes) {      // (a part: the tables of its own states, local numbering; wide_parts_host joins them)
     // decode tables of the traceback codes: the candidate lists of the state nodes, in the order the planner laid them out
     // (kept on the host as well: mb_debug_wide_retimed hands them to the device-free simulation of tests/test_retimed_plan.py)
-    std::vector<int> tbOff(S + 1, 0);
-    std::vector<std::vector<uint32_t>> ent(S);
-    bool fits = S < (1 << 15) && m->nTrans <= (1 << 16) && !P.backward && P.viterbi;
+    std::vector<int> tbOff(SC + 1, 0);
+    std::vector<std::vector<uint32_t>> ent(SC);
+    bool fits = m->S < (1 << 15) && m->nTrans <= (1 << 16) && !P.backward && P.viterbi;
     for (const WNode &nd : best.nd) {
       const uint32_t x = nd.dst & WIDE_RET_NO_DST;
-      if (x >= (uint32_t)S) continue;                       // relays, constants
+      if (x >= (uint32_t)SC) continue;                      // relays, constants, a part's imports and exports
       if (nd.t3.size() > 256) fits = false;
       for (const WCand &cd : nd.t3) {
         if (cd.ref == 0xFFFFFFFFu) { ent[x].push_back(0xFFFFFFFFu); continue; }      // the seed
@@ -1518,15 +1656,15 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       }
     }
     std::vector<uint32_t> flat;
-    for (int x = 0; x < S; ++x) { tbOff[x] = (int)flat.size(); flat.insert(flat.end(), ent[x].begin(), ent[x].end()); }
-    tbOff[S] = (int)flat.size();
+    for (int x = 0; x < SC; ++x) { tbOff[x] = (int)flat.size(); flat.insert(flat.end(), ent[x].begin(), ent[x].end()); }
+    tbOff[SC] = (int)flat.size();
     P.tbOk = fits && (hostOut || (up_w(P.d_tbOff, tbOff) && up_w(P.d_tbEntry, flat)));
     P.tbEntries = (long long)flat.size();
     P.h_tbOff = tbOff; P.h_tbEntry = flat;
   }
   if (verbose)
-    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
-            P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, T.candsPerColumn,
+    fprintf(stderr, "[mbhip] wide retimed %s%s program: period %d (shortest %d), %d columns in flight, %zu rounds, %d slots per period (%d before padding; %lld candidates = %.0f %% of the lane slots), ring %d x %d (%d relays)%s, LDS %zu bytes\n",
+            P.backward ? "backward" : "forward", P.viterbi ? " (max)" : "", best.period, pMin, best.kMax + 1, T.rounds.size(), padded, nSlots, T.candsPerColumn,
             100.0 * (double)T.candsPerColumn / (double)std::max<long long>(1, (long long)padded * W), best.NB, best.NVs, best.nRelay, best.gv ? " in L2" : "", P.retLdsBytes);
   return true;
 }
@@ -1572,14 +1710,18 @@ int scc_of(int n, const std::vector<int> &off, const std::vector<int> &adj, std:
 }
 }  // namespace
 
-bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot) {
+bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot,
+                     std::vector<int> *tbOffOut, std::vector<uint32_t> *tbEntryOut, WidePartHint *hint, int *WoutP, int *ringOutP) {
   parts.clear(); nExpTot = 0;
+  int WoutL = 0, ringOutL = 8;
+  int &Wout = WoutP ? *WoutP : WoutL, &ringOut = ringOutP ? *ringOutP : ringOutL;
+  std::vector<std::vector<uint32_t>> tbOfState(tbCodes ? m->S : 0);
   const int S = m->S, nTok = (m->nOut ? m->nOut : m->nIn) + 1;
   if (k < 2 || S < 2 * k) return false;
   const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
   std::vector<WNode> nodes;
   int nExtra = 0, nStages = 0; long long nPairs = 0;
-  if (!wide_nodes(m, backward, 0, W, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
+  if (!wide_nodes(m, backward, 0, 1024, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
   // the dependency graph of the sweep: source -> node, for every candidate the retimed program keeps (finite weight, a source that has
   // candidates itself)
   std::vector<char> live(S, 0);
@@ -1640,12 +1782,16 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
   expIdx0[K] = nExpTot;
   parts.resize(K);
   const int resultState = backward ? 0 : S - 1;
+  // every part's local nodes (see RetPart), once
+  struct Prep { std::vector<int> own, imps, exps; std::vector<WNode> ln; RetPart spec; };
+  std::vector<Prep> prep(K);
   for (int p = 0; p < K; ++p) {
-    std::vector<int> own, imps, exps;
+    Prep &Q = prep[p];
+    std::vector<int> &own = Q.own, &imps = Q.imps, &exps = Q.exps;
     for (int v = 0; v < S; ++v) if (partOf[v] == p) { loc[v] = (int)own.size(); own.push_back(v); if (exported[v]) exps.push_back(v); }
     for (int v : own) if (nodeOf[v] >= 0) forCands(nodes[nodeOf[v]], [&](const WCand &cd) { if (kept(cd) && partOf[srcOf(cd)] != p) imps.push_back(srcOf(cd)); });
     std::sort(imps.begin(), imps.end()); imps.erase(std::unique(imps.begin(), imps.end()), imps.end());
-    RetPart spec; spec.nOwn = (int)own.size(); spec.nImp = (int)imps.size(); spec.nExp = (int)exps.size();
+    RetPart &spec = Q.spec; spec.nOwn = (int)own.size(); spec.nImp = (int)imps.size(); spec.nExp = (int)exps.size();
     const int SV = spec.nOwn + spec.nImp + spec.nExp;
     auto localOf = [&](const WCand &cd, WCand &out) -> bool {      // false: a candidate the program drops anyway (its source never holds a value)
       const int y = srcOf(cd);
@@ -1656,7 +1802,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
       out.src = (cd.src & 0xC0000000u) | (uint32_t)v;
       return true;
     };
-    std::vector<WNode> ln;
+    std::vector<WNode> &ln = Q.ln;
     for (int v : own) {
       if (nodeOf[v] < 0) continue;
       const WNode &nd = nodes[nodeOf[v]];
@@ -1669,12 +1815,83 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
     }
     for (int i = 0; i < spec.nImp; ++i) ln.push_back(WNode{CUR(spec.nOwn + i), 0, {}, {}});
     for (int j = 0; j < spec.nExp; ++j) ln.push_back(WNode{CUR(spec.nOwn + spec.nImp + j), 0, {}, {WCand{CUR(loc[exps[j]]), 0.0}}});
+    if (hint && hint->valid && p < (int)hint->merged.size()) { spec.mergeKnown = true; spec.merged = hint->merged[p]; spec.nEdges = hint->nEdges[p]; }
+    for (int v : own) loc[v] = -1;
+  }
+  // Lanes per part and ring depth: every part is planned for every candidate and the launch takes the pair whose SLOWEST part is fastest
+  // under a model fitted on the 5 063-state machine cut in four (ms per 10 000 periods: 2.84 per round + 1.45 per slot of the padded
+  // period, x 1 + 0.44 per eight wavefronts beyond eight; a ring of 4 saves padding and costs 2 %).  The two-transition candidates of
+  // a part are chosen at the first candidate and kept.  A hint (the choice of an earlier build of the same cut) skips the search.
+  struct Cand { int first, second; bool merge; };
+  std::vector<Cand> cand;
+  if (hint && hint->valid) cand.push_back({hint->W, hint->ring, hint->merge});
+  else {
+    const int ringEnv = env_int_w("MB_ONETAPE_PART_RING", 0);
+    const bool mayMerge = env_int_w("MB_ONETAPE_PART_MERGE", 1) != 0;
+    std::vector<int> Ws;
+    if (W > 0) Ws.push_back(W);
+    else for (int w : {384, 512, 640, 768, 896, 1024}) Ws.push_back(w);
+    (void)ringEnv;      // (a ring of 4 was measured: within 3 % either way, not worth a second set of kernels)
+    for (int mg = mayMerge ? 1 : 0; mg >= 0; --mg) for (int w : Ws) cand.push_back({w, 8, mg != 0});
+  }
+  auto buildPart = [&](int p, int w, int r, bool mg, WideProgram &T, std::vector<WideRec> *stream) -> bool {
+    Prep &Q = prep[p];
+    Q.spec.ring = WIDE_RING; (void)r; Q.spec.useMerge = mg;
+    T = WideProgram();
+    T.backward = backward; T.viterbi = viterbi; T.tbCodes = tbCodes; T.W = w;
+    std::vector<WideRec> scratch;
+    return wide_ret_build(m, T, Q.ln, nTok, stream ? stream : &scratch, 0, &Q.spec) && T.retOk && !T.retGv && (!tbCodes || T.tbOk);
+  };
+  int bestW = 0, bestRing = 8; double bestCost = 1e300; bool bestMerge = true;
+  if (cand.size() == 1) { bestW = cand[0].first; bestRing = cand[0].second; bestMerge = cand[0].merge; }
+  else {
+    const bool quiet = getenv("MB_WIDE_VERBOSE_PARTS") == nullptr;      // (the search's own builds stay silent unless asked)
+    const char *keepVerbose = getenv("MB_WIDE_VERBOSE");
+    std::string saved = keepVerbose ? keepVerbose : "";
+    if (quiet && keepVerbose) unsetenv("MB_WIDE_VERBOSE");
+    struct Res { bool ok = false; double cost = 0.0; int period = 0; };
+    std::vector<Res> res(cand.size());
+    for (size_t ci = 0; ci < cand.size(); ++ci) {
+      const Cand &c = cand[ci];
+      double worst = 0.0; bool ok = true; int maxPeriod = 0;
+      for (int p = 0; p < K && ok; ++p) {
+        WideProgram T;
+        ok = buildPart(p, c.first, c.second, c.merge, T, nullptr);
+        if (ok) {
+          worst = std::max(worst, (2.84 * (double)T.rounds.size() + 1.45 * (double)T.ret.nSlots) * (1.0 + 0.44 * std::max(0, c.first / 64 - 8) / 8.0) * (c.second == 4 ? 1.02 : 1.0));
+          maxPeriod = std::max(maxPeriod, T.retPeriod);
+        }
+      }
+      res[ci].ok = ok; res[ci].cost = worst; res[ci].period = maxPeriod;
+    }
+    for (size_t ci = 0; ci < cand.size(); ++ci) {
+      const Cand &c = cand[ci];
+      bool ok = res[ci].ok;
+      // two-transition candidates lengthen the spans between a value and its readers: in a part whose ring nearly fills the LDS the relays
+      // push the period back up (whole fn3 profile cut in four: period 13 where the one-transition program has 9) and the sweep is slower than
+      // the model says -- taken only where they shorten the slowest part's period by a quarter at least
+      if (ok && c.merge)
+        for (size_t cj = 0; cj < cand.size(); ++cj)
+          if (!cand[cj].merge && cand[cj].first == c.first && cand[cj].second == c.second && res[cj].ok && 4 * res[ci].period > 3 * res[cj].period) ok = false;
+      if (verbose) fprintf(stderr, "[mbhip] wide parts: %d lanes, ring %d, %s-transition candidates: %s, slowest part's period %d, modelled %.1f\n", c.first, c.second, c.merge ? "two" : "one",
+                           ok ? "taken into account" : (res[ci].ok ? "set aside" : "no program"), res[ci].period, res[ci].cost);
+      if (ok && res[ci].cost < bestCost) { bestCost = res[ci].cost; bestW = c.first; bestRing = c.second; bestMerge = c.merge; }
+    }
+    if (quiet && keepVerbose) setenv("MB_WIDE_VERBOSE", saved.c_str(), 1);
+    if (!bestW) { parts.clear(); return false; }
+  }
+  for (int p = 0; p < K; ++p) {
+    Prep &Q = prep[p];
+    const RetPart &spec = Q.spec;
+    const std::vector<int> &own = Q.own, &imps = Q.imps;
+    for (size_t q = 0; q < own.size(); ++q) loc[own[q]] = (int)q;
     WideProgram T;
-    T.backward = backward; T.viterbi = viterbi; T.tbCodes = tbCodes; T.W = W;
     WidePartHost &H = parts[p];
-    if (!wide_ret_build(m, T, ln, nTok, &H.stream, 0, &spec) || !T.retOk || T.retGv) { parts.clear(); return false; }
+    if (!buildPart(p, bestW, bestRing, bestMerge, T, &H.stream)) { parts.clear(); return false; }
+    if (tbCodes) for (int q = 0; q < spec.nOwn; ++q) tbOfState[own[q]].assign(T.h_tbEntry.begin() + T.h_tbOff[q], T.h_tbEntry.begin() + T.h_tbOff[q + 1]);
     H.h = WidePartDev{};
     H.h.ret = T.ret; H.h.ret.rec = nullptr;
+    H.h.w2Offset = (int)T.retW2Offset;
     H.h.Sloc = spec.nOwn; H.h.nImp = spec.nImp; H.h.expBase = spec.nOwn + spec.nImp + 2; H.h.expIdx0 = expIdx0[p]; H.h.nExp = spec.nExp;
     H.h.resultEntry = partOf[resultState] == p ? loc[resultState] : -1;
     H.tab.clear();
@@ -1683,9 +1900,19 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
     H.period = T.retPeriod;
     H.ldsBytes = ((T.retLdsBytes + 7) & ~(size_t)7) + 512 + 4 * (size_t)spec.nOwn;
     if (verbose)
-      fprintf(stderr, "[mbhip] wide retimed part %d of %d: %d states, %d imports, %d exports, period %d, %d slots per period, %d columns in flight, ring %d x %d, LDS %zu bytes\n",
-              p, K, spec.nOwn, spec.nImp, spec.nExp, T.retPeriod, T.ret.nSlots, T.ret.kMax + 1, T.ret.NB, T.ret.NVs, H.ldsBytes);
+      fprintf(stderr, "[mbhip] wide retimed part %d of %d: %d states, %d imports, %d exports, %d lanes, period %d, %zu rounds, %d slots per period, %d columns in flight, ring %d x %d, LDS %zu bytes\n",
+              p, K, spec.nOwn, spec.nImp, spec.nExp, bestW, T.retPeriod, T.rounds.size(), T.ret.nSlots, T.ret.kMax + 1, T.ret.NB, T.ret.NVs, H.ldsBytes);
     for (int v : own) loc[v] = -1;
+  }
+  Wout = bestW; ringOut = bestMerge ? 1 : 0;      // (second output: the parts carry two-transition candidates)
+  if (hint && !hint->valid) {
+    hint->valid = true; hint->W = bestW; hint->ring = bestRing; hint->merge = bestMerge; hint->merged.clear(); hint->nEdges.clear();
+    for (int p = 0; p < K; ++p) { hint->merged.push_back(prep[p].spec.merged); hint->nEdges.push_back(prep[p].spec.nEdges); }
+  }
+  if (tbCodes && tbOffOut && tbEntryOut) {
+    tbOffOut->assign(S + 1, 0); tbEntryOut->clear();
+    for (int v = 0; v < S; ++v) { (*tbOffOut)[v] = (int)tbEntryOut->size(); tbEntryOut->insert(tbEntryOut->end(), tbOfState[v].begin(), tbOfState[v].end()); }
+    (*tbOffOut)[S] = (int)tbEntryOut->size();
   }
   return true;
 }
@@ -1694,8 +1921,10 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   const bool haveShape = P.ok && P.shapeChosen;    // a weight refresh keeps the shape that was chosen
   const int keepStages = P.stages, keepPeriod = (P.ok && P.retOk) ? P.retPeriod : 0, keepPeriodMin = P.retPeriodMin;
   const bool keepTb = P.tbCodes;
+  std::vector<WidePartHint> keepHints = std::move(P.partHints);      // (the cuts' choices depend on the graph: a weight update re-plans with them)
   wide_free(P);
   P.backward = backward; P.viterbi = viterbi; P.tbCodes = keepTb;
+  P.partHints = std::move(keepHints);
   P.W = env_int_w("MB_WIDE_LANES", m->S >= 192 ? 1024 : 256);      // 509 states: 48 G cells/s with 1024 lanes, 35 with 256
   const int S = m->S, nLev = backward ? m->nLevB : m->nLevF;
   long long nSilent = 0;
@@ -1893,16 +2122,26 @@ static int wide_parts_k(const WideProgram &P, long long nPairs, int cus) {
 }
 
 static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
-  // lanes per part: about 0.4 per state (5 063 states: 2 parts x 1 024, 4 x 512; 21 761 states: 4 x 1 024, 8 and 16 x 512)
-  int lanes = env_int_w("MB_ONETAPE_PART_LANES", m->S / k >= 2500 ? 1024 : 512);
-  if (lanes < 64 || lanes > 1024 || lanes % 64) lanes = 512;
-  for (WidePartSet &ps : P.partSets) if (ps.kWanted == k && ps.W == lanes) return ps.ok ? &ps : nullptr;
+  // lanes per part and ring depth: MB_ONETAPE_PART_LANES / MB_ONETAPE_PART_RING, else searched by wide_parts_host (0: its choice)
+  int lanes = env_int_w("MB_ONETAPE_PART_LANES", 0);
+  if (lanes < 64 || lanes > 1024 || lanes % 64) lanes = 0;
+  const int ringAsk = env_int_w("MB_ONETAPE_PART_RING", 0) == 4 ? 4 : (env_int_w("MB_ONETAPE_PART_RING", 0) == 8 ? 8 : 0);
+  for (WidePartSet &ps : P.partSets) if (ps.kWanted == k && ps.lanesAsked == lanes && ps.ringAsked == ringAsk) return ps.ok ? &ps : nullptr;
   P.partSets.emplace_back();
   WidePartSet &ps = P.partSets.back();
-  ps.kWanted = k;
-  ps.W = lanes;
+  ps.kWanted = k; ps.lanesAsked = lanes; ps.ringAsked = ringAsk;
+  WidePartHint *hint = nullptr;      // what an earlier build of this cut chose (kept across weight updates: it depends on the graph)
+  for (WidePartHint &h : P.partHints) if (h.kWanted == k && h.lanesAsked == lanes && h.ringAsked == ringAsk) hint = &h;
+  if (!hint) { P.partHints.emplace_back(); hint = &P.partHints.back(); hint->kWanted = k; hint->lanesAsked = lanes; hint->ringAsked = ringAsk; }
   std::vector<WidePartHost> hp;
-  if (!wide_parts_host(m, P.backward, P.viterbi, P.tbCodes, k, ps.W, hp, ps.nExpTot)) return nullptr;
+  std::vector<int> tbOff; std::vector<uint32_t> tbEntry;
+  int mergeFlag = 0;
+  if (!wide_parts_host(m, P.backward, P.viterbi, P.tbCodes, k, lanes, hp, ps.nExpTot, &tbOff, &tbEntry, hint, &ps.W, &mergeFlag)) { hint->valid = false; return nullptr; }
+  ps.merge = mergeFlag != 0;
+  if (P.tbCodes) {
+    if (!up_w(ps.d_tbOff, tbOff) || !up_w(ps.d_tbEntry, tbEntry)) return nullptr;
+    ps.tbEntries = (long long)tbEntry.size();
+  }
   ps.k = (int)hp.size();
   ps.d_rec.assign(ps.k, nullptr); ps.d_tab.assign(ps.k, nullptr);
   ps.h_parts.resize(ps.k);
@@ -1954,20 +2193,17 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   size_t lds = ps.ldsBytes;
   if (env_int_w("MB_ONETAPE_PART_EXCLUSIVE", 1)) lds = std::max<size_t>(lds, 82 * 1024);
   if (lds > WIDE_LDS_MAX) { set_error("one-tape parts: LDS"); return 1; }
-  static bool attr = false;
-  if (!attr) {
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_VITERBI, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_VITERBI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_FORWARD, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-    MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<MB_FORWARD, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
-    attr = true;
-  }
   const dim3 grid((unsigned)(nPairs * ps.k)), block((unsigned)ps.W);
-  if (P.viterbi) {
-    if (tb) hipLaunchKernelGGL((k_wide_retimed_parts<MB_VITERBI, true, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
-    else hipLaunchKernelGGL((k_wide_retimed_parts<MB_VITERBI, false, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
-  } else if (g_wide_accurate) hipLaunchKernelGGL((k_wide_retimed_parts<MB_FORWARD, false, true>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
-  else hipLaunchKernelGGL((k_wide_retimed_parts<MB_FORWARD, false, false>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike);
+#define WIDE_PART_GO(M, T, AC, W2F) do { \
+    static bool attr = false; \
+    if (!attr) { MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<M, T, AC, W2F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX)); attr = true; } \
+    hipLaunchKernelGGL((k_wide_retimed_parts<M, T, AC, W2F>), grid, block, lds, st, dev, A, d_desc, d_tape, pool, loglike); } while (0)
+#define WIDE_PART_W2(M, T, AC) do { if (ps.merge) WIDE_PART_GO(M, T, AC, true); else WIDE_PART_GO(M, T, AC, false); } while (0)
+  if (P.viterbi) { if (tb) WIDE_PART_W2(MB_VITERBI, true, false); else WIDE_PART_W2(MB_VITERBI, false, false); }
+  else if (g_wide_accurate) WIDE_PART_W2(MB_FORWARD, false, true);
+  else WIDE_PART_W2(MB_FORWARD, false, false);
+#undef WIDE_PART_W2
+#undef WIDE_PART_GO
   MB_HIP(hipGetLastError());
   g_last_launches += 1;
   g_last_parts = ps.k;
@@ -2069,8 +2305,9 @@ int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, lo
   if (h_desc) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
-    if (ps) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true);
+    if (ps) { P.tbFromSet = (int)(ps - P.partSets.data()); return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true); }
   }
+  P.tbFromSet = -1;
   static bool attr = false;
   if (!attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));
@@ -2218,12 +2455,17 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
   if (!P.tbOk) { set_error("one-tape traceback-code program not built"); return 1; }
   if (nPairs <= 0) return 0;
   const int S = m->S, Sb = wide_tb_stride(S);
-  size_t tabBytes = (((size_t)(S + 1) * 2 + 3) & ~(size_t)3) + (size_t)P.tbEntries * 4;
-  WideTbWalk Q{P.d_tbOff, P.d_tbEntry, P.tbEntries, 0, 1, 0};
+  // (codes written by k workgroups per sequence decode with that cut's tables: two-transition candidates change the places)
+  const bool fromSet = P.tbFromSet >= 0 && P.tbFromSet < (int)P.partSets.size();
+  const int *tbOffD = fromSet ? P.partSets[P.tbFromSet].d_tbOff : P.d_tbOff;
+  const uint32_t *tbEntryD = fromSet ? P.partSets[P.tbFromSet].d_tbEntry : P.d_tbEntry;
+  const long long tbEntriesN = fromSet ? P.partSets[P.tbFromSet].tbEntries : P.tbEntries;
+  size_t tabBytes = (((size_t)(S + 1) * 2 + 3) & ~(size_t)3) + (size_t)tbEntriesN * 4;
+  WideTbWalk Q{tbOffD, tbEntryD, tbEntriesN, 0, 1, 0};
   const size_t budget = 150 * 1024;
   // the window wants at least 2 x 2 rows; the tables go to LDS when 2 x 4 rows still fit beside them, the fast words (8 bytes per
   // state) when they do too
-  if (tabBytes + (size_t)8 * Sb <= budget && P.tbEntries < 65536) Q.tablesInLds = 1;
+  if (tabBytes + (size_t)8 * Sb <= budget && tbEntriesN < 65536) Q.tablesInLds = 1;
   if (Q.tablesInLds && tabBytes + (size_t)S * 8 + 8 + (size_t)8 * Sb <= budget && env_int_w("MB_ONETAPE_TB_FAST", 1) != 0) { Q.fast = 1; tabBytes += (size_t)S * 8 + 8; }
   const size_t forRows = budget - (Q.tablesInLds ? tabBytes : 0);
   Q.rowsPerHalf = (int)std::max<size_t>(1, std::min<size_t>(forRows / (2 * (size_t)Sb), 32));
@@ -2232,7 +2474,7 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_onetape_traceback_codes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(k_onetape_traceback_codes, dim3((unsigned)nPairs), dim3(256), lds, st, m->dev, Q, d_pairs, m->nIn != 0 ? 1 : 0, tb, d_loglike, d_slotOff, d_pathBuf, d_pathLen);
-  hipLaunchKernelGGL(k_onetape_path_ids, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, P.d_tbEntry, d_slotOff, (const long long *)d_pathLen, d_pathBuf);
+  hipLaunchKernelGGL(k_onetape_path_ids, dim3((unsigned)nPairs), dim3(256), 0, st, m->dev, tbEntryD, d_slotOff, (const long long *)d_pathLen, d_pathBuf);
   return hip_ok(hipGetLastError(), "one-tape traceback (codes) launch") ? 0 : 1;
 }
 

@@ -1,7 +1,7 @@
 """Device-free fuzz of the one-tape family's k-workgroups-per-sequence planner: random BLOCK machines (cycles inside blocks
 only, so the transition graph has cuts) x k x lanes per part, the parts' record streams (mb_debug_wide_parts) replayed in workgroup order by
-tests/test_retimed_plan.simulate_parts against the oracle -- max (bit for bit), sum, backward sum, and the traceback codes against the
-one-workgroup program's.   usage: python scripts/fuzz_parts_plan.py [cases=100] [seed0=9000]"""
+tests/test_retimed_plan.simulate_parts against the oracle -- max (bit for bit), sum, backward sum, and the traceback codes walked into the
+oracle's paths.   usage: python scripts/fuzz_parts_plan.py [cases=100] [seed0=9000]"""
 import math, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,10 +30,8 @@ for c in range(n):
     except capi.MbError as e:
         skipped += 1; continue
     np_ = len(progs[(capi.MB_VITERBI, False)]["parts"]); parts_seen[np_] = parts_seen.get(np_, 0) + 1
-    try:
-        one = capi.debug_wide_retimed(em, tmp + "/t1.bin", capi.MB_VITERBI, False, tb_codes=True)
-        tbp = capi.debug_wide_parts(em, tmp + "/t.bin", k, lanes, capi.MB_VITERBI, False, tb_codes=True)
-    except capi.MbError: one = tbp = None
+    try: tbp = capi.debug_wide_parts(em, tmp + "/t.bin", k, lanes, capi.MB_VITERBI, False, tb_codes=True)
+    except capi.MbError: tbp = None
     ok = True
     try:
         for L in (0, int(rng.randint(1, 12)), int(rng.randint(12, 40))):
@@ -47,9 +45,9 @@ for c in range(n):
                 ok &= np.array_equal(np.isneginf(got), np.isneginf(R)) and np.allclose(got[fin], R[fin], rtol=1e-11, atol=1e-11)
             if tbp is not None:
                 cells, codes = simulate_parts(tbp, seq, False, True, tb=True)
-                c1, codes1 = simulate(one, seq, False, True, tb=True)
-                ok &= np.array_equal(cells, V) and np.array_equal(codes, codes1)
-                if V[-1, -1] > -math.inf: ok &= np.array_equal(walk_codes(one, codes, L), om.traceback(x, y, om.viterbi(x, y)))
+                ok &= np.array_equal(cells, V)
+                tabs = {"S": S, "tbOff": tbp["tbOff"], "tbEntry": tbp["tbEntry"], "inEid": tbp["inEid"]}
+                if V[-1, -1] > -math.inf: ok &= np.array_equal(walk_codes(tabs, codes, L), om.traceback(x, y, om.viterbi(x, y)))
     except AssertionError as e:
         ok = False; print("ASSERTION", e)
     if not ok: bad += 1; print("MISMATCH case", c, "blocks", blocks, "x", per, "generator" if gen else "recogniser", nt, "k", k, "lanes", lanes, flush=True)
