@@ -1511,8 +1511,8 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     a topological order of its strongly connected components, one retimed program and one workgroup per part, values crossing through
     an exchange buffer.  Against the ONE-workgroup sweep (MB_ONETAPE_PARTS=1) and the oracle, on config 5's literal composition with a
     3-node profile (762 states) and ragged lengths (an empty sequence among them): Viterbi matrices, scores and paths bit for bit --
-    through fp64 cells and through traceback codes --, Forward / Backward matrices to 1e-9 (the same candidates, summed by other lane
-    groups), rolling log-likelihoods (cut in two on top) and counts within the fast-path tolerance of the oracle;
+    through fp64 cells and through traceback codes --, Forward / Backward matrices to 1e-8 relative (the same sums in another order:
+    other lane groups, two-transition candidates), rolling log-likelihoods (cut in two on top) and counts within the fast-path tolerance of the oracle;
     default cut, seven parts of two wavefronts, two parts, three parts sharing CUs."""
     m, em = _profile_machine(3)
     om = oracle_mod.OracleMachine(em)
@@ -1554,10 +1554,10 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     assert np.array_equal(got["V"], one["V"])
     for key in ("F", "B", "mat"):      # (other lane groups: another order of the same sum, and other fp32 roundings of its correction term)
         d = np.abs(np.asarray(got[key]) - np.asarray(one[key])); d = d[np.isfinite(d)]
-        assert np.array_equal(np.isneginf(got[key]), np.isneginf(one[key])) and (d.size == 0 or d.max() < 1e-6), (key, float(d.max()))
+        assert np.array_equal(np.isneginf(got[key]), np.isneginf(one[key])) and (d.size == 0 or d.max() < 5e-6), (key, float(d.max()))      # (cells of -400: 1e-8 relative)
     for key in ("vit", "vit64"):
         for a, b_ in zip(got[key], one[key]): assert np.array_equal(np.asarray(a), np.asarray(b_)), key
-    assert close(got["roll"], one["roll"], 1e-8, 1e-9) and close(got["cnt"][0], one["cnt"][0], 1e-6, 1e-9)
+    assert close(got["roll"], one["roll"], 1e-6, 1e-6) and close(got["cnt"][0], one["cnt"][0], 1e-5, 1e-8)      # (the fp32 correction terms fall differently)
     # ... and against the oracle
     y = ys[3]
     assert np.array_equal(got["V"], om.viterbi(x, y))
