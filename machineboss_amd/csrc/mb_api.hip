@@ -516,9 +516,6 @@ static WideProgram *wide_tb_program(mb_machine *m) {
   return (P.ok && P.retOk && P.tbOk) ? &P : nullptr;
 }
 
-// (the count sweep of a one-tape machine runs its two fills side by side: each may count on half of the CUs)
-static int g_fill_share = 1;
-
 // Fill the matrices of one chunk of pairs (materialised), choosing the kernel family.
 static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std::vector<PairDesc> &hp, const int *d_in,
                       const int *d_out, double *pool, int startState, const mb_batch *b) {
@@ -532,7 +529,7 @@ static int fill_chunk(mb_machine *m, int mode, const PairDesc *d_desc, const std
   if (!env && startState == 0 && wide_applicable(m) && g_kernel_choice != 1 && !tiledViterbi) {
     WideProgram *W = wide_program(m, mode);
     if (!W) return 1;
-    const int rcW = wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream, false, hp.data(), device_cus() / g_fill_share);
+    const int rcW = wide_fill(m, *W, d_desc, (long long)hp.size(), m->nOut ? d_out : d_in, pool, nullptr, g_stream, false, hp.data(), device_cus());
     g_last_kernel = wide_kernel_name(*W);
     return rcW;
   }
@@ -1134,8 +1131,8 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
             hipEventRecord(evStart, g_stream) != hipSuccess || hipStreamWaitEvent(s2, evStart, 0) != hipSuccess) { set_error("one-tape split: stream set-up failed"); rc = 1; break; }
         // (with CUs to spare both halves run k workgroups per sequence, each launch on a stream of its own)
         // (a machine whose ring lives in L2 and whose parts fit the LDS only when a sweep has the whole chip: one half after the other)
-        bool parts = wide_parts_for(m, *W, n, device_cus() / 2) > 1 && wide_parts_for(m, *WB, n, device_cus() / 2) > 1;
-        const bool oneByOne = !parts && (W->retGv || WB->retGv) && wide_parts_for(m, *W, n, device_cus()) > 1 && wide_parts_for(m, *WB, n, device_cus()) > 1;
+        bool parts = wide_parts_for(m, *W, n, device_cus() / 2, pre.data()) > 1 && wide_parts_for(m, *WB, n, device_cus() / 2, suf.data()) > 1;
+        const bool oneByOne = !parts && (W->retGv || WB->retGv) && wide_parts_for(m, *W, n, device_cus(), pre.data()) > 1 && wide_parts_for(m, *WB, n, device_cus(), suf.data()) > 1;
         parts = parts || oneByOne;
         const int share = oneByOne ? 1 : 2;
         const int fusedFill = parts ? -1 : wide_fill2(m, *W, *WB, d_pre, d_suf, n, n, tape, vec, vec + n * S, g_stream, true);   // both sweeps in ONE launch
@@ -1440,8 +1437,8 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         if (!WB || !WF) { rc = 1; break; }
         // (with CUs to spare each fill runs k workgroups per sequence, on a stream of its own)
         // (a machine whose ring lives in L2 and whose parts fit the LDS only when a fill has the whole chip: one fill after the other)
-        bool parts = s2 && wide_parts_for(b->m, *WF, np, device_cus() / 2) > 1 && wide_parts_for(b->m, *WB, np, device_cus() / 2) > 1;
-        const bool oneByOne = s2 && !parts && (WF->retGv || WB->retGv) && wide_parts_for(b->m, *WF, np, device_cus()) > 1 && wide_parts_for(b->m, *WB, np, device_cus()) > 1;
+        bool parts = s2 && wide_parts_for(b->m, *WF, np, device_cus() / 2, hp.data()) > 1 && wide_parts_for(b->m, *WB, np, device_cus() / 2, hp.data()) > 1;
+        const bool oneByOne = s2 && !parts && (WF->retGv || WB->retGv) && wide_parts_for(b->m, *WF, np, device_cus(), hp.data()) > 1 && wide_parts_for(b->m, *WB, np, device_cus(), hp.data()) > 1;
         parts = parts || oneByOne;
         const int share = oneByOne ? 1 : 2;
         const int fusedFill = parts ? -1 : wide_fill2(b->m, *WF, *WB, d_desc, d_desc, np, np, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, g_stream, false);   // both sweeps in ONE launch

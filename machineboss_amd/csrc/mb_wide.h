@@ -149,7 +149,7 @@ struct WidePartArgs {
 };
 // what a build of a cut chose -- lanes, ring depth, the two-transition candidates of every part (indices into the part's edge list, with its
 // length as a check) -- kept by the program across weight updates: the choice depends on the machine's graph, not on its weights
-struct WidePartHint { bool valid = false, merge = true; int kWanted = 0, lanesAsked = 0, ringAsked = 0, W = 0, ring = 8; std::vector<std::vector<int>> merged; std::vector<size_t> nEdges; };
+struct WidePartHint { bool valid = false, merge = true; int kWanted = 0, lanesAsked = 0, ringAsked = 0, W = 0, ring = 8; std::vector<std::vector<int>> merged; std::vector<size_t> nEdges; std::vector<int> period, periodMin; };
 struct WidePartSet {
   bool ok = false;
   int kWanted = 0, lanesAsked = 0, ringAsked = 0;      // what was asked for (0: the builder's choice)
@@ -230,7 +230,7 @@ void wide_set_accurate(bool on);      // the next retimed sum fills carry their 
 bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes = false);
 // ... and its k-part form: the record stream, geometry and tables of every part (a part's `h` holds HOST pointers into tabs[part]:
 // gmap [Sloc], then impIdx [nImp]); false when the machine's graph has no cut
-struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0; size_t ldsBytes = 0; };
+struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0, periodMin = 0; size_t ldsBytes = 0; };
 // W = 0: the lanes per part (and the ring depth) are searched; hint: the choice of an earlier build of the same cut (in / out)
 bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot,
                      std::vector<int> *tbOff = nullptr, std::vector<uint32_t> *tbEntry = nullptr, WidePartHint *hint = nullptr, int *Wout = nullptr, int *ringOut = nullptr);
@@ -241,7 +241,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly = false, const PairDesc *h_desc = nullptr, int cus = 0);
 int wide_last_parts();      // k of the last launch of this family (1: one workgroup per sequence)
-int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus);      // k such a launch would use (builds the parts)
+int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc = nullptr);      // k such a launch would use (builds the parts); h_desc: the launch's sequences (short ones are not worth a cut)
 bool wide_parts_failed();   // after the streams were synchronised: a bounded wait ran out (error set, flag cleared)
 const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
 // ViterbiMatrix::fill keeping one traceback code per cell (P.tbOk): tb = bytes, wide_tb_stride(S) per column, PairDesc::cellBase =

@@ -1834,13 +1834,17 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
     (void)ringEnv;      // (a ring of 4 was measured: within 3 % either way, not worth a second set of kernels)
     for (int mg = mayMerge ? 1 : 0; mg >= 0; --mg) for (int w : Ws) cand.push_back({w, 8, mg != 0});
   }
+  const bool hinted = hint && hint->valid && (int)hint->period.size() == K;
   auto buildPart = [&](int p, int w, int r, bool mg, WideProgram &T, std::vector<WideRec> *stream) -> bool {
     Prep &Q = prep[p];
     Q.spec.ring = WIDE_RING; (void)r; Q.spec.useMerge = mg;
     T = WideProgram();
     T.backward = backward; T.viterbi = viterbi; T.tbCodes = tbCodes; T.W = w;
     std::vector<WideRec> scratch;
-    return wide_ret_build(m, T, Q.ln, nTok, stream ? stream : &scratch, 0, &Q.spec) && T.retOk && !T.retGv && (!tbCodes || T.tbOk);
+    // (a build from a kept choice -- a weight update -- also keeps every part's period: one relaxation, one plan)
+    int keepPeriod = 0;
+    if (hinted) { keepPeriod = hint->period[p]; T.retPeriodMin = hint->periodMin[p]; }
+    return wide_ret_build(m, T, Q.ln, nTok, stream ? stream : &scratch, keepPeriod, &Q.spec) && T.retOk && !T.retGv && (!tbCodes || T.tbOk);
   };
   int bestW = 0, bestRing = 8; double bestCost = 1e300; bool bestMerge = true;
   if (cand.size() == 1) { bestW = cand[0].first; bestRing = cand[0].second; bestMerge = cand[0].merge; }
@@ -1897,7 +1901,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
     H.tab.clear();
     for (int v : own) H.tab.push_back((uint32_t)v);
     for (int y : imps) H.tab.push_back((uint32_t)expIdx[y]);
-    H.period = T.retPeriod;
+    H.period = T.retPeriod; H.periodMin = T.retPeriodMin;
     H.ldsBytes = ((T.retLdsBytes + 7) & ~(size_t)7) + 512 + 4 * (size_t)spec.nOwn;
     if (verbose)
       fprintf(stderr, "[mbhip] wide retimed part %d of %d: %d states, %d imports, %d exports, %d lanes, period %d, %zu rounds, %d slots per period, %d columns in flight, ring %d x %d, LDS %zu bytes\n",
@@ -1907,7 +1911,8 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
   Wout = bestW; ringOut = bestMerge ? 1 : 0;      // (second output: the parts carry two-transition candidates)
   if (hint && !hint->valid) {
     hint->valid = true; hint->W = bestW; hint->ring = bestRing; hint->merge = bestMerge; hint->merged.clear(); hint->nEdges.clear();
-    for (int p = 0; p < K; ++p) { hint->merged.push_back(prep[p].spec.merged); hint->nEdges.push_back(prep[p].spec.nEdges); }
+    hint->period.clear(); hint->periodMin.clear();
+    for (int p = 0; p < K; ++p) { hint->merged.push_back(prep[p].spec.merged); hint->nEdges.push_back(prep[p].spec.nEdges); hint->period.push_back(parts[p].period); hint->periodMin.push_back(parts[p].periodMin); }
   }
   if (tbCodes && tbOffOut && tbEntryOut) {
     tbOffOut->assign(S + 1, 0); tbEntryOut->clear();
@@ -2211,7 +2216,17 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   return 0;
 }
 
-int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus) {
+// Cutting a machine and planning its parts costs 0.5-1 s the first time (20-40 ms after a weight update): worth it for sweeps of
+// thousands of columns -- from MB_ONETAPE_PARTS_MIN_LEN (4 096; 64 for a machine whose one-workgroup ring lives in L2, where the
+// parts are 5-17 x faster) symbols in the longest sequence of the launch
+static bool wide_parts_worth(const mb_machine *m, const WideProgram &P, const PairDesc *h_desc, long long nPairs) {
+  const int minLen = env_int_w("MB_ONETAPE_PARTS_MIN_LEN", P.retGv ? 64 : 4096);
+  for (long long p = 0; p < nPairs; ++p) if ((m->nOut ? h_desc[p].outLen : h_desc[p].inLen) >= minLen) return true;
+  return false;
+}
+
+int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc) {
+  if (h_desc && !wide_parts_worth(m, P, h_desc, nPairs)) return 1;
   const int k = wide_parts_k(P, nPairs, cus);
   if (k < 2) return 1;
   WidePartSet *ps = wide_parts_get(m, P, k);
@@ -2228,7 +2243,7 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   // the device
   const int scratchSlot = P.backward ? 12 : 11;
   g_last_parts = 1;
-  if (P.retOk && h_desc) {
+  if (P.retOk && h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
     if (ps) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, pool, loglike, st, lastOnly, false);
@@ -2302,7 +2317,7 @@ int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, lo
   if (!P.ok || !P.retOk || !P.tbOk || !P.viterbi || P.backward) { set_error("one-tape traceback-code program not built"); return 1; }
   if (nPairs <= 0) return 0;
   g_last_parts = 1;
-  if (h_desc) {
+  if (h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
     if (ps) { P.tbFromSet = (int)(ps - P.partSets.data()); return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true); }

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 os.environ["MB_WIDE_MIN_STATES"] = "1"
 os.environ["MB_ONETAPE_TRACEBACK_MIN_TRANS"] = "0"
+os.environ["MB_ONETAPE_PARTS_MIN_LEN"] = "0"
 os.environ.setdefault("MB_ONETAPE_PART_TIMEOUT_S", "10")
 from machineboss_amd import capi
 from oracle import oracle

@@ -1522,6 +1522,7 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     pairs = [(x, y) for y in ys]
     monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
     monkeypatch.setenv("MB_ONETAPE_TRACEBACK_MIN_TRANS", "0")
+    monkeypatch.setenv("MB_ONETAPE_PARTS_MIN_LEN", "0")      # (by default a machine is cut for sweeps of thousands of columns only: the planning costs 0.5-1 s)
     def run(dm):
         b = capi.DeviceBatch.from_pairs(dm, pairs)
         out = {"names": []}
@@ -1585,6 +1586,7 @@ def test_one_tape_parts_fail_the_call_when_a_value_never_arrives(capi, monkeypat
     m, em = _profile_machine(3)
     x = np.zeros(0, np.int32)
     ys = [np.random.RandomState(3 + n).randint(1, em.nOutTok + 1, size=n).astype(np.int32) for n in (80, 120)]
+    monkeypatch.setenv("MB_ONETAPE_PARTS_MIN_LEN", "0")
     dm = capi.DeviceMachine(em)
     b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
     good = b.viterbi(paths=False)[0]
