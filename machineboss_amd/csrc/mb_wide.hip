@@ -2115,12 +2115,12 @@ static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for a
 
 // k for a launch of nPairs sequences that may count on `cus` CUs: as many parts as fit, at most MB_ONETAPE_PARTS (0 or 1: off).
 // Measured.  A machine whose ring fits the LDS of ONE CU (5 063 states): a part's period is bound by its chain of stages,
-// not by its width -- 4 parts of 512 lanes are the best cut for every mode (+5...12 %), 8 and 16 parts no better, two parts (of 1 024
-// lanes) pay for the sum sweeps only: default at most 4.  A machine whose ring lives in L2 (21 761 states): the parts bring it into
-// LDS -- 16 sequences: Viterbi fill 160 -> 17 ms with 16 parts, log-likelihoods 79 -> 12.5 ms with 8 -- default at most 16.
+// not by its width -- with two-transition candidates 4 parts serve 64 sequences, 8 parts are 10 % faster than 4 for 8 sequences (Viterbi
+// 25 vs 27.6 ms), 16 no better, two parts pay for the sum sweeps only: default at most 8.  A machine whose ring lives in L2 (21 761
+// states): the parts bring it into LDS -- 16 sequences: Viterbi fill 160 -> 17 ms with 16 parts -- default at most 16.
 static int wide_parts_k(const WideProgram &P, long long nPairs, int cus) {
   if (!P.retOk || nPairs <= 0 || cus <= 0) return 1;
-  const int maxK = env_int_w("MB_ONETAPE_PARTS", P.retGv ? 16 : 4);
+  const int maxK = env_int_w("MB_ONETAPE_PARTS", P.retGv ? 16 : 8);
   const long long k = std::min<long long>(maxK, cus / nPairs);
   if (k < 2 || (k == 2 && P.viterbi && !P.retGv && !getenv("MB_ONETAPE_PARTS"))) return 1;
   return (int)k;
@@ -2216,6 +2216,15 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   return 0;
 }
 
+// the exchange buffer of a launch (8 bytes x exports per column) must leave the device room for the matrices: at most a quarter of its memory
+static bool wide_parts_fit(const mb_machine *m, const WidePartSet &ps, const PairDesc *h_desc, long long nPairs) {
+  long long rows = 0;
+  for (long long p = 0; p < nPairs; ++p) rows += (long long)(m->nOut ? h_desc[p].outLen : h_desc[p].inLen) + 1;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return (double)rows * (double)ps.nExpTot * 8.0 <= 0.25 * (double)totalB;
+}
+
 // Cutting a machine and planning its parts costs 0.5-1 s the first time (20-40 ms after a weight update): worth it for sweeps of
 // thousands of columns -- from MB_ONETAPE_PARTS_MIN_LEN (4 096; 64 for a machine whose one-workgroup ring lives in L2, where the
 // parts are 5-17 x faster) symbols in the longest sequence of the launch
@@ -2230,6 +2239,7 @@ int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cu
   const int k = wide_parts_k(P, nPairs, cus);
   if (k < 2) return 1;
   WidePartSet *ps = wide_parts_get(m, P, k);
+  if (ps && h_desc && !wide_parts_fit(m, *ps, h_desc, nPairs)) return 1;
   return ps ? ps->k : 1;
 }
 
@@ -2246,7 +2256,7 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   if (P.retOk && h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
-    if (ps) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, pool, loglike, st, lastOnly, false);
+    if (ps && wide_parts_fit(m, *ps, h_desc, nPairs)) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, pool, loglike, st, lastOnly, false);
   }
   if (P.retOk) {
     static bool attr = false;
@@ -2320,7 +2330,7 @@ int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, lo
   if (h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
-    if (ps) { P.tbFromSet = (int)(ps - P.partSets.data()); return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true); }
+    if (ps && wide_parts_fit(m, *ps, h_desc, nPairs)) { P.tbFromSet = (int)(ps - P.partSets.data()); return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true); }
   }
   P.tbFromSet = -1;
   static bool attr = false;
