@@ -1107,12 +1107,22 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
     else if (split) {
       WideProgram *WB = wide_program(m, MB_BACKWARD);
       const long long n = b->nPairs, S = m->S;
-      std::vector<PairDesc> pre(b->pairs), suf(b->pairs);
-      for (long long p = 0; p < n; ++p) {
-        const int L = m->nOut ? b->pairs[p].outLen : b->pairs[p].inLen, mid = L / 2;
-        pre[p].cellBase = suf[p].cellBase = p * S;
-        if (m->nOut) { pre[p].outLen = mid; suf[p].outBase += mid + 1; suf[p].outLen = L - mid - 1; }
-        else { pre[p].inLen = mid; suf[p].inBase += mid + 1; suf[p].inLen = L - mid - 1; }
+      std::vector<PairDesc> pre, suf;
+      auto cutAt = [&](double frac) {
+        pre = b->pairs; suf = b->pairs;
+        for (long long p = 0; p < n; ++p) {
+          const int L = m->nOut ? b->pairs[p].outLen : b->pairs[p].inLen, mid = std::min(L - 1, std::max(0, (int)(L * frac)));
+          pre[p].cellBase = suf[p].cellBase = p * S;
+          if (m->nOut) { pre[p].outLen = mid; suf[p].outBase += mid + 1; suf[p].outLen = L - mid - 1; }
+          else { pre[p].inLen = mid; suf[p].inBase += mid + 1; suf[p].inLen = L - mid - 1; }
+        }
+      };
+      cutAt(0.5);
+      // k workgroups per sequence: the two programs' parts are not equally fast (the Backward program of the 5 063-state machine takes 136 ms
+      // where the Forward one takes 120): the cut goes where both halves end together under the planner's model
+      if (WB) {
+        const double cF = wide_parts_cost(m, *W, n, device_cus() / 2, pre.data()), cB = wide_parts_cost(m, *WB, n, device_cus() / 2, suf.data());
+        if (cF > 0.0 && cB > 0.0 && env_int("MB_ONETAPE_SPLIT_BALANCE", 1)) cutAt(std::min(0.65, std::max(0.35, cB / (cF + cB))));
       }
       PairDesc *d_pre = nullptr, *d_suf = nullptr;
       double *vec = nullptr;
@@ -1142,7 +1152,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
           if ((rc = wide_fill(m, *WB, d_suf, n, tape, vec + n * S, nullptr, g_stream, true, parts ? suf.data() : nullptr, device_cus() / share))) break;
           if (hipEventRecord(evDone, s2) != hipSuccess || hipStreamWaitEvent(g_stream, evDone, 0) != hipSuccess) { set_error("one-tape split: stream synchronisation failed"); rc = 1; break; }
         }
-        if ((rc = wide_join(m, b->d_pairs, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
+        if ((rc = wide_join(m, d_pre, n, tape, vec, vec + n * S, d_ll, g_stream))) break;
         { static thread_local std::string nm; nm = std::string(wide_kernel_name(*W)) + " x2 + k_onetape_join"; g_last_kernel = nm.c_str(); }
         g_last_ms += tm.stop();
         if (!hip_ok(hipStreamSynchronize(g_stream), "one-tape forward kernels")) rc = 1;

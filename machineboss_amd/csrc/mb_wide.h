@@ -154,6 +154,7 @@ struct WidePartSet {
   bool ok = false;
   int kWanted = 0, lanesAsked = 0, ringAsked = 0;      // what was asked for (0: the builder's choice)
   int k = 0, W = 0, nExpTot = 0, ring = WIDE_RING;
+  double modelCost = 0.0;                    // modelled ms per 10 000 columns of the slowest part (wide_parts_host's model)
   bool merge = false;                        // the parts carry two-transition candidates (kernel variant with the second weights' stream)
   size_t ldsBytes = 0;                       // largest part (with the fp64 correction term's table)
   std::vector<WideRec *> d_rec;
@@ -230,7 +231,7 @@ void wide_set_accurate(bool on);      // the next retimed sum fills carry their 
 bool wide_ret_host(const mb_machine *m, bool backward, bool viterbi, WideProgram &P, std::vector<WideRec> &stream, bool tbCodes = false);
 // ... and its k-part form: the record stream, geometry and tables of every part (a part's `h` holds HOST pointers into tabs[part]:
 // gmap [Sloc], then impIdx [nImp]); false when the machine's graph has no cut
-struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0, periodMin = 0; size_t ldsBytes = 0; };
+struct WidePartHost { WidePartDev h; std::vector<WideRec> stream; std::vector<uint32_t> tab; int period = 0, periodMin = 0; size_t ldsBytes = 0; double modelCost = 0.0; };
 // W = 0: the lanes per part (and the ring depth) are searched; hint: the choice of an earlier build of the same cut (in / out)
 bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCodes, int k, int W, std::vector<WidePartHost> &parts, int &nExpTot,
                      std::vector<int> *tbOff = nullptr, std::vector<uint32_t> *tbEntry = nullptr, WidePartHint *hint = nullptr, int *Wout = nullptr, int *ringOut = nullptr);
@@ -242,6 +243,7 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
               double *loglike, hipStream_t st, bool lastOnly = false, const PairDesc *h_desc = nullptr, int cus = 0);
 int wide_last_parts();      // k of the last launch of this family (1: one workgroup per sequence)
 int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc = nullptr);      // k such a launch would use (builds the parts); h_desc: the launch's sequences (short ones are not worth a cut)
+double wide_parts_cost(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc = nullptr);      // modelled time per column of that cut (0: none)
 bool wide_parts_failed();   // after the streams were synchronised: a bounded wait ran out (error set, flag cleared)
 const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
 // ViterbiMatrix::fill keeping one traceback code per cell (P.tbOk): tb = bytes, wide_tb_stride(S) per column, PairDesc::cellBase =
@@ -258,7 +260,7 @@ int wide_traceback_codes(const mb_machine *m, const WideProgram &P, const PairDe
 // (nothing launched) when the two programs do not share a kernel variant.
 int wide_fill2(const mb_machine *m, WideProgram &A, WideProgram &B, const PairDesc *d_descA, const PairDesc *d_descB, long long nA, long long nB,
                const int *d_tape, double *poolA, double *poolB, hipStream_t st, bool lastOnly);
-// log-likelihood of a sequence cut at position `mid` = inLen or outLen / 2: Forward column of the prefix x emitting transitions
+// log-likelihood of a sequence cut behind its prefix (d_pairs: the PREFIXES' descriptors): Forward column of the prefix x emitting transitions
 // labelled with the token at the cut x Backward column of the suffix behind it (every path crosses the cut exactly once)
 int wide_join(const mb_machine *m, const PairDesc *d_pairs, long long nPairs, const int *d_tape, const double *fvec, const double *bvec,
               double *loglike, hipStream_t st);

@@ -1822,6 +1822,9 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
   // under a model fitted on the 5 063-state machine cut in four (ms per 10 000 periods: 2.84 per round + 1.45 per slot of the padded
   // period, x 1 + 0.44 per eight wavefronts beyond eight; a ring of 4 saves padding and costs 2 %).  The two-transition candidates of
   // a part are chosen at the first candidate and kept.  A hint (the choice of an earlier build of the same cut) skips the search.
+  // (a round of a sum program -- two butterflies, an exponential per lane, a logarithm -- is about twice a max program's: 110 against 60
+  //  instructions; fitted on nothing but the Forward / Backward halves of the 5 063-state machine, 120 and 136 ms for 5 and 6 rounds)
+  const double cRoundM = viterbi ? 2.84 : 5.7;
   struct Cand { int first, second; bool merge; };
   std::vector<Cand> cand;
   if (hint && hint->valid) cand.push_back({hint->W, hint->ring, hint->merge});
@@ -1862,7 +1865,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
         WideProgram T;
         ok = buildPart(p, c.first, c.second, c.merge, T, nullptr);
         if (ok) {
-          worst = std::max(worst, (2.84 * (double)T.rounds.size() + 1.45 * (double)T.ret.nSlots) * (1.0 + 0.44 * std::max(0, c.first / 64 - 8) / 8.0) * (c.second == 4 ? 1.02 : 1.0));
+          worst = std::max(worst, (cRoundM * (double)T.rounds.size() + 1.45 * (double)T.ret.nSlots) * (1.0 + 0.44 * std::max(0, c.first / 64 - 8) / 8.0) * (c.second == 4 ? 1.02 : 1.0));
           maxPeriod = std::max(maxPeriod, T.retPeriod);
         }
       }
@@ -1902,6 +1905,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
     for (int v : own) H.tab.push_back((uint32_t)v);
     for (int y : imps) H.tab.push_back((uint32_t)expIdx[y]);
     H.period = T.retPeriod; H.periodMin = T.retPeriodMin;
+    H.modelCost = (cRoundM * (double)T.rounds.size() + 1.45 * (double)T.ret.nSlots) * (1.0 + 0.44 * std::max(0, bestW / 64 - 8) / 8.0);
     H.ldsBytes = ((T.retLdsBytes + 7) & ~(size_t)7) + 512 + 4 * (size_t)spec.nOwn;
     if (verbose)
       fprintf(stderr, "[mbhip] wide retimed part %d of %d: %d states, %d imports, %d exports, %d lanes, period %d, %zu rounds, %d slots per period, %d columns in flight, ring %d x %d, LDS %zu bytes\n",
@@ -2157,6 +2161,7 @@ static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
     ps.h_parts[p] = d;
     ps.ldsBytes = std::max(ps.ldsBytes, hp[p].ldsBytes);
     ps.period.push_back(hp[p].period); ps.slots.push_back(d.ret.nSlots);
+    ps.modelCost = std::max(ps.modelCost, hp[p].modelCost);
   }
   if (!up_w(ps.d_parts, ps.h_parts)) return nullptr;
   if (!g_part_err) {
@@ -2232,6 +2237,15 @@ static bool wide_parts_worth(const mb_machine *m, const WideProgram &P, const Pa
   const int minLen = env_int_w("MB_ONETAPE_PARTS_MIN_LEN", P.retGv ? 64 : 4096);
   for (long long p = 0; p < nPairs; ++p) if ((m->nOut ? h_desc[p].outLen : h_desc[p].inLen) >= minLen) return true;
   return false;
+}
+
+// modelled time per column of the cut such a launch would use (its slowest part; 0: no cut) -- what a sequence cut in two is divided by
+double wide_parts_cost(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc) {
+  if (h_desc && !wide_parts_worth(m, P, h_desc, nPairs)) return 0.0;
+  const int k = wide_parts_k(P, nPairs, cus);
+  if (k < 2) return 0.0;
+  WidePartSet *ps = wide_parts_get(m, P, k);
+  return ps ? ps->modelCost : 0.0;
 }
 
 int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc) {
@@ -2546,7 +2560,7 @@ __global__ __launch_bounds__(256) void k_onetape_join(DevMachine m, const PairDe
   __shared__ double red[256];
   const long long p = blockIdx.x;
   const PairDesc pd = pairs[p];
-  const int L = inputTape ? pd.inLen : pd.outLen, S = m.S, mid = L / 2;
+  const int S = m.S, mid = inputTape ? pd.inLen : pd.outLen;      // (pairs: the PREFIXES' descriptors -- the cut sits behind a prefix's last symbol)
   const int y = tape[(inputTape ? pd.inBase : pd.outBase) + mid];   // (the key of a one-tape label is the token itself)
   const double *F = fvec + p * (long long)S, *B = bvec + p * (long long)S;
   double mx = -INFINITY;
