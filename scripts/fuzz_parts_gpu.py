@@ -2,7 +2,7 @@
 forced into the one-tape family at any size, random k / lanes per part / sharing of CUs, ragged batches -- against the oracle: Viterbi
 matrix of one sequence and every score and path bit for bit (paths through traceback codes and through the fp64 matrix), Forward / Backward
 matrices, rolling log-likelihoods (cut in two) and counts within the fast-path tolerance; and against the one-workgroup sweep.
-usage: python scripts/fuzz_parts_gpu.py [cases=100] [seed0=11000]"""
+usage: python scripts/fuzz_parts_gpu.py [cases=100] [seed0=11000] [big]"""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -25,7 +25,8 @@ def close(a, b, rel=REL, abs_=ABS):
 bad = 0; ran = 0; with_parts = 0; t0 = time.time()
 for c in range(n):
     rng = np.random.RandomState(seed0 + c)
-    blocks, per = int(rng.choice([2, 3, 5, 8, 12, 20])), int(rng.choice([3, 6, 12, 25]))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"      # machines of up to 2 400 states (relays, several slots per round)
+    blocks, per = (int(rng.choice([12, 20, 40])), int(rng.choice([25, 40, 60]))) if big else (int(rng.choice([2, 3, 5, 8, 12, 20])), int(rng.choice([3, 6, 12, 25])))
     gen = bool(c % 3)
     nt = int(rng.randint(1, 5))
     em = random_block_machine(blocks, per, 0 if gen else nt, nt if gen else 0, seed0 + c, density=float(rng.uniform(0.8, 3.0)),
