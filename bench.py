@@ -639,7 +639,7 @@ def main():
         extra["expected_scaling"] = {
             "config 2-4 (batches of pairs, this line)": "weak scaling 1.0 per GPU by construction: every rank fills its own pairs, no data-path collective; strong scaling of 256 pairs over 8 GPUs leaves 32 pairs per GPU, whose tile wavefront still fills 256 CUs (672 live tiles per launch)",
             "config 3 (--train)": "one all-reduce of nTransitions + 1 doubles (3.6 KB) per EM iteration: latency only",
-            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling ~1.0-1.2x for the 5 063-state machine: a one-tape lattice is serial along its columns, a sequence is k <= 4 workgroups (DESIGN.md 4.2d: the period is bound by its chain of stages, more workgroups per sequence do not shorten it), so 8 sequences per GPU take almost as long as 64 on one GPU (extra.config5.eight_per_gpu of the N = 1 line measures it); only a batch of more sequences than CUs scales.  The whole fn3 profile (21 761 states, ring beyond one CU's LDS) does scale with workgroups per sequence: 64 -> 16 -> 4 sequences x 3 kb take 30 -> 17 -> 16 ms (Viterbi fill)"}
+            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling 1.1-1.3x for the 5 063-state machine (measured on one GPU, extra.config5.eight_per_gpu of the N = 1 line: 64 sequences against 8): a one-tape lattice is serial along its columns, a sequence is k <= 8 workgroups and its period a latency chain of 5 stages (DESIGN.md 4.2d), so 8 sequences per GPU take almost as long as 64 on one GPU; only a batch of more sequences than CUs scales.  The whole fn3 profile (21 761 states, ring beyond one CU's LDS) does scale with workgroups per sequence: 64 -> 16 -> 4 sequences x 3 kb take 30 -> 18 -> 15 ms (Viterbi fill)"}
     if grp and not args.no_extra:
         # the ONE collective of the path (--train): E-step on this rank's shard of config 3, then the all-reduce of
         # nTransitions + 1 doubles over RCCL (xGMI)
