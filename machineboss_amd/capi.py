@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmbhip.so")
+LIB_PATH = os.environ.get("MBHIP_LIBRARY") or os.path.join(HERE, "libmbhip.so")      # (MBHIP_LIBRARY: another build of the same library, e.g. the sanitizer build of scripts/asan_planner.sh)
 
 MB_FORWARD, MB_VITERBI, MB_BACKWARD = 0, 1, 2
 MB_MATERIALISE, MB_ROLLING = 0, 1

@@ -19,11 +19,11 @@ RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 [ -f "$RT" ] || RT=$(find /opt/rocm/lib/llvm/lib/clang -name 'libclang_rt.asan*x86_64*.so' | head -1)
 echo "sanitizer runtime: $RT; instrumented symbols in the library: $(nm -D $T/libmbhip_asan.so | grep -c __asan_)"
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1
-MB_LIB_PATH=$T/libmbhip_asan.so LD_PRELOAD=$RT python3 - > $T/run.out 2> $T/run.err <<'PY'
+MBHIP_LIBRARY=$T/libmbhip_asan.so LD_PRELOAD=$RT python3 - > $T/run.out 2> $T/run.err <<'PY'
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from machineboss_amd import capi
-capi.LIB_PATH = os.environ["MB_LIB_PATH"]      # (before the first call loads the library)
+assert "asan" in capi.LIB_PATH
 from machineboss_amd.machine import Machine
 from machineboss_amd.evalmachine import EvaluatedMachine
 from machineboss_amd.hmmer import HmmerModel
@@ -53,5 +53,7 @@ for name in ("psw2dna", "dnapsw", "protpsw"):
 print("planner calls under the sanitizers:", n)
 PY
 echo "rc $?  $(tail -1 $T/run.out)  sanitizer reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' $T/run.err)"
+# (On a GPU box the same build cannot run real calls: ROCm's AddressSanitizer runtime intercepts hsa_amd_memory_pool_allocate and needs XNACK,
+#  which this pool does not offer -- the launch side is covered by the GPU tests and fuzzers with the product build.)
 grep -h -A8 'ERROR: AddressSanitizer\|runtime error' $T/run.err | head -40
 tail -3 $T/run.err | cut -c1-300
