@@ -1579,6 +1579,26 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     dm1.close(); dmk.close()
 
 
+def test_one_tape_machines_are_cut_for_long_sweeps_only(capi, monkeypatch):
+    """Cutting a machine and planning its parts costs 0.5-1 s: by default only a launch whose longest sequence has >= 4 096 symbols runs k
+    workgroups per sequence (MB_ONETAPE_PARTS_MIN_LEN), and MB_ONETAPE_PARTS=1 turns the cut off; the results agree either way."""
+    m, em = _profile_machine(3)
+    x = np.zeros(0, np.int32)
+    rng = np.random.RandomState(17)
+    short = [(x, rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32)) for n in (300, 120)]
+    long_ = [(x, rng.randint(1, em.nOutTok + 1, size=n).astype(np.int32)) for n in (4500, 120)]
+    dm = capi.DeviceMachine(em)
+    bs, bl = capi.DeviceBatch.from_pairs(dm, short), capi.DeviceBatch.from_pairs(dm, long_)
+    vs = bs.viterbi(paths=False)[0]; assert " parts" not in capi.last_kernel_name()
+    vl = bl.viterbi(paths=False)[0]; assert " parts" in capi.last_kernel_name()
+    monkeypatch.setenv("MB_ONETAPE_PARTS", "1")
+    assert np.array_equal(bl.viterbi(paths=False)[0], vl) and " parts" not in capi.last_kernel_name()
+    monkeypatch.delenv("MB_ONETAPE_PARTS")
+    monkeypatch.setenv("MB_ONETAPE_PARTS_MIN_LEN", "100")
+    assert np.array_equal(bs.viterbi(paths=False)[0], vs) and " parts" in capi.last_kernel_name()
+    dm.close()
+
+
 def test_one_tape_parts_fail_the_call_when_a_value_never_arrives(capi, monkeypatch):
     """The exchange between the parts of a sequence has no way to hang: a lane waits a bounded time for another part's value, then raises
     the launch's status word, every other waiter stops, the kernel drains and the host FAILS the call.  Provoked with the test hook that
