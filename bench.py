@@ -421,14 +421,16 @@ def extra_single_gpu(capi, np, hbm_peak):
         # only parallelism left is inside a column: k workgroups per sequence, against one workgroup per sequence
         b5e = capi.DeviceBatch(dm5, *synth_batch(5, 8, 0, 50000, em5.nInTok, em5.nOutTok))
         eight = {"workload": "the same machine, 8 sequences x 50000 nt (one GPU's share of config 5 split over 8 GPUs)"}
-        for label, env in (("k_workgroups_per_sequence", None), ("one_workgroup_per_sequence", "1")):
+        parts_env = os.environ.get("MB_ONETAPE_PARTS")      # (restored below: a run under a knob keeps it for the other extras)
+        for label, env in (("k_workgroups_per_sequence", parts_env), ("one_workgroup_per_sequence", "1")):
             if env is None: os.environ.pop("MB_ONETAPE_PARTS", None)
             else: os.environ["MB_ONETAPE_PARTS"] = env
             _, te = timed(lambda: b5e.forward(capi.MB_ROLLING), 1); ke = capi.last_kernel_name()
             _, tve = timed(lambda: b5e.viterbi(paths=False), 1); kve = capi.last_kernel_name()
             _, tpe = timed(lambda: b5e.viterbi(), 1)
             eight[label] = {"forward_ms": round(te * 1e3, 1), "viterbi_ms": round(tve * 1e3, 1), "viterbi_with_paths_ms": round(tpe * 1e3, 1), "kernels": [ke, kve]}
-        os.environ.pop("MB_ONETAPE_PARTS", None)
+        if parts_env is None: os.environ.pop("MB_ONETAPE_PARTS", None)
+        else: os.environ["MB_ONETAPE_PARTS"] = parts_env
         fs = out["config5"]["full_size"]
         eight["strong_scaling_ceiling_over_8_gpus"] = {k: round(fs[k] / eight["k_workgroups_per_sequence"][k], 2) for k in ("forward_ms", "viterbi_ms", "viterbi_with_paths_ms")}
         eight["note"] = "ceiling = time of 64 sequences on one GPU / time of 8 sequences on one GPU (no communication: the shards are independent)"
