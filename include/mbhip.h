@@ -88,6 +88,11 @@ mb_batch *mb_batch_create(mb_machine *m, int64_t nPairs, const int32_t *inTok, c
                           const int32_t *outTok, const int64_t *outOff);
 void mb_batch_destroy(mb_batch *b);
 int64_t mb_batch_cells(const mb_batch *b); /* sum over pairs of (inLen+1)(outLen+1)nStates */
+/* ONE-TAPE machines (generators / recognisers of >= 256 states), every call below: a batch of fewer sequences than the device has CUs,
+ * whose longest sequence has >= MB_ONETAPE_PARTS_MIN_LEN (4 096) symbols, is swept with k workgroups per sequence (the machine cut along
+ * its strongly connected components).  Viterbi matrices, scores and paths are the same bits as with one workgroup; sums
+ * move in the last digits.  A workgroup waits for another part's value at most MB_ONETAPE_PART_TIMEOUT_S (20) seconds: past that the
+ * CALL FAILS (non-zero return, mb_last_error names the wait) -- it neither hangs nor returns partial results.  MB_ONETAPE_PARTS=1: off. */
 /* Envelopes of the pairs (Envelope::inStart / inEnd, src/seqpair.h:75-97): pair p owns rows envOff[p]..envOff[p+1] of
  * inStart[] / inEnd[] -- either outLen+1 rows (cell (x,y) exists <=> inStart[y] <= x < inEnd[y]) or none (full).
  * Rejected like DPMatrix::alloc does (src/dpmatrix.defs.h:31-32): "Envelope/sequence mismatch", "Envelope is not
