@@ -37,12 +37,12 @@ if "full_size" in c5:
     fs = c5["full_size"]
     if "viterbi_with_paths" in fs:
         row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill / with paths (traceback codes)", "one-tape", "%s / %s / %s" % (fs["forward_rolling"], fs["viterbi_fill"], fs["viterbi_with_paths"]), "G cells/s", None,
-            "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
+            "a latency chain of 5 stages per column, k workgroups per sequence on all 256 CUs", "see 4.2d", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
     else:
-        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "vector issue on 128 / 64 of 256 CUs", "see 4.2c", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
+        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "a latency chain of 5 stages per column, k workgroups per sequence on all 256 CUs", "see 4.2d", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
     if "counts_lattice" in fs:
-        row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "vector issue on 128 of 256 CUs", "--", "%.0f ms" % fs["counts_ms"])
-    row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
+        row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "the two fills side by side, 2-4 workgroups per sequence each (4.2d)", "--", "%.0f ms" % fs["counts_ms"])
+    row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "one workgroup per sequence (sweeps below 4 096 columns are not cut): vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
 dr = e.get("dropin", {})
 for key, name in (("config4", "4a through the reference's call sites (8 pairs)"), ("config2", "2 through the reference's call sites (1024 pairs)")):
     d = dr.get(key) or {}
