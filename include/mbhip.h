@@ -178,6 +178,11 @@ int mb_set_kernel(int which);
 int mb_set_memory_budget(size_t bytes);
 /* The library keeps its matrix pools allocated between calls (grow-only); this frees them. */
 int mb_release_workspace(void);
+/* What the matrix pools cost this process so far: device allocations and releases of pool slots, slots evicted to make room,
+ * bytes allocated in all, and the wall-clock milliseconds spent inside hipMalloc / hipFree for them.  Steady-state calls do none
+ * (the pools are grow-only and the budget that sizes chunks is sticky); a caller that sees these move between two like calls is
+ * paying seconds per call for memory, not for kernels.  Any pointer may be NULL. */
+int mb_alloc_stats(int64_t *poolAllocs, int64_t *poolFrees, int64_t *evictions, uint64_t *bytesAllocated, double *ms);
 /* Run-time compilation (hiprtc) done by this process so far: wall-clock milliseconds, compiles, and code objects taken
  * from the on-disk cache instead ($MB_JIT_CACHE_DIR, default ~/.cache/mbhip; MB_JIT_CACHE=0 disables it). */
 int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits);
@@ -235,6 +240,12 @@ int mb_debug_wide_retimed(int32_t nStates, int32_t nInTok, int32_t nOutTok, int6
 int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
                         const uint32_t *dst, const uint16_t *inTok, const uint16_t *outTok, const double *logWeight,
                         int mode, int backward, int k, int lanes, const char *path);
+/* The one-tape sweep GENERATED for this machine (run-time specialised retimed kernel), rendered on the host only: HIP source to `path`,
+ * the unrolled program (rounds, slots, per-lane constant table) to `path`.prog for a device-free replay; k >= 2: the machine cut for k
+ * workgroups per sequence, k <= 1: the one-workgroup program; mode: MB_FORWARD / MB_VITERBI (+ 16: traceback codes, + 64: fp64 correction
+ * term); compile != 0: also compiled with hiprtc (fails when the kernel would spill to scratch memory). */
+int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                      const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int k, int lanes, int compile, const char *path);
 
 #ifdef __cplusplus
 }

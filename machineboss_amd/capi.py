@@ -25,7 +25,7 @@ EXPORTS = [
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
     "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source", "mb_debug_wide_retimed", "mb_debug_wide_parts",
-    "mb_jit_stats", "mb_machine_sweep_ops", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
+    "mb_jit_stats", "mb_alloc_stats", "mb_machine_sweep_ops", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
 ]
@@ -90,6 +90,7 @@ def load():
     L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
     L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
     L.mb_jit_stats.argtypes = [dp, i64p, i64p]
+    L.mb_alloc_stats.argtypes = [i64p, i64p, i64p, C.POINTER(C.c_uint64), dp]
     L.mb_machine_sweep_ops.argtypes = [C.c_void_p, dp, dp, C.POINTER(C.c_char_p)]
     L.mb_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.mb_get_option.argtypes = [C.c_char_p]; L.mb_get_option.restype = C.c_char_p
@@ -135,6 +136,13 @@ def jit_stats() -> dict:
     ms = C.c_double(0.0); n = C.c_int64(0); h = C.c_int64(0)
     _check(load().mb_jit_stats(C.byref(ms), C.byref(n), C.byref(h)))
     return {"compile_ms": round(ms.value, 1), "compiles": n.value, "cache_hits": h.value}
+
+
+def alloc_stats() -> dict:
+    """Device allocations the matrix pools cost this process so far (steady-state calls do none)."""
+    a = C.c_int64(0); f = C.c_int64(0); e = C.c_int64(0); b = C.c_uint64(0); ms = C.c_double(0.0)
+    _check(load().mb_alloc_stats(C.byref(a), C.byref(f), C.byref(e), C.byref(b), C.byref(ms)))
+    return {"pool_allocs": a.value, "pool_frees": f.value, "evictions": e.value, "bytes_allocated": b.value, "ms": round(ms.value, 2)}
 
 
 def sweep_ops(dm) -> dict:

@@ -15,6 +15,7 @@
 #include "mb_medium.h"
 #include "mb_small.h"
 #include "mb_wide.h"
+#include "mb_wide_jit.h"
 
 namespace mb {
 
@@ -80,33 +81,70 @@ static size_t cached_bytes() { size_t t = 0; for (const Workspace &w : g_ws) t +
 // unpinned one (a Viterbi batch that needs 80 % of HBM in slot 0 must be able to reclaim the Backward pool a previous
 // count sweep left in slot 1 -- budget_bytes() counts cached bytes as available).
 static void ws_begin_call() { for (Workspace &w : g_ws) w.pinned = false; }   // (declared above, next to ApiGuard)
+// what the pools cost this process so far (mb_alloc_stats): a 200 GB hipMalloc / hipFree pair takes SECONDS, so a caller -- and the
+// tests -- must be able to see that steady-state calls do none
+struct AllocStats { long long allocs = 0, frees = 0, evictions = 0; unsigned long long bytes = 0; double ms = 0.0; };
+static AllocStats g_alloc;
+static void ws_free_slot(Workspace &w) {
+  if (!w.p) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  (void)hipFree(w.p);
+  g_alloc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ++g_alloc.frees;
+  w.p = nullptr; w.bytes = 0;
+}
 static void ws_release_unpinned(int except) {
   for (int k = 0; k < WS_SLOTS; ++k) {
     Workspace &w = g_ws[k];
     if (k == except || w.pinned || !w.p) continue;
-    (void)hipFree(w.p); w.p = nullptr; w.bytes = 0;
+    ws_free_slot(w); ++g_alloc.evictions;
   }
 }
+
+size_t ws_bytes(int slot) { return g_ws[slot].p ? g_ws[slot].bytes : 0; }
 
 void *ws_get(int slot, size_t bytes) {
   Workspace &w = g_ws[slot];
   w.pinned = true;
   if (w.bytes >= bytes && w.p) return w.p;
-  if (w.p) { (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+  ws_free_slot(w);
   const size_t want = std::max<size_t>(bytes, 256);
   size_t freeB = 0, totalB = 0;
   // an explicit budget (mb_set_memory_budget) bounds everything the library keeps; otherwise only a shortage evicts
   const bool over = g_mem_budget && cached_bytes() + want > g_mem_budget;
   if (over || (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < want + ((size_t)256 << 20))) ws_release_unpinned(slot);
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&w.p, want);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     ws_release_unpinned(slot);
     e = hipMalloc(&w.p, want);
   }
+  g_alloc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!hip_ok(e, "hipMalloc(workspace)")) { w.p = nullptr; return nullptr; }
+  ++g_alloc.allocs; g_alloc.bytes += want;
   w.bytes = want;
   return w.p;
+}
+
+// Before a call takes SEVERAL large slots: a grow-only slot that an earlier call left far larger than this call needs (the 230 GB
+// pipeline pool of a materialised Forward, then an E-step that wants 2 x 115 GB) would starve the other slot -- ws_get hands the big
+// one out as it is, pins it, and the second request finds no memory.  When the growth the listed requests need does not fit beside
+// what is allocated, the listed slots that are larger than their request are released first (one re-allocation, not a failure).
+void ws_plan(int n, const int *slots, const size_t *bytes) {
+  size_t growth = 0, reclaim = 0;
+  for (int k = 0; k < n; ++k) {
+    const Workspace &w = g_ws[slots[k]];
+    if (!w.p || w.bytes < bytes[k]) { growth += std::max<size_t>(bytes[k], 256); reclaim += w.p ? w.bytes : 0; }
+  }
+  if (!growth) return;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (freeB + reclaim >= growth + ((size_t)256 << 20)) return;
+  for (int k = 0; k < n; ++k) {
+    Workspace &w = g_ws[slots[k]];
+    if (w.p && !w.pinned && w.bytes > bytes[k]) { ws_free_slot(w); ++g_alloc.evictions; }
+  }
 }
 
 // Small per-call device buffers (pair descriptors, log-likelihoods, offsets): a hipMalloc / hipFree pair per call is
@@ -190,17 +228,34 @@ int h2d_large(void *dstDev, const void *src, size_t bytes) {
 }
 
 static void ws_release() {
-  for (Workspace &w : g_ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+  for (Workspace &w : g_ws) ws_free_slot(w);
   for (SmallBlock &b : g_smallFree) (void)hipFree(b.p);
   g_smallFree.clear();
   for (int k = 0; k < 2; ++k) if (g_pinned[k]) { (void)hipHostFree(g_pinned[k]); g_pinned[k] = nullptr; }
+}
+
+static int env_flag_default(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
 }
 
 size_t budget_bytes() {
   if (g_mem_budget) return g_mem_budget;
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return (size_t)8 << 30;
-  return (size_t)((double)(freeB + cached_bytes()) * 0.80);
+  // STICKY: what is free + cached moves by megabytes from call to call (a batch's tokens, a machine's record tables, a small block
+  // released), chunk sizes and the pipeline's pool follow the budget, and ws_get re-allocates a pool for a request that grew by ANY
+  // amount -- a 230 GB hipFree + hipMalloc pair is seconds (round 5: 7.1 s of wall around 75 ms of kernels in every call that
+  // alternated with the one-tape sweeps).  So the budget only ever follows the memory DOWN, or up by more than an eighth.
+  // MB_MEM_FRACTION (default 0.80): the share of the device this process may fill -- several ranks on ONE device (the gloo dry runs of
+  // bench.py / boss.py, or a host that co-locates processes) must not each claim 80 % of it
+  static size_t sticky = 0;
+  static double stickyFrac = 0.0;
+  double frac = 0.80;
+  if (const char *e = getenv("MB_MEM_FRACTION")) { const double f = atof(e); if (f > 0.0 && f <= 0.95) frac = f; }
+  const size_t cur = (size_t)((double)(freeB + cached_bytes()) * frac);
+  if (!sticky || frac != stickyFrac || cur < sticky || cur > sticky + sticky / 8 || !env_flag_default("MB_POOL_STICKY", 1)) { sticky = cur; stickyFrac = frac; }
+  return sticky;
 }
 
 // kernel launchers implemented in the kernel files
@@ -863,6 +918,16 @@ int mb_release_workspace(void) {
   return 0;
 }
 
+int mb_alloc_stats(int64_t *poolAllocs, int64_t *poolFrees, int64_t *evictions, uint64_t *bytesAllocated, double *ms) {
+  ApiLock lock;
+  if (poolAllocs) *poolAllocs = g_alloc.allocs;
+  if (poolFrees) *poolFrees = g_alloc.frees;
+  if (evictions) *evictions = g_alloc.evictions;
+  if (bytesAllocated) *bytesAllocated = g_alloc.bytes;
+  if (ms) *ms = g_alloc.ms;
+  return 0;
+}
+
 int mb_jit_stats(double *compileMs, int64_t *compiles, int64_t *cacheHits) {
   if (compileMs) *compileMs = jit_compile_ms();
   if (compiles) *compiles = jit_compiles();
@@ -1423,6 +1488,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
     std::vector<PairDesc> hp;
     do {
       if ((rc = upload_chunk_descs(b, c, &d_desc, hp))) break;
+      { const size_t need = (size_t)std::max<long long>(c.cells, 1) * sizeof(double); const int sl[2] = {1, 0}; const size_t nb[2] = {need, need}; ws_plan(roll ? 1 : 2, sl, nb); }
       if (!roll && !(fwd = (double *)ws_get(0, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       if (!(bwd = (double *)ws_get(1, std::max<long long>(c.cells, 1) * sizeof(double)))) { rc = 1; break; }
       long long maxc = 0;
@@ -1755,6 +1821,88 @@ int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   }
   fclose(f);
   if (!ok) { set_error("mb_debug_wide_parts: short write"); return 1; }
+  return 0;
+}
+
+// the one-tape sweep GENERATED for this machine (mb_wide_jit.cpp), planned and rendered on the host only: k >= 2: the machine cut for k
+// workgroups per sequence (lanes = 0: searched), k <= 1: the one-workgroup program.  mode: MB_FORWARD / MB_VITERBI, + 16 traceback codes,
+// + 64 the fp64 correction term.  Writes the HIP source to `path` and, to `path`.prog, what the source unrolls -- for the device-free replay
+// of tests/test_retimed_plan.py: int32 magic 0x4A495431, parts, exchange columns, states; per part 24 int32 (lanes, NB, NVs, kMax, rowLen,
+// nPen, nImp, S, expBase, nExp, expIdx0, resultEntry, slots, rounds, NPT, U, penBase, tokBase, ringBase, dummyAddr, ldsBytes, fields,
+// words, 0), per slot 2 int32 (anyPen, anyW2), per round 8 int32 (firstSlot, depth, sync, uniform, gAll, anyMixed, resultLane, 0), per
+// field 4 int32 (kind, index, cm, words), then the table [words][lanes] uint32.  compile != 0: the source is also compiled with hiprtc
+// (no device needed) and the call fails when the kernel would use scratch memory.
+int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
+                      const uint16_t *inTok, const uint16_t *outTok, const double *logWeight, int mode, int backward, int k, int lanes, int compile, const char *path) {
+  ApiLock lock;
+  if (nStates <= 0 || nTrans < 0 || !path || (nInTok != 0) == (nOutTok != 0)) { set_error("mb_debug_wide_jit: bad argument (one-tape machines only)"); return 1; }
+  mb_machine m;
+  m.S = nStates; m.nIn = nInTok; m.nOut = nOutTok; m.nTrans = nTrans;
+  m.src.assign(src, src + nTrans); m.dst.assign(dst, dst + nTrans);
+  m.inTok.assign(inTok, inTok + nTrans); m.outTok.assign(outTok, outTok + nTrans);
+  m.logW.assign(logWeight, logWeight + nTrans);
+  std::string err;
+  if (!compile_machine(&m, &err)) { set_error(err); return 1; }
+  const bool tbCodes = (mode & 16) != 0, acc = (mode & 64) != 0;
+  mode &= 15;
+  if (tbCodes && (mode != MB_VITERBI || backward)) { set_error("mb_debug_wide_jit: traceback codes belong to the forward max program"); return 1; }
+  std::vector<WidePartHost> parts;
+  std::vector<WideRec> stream;
+  WideProgram P;
+  std::vector<WideJitIn> ins;
+  int nExpTot = 0;
+  if (k >= 2) {
+    int lanesChosen = lanes, mergeFlag = 0;
+    if (!wide_parts_host(&m, backward != 0, mode == MB_VITERBI, tbCodes, k, lanes, parts, nExpTot, nullptr, nullptr, nullptr, &lanesChosen, &mergeFlag)) { set_error("machine has no k-part retimed program"); return 1; }
+    for (const WidePartHost &H : parts) {
+      WideJitIn in;
+      in.ret = H.h.ret; in.W = lanesChosen; in.stream = H.stream.data();
+      in.w2 = H.h.w2Offset ? (const double *)((const char *)H.stream.data() + H.h.w2Offset) : nullptr;
+      in.part = true; in.S = H.h.Sloc; in.Sg = nStates; in.nImp = H.h.nImp; in.expBase = H.h.expBase; in.nExp = H.h.nExp; in.expIdx0 = H.h.expIdx0; in.resultEntry = H.h.resultEntry;
+      in.gmap = H.tab.data();
+      ins.push_back(in);
+    }
+  } else {
+    if (!wide_ret_host(&m, backward != 0, mode == MB_VITERBI, P, stream, tbCodes) || P.retGv) { set_error("machine has no retimed program with its ring in LDS"); return 1; }
+    WideJitIn in;
+    in.ret = P.ret; in.W = P.W; in.stream = stream.data(); in.S = nStates; in.Sg = nStates; in.resultEntry = backward ? 0 : nStates - 1;
+    ins.push_back(in);
+  }
+  WideJitFlags F; F.viterbi = mode == MB_VITERBI; F.tb = tbCodes; F.acc = acc; F.backward = backward != 0; F.inputTape = nOutTok == 0; F.nExpTot = nExpTot;
+  std::vector<WideJitDesc> descs(ins.size());
+  for (size_t p = 0; p < ins.size(); ++p) { std::string why; if (!wide_jit_describe(ins[p], acc, descs[p], &why)) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": " + why); return 1; } }
+  const std::string code = wide_jit_source(descs, F);
+  FILE *f = fopen(path, "w");
+  if (!f) { set_error("mb_debug_wide_jit: cannot open output file"); return 1; }
+  fputs(code.c_str(), f);
+  fclose(f);
+  f = fopen((std::string(path) + ".prog").c_str(), "wb");
+  if (!f) { set_error("mb_debug_wide_jit: cannot open output file"); return 1; }
+  const int32_t head[4] = {0x4A495431, (int32_t)descs.size(), nExpTot, nStates};
+  bool ok = fwrite(head, sizeof(head), 1, f) == 1;
+  for (const WideJitDesc &D : descs) {
+    const WideJitIn &in = D.in;
+    const int32_t ph[24] = {in.W, in.ret.NB, in.ret.NVs, in.ret.kMax, in.ret.rowLen, in.ret.nPen, in.nImp, in.S, in.expBase, in.nExp, in.expIdx0, in.resultEntry,
+                            D.nSlots, (int32_t)D.rounds.size(), D.NPT, D.U, (int32_t)D.penBase, (int32_t)D.tokBase, (int32_t)D.ringBase, (int32_t)D.dummyAddr, (int32_t)D.ldsBytes,
+                            (int32_t)D.fields.size(), D.nWords, 0};
+    ok = ok && fwrite(ph, sizeof(ph), 1, f) == 1;
+    for (const WideJitSlot &sl : D.slots) { const int32_t v[2] = {sl.anyPen, sl.anyW2}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
+    for (const WideJitRound &R : D.rounds) { const int32_t v[8] = {R.firstSlot, R.depth, R.sync, R.uniform, R.gAll, R.anyMixed, R.resultLane, 0}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
+    for (const WideJitField &fd : D.fields) { const int32_t v[4] = {fd.kind, fd.index, fd.cm, fd.words}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
+    std::vector<uint32_t> tab;
+    wide_jit_table(D, F, tab);
+    ok = ok && fwrite(tab.data(), 4, tab.size(), f) == tab.size();
+    if (in.part) ok = ok && fwrite(in.gmap + in.S, 4, (size_t)in.nImp, f) == (size_t)in.nImp;      // the exchange columns of the imports
+  }
+  fclose(f);
+  if (!ok) { set_error("mb_debug_wide_jit: short write"); return 1; }
+  if (compile) {
+    std::string obj, log;
+    if (!jit_compile(code, "mb_wide_jit.hip", obj, &log, nullptr)) { set_error("mb_debug_wide_jit: hiprtc: " + log.substr(0, 2000)); return 1; }
+    const long long scratch = jit_kernel_meta(obj, ".private_segment_fixed_size");
+    if (scratch > 0) { set_error("mb_debug_wide_jit: the kernel uses " + std::to_string(scratch) + " bytes of scratch memory"); return 1; }
+    if (FILE *g = fopen((std::string(path) + ".co").c_str(), "wb")) { fwrite(obj.data(), 1, obj.size(), g); fclose(g); }
+  }
   return 0;
 }
 
