@@ -194,16 +194,33 @@ def spawn_ranks(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def timed(fn, reps=1):
+TIMINGS = {}      # label -> [wall ms, device ms] of every timed mode of the line (extra.timings; host_overhead_flags reads it)
+
+
+def timed(fn, reps=1, label=None):
     """Mean wall time of `reps` calls after one warm-up call.  The results stay referenced until the clock stops: freeing
     a large host array (munmap) inside the timed region stalls the NEXT GPU submission of the process by tens of
-    milliseconds on this driver (scripts/vit_timing.py keep / drop), which is the caller's cost, not the library's."""
+    milliseconds on this driver (scripts/vit_timing.py keep / drop), which is the caller's cost, not the library's.
+    label: wall AND device milliseconds (HIP events of the library around its kernels, mean over the calls) go to TIMINGS -- round 5
+    shipped a mode whose wall clock was 95 x its device time (a 230 GB pool re-allocated in every call) and only the device-side
+    figure was printed."""
+    from machineboss_amd import capi
     held = [fn()]
+    dev = 0.0
     t0 = time.perf_counter()
     for _ in range(reps):
         held.append(fn())
+        dev += capi.last_device_ms()
     dt = (time.perf_counter() - t0) / reps
+    if label:
+        TIMINGS[label] = [round(dt * 1e3, 3), round(dev / reps, 3)]
     return held[-1], dt
+
+
+def host_overhead_flags():
+    """modes whose wall clock exceeds 1.2 x their device time (modes of more than 50 ms): memory management, host-side planning or
+    copies that the device-side roofline figures do not show"""
+    return sorted(k for k, (w, d) in TIMINGS.items() if w > 50.0 and w > 1.2 * d)
 
 
 def extra_single_gpu(capi, np, hbm_peak):
@@ -226,7 +243,7 @@ def extra_single_gpu(capi, np, hbm_peak):
     b1 = capi.DeviceBatch(dm1, *synth_batch(1, 1, 50, 50, em1.nInTok, em1.nOutTok))
     ll1 = b1.forward(capi.MB_ROLLING)
     cold = time.perf_counter() - t0
-    _, warm = timed(lambda: b1.forward(capi.MB_ROLLING), 20)
+    _, warm = timed(lambda: b1.forward(capi.MB_ROLLING), 20, label="config1.warm_call")
     out["config1_latency"] = {"workload": "protpsw, one 50 x 50 aa pair, boss --loglike (rolling Forward)", "cold_start_ms": round(cold * 1e3, 2),
                               "warm_call_us": round(warm * 1e6, 1), "loglike": float(ll1[0]), "kernel": capi.last_kernel_name(),
                               "jit": capi.jit_stats()}
@@ -240,6 +257,7 @@ def extra_single_gpu(capi, np, hbm_peak):
     for _ in range(5):
         cnt, s3, _ = b3.counts(); dev.append(capi.last_device_ms())
     wall = (time.perf_counter() - t0) / 5
+    TIMINGS["counts_config3"] = [round(wall * 1e3, 3), round(sum(dev) / len(dev), 3)]
     ach = 16.0 * cells3 / (sum(dev) / len(dev) / 1e3) / 1e9
     tr3, tr3src = pmc_traffic("counts_pmc_hbm.json", cells3, ["protpsw.m0.mat.bwd", "protpsw.m3.roll.fwd"])
     nsym = float(cnt[np.asarray(em1.inTok) != 0].sum()), float(cnt[np.asarray(em1.outTok) != 0].sum())
@@ -250,7 +268,7 @@ def extra_single_gpu(capi, np, hbm_peak):
                                   "algorithmic_bytes_per_lattice_cell": 16, "kernel": "k_small_sum_bwd + " + capi.last_kernel_name(), "traffic": tr3, "traffic_source": tr3src,
                                   "issue": valu_issue(["protpsw.m0.mat.bwd.hip", "protpsw.m3.roll.fwd.hip"], cells3 / (sum(dev) / len(dev) / 1e3))},
                      "symbol_count_invariant": [nsym[0] / (1024 * 400), nsym[1] / (1024 * 400)], "loglike_sum": float(s3)}
-    mfw, tf = timed(lambda: b3.forward(capi.MB_MATERIALISE), 5); devf = capi.last_device_ms()
+    mfw, tf = timed(lambda: b3.forward(capi.MB_MATERIALISE), 5, label="forward_config3.materialised"); devf = capi.last_device_ms()
     out["forward_config3"] = {"workload": "protpsw 1024 x 400 x 400, materialised Forward", "value": round(cells3 / tf / 1e9, 2), "unit": "Gcells/s",
                               "roofline": {"bound": "hbm", "achieved": round(8.0 * cells3 / (devf / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                            "frac": round(8.0 * cells3 / (devf / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name(),
@@ -264,8 +282,8 @@ def extra_single_gpu(capi, np, hbm_peak):
     dm2 = capi.DeviceMachine(em2)
     b2 = capi.DeviceBatch(dm2, *synth_batch(2, 1024, 1000, 1000, em2.nInTok, em2.nOutTok))
     cells2 = b2.cells()
-    (vll, off, edges), tv = timed(lambda: b2.viterbi(paths=True), 3); devv = capi.last_device_ms(); kv = capi.last_kernel_name()
-    _, tvf = timed(lambda: b2.viterbi(paths=False), 3); devvf = capi.last_device_ms()
+    (vll, off, edges), tv = timed(lambda: b2.viterbi(paths=True), 3, label="viterbi.with_paths"); devv = capi.last_device_ms(); kv = capi.last_kernel_name()
+    _, tvf = timed(lambda: b2.viterbi(paths=False), 3, label="viterbi.fill"); devvf = capi.last_device_ms()
     out["viterbi"] = {"workload": "config 2: dnapsw (8 states, 34 transitions), 1024 pairs x 1000 x 1000 nt, ViterbiMatrix + traceBack",
                       "value": round(cells2 / tv / 1e9, 2), "unit": "Gcells/s (fill + traceback + paths copied to the host)",
                       "fill_only": round(cells2 / tvf / 1e9, 2), "device_ms": round(devv, 3), "fill_device_ms": round(devvf, 3),
@@ -273,8 +291,8 @@ def extra_single_gpu(capi, np, hbm_peak):
                       "roofline": {"bound": "valu", "note": "1 traceback byte per cell: HBM traffic is 1/8 of the materialised fill; the sweep is bound by vector instruction issue (fp64 add/max at half rate), see DESIGN.md",
                                    "achieved": round(1.0 * cells2 / (devvf / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                    "frac": round(1.0 * cells2 / (devvf / 1e3) / 1e9 / hbm_peak, 4), "algorithmic_bytes_per_cell": 1, "kernel": kv}}
-    _, tr = timed(lambda: b2.forward(capi.MB_ROLLING), 3)
-    _, tm = timed(lambda: b2.forward(capi.MB_MATERIALISE), 3); devm = capi.last_device_ms()
+    _, tr = timed(lambda: b2.forward(capi.MB_ROLLING), 3, label="forward_config2.rolling")
+    _, tm = timed(lambda: b2.forward(capi.MB_MATERIALISE), 3, label="forward_config2.materialised"); devm = capi.last_device_ms()
     out["forward_config2"] = {"workload": "dnapsw 1024 x 1000 x 1000, Forward", "rolling": round(cells2 / tr / 1e9, 2), "materialised": round(cells2 / tm / 1e9, 2),
                               "unit": "Gcells/s", "roofline": {"bound": "hbm", "achieved": round(8.0 * cells2 / (devm / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s",
                                                                "frac": round(8.0 * cells2 / (devm / 1e3) / 1e9 / hbm_peak, 4), "kernel": capi.last_kernel_name()}}
@@ -289,8 +307,8 @@ def extra_single_gpu(capi, np, hbm_peak):
     nv = 256
     b4 = capi.DeviceBatch(dm4, *synth_batch(4, nv, 487, 10000, em4.nInTok, em4.nOutTok))
     cells4 = b4.cells()
-    (v4, off4, e4), tv4 = timed(lambda: b4.viterbi(paths=True), 1); devv4 = capi.last_device_ms(); kv4 = capi.last_kernel_name()
-    _, tvf4 = timed(lambda: b4.viterbi(paths=False), 1); devvf4 = capi.last_device_ms()
+    (v4, off4, e4), tv4 = timed(lambda: b4.viterbi(paths=True), 1, label="viterbi4.with_paths"); devv4 = capi.last_device_ms(); kv4 = capi.last_kernel_name()
+    _, tvf4 = timed(lambda: b4.viterbi(paths=False), 1, label="viterbi4.fill"); devvf4 = capi.last_device_ms()
     out["viterbi4"] = {"workload": "config 4: psw2dna (271 states), %d pairs x 487 aa x 10000 nt, ViterbiMatrix + traceBack, one traceback byte per cell" % nv,
                        "value": round(cells4 / tv4 / 1e9, 2), "unit": "Gcells/s (fill + traceback + paths copied to the host)", "fill_only": round(cells4 / tvf4 / 1e9, 2),
                        "device_ms": round(devv4, 3), "fill_device_ms": round(devvf4, 3), "path_edges": int(off4[-1]), "loglike_sum": float(v4.sum()),
@@ -303,7 +321,7 @@ def extra_single_gpu(capi, np, hbm_peak):
     nc4 = 63      # three chunks of Backward matrices (21 pairs of 10.6 GB each fit the 80 % budget of a 288 GB GPU)
     b4c = capi.DeviceBatch(dm4, *synth_batch(4, nc4, 487, 10000, em4.nInTok, em4.nOutTok))
     cells4c = b4c.cells()
-    (cnt4, s4, _), tc4 = timed(lambda: b4c.counts(), 1); devc4 = capi.last_device_ms()
+    (cnt4, s4, _), tc4 = timed(lambda: b4c.counts(), 1, label="counts4"); devc4 = capi.last_device_ms()
     ach4 = 16.0 * cells4c / (devc4 / 1e3) / 1e9
     out["counts4"] = {"workload": "config 4: psw2dna, %d pairs x 487 aa x 10000 nt, Backward fill + Forward/count sweep without a Forward matrix (MachineCounts)" % nc4,
                       "value": round(cells4c / tc4 / 1e9, 2), "unit": "G lattice-cells/s (two matrices per lattice cell)", "ms": round(tc4 * 1e3, 2), "device_ms": round(devc4, 2),
@@ -327,17 +345,17 @@ def extra_single_gpu(capi, np, hbm_peak):
         dm4b = capi.DeviceMachine(em4b)
         bb = capi.DeviceBatch(dm4b, *synth_batch(4, 256, 487, 10000, em4b.nInTok, 3))      # DNA over {A,C,G}: no stop codons
         cellsb = bb.cells()
-        llb, tfb = timed(lambda: bb.forward(capi.MB_MATERIALISE), 1); devfb = capi.last_device_ms(); kfb = capi.last_kernel_name()
-        _, trb = timed(lambda: bb.forward(capi.MB_ROLLING), 1)
+        llb, tfb = timed(lambda: bb.forward(capi.MB_MATERIALISE), 1, label="config4b.forward_materialised"); devfb = capi.last_device_ms(); kfb = capi.last_kernel_name()
+        _, trb = timed(lambda: bb.forward(capi.MB_ROLLING), 1, label="config4b.forward_rolling")
         del bb
         bbv = capi.DeviceBatch(dm4b, *synth_batch(4, 64, 487, 10000, em4b.nInTok, 3))
         cellsbv = bbv.cells()
-        (vb, offb, eb), tvb = timed(lambda: bbv.viterbi(paths=True), 1)
-        _, tvfb = timed(lambda: bbv.viterbi(paths=False), 1); devvfb = capi.last_device_ms()
+        (vb, offb, eb), tvb = timed(lambda: bbv.viterbi(paths=True), 1, label="config4b.viterbi_with_paths")
+        _, tvfb = timed(lambda: bbv.viterbi(paths=False), 1, label="config4b.viterbi_fill"); devvfb = capi.last_device_ms()
         del bbv
         bbc = capi.DeviceBatch(dm4b, *synth_batch(4, 24, 487, 10000, em4b.nInTok, 3))      # two chunks of Backward matrices (18.8 GB each)
         cellsbc = bbc.cells()
-        (cntb, sb, _), tcb = timed(lambda: bbc.counts(), 1); devcb = capi.last_device_ms()
+        (cntb, sb, _), tcb = timed(lambda: bbc.counts(), 1, label="config4b.counts"); devcb = capi.last_device_ms()
         del bbc
         out["config4b"] = {"workload": "config 4 literally: protpsw . translate . dnapsw (dnapsw's constraints cleared; %d states, %d transitions), composed here in %.2f s; 256 / 64 / 24 pairs x 487 aa x 10000 nt" % (em4b.nStates, em4b.nTransitions, tc4b),
                            "forward_materialised": round(cellsb / tfb / 1e9, 2), "forward_rolling": round(cellsb / trb / 1e9, 2), "unit": "Gcells/s",
@@ -372,10 +390,10 @@ def extra_single_gpu(capi, np, hbm_peak):
         dm5 = capi.DeviceMachine(em5)
         b5 = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 2000, em5.nInTok, em5.nOutTok))
         cells5 = b5.cells()
-        ll5, t5 = timed(lambda: b5.forward(capi.MB_ROLLING), 2); k5 = capi.last_kernel_name()
-        _, t5v = timed(lambda: b5.viterbi(paths=False), 1)
-        (_, _, e5), t5p = timed(lambda: b5.viterbi(), 1)
-        (cnt5, s5, _), t5c = timed(lambda: b5.counts(), 1); k5c = capi.last_kernel_name()
+        ll5, t5 = timed(lambda: b5.forward(capi.MB_ROLLING), 2, label="config5.forward_rolling"); k5 = capi.last_kernel_name()
+        _, t5v = timed(lambda: b5.viterbi(paths=False), 1, label="config5.viterbi_fill")
+        (_, _, e5), t5p = timed(lambda: b5.viterbi(), 1, label="config5.viterbi_with_paths")
+        (cnt5, s5, _), t5c = timed(lambda: b5.counts(), 1, label="config5.counts"); k5c = capi.last_kernel_name()
         out["config5"] = {"workload": "fn3 profile (20 nodes) . simple_introns . translate . dnapsw: %d states, %d transitions, one tape; 64 sequences x 2000 nt" % (em5.nStates, em5.nTransitions),
                           "compose_s": round(tc, 2), "forward_rolling": round(cells5 / t5 / 1e9, 2), "viterbi_fill": round(cells5 / t5v / 1e9, 2),
                           "viterbi_with_paths": round(cells5 / t5p / 1e9, 2), "path_edges": int(len(e5)),
@@ -388,18 +406,18 @@ def extra_single_gpu(capi, np, hbm_peak):
         # ... with every CU busy: 256 sequences x 4 kb
         b5w = capi.DeviceBatch(dm5, *synth_batch(5, 256, 0, 4000, em5.nInTok, em5.nOutTok))
         cells5w = b5w.cells()
-        _, t5w = timed(lambda: b5w.forward(capi.MB_ROLLING), 1); k5w = capi.last_kernel_name()
-        _, t5wv = timed(lambda: b5w.viterbi(paths=False), 1); k5wv = capi.last_kernel_name()
+        _, t5w = timed(lambda: b5w.forward(capi.MB_ROLLING), 1, label="config5.all_cus.forward_rolling"); k5w = capi.last_kernel_name()
+        _, t5wv = timed(lambda: b5w.viterbi(paths=False), 1, label="config5.all_cus.viterbi_fill"); k5wv = capi.last_kernel_name()
         out["config5"]["all_cus"] = {"workload": "the same machine, 256 sequences x 4000 nt (one workgroup per CU)", "forward_rolling": round(cells5w / t5w / 1e9, 2),
                                      "viterbi_fill": round(cells5w / t5wv / 1e9, 2), "unit": "Gcells/s", "kernels": [k5w, k5wv]}
         del b5w
         # ... and at the config's STATED length: 64 sequences x 50 kb on this one GPU (16.2 G cells per matrix)
         b5f = capi.DeviceBatch(dm5, *synth_batch(5, 64, 0, 50000, em5.nInTok, em5.nOutTok))
         cells5f = b5f.cells()
-        ll5f, t5f = timed(lambda: b5f.forward(capi.MB_ROLLING), 1); k5f = capi.last_kernel_name()
-        (v5f, _, _), t5vf = timed(lambda: b5f.viterbi(paths=False), 1); k5vf = capi.last_kernel_name()
+        ll5f, t5f = timed(lambda: b5f.forward(capi.MB_ROLLING), 1, label="config5.full_size.forward_rolling"); k5f = capi.last_kernel_name()
+        (v5f, _, _), t5vf = timed(lambda: b5f.viterbi(paths=False), 1, label="config5.full_size.viterbi_fill"); k5vf = capi.last_kernel_name()
         # --align at that size: one traceback code per cell (16 GB where the fp64 Viterbi matrices would be 130), the paths on the host
-        (v5p, o5p, e5p), t5pf = timed(lambda: b5f.viterbi(), 1); k5pf = capi.last_kernel_name()
+        (v5p, o5p, e5p), t5pf = timed(lambda: b5f.viterbi(), 1, label="config5.full_size.viterbi_with_paths"); k5pf = capi.last_kernel_name()
         out["config5"]["full_size"] = {"viterbi_with_paths": round(cells5f / t5pf / 1e9, 2), "viterbi_with_paths_ms": round(t5pf * 1e3, 1), "path_edges": int(len(e5p)),
                                        "paths_kernel": k5pf, "paths_score_equals_fill": bool(np.array_equal(v5p, v5f)),
                                        "note_paths": "the paths are oracle-checked bit for bit at this length in tests/test_gpu_parity.py (test_baseline_config5_one_sequence_at_50kb_against_the_oracle)"}
@@ -410,7 +428,7 @@ def extra_single_gpu(capi, np, hbm_peak):
         # ... and the E-step at that size (two fp64 matrices of 130 GB each: the library cuts the batch into chunks that fit; fills with the fp64
         # correction term, sequences being >= 10 000 symbols)
         try:
-            (cnt5f, s5cf, _), t5cf = timed(lambda: b5f.counts(), 1)
+            (cnt5f, s5cf, _), t5cf = timed(lambda: b5f.counts(), 1, label="config5.full_size.counts")
             out["config5"]["full_size"].update({"counts_lattice": round(cells5f / t5cf / 1e9, 2), "counts_ms": round(t5cf * 1e3, 1), "counts_device_ms": round(capi.last_device_ms(), 1),
                                                 "counts_kernel": capi.last_kernel_name(), "counts_symbol_invariant": float(cnt5f[np.asarray(em5.outTok) != 0].sum()) / (64 * 50000),
                                                 "counts_note": "Forward + Backward fills (k_wide_retimed, fp64 log-sum-exp correction term: sequences >= 10 000 symbols) + k_onetape_counts, G lattice-cells/s"})
@@ -425,9 +443,9 @@ def extra_single_gpu(capi, np, hbm_peak):
         for label, env in (("k_workgroups_per_sequence", parts_env), ("one_workgroup_per_sequence", "1")):
             if env is None: os.environ.pop("MB_ONETAPE_PARTS", None)
             else: os.environ["MB_ONETAPE_PARTS"] = env
-            _, te = timed(lambda: b5e.forward(capi.MB_ROLLING), 1); ke = capi.last_kernel_name()
-            _, tve = timed(lambda: b5e.viterbi(paths=False), 1); kve = capi.last_kernel_name()
-            _, tpe = timed(lambda: b5e.viterbi(), 1)
+            _, te = timed(lambda: b5e.forward(capi.MB_ROLLING), 1, label="config5.eight_per_gpu.%s.forward_rolling" % label); ke = capi.last_kernel_name()
+            _, tve = timed(lambda: b5e.viterbi(paths=False), 1, label="config5.eight_per_gpu.%s.viterbi_fill" % label); kve = capi.last_kernel_name()
+            _, tpe = timed(lambda: b5e.viterbi(), 1, label="config5.eight_per_gpu.%s.viterbi_with_paths" % label)
             eight[label] = {"forward_ms": round(te * 1e3, 1), "viterbi_ms": round(tve * 1e3, 1), "viterbi_with_paths_ms": round(tpe * 1e3, 1), "kernels": [ke, kve]}
         if parts_env is None: os.environ.pop("MB_ONETAPE_PARTS", None)
         else: os.environ["MB_ONETAPE_PARTS"] = parts_env
@@ -460,13 +478,14 @@ def extra_single_gpu(capi, np, hbm_peak):
         dmn = capi.DeviceMachine(emn)
         bn = capi.DeviceBatch(dmn, *synth_batch(4, 32, 487, 10000, emn.nInTok, emn.nOutTok))
         cellsn = bn.cells()
-        lln, tfn = timed(lambda: bn.forward(capi.MB_MATERIALISE), 1); devn = capi.last_device_ms()
-        (vn, offn, en), tvn = timed(lambda: bn.viterbi(paths=True), 1)
+        lln, tfn = timed(lambda: bn.forward(capi.MB_MATERIALISE), 1, label="nonuniform.forward_materialised"); devn = capi.last_device_ms()
+        (vn, offn, en), tvn = timed(lambda: bn.viterbi(paths=True), 1, label="nonuniform.viterbi_with_paths")
         lw = np.asarray(emn.logWeight)
         rescore = float(np.sum(lw[en[offn[0]:offn[1]]]))
         out["nonuniform"] = {"workload": "psw2dna under parameters fitted by Baum-Welch (%d iterations, %.1f s, log-likelihood %.4f -> %.4f on 16 pairs of 40 aa x 130 nt); 32 pairs x 487 aa x 10000 nt"
                                          % (len(fitter.log), tfit, fitter.log[0], fitter.log[-1]),
-                             "forward_materialised": round(cellsn / tfn / 1e9, 2), "viterbi_with_paths": round(cellsn / tvn / 1e9, 2), "unit": "Gcells/s",
+                             "forward_materialised": round(cellsn / tfn / 1e9, 2), "viterbi_with_paths": round(cellsn / tvn / 1e9, 2), "unit": "Gcells/s (wall clock)",
+                             "ms": round(tfn * 1e3, 2), "device_ms": round(devn, 2),
                              "roofline": {"bound": "hbm", "achieved": round(8.0 * cellsn / (devn / 1e3) / 1e9, 1), "peak": hbm_peak, "unit": "GB/s", "frac": round(8.0 * cellsn / (devn / 1e3) / 1e9 / hbm_peak, 4)},
                              "loglike_checksum": float(np.sum(lln)), "viterbi_checksum": float(np.sum(vn)),
                              "path0_rescored_minus_viterbi": rescore - float(vn[0]), "_em": emn, "_dm": dmn}
@@ -667,7 +686,7 @@ def main():
                                  "symbol_count_invariant": nsym / (world * per * 400)}
     if world == 1 and rank == 0 and not args.no_extra and not args.extra_em_only:
         other = capi.MB_ROLLING if flags == capi.MB_MATERIALISE else capi.MB_MATERIALISE
-        _, d1 = timed(lambda: batch.forward(other))
+        _, d1 = timed(lambda: batch.forward(other), label="headline.other_mode")
         extra["rolling_gcells_per_gpu" if other == capi.MB_ROLLING else "materialised_gcells_per_gpu"] = round(cells_rank / d1 / 1e9, 3)
         if other == capi.MB_ROLLING:
             # the rolling mode is priced against the transcendental issue rate, not HBM
@@ -783,6 +802,11 @@ def main():
             "recorded_constants": {"tag": PROFILE_TAG, "refused": dict(REFUSED), "kernel_sha": kernel_sha_now()},
             "extra": extra,
         }
+        if extra:
+            # wall clock beside device time for every timed mode, and the modes where the two differ
+            extra["timings"] = {"unit": "[wall ms, device ms] per call", **TIMINGS}
+            out["host_overhead_flags"] = host_overhead_flags()
+            out["alloc_stats"] = capi.alloc_stats()
         if args.write_kernel_sha:
             with open(args.write_kernel_sha, "w") as fh:
                 json.dump({"written_by": "python bench.py --write-kernel-sha (the round's profile run)", "kernels": kernel_sha_now()}, fh, indent=1, sort_keys=True)
@@ -795,6 +819,8 @@ def main():
             out["summary"] = {"headline": [out["value"], out["roofline"]["frac"]], "rolling_gcells": extra.get("rolling_gcells_per_gpu"),
                               "counts4": _rf("counts4"), "viterbi4_with_paths": _rf("viterbi4"), "counts_config3": _rf("counts"), "forward_config3": _rf("forward_config3"),
                               "config4b_forward_materialised": _rf("config4b", "forward_materialised"), "config4b_counts": _rf("config4b", "counts_lattice", "roofline_counts"),
+                              "nonuniform_forward_materialised": [(extra.get("nonuniform") or {}).get("forward_materialised"), ((extra.get("nonuniform") or {}).get("roofline") or {}).get("frac")],
+                              "host_overhead_flags": out.get("host_overhead_flags"),
                               "config5_50kb_forward_viterbi_withpaths": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill", "viterbi_with_paths")],
                               "unit": "G cells/s (counts: G lattice-cells/s), fraction of 8 TB/s at the mode's algorithmic bytes"}
         print(json.dumps(out))

@@ -24,7 +24,7 @@ EXPORTS = [
     "mb_machine_n_levels", "mb_machine_edge_order",
     "mb_batch_create", "mb_batch_destroy", "mb_batch_cells", "mb_batch_forward", "mb_viterbi_path_bound",
     "mb_batch_viterbi", "mb_batch_counts", "mb_fill", "mb_forward_batch", "mb_viterbi_batch", "mb_counts_batch",
-    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source", "mb_debug_wide_retimed", "mb_debug_wide_parts",
+    "mb_set_kernel", "mb_set_memory_budget", "mb_release_workspace", "mb_debug_jit_source", "mb_debug_small_source", "mb_debug_wide_retimed", "mb_debug_wide_parts", "mb_debug_wide_jit",
     "mb_jit_stats", "mb_alloc_stats", "mb_machine_sweep_ops", "mb_set_option", "mb_get_option", "mb_log_sum_exp", "mb_log_sum_exp_n", "mb_log_inner_product",
     "mb_batch_set_envelopes", "mb_fill_env",
     "mb_comm_unique_id", "mb_comm_init", "mb_comm_destroy", "mb_allreduce_counts",
@@ -86,6 +86,8 @@ def load():
                                         C.c_int, C.c_int, C.c_char_p]
     L.mb_debug_wide_parts.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.mb_debug_wide_jit.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, u32p, u32p, u16p, u16p, dp,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.mb_log_sum_exp.argtypes = [C.c_double, C.c_double]; L.mb_log_sum_exp.restype = C.c_double
     L.mb_log_sum_exp_n.argtypes = [dp, C.c_size_t]; L.mb_log_sum_exp_n.restype = C.c_double
     L.mb_log_inner_product.argtypes = [dp, dp, dp, C.c_size_t]; L.mb_log_inner_product.restype = C.c_double
@@ -337,6 +339,46 @@ def debug_wide_parts(em, path: str, k: int, lanes: int = 256, mode: int = MB_VIT
         assert q == rest.size and out["tbOff"].size == em.nStates + 1 and out["inEid"].size == em.nTransitions
         pos += 4 * rest.size
     assert os.path.getsize(path) == pos
+    return out
+
+
+def debug_wide_jit(em, path: str, k: int = 1, lanes: int = 0, mode: int = MB_VITERBI, backward: bool = False, tb_codes: bool = False,
+                   acc: bool = False, compile: bool = False) -> dict:
+    """The one-tape sweep GENERATED for this machine (mb_wide_jit.cpp; host only): the HIP source goes to `path`, and what it unrolls
+    comes back as {"nExp", "S", "parts": [{geometry ..., "slots": [(anyPen, anyW2)], "rounds": [{firstSlot, depth, sync, uniform, gAll,
+    anyMixed, resultLane}], "fields": [(kind, index, cm, words)], "table": uint32 [words][lanes], "impIdx"}]} -- the per-lane constant
+    table exactly as the kernel loads it.  compile: also through hiprtc (raises when the kernel would spill to scratch memory)."""
+    a = [np.ascontiguousarray(em.src, np.uint32), np.ascontiguousarray(em.dst, np.uint32),
+         np.ascontiguousarray(em.inTok, np.uint16), np.ascontiguousarray(em.outTok, np.uint16),
+         np.ascontiguousarray(em.logWeight, np.float64)]
+    _check(load().mb_debug_wide_jit(em.nStates, em.nInTok, em.nOutTok, em.nTransitions, _p(a[0], C.c_uint32),
+                                    _p(a[1], C.c_uint32), _p(a[2], C.c_uint16), _p(a[3], C.c_uint16), _p(a[4], C.c_double),
+                                    mode | (16 if tb_codes else 0) | (64 if acc else 0), int(backward), int(k), int(lanes), int(compile), path.encode()))
+    prog = path + ".prog"
+    head = np.fromfile(prog, np.int32, 4)
+    assert head[0] == 0x4A495431
+    out = {"nExp": int(head[2]), "S": int(head[3]), "parts": []}
+    pos = 16
+    keys = ("lanes", "NB", "NVs", "kMax", "rowLen", "nPen", "nImp", "Sloc", "expBase", "nExp", "expIdx0", "resultEntry", "nSlots", "nRounds", "NPT", "U",
+            "penBase", "tokBase", "ringBase", "dummyAddr", "ldsBytes", "nFields", "nWords", "pad")
+    for _ in range(int(head[1])):
+        ph = np.fromfile(prog, np.int32, 24, offset=pos); pos += 96
+        part = {k_: int(v) for k_, v in zip(keys, ph)}
+        sl = np.fromfile(prog, np.int32, 2 * part["nSlots"], offset=pos).reshape(-1, 2); pos += 8 * part["nSlots"]
+        rd = np.fromfile(prog, np.int32, 8 * part["nRounds"], offset=pos).reshape(-1, 8); pos += 32 * part["nRounds"]
+        fd = np.fromfile(prog, np.int32, 4 * part["nFields"], offset=pos).reshape(-1, 4); pos += 16 * part["nFields"]
+        part["slots"] = [(bool(x[0]), bool(x[1])) for x in sl]
+        part["rounds"] = [dict(firstSlot=int(x[0]), depth=int(x[1]), sync=bool(x[2]), uniform=bool(x[3]), gAll=int(x[4]), anyMixed=bool(x[5]), resultLane=int(x[6]), gMask=int(x[7])) for x in rd]
+        part["fields"] = [tuple(int(v) for v in x) for x in fd]
+        part["table"] = np.fromfile(prog, np.uint32, part["nWords"] * part["lanes"], offset=pos).reshape(part["nWords"], part["lanes"]); pos += 4 * part["nWords"] * part["lanes"]
+        part["level"], part["IP"], part["ring"] = part["pad"] & 0xff, (part["pad"] >> 8) & 0xfff, part["pad"] >> 20
+        if part["level"] >= 1:      # the packed address words of a streamed program: [rotation][item][lane]
+            n = part["NB"] * part["IP"] * part["lanes"]
+            part["stream"] = np.fromfile(prog, np.uint32, n, offset=pos).reshape(part["NB"], part["IP"], part["lanes"]); pos += 4 * n
+        if len(out["parts"]) > 0 or int(head[1]) > 1:
+            part["impIdx"] = np.fromfile(prog, np.uint32, part["nImp"], offset=pos).astype(np.int64); pos += 4 * part["nImp"]
+        out["parts"].append(part)
+    assert os.path.getsize(prog) == pos
     return out
 
 

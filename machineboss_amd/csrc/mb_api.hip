@@ -1829,7 +1829,7 @@ int mb_debug_wide_parts(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
 // + 64 the fp64 correction term.  Writes the HIP source to `path` and, to `path`.prog, what the source unrolls -- for the device-free replay
 // of tests/test_retimed_plan.py: int32 magic 0x4A495431, parts, exchange columns, states; per part 24 int32 (lanes, NB, NVs, kMax, rowLen,
 // nPen, nImp, S, expBase, nExp, expIdx0, resultEntry, slots, rounds, NPT, U, penBase, tokBase, ringBase, dummyAddr, ldsBytes, fields,
-// words, 0), per slot 2 int32 (anyPen, anyW2), per round 8 int32 (firstSlot, depth, sync, uniform, gAll, anyMixed, resultLane, 0), per
+// words, 0), per slot 2 int32 (anyPen, anyW2), per round 8 int32 (firstSlot, depth, sync, uniform, gAll, anyMixed, resultLane, mask of the lane-group sizes its switch serves), per
 // field 4 int32 (kind, index, cm, words), then the table [words][lanes] uint32.  compile != 0: the source is also compiled with hiprtc
 // (no device needed) and the call fails when the kernel would use scratch memory.
 int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src, const uint32_t *dst,
@@ -1870,7 +1870,15 @@ int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t 
   }
   WideJitFlags F; F.viterbi = mode == MB_VITERBI; F.tb = tbCodes; F.acc = acc; F.backward = backward != 0; F.inputTape = nOutTok == 0; F.nExpTot = nExpTot;
   std::vector<WideJitDesc> descs(ins.size());
-  for (size_t p = 0; p < ins.size(); ++p) { std::string why; if (!wide_jit_describe(ins[p], acc, descs[p], &why)) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": " + why); return 1; } }
+  const int regs = 512 / ((ins[0].W / 64 + 3) / 4), forceLevel = env_int("MB_WIDE_JIT_LEVEL", -1);
+  for (size_t p = 0; p < ins.size(); ++p) {
+    std::string why; bool ok = false;
+    for (int level = forceLevel >= 0 ? forceLevel : 0; level <= (forceLevel >= 0 ? forceLevel : 1) && !ok; ++level) {
+      if (!wide_jit_describe(ins[p], acc, level, descs[p], &why)) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": " + why); return 1; }
+      ok = descs[p].regEstimate <= regs || forceLevel >= 0;
+    }
+    if (!ok) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": constants per lane beyond the register file"); return 1; }
+  }
   const std::string code = wide_jit_source(descs, F);
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_wide_jit: cannot open output file"); return 1; }
@@ -1884,14 +1892,20 @@ int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t 
     const WideJitIn &in = D.in;
     const int32_t ph[24] = {in.W, in.ret.NB, in.ret.NVs, in.ret.kMax, in.ret.rowLen, in.ret.nPen, in.nImp, in.S, in.expBase, in.nExp, in.expIdx0, in.resultEntry,
                             D.nSlots, (int32_t)D.rounds.size(), D.NPT, D.U, (int32_t)D.penBase, (int32_t)D.tokBase, (int32_t)D.ringBase, (int32_t)D.dummyAddr, (int32_t)D.ldsBytes,
-                            (int32_t)D.fields.size(), D.nWords, 0};
+                            (int32_t)D.fields.size(), D.nWords, D.level | (D.IP << 8) | (D.ring << 20)};
     ok = ok && fwrite(ph, sizeof(ph), 1, f) == 1;
     for (const WideJitSlot &sl : D.slots) { const int32_t v[2] = {sl.anyPen, sl.anyW2}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
-    for (const WideJitRound &R : D.rounds) { const int32_t v[8] = {R.firstSlot, R.depth, R.sync, R.uniform, R.gAll, R.anyMixed, R.resultLane, 0}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
+    for (const WideJitRound &R : D.rounds) {
+      int32_t mask = 0;      // the lane-group sizes the round's switch has a case for
+      for (int g : R.gWaves) mask |= g;
+      const int32_t v[8] = {R.firstSlot, R.depth, R.sync, R.uniform, R.gAll, R.anyMixed, R.resultLane, mask};
+      ok = ok && fwrite(v, sizeof(v), 1, f) == 1;
+    }
     for (const WideJitField &fd : D.fields) { const int32_t v[4] = {fd.kind, fd.index, fd.cm, fd.words}; ok = ok && fwrite(v, sizeof(v), 1, f) == 1; }
-    std::vector<uint32_t> tab;
-    wide_jit_table(D, F, tab);
+    std::vector<uint32_t> tab, stream;
+    wide_jit_table(D, F, tab, &stream);
     ok = ok && fwrite(tab.data(), 4, tab.size(), f) == tab.size();
+    if (D.level >= 1) ok = ok && fwrite(stream.data(), 4, stream.size(), f) == stream.size();      // [NB][IP][lanes] packed address words
     if (in.part) ok = ok && fwrite(in.gmap + in.S, 4, (size_t)in.nImp, f) == (size_t)in.nImp;      // the exchange columns of the imports
   }
   fclose(f);

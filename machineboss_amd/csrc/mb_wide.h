@@ -1,5 +1,7 @@
 // mb_wide.h -- "one workgroup = one column" kernel family for large one-tape machines (see mb_wide.hip).
 #pragma once
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "mb_internal.h"
@@ -109,6 +111,30 @@ struct WideRetDev {
   int rowLen, nPen;            // penalty table: rowLen = tokens + 2 entries (silent, each token, seed) per ktau, nPen entries in all
 };
 
+// ---- the sweep GENERATED per machine (mb_wide_jit.h / mb_wide_jit.cpp): a compiled module and the per-lane constant tables of its parts ----
+constexpr int WIDE_JIT_MAX_PARTS = 16;
+struct WideJitArgs {
+  const uint32_t *tab[WIDE_JIT_MAX_PARTS];      // per part: [word][lane] constants (weights, source / destination addresses per ring rotation, lags, offsets)
+  const uint32_t *impIdx[WIDE_JIT_MAX_PARTS];   // per part: exchange column of import i
+  const uint32_t *stream[WIDE_JIT_MAX_PARTS];   // per part: [rotation][item][lane] packed address words of a streamed program (nullptr: all in registers)
+  int nSeq, nExpTot;
+  double *X;
+  const long long *xOff;
+  unsigned *err;
+  long long timeoutTicks;
+};
+struct WideJitModule { void *module = nullptr, *func = nullptr; ~WideJitModule(); };
+struct WideJitKernel {
+  bool tried = false;
+  std::shared_ptr<WideJitModule> mod;           // shared between programs of the same structure (a weight update finds its kernel again)
+  size_t ldsBytes = 0;
+  int W = 0, k = 0;
+  std::vector<uint32_t *> d_tab, d_stream;
+  WideJitArgs args{};
+  std::string why;                              // why the interpreter kept the program (empty: built)
+  void release();
+};
+
 // ---- k WORKGROUPS PER SEQUENCE (round 5; k_wide_retimed_parts) -----------------------------------------------------------------
 // One workgroup per sequence leaves most of the chip idle when a batch has fewer sequences than the device has CUs (BASELINE config 5:
 // 64 sequences, 256 CUs -- and 8 per GPU when the batch is split over eight).  The states of the machine are cut into k PARTS along a
@@ -164,6 +190,10 @@ struct WidePartSet {
   std::vector<int> period, slots, nSync;     // per part, for the log
   // traceback-code programs: the decode tables of the parts' own candidate lists (two-transition candidates change the places), joined
   int *d_tbOff = nullptr; uint32_t *d_tbEntry = nullptr; long long tbEntries = 0;
+  // the generated kernel of this cut ([1]: with the fp64 correction term), built on first use from the host copies of the parts' streams
+  std::vector<std::vector<WideRec>> h_stream;
+  std::vector<std::vector<uint32_t>> h_tab;
+  WideJitKernel jit[2];
 };
 
 // a second sweep fused into the same launch (workgroups >= nFirst run it): Forward and Backward of one batch side by side
@@ -214,6 +244,8 @@ struct WideProgram {
   long long tbEntries = 0;
   int tbFromSet = -1;                // the last traceback-code fill ran through partSets[tbFromSet] (its codes decode with that set's tables)
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
+  std::vector<WideRec> h_ret;        // host copy of the retimed streams (the generated kernel's table is built from it on first use)
+  WideJitKernel jit[2];              // the generated kernel of the one-workgroup sweep ([1]: fp64 correction term)
   std::vector<WidePartSet> partSets; // k workgroups per sequence: one set per k that was asked for (built on first use)
   std::vector<WidePartHint> partHints;
   size_t vecBytes32() const { return (size_t)(2 * NV + NX) * sizeof(float); }

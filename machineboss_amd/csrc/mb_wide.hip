@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "mb_wide.h"
+#include "mb_wide_jit.h"
 #include "mb_device_math.h"
 
 namespace mb {
@@ -920,7 +921,9 @@ void wide_free(WideProgram &P) {
   if (P.d_ret) (void)hipFree(P.d_ret);
   if (P.d_tbOff) (void)hipFree(P.d_tbOff);
   if (P.d_tbEntry) (void)hipFree(P.d_tbEntry);
+  for (WideJitKernel &J : P.jit) J.release();
   for (WidePartSet &ps : P.partSets) {
+    for (WideJitKernel &J : ps.jit) J.release();
     for (WideRec *r : ps.d_rec) if (r) (void)hipFree(r);
     for (uint32_t *t : ps.d_tab) if (t) (void)hipFree(t);
     if (ps.d_parts) (void)hipFree(ps.d_parts);
@@ -1630,7 +1633,10 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
       fprintf(stderr, "[mbhip]   round: %d lanes, depth %d, sync %d, nodes by group size 1/2/4/8/16/32/64: %d %d %d %d %d %d %d\n", R.pad0, R.depth, R.sync, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
     }
   if (hostOut) hostOut->swap(st);
-  else if (!up_w(P.d_ret, st)) return false;
+  else {
+    if (!up_w(P.d_ret, st)) return false;
+    if (!best.gv && !part) P.h_ret.swap(st);      // (kept for the generated kernel: its per-lane table is built from the streams on first use)
+  }
   P.ret.rec = P.d_ret; P.ret.nSlots = padded; P.ret.NB = best.NB; P.ret.NVs = best.NVs; P.ret.kMax = best.kMax;
   P.ret.rowLen = rowLen; P.ret.nPen = (best.kMax + 1) * rowLen;
   P.retGv = best.gv;
@@ -2095,12 +2101,14 @@ static int launch_wide32(const WideProgram &P, const PairDesc *d_desc, long long
 }
 
 static int g_last_parts = 1;
+static bool g_last_jit = false;          // the last launch of this family ran the kernel generated for the machine (mb_wide_jit.cpp)
 const char *wide_kernel_name(const WideProgram &P) {
   if (P.retOk && g_last_parts > 1) {      // (asked after the launch)
     static thread_local char nm[64];
-    snprintf(nm, sizeof(nm), "k_wide_retimed<%s> in %d parts", P.viterbi ? (P.tbCodes ? "1,codes" : "1") : "0", g_last_parts);
+    snprintf(nm, sizeof(nm), "%s<%s> in %d parts", g_last_jit ? "k_wide_jit" : "k_wide_retimed", P.viterbi ? (P.tbCodes ? "1,codes" : "1") : "0", g_last_parts);
     return nm;
   }
+  if (P.retOk && g_last_jit) return P.viterbi ? (P.tbCodes ? "k_wide_jit<1,codes>" : "k_wide_jit<1>") : "k_wide_jit<0>";
   if (P.retOk) return P.retGv ? (P.viterbi ? "k_wide_retimed<1,L2>" : "k_wide_retimed<0,L2>") : (P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>");
   if (P.f32) return "k_wide_sum32";
   if (P.viterbi) return P.vitOk ? "k_wide_viterbi" : "k_wide_sweep<1>";
@@ -2163,6 +2171,7 @@ static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
     ps.period.push_back(hp[p].period); ps.slots.push_back(d.ret.nSlots);
     ps.modelCost = std::max(ps.modelCost, hp[p].modelCost);
   }
+  for (int p = 0; p < ps.k; ++p) { ps.h_stream.push_back(std::move(hp[p].stream)); ps.h_tab.push_back(std::move(hp[p].tab)); }      // (the generated kernel's tables are built from them on first use)
   if (!up_w(ps.d_parts, ps.h_parts)) return nullptr;
   if (!g_part_err) {
     if (!hip_ok(hipMalloc((void **)&g_part_err, 256), "hipMalloc(part status)") || !hip_ok(hipMemset(g_part_err, 0, 256), "hipMemset(part status)")) { g_part_err = nullptr; return nullptr; }
@@ -2204,6 +2213,35 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   if (env_int_w("MB_ONETAPE_PART_EXCLUSIVE", 1)) lds = std::max<size_t>(lds, 82 * 1024);
   if (lds > WIDE_LDS_MAX) { set_error("one-tape parts: LDS"); return 1; }
   const dim3 grid((unsigned)(nPairs * ps.k)), block((unsigned)ps.W);
+  // the sweep generated for this machine and this cut (mb_wide_jit.cpp); the interpreter below is the fallback
+  if (!A.dropExports && wide_jit_enabled() && (long long)rows * ps.nExpTot * 8 < (1ll << 40)) {
+    const bool acc = !P.viterbi && g_wide_accurate;
+    WideJitKernel &J = ps.jit[acc ? 1 : 0];
+    if (!J.tried) {
+      std::vector<WideJitIn> ins(ps.k);
+      for (int p = 0; p < ps.k; ++p) {
+        const WidePartDev &h = ps.h_parts[p];
+        WideJitIn &in = ins[p];
+        in.ret = h.ret; in.W = ps.W; in.stream = ps.h_stream[p].data();
+        in.w2 = ps.merge ? (const double *)((const char *)ps.h_stream[p].data() + h.w2Offset) : nullptr;
+        in.part = true; in.S = h.Sloc; in.Sg = m->S; in.nImp = h.nImp; in.expBase = h.expBase; in.nExp = h.nExp; in.expIdx0 = h.expIdx0; in.resultEntry = h.resultEntry;
+        in.gmap = ps.h_tab[p].data();
+      }
+      WideJitFlags F; F.viterbi = P.viterbi; F.tb = tb; F.acc = acc; F.backward = P.backward; F.inputTape = m->nOut == 0; F.nExpTot = ps.nExpTot;
+      if (!wide_jit_build(ins, F, J, &J.why) && getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (%d parts): interpreter kept -- %s\n", ps.k, J.why.c_str());
+    }
+    if (J.mod) {
+      for (int p = 0; p < ps.k; ++p) J.args.impIdx[p] = ps.h_parts[p].impIdx;
+      J.args.nSeq = A.nSeq; J.args.nExpTot = A.nExpTot; J.args.X = A.X; J.args.xOff = A.xOff; J.args.err = A.err; J.args.timeoutTicks = A.timeoutTicks;
+      if (wide_jit_launch(J, dev, grid.x, lds, d_desc, d_tape, pool, loglike, st)) return 1;
+      g_last_launches += 1;
+      g_last_parts = ps.k;
+      g_parts_pending = true;
+      g_last_jit = true;
+      return 0;
+    }
+  }
+  g_last_jit = false;
 #define WIDE_PART_GO(M, T, AC, W2F) do { \
     static bool attr = false; \
     if (!attr) { MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed_parts<M, T, AC, W2F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX)); attr = true; } \
@@ -2257,6 +2295,20 @@ int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cu
   return ps ? ps->k : 1;
 }
 
+// the generated kernel of the ONE-workgroup retimed program (ring in LDS), built on first use; nullptr: the interpreter keeps the program
+static WideJitKernel *wide_jit_one(const mb_machine *m, WideProgram &P, bool tb, bool acc) {
+  if (!P.retOk || P.retGv || P.h_ret.empty() || !wide_jit_enabled()) return nullptr;
+  WideJitKernel &J = P.jit[acc ? 1 : 0];
+  if (!J.tried) {
+    std::vector<WideJitIn> ins(1);
+    WideJitIn &in = ins[0];
+    in.ret = P.ret; in.W = P.W; in.stream = P.h_ret.data(); in.S = m->S; in.Sg = m->S; in.resultEntry = P.dev.resultIdx;
+    WideJitFlags F; F.viterbi = P.viterbi; F.tb = tb; F.acc = acc; F.backward = P.backward; F.inputTape = m->nOut == 0;
+    if (!wide_jit_build(ins, F, J, &J.why) && getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (one workgroup per sequence): interpreter kept -- %s\n", J.why.c_str());
+  }
+  return J.mod ? &J : nullptr;
+}
+
 int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long long nPairs, const int *d_tape, double *pool,
               double *loglike, hipStream_t st, bool lastOnly, const PairDesc *h_desc, int cus) {
   const int *d_out = d_tape;       // the token array of the machine's one tape (outputs of a generator, inputs of a recogniser)
@@ -2266,11 +2318,21 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
   // sweep direction, so that a Forward and a Backward sweep may run side by side on two streams); nothing here waits for
   // the device
   const int scratchSlot = P.backward ? 12 : 11;
-  g_last_parts = 1;
+  g_last_parts = 1; g_last_jit = false;
   if (P.retOk && h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
     if (ps && wide_parts_fit(m, *ps, h_desc, nPairs)) return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, pool, loglike, st, lastOnly, false);
+  }
+  if (P.retOk && !P.retGv) {
+    const bool acc = g_wide_accurate && !P.viterbi;
+    if (WideJitKernel *J = wide_jit_one(m, P, false, acc)) {
+      WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0;
+      if (wide_jit_launch(*J, dev, (unsigned)nPairs, 0, d_desc, d_out, pool, loglike, st)) return 1;
+      g_last_launches += 1;
+      g_last_jit = true;
+      return 0;
+    }
   }
   if (P.retOk) {
     static bool attr = false;
@@ -2340,13 +2402,20 @@ int wide_fill_tb(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, lo
                  double *loglike, hipStream_t st, const PairDesc *h_desc, int cus) {
   if (!P.ok || !P.retOk || !P.tbOk || !P.viterbi || P.backward) { set_error("one-tape traceback-code program not built"); return 1; }
   if (nPairs <= 0) return 0;
-  g_last_parts = 1;
+  g_last_parts = 1; g_last_jit = false;
   if (h_desc && wide_parts_worth(m, P, h_desc, nPairs)) {
     const int k = wide_parts_k(P, nPairs, cus);
     WidePartSet *ps = k >= 2 ? wide_parts_get(m, P, k) : nullptr;
     if (ps && wide_parts_fit(m, *ps, h_desc, nPairs)) { P.tbFromSet = (int)(ps - P.partSets.data()); return wide_fill_parts(m, P, *ps, d_desc, h_desc, nPairs, d_tape, (double *)tb, loglike, st, false, true); }
   }
   P.tbFromSet = -1;
+  if (WideJitKernel *J = wide_jit_one(m, P, true, false)) {
+    WideDev dev = P.dev; dev.lastOnly = 0;
+    if (wide_jit_launch(*J, dev, (unsigned)nPairs, 0, d_desc, d_tape, (double *)tb, loglike, st)) return 1;
+    g_last_launches += 1;
+    g_last_jit = true;
+    return 0;
+  }
   static bool attr = false;
   if (!attr) {
     MB_HIP(hipFuncSetAttribute((const void *)k_wide_retimed<MB_VITERBI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_MAX));

@@ -23,10 +23,15 @@ FAST_REL = 2e-6     # tiled families: fp32 exp/log correction term, ~1e-7 abs pe
 FAST_ABS = 2e-5
 
 
+def _kn(name):
+    """kernel name with the sweep GENERATED for the machine (k_wide_jit, mb_wide_jit.cpp) spelled like the interpreter it replaces"""
+    return name.replace("k_wide_jit", "k_wide_retimed")
+
+
 def _one_wg(name):
     """kernel name without the ' in k parts' of a sweep that ran k workgroups per sequence"""
     import re
-    return re.sub(r" in \d+ parts", "", name)
+    return re.sub(r" in \d+ parts", "", _kn(name))
 ABS_TABLE = 1e-4    # vs the reference's table build: the table drops terms >= 10 nats below the running max and
 REL_TABLE = 1e-4    # interpolates at step 1e-4 (src/logsumexp.h:20-21,48-70); 1e-4 relative is the north-star tolerance
 COUNT_TOL = 1e-9
@@ -522,7 +527,7 @@ def test_baseline_config5_one_sequence_at_50kb_against_the_oracle(capi, oracle_m
     assert close([llr[0], llp[0], llm[0]], [ref] * 3, FAST_REL, FAST_ABS)
     assert close(llr, [om.loglike(x, y, oracle_mod.SUM_TABLE)], REL_TABLE, ABS_TABLE)
     V = om.viterbi(x, y)
-    Vd = dm.fill(capi.MB_VITERBI, x, y); assert capi.last_kernel_name().startswith("k_wide_retimed<1")
+    Vd = dm.fill(capi.MB_VITERBI, x, y); assert _kn(capi.last_kernel_name()).startswith("k_wide_retimed<1")
     assert np.array_equal(Vd, V)
     Vd_end = float(Vd[-1, -1, -1])
     del Vd
@@ -1356,13 +1361,13 @@ def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
         ref = np.zeros(em.nTransitions)
         for x, y in pairs:
             V = dm.fill(capi.MB_VITERBI, x, y); assert _one_wg(capi.last_kernel_name()) == ("k_wide_retimed<1,L2>" if "MB_WIDE_GLOBAL_VECTORS" in knobs else "k_wide_retimed<1>")
-            F = dm.fill(capi.MB_FORWARD, x, y); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
+            F = dm.fill(capi.MB_FORWARD, x, y); assert _kn(capi.last_kernel_name()).startswith("k_wide_retimed<0")
             B = dm.fill(capi.MB_BACKWARD, x, y)
             assert np.array_equal(V, om.viterbi(x, y))
             assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS) and close(B, om.backward(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
             if F[-1, -1, -1] > -math.inf: om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
         b = capi.DeviceBatch.from_pairs(dm, pairs)
-        ll = b.forward(capi.MB_ROLLING); assert capi.last_kernel_name().startswith("k_wide_retimed<0")
+        ll = b.forward(capi.MB_ROLLING); assert _kn(capi.last_kernel_name()).startswith("k_wide_retimed<0")
         vll, off, edges = b.viterbi()
         # (paths: one traceback CODE per cell kept by the max sweep, walked by k_onetape_traceback_codes -- round 4, the default since the
         # code sweep's reduction became two butterflies -- or, MB_ONETAPE_TB=0, the fp64 matrix and its walkers)
@@ -1398,7 +1403,7 @@ def test_one_tape_retimed_single_stage_period(capi, oracle_mod, tmp_path):
         z = np.zeros(0, np.int32)
         ys = [np.random.RandomState(300 + n).randint(1, 5, size=n).astype(np.int32) for n in (1, 9, 70, 200)]
         for y in ys:
-            V = dm.fill(capi.MB_VITERBI, z, y); assert capi.last_kernel_name().startswith("k_wide_retimed<1")
+            V = dm.fill(capi.MB_VITERBI, z, y); assert _kn(capi.last_kernel_name()).startswith("k_wide_retimed<1")
             assert np.array_equal(V, om.viterbi(z, y))
             assert close(dm.fill(capi.MB_FORWARD, z, y), om.forward(z, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
             assert close(dm.fill(capi.MB_BACKWARD, z, y), om.backward(z, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
@@ -1548,7 +1553,7 @@ def test_one_tape_k_workgroups_per_sequence(capi, oracle_mod, monkeypatch, knobs
     dmk = capi.DeviceMachine(em)
     got = run(dmk)
     want = int(knobs.get("MB_ONETAPE_PARTS", "8"))      # (the default cap of a machine whose ring fits one CU)
-    sweeps = [n for n in got["names"] if "k_wide_retimed" in n]
+    sweeps = [n for n in got["names"] if "k_wide_retimed" in n or "k_wide_jit" in n]      # (k_wide_jit: the sweep generated for this machine and this cut, mb_wide_jit.cpp)
     assert sweeps and all(" parts" in n for n in sweeps if not (want == 2 and "<1" in n and "MB_ONETAPE_PARTS" not in knobs)), got["names"]
     assert any("in %d parts" % want in n for n in sweeps) or want == 7, got["names"]      # (a cut may come out with fewer parts than asked for)
     # bit for bit against the one-workgroup sweep
@@ -1642,7 +1647,7 @@ def test_baseline_config5_full_size_properties(capi, oracle_mod, monkeypatch, no
     llr = b.forward(capi.MB_ROLLING)
     kern = capi.last_kernel_name()
     import re
-    assert kern.startswith("k_wide_retimed<0>") and (nodes == 20 or re.match(r"k_wide_retimed<0> in \d+ parts", kern))      # (21 761 states: one workgroup keeps its ring in L2, the parts of eight sequences keep theirs in LDS)   # (+ " x2 + k_onetape_join": few sequences are cut in two)
+    assert re.match(r"k_wide_(retimed|jit)<0>", kern) and (nodes == 20 or re.match(r"k_wide_(retimed|jit)<0> in \d+ parts", kern))      # (21 761 states: one workgroup keeps its ring in L2, the parts of eight sequences keep theirs in LDS)   # (+ " x2 + k_onetape_join": few sequences are cut in two)
     nm = min(nSeq, 4)                                                            # matrices of a few sequences (21 761 x 301 doubles each)
     bm = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys[:nm]])
     llm = bm.forward(capi.MB_MATERIALISE)

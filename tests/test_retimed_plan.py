@@ -314,6 +314,260 @@ def test_k_part_programs_reproduce_the_oracle(name, k, lanes, tmp_path):
         if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_codes(tabs, codes, n), om.traceback(x, y, V))
 
 
+# ---- the sweep GENERATED per machine (mb_wide_jit.cpp): what the source unrolls, replayed -------------------------------------------
+WJ_W, WJ_W2, WJ_ADDR, WJ_PEN, WJ_DST, WJ_KQ, WJ_GX, WJ_XO, WJ_GL = range(9)
+
+
+def simulate_jit(prog, seq, backward, mode_max, tb=False, shared=None, S=None):
+    """One part of a generated kernel (capi.debug_wide_jit) replayed from its per-lane constant table -- and, for a streamed program, its
+    packed address words -- with the data flow of the generated source: LDS as one array of doubles addressed in BYTES (penalty tables
+    first, the ring behind them), a period per rotation of the ring, a round's slots folded into `(lds[addr] + (w + lds[pen])) + w2`, the
+    lane groups reduced by the ladder the round's switch would pick for the wavefront (its first lane's word), every lane storing to its
+    destination (the dummy entry for lanes without a node).  shared = (X, cells, codes, loglike): a part; None: the whole machine."""
+    W, NB, NVs, kMax, rowLen, nPen, nImp = (prog[k] for k in ("lanes", "NB", "NVs", "kMax", "rowLen", "nPen", "nImp"))
+    NPT, U, ringBase, dummy = prog["NPT"], prog["U"], prog["ringBase"], prog["dummyAddr"]
+    nPenAll = nPen + nImp
+    L = len(seq)
+    tab = prog["table"]
+    cons = {}
+    k = 0
+    for kind, index, cm, words in prog["fields"]:
+        if words == 2: cons[(kind, index, cm)] = (tab[k].astype(np.uint64) | (tab[k + 1].astype(np.uint64) << np.uint64(32))).view(np.float64)
+        else: cons[(kind, index, cm)] = tab[k].astype(np.int64)
+        k += words
+    assert k == prog["nWords"]
+    streamed = prog["level"] >= 1
+    if streamed:      # the items of a period in execution order: a round's slots, then its destination word
+        order = []
+        for r, R in enumerate(prog["rounds"]):
+            order += [("a", R["firstSlot"] + q) for q in range(R["depth"])] + [("d", r)]
+        assert len(order) <= prog["IP"] and prog["IP"] % prog["ring"] == 0
+        pos = {it: i for i, it in enumerate(order)}
+    lds = np.full(prog["ldsBytes"] // 8, np.nan)
+    at = lambda a: (np.asarray(a) >> 3)
+    lds[ringBase // 8: ringBase // 8 + NB * NVs] = -np.inf
+    Sown = prog["Sloc"]
+    for b in range(NB): lds[ringBase // 8 + b * NVs + Sown + 1] = 0.0
+    if shared: X, cells, codes, llout = shared
+    else:
+        X = None; cells = np.full((L + 1, Sown), np.nan); codes = np.full((L + 1, Sown), -1, np.int64); llout = [None]
+    tok_at = lambda c: (int(seq[L - c]) if backward else int(seq[c - 1])) if 1 <= c <= L else 0
+    def write_pen(table, newest):      # what the first lanes write one period ahead (and the last lanes: the imports of column `newest`)
+        base = table * nPenAll
+        for e in range(nPen):
+            kt, col = divmod(e, rowLen); c = newest - kt
+            ok = col == 0 or (c == 0 if col == rowLen - 1 else (c >= 1 and tok_at(c) == col))
+            lds[base + e] = 0.0 if ok else -np.inf
+        if nImp:
+            imp = X[newest, prog["impIdx"]] if newest <= L else np.full(nImp, -np.inf)
+            assert not np.any(np.isnan(imp)), "an import is read before an earlier part wrote it"
+            lds[base + nPen: base + nPen + nImp] = imp
+    write_pen(0, 0)
+    lanes = np.arange(W)
+    for t in range(L + 1 + kMax):
+        cm, pt = t % NB, t % NPT
+        assert (t % U) % NB == cm and (t % U) % NPT == pt
+        write_pen((t + 1) % NPT, t + 1)
+        penOff = pt * nPenAll * 8
+        for r, R in enumerate(prog["rounds"]):
+            m = None; ssum = None; best = np.zeros(W, np.int64)
+            for q in range(R["depth"]):
+                j = R["firstSlot"] + q
+                anyPen, anyW2 = prog["slots"][j]
+                if streamed:
+                    x = prog["stream"][cm][pos[("a", j)]].astype(np.int64)
+                    addr, pen = x >> 14, (x & 0x3FFF)
+                else:
+                    addr = cons[(WJ_ADDR, j, cm)]; pen = cons.get((WJ_PEN, j, 0))
+                assert np.all(addr % 8 == 0) and np.all(addr >= ringBase) and np.all(addr < dummy)
+                w = cons[(WJ_W, j, 0)]
+                v = lds[at(addr)]
+                assert not np.any(np.isnan(v))
+                if anyPen:
+                    pv = lds[at(pen + penOff)]
+                    assert not np.any(np.isnan(pv))
+                    cand = v + (w + pv)
+                else: cand = v + w
+                if anyW2: cand = cand + cons[(WJ_W2, j, 0)]
+                if mode_max:
+                    if q == 0: m = cand.copy()
+                    else:
+                        if tb: best = np.where(cand > m, q, best)
+                        m = np.maximum(m, cand)
+                else:
+                    if m is None: m = np.full(W, -np.inf); ssum = np.zeros(W)
+                    new = np.maximum(m, cand)
+                    with np.errstate(invalid="ignore"):
+                        ssum = np.where(np.isneginf(new), 0.0, ssum * np.exp(np.where(np.isneginf(m), -np.inf, m - new)) + np.exp(np.where(np.isneginf(cand), -np.inf, cand - new)))
+                    m = new
+            # the ladder: uniform rounds a literal group size; else the wavefront's first lane selects (log2 of its largest group, | 8: masked)
+            if R["uniform"]: gl = None; glane = np.full(W, R["gAll"])
+            else:
+                gl = cons[(WJ_GL, r, 0)]; glane = np.empty(W, np.int64)
+                for w0 in range(0, W, 64):
+                    head = int(gl[w0]); gw = 1 << (head & 7)
+                    if not (R["gMask"] & gw): glane[w0:w0 + 64] = 1; continue      # (no case for it: the switch falls through, nothing is reduced)
+                    glane[w0:w0 + 64] = (1 << (gl[w0:w0 + 64] & 7)) if (head & 8 or tb) else gw
+                    assert np.all((1 << (gl[w0:w0 + 64] & 7)) <= gw)
+            res = np.empty(W); key = np.zeros(W, np.int64)
+            for l in range(W):
+                g = int(glane[l]); l0 = l - l % g
+                grp = slice(l0, l0 + g)
+                if mode_max:
+                    res[l] = np.max(m[grp])
+                    if tb:
+                        lg = int(g).bit_length() - 1 if R["uniform"] else int(gl[l] & 7)
+                        own = (best[grp] << lg) | (lanes[grp] & ((1 << lg) - 1))
+                        key[l] = int(np.min(own[m[grp] == res[l]]))
+                else:
+                    mx = float(np.max(m[grp]))
+                    res[l] = -math.inf if mx == -math.inf else mx + math.log(float(np.sum(ssum[grp] * np.exp(np.where(np.isneginf(m[grp]), -np.inf, m[grp] - mx)))))
+            if streamed:
+                dw = prog["stream"][cm][pos[("d", r)]].astype(np.int64); dst = dw & 0x3FFFF; kq = dw >> 18
+            else:
+                dst = cons[(WJ_DST, r, cm)]; kq = cons.get((WJ_KQ, r, 0))
+            real = dst != dummy
+            assert np.all(dst[real] >= ringBase) and np.all(dst[real] < dummy) and len(set(dst[real].tolist())) == int(real.sum())      # one lane per entry
+            lds[at(dst[real])] = res[real]
+            gx, xo = cons.get((WJ_GX, r, 0)), cons.get((WJ_XO, r, 0))
+            if kq is not None:
+                c = (t - kq) if backward else (t - kMax + kq)
+                ok = (c >= 0) & (c <= L)
+                if xo is not None:
+                    for l in np.nonzero((xo != 0xFFFFFFFF) & ok)[0]:
+                        e = int(xo[l]) // 8
+                        assert np.isnan(X[c[l], e]); X[c[l], e] = res[l]
+                if gx is not None:
+                    for l in np.nonzero((gx != 0xFFFFFFFF) & ok)[0]:
+                        col = int(gx[l]) if tb else int(gx[l]) // 8
+                        row = L - c[l] if backward else c[l]
+                        assert real[l] and np.isnan(cells[row, col])      # every cell exactly once
+                        cells[row, col] = res[l]
+                        if tb: assert 0 <= key[l] < 256; codes[c[l], col] = key[l]
+                if R["resultLane"] >= 0 and c[R["resultLane"]] == L: llout[0] = float(res[R["resultLane"]])
+            else: assert gx is None and xo is None and R["resultLane"] < 0
+            assert R["sync"] or r + 1 < len(prog["rounds"])
+    if shared: return None
+    assert not np.any(np.isnan(cells)) and llout[0] is not None
+    return (cells, codes, llout[0]) if tb else (cells, llout[0])
+
+
+def simulate_jit_parts(jp, seq, backward, mode_max, tb=False):
+    L = len(seq); S = jp["S"]
+    X = np.full((L + 1, max(jp["nExp"], 1)), np.nan)
+    cells = np.full((L + 1, S), np.nan); codes = np.full((L + 1, S), -1, np.int64); ll = [None]
+    for p in jp["parts"]: simulate_jit(p, seq, backward, mode_max, tb, shared=(X, cells, codes, ll))
+    assert not np.any(np.isnan(cells)) and not np.any(np.isnan(X[:, :jp["nExp"]])) and ll[0] is not None
+    return (cells, codes, ll[0]) if tb else (cells, ll[0])
+
+
+@pytest.mark.parametrize("name", ["tiny", "fn3-10", "composite-2", "random-40", "random-recogniser-25"])
+@pytest.mark.parametrize("level", [0, 1])
+def test_generated_one_workgroup_program_reproduces_the_oracle(name, level, monkeypatch, tmp_path):
+    """The kernel generated for a machine (mb_wide_jit.cpp), WITHOUT a device: its unrolled program -- rounds, slots,
+    the per-lane constant table, the packed address words of the streamed form -- replayed with the generated source's data flow gives the
+    oracle's Viterbi cells bit for bit, Forward / Backward cells to 1e-12, the log-likelihood from the result lane, and traceback codes
+    that walk into the oracle's paths.  level 0: every constant in registers; 1: rotation-dependent words streamed."""
+    from machineboss_amd import capi
+    from oracle import oracle
+    em = _machines()[name]
+    tape_out = em.nOutTok > 0
+    nt = em.nOutTok if tape_out else em.nInTok
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    monkeypatch.setenv("MB_WIDE_JIT_LEVEL", str(level))
+    for mode, backward in ((capi.MB_VITERBI, False), (capi.MB_FORWARD, False), (capi.MB_FORWARD, True)):
+        jp = capi.debug_wide_jit(em, str(tmp_path / "j.hip"), k=1, mode=mode, backward=backward)
+        part = jp["parts"][0]
+        assert part["level"] == level and part["Sloc"] == em.nStates and part["ldsBytes"] <= 160 * 1024
+        src = open(str(tmp_path / "j.hip")).read()
+        assert "k_wide_jit" in src and src.count("part_0(") == 2
+        for n in (0, 1, 9, 70 if part["lanes"] * part["nSlots"] <= 4096 else 20):
+            seq = np.random.RandomState(n + 3).randint(1, nt + 1, size=n).astype(np.int32)
+            x, y = (z, seq) if tape_out else (seq, z)
+            got, ll = simulate_jit(part, seq, backward, mode == capi.MB_VITERBI)
+            if mode == capi.MB_VITERBI: ref = om.viterbi(x, y)
+            else: ref = om.backward(x, y, oracle.SUM_EXACT) if backward else om.forward(x, y, oracle.SUM_EXACT)
+            ref = ref.reshape(n + 1, em.nStates)
+            end = ref[0, 0] if backward else ref[n, em.nStates - 1]
+            if mode == capi.MB_VITERBI: assert np.array_equal(got, ref) and ll == end
+            else:
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+                assert (ll == end) or abs(ll - end) <= 1e-12 * abs(end)
+    # traceback codes through the generated program, decoded with the interpreter program's tables (the candidate lists are the same)
+    try:
+        jt = capi.debug_wide_jit(em, str(tmp_path / "jt.hip"), k=1, mode=capi.MB_VITERBI, tb_codes=True)
+        tabs = capi.debug_wide_retimed(em, str(tmp_path / "tb.bin"), capi.MB_VITERBI, False, tb_codes=True)
+    except RuntimeError:
+        return
+    for n in (9, 33):
+        seq = np.random.RandomState(n + 5).randint(1, nt + 1, size=n).astype(np.int32)
+        x, y = (z, seq) if tape_out else (seq, z)
+        cells, codes, ll = simulate_jit(jt["parts"][0], seq, False, True, tb=True)
+        V = om.viterbi(x, y)
+        assert np.array_equal(cells, V.reshape(n + 1, em.nStates))
+        if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_codes(tabs, codes, n), om.traceback(x, y, V))
+
+
+@pytest.mark.parametrize("name", ["fn3-10", "composite-2", "random-40"])
+@pytest.mark.parametrize("k,lanes,level", [(2, 256, 0), (3, 64, 1), (4, 1024, 0)])
+def test_generated_k_part_programs_reproduce_the_oracle(name, k, lanes, level, monkeypatch, tmp_path):
+    """... and the k-part form (one function per part in one kernel, values crossing through the exchange array): replayed part by part in
+    workgroup order, against the oracle; the traceback codes decode with the joined tables of the parts' own candidate lists."""
+    from machineboss_amd import capi
+    from oracle import oracle
+    em = _machines()[name]
+    tape_out = em.nOutTok > 0
+    nt = em.nOutTok if tape_out else em.nInTok
+    om = oracle.OracleMachine(em)
+    z = np.zeros(0, np.int32)
+    monkeypatch.setenv("MB_WIDE_JIT_LEVEL", str(level))
+    try:
+        capi.debug_wide_jit(em, str(tmp_path / "j.hip"), k=k, lanes=lanes, mode=capi.MB_VITERBI)
+    except RuntimeError as e:
+        assert name.startswith("random") and "no k-part" in str(e)
+        pytest.skip("the machine's graph has no cut")
+    for mode, backward in ((capi.MB_VITERBI, False), (capi.MB_FORWARD, False), (capi.MB_FORWARD, True)):
+        jp = capi.debug_wide_jit(em, str(tmp_path / "j.hip"), k=k, lanes=lanes, mode=mode, backward=backward)
+        assert 2 <= len(jp["parts"]) <= k and all(p["level"] == level for p in jp["parts"])
+        for n in (0, 1, 9, 70 if max(p["lanes"] * p["nSlots"] for p in jp["parts"]) <= 4096 else 20):
+            seq = np.random.RandomState(n + 3).randint(1, nt + 1, size=n).astype(np.int32)
+            x, y = (z, seq) if tape_out else (seq, z)
+            got, ll = simulate_jit_parts(jp, seq, backward, mode == capi.MB_VITERBI)
+            if mode == capi.MB_VITERBI: ref = om.viterbi(x, y)
+            else: ref = om.backward(x, y, oracle.SUM_EXACT) if backward else om.forward(x, y, oracle.SUM_EXACT)
+            ref = ref.reshape(n + 1, em.nStates)
+            if mode == capi.MB_VITERBI: assert np.array_equal(got, ref)
+            else:
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+    try:
+        jt = capi.debug_wide_jit(em, str(tmp_path / "jt.hip"), k=k, lanes=lanes, mode=capi.MB_VITERBI, tb_codes=True)
+        pt = capi.debug_wide_parts(em, str(tmp_path / "pt.bin"), k, lanes, capi.MB_VITERBI, False, tb_codes=True)
+    except RuntimeError:
+        return
+    for n in (9, 33):
+        seq = np.random.RandomState(n + 5).randint(1, nt + 1, size=n).astype(np.int32)
+        x, y = (z, seq) if tape_out else (seq, z)
+        cells, codes, ll = simulate_jit_parts(jt, seq, False, True, tb=True)
+        V = om.viterbi(x, y)
+        assert np.array_equal(cells, V.reshape(n + 1, em.nStates))
+        tabs = {"S": em.nStates, "tbOff": pt["tbOff"], "tbEntry": pt["tbEntry"], "inEid": pt["inEid"]}
+        if V.reshape(-1)[-1] > -math.inf: assert np.array_equal(walk_codes(tabs, codes, n), om.traceback(x, y, V))
+
+
+def test_generated_source_compiles_without_a_device(tmp_path):
+    """hiprtc needs no GPU: the source generated for a cut machine (sum semiring with the fp64 correction term, max semiring with
+    traceback codes) compiles for gfx950 and keeps its constants in registers (no scratch memory)."""
+    from machineboss_amd import capi
+    em = _machines()["composite-2"]
+    for kw in (dict(mode=capi.MB_FORWARD, acc=True), dict(mode=capi.MB_VITERBI, tb_codes=True), dict(mode=capi.MB_FORWARD, backward=True)):
+        jp = capi.debug_wide_jit(em, str(tmp_path / "c.hip"), k=3, lanes=256, compile=True, **kw)
+        assert len(jp["parts"]) >= 2
+    capi.debug_wide_jit(em, str(tmp_path / "c1.hip"), k=1, mode=capi.MB_VITERBI, compile=True)
+
+
 def test_retimed_program_refuses_two_tape_machines(tmp_path):
     from machineboss_amd import capi
     em = random_machine(12, 2, 2, 5, density=1.5, silent_density=1.0, allow_inf=False)
