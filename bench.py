@@ -494,6 +494,45 @@ def extra_single_gpu(capi, np, hbm_peak):
     return out
 
 
+def extra_train(capi, np):
+    """`boss --train` end to end at N = 1 (VERDICT r5 missing 3; src/fitter.cpp:23-47): wall clock of a full Baum-Welch iteration -- weight
+    expressions evaluated, mb_machine_set_weights (for a one-tape machine cut for k workgroups: the parts re-planned), E-step, M-step --
+    on config 3 per GPU (protpsw, 1 024 x 400 x 400 aa) and on config 5's 5 063-state machine at 64 x 2 kb.  The first iteration
+    carries the upload, the kernel specialisation and the tokenisation; `steady` is the mean of the later ones."""
+    from machineboss_amd import fitter as F, algebra as A
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    from machineboss_amd.seqpair import SeqPair
+    from machineboss_amd.seqgen import synth_tokens
+    P = lambda n: Machine.fromFile(os.path.join(ROOT, "tests", "golden", "preset", n + ".json"))
+    out = {}
+    keep = (F.MaxEMIterations, F.MinEMImprovement)
+    F.MaxEMIterations, F.MinEMImprovement = 3, -1e300      # a bounded run: four E-steps, three M-steps
+    try:
+        for name, m, nPairs, inLen, outLen in (("config3", P("protpsw"), 1024, 400, 400),
+                                                ("config5_2kb", A.composeLeftToRight([HmmerModel.fromFile(os.path.join(ROOT, "tests", "golden", "hmmer", "fn3.hmm")).truncated(20).machine(True),
+                                                                                      P("simple_introns"), P("translate"), P("dnapsw")]), 64, 0, 2000)):
+            em0 = EvaluatedMachine.fromMachine(m, None, useDefaults=True)
+            data = []
+            for k in range(nPairs):
+                x, y = synth_tokens(3000 + k, inLen, outLen, max(em0.nInTok, 1), em0.nOutTok)
+                data.append(SeqPair(em0.inputTokenizer.detokenize(x) if em0.nInTok else [], em0.outputTokenizer.detokenize(y)))
+            fit = F.MachineFitter(m)
+            t0 = time.perf_counter(); fit.fit(data); dt = time.perf_counter() - t0
+            tl = fit.timing
+            mean = lambda key: round(sum(t.get(key, 0.0) for t in tl[1:]) / max(len(tl) - 1, 1), 2)
+            steady = {k_: mean(k_) for k_ in ("eval_ms", "set_weights_ms", "estep_ms", "estep_device_ms", "mstep_ms")}
+            steady["iteration_ms"] = round(sum(steady[k_] for k_ in ("eval_ms", "set_weights_ms", "estep_ms", "mstep_ms")), 2)
+            cells = nPairs * (inLen + 1) * (outLen + 1) * em0.nStates
+            out[name] = {"workload": "%d states, %d transitions, %d pairs x %d x %d" % (em0.nStates, em0.nTransitions, nPairs, inLen, outLen), "iterations": len(tl), "total_s": round(dt, 2),
+                         "first_iteration_ms": {k_: round(v, 2) for k_, v in tl[0].items()}, "steady": steady,
+                         "lattice_gcells_per_s_end_to_end": round(cells / (steady["iteration_ms"] / 1e3) / 1e9, 2), "loglike": [round(x, 4) for x in fit.log]}
+    finally:
+        F.MaxEMIterations, F.MinEMImprovement = keep
+    return out
+
+
 def extra_dropin(capi, np, quick=False):
     """The boundary as the REFERENCE'S OWN CALLERS drive it: tests/cxx/dropin.cpp runs the `--loglike` loop of
     target/boss.cpp:796-800 and the `--viterbi / --align` loop of :826-833 exactly as written there -- one matrix object per pair --
@@ -742,6 +781,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and not args.extra_em_only:
         extra.update(extra_single_gpu(capi, np, HBM_PEAK_GBS))
         try:
+            extra["train"] = extra_train(capi, np)
+        except Exception as e:
+            extra["train"] = {"error": str(e)}
+        try:
             extra["dropin"] = extra_dropin(capi, np)
         except Exception as e:
             extra["dropin"] = {"error": str(e)}
@@ -821,6 +864,7 @@ def main():
                               "config4b_forward_materialised": _rf("config4b", "forward_materialised"), "config4b_counts": _rf("config4b", "counts_lattice", "roofline_counts"),
                               "nonuniform_forward_materialised": [(extra.get("nonuniform") or {}).get("forward_materialised"), ((extra.get("nonuniform") or {}).get("roofline") or {}).get("frac")],
                               "host_overhead_flags": out.get("host_overhead_flags"),
+                              "train_iteration_ms_config3_config5_2kb": [((extra.get("train") or {}).get(k_) or {}).get("steady", {}).get("iteration_ms") for k_ in ("config3", "config5_2kb")],
                               "config5_50kb_forward_viterbi_withpaths": [((extra.get("config5") or {}).get("full_size") or {}).get(k) for k in ("forward_rolling", "viterbi_fill", "viterbi_with_paths")],
                               "unit": "G cells/s (counts: G lattice-cells/s), fraction of 8 TB/s at the mode's algorithmic bytes"}
         print(json.dumps(out))

@@ -6,6 +6,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -29,6 +31,19 @@ size_t g_mem_budget = 0;
 static bool g_init = false;
 
 void set_error(const std::string &msg) { g_err = msg; }
+
+// the library's own option table (mb_set_option); readers run inside API calls, under the API lock
+static std::map<std::string, std::string> g_options;
+const char *opt_env(const char *name) {
+  if (!g_options.empty()) {
+    auto it = g_options.find(name);
+    if (it != g_options.end()) return it->second.c_str();
+  }
+  return getenv(name);
+}
+void opt_set(const char *name, const char *value) {
+  if (value && *value) g_options[name] = value; else g_options.erase(name);
+}
 
 bool hip_ok(hipError_t e, const char *what) {
   if (e == hipSuccess) return true;
@@ -235,7 +250,7 @@ static void ws_release() {
 }
 
 static int env_flag_default(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 
@@ -252,7 +267,7 @@ size_t budget_bytes() {
   static size_t sticky = 0;
   static double stickyFrac = 0.0;
   double frac = 0.80;
-  if (const char *e = getenv("MB_MEM_FRACTION")) { const double f = atof(e); if (f > 0.0 && f <= 0.95) frac = f; }
+  if (const char *e = opt_env("MB_MEM_FRACTION")) { const double f = atof(e); if (f > 0.0 && f <= 0.95) frac = f; }
   const size_t cur = (size_t)((double)(freeB + cached_bytes()) * frac);
   if (!sticky || frac != stickyFrac || cur < sticky || cur > sticky + sticky / 8 || !env_flag_default("MB_POOL_STICKY", 1)) { sticky = cur; stickyFrac = frac; }
   return sticky;
@@ -375,7 +390,7 @@ struct FastState {
 };
 
 static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 
@@ -420,7 +435,7 @@ static FastState *fast_state(mb_machine *m) {
         if (forced >= 0) return forced;
         if (!wantClosure) return 0;
         const int nLev = backward ? m->nLevB : m->nLevF;
-        const bool verbose = getenv("MB_MEDIUM_JIT_VERBOSE") != nullptr;
+        const bool verbose = opt_env("MB_MEDIUM_JIT_VERBOSE") != nullptr;
         auto tryBuild = [&](int K, const std::vector<int> &cs, long long &c) {
           MedProgram P; MedGeom g;
           medium_set_cuts(cs);
@@ -437,7 +452,7 @@ static FastState *fast_state(mb_machine *m) {
           if (verbose) fprintf(stderr, "[mbhip] %s program, closure stages %d: cost %lld\n", backward ? "backward" : "forward", K, c);
           if (best < 0 || c < best) { best = c; bestK = K; }
         }
-        if (env_int("MB_MEDIUM_CUTS_SEARCH", 1) && nLev > 2 && !getenv("MB_MEDIUM_CUTS")) {
+        if (env_int("MB_MEDIUM_CUTS_SEARCH", 1) && nLev > 2 && !opt_env("MB_MEDIUM_CUTS")) {
           std::vector<int> cur;
           long long curCost;
           if (tryBuild(1, {}, curCost)) {
@@ -720,7 +735,7 @@ static int small_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
   int rc = 0;
   Timer tm;
   long long written = 0;
-  const bool timing = getenv("MB_TIMING") != nullptr;
+  const bool timing = opt_env("MB_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tPrev = now();
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip] viterbi %-28s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
@@ -967,8 +982,7 @@ int mb_machine_sweep_ops(mb_machine *m, double *expPerCell, double *logPerCell, 
 int mb_set_option(const char *name, const char *value) {
   ApiLock lock;
   if (!name || strncmp(name, "MB_", 3) != 0) { set_error("mb_set_option: option names start with MB_"); return 1; }
-  const int rc = (value && *value) ? setenv(name, value, 1) : unsetenv(name);
-  if (rc) { set_error("mb_set_option: cannot set option"); return 1; }
+  opt_set(name, value);      // (the library's table: the process environment is the host's, not ours to write)
   return 0;
 }
 
@@ -980,7 +994,7 @@ const char *mb_get_option(const char *name) {
     v = std::to_string(medium_inplace_kernels());
     return v.c_str();
   }
-  return getenv(name);
+  return opt_env(name);
 }
 
 mb_machine *mb_machine_create(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t nTrans, const uint32_t *src,
@@ -1307,10 +1321,22 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
   return rc;
 }
 
+// A one-tape sweep with k workgroups per sequence whose exchange timed out (the device is shared, a CU mask is set: the parts were
+// not co-resident) has latched its programs to one workgroup per sequence: the call is run once more instead of failing.
+static int with_parts_retry(const std::function<int()> &run) {
+  int rc = run();
+  if (rc > 0 && wide_parts_retry()) {
+    (void)hipStreamSynchronize(g_stream);
+    rc = run();
+  }
+  if (rc) wide_parts_reset();
+  return rc;
+}
+
 int mb_batch_forward(mb_batch *b, int flags, double *loglike) {
   ApiGuard guard;
   if (!b || !loglike) { set_error("null argument"); return 1; }
-  return run_fill_loglike(b, MB_FORWARD, flags, loglike);
+  return with_parts_retry([&] { return run_fill_loglike(b, MB_FORWARD, flags, loglike); });
 }
 
 // ---- Viterbi ------------------------------------------------------------------------------------------------
@@ -1332,7 +1358,7 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
   int rc = 0;
   Timer tm;
   long long written = 0;
-  const bool timing = getenv("MB_TIMING") != nullptr;
+  const bool timing = opt_env("MB_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now(), tPrev = t0;
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip] viterbi %-28s %7.2f ms\n", what, t - tPrev); tPrev = t; } };
@@ -1432,9 +1458,13 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
   return rc;
 }
 
+static int batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap);
 int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
   ApiGuard guard;
   if (!b || !loglike) { set_error("null argument"); return 1; }
+  return with_parts_retry([&] { return batch_viterbi(b, loglike, pathOff, pathEdges, pathCap); });
+}
+static int batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *pathEdges, int64_t pathCap) {
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
   if (pathOff) pathOff[0] = 0;
@@ -1602,9 +1632,13 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
   return rc;
 }
 
+static int batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike);
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
   ApiGuard guard;
   if (!b || !counts) { set_error("null argument"); return 1; }
+  return with_parts_retry([&] { return batch_counts(b, counts, loglikeSum, loglike); });      // (the counts reach the caller's array after the last chunk only: a second run adds nothing twice)
+}
+static int batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike) {
   g_last_ms = 0.0; g_last_launches = 0;
   g_last_kernel = "";
   g_deterministic = env_int("MB_DETERMINISTIC", 0) != 0;
@@ -1645,9 +1679,13 @@ int mb_fill_env(mb_machine *m, int mode, const int32_t *in, int64_t inLen, const
   if (n * 8ull > budget_bytes()) { set_error("matrix exceeds the device memory budget"); rc = 1; }
   if (!rc && !(pool = (double *)ws_get(0, n * sizeof(double)))) rc = 1;
   if (!rc && env_int("MB_DEBUG_POISON", 0)) (void)hipMemsetAsync(pool, 0xFF, n * sizeof(double), g_stream);
-  if (!rc) rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, b);
-  if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
-  if (!rc && wide_parts_failed()) rc = 1;
+  for (int attempt = 0; attempt < 2 && !rc; ++attempt) {      // (a second time when the exchange between the parts of a one-tape sweep timed out: see with_parts_retry)
+    rc = fill_chunk(m, mode, b->d_pairs, b->pairs, b->d_in, b->d_out, pool, mode == MB_FORWARD ? startState : 0, b);
+    if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
+    if (!rc && wide_parts_failed()) { if (attempt == 0 && wide_parts_retry()) continue; rc = 1; }
+    break;
+  }
+  if (rc) wide_parts_reset();
   if (!rc && !hip_ok(hipMemcpy(cellsOut, pool, n * sizeof(double), hipMemcpyDeviceToHost), "D2H matrix")) rc = 1;
   mb_batch_destroy(b);
   return rc;
@@ -1683,7 +1721,7 @@ int mb_debug_jit_source(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_
   if (mode == MED_MODE_COUNT) {
     if (!medium_build_count_host(&m, G, P, geo, closure)) { set_error("machine does not qualify for the fused count kernel"); return 1; }
   } else if (!medium_build_host(&m, backward != 0, closure, G, P, geo)) return 1;
-  if (getenv("MB_MEDIUM_JIT_VERBOSE")) {
+  if (opt_env("MB_MEDIUM_JIT_VERBOSE")) {
     const long long c = medium_program_cost(P); int syncs = 0;
     for (const MedRoundInfo &ri : P.roundInfo) syncs += ri.sync;
     fprintf(stderr, "[mbhip] program cost %lld (rounds %zu, syncs %d, pairs %d, levels %d)\n", c, P.roundInfo.size(), syncs, P.nPairs, backward ? m.nLevB : m.nLevF);

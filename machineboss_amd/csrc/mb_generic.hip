@@ -13,7 +13,7 @@
 
 namespace mb {
 
-static int env_int_g(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static int env_int_g(const char *name, int dflt) { const char *v = opt_env(name); return v && *v ? atoi(v) : dflt; }
 
 // ---- DPMatrix::accumulate over `incoming` (src/dpmatrix.h:101-115) -----------------------------------------
 template <int MODE>
@@ -627,7 +627,7 @@ int launch_traceback(const mb_machine *m, const PairDesc *d_pairs, long long nPa
   const long long nRows = (long long)m->S * m->K;
   const size_t ldsBytes = (((size_t)(nRows + 1) * 4 + 15) & ~(size_t)15) + (size_t)m->nTrans * sizeof(TbEdge);
   static int useLds = -1;
-  if (useLds < 0) { const char *e = getenv("MB_TRACEBACK_LDS"); useLds = (e && *e == '0') ? 0 : 1; }
+  if (useLds < 0) { const char *e = opt_env("MB_TRACEBACK_LDS"); useLds = (e && *e == '0') ? 0 : 1; }
   if (useLds && nRows <= 8192 && m->nTrans <= 2048 && m->S <= 65535 && ldsBytes <= 64 * 1024) {
     hipLaunchKernelGGL(k_traceback_lds<true>, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), ldsBytes, st, m->dev, d_pairs, nPairs,
                        (long long)m->nTrans, d_in, d_out, d_pool, d_slotOff, d_pathBuf, d_pathLen);

@@ -93,6 +93,10 @@ struct mb_batch {
 
 namespace mb {
 void set_error(const std::string &msg);
+// Tuning knobs: `mb_set_option` keeps them in a table of the LIBRARY -- it does not write the process environment --
+// and every reader asks here: the table first, then the environment (the defaults a host sets before it starts).
+const char *opt_env(const char *name);
+void opt_set(const char *name, const char *value);      // value nullptr / "": back to the environment's (or the built-in) default
 // MB_DETERMINISTIC=1 (read when a count call begins): posterior counts are summed in 64-bit FIXED POINT wherever the order of the
 // additions depends on scheduling (LDS accumulators shared by wavefronts, global accumulators shared by tiles) -- integer addition
 // is associative, so `--counts / --train` reproduce bit for bit from run to run like the reference's serial loop

@@ -1,5 +1,6 @@
 // mb_jit.cpp -- hiprtc front end with an on-disk code-object cache (see mb_jit.h).
 #include "mb_jit.h"
+#include "mb_internal.h"
 
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
@@ -30,7 +31,7 @@ static std::string g_moreOpts;
 void jit_more_opts(const char *opts) { g_moreOpts = opts ? opts : ""; }
 static std::vector<std::string> extra_opts() {
   std::vector<std::string> v;
-  const char *e = getenv("MB_JIT_EXTRA_OPTS");
+  const char *e = opt_env("MB_JIT_EXTRA_OPTS");
   const std::string all = std::string(e ? e : "") + " " + g_moreOpts;
   std::string cur;
   for (const char *p = all.c_str();; ++p) {
@@ -68,10 +69,10 @@ static bool dir_is_private(const std::string &d) {
 
 // read on every compile: mb_set_option("MB_JIT_CACHE", "0") or a new MB_JIT_CACHE_DIR takes effect at once
 static std::string cache_dir() {
-  const char *off = getenv("MB_JIT_CACHE");
+  const char *off = opt_env("MB_JIT_CACHE");
   if (off && *off == '0') return "";
   std::string d;
-  if (const char *e = getenv("MB_JIT_CACHE_DIR")) d = e;
+  if (const char *e = opt_env("MB_JIT_CACHE_DIR")) d = e;
   else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/mbhip";
   else if (const char *h = getenv("HOME")) d = std::string(h) + "/.cache/mbhip";
   static std::string validated;      // the last directory that passed (mkdir + ownership check are not repeated for it)
@@ -123,7 +124,12 @@ bool jit_compile(const std::string &src, const char *name, std::string &code, st
   }
   const auto t0 = std::chrono::steady_clock::now();
   hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { if (log) *log = "hiprtcCreateProgram failed"; return false; }
+  if (hiprtcCreateProgram(&prog, src.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    if (log) *log = "hiprtcCreateProgram failed";
+    static bool told = false;
+    if (!told) { told = true; fprintf(stderr, "[mbhip] WARNING: hiprtc is unusable (hiprtcCreateProgram failed) -- the ahead-of-time interpreter kernels run instead, 2-4 x slower\n"); }
+    return false;
+  }
   const std::vector<std::string> extra = extra_opts();
   std::vector<const char *> opts(kOpts, kOpts + kNOpts);
   for (const std::string &o : extra) opts.push_back(o.c_str());
@@ -135,6 +141,12 @@ bool jit_compile(const std::string &src, const char *name, std::string &code, st
     if (ls) hiprtcGetProgramLog(prog, &lg[0]);
     if (log) *log = lg;
     hiprtcDestroyProgram(&prog);
+    // never silently: the kernel families fall back to their ahead-of-time interpreters, which are 2-4 x slower
+    static bool told = false;
+    if (!told) {
+      told = true;
+      fprintf(stderr, "[mbhip] WARNING: run-time compilation of %s failed (hiprtc: %.200s%s) -- the ahead-of-time interpreter kernels run instead, 2-4 x slower\n", name, lg.c_str(), lg.size() > 200 ? " ..." : "");
+    }
     return false;
   }
   size_t cs = 0;

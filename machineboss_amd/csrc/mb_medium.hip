@@ -375,7 +375,7 @@ std::vector<int> g_medium_cuts;
 void medium_set_cuts(const std::vector<int> &cuts) { g_medium_cuts = cuts; }
 
 static int env_int_m(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 
@@ -453,7 +453,7 @@ static void build_program(const mb_machine *m, bool backward, int closure, int G
     // explicit stage boundaries (first silent level of stages 2, 3, ...): set by the chooser (medium_set_cuts) or
     // MB_MEDIUM_CUTS="l1,l2,..." for experiments; levels need not be cut evenly -- a cut belongs where the closure is cheap
     std::vector<int> cuts = g_medium_cuts;
-    if (const char *e = getenv("MB_MEDIUM_CUTS")) { cuts.clear(); for (const char *q = e; *q;) { cuts.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (const char *e = opt_env("MB_MEDIUM_CUTS")) { cuts.clear(); for (const char *q = e; *q;) { cuts.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
     if (!cuts.empty()) {
       std::sort(cuts.begin(), cuts.end());
       for (int s = 0; s < S; ++s)
@@ -810,9 +810,9 @@ bool medium_build_host(const mb_machine *m, bool backward, int closure, int G, M
 // 670 KB per step and CU -- the L1 fill rate, not HBM, bounded the kernel).  Give columns up -- down to half -- until
 // the records that cannot sit in VGPRs fit next to the ring.
 void medium_fit_records(const mb_machine *m, const MedProgram &P, MedGeom &geo) {
-  const char *e = getenv("MB_MEDIUM_MAXWAVES");
+  const char *e = opt_env("MB_MEDIUM_MAXWAVES");
   if (e && atoi(e) > 0 && atoi(e) < geo.waves) { geo.waves = atoi(e); geo.C = geo.waves * P.G; }
-  if (getenv("MB_MEDIUM_FIT_RECORDS") && atoi(getenv("MB_MEDIUM_FIT_RECORDS")) == 0) return;
+  if (opt_env("MB_MEDIUM_FIT_RECORDS") && atoi(opt_env("MB_MEDIUM_FIT_RECORDS")) == 0) return;
   if (P.counting && env_int_m("MB_MEDIUM_COUNT_FIT", 1) == 0) return;
   const long long ntokT[4] = {(long long)(m->nIn + 1) * (m->nOut + 1), m->nIn + 1, m->nOut + 1, 1};
   long long slotsT[4] = {0, 0, 0, 0};
@@ -1198,7 +1198,7 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
 // outputs); short ones keep 64 so that a pair still cuts into enough tiles to fill the wavefront of launches.
 static int tile_steps(int C, size_t nPairs, int maxOut) {
   int TS = std::max(C, maxOut >= 4096 ? 128 : 64);
-  const char *e = getenv("MB_MEDIUM_TS");
+  const char *e = opt_env("MB_MEDIUM_TS");
   if (e && atoi(e) >= C) TS = atoi(e);
   (void)nPairs;
   return TS;
@@ -1257,14 +1257,14 @@ MedGeom medium_roll_geometry(const mb_machine *m, MedProgram &P, const MedGeom &
     // (9 ... 12 wavefronts leave a wavefront the same 168 registers, 5 ... 8 the same 256: at most two attempts -- the most wavefronts
     //  the LDS allows, then 8 when that is still more than the plain ring's)
     bool ok = medium_jit_get(m, P, g, mode, matKind, /*allowReplan=*/false);
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring (mode %d, matrix kind %d%s): %zu of %d states per short vector, %d wavefronts -> %s\n", mode, matKind, env ? ", envelopes" : "",
+    if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring (mode %d, matrix kind %d%s): %zu of %d states per short vector, %d wavefronts -> %s\n", mode, matKind, env ? ", envelopes" : "",
                                                   P.haloStates.size(), m->S, g.waves, ok ? "in use" : "does not fit its registers");
     if (!ok && g.waves > 8 && geoIn.waves < 8) {
       J = MedJit();
       g.waves = 8; g.C = g.waves * P.G;
       g.ldsBytes = (size_t)(g.C + 1) * (size_t)(P.Spad + P.NS * KC) * sizeof(double);
       ok = medium_jit_get(m, P, g, mode, matKind, /*allowReplan=*/false);
-      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring: 8 wavefronts -> %s\n", ok ? "in use" : "does not fit its registers: plain ring");
+      if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] in-place ring: 8 wavefronts -> %s\n", ok ? "in use" : "does not fit its registers: plain ring");
     }
     if (!ok) { J = MedJit(); return plain(); }
     P.compactState[kind] = 1;

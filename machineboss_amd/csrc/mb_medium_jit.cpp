@@ -24,13 +24,13 @@
 namespace mb {
 
 static int env_int_early(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 static const int JIT_MAX_CANDS = std::max(2, env_int_early("MB_JIT_MAXCANDS", 12));   // candidates evaluated in one straight-line round body
 
 static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 int medium_jit_max_cands() { return JIT_MAX_CANDS; }
@@ -410,7 +410,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
   if (J.tried) return J.func != nullptr;
   if ((mode == MED_MODE_COUNT) != P.counting) return false;   // count programs carry packed records: one mode only
   J.tried = true;
-  const char *e = getenv("MB_MEDIUM_JIT");
+  const char *e = opt_env("MB_MEDIUM_JIT");
   if (e && *e == '0') return false;
   long long totalSlots = 0;
   for (const MedRoundInfo &ri : P.roundInfo) {
@@ -424,16 +424,16 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
   for (int attempt = 0; attempt < 8; ++attempt) {
     J.ldsBytes = medium_jit_lds_bytes(P, geo, mode);
     if (J.ldsBytes > 160 * 1024) {
-      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit (mode %d, matrix kind %d): %zu bytes of LDS at register budget %d -- ahead-of-time kernel\n", mode, matKind, (size_t)J.ldsBytes, P.regBudget);
+      if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit (mode %d, matrix kind %d): %zu bytes of LDS at register budget %d -- ahead-of-time kernel\n", mode, matKind, (size_t)J.ldsBytes, P.regBudget);
       return false;
     }
     src = medium_jit_source(m, P, geo, mode, matKind);
-    if (const char *dump = getenv("MB_MEDIUM_JIT_DUMP")) {
+    if (const char *dump = opt_env("MB_MEDIUM_JIT_DUMP")) {
       if (FILE *f = fopen((std::string(dump) + (mode == MB_VITERBI ? ".vit" : (mode == MED_MODE_COUNT ? ".cnt" : (mode == MED_MODE_TB ? ".tb" : ".sum"))) + (materialise ? ".mat" : (matKind == MED_MAT_ROLL ? ".tiles" : ".roll")) + (P.backward ? ".bwd" : ".fwd") + (P.closure ? ".clos" : ".exact") + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     std::string log;
     if (!jit_compile(src, "mb_medium_jit.hip", code, &log, &fromCache)) {
-      if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
+      if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed:\n%s\n", log.c_str());
       return false;
     }
     // What counts is SCRATCH memory (.private_segment_fixed_size): registers parked in AGPRs (a workgroup of <= 4 wavefronts has 512
@@ -442,7 +442,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
     long long spills = medium_jit_spill_count(code);
     if (jit_kernel_meta(code, ".private_segment_fixed_size") == 0) spills = 0;
     if (attempt == 0 && (jit_debug_bits() & 4)) spills = 3;      // experiments: force one re-plan
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs (scratch %lld bytes)\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : (mode == MED_MODE_TB ? "max+tb" : "sum")), P.regBudget, spills, jit_kernel_meta(code, ".private_segment_fixed_size"));
+    if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit %s: register budget %d, %lld spilled VGPRs (scratch %lld bytes)\n", mode == MB_VITERBI ? "max" : (mode == MED_MODE_COUNT ? "count" : (mode == MED_MODE_TB ? "max+tb" : "sum")), P.regBudget, spills, jit_kernel_meta(code, ".private_segment_fixed_size"));
     // (the LAST attempt keeps what it compiled: re-planning behind it would leave the placement -- the LDS image, the record tables
     // the host refreshes -- one step ahead of the code; round 4 found exactly that, counts of 1e19, when a kernel never stopped spilling)
     if (spills > 0 && !allowReplan) return false;      // (a trial build that must not touch the program's placement: medium_roll_geometry)
@@ -472,7 +472,7 @@ bool medium_jit_get(const mb_machine *m, MedProgram &P, const MedGeom &geoIn, in
   if (noAgprSpills.on) {
     std::string log;
     if (!jit_compile(src, "mb_medium_jit.hip", code, &log, &fromCache)) return false;
-    if (getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit: scratch memory at the last budget -- compiled again without AGPR spill slots (scratch %lld bytes)\n", jit_kernel_meta(code, ".private_segment_fixed_size"));
+    if (opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] jit: scratch memory at the last budget -- compiled again without AGPR spill slots (scratch %lld bytes)\n", jit_kernel_meta(code, ".private_segment_fixed_size"));
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;

@@ -99,7 +99,7 @@ mb_comm *mb_comm_init(const char id[128], int nRanks, int rank) {
   std::memcpy(u.internal, id, 128);
   int dev = 0;
   if (!mb::hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
-  const char *ts = getenv("MB_COMM_TIMEOUT_S");
+  const char *ts = mb::opt_env("MB_COMM_TIMEOUT_S");
   const double timeout = (ts && *ts) ? atof(ts) : 180.0;
   struct Result { void *comm = nullptr; int rc = 0; bool deviceOk = true; };
   auto prom = std::make_shared<std::promise<Result>>();      // shared: the helper may outlive this call

@@ -48,7 +48,7 @@
 namespace mb {
 
 static int env_int_s(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 
@@ -647,17 +647,17 @@ bool small_jit_get(SmallProgram &P, int mode, bool materialise, bool env) {
   bool fromCache = false;
   for (int mw = small_default_minwaves(mode, env); mw >= 1; --mw) {
     src = small_jit_source(P, mode, materialise, env, mw);
-    if (const char *dump = getenv("MB_SMALL_JIT_DUMP")) {
+    if (const char *dump = opt_env("MB_SMALL_JIT_DUMP")) {
       const std::string fn = std::string(dump) + ".m" + I(mode) + (materialise ? ".mat" : ".roll") + (P.backward ? ".bwd" : ".fwd") + ".hip";
       if (FILE *f = fopen(fn.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     if (!jit_compile(src, "mb_small_jit.hip", code, &log, &fromCache)) {
-      if (getenv("MB_SMALL_JIT_VERBOSE") || getenv("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
+      if (opt_env("MB_SMALL_JIT_VERBOSE") || opt_env("MB_MEDIUM_JIT_VERBOSE")) fprintf(stderr, "[mbhip] hiprtc failed (small family):\n%s\n", log.c_str());
       set_error("run-time compilation of the small-machine kernel failed: " + log.substr(0, 400));
       return false;
     }
     J.scratch = jit_kernel_meta(code, ".private_segment_fixed_size") != 0;
-    if (getenv("MB_SMALL_JIT_VERBOSE")) fprintf(stderr, "[mbhip] small family, mode %d: %d wavefront(s) per SIMD, %lld VGPRs, %lld spilled, scratch %lld bytes\n", mode, mw,
+    if (opt_env("MB_SMALL_JIT_VERBOSE")) fprintf(stderr, "[mbhip] small family, mode %d: %d wavefront(s) per SIMD, %lld VGPRs, %lld spilled, scratch %lld bytes\n", mode, mw,
                                                 jit_kernel_meta(code, ".vgpr_count"), jit_kernel_meta(code, ".vgpr_spill_count"), jit_kernel_meta(code, ".private_segment_fixed_size"));
     if (!J.scratch || env_int_s("MB_SMALL_ALLOW_SCRATCH", 0)) break;
   }
@@ -715,7 +715,7 @@ static int pick_tile_steps(const std::vector<PairDesc> &pairs) {
 int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, hipStream_t st) {
   const std::vector<PairDesc> &pairs = *sw.pairs;
   if (pairs.empty()) return 0;
-  const bool timing = getenv("MB_TIMING") != nullptr;
+  const bool timing = opt_env("MB_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tPrev = now();
   auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[mbhip]   sweep %-24s %7.2f ms\n", what, t - tPrev); tPrev = t; } };

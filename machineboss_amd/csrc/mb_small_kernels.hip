@@ -308,7 +308,7 @@ int launch_small_traceback(const SmallProgram &P, const PairDesc *d_pairs, long 
   const int nDec = (int)P.dec.size(), nEid = P.nEntries <= 12288 ? (int)P.nEntries : 0;
   const size_t lds = (size_t)(P.S + 1 + nDec + nEid) * 4, ldsWave = (size_t)(P.S + 1 + 3 * nDec + nEid) * 4;
   // one wavefront per pair unless the batch is so large that one lane per pair already fills the chip
-  static const int waveMax = []() { const char *e = getenv("MB_SMALL_TRACEBACK_WAVE_MAX_PAIRS"); return e && *e ? atoi(e) : 262144; }();
+  static const int waveMax = []() { const char *e = opt_env("MB_SMALL_TRACEBACK_WAVE_MAX_PAIRS"); return e && *e ? atoi(e) : 262144; }();
   if (nPairs <= waveMax) {
     switch (T.tbStride / 4) {
       case 1: launch_tb_wave<1>(T, nDec, nEid, ldsWave, d_pairs, nPairs, d_in, d_out, d_tb, d_aux, d_ll, d_slotOff, d_pathBuf, d_pathLen, st); break;

@@ -171,7 +171,6 @@ struct WidePartArgs {
   const long long *xOff;       // first exchange row of every sequence
   unsigned *err;               // raised by a lane whose wait ran out
   long long timeoutTicks;      // of wall_clock64() (100 MHz)
-  int dropExports;             // test hook (MB_ONETAPE_PART_TEST_DROP_EXPORTS=1): nothing is exported, every consumer's wait runs out, the call fails
 };
 // what a build of a cut chose -- lanes, ring depth, the two-transition candidates of every part (indices into the part's edge list, with its
 // length as a check) -- kept by the program across weight updates: the choice depends on the machine's graph, not on its weights
@@ -244,6 +243,7 @@ struct WideProgram {
   long long tbEntries = 0;
   int tbFromSet = -1;                // the last traceback-code fill ran through partSets[tbFromSet] (its codes decode with that set's tables)
   bool shapeChosen = false;          // the column-by-column program was built (its closure shape is kept across weight refreshes)
+  bool partsOff = false;             // latched: a partitioned launch of this program waited in vain once (wide_parts_failed) -- one workgroup per sequence until it is rebuilt
   std::vector<WideRec> h_ret;        // host copy of the retimed streams (the generated kernel's table is built from it on first use)
   WideJitKernel jit[2];              // the generated kernel of the one-workgroup sweep ([1]: fp64 correction term)
   std::vector<WidePartSet> partSets; // k workgroups per sequence: one set per k that was asked for (built on first use)
@@ -276,7 +276,9 @@ int wide_fill(const mb_machine *m, WideProgram &P, const PairDesc *d_desc, long 
 int wide_last_parts();      // k of the last launch of this family (1: one workgroup per sequence)
 int wide_parts_for(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc = nullptr);      // k such a launch would use (builds the parts); h_desc: the launch's sequences (short ones are not worth a cut)
 double wide_parts_cost(const mb_machine *m, WideProgram &P, long long nPairs, int cus, const PairDesc *h_desc = nullptr);      // modelled time per column of that cut (0: none)
-bool wide_parts_failed();   // after the streams were synchronised: a bounded wait ran out (error set, flag cleared)
+bool wide_parts_failed();   // after the streams were synchronised: a bounded wait ran out (error set, flag cleared, the programs latched to one workgroup per sequence)
+bool wide_parts_retry();    // the API call that just failed did so because of that: run it once more (asked once)
+void wide_parts_reset();    // an API call left through an error: no raised status word, no pending flag for the next one
 const char *wide_kernel_name(const WideProgram &P);       // the kernel wide_fill launches for this program
 // ViterbiMatrix::fill keeping one traceback code per cell (P.tbOk): tb = bytes, wide_tb_stride(S) per column, PairDesc::cellBase =
 // BYTE offset of the sequence's first column; scores of the end cells in loglike

@@ -597,7 +597,7 @@ __device__ __forceinline__ void wide_retimed_body(const WideDev &P, const WideRe
             const uint32_t d = __umul24((dst >> 18) & 3u, (unsigned)NVs) + x;
             if (GV) V[d] = res; else wide_lds_write(d << 3, res);
             if constexpr (PART) {
-              if (x - (unsigned)pExpBase < (unsigned)pExp && !A.dropExports) {      // an export (relay entries follow them): one 8-byte store that the consumers' lanes wait for (a NaN would read as "not yet": none is stored as all-ones)
+              if (x - (unsigned)pExpBase < (unsigned)pExp) {      // an export (relay entries follow them): one 8-byte store that the consumers' lanes wait for (a NaN would read as "not yet": none is stored as all-ones)
                 const unsigned long long bits = res == res ? (unsigned long long)__double_as_longlong(res) : 0x7ff8000000000000ull;
                 __hip_atomic_store(xRow + (size_t)c * xStride + (size_t)(pExpIdx0 + (int)(x - (unsigned)pExpBase)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
@@ -807,7 +807,7 @@ inline uint32_t EXTRA(int i) { return (1u << 30) | (uint32_t)i; }
 inline uint32_t PREV(int i) { return (2u << 30) | (uint32_t)i; }
 
 int env_int_w(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 
@@ -1401,7 +1401,7 @@ void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState
     if (p0 < 0) p0 = p;
     if (p <= target || p > 64) break;
     const std::vector<int> cyc = ret_cycle(edges, nStates, p - 1, 62 * (p - 1) + p - 2);
-    if (verbose && getenv("MB_WIDE_VERBOSE_MERGE")) fprintf(stderr, "[mbhip]   merge iteration %d: period %d, cycle of %zu edges\n", iter, p, cyc.size());
+    if (verbose && opt_env("MB_WIDE_VERBOSE_MERGE")) fprintf(stderr, "[mbhip]   merge iteration %d: period %d, cycle of %zu edges\n", iter, p, cyc.size());
     if (cyc.empty()) break;
     int picked = 0;
     for (int k : cyc) {
@@ -1421,6 +1421,7 @@ void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState
 }
 }  // namespace
 
+static bool g_quiet_search = false;      // the lane search of wide_parts_host plans every candidate: its builds stay silent under MB_WIDE_VERBOSE
 // hostOut: keep the record stream on the host instead of uploading it (mb_debug_wide_retimed: the planner without a device)
 static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vector<WNode> &nodes, int nTok, std::vector<WideRec> *hostOut = nullptr,
                            int keepPeriod = 0, const RetPart *part = nullptr) {
@@ -1435,7 +1436,7 @@ static bool wide_ret_build(const mb_machine *m, WideProgram &P, const std::vecto
   const int rowLen = nTok + 1;                                 // penalty columns: silent, tokens 1 .. nTok - 1, the seed
   if (S + 2 >= (int)WIDE_RET_NO_DST || rowLen > 64) return true;
   if (part && (hostOut == nullptr || nImp > W)) return true;
-  const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
+  const bool verbose = opt_env("MB_WIDE_VERBOSE") != nullptr && !g_quiet_search;
   // the levelled nodes as a graph over states: t2[tok] = emitting candidates (source in the column before), t3 = silent ones
   std::vector<char> live(S, 0);
   for (const WNode &nd : nodes) live[nd.dst & W_IDX_MASK] = 1;
@@ -1724,7 +1725,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
   std::vector<std::vector<uint32_t>> tbOfState(tbCodes ? m->S : 0);
   const int S = m->S, nTok = (m->nOut ? m->nOut : m->nIn) + 1;
   if (k < 2 || S < 2 * k) return false;
-  const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
+  const bool verbose = opt_env("MB_WIDE_VERBOSE") != nullptr;
   std::vector<WNode> nodes;
   int nExtra = 0, nStages = 0; long long nPairs = 0;
   if (!wide_nodes(m, backward, 0, 1024, 1ll << 40, nodes, nExtra, nStages, nPairs)) return false;
@@ -1858,10 +1859,9 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
   int bestW = 0, bestRing = 8; double bestCost = 1e300; bool bestMerge = true;
   if (cand.size() == 1) { bestW = cand[0].first; bestRing = cand[0].second; bestMerge = cand[0].merge; }
   else {
-    const bool quiet = getenv("MB_WIDE_VERBOSE_PARTS") == nullptr;      // (the search's own builds stay silent unless asked)
-    const char *keepVerbose = getenv("MB_WIDE_VERBOSE");
-    std::string saved = keepVerbose ? keepVerbose : "";
-    if (quiet && keepVerbose) unsetenv("MB_WIDE_VERBOSE");
+    const bool quiet = opt_env("MB_WIDE_VERBOSE_PARTS") == nullptr;      // (the search's own builds stay silent unless asked)
+    const char *keepVerbose = opt_env("MB_WIDE_VERBOSE");
+    if (quiet && keepVerbose) g_quiet_search = true;
     struct Res { bool ok = false; double cost = 0.0; int period = 0; };
     std::vector<Res> res(cand.size());
     for (size_t ci = 0; ci < cand.size(); ++ci) {
@@ -1890,7 +1890,7 @@ bool wide_parts_host(const mb_machine *m, bool backward, bool viterbi, bool tbCo
                            ok ? "taken into account" : (res[ci].ok ? "set aside" : "no program"), res[ci].period, res[ci].cost);
       if (ok && res[ci].cost < bestCost) { bestCost = res[ci].cost; bestW = c.first; bestRing = c.second; bestMerge = c.merge; }
     }
-    if (quiet && keepVerbose) setenv("MB_WIDE_VERBOSE", saved.c_str(), 1);
+    if (quiet && keepVerbose) g_quiet_search = false;
     if (!bestW) { parts.clear(); return false; }
   }
   for (int p = 0; p < K; ++p) {
@@ -1967,7 +1967,7 @@ bool wide_build(const mb_machine *m, bool backward, bool viterbi, WideProgram &P
   int nExtra = 0, nStages = 0, bestExtra = 0, bestStages = 0, bestK = 0;
   long long nPairs = 0, bestPairs = 0;
   double best = 1e300;
-  const bool verbose = getenv("MB_WIDE_VERBOSE") != nullptr;
+  const bool verbose = opt_env("MB_WIDE_VERBOSE") != nullptr;
   auto consider = [&](int K) {
     if (!wide_nodes(m, backward, K, P.W, pairCap, nodes, nExtra, nStages, nPairs)) return false;
     const double c = wide_plan(nodes, nStages, (m->nOut ? m->nOut : m->nIn) + 1, P.W, false, nullptr);
@@ -2123,7 +2123,12 @@ void wide_set_accurate(bool on) { g_wide_accurate = on; }
 // ---- k workgroups per sequence: program sets and launches ------------------------------------------------------------------------
 int wide_last_parts() { return g_last_parts; }
 static bool g_parts_pending = false;        // a partitioned launch since the status was last read
-static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for an exchange value ran out (sticky until wide_parts_failed looks)
+static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for an exchange value ran out (cleared on the stream in front of every partitioned launch)
+// the programs with a partitioned launch in flight: when a wait runs out they are LATCHED to one workgroup per sequence (until they are
+// rebuilt) and the API call is run once more -- a co-tenant on the device, a CU mask or two partitioned launches that do not fit the chip
+// together cost one time-out, not every call that follows
+static std::vector<WideProgram *> g_parts_inflight;
+static bool g_parts_retry = false;
 
 // k for a launch of nPairs sequences that may count on `cus` CUs: as many parts as fit, at most MB_ONETAPE_PARTS (0 or 1: off).
 // Measured.  A machine whose ring fits the LDS of ONE CU (5 063 states): a part's period is bound by its chain of stages,
@@ -2131,10 +2136,10 @@ static unsigned *g_part_err = nullptr;      // raised by a lane whose wait for a
 // 25 vs 27.6 ms), 16 no better, two parts pay for the sum sweeps only: default at most 8.  A machine whose ring lives in L2 (21 761
 // states): the parts bring it into LDS -- 16 sequences: Viterbi fill 160 -> 17 ms with 16 parts -- default at most 16.
 static int wide_parts_k(const WideProgram &P, long long nPairs, int cus) {
-  if (!P.retOk || nPairs <= 0 || cus <= 0) return 1;
+  if (!P.retOk || nPairs <= 0 || cus <= 0 || P.partsOff) return 1;
   const int maxK = env_int_w("MB_ONETAPE_PARTS", P.retGv ? 16 : 8);
   const long long k = std::min<long long>(maxK, cus / nPairs);
-  if (k < 2 || (k == 2 && P.viterbi && !P.retGv && !getenv("MB_ONETAPE_PARTS"))) return 1;
+  if (k < 2 || (k == 2 && P.viterbi && !P.retGv && !opt_env("MB_ONETAPE_PARTS"))) return 1;
   return (int)k;
 }
 
@@ -2184,12 +2189,26 @@ static WidePartSet *wide_parts_get(const mb_machine *m, WideProgram &P, int k) {
 bool wide_parts_failed() {
   if (!g_part_err || !g_parts_pending) return false;
   g_parts_pending = false;
+  std::vector<WideProgram *> inflight;
+  inflight.swap(g_parts_inflight);
   unsigned e = 0;
   if (hipMemcpy(&e, g_part_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) { set_error("one-tape parts: status unreadable"); return true; }
   if (!e) return false;
   (void)hipMemset(g_part_err, 0, sizeof(e));
+  for (WideProgram *P : inflight) P->partsOff = true;
+  g_parts_retry = true;
+  fprintf(stderr, "[mbhip] WARNING: a one-tape sweep with k workgroups per sequence waited longer than MB_ONETAPE_PART_TIMEOUT_S for a value of another part "
+                  "(is the device shared, or a CU mask set?): results discarded, the machine's sweeps fall back to one workgroup per sequence\n");
   set_error("one-tape sweep with k workgroups per sequence: a workgroup waited longer than MB_ONETAPE_PART_TIMEOUT_S for a value of another part (results discarded)");
   return true;
+}
+// a call that failed because a wait ran out may be run once more: its programs are latched to one workgroup per sequence
+bool wide_parts_retry() { const bool r = g_parts_retry; g_parts_retry = false; return r; }
+// an API call that ends in an error must not leave a raised status word or a pending flag to the next call
+void wide_parts_reset() {
+  if (!g_parts_pending) return;
+  g_parts_pending = false; g_parts_inflight.clear();
+  if (g_part_err) (void)hipMemset(g_part_err, 0, sizeof(unsigned));
 }
 
 // mode: 0 fp64 cells / log-likelihood only, 1 traceback codes
@@ -2203,10 +2222,13 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   if (!buf) return 1;
   hipLaunchKernelGGL(k_wide_part_rows, dim3(1), dim3(1), 0, st, d_desc, (int)nPairs, m->nOut ? 0 : 1, (long long *)buf);
   MB_HIP(hipMemsetAsync(buf + headBytes, 0xFF, std::max<size_t>(xBytes, 8), st));
+  if (!g_parts_pending) MB_HIP(hipMemsetAsync(g_part_err, 0, sizeof(unsigned), st));      // (a second launch of the same call -- the other sweep on the other stream -- shares the word)
   WidePartArgs A{};
   A.parts = ps.d_parts; A.nSeq = (int)nPairs; A.nExpTot = ps.nExpTot; A.X = (double *)(buf + headBytes); A.xOff = (const long long *)buf;
-  A.err = g_part_err; A.timeoutTicks = (long long)std::max(1, env_int_w("MB_ONETAPE_PART_TIMEOUT_S", 20)) * 100000000ll;
-  A.dropExports = env_int_w("MB_ONETAPE_PART_TEST_DROP_EXPORTS", 0) ? 1 : 0;      // (fails the call loudly, never a wrong result: tests/test_gpu_parity.py)
+  { const char *ts = opt_env("MB_ONETAPE_PART_TIMEOUT_S");      // seconds (a fraction is taken: the tests provoke the time-out with microseconds)
+    const double secs = ts && *ts ? atof(ts) : 20.0;
+    A.err = g_part_err; A.timeoutTicks = std::max<long long>(1, (long long)(secs * 1e8)); }
+  if (std::find(g_parts_inflight.begin(), g_parts_inflight.end(), &P) == g_parts_inflight.end()) g_parts_inflight.push_back(&P);
   WideDev dev = P.dev; dev.lastOnly = lastOnly ? 1 : 0; dev.W = ps.W;
   // one workgroup per CU: a part's LDS is padded beyond half a CU's (the parts of a sequence are meant to run side by side on CUs of their own)
   size_t lds = ps.ldsBytes;
@@ -2214,7 +2236,7 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
   if (lds > WIDE_LDS_MAX) { set_error("one-tape parts: LDS"); return 1; }
   const dim3 grid((unsigned)(nPairs * ps.k)), block((unsigned)ps.W);
   // the sweep generated for this machine and this cut (mb_wide_jit.cpp); the interpreter below is the fallback
-  if (!A.dropExports && wide_jit_enabled() && (long long)rows * ps.nExpTot * 8 < (1ll << 40)) {
+  if (wide_jit_enabled()) {
     const bool acc = !P.viterbi && g_wide_accurate;
     WideJitKernel &J = ps.jit[acc ? 1 : 0];
     if (!J.tried) {
@@ -2228,7 +2250,7 @@ static int wide_fill_parts(const mb_machine *m, WideProgram &P, WidePartSet &ps,
         in.gmap = ps.h_tab[p].data();
       }
       WideJitFlags F; F.viterbi = P.viterbi; F.tb = tb; F.acc = acc; F.backward = P.backward; F.inputTape = m->nOut == 0; F.nExpTot = ps.nExpTot;
-      if (!wide_jit_build(ins, F, J, &J.why) && getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (%d parts): interpreter kept -- %s\n", ps.k, J.why.c_str());
+      if (!wide_jit_build(ins, F, J, &J.why) && opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (%d parts): interpreter kept -- %s\n", ps.k, J.why.c_str());
     }
     if (J.mod) {
       for (int p = 0; p < ps.k; ++p) J.args.impIdx[p] = ps.h_parts[p].impIdx;
@@ -2304,7 +2326,7 @@ static WideJitKernel *wide_jit_one(const mb_machine *m, WideProgram &P, bool tb,
     WideJitIn &in = ins[0];
     in.ret = P.ret; in.W = P.W; in.stream = P.h_ret.data(); in.S = m->S; in.Sg = m->S; in.resultEntry = P.dev.resultIdx;
     WideJitFlags F; F.viterbi = P.viterbi; F.tb = tb; F.acc = acc; F.backward = P.backward; F.inputTape = m->nOut == 0;
-    if (!wide_jit_build(ins, F, J, &J.why) && getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (one workgroup per sequence): interpreter kept -- %s\n", J.why.c_str());
+    if (!wide_jit_build(ins, F, J, &J.why) && opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit (one workgroup per sequence): interpreter kept -- %s\n", J.why.c_str());
   }
   return J.mod ? &J : nullptr;
 }

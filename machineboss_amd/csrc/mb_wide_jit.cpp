@@ -21,10 +21,19 @@
 namespace mb {
 
 static int jenv(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = opt_env(name);
   return v && *v ? atoi(v) : dflt;
 }
 bool wide_jit_enabled() { return jenv("MB_WIDE_JIT", 1) != 0; }
+// timing experiments with WRONG results (library built with -DMB_EXPERIMENTS only): bits of MB_WIDE_JIT_KNOCKOUT -- 1 no lane-group
+// reduction, 2 no barriers, 4 no per-period bookkeeping (token window, penalty table, imports), 8 no exports / matrix stores
+static int knockout() {
+#ifdef MB_EXPERIMENTS
+  return jenv("MB_WIDE_JIT_KNOCKOUT", 0);
+#else
+  return 0;
+#endif
+}
 
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
@@ -227,13 +236,27 @@ struct Gen {
     if (f.kind == WJ_ADDR || f.kind == WJ_DST) s += "_" + std::to_string(f.cm);
     return s;
   }
-  void reduce(const WideJitRound &R, int r) {
+  // what: 0 the mode's own reduction; 1 / 2 (two-pass sum rounds): the maximum over the group / the sum over the group
+  std::string sumExpr;      // what == 3: the statement that sums a lane's exponentials once the group's maximum is known
+  void reduce(const WideJitRound &R, int r, int what = 0) {
+    if (knockout() & 1) { if (what == 3) o << "      " << sumExpr << "\n"; return; }
     const char *sfx = F.acc ? "64" : "";
     const std::string tabArg = F.acc ? ", EXPTAB_" : "";
     auto ladder = [&](int g, bool masked, const char *ind) {
+      if (what == 3) {      // two-pass sum round: the group's maximum, every lane's exponentials relative to it, the group's sum -- one switch
+        if (g > 1) { if (masked) o << ind << "jreduce_max_msk<" << g << ">(m, 1 << (int)(gl" << r << " & 7u));\n"; else o << ind << "jreduce_max_all<" << g << ">(m);\n"; }
+        o << ind << sumExpr << "\n";
+        if (g > 1) { if (masked) o << ind << "jreduce_fsum_msk<" << g << ">(s, 1 << (int)(gl" << r << " & 7u));\n"; else o << ind << "jreduce_fsum_all<" << g << ">(s);\n"; }
+        return;
+      }
       if (g <= 1 && !F.tb) return;
       if (F.tb) { o << ind << "jreduce_tb<" << g << ">(m, key, 1 << (int)(gl" << r << " & 7u));\n"; return; }
-      if (F.viterbi) {
+      if (what == 2) {
+        if (masked) o << ind << "jreduce_fsum_msk<" << g << ">(s, 1 << (int)(gl" << r << " & 7u));\n";
+        else o << ind << "jreduce_fsum_all<" << g << ">(s);\n";
+        return;
+      }
+      if (F.viterbi || what == 1) {
         if (masked) o << ind << "jreduce_max_msk<" << g << ">(m, 1 << (int)(gl" << r << " & 7u));\n";
         else o << ind << "jreduce_max_all<" << g << ">(m);\n";
       } else {
@@ -260,36 +283,59 @@ struct Gen {
       else ladder(g, false, "            ");
       o << "            break;\n";
     }
-    o << "          default: break;\n        }\n      }\n";
+    o << "          default: " << (what == 3 ? sumExpr + " " : std::string()) << "break;\n        }\n      }\n";
   }
   void round(int r, int cm, int pt) {
     const WideJitRound &R = D.rounds[r];
     const WideJitIn &in = D.in;
     const unsigned penOff = (unsigned)pt * (unsigned)(in.ret.nPen + in.nImp) * 8u;
+    const bool twoPass = !F.viterbi && jenv("MB_WIDE_JIT_TWOPASS", 1) != 0 && R.depth <= 8;
     o << "    { // round " << r << ": slots " << R.firstSlot << ".." << R.firstSlot + R.depth - 1 << "\n";
-    o << "      double m" << (F.viterbi ? ";" : " = W_NEG_BIG;") << (F.viterbi ? "" : (F.acc ? " double s = 0.0;" : " float s = 0.0f;")) << (F.tb ? " unsigned best = 0u;" : "") << "\n";
+    // the LDS reads of every slot first (a streamed program: its packed words taken from the prefetch ring), then -- in the period's first
+    // round -- the bookkeeping of the NEXT period (token window, penalty table, imports: a few lanes' work whose own LDS round trip then
+    // overlaps with the round's reads instead of standing in front of them: it was 10 % of a period), then the arithmetic
     for (int q = 0; q < R.depth; ++q) {
       const int j = R.firstSlot + q;
+      std::string addr = "a" + std::to_string(j) + "_" + std::to_string(cm), pen = "p" + std::to_string(j) + " + " + std::to_string(penOff) + "u";
       if (D.level >= 1) {
-        o << "      { " << take("x_") << " double c_ = lds_rd(x_ >> 14) + ";
-        if (D.slots[j].anyPen) o << "(w" << j << " + lds_rd((x_ & 0x3FFFu) + " << penOff << "u));";
-        else o << "w" << j << ";";
-      } else {
-        o << "      { double c_ = lds_rd(a" << j << "_" << cm << ") + ";
-        if (D.slots[j].anyPen) o << "(w" << j << " + lds_rd(p" << j << " + " << penOff << "u));";
-        else o << "w" << j << ";";
+        const std::string xn = "x" + std::to_string(q) + "_";
+        o << "      " << take(xn.c_str()) << "\n";
+        addr = xn + " >> 14"; pen = "(" + xn + " & 0x3FFFu) + " + std::to_string(penOff) + "u";
       }
-      if (D.slots[j].anyW2) o << " c_ = c_ + v" << j << ";";
-      if (F.viterbi) {
-        if (q == 0) o << " m = c_;";
-        else { if (F.tb) o << " best = c_ > m ? " << q << "u : best;"; o << " m = jmax(m, c_);"; }
-      } else o << (F.acc ? " jfold64(m, s, c_, EXPTAB_);" : " jfold(m, s, c_);");
-      o << " }\n";
+      o << "      const double r" << q << "_ = lds_rd(" << addr << ");";
+      if (D.slots[j].anyPen) o << " const double p" << q << "_ = lds_rd(" << pen << ");";
+      o << "\n";
+    }
+    if (r == 0) top(topU);
+    for (int q = 0; q < R.depth; ++q) {
+      const int j = R.firstSlot + q;
+      o << "      const double c" << q << "_ = r" << q << "_ + " << (D.slots[j].anyPen ? "(w" + std::to_string(j) + " + p" + std::to_string(q) + "_)" : "w" + std::to_string(j));
+      if (D.slots[j].anyW2) o << " + v" << j;
+      o << ";\n";
+    }
+    if (twoPass) o << "      double m;\n";
+    else {
+      o << "      double m" << (F.viterbi ? " = c0_;" : " = W_NEG_BIG;") << (F.viterbi ? "" : (F.acc ? " double s = 0.0;" : " float s = 0.0f;")) << (F.tb ? " unsigned best = 0u;" : "") << "\n";
+      for (int q = F.viterbi ? 1 : 0; q < R.depth; ++q) {
+        if (F.viterbi) { o << "     "; if (F.tb) o << " best = c" << q << "_ > m ? " << q << "u : best;"; o << " m = jmax(m, c" << q << "_);\n"; }
+        else o << "      " << (F.acc ? "jfold64(m, s, c" : "jfold(m, s, c") << q << (F.acc ? "_, EXPTAB_);\n" : "_);\n");
+      }
     }
     if (F.tb) {
       if (R.uniform) { int lg = 0; while ((1 << lg) < R.gAll) ++lg; o << "      unsigned key = (best << " << lg << ") | ((unsigned)tid & " << (R.gAll - 1) << "u);\n"; }
       else o << "      unsigned key = (best << (gl" << r << " & 7u)) | ((unsigned)tid & ((1u << (gl" << r << " & 7u)) - 1u));\n";
     }
+    if (twoPass) {
+      o << "      m = c0_;";
+      for (int q = 1; q < R.depth; ++q) o << " m = jmax(m, c" << q << "_);";
+      o << " m = jmax(m, W_NEG_BIG);\n";      // (a finite stand-in: -inf - -inf below would be NaN)
+      std::ostringstream se;
+      if (F.acc) { se << "s = jexp64(c0_ - m, EXPTAB_);"; for (int q = 1; q < R.depth; ++q) se << " s += jexp64(c" << q << "_ - m, EXPTAB_);"; }
+      else { se << "s = jexp(c0_ - m);"; for (int q = 1; q < R.depth; ++q) se << " s += jexp(c" << q << "_ - m);"; }
+      sumExpr = se.str();
+      o << "      " << (F.acc ? "double" : "float") << " s;\n";
+      reduce(R, r, 3);
+    } else
     reduce(R, r);
     if (F.viterbi) o << "      const double res = m;\n";
     else if (F.acc) o << "      const double res = s >= 0.5 ? m + (s == 1.0 ? 0.0 : jlog64(s, EXPTAB_)) : NEG_INF;\n";
@@ -299,7 +345,7 @@ struct Gen {
       o << "      " << take("dw_") << " lds_wr(dw_ & 0x3FFFFu, res);\n";
       kq = "(dw_ >> 18)";
     } else o << "      lds_wr(d" << r << "_" << cm << ", res);\n";
-    if (R.anyCell || R.anyExport || R.resultLane >= 0) {
+    if ((R.anyCell || R.anyExport || R.resultLane >= 0) && !(knockout() & 8)) {
       o << "      { const int c = " << (F.backward ? "t - (int)" : "(t - KMAX_) + (int)") << kq << ";\n";
       if (R.anyExport) o << "        if (xo" << r << " != 0xFFFFFFFFu && (unsigned)c <= (unsigned)L) x_store((unsigned long long *)(xRowB + ((size_t)(unsigned)c * XS8_ + xo" << r << ")), res);\n";
       if (R.anyCell) {
@@ -312,29 +358,36 @@ struct Gen {
       if (R.resultLane >= 0) o << "        if (loglike && tid == " << R.resultLane << " && c == L) loglike[seq] = res;\n";
       o << "      }\n";
     }
-    if (R.sync) o << "      __syncthreads();\n";
+    if (R.sync && !((knockout() & 2) && r + 1 < (int)D.rounds.size())) o << "      __syncthreads();\n";
     o << "    }\n";
+  }
+  int topU = 0;
+  // the bookkeeping of period u: the token of column t + 2 into the window, the NEXT period's penalty table (and the imports of its newest column)
+  void top(int u) {
+    const WideJitIn &in = D.in;
+    const int pn = (u + 1) % D.NPT, nPen = in.ret.nPen, nPenAll = nPen + in.nImp, W = in.W;
+    const unsigned PN = (unsigned)pn * (unsigned)nPenAll * 8u;
+    if (knockout() & 4) return;
+    o << "      if (tid == 0) { lds_wri(TOK_ + (unsigned)((t + 2) & 63) * 4u, tokNext); tokNext = tokAt(t + 3); }\n";
+    for (int e0 = 0; e0 < nPen; e0 += W) {
+      if (e0 == 0) o << "      if (tid < " << std::min(nPen, W) << ") lds_wr(" << PN << "u + (unsigned)tid * 8u, penalty(myKt, myCol, t + 1));\n";
+      else o << "      if (tid + " << e0 << " < " << nPen << ") { const int e_ = tid + " << e0 << ", kt_ = e_ / ROWLEN_; lds_wr(" << PN << "u + (unsigned)e_ * 8u, penalty(kt_, e_ - kt_ * ROWLEN_, t + 1)); }\n";
+    }
+    if (in.nImp > 0) {
+      o << "      if (impLane) {\n"
+        << "        double v_ = NEG_INF;\n"
+        << "        if (t + 1 <= L) v_ = impAhead != X_EMPTY ? __longlong_as_double((long long)impAhead) : x_wait(impPtr + (size_t)(t + 1) * XS_, A.err, A.timeoutTicks);\n"
+        << "        lds_wr(" << PN + (unsigned)nPen * 8u << "u + (unsigned)impI * 8u, v_);\n"
+        << "        if (t + 2 <= L) impAhead = x_load(impPtr + (size_t)(t + 2) * XS_);\n"
+        << "      }\n";
+    }
   }
   void period(int u) {
     const WideJitIn &in = D.in;
-    const int NB = in.ret.NB, cm = u % NB, pt = u % D.NPT, pn = (u + 1) % D.NPT, nPen = in.ret.nPen, nPenAll = nPen + in.nImp, W = in.W;
-    const unsigned PN = (unsigned)pn * (unsigned)nPenAll * 8u;
+    const int NB = in.ret.NB, cm = u % NB, pt = u % D.NPT;
+    topU = u;
     o << "    // ---- period t, t mod " << D.U << " == " << u << ": newest column in ring vector " << cm << ", penalties in table " << pt << " ----\n";
     o << "    if (t >= nPer) break;\n";
-    o << "    if (tid == 0) { lds_wri(TOK_ + (unsigned)((t + 2) & 63) * 4u, tokNext); tokNext = tokAt(t + 3); }\n";
-    // the next period's penalty table, one period ahead
-    for (int e0 = 0; e0 < nPen; e0 += W) {
-      if (e0 == 0) o << "    if (tid < " << std::min(nPen, W) << ") lds_wr(" << PN << "u + (unsigned)tid * 8u, penalty(myKt, myCol, t + 1));\n";
-      else o << "    if (tid + " << e0 << " < " << nPen << ") { const int e_ = tid + " << e0 << ", kt_ = e_ / ROWLEN_; lds_wr(" << PN << "u + (unsigned)e_ * 8u, penalty(kt_, e_ - kt_ * ROWLEN_, t + 1)); }\n";
-    }
-    if (in.nImp > 0) {
-      o << "    if (impLane) {\n"
-        << "      double v_ = NEG_INF;\n"
-        << "      if (t + 1 <= L) v_ = impAhead != X_EMPTY ? __longlong_as_double((long long)impAhead) : x_wait(impPtr + (size_t)(t + 1) * XS_, A.err, A.timeoutTicks);\n"
-        << "      lds_wr(" << PN + (unsigned)nPen * 8u << "u + (unsigned)impI * 8u, v_);\n"
-        << "      if (t + 2 <= L) impAhead = x_load(impPtr + (size_t)(t + 2) * XS_);\n"
-        << "    }\n";
-    }
     if (F.tb) o << "    codeRow = codes + (long long)(t - KMAX_) * SB_;\n";
     else o << "    rowPtr = (char *)cells + (long long)(" << (F.backward ? "L - t" : "t - KMAX_") << ") * (SG_ * 8);\n";
     for (int r = 0; r < (int)D.rounds.size(); ++r) round(r, cm, pt);
@@ -471,7 +524,7 @@ bool wide_jit_build(const std::vector<WideJitIn> &ins, const WideJitFlags &F, Wi
     lds = std::max(lds, descs[p].ldsBytes);
   }
   const std::string src = wide_jit_source(descs, F);
-  if (const char *dump = getenv("MB_WIDE_JIT_DUMP")) {
+  if (const char *dump = opt_env("MB_WIDE_JIT_DUMP")) {
     const std::string path = std::string(dump) + (F.viterbi ? (F.tb ? ".tb" : ".max") : (F.acc ? ".sum64" : ".sum")) + (F.backward ? ".bwd" : ".fwd") + ".k" + std::to_string(ins.size()) + ".hip";
     if (FILE *f = fopen(path.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
   }
@@ -481,11 +534,11 @@ bool wide_jit_build(const std::vector<WideJitIn> &ins, const WideJitFlags &F, Wi
     std::string code, log;
     bool fromCache = false;
     if (!jit_compile(src, "mb_wide_jit.hip", code, &log, &fromCache)) {
-      if (getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: hiprtc failed:\n%s\n", log.c_str());
+      if (opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: hiprtc failed:\n%s\n", log.c_str());
       return fail("hiprtc: " + log.substr(0, 400));
     }
     const long long scratch = jit_kernel_meta(code, ".private_segment_fixed_size");
-    if (getenv("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: %zu bytes of source, code object %zu bytes%s, scratch %lld bytes, %lld spilled VGPRs\n", src.size(), code.size(), fromCache ? " (cache)" : "", scratch, jit_kernel_meta(code, ".vgpr_spill_count"));
+    if (opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: %zu bytes of source, code object %zu bytes%s, scratch %lld bytes, %lld spilled VGPRs\n", src.size(), code.size(), fromCache ? " (cache)" : "", scratch, jit_kernel_meta(code, ".vgpr_spill_count"));
     if (scratch > 0 && !jenv("MB_WIDE_JIT_ALLOW_SCRATCH", 0)) return fail("the kernel spills to scratch memory (" + std::to_string(scratch) + " bytes)");
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {

@@ -66,6 +66,12 @@ template <int GW> __device__ __forceinline__ void jreduce_sum_msk(double &m, flo
   s *= jexp(own - m);
   jsum_msk<1, GW>(s, g); jsum_msk<2, GW>(s, g); jsum_msk<4, GW>(s, g); jsum_msk<8, GW>(s, g); jsum_msk<16, GW>(s, g); jsum_msk<32, GW>(s, g);
 }
+// the two-pass log-sum-exp of a generated round: group maximum first (the ladders above), then every lane sums exp(candidate - maximum) over
+// its own candidates and the group sums the lanes -- no running rescale per candidate, no rescale between the two ladders
+template <int G> __device__ __forceinline__ void jreduce_fsum_all(float &s) { jsum_all<1, G>(s); jsum_all<2, G>(s); jsum_all<4, G>(s); jsum_all<8, G>(s); jsum_all<16, G>(s); jsum_all<32, G>(s); }
+template <int G> __device__ __forceinline__ void jreduce_fsum_all(double &s) { jsum_all<1, G>(s); jsum_all<2, G>(s); jsum_all<4, G>(s); jsum_all<8, G>(s); jsum_all<16, G>(s); jsum_all<32, G>(s); }
+template <int GW> __device__ __forceinline__ void jreduce_fsum_msk(float &s, int g) { jsum_msk<1, GW>(s, g); jsum_msk<2, GW>(s, g); jsum_msk<4, GW>(s, g); jsum_msk<8, GW>(s, g); jsum_msk<16, GW>(s, g); jsum_msk<32, GW>(s, g); }
+template <int GW> __device__ __forceinline__ void jreduce_fsum_msk(double &s, int g) { jsum_msk<1, GW>(s, g); jsum_msk<2, GW>(s, g); jsum_msk<4, GW>(s, g); jsum_msk<8, GW>(s, g); jsum_msk<16, GW>(s, g); jsum_msk<32, GW>(s, g); }
 // (value, place): the maximum, among equal maxima the SMALLEST place -- std::max_element's first maximum (src/dpmatrix.defs.h:171-174)
 template <int H, int GW> __device__ __forceinline__ void jkey_msk(unsigned &key, int g) { if (GW > H) { const unsigned ko = (unsigned)jxor<H>((int)key); if (H < g) key = min(key, ko); } }
 template <int GW> __device__ __forceinline__ void jreduce_tb(double &m, unsigned &key, int g) {

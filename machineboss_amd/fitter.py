@@ -205,6 +205,7 @@ class MachineFitter:
         self.constants = dict(constants or {})
         self.seed = dict(seed) if seed is not None else self.allConstraints().defaultParams()
         self.log: List[float] = []       # log-likelihood per iteration ("Baum-Welch iteration #k", src/fitter.cpp:31)
+        self.timing: List[Dict[str, float]] = []      # per iteration, milliseconds: weight evaluation, set_weights, E-step (wall / device), M-step
 
     def allConstraints(self) -> Constraints:
         return combineConstraints(self.machine.cons, self.constraints)
@@ -223,9 +224,15 @@ class MachineFitter:
         it = 0
         dm = None
         batch = None
+        import time
+        from . import capi as _capi
+        self.timing = []
         while True:
+            tm = {}
+            t0 = time.perf_counter()
             allParams = dict(self.machine.funcs); allParams.update(self.constants); allParams.update(params)
             ev = EvaluatedMachine.fromMachine(self.machine, allParams)
+            tm["eval_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
             # the topology is uploaded (and its kernels specialised) once; later iterations only send new log-weights
             # (mb_machine_set_weights) -- the reference rebuilds its EvaluatedMachine every iteration (src/fitter.cpp:28-29)
             if dm is None:
@@ -234,8 +241,11 @@ class MachineFitter:
             else:
                 dm.set_weights(ev.logWeight)
                 ev._device = dm
+            tm["set_weights_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()      # (first iteration: upload, kernel specialisation, tokenisation)
             counts = MachineCounts(ev)
             counts.addDeviceBatch(batch)
+            tm["estep_ms"] = (time.perf_counter() - t0) * 1e3; tm["estep_device_ms"] = _capi.last_device_ms()
+            self.timing.append(tm)
             if reduce is not None:
                 _, ll = reduce(counts._flat, counts.loglike)
                 counts.loglike = ll
@@ -246,7 +256,9 @@ class MachineFitter:
                 improvement = (counts.loglike - prev) / abs(prev)
                 if improvement < MinEMImprovement:
                     break
+            t0 = time.perf_counter()
             params = MachineObjective(self.machine, counts, self.constraints, self.constants).optimize(params)
+            tm["mstep_ms"] = (time.perf_counter() - t0) * 1e3
             prev = counts.loglike
             it += 1
         return params

@@ -85,6 +85,15 @@ class RankGroup:
         elif have_gpu and backend == "gloo" and local >= capi.device_count():
             local %= capi.device_count()      # all-host collectives: several ranks may share a GPU (a one-GPU box under torchrun --nproc-per-node 2)
         if have_gpu:
+            # ranks that SHARE a device (the gloo dry runs on a one-GPU box; a host that co-locates processes) must not each claim 80 % of
+            # its memory, and must not count on its CUs for themselves: the pools take a share (MB_MEM_FRACTION, read by the library when
+            # it sizes a pool) and one-tape sweeps stay at one workgroup per sequence (k workgroups per sequence need their parts co-resident)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            ndev = max(capi.device_count(), 1)
+            sharers = local_world if share_device else -(-local_world // ndev)
+            if sharers > 1:
+                os.environ.setdefault("MB_MEM_FRACTION", "%.4f" % (0.8 / sharers))
+                os.environ.setdefault("MB_ONETAPE_PARTS", "1")
             capi.set_device(local)
         import torch.distributed as dist
         opened = False

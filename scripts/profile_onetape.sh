@@ -41,8 +41,10 @@ dur = {}
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "k_wide_retimed" not in n: continue
+        if "k_wide_retimed" not in n and "k_wide_jit" not in n: continue
+        # (k_wide_jit: the sweep generated for the machine -- one symbol for every mode; the modes are told apart by the run: mode v launches the max sweep only)
         key = "viterbi_fill" if ("k_wide_retimed<1" in n or "k_wide_retimed_parts<1" in n) else "forward_cut_in_two"
+        if "k_wide_jit" in n: key = "jit_sweeps"
         d = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
         dur[key] = max(dur.get(key, 0.0), d)
 sweeps = {}
@@ -53,7 +55,7 @@ for mode, key, cus in (("v", "viterbi_fill", 64 if one_wg else 256), ("r", "forw
     for sub in ("pmc_", "pmc2_"):
         for f in glob.glob(os.path.join(out, sub + mode, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "k_wide_retimed" in r["Kernel_Name"]: per[sub][r["Counter_Name"]] += float(r["Counter_Value"])
+                if "k_wide_retimed" in r["Kernel_Name"] or "k_wide_jit" in r["Kernel_Name"]: per[sub][r["Counter_Name"]] += float(r["Counter_Value"])
     if not per or key not in dur: continue
     # counters summed over the run's k_wide_retimed dispatches (the run calls the sweep twice: first call + timed call), time likewise
     ndisp = 2

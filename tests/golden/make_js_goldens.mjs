@@ -12,6 +12,10 @@ import { prepareMachine } from '/root/reference/js/webgpu/internal/machine-prep.
 import { forward2DFull } from '/root/reference/js/webgpu/cpu/forward-2d.mjs';
 import { backward2D } from '/root/reference/js/webgpu/cpu/backward-2d.mjs';
 import { viterbi2D } from '/root/reference/js/webgpu/cpu/viterbi-2d.mjs';
+// ... and its 1-D tier for generators / recognisers (one tape; BASELINE config 5's family): cases with `oneTape`
+import { forward1DFull } from '/root/reference/js/webgpu/cpu/forward-1d.mjs';
+import { backward1D } from '/root/reference/js/webgpu/cpu/backward-1d.mjs';
+import { viterbi1D } from '/root/reference/js/webgpu/cpu/viterbi-1d.mjs';
 
 const here = dirname(fileURLToPath(import.meta.url));
 const cases = JSON.parse(readFileSync(join(here, 'js', 'cases.json'), 'utf8'));
@@ -25,6 +29,21 @@ async function main() {
     if (pm.nStates !== c.nStates) throw new Error('state count mismatch for ' + c.name);
     const x = Uint32Array.from(c.input), y = Uint32Array.from(c.output);
     const Li = x.length, Lo = y.length, S = pm.nStates;
+    if (c.oneTape) {
+      // the 1-D tier: null for the tape the machine does not have; grids are [(position)*nStates + state], position 0..L
+      const xi = c.oneTape === 'in' ? x : null, yo = c.oneTape === 'in' ? null : y;
+      if ((c.oneTape === 'in' ? pm.nOutputTokens : pm.nInputTokens) !== 1) throw new Error('not a one-tape machine: ' + c.name);
+      const f = await forward1DFull(pm, xi, yo);
+      const b = await backward1D(pm, xi, yo);
+      const v = await viterbi1D(pm, xi, yo);
+      const rec = { name: c.name, forward: num(f.logLikelihood), backward: num(b.logLikelihood), viterbi: num(v.score), layout: 'cells[p*nStates+s]', oneTape: c.oneTape };
+      const n = (Math.max(Li, Lo) + 1) * S;
+      if (n <= 6000) { rec.forwardCells = Array.from(f.dp, num); rec.backwardCells = Array.from(b.bp, num); }
+      else { rec.sample = []; for (let k = 0; k < n; k += 89) rec.sample.push([k, num(f.dp[k]), num(b.bp[k])]); }
+      out.push(rec);
+      console.log(c.name, f.logLikelihood, b.logLikelihood, v.score);
+      continue;
+    }
     const f = await forward2DFull(pm, x, y);
     const b = await backward2D(pm, x, y);
     const v = await viterbi2D(pm, x, y);

@@ -190,11 +190,15 @@ def _num(v):
     return -math.inf if v == "-inf" else (math.inf if v == "inf" else float(v))
 
 
-@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("idx", range(10))
 def test_oracle_matches_reference_js_tier(oracle_mod, idx):
     """The reference ships a second, independent implementation of this DP path (js/webgpu/cpu/*-2d.mjs: Float64, exact
     logsumexp, dense transition tensor).  Its outputs on five machines -- generated by running THAT code here with node --
-    pin the oracle: Forward/Backward log-likelihoods and every cell to 1e-10 relative, Viterbi scores bit for bit."""
+    pin the oracle: Forward/Backward log-likelihoods and every cell to 1e-10 relative, Viterbi scores bit for bit.
+    Cases 5-9 (round 6): ONE-TAPE machines through the reference's 1-D tier (js/webgpu/cpu/{forward,backward,viterbi}-1d.mjs) -- fn3
+    profile truncations composed with `translate` (generators of DNA; one turned into a recogniser), a Plan7-flanked profile, and the
+    2-node form of BASELINE config 5's composition -- the family the oracle otherwise covers only through its 2-D restatement with
+    inLen = 0."""
     from machineboss_amd.machine import Machine
     from machineboss_amd.evalmachine import EvaluatedMachine
     case, gold = _js_cases()[idx]
@@ -210,8 +214,10 @@ def test_oracle_matches_reference_js_tier(oracle_mod, idx):
     assert rel(om.loglike(x, y, oracle_mod.SUM_TABLE), _num(gold["forward"])) or abs(om.loglike(x, y) - _num(gold["forward"])) < 1e-4
     S = em.nStates; Lo = len(y)
 
-    def cell(M, k):   # JS layout [(i*(Lo+1)+o)*S+s] -> ours [o][i][s]
-        s = k % S; io = k // S; return M[io % (Lo + 1), io // (Lo + 1), s]
+    def cell(M, k):   # JS layout [(i*(Lo+1)+o)*S+s] -> ours [o][i][s]; the 1-D tier: [p*S+s], p along the machine's one tape
+        s = k % S; io = k // S
+        if gold.get("oneTape") == "in": return M[0, io, s]
+        return M[io % (Lo + 1), io // (Lo + 1), s]
     if "forwardCells" in gold:
         pairs = [(k, _num(f), _num(b)) for k, (f, b) in enumerate(zip(gold["forwardCells"], gold["backwardCells"]))]
     else:
