@@ -38,7 +38,7 @@ TRANSCENDENTAL_PEAK_T = 157.0 / 2 / 4   # v_exp_f32 / v_log_f32 per second (x 1e
 BYTES_PER_CELL = 8      # materialised Forward: one fp64 store per cell (w = 8)
 
 
-PROFILE_TAG = "r05"      # profiles/<tag>_*: the recorded constants this bench line may quote
+PROFILE_TAG = "r06"      # profiles/<tag>_*: the recorded constants this bench line may quote
 DUMP_DIR = None          # generated kernel sources of THIS run (MB_MEDIUM_JIT_DUMP / MB_SMALL_JIT_DUMP), hashed against profiles/<tag>_kernel_sha.json
 REFUSED = {}             # recorded figure -> why it was not quoted
 
@@ -56,6 +56,7 @@ def dump_kernels_as(tag):
     if DUMP_DIR:
         os.environ["MB_MEDIUM_JIT_DUMP"] = os.path.join(DUMP_DIR, tag)
         os.environ["MB_SMALL_JIT_DUMP"] = os.path.join(DUMP_DIR, tag)
+        os.environ["MB_WIDE_JIT_DUMP"] = os.path.join(DUMP_DIR, tag)
 
 
 def _sha16(path):
@@ -72,7 +73,7 @@ def kernel_sha_now():
                 out[f[:-4]] = _sha16(os.path.join(DUMP_DIR, f))
     import hashlib
     h = hashlib.sha256()
-    for f in ("mb_wide.hip", "mb_wide.h"):
+    for f in ("mb_wide.hip", "mb_wide.h", "mb_wide_jit.cpp", "mb_wide_jit_src.h"):      # the one-tape family: interpreter kernels + the generator of the per-machine sweep
         h.update(open(os.path.join(ROOT, "machineboss_amd", "csrc", f), "rb").read())
     out["aot:mb_wide"] = h.hexdigest()[:16]
     return out

@@ -16,6 +16,7 @@
 #include "mb_jit.h"
 #include "mb_medium.h"
 #include "mb_small.h"
+#include "mb_usage.h"
 #include "mb_wide.h"
 #include "mb_wide_jit.h"
 
@@ -332,7 +333,10 @@ static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &ou
     const long long even = (b->totalCells + nChunks - 1) / nChunks + b->maxPairCells;
     if (even < maxCells) maxCells = std::max(even, b->maxPairCells);
   }
-  long long p0 = 0, acc = 0;
+  // (a chunk also closes when it has reached its even share of what is LEFT: 64 equal pairs in two chunks are 32 + 32, not 33 + 31 -- the
+  //  one-tape E-step runs k = CUs / pairs workgroups per sequence, and 33 pairs get 3 where 32 get 4)
+  long long p0 = 0, acc = 0, left = b->totalCells;
+  long long chunksLeft = maxCells > 0 ? std::max<long long>(1, (b->totalCells + maxCells - 1) / maxCells) : 1;
   for (long long p = 0; p < b->nPairs; ++p) {
     const PairDesc &pd = b->pairs[p];
     const long long c = (long long)(pd.inLen + 1) * (pd.outLen + 1) * b->m->S;
@@ -340,8 +344,9 @@ static bool plan_chunks(const mb_batch *b, int nMatrices, std::vector<Chunk> &ou
       set_error("a single DP matrix (" + std::to_string(bytesPerCell > 0.0 ? (long long)((double)c * bytesPerCell) : c * 8ll * nMatrices) + " bytes) exceeds the device memory budget");
       return false;
     }
-    if (acc + c > maxCells) { out.push_back({p0, p, acc}); p0 = p; acc = 0; }
-    acc += c;
+    const bool shareReached = chunksLeft > 1 && acc > 0 && (acc + c / 2) * chunksLeft > left + acc;      // (left + acc = cells from this chunk's start on)
+    if (acc + c > maxCells || shareReached) { out.push_back({p0, p, acc}); p0 = p; acc = 0; chunksLeft = std::max<long long>(1, chunksLeft - 1); }
+    acc += c; left -= c;
   }
   if (b->nPairs > p0) out.push_back({p0, b->nPairs, acc});
   return true;
@@ -383,6 +388,7 @@ struct FastState {
   WideProgram wVitTb;        // ... the max program that keeps one traceback code per cell (`--align` without the fp64 matrix)
   bool wVitTbTried = false;
   WideCountPlan wCnt;        // posterior counts of one-tape machines (any size): lane = transition
+  UsagePlan usage;           // tiled family: posterior counts as a third pass over two materialised matrices (mb_usage.hip)
   WideTbPlan wTb;            // Viterbi traceback of one-tape machines too large for the LDS edge tables of mb_generic.hip
   // machines with a handful of states (mb_small.cpp): lane = column, states in registers
   bool smallTried = false, smallOk = false;
@@ -1027,6 +1033,7 @@ int mb_machine_set_weights(mb_machine *m, const double *logWeight) {
     if (f->tbOk && !medium_refresh_weights(m, f->fwdTb)) return 1;
     if (f->smallOk && !(small_refresh_weights(m, f->smF) && small_refresh_weights(m, f->smB))) return 1;
     f->wFwd.dirty = f->wBwd.dirty = f->wVit.dirty = f->wVitTb.dirty = true;
+    usage_free(f->usage);      // (its records carry the weights, and which transitions are -inf: rebuilt by the next count call)
   }
   return 0;
 }
@@ -1039,6 +1046,7 @@ void mb_machine_destroy(mb_machine *m) {
     medium_free(f->fwdExact); medium_free(f->fwdSum); medium_free(f->bwdSum); medium_free(f->fwdCnt); medium_free(f->fwdTb);
     wide_free(f->wFwd); wide_free(f->wBwd); wide_free(f->wVit); wide_free(f->wVitTb); wide_counts_free(f->wCnt); wide_traceback_free(f->wTb);
     small_free(f->smF); small_free(f->smB);
+    usage_free(f->usage);
     delete f;
   }
   free_machine_device(m);
@@ -1499,7 +1507,8 @@ static int batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_
 // ---- Forward-Backward counts --------------------------------------------------------------------------------
 // roll: the tiled family's count sweep WITHOUT a Forward matrix (medium_counts_rolling) -- one matrix per pair instead of two,
 // so twice the pairs per chunk; returns -1 before anything was accumulated when that kernel is unavailable
-static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double *loglike, bool roll) {
+// usage3: both matrices materialised by the plain fills, then the dependency-free usage pass of mb_usage.hip (tiled family)
+static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double *loglike, bool roll, bool usage3 = false) {
   const long long nT = b->m->nTrans;
   std::vector<Chunk> chunks;
   if (!plan_chunks(b, roll ? 1 : 2, chunks)) return 1;
@@ -1580,6 +1589,8 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         if (fused < 0 && c.p0 == 0) { rc = -1; break; }      // kernel unavailable: the caller runs the two-matrix path
         if (fused) { if (fused < 0) set_error("count sweep kernel became unavailable mid-batch"); rc = 1; break; }
         g_last_kernel = "k_medium_jit";
+      } else if (usage3) {
+        // (fused stays -1: Forward fill, log-likelihoods, then the usage pass below)
       } else if (use_medium(b->m) && fast_state(b->m)->countOk && !(b->hasEnv && wide_applicable(b->m))) {
         FastState *f = fast_state(b->m);
         MedEnv me;
@@ -1596,7 +1607,10 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
         if ((rc = launch_gather_loglike(d_desc, np, fwd, b->m->S, 0, d_ll + c.p0, g_stream))) break;
         // one-tape machines: a lane owns a transition and walks the columns (mb_wide.hip); two tapes: one thread per cell
         const bool oneTape = ((b->m->nIn != 0) != (b->m->nOut != 0)) && g_kernel_choice != 1 && env_int("MB_ONETAPE_COUNTS", 1);
-        if (oneTape) {
+        if (usage3) {
+          if ((rc = usage_launch(b->m, fast_state(b->m)->usage, d_desc, hp, b->d_in, b->d_out, fwd, bwd, d_counts, g_stream))) break;
+          g_last_kernel = "k_medium_jit (two fills) + k_medium_usage";
+        } else if (oneTape) {
           FastState *f = fast_state(b->m);
           if (!f->wCnt.ok && !wide_counts_build(b->m, f->wCnt)) { rc = 1; break; }
           if ((rc = wide_counts(b->m, f->wCnt, d_desc, hp, b->m->nOut ? b->d_out : b->d_in, fwd, bwd, d_counts, g_stream))) break;
@@ -1645,6 +1659,20 @@ static int batch_counts(mb_batch *b, double *counts, double *loglikeSum, double 
   if (b->nPairs == 0) return 0;
   if (use_small(b->m) && small_count_fits(((FastState *)b->m->fast)->smF, b->hasEnv) && small_can_run(((FastState *)b->m->fast)->smB, SM_SUM, true, b->hasEnv))
     return small_counts(b, counts, loglikeSum, loglike);
+  // Tiled family, two ways: the FUSED sweep (Backward fill, then a Forward sweep that weighs the transitions while its cells are in LDS:
+  // 16 B per lattice cell, one matrix per pair) or THREE passes (both fills materialised, then the dependency-free usage pass of
+  // mb_usage.hip).  Measured on the 482-state composition at 24 x 487 aa x 10 kb: fused 593 ms; three passes 946 ms -- the usage pass
+  // itself 286 ms, but two matrices per pair leave 6 pairs per chunk and the two fills of such a chunk cannot fill the chip (660 ms
+  // where 256 pairs through the pipeline would take 280).  So the fused sweep is the default; MB_MEDIUM_COUNT_PASSES=3 asks for the three
+  // passes (a host with few long pairs and memory to spare; the parity tests).
+  if (!wide_applicable(b->m) && use_medium(b->m) && !b->hasEnv) {
+    const int passes = env_int("MB_MEDIUM_COUNT_PASSES", 0);
+    FastState *f = fast_state(b->m);
+    if (f->mediumOk && passes == 3 && (size_t)b->maxPairCells * 16 <= budget_bytes()) {
+      if (!f->usage.tried) usage_build(b->m, f->usage);
+      if (f->usage.ok) return counts_chunks(b, counts, loglikeSum, loglike, false, true);
+    }
+  }
   if (!wide_applicable(b->m) && use_medium(b->m) && fast_state(b->m)->countOk && env_int("MB_MEDIUM_COUNTS_ROLL", 1)) {
     const int rc = counts_chunks(b, counts, loglikeSum, loglike, true);
     if (rc >= 0) return rc;

@@ -2932,9 +2932,15 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
   // columns staged in LDS when three state vectors fit and a thread's share of the transitions fits its registers
   const long long nE = (long long)C.nWaves * 64;
   if ((size_t)3 * m->S * sizeof(double) <= 158 * 1024 && nE <= 32 * 512 && env_int_w("MB_ONETAPE_COUNTS_LDS", 1)) {
-    int cs = 1;                                   // one workgroup per CU: cut until there are two parts per CU (parts of >= 64 columns)
+    // one workgroup per CU (three state vectors in LDS): the sequences are cut into column parts (>= 64 columns) until the launch fills
+    // the chip AND its last round of workgroups is nearly full -- 33 sequences x 8 parts = 264 workgroups on 256 CUs ran two rounds for
+    // the work of one (141 ms where 31 x 16 parts took 71; profiles/r06_onetape_estep_trace.txt)
+    int cs = 1;
     const int wantUnits = env_int_w("MB_ONETAPE_COUNT_LDS_UNITS", 256);
-    while ((long long)hp.size() * cs < wantUnits && (maxLen + 1) / (cs * 2) >= 64) cs *= 2;
+    int cus = 0;
+    { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; (void)hipGetLastError(); }
+    auto tailOk = [&](long long units) { if (cus <= 0) return true; const long long rounds = (units + cus - 1) / cus; return (double)units >= 0.9 * (double)(rounds * cus); };
+    while (((long long)hp.size() * cs < wantUnits || !tailOk((long long)hp.size() * cs)) && (maxLen + 1) / (cs * 2) >= 64 && cs < 1024) cs *= 2;
     const long long units = (long long)hp.size() * cs;
     if (nE <= 8 * 512) launch_counts_lds<8>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
     else if (nE <= 16 * 512) launch_counts_lds<16>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);

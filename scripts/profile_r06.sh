@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence in one go (through gpurun, from the repo root; summaries land under gpurun_out/prof_*/summary and gpurun_out/r05/, copy them
+# Round-6 evidence in one go (through gpurun, from the repo root; summaries land under gpurun_out/prof_*/summary and gpurun_out/r05/, copy them
 # to profiles/):
 #   1. the headline bench under rocprofv3 (kernel stats + HBM PMC passes) and the hashes of every kernel source it generated
 #      (r05_kernel_sha.json: what bench.py checks its recorded constants against);
@@ -9,7 +9,7 @@
 #   4. the generated sources of every specialised kernel for the vector-issue model (scripts/valu_model.py).
 set -u
 export TMPDIR=/tmp
-T=r05
+T=r06
 mkdir -p gpurun_out/$T
 bash scripts/profile_round.sh $T > gpurun_out/profile_round_$T.log 2>&1; tail -2 gpurun_out/profile_round_$T.log | cut -c1-300
 cp gpurun_out/prof_$T/summary_kernel_sha.json gpurun_out/$T/${T}_kernel_sha.json 2>/dev/null

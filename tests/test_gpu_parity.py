@@ -327,6 +327,68 @@ def test_medium_batch_counts_and_paths(capi, oracle_mod, machines):
     assert close(counts, ref_c, 1e-5, 1e-7) and close(s, ref_s, FAST_REL, FAST_ABS)
 
 
+@pytest.mark.parametrize("case", ["psw2dna", "random-match-60", "random-300", "c4b"])
+def test_three_pass_counts_match_the_fused_sweep_and_the_oracle(capi, oracle_mod, machines, monkeypatch, case):
+    """BackwardMatrix::getCounts as a THIRD pass over two materialised matrices (mb_usage.hip, round 6; src/backward.cpp:58-87): one
+    workgroup per input column, a lane per transition, both matrices streamed once.  Forced on (MB_MEDIUM_COUNT_PASSES=3) and off (2: the
+    fused sweep) on psw2dna, on random machines with match transitions (both tapes consumed: B(i + 1, o + 1)) and of 300 states, and on
+    the 482-state composition it was built for: the two agree, both agree with the oracle, ragged batches with empty sequences,
+    MB_DETERMINISTIC=1 included; a weight update is followed."""
+    from randmachine import random_machine, random_seq
+    rng = np.random.RandomState(7)
+    if case == "psw2dna":
+        m, em = machines("psw2dna", None, useDefaults=True, preset=True)
+        pairs = [synth_tokens(60 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(12, 50), (40, 90), (3, 7), (0, 9), (5, 0), (33, 130)])]
+    elif case == "c4b":
+        from machineboss_amd import algebra
+        from machineboss_amd.evalmachine import EvaluatedMachine
+        em = EvaluatedMachine.fromMachine(algebra.config4bMachine(golden_path("preset")), None, useDefaults=True)
+        pairs = [synth_tokens(70 + k, a, b, em.nInTok, 3) for k, (a, b) in enumerate([(9, 40), (20, 70), (2, 5)])]
+    else:
+        S = 60 if case == "random-match-60" else 300
+        em = random_machine(S, 3, 2, 4242 + S, density=2.0, silent_density=0.8, allow_inf=True)
+        assert np.any((np.asarray(em.inTok) != 0) & (np.asarray(em.outTok) != 0))      # match transitions
+        pairs = [(random_seq(rng, a, 3), random_seq(rng, b, 2)) for a, b in [(7, 11), (30, 44), (0, 6), (9, 0), (1, 1)]]
+    om = oracle_mod.OracleMachine(em)
+    ref_c = np.zeros(em.nTransitions); ref_s = 0.0
+    for x, y in pairs: ref_s += om.counts_add(x, y, ref_c, oracle_mod.SUM_EXACT)
+    got = {}
+    for passes in ("3", "2"):
+        monkeypatch.setenv("MB_MEDIUM_COUNT_PASSES", passes)
+        dm = capi.DeviceMachine(em)
+        b = capi.DeviceBatch.from_pairs(dm, pairs)
+        counts, s, ll = b.counts()
+        kern = capi.last_kernel_name()
+        assert ("k_medium_usage" in kern) == (passes == "3"), kern
+        assert close(counts, ref_c, 1e-5, 1e-7) and close(s, ref_s, FAST_REL, FAST_ABS)
+        got[passes] = counts
+        if passes == "3":
+            monkeypatch.setenv("MB_DETERMINISTIC", "1")
+            c1, _, _ = b.counts(); c2, _, _ = b.counts()
+            assert np.array_equal(c1, c2) and close(c1, counts, 1e-8, 1e-9)
+            monkeypatch.delenv("MB_DETERMINISTIC")
+            # new weights: the usage records follow (half of every weight's probability)
+            lw = np.asarray(em.logWeight) + np.log(0.5)
+            dm.set_weights(lw)
+            c3, s3, _ = b.counts()
+            assert "k_medium_usage" in capi.last_kernel_name()
+            import copy
+            em2 = copy.copy(em); em2.logWeight = lw
+            dm2 = capi.DeviceMachine(em2)
+            c4, s4, _ = capi.DeviceBatch.from_pairs(dm2, pairs).counts()
+            assert close(c3, c4, 1e-9, 1e-12) and close(s3, s4, 1e-12)
+            dm2.close()
+            dm.set_weights(np.asarray(em.logWeight))
+        dm.close()
+    assert close(got["3"], got["2"], 2e-6, 1e-8)
+    # the default is the fused sweep (DESIGN 4.2b: two matrices per pair halve the pairs of a chunk, and the fills of small chunks lose more than the usage pass gains)
+    monkeypatch.delenv("MB_MEDIUM_COUNT_PASSES")
+    if case in ("psw2dna", "c4b"):
+        dm = capi.DeviceMachine(em)
+        capi.DeviceBatch.from_pairs(dm, pairs).counts()
+        assert "k_medium_usage" not in capi.last_kernel_name()
+
+
 def test_tiled_family_placement_serves_every_strip_width(capi):
     """A 17-state machine whose rolling kernel (narrow strips of a short batch, tiles without a matrix) spills at the first
     register budget: the re-plan that follows is shared with the matrix kernel of the wider strips, which must still fit the
