@@ -71,7 +71,8 @@ struct mb_machine {
 
 namespace mb {
 // tile lists of one chunk of a batch for the small-machine family (mb_small.cpp), kept on the device between calls
-struct SmTileCache { long long p0 = -1, p1 = -1; int TS = 0; long long envVersion = -1; void *d_tiles = nullptr; std::vector<long long> off; };
+// (d_deps / d_flags: the one-launch form of a sweep -- per tile the list positions of the tiles it reads from, and a "done" word per tile)
+struct SmTileCache { long long p0 = -1, p1 = -1; int TS = 0; long long envVersion = -1; void *d_tiles = nullptr; std::vector<long long> off; void *d_deps = nullptr; void *d_flags = nullptr; };
 }
 
 struct mb_batch {

@@ -216,7 +216,21 @@ struct SmallArgs {
   double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
   double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
   const int *envStart; const int *envEnd;
+  const int4 *deps; unsigned *flags; unsigned *err; long long timeoutTicks;      // the one-launch form of a sweep (flags == nullptr: one launch per wavefront of tiles)
 };
+// ONE LAUNCH for a whole sweep (batches whose launches hold a handful of tiles: a single 1 kb x 1 kb pair is a chain of 47 dependent
+// launches of ~20 us each): every tile of the sweep is in the grid, in wavefront order, and waits for the tiles it reads from -- the
+// block before it in its strip (boundary record) and the blocks of the strip to its left whose halo rows it reads -- through one
+// "done" word per tile.  A tile only ever waits for tiles EARLIER in the list, which the dispatcher starts first; the wait is bounded
+// (the host then runs the sweep launch by launch).
+__device__ __forceinline__ void sm_wait(const unsigned *p, unsigned *err, long long timeoutTicks) {
+  const long long t0 = (long long)wall_clock64();
+  while (!__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if ((long long)wall_clock64() - t0 > timeoutTicks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 typedef const __attribute__((address_space(4))) double *cdbl_t;
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d2a8 __attribute__((ext_vector_type(2), aligned(8)));
@@ -293,6 +307,13 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
   const int tile = A.tileBase + blockIdx.x * 4 + wv;
   if (tile < A.tileEnd) {
     const int4 tl = A.tiles[tile];
+#if JMODE != 3      // (the count sweep always runs launch by launch: see small_sweep -- and has no registers to spare)
+    if (A.flags) {
+      const int4 dp = A.deps[tile];
+      if (lane < 3) { const int d = lane == 0 ? dp.x : (lane == 1 ? dp.y : dp.z); if (d >= 0) sm_wait(A.flags + d, A.err, A.timeoutTicks); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what those tiles stored (halo rows, boundary records) is read below
+    }
+#endif
     const int pairIdx = tl.x, a = tl.y, b = tl.z;
     const PairDesc pd = A.pairs[pairIdx];
     const SmAux ax = A.aux[pairIdx];
@@ -395,6 +416,12 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
     }
 #if JMODE == 3
 /*@FLUSH@*/
+#endif
+#if JMODE != 3
+    if (A.flags) {      // this tile's halo rows and boundary record are written: the tiles that wait for it may go
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_store(A.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #endif
   }
 #if JMODE == 3
@@ -692,6 +719,7 @@ struct SmallArgsHost {   // must match SmallArgs in the generated source
   double *pool; unsigned char *tb; double *halo; double *bound; const SmAux *aux;
   double *loglike; const double *w; const int *eid; const double *bwdLL; double *counts;
   const int *envStart; const int *envEnd;
+  const int4 *deps; unsigned *flags; unsigned *err; long long timeoutTicks;
 };
 
 // Steps per tile: the longest tile that still leaves ~12 tiles per CU in an average launch; 64 (the minimum: a tile must
@@ -767,16 +795,35 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     tc.off.assign(nLaunch + 1, 0);
     for (int l = 0; l < nLaunch; ++l) tc.off[l + 1] = tc.off[l] + cnt[l];
     if (tc.off[nLaunch] > 0x7fffffffLL) { set_error("too many tiles in one sweep"); return 1; }
-    std::vector<int4> tiles((size_t)tc.off[nLaunch]);
+    std::vector<int4> tiles((size_t)tc.off[nLaunch]), deps((size_t)tc.off[nLaunch], make_int4(-1, -1, -1, -1));
     {
       std::vector<long long> fill(tc.off.begin(), tc.off.end() - 1);
+      std::vector<std::vector<int>> pos(pairs.size());      // position of every live tile in the list
+      for (size_t p = 0; p < pairs.size(); ++p) {
+        const PairDesc &pd = pairs[p];
+        const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
+        pos[p].assign((size_t)NA * NB, -1);
+        for (int a = 0; a < NA; ++a)
+          for (int b = 0; b < NB; ++b)
+            if (live[p][(size_t)a * NB + b]) {
+              pos[p][(size_t)a * NB + b] = (int)fill[2 * a + b];
+              tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, (b > 0 && !live[p][(size_t)a * NB + b - 1]) ? 1 : 0);
+            }
+      }
+      // what a tile reads from other tiles (the one-launch form): the boundary record of the block before it, the halo rows of the
+      // strip to its left written by that strip's blocks b and b + 1 (a tile's rows reach 63 steps past its own)
       for (size_t p = 0; p < pairs.size(); ++p) {
         const PairDesc &pd = pairs[p];
         const int NA = small_strips(pd.inLen), NB = (small_steps(pd.outLen) + TS - 1) / TS;
         for (int a = 0; a < NA; ++a)
-          for (int b = 0; b < NB; ++b)
-            if (live[p][(size_t)a * NB + b])
-              tiles[(size_t)fill[2 * a + b]++] = make_int4((int)p, a, b, (b > 0 && !live[p][(size_t)a * NB + b - 1]) ? 1 : 0);
+          for (int b = 0; b < NB; ++b) {
+            const int at = pos[p][(size_t)a * NB + b];
+            if (at < 0) continue;
+            int4 d = make_int4(-1, -1, -1, -1);
+            if (b > 0) d.x = pos[p][(size_t)a * NB + b - 1];
+            if (a > 0) { d.y = pos[p][(size_t)(a - 1) * NB + b]; if (b + 1 < NB) d.z = pos[p][(size_t)(a - 1) * NB + b + 1]; }
+            deps[(size_t)at] = d;
+          }
       }
     }
     lap("tile lists");
@@ -784,6 +831,14 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     if (h2d_large(tc.d_tiles, tiles.data(), tiles.size() * sizeof(int4)) || !hip_ok(hipStreamSynchronize(st), "H2D tile list")) {
       (void)hipFree(tc.d_tiles); tc.d_tiles = nullptr;
       return 1;
+    }
+    if (tc.d_deps) { (void)hipFree(tc.d_deps); tc.d_deps = nullptr; }
+    if (tc.d_flags) { (void)hipFree(tc.d_flags); tc.d_flags = nullptr; }
+    if (hipMalloc(&tc.d_deps, std::max<size_t>(deps.size(), 1) * sizeof(int4)) != hipSuccess || hipMalloc(&tc.d_flags, (std::max<size_t>(deps.size(), 1) + 1) * sizeof(unsigned)) != hipSuccess ||
+        h2d_large(tc.d_deps, deps.data(), deps.size() * sizeof(int4)) || !hip_ok(hipStreamSynchronize(st), "H2D tile dependencies")) {
+      (void)hipGetLastError();      // (without them the sweep runs launch by launch)
+      if (tc.d_deps) { (void)hipFree(tc.d_deps); tc.d_deps = nullptr; }
+      if (tc.d_flags) { (void)hipFree(tc.d_flags); tc.d_flags = nullptr; }
     }
     tc.TS = TS;
   }
@@ -798,6 +853,33 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
   A.envStart = sw.d_envStart; A.envEnd = sw.d_envEnd;
   bool ok = true;
+  // ONE launch when the launches of the sweep would hold a handful of tiles each (a single pair, a few short pairs): see sm_wait in the
+  // generated source.  MB_SMALL_ONE_LAUNCH: 1 always, 0 never; default: fewer than 256 tiles per launch on average over >= 4 launches.
+  static bool oneLaunchOff = false;      // latched when a tile's wait ran out once (a shared device: the tiles were not scheduled in list order)
+  const long long nTiles = off[nLaunch];
+  const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", -1);
+  // (not the count sweep: it adds into the caller's accumulators as it goes, so a sweep that gave up could not simply be run again)
+  const bool oneLaunch = tc.d_deps && tc.d_flags && nTiles > 0 && !oneLaunchOff && oneWant != 0 && mode != SM_COUNT &&
+                         (oneWant == 1 || (nLaunch >= 4 && nTiles / nLaunch < 256 && nTiles <= (1 << 20)));
+  if (oneLaunch) {
+    unsigned *flags = (unsigned *)tc.d_flags;      // [nTiles] done words + the error word behind them
+    if (!hip_ok(hipMemsetAsync(flags, 0, ((size_t)nTiles + 1) * sizeof(unsigned), st), "memset(tile flags)")) return 1;
+    A.deps = (const int4 *)tc.d_deps; A.flags = flags; A.err = flags + nTiles;
+    A.timeoutTicks = (long long)std::max(1, env_int_s("MB_SMALL_ONE_LAUNCH_TIMEOUT_S", 20)) * 100000000ll;
+    A.tileBase = 0; A.tileEnd = (int)nTiles;
+    void *args[] = {&A};
+    ++g_last_launches;
+    ok = hipModuleLaunchKernel((hipFunction_t)J.func, (unsigned)((nTiles + 3) / 4), 1, 1, 256, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
+    unsigned e = 0;
+    ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipMemcpyAsync(&e, flags + nTiles, sizeof(e), hipMemcpyDeviceToHost, st), "tile status") && hip_ok(hipStreamSynchronize(st), "small tile kernel");
+    lap("one launch");
+    if (ok && !e) { if (!cached && local.d_tiles) { (void)hipFree(local.d_tiles); if (local.d_deps) (void)hipFree(local.d_deps); if (local.d_flags) (void)hipFree(local.d_flags); } return 0; }
+    if (!ok) { set_error("small-machine kernel launch failed"); return 1; }
+    oneLaunchOff = true;
+    fprintf(stderr, "[mbhip] WARNING: a tile of a one-launch sweep waited longer than MB_SMALL_ONE_LAUNCH_TIMEOUT_S for the tiles it reads from (is the device shared?): the sweep is run again launch by launch, and so are the sweeps that follow\n");
+    A.deps = nullptr; A.flags = nullptr; A.err = nullptr;
+    if (skipDead && sw.haloDoubles > 0 && launch_fill_neg_inf(sw.d_halo, sw.haloDoubles, st)) return 1;
+  }
   for (int l = 0; l < nLaunch && ok; ++l) {
     const long long nt = off[l + 1] - off[l];
     if (nt <= 0) continue;
@@ -811,7 +893,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   if (!ok) set_error("small-machine kernel launch failed");
   ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipStreamSynchronize(st), "small tile kernels");
   lap("stream synchronize");
-  if (!cached && local.d_tiles) (void)hipFree(local.d_tiles);
+  if (!cached && local.d_tiles) { (void)hipFree(local.d_tiles); if (local.d_deps) (void)hipFree(local.d_deps); if (local.d_flags) (void)hipFree(local.d_flags); }
   return ok ? 0 : 1;
 }
 

@@ -96,6 +96,78 @@ def test_small_tile_lengths(capi, oracle_mod, machines, monkeypatch, ts):
 
 
 @pytest.mark.gpu
+def test_small_one_launch_sweeps(capi, oracle_mod, machines, monkeypatch):
+    """ONE launch for a whole sweep (round 6; `src/api.cpp:31-66`, `target/boss.cpp:796-800`: one matrix object per
+    pair): a single 1 kb x 1 kb dnapsw pair was a chain of 47 dependent launches -- now every tile of the sweep is in one grid, in
+    wavefront order, and waits for the tiles it reads from through a "done" word per tile.  Same results as launch by launch
+    (MB_SMALL_ONE_LAUNCH=0), bit for bit: log-likelihoods, Forward / Backward / Viterbi matrices, Viterbi scores and paths; the oracle
+    on the short pairs; envelopes (tiles that do not run have no "done" word to wait for); one launch counted."""
+    m, em = machines("dnapsw", None, useDefaults=True, preset=True)
+    big = [synth_tokens(900, 1000, 1000, em.nInTok, em.nOutTok)]
+    ragged = [synth_tokens(910 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(150, 333), (70, 64), (3, 190), (0, 5), (300, 129)])]
+    out = {}
+    for one in ("1", "0"):
+        monkeypatch.setenv("MB_SMALL_ONE_LAUNCH", one)
+        dm = capi.DeviceMachine(em)
+        r = {}
+        for name, pairs in (("big", big), ("ragged", ragged)):
+            b = capi.DeviceBatch.from_pairs(dm, pairs)
+            r[name + ".roll"] = b.forward(capi.MB_ROLLING); r[name + ".roll.launches"] = capi.last_launch_count()
+            r[name + ".mat"] = b.forward(capi.MB_MATERIALISE)
+            r[name + ".vit"] = b.viterbi(); r[name + ".vit.launches"] = capi.last_launch_count()
+            r[name + ".cnt"] = b.counts()
+        x, y = ragged[0]
+        for mode in (capi.MB_FORWARD, capi.MB_BACKWARD, capi.MB_VITERBI): r["fill%d" % mode] = dm.fill(mode, x, y)
+        out[one] = r
+        dm.close()
+    a, b_ = out["1"], out["0"]
+    assert a["big.roll.launches"] == 1 and b_["big.roll.launches"] > 20, (a["big.roll.launches"], b_["big.roll.launches"])
+    for k in a:
+        if k.endswith(".launches"): continue
+        if k.endswith(".vit"):
+            for u, v in zip(a[k], b_[k]): assert np.array_equal(np.asarray(u), np.asarray(v)), k
+        elif k.endswith(".cnt"): assert close(a[k][0], b_[k][0], 1e-9, 1e-12) and close(a[k][1], b_[k][1], 1e-12)      # (the count sweep itself runs launch by launch; its Backward fill in one)
+        else: assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), k
+    om = oracle_mod.OracleMachine(em)
+    for k, (x, y) in enumerate(ragged):
+        assert close(a["ragged.roll"][k], om.loglike(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        V = om.viterbi(x, y); vll, off, edges = a["ragged.vit"]
+        assert vll[k] == V[-1, -1, -1] and np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, V))
+    # a path envelope (quirk Q1: what an aligned pair gets): dead tiles are not in the grid
+    monkeypatch.setenv("MB_SMALL_ONE_LAUNCH", "1")
+    x, y = synth_tokens(950, 200, 260, em.nInTok, em.nOutTok)
+    rng = np.random.RandomState(5)
+    cols = []; i = o = 0
+    while i < len(x) or o < len(y):
+        step = rng.randint(3) if (i < len(x) and o < len(y)) else (1 if i < len(x) else 2)
+        if step == 0: cols.append((i, o)); i += 1; o += 1
+        elif step == 1: cols.append((i, None)); i += 1
+        else: cols.append((None, o)); o += 1
+    envStart = np.zeros(len(y) + 1, np.int32); envEnd = np.zeros(len(y) + 1, np.int32)
+    # the band of width 8 around the alignment's path
+    ii = oo = 0; lo = [len(x) + 1] * (len(y) + 1); hi = [0] * (len(y) + 1)
+    def mark(ii, oo):
+        lo[oo] = min(lo[oo], ii); hi[oo] = max(hi[oo], ii)
+    mark(0, 0)
+    for ci, co in cols:
+        if ci is not None: ii += 1
+        if co is not None: oo += 1
+        mark(ii, oo)
+    for oo in range(len(y) + 1): envStart[oo] = max(0, lo[oo] - 8); envEnd[oo] = min(len(x) + 1, hi[oo] + 9)
+    res = {}
+    for one in ("1", "0"):
+        monkeypatch.setenv("MB_SMALL_ONE_LAUNCH", one)
+        dm = capi.DeviceMachine(em)
+        b = capi.DeviceBatch.from_pairs(dm, [(x, y)])
+        b.set_envelopes([(envStart, envEnd)])
+        res[one] = (b.forward(capi.MB_ROLLING), b.viterbi())
+        dm.close()
+    assert np.array_equal(res["1"][0], res["0"][0]) and all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(res["1"][1], res["0"][1]))
+    ref = om.loglike_env(x, y, envStart, envEnd, oracle_mod.SUM_EXACT) if hasattr(om, "loglike_env") else None
+    if ref is not None: assert close(res["1"][0][0], ref, FAST_REL, FAST_ABS)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S,seed", [(2, 1), (3, 2), (5, 3), (8, 4), (12, 5), (16, 6), (7, 7), (9, 8)])
 def test_small_random_machines(capi, oracle_mod, S, seed):
     """Random machines: odd state counts (8-byte chunks), duplicate edges, several edges per label, match edges, -inf weights."""
