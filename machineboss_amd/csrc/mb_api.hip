@@ -688,6 +688,9 @@ static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, boo
       SmTileCache &tc = b->smTiles[2 * chunkNo + bw];
       if (tc.p0 != c.p0 || tc.p1 != c.p1 || tc.envVersion != b->envVersion) {
         if (tc.d_tiles) (void)hipFree(tc.d_tiles);
+        if (tc.d_deps) (void)hipFree(tc.d_deps);
+        if (tc.d_flags) (void)hipFree(tc.d_flags);
+        tc.d_deps = tc.d_flags = nullptr;
         tc = SmTileCache(); tc.p0 = c.p0; tc.p1 = c.p1; tc.envVersion = b->envVersion;
       }
     }
@@ -1110,7 +1113,7 @@ void mb_batch_destroy(mb_batch *b) {
   if (b->d_pairs) (void)hipFree(b->d_pairs);
   if (b->d_envStart) (void)hipFree(b->d_envStart);
   if (b->d_envEnd) (void)hipFree(b->d_envEnd);
-  for (mb::SmTileCache &tc : b->smTiles) if (tc.d_tiles) (void)hipFree(tc.d_tiles);
+  for (mb::SmTileCache &tc : b->smTiles) { if (tc.d_tiles) (void)hipFree(tc.d_tiles); if (tc.d_deps) (void)hipFree(tc.d_deps); if (tc.d_flags) (void)hipFree(tc.d_flags); }
   delete b;
 }
 

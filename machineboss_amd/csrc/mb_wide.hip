@@ -1301,7 +1301,7 @@ struct RetPart {
   bool useMerge = true;       // two-transition candidates (off: the part's LDS is tight -- they lengthen the spans, the relays push the period up)
   // the two-transition candidates of this part, chosen once (they depend on the graph, not on the lanes or the weights): indices into
   // the part's edge list in construction order, and that list's length as a check
-  bool mergeKnown = false; std::vector<int> merged; size_t nEdges = 0;
+  bool mergeKnown = false; std::vector<int> merged; size_t nEdges = 0;      // nEdges: ret_edge_sig of the list the indices refer to
 };
 
 namespace {
@@ -1363,7 +1363,19 @@ std::vector<int> ret_cycle(const std::vector<RetEdge> &edges, int nStates, int p
 // finds v's own code where it always was.  Merged: silent transitions only (an emitting second transition would need the source two
 // columns back), never into a state that is itself read through a merge nor out of one (no three-transition candidates), not out
 // of the seed's state, fan-ins bounded.  Chosen greedily along the cycles that forbid the next shorter period, until `target`.
+// signature of a part's edge list (source, destination, emitting, token of every edge, in order, and their number): the merges chosen
+// for a part are indices into this list, so they are re-applied only to the very same list -- a weight update that turns an edge to
+// -inf and brings another back keeps the COUNT but not the edges
+static size_t ret_edge_sig(const std::vector<RetEdge> &edges, int nStates, int nOwn) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { h ^= v; h *= 1099511628211ull; };
+  mix(edges.size()); mix((unsigned long long)nStates); mix((unsigned long long)nOwn);
+  for (const RetEdge &e : edges) { mix(((unsigned long long)(unsigned)e.src << 32) | (unsigned)e.dst); mix(((unsigned long long)(unsigned)e.em << 32) | (unsigned)e.tok); }
+  return (size_t)h;
+}
+
 void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState, int target, int bound, bool backward, bool verbose, RetPart *cache) {
+  const size_t sig = ret_edge_sig(edges, nStates, nOwn);
   std::vector<RetEdge> orig = edges;
   for (size_t i = 0; i < orig.size(); ++i) orig[i].orig = (int)i;
   edges = orig;
@@ -1391,7 +1403,7 @@ void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState
     return lo;
   };
   int nMerged = 0, p0 = -1, p = -1;
-  if (cache && cache->mergeKnown && cache->nEdges == orig.size()) {      // chosen before (another lane count, a weight update): apply
+  if (cache && cache->mergeKnown && cache->nEdges == sig) {      // chosen before for this very edge list (another lane count, a weight update): apply
     for (int i : cache->merged) if (i >= 0 && i < (int)orig.size()) merged[i] = 1;
     if (!cache->merged.empty()) rebuild();
     return;
@@ -1416,7 +1428,7 @@ void ret_merge(std::vector<RetEdge> &edges, int nStates, int nOwn, int seedState
     if (!picked) break;
     rebuild();
   }
-  if (cache) { cache->mergeKnown = true; cache->nEdges = orig.size(); cache->merged.clear(); for (size_t i = 0; i < orig.size(); ++i) if (merged[i]) cache->merged.push_back((int)i); }
+  if (cache) { cache->mergeKnown = true; cache->nEdges = sig; cache->merged.clear(); for (size_t i = 0; i < orig.size(); ++i) if (merged[i]) cache->merged.push_back((int)i); }
   if (verbose) fprintf(stderr, "[mbhip] wide retimed part: %d silent transitions merged into two-transition candidates, shortest period %d -> %d (%zu -> %zu candidates)\n", nMerged, p0, p, orig.size(), edges.size());
 }
 }  // namespace

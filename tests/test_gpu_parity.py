@@ -1684,6 +1684,44 @@ def test_one_tape_machines_are_cut_for_long_sweeps_only(capi, monkeypatch):
     dm.close()
 
 
+def test_one_tape_parts_follow_a_weight_update_that_changes_the_edge_set(capi, oracle_mod, monkeypatch):
+    """the two-transition candidates of a part are remembered as indices into the part's edge list, and that list drops
+    edges of weight -inf -- a weight update that silences one transition and revives another keeps the list's LENGTH but not its
+    edges.  The remembered choice is keyed by a signature of the list now: after such an update the k-part sweep still returns what a
+    fresh machine with those weights returns, and what the oracle says."""
+    import copy
+    m, em = _profile_machine(3)
+    x = np.zeros(0, np.int32)
+    ys = [np.random.RandomState(30 + n).randint(1, 4, size=n).astype(np.int32) for n in (90, 150)]
+    monkeypatch.setenv("MB_ONETAPE_PARTS_MIN_LEN", "0")
+    monkeypatch.setenv("MB_WIDE_MIN_STATES", "1")
+    dm = capi.DeviceMachine(em)
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    b.viterbi(paths=False); assert " parts" in capi.last_kernel_name()
+    lw = np.asarray(em.logWeight).copy()
+    sil = np.nonzero((np.asarray(em.inTok) == 0) & (np.asarray(em.outTok) == 0) & np.isfinite(lw))[0]
+    rng = np.random.RandomState(4)
+    for trial in range(3):
+        lw2 = lw.copy()
+        kill = rng.choice(sil, size=3, replace=False)
+        lw2[kill] = -np.inf                                   # three silent transitions silenced ...
+        dm.set_weights(lw2)
+        got1 = b.viterbi(paths=False)[0]; ll1 = b.forward(capi.MB_ROLLING)
+        lw3 = lw2.copy(); lw3[kill[0]] = lw[kill[0]]; lw3[rng.choice(np.setdiff1d(sil, kill))] = -np.inf      # ... then one revived and another silenced: same count
+        dm.set_weights(lw3)
+        got = b.viterbi(paths=False)[0]; ll = b.forward(capi.MB_ROLLING)
+        assert " parts" in capi.last_kernel_name() or "k_onetape_join" in capi.last_kernel_name()
+        em3 = copy.copy(em); em3.logWeight = lw3
+        dmf = capi.DeviceMachine(em3)
+        bf = capi.DeviceBatch.from_pairs(dmf, [(x, y) for y in ys])
+        assert np.array_equal(got, bf.viterbi(paths=False)[0]) and close(ll, bf.forward(capi.MB_ROLLING), 1e-9, 1e-9)
+        om = oracle_mod.OracleMachine(em3)
+        for k, y in enumerate(ys):
+            assert got[k] == om.viterbi(x, y)[-1, -1, -1] and close(ll[k], om.loglike(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        dmf.close()
+    dm.close()
+
+
 def test_one_tape_parts_fall_back_when_a_value_never_arrives(capi, monkeypatch, capfd):
     """The exchange between the parts of a sequence has no way to hang: a lane waits a bounded time for another part's value, then raises
     the launch's status word, every other waiter stops, the kernel drains -- and the host discards the results, LATCHES the machine's
