@@ -123,7 +123,10 @@ int mb_batch_viterbi(mb_batch *b, double *loglike, int64_t *pathOff, uint32_t *p
  * Pairs with a -inf likelihood contribute nothing to counts (the reference would produce NaN there).
  * The reference's loop is serial and reproduces bit for bit; here the order of some additions follows the scheduling (counts agree
  * to ~1e-10 from run to run).  Option MB_DETERMINISTIC=1 (mb_set_option or the environment, read when the call begins) puts every
- * such accumulator into 64-bit fixed point: repeated calls return identical counts, below 6.7e7 per transition and call (a count beyond that makes the call FAIL: every conversion saturates, the host checks). */
+ * such accumulator into 64-bit fixed point: repeated calls return identical counts, below 6.7e7 per transition and call.  A count in [6.7e7, 2.7e8) makes the call FAIL (every conversion saturates at 2^62, the host
+ * checks the accumulators); the check is NOT airtight beyond that -- a 64-bit accumulator that several saturated terms push past 2^64
+ * wraps, and a true count of 2.7e8 or more per transition and call may come back small with rc = 0: keep a call's batch below 2.7e8
+ * expected uses of any one transition (2.7e8 emitted symbols), or use the floating-point mode. */
 int mb_batch_counts(mb_batch *b, double *counts, double *loglikeSum, double *loglike);
 
 /* One full matrix back to the host, for DPMatrix::cell()/writeJson() (src/dpmatrix.defs.h:39-53), the golden

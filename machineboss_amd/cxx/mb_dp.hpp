@@ -493,20 +493,24 @@ public:
 };
 
 class ForwardCore : public DPMatrixCore {      // src/forward.h:19-27
-  double ll = 0;
-  bool haveLL = false;
+  mutable double ll = 0;
+  mutable bool haveLL = false;
+  const bool rollable;
 public:
-  // pre: this pair's result of prefetch(), if there is one
+  // pre: this pair's result of prefetch(), if there is one.  NOTHING is swept at construction (a caller that builds a
+  // ForwardMatrix only to walk it -- getCounts(forward, backward), samplePath -- paid a rolling sweep per pair for a value it never read)
   ForwardCore(const FlatMachine &m, const std::vector<InputToken> &in, const std::vector<OutputToken> &out, const Envelope &e, StateIndex startState = 0, const PrefetchedPair *pre = nullptr)
-      : DPMatrixCore(m, in, out, e, MB_FORWARD, (int)startState) {
-    if (startState != 0) return;       // a caller-chosen start state (src/forward.h:24) exists on the matrix route only: logLike() fetches it
-    if (pre) ll = pre->ll;
-    else ll = onePairBatch()->forward(MB_ROLLING)[0];
-    haveLL = true;
+      : DPMatrixCore(m, in, out, e, MB_FORWARD, (int)startState), rollable(startState == 0) {      // (a caller-chosen start state, src/forward.h:24, exists on the matrix route only)
+    if (rollable && pre) { ll = pre->ll; haveLL = true; }
   }
-  // the rolling sweep's value (src/forward.defs.h:51-55 reads the end cell of the same recursion; the two agree to ~1e-9
-  // relative when the sweep sums in another order than the materialised fill)
-  double logLike() const { return haveLL ? ll : endCell(); }
+  // src/forward.defs.h:51-55.  Once the matrix has been fetched this IS its end cell, so that posteriors normalised with logLike()
+  // agree with the cells they are computed from; before that, the rolling sweep's value (run on the first call; the two agree to
+  // ~1e-9 relative when the sweep sums in another order than the materialised fill)
+  double logLike() const {
+    if (matrixFetched() || !rollable) return endCell();
+    if (!haveLL) { ll = onePairBatch()->forward(MB_ROLLING)[0]; haveLL = true; }
+    return ll;
+  }
   // stochastic traceback (src/forward.cpp:17-23)
   template <class MachineT, class Generator>
   typename PathOf<MachineT>::type samplePath(const MachineT &m, Generator &rng) const { return traceBack(m, randomTransSelector(rng)); }

@@ -300,13 +300,18 @@ class ForwardMatrix(_DPMatrix):
     def __init__(self, machine: EvaluatedMachine, seqPair: SeqPair, envelope: Optional[Envelope] = None, startState: int = 0):
         super().__init__(machine, seqPair, envelope, startState)
         self._ll = None
-        if startState == 0:            # a caller-chosen start state (src/forward.h:24) exists on the matrix route only
+        self._rollable = startState == 0            # a caller-chosen start state (src/forward.h:24) exists on the matrix route only
+
+    def logLike(self) -> float:
+        """The matrix's end cell once the matrix has been fetched (posteriors normalised with it agree with the cells); before that the
+        rolling sweep's value, computed on the first call -- nothing is swept at construction."""
+        if self._matrix is not None or not self._rollable:
+            return self.endCell()
+        if self._ll is None:
             b = self._onePairBatch()
             self._ll = float(b.forward(capi.MB_ROLLING)[0])
             b.close()
-
-    def logLike(self) -> float:
-        return self.endCell() if self._ll is None else self._ll
+        return self._ll
 
     def samplePath(self, m: Machine, rng, s: Optional[int] = None) -> MachinePath:
         """Stochastic traceback with exp(candidate) weights (src/forward.cpp:17-23)."""
