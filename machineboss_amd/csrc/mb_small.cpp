@@ -853,14 +853,16 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
   A.envStart = sw.d_envStart; A.envEnd = sw.d_envEnd;
   bool ok = true;
-  // ONE launch when the launches of the sweep would hold a handful of tiles each (a single pair, a few short pairs): see sm_wait in the
-  // generated source.  MB_SMALL_ONE_LAUNCH: 1 always, 0 never; default: fewer than 256 tiles per launch on average over >= 4 launches.
+  // ONE launch for the whole sweep (sm_wait in the generated source): MB_SMALL_ONE_LAUNCH=1.  OFF by default -- measured on a single
+  // 1 kb x 1 kb dnapsw pair (scripts/single_pair_probe.py): 47 launches 1.011 ms, one launch 1.033 ms.  The chain is not bound by the
+  // launches: a lone wavefront issues a Forward step in 294 ns (705 cycles of VALU issue) and a tile is 64 steps + 3 us, and the
+  // hand-over by whole 64-step blocks makes a strip lag the one to its left by two blocks, with one launch or with 47.
   static bool oneLaunchOff = false;      // latched when a tile's wait ran out once (a shared device: the tiles were not scheduled in list order)
   const long long nTiles = off[nLaunch];
-  const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", -1);
+  const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", 0);
   // (not the count sweep: it adds into the caller's accumulators as it goes, so a sweep that gave up could not simply be run again)
   const bool oneLaunch = tc.d_deps && tc.d_flags && nTiles > 0 && !oneLaunchOff && oneWant != 0 && mode != SM_COUNT &&
-                         (oneWant == 1 || (nLaunch >= 4 && nTiles / nLaunch < 256 && nTiles <= (1 << 20)));
+                         oneWant == 1 && nTiles <= (1 << 20);
   if (oneLaunch) {
     unsigned *flags = (unsigned *)tc.d_flags;      // [nTiles] done words + the error word behind them
     if (!hip_ok(hipMemsetAsync(flags, 0, ((size_t)nTiles + 1) * sizeof(unsigned), st), "memset(tile flags)")) return 1;

@@ -1406,6 +1406,42 @@ def test_one_tape_family_profile_machine(capi, oracle_mod, monkeypatch, stages):
     assert close(b.forward(capi.MB_ROLLING), [om.loglike(x, y, oracle_mod.SUM_EXACT) for y in ys], FAST_REL, FAST_ABS)
 
 
+@pytest.mark.parametrize("nSym,S", [(70, 300), (100, 2600), (70, 10400)])
+def test_one_tape_machines_the_retimed_planner_declines(capi, oracle_mod, nSym, S):
+    """Why the column-by-column sweeps (k_wide_sweep, k_wide_viterbi, k_wide_sum32) stay in the library: the retimed planner keeps one penalty column per
+    symbol in a 64-entry row (mb_wide.hip, wide_ret_build: rowLen > 64 declines), so a one-tape machine over more than 63 symbols -- a
+    byte or codon-pair alphabet; the reference puts no bound on an alphabet (src/machine.h:95-101) -- gets no retimed program.  No knob
+    is set here: the family's own choice, checked like every other one-tape kernel.  10 400 states: two fp64 columns no longer fit the LDS
+    and the sum semiring takes the fp32-relative kernel (k_wide_sum32), also by itself.  The max semiring: up to 2 048 states the tile
+    kernel specialised at run time (mb_api.hip, onetape_tiled_viterbi), k_wide_viterbi while a column fits the LDS, k_wide_sweep<1> beyond."""
+    from randmachine import random_machine
+    em = random_machine(S, 0, nSym, 9100 + nSym, density=2.2, silent_density=1.0)
+    om = oracle_mod.OracleMachine(em); dm = capi.DeviceMachine(em)
+    rng = np.random.RandomState(nSym)
+    x = np.zeros(0, np.int32)
+    ys = [rng.randint(1, nSym + 1, size=n).astype(np.int32) for n in (37, 0, 1, 90)]
+    b = capi.DeviceBatch.from_pairs(dm, [(x, y) for y in ys])
+    ll = b.forward(capi.MB_ROLLING)
+    f32 = capi.last_kernel_name() == "k_wide_sum32"
+    assert f32 == (S > 10000) and (f32 or capi.last_kernel_name() == "k_wide_sweep<0>")
+    rel, ab = (2e-5, 2e-5) if f32 else (FAST_REL, FAST_ABS)
+    b.viterbi(paths=False)
+    assert capi.last_kernel_name() == ("k_medium_jit" if S <= 2048 else ("k_wide_viterbi" if S < 10000 else "k_wide_sweep<1>"))
+    vll, off, edges = b.viterbi()
+    counts, s, _ = b.counts()
+    ref = np.zeros(em.nTransitions)
+    for k, y in enumerate(ys):
+        V = dm.fill(capi.MB_VITERBI, x, y); F = dm.fill(capi.MB_FORWARD, x, y)
+        Vo = om.viterbi(x, y)
+        assert np.array_equal(V, Vo) and vll[k] == Vo[-1, -1, -1]
+        assert close(F, om.forward(x, y, oracle_mod.SUM_EXACT), rel, ab) and close(ll[k], F[-1, -1, -1], 1e-6 if f32 else 1e-9, 1e-12)
+        if Vo[-1, -1, -1] > -math.inf:
+            assert np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, Vo))
+        if F[-1, -1, -1] > -math.inf:
+            om.counts_add(x, y, ref, oracle_mod.SUM_EXACT)
+    assert close(counts, ref, 1e-4 if f32 else 1e-5, 1e-6 if f32 else 1e-7)
+
+
 @pytest.mark.parametrize("knobs", [{}, {"MB_WIDE_RETIMED_PERIOD": "+3"}, {"MB_WIDE_LANES": "256"}, {"MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_ONETAPE_TB": "0"}, {"MB_ONETAPE_TB": "0", "MB_WIDE_GLOBAL_VECTORS": "1"}, {"MB_ONETAPE_TB_FAST": "0"}])
 def test_one_tape_retimed_sweep(capi, oracle_mod, monkeypatch, knobs):
     """The retimed sweep of the one-tape family (mb_wide.hip k_wide_retimed: every state on its own column, a period of a
