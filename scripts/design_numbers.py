@@ -1,9 +1,9 @@
-"""The "current numbers" table of DESIGN.md section 4.3, generated from the last full bench line (profiles/<tag>_bench.json), so that
-the document quotes ONE figure per mode and says where it comes from.  usage: python scripts/design_numbers.py [tag=r05] [--write]
+"""The "current numbers" table of DESIGN.md section 4.5, generated from the last full bench line (profiles/<tag>_bench.json), so that
+the document quotes ONE figure per mode and says where it comes from.  usage: python scripts/design_numbers.py [tag=r06] [--write]
 --write replaces the text between <!-- NUMBERS:BEGIN --> and <!-- NUMBERS:END --> in DESIGN.md."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r06")
 b = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench.json")))
 e = b["extra"]
 rows = []
@@ -26,7 +26,7 @@ c4 = e["counts4"]; row("4a", "Backward fill + count sweep (`--train` E-step), 63
 cb = e.get("config4b", {})
 if "forward_materialised" in cb:
     row("4b (literal composition, 482 states)", "materialised Forward 256 pairs / rolling", "tiled", "%s / %s" % (cb["forward_materialised"], cb["forward_rolling"]), "G cells/s", cb["roofline"]["frac"], "HBM, 8 B/cell", iss(cb["roofline"]), "composed on the box")
-    row("4b", "Viterbi fill / with paths (64 pairs); counts (24 pairs)", "tiled", "%s / %s; %s" % (cb["viterbi_fill"], cb["viterbi_with_paths"], cb["counts_lattice"]), "G (lattice-)cells/s", cb["roofline_counts"]["frac"], "counts: 16 B/lattice cell", iss(cb["roofline_counts"]), "counts: 7 columns = 7 wavefronts per CU (4.1d)")
+    row("4b", "Viterbi fill / with paths (64 pairs); counts (24 pairs)", "tiled", "%s / %s; %s" % (cb["viterbi_fill"], cb["viterbi_with_paths"], cb["counts_lattice"]), "G (lattice-)cells/s", cb["roofline_counts"]["frac"], "counts: 16 B/lattice cell", iss(cb["roofline_counts"]), "counts: 7 columns = 7 wavefronts per CU (history 4.1d)")
 c3 = e["counts"]; row("3", "Backward fill + count sweep, 1024 x 400 x 400 (per GPU)", "small", c3["value"], "G lattice-cells/s", c3["roofline"]["frac"], "HBM, 16 B", iss(c3["roofline"]), "%.2f ms device" % c3["device_ms"])
 f3 = e["forward_config3"]; row("3", "materialised Forward", "small", f3["value"], "G cells/s", f3["roofline"]["frac"], "HBM, 8 B", iss(f3["roofline"]))
 v2 = e["viterbi"]; row("2", "Viterbi fill / with paths, 1024 x 1 kb x 1 kb", "small", "%s / %s" % (v2["fill_only"], v2["value"]), "G cells/s", v2["roofline"]["frac"], "1 B/cell; issue", "--")
@@ -37,12 +37,21 @@ if "full_size" in c5:
     fs = c5["full_size"]
     if "viterbi_with_paths" in fs:
         row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill / with paths (traceback codes)", "one-tape", "%s / %s / %s" % (fs["forward_rolling"], fs["viterbi_fill"], fs["viterbi_with_paths"]), "G cells/s", None,
-            "a latency chain of 5 stages per column, k workgroups per sequence on all 256 CUs", "see 4.2d", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
+            "a latency chain of 5 rounds per column, k workgroups per sequence on all 256 CUs, straight-line code generated for the machine", "see 4.4", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
     else:
-        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "a latency chain of 5 stages per column, k workgroups per sequence on all 256 CUs", "see 4.2d", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
+        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "a latency chain of 5 rounds per column, k workgroups per sequence on all 256 CUs, straight-line code generated for the machine", "see 4.4", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
     if "counts_lattice" in fs:
-        row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "the two fills side by side, 2-4 workgroups per sequence each (4.2d)", "--", "%.0f ms" % fs["counts_ms"])
+        row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "the two fills side by side, 2 workgroups per sequence each, then the count kernel (4.4)", "--", "%.0f ms" % fs["counts_ms"])
     row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "one workgroup per sequence (sweeps below 4 096 columns are not cut): vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
+tr = e.get("train", {})
+if "config3" in tr:
+    t3 = tr["config3"]["steady"]
+    row("3 (`boss --train`, N = 1)", "one Baum-Welch iteration end to end: weights evaluated, set_weights, E-step, M-step", "small", t3["iteration_ms"], "ms", None, "host algebra + E-step", "--",
+        "eval %.1f + set_weights %.1f + E-step %.1f (device %.1f) + M-step %.1f ms; %s G lattice-cells/s end to end" % (t3["eval_ms"], t3["set_weights_ms"], t3["estep_ms"], t3["estep_device_ms"], t3["mstep_ms"], tr["config3"]["lattice_gcells_per_s_end_to_end"]))
+if "config5_2kb" in tr:
+    t5 = tr["config5_2kb"]["steady"]
+    row("5 (64 x 2 kb, `--train`, N = 1)", "device-facing part of an iteration: weights evaluated, set_weights (programs re-planned), E-step", "one-tape", t5["device_facing_ms"], "ms", None, "re-plan + E-step", "--",
+        "eval %.1f + set_weights %.1f + E-step %.1f (device %.1f) ms; the M-step (BFGS over 14 691 symbolic terms in Python) is host algebra and is not run" % (t5["eval_ms"], t5["set_weights_ms"], t5["estep_ms"], t5["estep_device_ms"]))
 dr = e.get("dropin", {})
 for key, name in (("config4", "4a through the reference's call sites (8 pairs)"), ("config2", "2 through the reference's call sites (1024 pairs)")):
     d = dr.get(key) or {}

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-6 evidence in one go (through gpurun, from the repo root; summaries land under gpurun_out/prof_*/summary and gpurun_out/r05/, copy them
+# Round-6 evidence in one go (through gpurun, from the repo root; summaries land under gpurun_out/prof_*/summary and gpurun_out/r06/, copy them
 # to profiles/):
 #   1. the headline bench under rocprofv3 (kernel stats + HBM PMC passes) and the hashes of every kernel source it generated
-#      (r05_kernel_sha.json: what bench.py checks its recorded constants against);
+#      (r06_kernel_sha.json: what bench.py checks its recorded constants against);
 #   2. the other modes with kernel stats + HBM PMC: config 3 counts / Forward (small family), config 4 counts / Viterbi (tiled family),
 #      the literal config 4 machine's Forward AND its E-step at the config's stated size (24 x 487 x 10 kb);
 #   3. SQ counters: the tiled count sweep (psw2dna), the 482-state E-step at the stated size, the one-tape sweeps at 64 x 50 kb;
@@ -23,6 +23,14 @@ bash scripts/profile_sq_c4b_counts.sh $T > gpurun_out/profile_sq_c4b_$T.log 2>&1
 cp gpurun_out/prof_sq_${T}_c4b_counts/summary/* gpurun_out/$T/ 2>/dev/null
 ONETAPE_LEN=50000 ONETAPE_MODES=rv bash scripts/profile_onetape.sh $T > gpurun_out/profile_onetape_$T.log 2>&1; tail -12 gpurun_out/profile_onetape_$T.log
 cp gpurun_out/prof_onetape_$T/summary/* gpurun_out/$T/ 2>/dev/null
+# round 6: the sweeps generated for config 5's machine against the interpreter (same process, results compared), the E-step's kernel table
+# at 64 x 50 kb, what the sticky pool budget removed (scripts/stall_repro.py) and the single-pair chain (scripts/single_pair_probe.py)
+timeout 900 python3 scripts/jit_probe.py 64 50000 20 roll,vit,align > gpurun_out/$T/${T}_jit_probe.txt 2>&1; tail -12 gpurun_out/$T/${T}_jit_probe.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_estep_$T -- python3 scripts/estep_probe.py 64 50000 2 > gpurun_out/$T/${T}_onetape_estep_run.txt 2>&1
+cp $(find gpurun_out/prof_estep_$T -name "*kernel_stats.csv" | head -1) gpurun_out/$T/${T}_onetape_estep_kernel_stats.csv 2>/dev/null
+tail -4 gpurun_out/$T/${T}_onetape_estep_run.txt
+timeout 600 python3 scripts/stall_repro.py > gpurun_out/$T/${T}_stall_repro.txt 2>&1; tail -6 gpurun_out/$T/${T}_stall_repro.txt
+timeout 300 python3 scripts/single_pair_probe.py dnapsw 1000 1000 200 > gpurun_out/$T/${T}_single_pair.txt 2>&1; cat gpurun_out/$T/${T}_single_pair.txt
 # the generated sources the library really runs (headline shapes: 487-aa inputs select the strip width), then their ISA
 J=gpurun_out/jit_$T; rm -rf $J; mkdir -p $J $J/strip
 MB_JIT_CACHE=0 MB_MEDIUM_JIT_DUMP=$J/psw2dna python3 scripts/mode_probe.py psw2dna 8 487 600 fwd,roll,vit,cnt > $J/psw2dna.log 2>&1
