@@ -432,7 +432,7 @@ def extra_single_gpu(capi, np, hbm_peak):
             (cnt5f, s5cf, _), t5cf = timed(lambda: b5f.counts(), 1, label="config5.full_size.counts")
             out["config5"]["full_size"].update({"counts_lattice": round(cells5f / t5cf / 1e9, 2), "counts_ms": round(t5cf * 1e3, 1), "counts_device_ms": round(capi.last_device_ms(), 1),
                                                 "counts_kernel": capi.last_kernel_name(), "counts_symbol_invariant": float(cnt5f[np.asarray(em5.outTok) != 0].sum()) / (64 * 50000),
-                                                "counts_note": "Forward + Backward fills (k_wide_retimed, fp64 log-sum-exp correction term: sequences >= 10 000 symbols) + k_onetape_counts, G lattice-cells/s"})
+                                                "counts_note": "Forward + Backward fills side by side (k_wide_jit, 2 workgroups per sequence each, fp64 log-sum-exp correction term: sequences >= 10 000 symbols) + k_onetape_counts, one chunk of 64 sequences (2 x 129.6 GB of matrices), G lattice-cells/s"})
         except Exception as e:
             out["config5"]["full_size"]["counts_error"] = str(e)
         del b5f, e5p
@@ -559,6 +559,7 @@ def extra_train(capi, np):
     out["config5_2kb"] = {"workload": "fn3 (20 nodes) . simple_introns . translate . dnapsw: %d states, %d transitions, 64 sequences x 2000 nt" % (ev.nStates, ev.nTransitions),
                           "first_iteration_ms": {k_: round(v, 2) for k_, v in rows[0].items() if k_ != "loglike"}, "steady": steady5,
                           "lattice_gcells_per_s_device_facing": round(cells5 / (steady5["device_facing_ms"] / 1e3) / 1e9, 2),
+                          "note": "set_weights only marks the programs stale (0.1 ms): the relaxation, the plan of the merged schedule and the upload are paid inside the E-step that follows (estep_ms - 18.8 ms of a plain E-step = the re-plan)",
                           "mstep": "not run: no closed form (84 parameters as products), the Python host's BFGS over 14 691 symbolic terms takes minutes -- host algebra outside the DP path"}
     return out
 
@@ -729,7 +730,7 @@ def main():
         extra["expected_scaling"] = {
             "config 2-4 (batches of pairs, this line)": "weak scaling 1.0 per GPU by construction: every rank fills its own pairs, no data-path collective; strong scaling of 256 pairs over 8 GPUs leaves 32 pairs per GPU, whose tile wavefront still fills 256 CUs (672 live tiles per launch)",
             "config 3 (--train)": "one all-reduce of nTransitions + 1 doubles (3.6 KB) per EM iteration: latency only",
-            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling 1.1-1.3x for the 5 063-state machine (measured on one GPU, extra.config5.eight_per_gpu of the N = 1 line: 64 sequences against 8): a one-tape lattice is serial along its columns, a sequence is k <= 8 workgroups and its period a latency chain of 5 stages (DESIGN.md 4.2d), so 8 sequences per GPU take almost as long as 64 on one GPU; only a batch of more sequences than CUs scales.  The whole fn3 profile (21 761 states, ring beyond one CU's LDS) does scale with workgroups per sequence: 64 -> 16 -> 4 sequences x 3 kb take 30 -> 18 -> 15 ms (Viterbi fill)"}
+            "config 5 (64 sequences x 50 kb over 8 GPUs)": "STRONG scaling ceiling 1.0-1.3x for the 5 063-state machine (measured on one GPU, extra.config5.eight_per_gpu of the N = 1 line: 64 sequences against 8; round 6 with the generated sweeps: Forward 1.27, Viterbi 1.06, --align 1.04): a one-tape lattice is serial along its columns, a sequence is k <= 8 workgroups and its period a latency chain of 5 rounds (DESIGN.md 4.4), so 8 sequences per GPU take almost as long as 64 on one GPU; only a batch of more sequences than CUs scales.  The whole fn3 profile (21 761 states, ring beyond one CU's LDS) does scale with workgroups per sequence: 64 -> 16 -> 4 sequences x 3 kb take 30 -> 18 -> 15 ms (Viterbi fill)"}
     if grp and not args.no_extra:
         # the ONE collective of the path (--train): E-step on this rank's shard of config 3, then the all-reduce of
         # nTransitions + 1 doubles over RCCL (xGMI)
