@@ -1940,17 +1940,21 @@ int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t 
     ins.push_back(in);
   }
   WideJitFlags F; F.viterbi = mode == MB_VITERBI; F.tb = tbCodes; F.acc = acc; F.backward = backward != 0; F.inputTape = nOutTok == 0; F.nExpTot = nExpTot;
-  std::vector<WideJitDesc> descs(ins.size());
-  const int regs = 512 / ((ins[0].W / 64 + 3) / 4), forceLevel = env_int("MB_WIDE_JIT_LEVEL", -1);
-  for (size_t p = 0; p < ins.size(); ++p) {
-    std::string why; bool ok = false;
-    for (int level = forceLevel >= 0 ? forceLevel : 0; level <= (forceLevel >= 0 ? forceLevel : 1) && !ok; ++level) {
-      if (!wide_jit_describe(ins[p], acc, level, descs[p], &why)) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": " + why); return 1; }
-      ok = descs[p].regEstimate <= regs || forceLevel >= 0;
-    }
-    if (!ok) { set_error("mb_debug_wide_jit: part " + std::to_string(p) + ": constants per lane beyond the register file"); return 1; }
+  // the plan the library would run: the register estimate's choice, planned again with fewer constants in registers while the compiled
+  // kernel spills (mb_wide_jit.cpp, wide_jit_plan; MB_WIDE_JIT_ATTEMPT: the attempt to start from -- the device-free replays of the later ones)
+  std::vector<WideJitDesc> descs;
+  std::string code, obj;
+  for (int attempt = std::max(0, std::min(env_int("MB_WIDE_JIT_ATTEMPT", 0), WIDE_JIT_ATTEMPTS - 1));; ++attempt) {
+    std::string why;
+    if (!wide_jit_plan(ins, acc != 0, attempt, descs, &why)) { set_error("mb_debug_wide_jit: " + why); return 1; }
+    code = wide_jit_source(descs, F);
+    if (!compile) break;
+    std::string log;
+    if (!jit_compile(code, "mb_wide_jit.hip", obj, &log, nullptr)) { set_error("mb_debug_wide_jit: hiprtc: " + log.substr(0, 2000)); return 1; }
+    const long long scratch = jit_kernel_meta(obj, ".private_segment_fixed_size");
+    if (scratch <= 0) break;
+    if (attempt + 1 >= WIDE_JIT_ATTEMPTS) { set_error("mb_debug_wide_jit: the kernel uses " + std::to_string(scratch) + " bytes of scratch memory"); return 1; }
   }
-  const std::string code = wide_jit_source(descs, F);
   FILE *f = fopen(path, "w");
   if (!f) { set_error("mb_debug_wide_jit: cannot open output file"); return 1; }
   fputs(code.c_str(), f);
@@ -1982,10 +1986,6 @@ int mb_debug_wide_jit(int32_t nStates, int32_t nInTok, int32_t nOutTok, int64_t 
   fclose(f);
   if (!ok) { set_error("mb_debug_wide_jit: short write"); return 1; }
   if (compile) {
-    std::string obj, log;
-    if (!jit_compile(code, "mb_wide_jit.hip", obj, &log, nullptr)) { set_error("mb_debug_wide_jit: hiprtc: " + log.substr(0, 2000)); return 1; }
-    const long long scratch = jit_kernel_meta(obj, ".private_segment_fixed_size");
-    if (scratch > 0) { set_error("mb_debug_wide_jit: the kernel uses " + std::to_string(scratch) + " bytes of scratch memory"); return 1; }
     if (FILE *g = fopen((std::string(path) + ".co").c_str(), "wb")) { fwrite(obj.data(), 1, obj.size(), g); fclose(g); }
   }
   return 0;

@@ -38,7 +38,7 @@ static int knockout() {
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
 // ---- the streams -> what is unrolled --------------------------------------------------------------------------------------------
-bool wide_jit_describe(const WideJitIn &in, bool acc, int level, WideJitDesc &D, std::string *why) {
+bool wide_jit_describe(const WideJitIn &in, bool acc, int level, WideJitDesc &D, std::string *why, int maxRing) {
   auto fail = [&](const char *msg) { if (why) *why = msg; return false; };
   D = WideJitDesc();
   D.in = in;
@@ -143,9 +143,9 @@ bool wide_jit_describe(const WideJitIn &in, bool acc, int level, WideJitDesc &D,
     }
     const int n = (int)D.items.size();
     D.ring = 0;
-    for (int d : {8, 9, 10, 11, 12, 7, 13, 6, 14, 15, 16, 17}) if (d <= n && n % d == 0) { D.ring = d; break; }      // a prefetch depth that divides the period, else padding
-    if (D.ring) D.IP = n; else { D.ring = 8; D.IP = (n + 7) / 8 * 8; }
-    if (n < 6) { D.ring = n; D.IP = n; }
+    for (int d : {8, 9, 10, 11, 12, 7, 13, 6, 14, 15, 16, 17}) if (d <= n && d <= maxRing && n % d == 0) { D.ring = d; break; }      // a prefetch depth that divides the period, else padding
+    if (D.ring) D.IP = n; else { D.ring = std::max(2, std::min(8, maxRing)); D.IP = (n + D.ring - 1) / D.ring * D.ring; }
+    if (n < 6 && n <= maxRing) { D.ring = n; D.IP = n; }
     D.regEstimate += D.ring + 6;
   }
   return true;
@@ -500,30 +500,59 @@ void WideJitKernel::release() {
 // across updates) and finds its kernel here instead of going through hiprtc's cache and the loader again
 static std::map<std::string, std::shared_ptr<WideJitModule>> g_wideJitModules;
 
+static bool wide_jit_build_one(const std::vector<WideJitDesc> &descs, const std::string &src, const std::vector<WideJitIn> &ins, const WideJitFlags &F, WideJitKernel &K, std::string *why, bool *spilled);
+
+// Where every part keeps its constants.  The compiler must hold them in registers: level 0 -- everything -- when a workgroup of this many
+// wavefronts has the registers by the estimate, else level 1 -- the rotation-dependent words streamed through a prefetch ring.  The
+// estimate is not the register allocator: a build that spills (config 5's Backward parts with the fp64 correction term at 2 workgroups
+// per sequence: 28 bytes of scratch) is planned again with less in registers -- attempt 1: every part streams; 2, 3: a prefetch ring of
+// 4, 2 words.  MB_WIDE_JIT_LEVEL forces the level of attempt 0.
+bool wide_jit_plan(const std::vector<WideJitIn> &ins, bool acc, int attempt, std::vector<WideJitDesc> &descs, std::string *why) {
+  auto fail = [&](const std::string &msg) { if (why) *why = msg; return false; };
+  descs.assign(ins.size(), WideJitDesc());
+  const int wavesPerSimd = (ins[0].W / 64 + 3) / 4, regs = 512 / wavesPerSimd;
+  const int forceLevel = attempt == 0 ? jenv("MB_WIDE_JIT_LEVEL", -1) : 1;
+  const int maxRing = attempt <= 1 ? 17 : (attempt == 2 ? 4 : 2);
+  for (size_t p = 0; p < ins.size(); ++p) {
+    std::string w;
+    bool ok = false;
+    for (int level = forceLevel >= 0 ? forceLevel : 0; level <= (forceLevel >= 0 ? forceLevel : 1) && !ok; ++level) {
+      if (!wide_jit_describe(ins[p], acc, level, descs[p], &w, maxRing)) return fail("part " + std::to_string(p) + ": " + w);
+      ok = descs[p].regEstimate <= regs || forceLevel >= 0;
+    }
+    if (!ok) return fail("constants per lane (" + std::to_string(descs[p].nWords) + " words even with the address words streamed) beyond the register file of " + std::to_string(wavesPerSimd) + " wavefronts per SIMD");
+    if (descs[p].in.W != descs[0].in.W) return fail("lanes differ between parts");
+  }
+  return true;
+}
+
 bool wide_jit_build(const std::vector<WideJitIn> &ins, const WideJitFlags &F, WideJitKernel &K, std::string *why) {
   K.release();
   K.tried = true;
   auto fail = [&](const std::string &msg) { if (why) *why = msg; return false; };
   if (!wide_jit_enabled()) return fail("MB_WIDE_JIT=0");
   if (ins.empty() || ins.size() > (size_t)WIDE_JIT_MAX_PARTS) return fail("parts");
-  std::vector<WideJitDesc> descs(ins.size());
-  size_t lds = 0;
-  // (the compiler must keep the constants in registers: level 0 -- everything -- when a workgroup of this many wavefronts has the
-  //  registers, else level 1 -- the rotation-dependent words streamed)
-  const int wavesPerSimd = (ins[0].W / 64 + 3) / 4, regs = 512 / wavesPerSimd;
-  const int forceLevel = jenv("MB_WIDE_JIT_LEVEL", -1);
-  for (size_t p = 0; p < ins.size(); ++p) {
+  std::string lastSrc, lastWhy = "no plan";
+  for (int attempt = 0; attempt < WIDE_JIT_ATTEMPTS; ++attempt) {
+    std::vector<WideJitDesc> descs;
     std::string w;
-    bool ok = false;
-    for (int level = forceLevel >= 0 ? forceLevel : 0; level <= (forceLevel >= 0 ? forceLevel : 1) && !ok; ++level) {
-      if (!wide_jit_describe(ins[p], F.acc, level, descs[p], &w)) return fail("part " + std::to_string(p) + ": " + w);
-      ok = descs[p].regEstimate <= regs || forceLevel >= 0;
-    }
-    if (!ok) return fail("constants per lane (" + std::to_string(descs[p].nWords) + " words even with the address words streamed) beyond the register file of " + std::to_string(wavesPerSimd) + " wavefronts per SIMD");
-    if (descs[p].in.W != descs[0].in.W) return fail("lanes differ between parts");
-    lds = std::max(lds, descs[p].ldsBytes);
+    if (!wide_jit_plan(ins, F.acc, attempt, descs, &w)) { if (attempt == 0) return fail(w); break; }
+    const std::string src = wide_jit_source(descs, F);
+    if (src == lastSrc) continue;      // (nothing left to move out of the registers at this step)
+    lastSrc = src;
+    bool spilled = false;
+    if (wide_jit_build_one(descs, src, ins, F, K, &lastWhy, &spilled)) return true;
+    if (!spilled) break;
+    if (opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: attempt %d spills (%s): planned again with fewer constants in registers\n", attempt, lastWhy.c_str());
   }
-  const std::string src = wide_jit_source(descs, F);
+  K.release(); K.tried = true;
+  return fail(lastWhy);
+}
+
+static bool wide_jit_build_one(const std::vector<WideJitDesc> &descs, const std::string &src, const std::vector<WideJitIn> &ins, const WideJitFlags &F, WideJitKernel &K, std::string *why, bool *spilled) {
+  auto fail = [&](const std::string &msg) { if (why) *why = msg; return false; };
+  size_t lds = 0;
+  for (const WideJitDesc &D : descs) lds = std::max(lds, D.ldsBytes);
   if (const char *dump = opt_env("MB_WIDE_JIT_DUMP")) {
     const std::string path = std::string(dump) + (F.viterbi ? (F.tb ? ".tb" : ".max") : (F.acc ? ".sum64" : ".sum")) + (F.backward ? ".bwd" : ".fwd") + ".k" + std::to_string(ins.size()) + ".hip";
     if (FILE *f = fopen(path.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -539,7 +568,7 @@ bool wide_jit_build(const std::vector<WideJitIn> &ins, const WideJitFlags &F, Wi
     }
     const long long scratch = jit_kernel_meta(code, ".private_segment_fixed_size");
     if (opt_env("MB_WIDE_VERBOSE")) fprintf(stderr, "[mbhip] wide jit: %zu bytes of source, code object %zu bytes%s, scratch %lld bytes, %lld spilled VGPRs\n", src.size(), code.size(), fromCache ? " (cache)" : "", scratch, jit_kernel_meta(code, ".vgpr_spill_count"));
-    if (scratch > 0 && !jenv("MB_WIDE_JIT_ALLOW_SCRATCH", 0)) return fail("the kernel spills to scratch memory (" + std::to_string(scratch) + " bytes)");
+    if (scratch > 0 && !jenv("MB_WIDE_JIT_ALLOW_SCRATCH", 0)) { *spilled = true; return fail("the kernel spills to scratch memory (" + std::to_string(scratch) + " bytes)"); }
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
       (void)hipGetLastError();

@@ -73,7 +73,10 @@ struct WideJitDesc {
 
 struct WideJitFlags { bool viterbi = false, tb = false, acc = false, backward = false, inputTape = false; int nExpTot = 0; };
 
-bool wide_jit_describe(const WideJitIn &in, bool acc, int level, WideJitDesc &D, std::string *why);
+bool wide_jit_describe(const WideJitIn &in, bool acc, int level, WideJitDesc &D, std::string *why, int maxRing = 17);
+// the plan of one build attempt (see mb_wide_jit.cpp): 0 the register estimate's choice ... WIDE_JIT_ATTEMPTS - 1 the least in registers
+const int WIDE_JIT_ATTEMPTS = 4;
+bool wide_jit_plan(const std::vector<WideJitIn> &ins, bool acc, int attempt, std::vector<WideJitDesc> &descs, std::string *why);
 std::string wide_jit_source(const std::vector<WideJitDesc> &parts, const WideJitFlags &F);
 void wide_jit_table(const WideJitDesc &D, const WideJitFlags &F, std::vector<uint32_t> &tab, std::vector<uint32_t> *stream = nullptr);
 

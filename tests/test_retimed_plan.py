@@ -511,10 +511,18 @@ def test_generated_one_workgroup_program_reproduces_the_oracle(name, level, monk
 
 
 @pytest.mark.parametrize("name", ["fn3-10", "composite-2", "random-40"])
-@pytest.mark.parametrize("k,lanes,level", [(2, 256, 0), (3, 64, 1), (4, 1024, 0)])
+@pytest.mark.parametrize("k,lanes,level", [(2, 256, 0), (3, 64, 1), (4, 1024, 0), (2, 256, "attempt 2"), (3, 64, "attempt 3")])
 def test_generated_k_part_programs_reproduce_the_oracle(name, k, lanes, level, monkeypatch, tmp_path):
     """... and the k-part form (one function per part in one kernel, values crossing through the exchange array): replayed part by part in
-    workgroup order, against the oracle; the traceback codes decode with the joined tables of the parts' own candidate lists."""
+    workgroup order, against the oracle; the traceback codes decode with the joined tables of the parts' own candidate lists.
+    "attempt n": the plans a build falls back to when the compiled kernel spills (wide_jit_plan: streamed words through a prefetch ring
+    of 4 / 2 entries, the period padded to a multiple of it)."""
+    if isinstance(level, str):
+        monkeypatch.setenv("MB_WIDE_JIT_ATTEMPT", level.split()[1])
+        maxRing = {"2": 4, "3": 2}[level.split()[1]]
+        level = 1
+    else:
+        maxRing = 17
     from machineboss_amd import capi
     from oracle import oracle
     em = _machines()[name]
@@ -531,6 +539,7 @@ def test_generated_k_part_programs_reproduce_the_oracle(name, k, lanes, level, m
     for mode, backward in ((capi.MB_VITERBI, False), (capi.MB_FORWARD, False), (capi.MB_FORWARD, True)):
         jp = capi.debug_wide_jit(em, str(tmp_path / "j.hip"), k=k, lanes=lanes, mode=mode, backward=backward)
         assert 2 <= len(jp["parts"]) <= k and all(p["level"] == level for p in jp["parts"])
+        if level == 1: assert all(2 <= p["ring"] <= maxRing and p["IP"] % p["ring"] == 0 for p in jp["parts"])
         for n in (0, 1, 9, 70 if max(p["lanes"] * p["nSlots"] for p in jp["parts"]) <= 4096 else 20):
             seq = np.random.RandomState(n + 3).randint(1, nt + 1, size=n).astype(np.int32)
             x, y = (z, seq) if tape_out else (seq, z)
@@ -566,6 +575,22 @@ def test_generated_source_compiles_without_a_device(tmp_path):
         jp = capi.debug_wide_jit(em, str(tmp_path / "c.hip"), k=3, lanes=256, compile=True, **kw)
         assert len(jp["parts"]) >= 2
     capi.debug_wide_jit(em, str(tmp_path / "c1.hip"), k=1, mode=capi.MB_VITERBI, compile=True)
+
+
+def test_generated_config5_backward_parts_with_the_fp64_term_are_planned_until_they_fit(tmp_path):
+    """BASELINE config 5's machine, Backward with the fp64 correction term at 2 workgroups per sequence (the E-step of 64 x 50 kb as ONE
+    chunk): the register estimate's plan spills 28 bytes, so the build plans again with a shorter prefetch ring -- and must end without
+    scratch memory (round 6: this sweep silently ran through the interpreter, 376 ms beside the Forward sweep's 284)."""
+    from machineboss_amd import capi, algebra as A
+    from machineboss_amd.machine import Machine
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).truncated(20)
+    em = EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")]), None, useDefaults=True)
+    jp = capi.debug_wide_jit(em, str(tmp_path / "b.hip"), k=2, mode=capi.MB_FORWARD, backward=True, acc=True, compile=True)
+    assert len(jp["parts"]) == 2 and all(p["level"] == 1 for p in jp["parts"])
+    assert os.path.getsize(str(tmp_path / "b.hip.co")) > 0
 
 
 def test_retimed_program_refuses_two_tape_machines(tmp_path):
