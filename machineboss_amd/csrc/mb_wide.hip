@@ -2802,7 +2802,11 @@ __global__ __launch_bounds__(256) void k_onetape_colnorm(DevMachine m, const Pai
 // with coalesced reads (B(c + 1) is the previous iteration's B(c)), and every thread evaluates its EPT transitions from LDS.
 // HBM traffic = both matrices exactly once, no L2 gathers (the kernel above: 12 ms on 64 x 2 kb, this one: the time of
 // streaming 10.4 GB).
-template <int EPT>
+// NL: loads per thread and state vector of a column (ceil(S / 512)): the staging loop is unrolled so that a thread's 2 NL loads of a
+// column are ALL in flight before the first one is stored to LDS.  As a run-time loop every iteration waited for its own two loads --
+// ten dependent trips to HBM per column on config 5's machine, 11.4 us per column where the compute phase needs 2 (71 ms per 32 sequences
+// x 50 kb = 1.8 TB/s; profiles/r06_onetape_estep_kernel_stats.csv).
+template <int EPT, int NL>
 __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const OtEdge *__restrict__ edges, const unsigned short *__restrict__ waveLabel,
                                                             int nEdges, const PairDesc *__restrict__ pairs, int colSplit, int inputTape,
                                                             const int *__restrict__ tape, const double *__restrict__ fwd,
@@ -2818,15 +2822,18 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
   const double *F = fwd + pd.cellBase, *B = bwd + pd.cellBase;
   const double ll = B[0];                       // BackwardMatrix::logLike() = cell(0,0,start), src/backward.cpp:48-50,66
   if (!(ll > -INFINITY)) return;
-  uint32_t esd[EPT]; int elab[EPT]; double ewl[EPT], acc[EPT];   // source | destination << 16 (S < 65 536 here), label, weight - LL, usage
+  // source | destination << 16 (S < 65 536 here), label, weight x log2(e) -- fp32: the term's exponent (F - LL) + B is formed in fp64 and
+  // rounded to fp32 anyway, the weight joins it in the conversion to base 2 --, usage.  Four registers a transition: with the weight
+  // in fp64 the 32-transition form spilled (17 VGPRs, 72 bytes of scratch per lane)
+  uint32_t esd[EPT]; int elab[EPT]; float ewl[EPT]; double acc[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = tid + k * 512;
     const bool in = e < nEdges;
     const OtEdge ed = in ? edges[e] : OtEdge{0u, 0xFFFFFFFFu};
     const bool live = ed.pos != 0xFFFFFFFFu;
-    esd[k] = live ? (ed.src | (m.outDst[ed.pos] << 16)) : 0u;
-    ewl[k] = live ? m.outW[ed.pos] - ll : -INFINITY;
+    esd[k] = live ? ((ed.src << 3) | (m.outDst[ed.pos] << 19)) : 0u;      // BYTE offsets into a staged vector (three vectors fit the LDS: S < 8 192)
+    ewl[k] = live ? (float)(m.outW[ed.pos] * 1.4426950408889634) : -INFINITY;
     // (the edge list is padded to whole wavefronts per label: the label is uniform inside a wavefront -> scalar registers)
     elab[k] = __builtin_amdgcn_readfirstlane((tid & ~63) + k * 512 < nEdges ? (int)waveLabel[((tid & ~63) + k * 512) >> 6] : -1);
     acc[k] = 0.0;
@@ -2838,7 +2845,16 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
   for (int c = cB - 1; c >= cA; --c) {
     { double *t = Bcur; Bcur = Bnext; Bnext = t; }                // Bnext = B(c + 1), Bcur is refilled with B(c)
     __syncthreads();                                              // the previous column's reads are done
-    for (int j = tid; j < S; j += 512) { Fl[j] = F[(long long)c * S + j]; Bcur[j] = B[(long long)c * S + j]; }
+    constexpr int NLB = (EPT >= 32 && NL > 10) ? (NL + 1) / 2 : NL;      // (32 transitions a thread leave registers for 20 loads in flight, not 28)
+#pragma unroll
+    for (int q0 = 0; q0 < NL; q0 += NLB) {
+      double fr[NLB], br[NLB];
+      const double *Fc = F + (long long)c * S, *Bc = B + (long long)c * S;
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) { const int j = tid + (q0 + q) * 512; if (q0 + q < NL && j < S) { fr[q] = Fc[j]; br[q] = Bc[j]; } }
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) { const int j = tid + (q0 + q) * 512; if (q0 + q < NL && j < S) { Fl[j] = fr[q] - ll; Bcur[j] = br[q]; } }      // (F - LL: every term's exponent needs it)
+    }
     __syncthreads();
     const int y = c < L ? tk[c] : -2;
     // The terms of this column, and their NORMALISER.  In exact arithmetic the emitting transitions that leave column c sum to 1
@@ -2852,8 +2868,12 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       t[k] = 0.0f;
-      if (elab[k] == 0) t[k] = __builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bcur[esd[k] >> 16] + ewl[k])) * 1.44269504088896f);
-      else if (elab[k] == y) { t[k] = __builtin_amdgcn_exp2f((float)(Fl[esd[k] & 0xffffu] + (Bnext[esd[k] >> 16] + ewl[k])) * 1.44269504088896f); zpart += t[k]; }
+      // (the packed offsets stay packed: unpacked once outside the column loop they would cost two registers a transition instead of one)
+      uint32_t sd = esd[k];
+      asm volatile("" : "+v"(sd));
+      const double fs = *(const double *)((const char *)Fl + (sd & 0xffffu));
+      if (elab[k] == 0) t[k] = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(fs + *(const double *)((const char *)Bcur + (sd >> 16))), 1.44269504088896f, ewl[k]));
+      else if (elab[k] == y) { t[k] = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(fs + *(const double *)((const char *)Bnext + (sd >> 16))), 1.44269504088896f, ewl[k])); zpart += t[k]; }
     }
     float inv;
     if (normalise) {
@@ -2864,7 +2884,7 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
       float z = 0.0f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) z += zred[(c & 1) * 8 + w];
-      if (c == L) z = __builtin_amdgcn_exp2f((float)(Fl[S - 1] - ll) * 1.44269504088896f);
+      if (c == L) z = __builtin_amdgcn_exp2f((float)Fl[S - 1] * 1.44269504088896f);
       inv = (z > 0.0f && z < 3.0e38f) ? 1.0f / z : 1.0f;
     } else inv = 1.0f;
 #pragma unroll
@@ -2877,13 +2897,13 @@ __global__ __launch_bounds__(512) void k_onetape_counts_lds(DevMachine m, const 
   }
 }
 
-template <int EPT>
+template <int EPT, int NL>
 static void launch_counts_lds(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_desc, long long nUnits, int colSplit, bool inputTape,
                               const int *d_tape, const double *fwd, const double *bwd, double *d_counts, hipStream_t st) {
   const size_t lds = (size_t)3 * m->S * sizeof(double) + 16 * sizeof(float);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)&k_onetape_counts_lds<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(k_onetape_counts_lds<EPT>, dim3((unsigned)nUnits), dim3(512), lds, st, m->dev, (const OtEdge *)C.d_edges,
+  if (!attr) { (void)hipFuncSetAttribute((const void *)&k_onetape_counts_lds<EPT, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_onetape_counts_lds<EPT, NL>), dim3((unsigned)nUnits), dim3(512), lds, st, m->dev, (const OtEdge *)C.d_edges,
                      (const unsigned short *)C.d_waveLabel, C.nWaves * 64, d_desc, colSplit, inputTape ? 1 : 0, d_tape, fwd, bwd, d_counts,
                      env_int_w("MB_ONETAPE_COUNT_NORMALISE", 1), g_deterministic ? 1 : 0);
 }
@@ -2954,9 +2974,15 @@ int wide_counts(const mb_machine *m, const WideCountPlan &C, const PairDesc *d_d
     auto tailOk = [&](long long units) { if (cus <= 0) return true; const long long rounds = (units + cus - 1) / cus; return (double)units >= 0.9 * (double)(rounds * cus); };
     while (((long long)hp.size() * cs < wantUnits || !tailOk((long long)hp.size() * cs)) && (maxLen + 1) / (cs * 2) >= 64 && cs < 1024) cs *= 2;
     const long long units = (long long)hp.size() * cs;
-    if (nE <= 8 * 512) launch_counts_lds<8>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
-    else if (nE <= 16 * 512) launch_counts_lds<16>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
-    else launch_counts_lds<32>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st);
+    const int nl = (int)((m->S + 511) / 512);      // <= 14: three state vectors fit the LDS
+#define OT_COUNTS_GO(E) (nl <= 4 ? launch_counts_lds<E, 4>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st) \
+                         : nl <= 8 ? launch_counts_lds<E, 8>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st) \
+                         : nl <= 10 ? launch_counts_lds<E, 10>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st) \
+                         : launch_counts_lds<E, 14>(m, C, d_desc, units, cs, inputTape, d_tape, fwd, bwd, d_counts, st))
+    if (nE <= 8 * 512) OT_COUNTS_GO(8);
+    else if (nE <= 16 * 512) OT_COUNTS_GO(16);
+    else OT_COUNTS_GO(32);
+#undef OT_COUNTS_GO
     return hip_ok(hipGetLastError(), "one-tape counts launch") ? 0 : 1;
   }
   const long long nUnits = (long long)hp.size() * colSplit;
