@@ -9,6 +9,8 @@ OUT=$ROOT/gpurun_out/prof_onetape_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} ${ONETAPE_MODES:-rmv} > "$OUT/stats.log" 2>&1
 for MODE in r v; do
+  # (the generated sweeps all carry ONE kernel name: a trace per mode tells the Forward sweeps from the max sweep)
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_$MODE" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} $MODE > "$OUT/trace_$MODE.log" 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_$MODE" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} $MODE > "$OUT/pmc_$MODE.log" 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc2_$MODE" -- python3 scripts/bench_onetape.py 20 64 ${ONETAPE_LEN:-2000} $MODE > "$OUT/pmc2_$MODE.log" 2>&1
 done
@@ -38,15 +40,13 @@ print(open(os.path.join(out, "summary", "%s_onetape_pmc_sq.txt" % tag)).read())
 # the figures bench.py quotes for config 5 (issue fraction of the occupied CUs): profiles/<tag>_onetape_sq.json
 import json
 dur = {}
-for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"]
-        if "k_wide_retimed" not in n and "k_wide_jit" not in n: continue
-        # (k_wide_jit: the sweep generated for the machine -- one symbol for every mode; the modes are told apart by the run: mode v launches the max sweep only)
-        key = "viterbi_fill" if ("k_wide_retimed<1" in n or "k_wide_retimed_parts<1" in n) else "forward_cut_in_two"
-        if "k_wide_jit" in n: key = "jit_sweeps"
-        d = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
-        dur[key] = max(dur.get(key, 0.0), d)
+for mode, key in (("v", "viterbi_fill"), ("r", "forward_cut_in_two")):
+    for f in glob.glob(os.path.join(out, "trace_" + mode, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"]
+            if "k_wide_retimed" not in n and "k_wide_jit" not in n: continue
+            d = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+            dur[key] = max(dur.get(key, 0.0), d)
 sweeps = {}
 # (round 5: k workgroups per sequence -- 64 sequences x 4 parts, or 2 halves x 2 parts: every CU holds one workgroup; MB_ONETAPE_PARTS=1: 64 / 128)
 one_wg = os.environ.get("MB_ONETAPE_PARTS") == "1"
