@@ -37,27 +37,27 @@ if "full_size" in c5:
     fs = c5["full_size"]
     if "viterbi_with_paths" in fs:
         row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill / with paths (traceback codes)", "one-tape", "%s / %s / %s" % (fs["forward_rolling"], fs["viterbi_fill"], fs["viterbi_with_paths"]), "G cells/s", None,
-            "a latency chain of 5 rounds per column, k workgroups per sequence on all 256 CUs, straight-line code generated for the machine", "see 4.4", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
+            "latency chain of 5 rounds per column; k workgroups per sequence, generated code", "see 4.4", "%.0f / %.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"], fs["viterbi_with_paths_ms"]))
     else:
-        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "a latency chain of 5 rounds per column, k workgroups per sequence on all 256 CUs, straight-line code generated for the machine", "see 4.4", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
+        row("5 (64 x 50 kb, 5 063 states)", "rolling Forward / Viterbi fill", "one-tape", "%s / %s" % (fs["forward_rolling"], fs["viterbi_fill"]), "G cells/s", None, "latency chain of 5 rounds per column; k workgroups per sequence, generated code", "see 4.4", "%.0f / %.0f ms" % (fs["forward_ms"], fs["viterbi_ms"]))
     if "counts_lattice" in fs:
         row("5 (64 x 50 kb)", "E-step (fills with the fp64 correction term + count kernel)", "one-tape", fs["counts_lattice"], "G lattice-cells/s", None, "the two fills side by side, 2 workgroups per sequence each, then the count kernel (4.4)", "--", "%.0f ms" % fs["counts_ms"])
-    row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "one workgroup per sequence (sweeps below 4 096 columns are not cut): vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
+    row("5 (64 x 2 kb)", "Forward / Viterbi fill / with paths / E-step", "one-tape", "%s / %s / %s / %s" % (c5["forward_rolling"], c5["viterbi_fill"], c5["viterbi_with_paths"], c5["counts_lattice"]), "G (lattice-)cells/s", None, "one workgroup per sequence: vector issue", "--", "256 x 4 kb: %s / %s" % (c5["all_cus"]["forward_rolling"], c5["all_cus"]["viterbi_fill"]))
 tr = e.get("train", {})
 if "config3" in tr:
     t3 = tr["config3"]["steady"]
-    row("3 (`boss --train`, N = 1)", "one Baum-Welch iteration end to end: weights evaluated, set_weights, E-step, M-step", "small", t3["iteration_ms"], "ms", None, "host algebra + E-step", "--",
+    row("3 (`boss --train`, N = 1)", "one Baum-Welch iteration end to end", "small", t3["iteration_ms"], "ms", None, "host algebra + E-step", "--",
         "eval %.1f + set_weights %.1f + E-step %.1f (device %.1f) + M-step %.1f ms; %s G lattice-cells/s end to end" % (t3["eval_ms"], t3["set_weights_ms"], t3["estep_ms"], t3["estep_device_ms"], t3["mstep_ms"], tr["config3"]["lattice_gcells_per_s_end_to_end"]))
 if "config5_2kb" in tr:
     t5 = tr["config5_2kb"]["steady"]
-    row("5 (64 x 2 kb, `--train`, N = 1)", "device-facing part of an iteration: weights evaluated, set_weights (programs re-planned), E-step", "one-tape", t5["device_facing_ms"], "ms", None, "re-plan + E-step", "--",
-        "eval %.1f + set_weights %.1f + E-step %.1f (device %.1f) ms; the M-step (BFGS over 14 691 symbolic terms in Python) is host algebra and is not run" % (t5["eval_ms"], t5["set_weights_ms"], t5["estep_ms"], t5["estep_device_ms"]))
+    row("5 (64 x 2 kb, `--train`, N = 1)", "device-facing part of an iteration", "one-tape", t5["device_facing_ms"], "ms", None, "re-plan + E-step", "--",
+        "eval %.1f + set_weights %.1f + E-step %.1f (device %.1f) ms; M-step (host BFGS) not run" % (t5["eval_ms"], t5["set_weights_ms"], t5["estep_ms"], t5["estep_device_ms"]))
 dr = e.get("dropin", {})
 for key, name in (("config4", "4a through the reference's call sites (8 pairs)"), ("config2", "2 through the reference's call sites (1024 pairs)")):
     d = dr.get(key) or {}
     if "unchanged_loop" in d:
         u, pf, bc = d["unchanged_loop"], d["unchanged_loop_prefetch"], d["batch_c_abi"]
-        row(name, "`--loglike` / `--align` loops of boss.cpp through the C++ classes: unchanged / + the prefetch line / batch C-ABI", "--",
+        row(name, "`--loglike`, `--align` loops of boss.cpp: unchanged / + prefetch line / batch C-ABI", "--",
             "%s, %s / %s, %s / %s, %s" % (u["loglike_pairs_per_s"], u["align_pairs_per_s"], pf["loglike_pairs_per_s"], pf["align_pairs_per_s"], bc["loglike_pairs_per_s"], bc["align_pairs_per_s"]),
             "pairs/s", None, "host buffers in, host objects out", "--", "no fp64 matrix over PCIe (fetches: %d)" % (u["matrix_fills"] + pf["matrix_fills"]))
 cpu = b.get("cpu_baseline") or {}
