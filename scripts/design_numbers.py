@@ -61,7 +61,7 @@ for key, name in (("config4", "4a through the reference's call sites (8 pairs)")
             "%s, %s / %s, %s / %s, %s" % (u["loglike_pairs_per_s"], u["align_pairs_per_s"], pf["loglike_pairs_per_s"], pf["align_pairs_per_s"], bc["loglike_pairs_per_s"], bc["align_pairs_per_s"]),
             "pairs/s", None, "host buffers in, host objects out", "--", "no fp64 matrix over PCIe (fetches: %d)" % (u["matrix_fills"] + pf["matrix_fills"]))
 cpu = b.get("cpu_baseline") or {}
-txt = ["Source: `profiles/%s_bench.json` (one `python3 bench.py` on the MI355X box; `frac` = algorithmic bytes / device time / 8 TB/s; `issue` = vector-issue fraction from the kernels' ISA, `profiles/%s_valu_model.json`, section 5; recorded constants are quoted only while the kernel sources' hashes match `profiles/%s_kernel_sha.json`).  Boxes of the pool differ by +-5 %%." % (tag, tag, tag), "",
+txt = ["Source: `profiles/%s_bench.json` (one `python3 bench.py` on the MI355X box; `frac` = algorithmic bytes / device time / 8 TB/s; `issue` = vector-issue fraction from the kernels' ISA, `profiles/%s_valu_model.json`; recorded constants only while the kernel hashes match `profiles/%s_kernel_sha.json`).  Boxes differ by +-5 %%." % (tag, tag, tag), "",
        "| Config | Mode | Family | Rate | HBM frac | Bound | Issue | Note |", "|---|---|---|---|---|---|---|---|"] + rows
 if cpu:
     txt += ["", "CPU baseline of the same run: %s %s on %d host cores (%s)." % (cpu["value"], cpu["unit"], cpu["cores"], cpu["kind"])]
