@@ -298,6 +298,13 @@ static hipStream_t second_stream() {
   return s2;
 }
 
+// an error path is about to release what launched kernels may still read: wait for both streams (their own errors are not news here)
+static void quiesce_streams() {
+  if (hipStream_t s2 = second_stream()) (void)hipStreamSynchronize(s2);
+  (void)hipStreamSynchronize(g_stream);
+  (void)hipGetLastError();
+}
+
 static int device_cus() {
   static int cus = -1;
   if (cus < 0) {
@@ -1325,6 +1332,7 @@ static int run_fill_loglike(mb_batch *b, int mode, int flags, double *loglike) {
       g_last_ms += tm.stop();
       if (!rc && !hip_ok(hipStreamSynchronize(g_stream), "fill kernel")) rc = 1;
       if (!rc && wide_parts_failed()) rc = 1;
+      if (rc) quiesce_streams();      // (a kernel launched before the failure may still read the descriptors)
       sm_free(d_desc);
       if (rc) break;
     }
@@ -1626,6 +1634,7 @@ static int counts_chunks(mb_batch *b, double *counts, double *loglikeSum, double
       if (!hip_ok(hipStreamSynchronize(g_stream), "counts kernels")) { rc = 1; break; }
       if (wide_parts_failed()) { rc = 1; break; }
     } while (0);
+    if (rc) quiesce_streams();      // (the sweep on the second stream may still read the descriptors freed below)
     sm_free(d_desc);
     if (rc) break;
   }
