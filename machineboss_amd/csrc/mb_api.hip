@@ -708,8 +708,8 @@ static int small_prepare(mb_batch *b, const Chunk &c, const SmallProgram &P, boo
   if (b->hasEnv) {   // PairDesc::envBase (-1: full) indexes them
     sw.d_envStart = b->d_envStart; sw.d_envEnd = b->d_envEnd;
     sw.h_envStart = b->h_envStart.data(); sw.h_envEnd = b->h_envEnd.data();
-    sw.haloDoubles = pl.haloD;
   }
+  sw.haloDoubles = pl.haloD;      // (pre-filled by the sweep: -inf for tiles that do not run, the sentinel of the persistent strips)
   if (wantPool && !(sw.d_pool = (double *)ws_get(0, (size_t)std::max<long long>(pl.poolD, 1) * 8))) return 1;
   if (wantTb && !(sw.d_tb = (unsigned char *)ws_get(8, (size_t)std::max<long long>(pl.tbB, 16)))) return 1;
   if (!(sw.d_halo = (double *)ws_get(9, (size_t)std::max<long long>(pl.haloD, 1) * 8))) return 1;

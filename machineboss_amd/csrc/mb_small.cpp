@@ -231,6 +231,28 @@ __device__ __forceinline__ void sm_wait(const unsigned *p, unsigned *err, long l
     __builtin_amdgcn_s_sleep(2);
   }
 }
+// PERSISTENT STRIPS (SmallArgs::TS beyond the pair's steps: a strip is ONE tile, no tile set-up per block).  The halo column is its own
+// hand-over: the host fills it with a sentinel (all ones: a NaN no cell ever holds), lane 63 stores its rows with agent-scope atomic
+// stores as the steps produce them -- no fence, no flag --, and the strip to the right stages the rows of its next JSUB steps with
+// agent-scope loads, repeating while a row still reads as the sentinel (bounded, like sm_wait).  A strip then lags its left neighbour
+// by 63 + JSUB steps (+ one load's latency) instead of two 64-step blocks.
+#define HALO_EMPTY (~0ull)
+__device__ __forceinline__ void halo_store(double *p, double v, bool jper) {
+  if (jper) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ double halo_wait(const double *p, unsigned *err, long long timeoutTicks) {
+  unsigned long long b = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b != HALO_EMPTY) return __longlong_as_double((long long)b);
+  const long long t0 = (long long)wall_clock64();
+  for (;;) {
+    b = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b != HALO_EMPTY) return __longlong_as_double((long long)b);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return NEG_INF;
+    if ((long long)wall_clock64() - t0 > timeoutTicks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return NEG_INF; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 typedef const __attribute__((address_space(4))) double *cdbl_t;
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d2a8 __attribute__((ext_vector_type(2), aligned(8)));
@@ -307,19 +329,23 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
   const int tile = A.tileBase + blockIdx.x * 4 + wv;
   if (tile < A.tileEnd) {
     const int4 tl = A.tiles[tile];
-#if JMODE != 3      // (the count sweep always runs launch by launch: see small_sweep -- and has no registers to spare)
-    if (A.flags) {
-      const int4 dp = A.deps[tile];
-      if (lane < 3) { const int d = lane == 0 ? dp.x : (lane == 1 ? dp.y : dp.z); if (d >= 0) sm_wait(A.flags + d, A.err, A.timeoutTicks); }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what those tiles stored (halo rows, boundary records) is read below
-    }
-#endif
     const int pairIdx = tl.x, a = tl.y, b = tl.z;
     const PairDesc pd = A.pairs[pairIdx];
     const SmAux ax = A.aux[pairIdx];
     const int inLen = pd.inLen, outLen = pd.outLen;
     const int NA = (inLen + 64) >> 6;
     const int Te = (outLen + 65) & ~1;
+#if JMODE != 3      // (the count sweep always runs launch by launch: see small_sweep -- and has no registers to spare)
+    const bool jper = A.flags != nullptr && A.TS >= Te;      // persistent strips: the hand-over is inside the step loop
+    if (A.flags && !jper) {
+      const int4 dp = A.deps[tile];
+      if (lane < 3) { const int d = lane == 0 ? dp.x : (lane == 1 ? dp.y : dp.z); if (d >= 0) sm_wait(A.flags + d, A.err, A.timeoutTicks); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what those tiles stored (halo rows, boundary records) is read below
+    }
+#else
+    const bool jper = false;
+#endif
+    (void)jper;
     const int t0 = b * A.TS, t1 = min(t0 + A.TS, Te);
     // Backward programs (reversed frame) keep their padding columns in FRONT of the sequence: frame column i of lane c of
     // strip a is then the mirror image of the Forward sweep's lane 63 - c of strip NA - 1 - a, so the count sweep reads
@@ -397,7 +423,7 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
       envSL[lane] = envRow(tb + lane, envS, 0); envEL[lane] = envRow(tb + lane, envE, inLen + 1);
 #endif
 #if JH > 0
-      if (a > 0) {
+      if (a > 0 && !jper) {
         const int ho = tb + lane;
 #pragma unroll
         for (int h = 0; h < JH; ++h) haloL[lane * JH + h] = (ho <= outLen) ? haloIn[(long long)min(ho, outLen) * JH + h] : NEG_INF;
@@ -405,9 +431,24 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
 #endif
       wave_sync();
       const int nj = min(64, t1 - tb);
-      for (int j = 0; j < nj; j += 2) {
+      const int sub = jper ? JSUB : 64;
+      for (int j0 = 0; j0 < nj; j0 += sub) {
+        const int j1 = min(j0 + sub, nj);
+#if JH > 0 && JMODE != 3
+        if (jper && a > 0) {
+          // halo rows tb + j0 ... tb + j1 - 1: the strip to the left stores row r in its step r + 63
+          if (lane < j1 - j0) {
+            const int ho = tb + j0 + lane;
+#pragma unroll
+            for (int h = 0; h < JH; ++h) haloL[(j0 + lane) * JH + h] = (ho <= outLen) ? halo_wait(haloIn + (long long)ho * JH + h, A.err, A.timeoutTicks) : NEG_INF;
+          }
+          wave_sync();
+        }
+#endif
+        for (int j = j0; j < j1; j += 2) {
 /*@STEP0@*/
 /*@STEP1@*/
+        }
       }
       wave_sync();   // the block buffers are rewritten next
     }
@@ -420,7 +461,7 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
 #if JMODE != 3
     if (A.flags) {      // this tile's halo rows and boundary record are written: the tiles that wait for it may go
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_store(A.flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(A.flags + tile, jper ? (unsigned)Te : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
   }
@@ -468,7 +509,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
        << "\n#define JNTRANS " << P.nTrans << "\n#define JROWF " << rowF << "\n#define JOUTACC " << outacc_floats(P) << "\n#define JLDSW " << lds_w_doubles(P)
        << "\n#define JLDSWN " << (P.nEntries - P.off[2]) << "\n#define JWAVEDBL " << wave_doubles(P, mode)
        << "\n#define JOFFSIL " << P.off[3] << "\n#define JOFFIN " << P.off[1] << "\n#define JOFFOUT " << P.off[2] << "\n#define JOFFMAT " << P.off[0]
-       << "\n#define JENDSTATE " << P.endState << "\n#define JLINELANES " << (env_int_s("MB_SMALL_STORE_LINES", 1) ? 128 / CB : 64) << "\n";
+       << "\n#define JSUB " << std::max(2, std::min(64, env_int_s("MB_SMALL_JSUB", 16) & ~1)) << "\n#define JENDSTATE " << P.endState << "\n#define JLINELANES " << (env_int_s("MB_SMALL_STORE_LINES", 1) ? 128 / CB : 64) << "\n";
   for (int k = 0; k < P.nTab[3]; ++k) weights << "    const double wS" << k << " = wc[JOFFSIL + " << k << "];\n";
   for (int k = 0; k < P.nTab[1]; ++k) weights << "    const double wI" << k << " = A.w[JOFFIN + " << (long long)k * (P.nIn + 1) << " + it];\n";
   // persistent state: two sets of cells and of left-neighbour values, alternating by step parity
@@ -594,7 +635,7 @@ std::string small_jit_source(const SmallProgram &P, int mode, bool materialise, 
     }
     if (P.H > 0) {
       b << "          if (lane == 63 && a + 1 < NA && o >= 0 && o <= outLen) {\n";
-      for (size_t k = 0; k < P.needLeft.size(); ++k) b << "            haloOut[(long long)o * JH + " << k << "] = " << cp << P.needLeft[k] << ";\n";
+      for (size_t k = 0; k < P.needLeft.size(); ++k) b << "            halo_store(haloOut + (long long)o * JH + " << k << ", " << cp << P.needLeft[k] << ", jper);\n";
       b << "          }\n";
     }
     b << "          if (active && i == inLen && o == outLen) A.loglike[pairIdx] = " << cp << P.endState << ";\n";
@@ -750,7 +791,23 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   if (!small_jit_get(P, mode, materialise, sw.d_envStart != nullptr)) return 1;
   lap("kernel lookup / jit");
   const SmJit &J = P.jit[mode][materialise ? 1 : 0][sw.d_envStart != nullptr ? 1 : 0];
-  const int TS = pick_tile_steps(pairs);
+  // PERSISTENT STRIPS: every strip of every pair is one wavefront of ONE grid and sweeps its whole strip; the halo column between two
+  // strips is its own hand-over (HALO_EMPTY in the generated source).  For batches that cannot fill the chip -- a single pair, the
+  // unchanged `for (seqPair : data.seqPairs)` loops of target/boss.cpp:796-833, src/api.cpp:31-66 -- the sweep is then bound by the
+  // lattice's own critical path -- a strip lags its left neighbour by 63 + JSUB steps -- instead of 2 NA + NB launches of 64-step tiles
+  // (two blocks of lag and 3 us of tile set-up per block): one 1 kb x 1 kb dnapsw pair 1.19 -> 0.90 ms (Forward), 0.95 -> 0.74 ms
+  // (Viterbi) on the same box, bit-identical (scripts/single_pair_probe.py; with hand-over blocks of 8 / 16 / 32 steps 0.94 / 0.90 /
+  // 0.95 ms: a step of 16 concurrent strips is 0.36 us, so 1 088 + 15 x 79 steps are 0.82 ms).  Chosen when all strips are co-resident with one workgroup (four strips) per CU at most
+  // (<= 1 024 strips; a larger batch fills the chip with tiles and is bound by vector issue either way); not for the count sweep (it
+  // adds into the caller's accumulators as it goes: a sweep that gave up could not simply be run again) nor with dead tiles.
+  // MB_SMALL_ONE_LAUNCH: 0 never, 2 always, 1 the 64-step TILES of a sweep in one grid with done-flags (measured: no faster than the
+  // launches), default: the rule above.  A wait that runs out (MB_SMALL_ONE_LAUNCH_TIMEOUT_S; a shared device) latches both forms off.
+  static bool oneLaunchOff = false;
+  const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", -1);
+  long long nStrips = 0;
+  for (const PairDesc &pd : pairs) nStrips += small_strips(pd.inLen);
+  const bool persist = (oneWant == 2 || (oneWant < 0 && nStrips <= 1024)) && !oneLaunchOff && mode != SM_COUNT && !(sw.d_envStart != nullptr && sw.h_envStart != nullptr);
+  const int TS = persist ? (1 << 20) : pick_tile_steps(pairs);
   // The tile lists depend on the pairs' shapes (and envelopes) only: built and uploaded once per batch chunk and sweep
   // direction, reused by every later sweep.  With restricted envelopes a tile none of whose cells lies inside its pair's
   // envelope is not launched at all: its cells stay -inf (the halo columns are pre-filled with -inf, the next block of
@@ -853,17 +910,14 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   A.w = P.d_w; A.eid = P.d_eid; A.bwdLL = sw.d_bwdLL; A.counts = sw.d_counts;
   A.envStart = sw.d_envStart; A.envEnd = sw.d_envEnd;
   bool ok = true;
-  // ONE launch for the whole sweep (sm_wait in the generated source): MB_SMALL_ONE_LAUNCH=1.  OFF by default -- measured on a single
-  // 1 kb x 1 kb dnapsw pair (scripts/single_pair_probe.py): 47 launches 1.011 ms, one launch 1.033 ms.  The chain is not bound by the
-  // launches: a lone wavefront issues a Forward step in 294 ns (705 cycles of VALU issue) and a tile is 64 steps + 3 us, and the
-  // hand-over by whole 64-step blocks makes a strip lag the one to its left by two blocks, with one launch or with 47.
-  static bool oneLaunchOff = false;      // latched when a tile's wait ran out once (a shared device: the tiles were not scheduled in list order)
+  // (MB_SMALL_ONE_LAUNCH=1, the tiles of the sweep in one grid: 47 launches 1.011 ms, one launch 1.033 ms on a 1 kb x 1 kb dnapsw pair --
+  //  the hand-over by whole 64-step blocks makes a strip lag the one to its left by two blocks, with one launch or with 47)
   const long long nTiles = off[nLaunch];
-  const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", 0);
   // (not the count sweep: it adds into the caller's accumulators as it goes, so a sweep that gave up could not simply be run again)
   const bool oneLaunch = tc.d_deps && tc.d_flags && nTiles > 0 && !oneLaunchOff && oneWant != 0 && mode != SM_COUNT &&
-                         oneWant == 1 && nTiles <= (1 << 20);
+                         (oneWant == 1 || persist) && nTiles <= (1 << 20);
   if (oneLaunch) {
+    if (persist && sw.haloDoubles > 0 && !hip_ok(hipMemsetAsync(sw.d_halo, 0xFF, (size_t)sw.haloDoubles * sizeof(double), st), "memset(halo sentinel)")) return 1;
     unsigned *flags = (unsigned *)tc.d_flags;      // [nTiles] done words + the error word behind them
     if (!hip_ok(hipMemsetAsync(flags, 0, ((size_t)nTiles + 1) * sizeof(unsigned), st), "memset(tile flags)")) return 1;
     A.deps = (const int4 *)tc.d_deps; A.flags = flags; A.err = flags + nTiles;
@@ -880,6 +934,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     oneLaunchOff = true;
     fprintf(stderr, "[mbhip] WARNING: a tile of a one-launch sweep waited longer than MB_SMALL_ONE_LAUNCH_TIMEOUT_S for the tiles it reads from (is the device shared?): the sweep is run again launch by launch, and so are the sweeps that follow\n");
     A.deps = nullptr; A.flags = nullptr; A.err = nullptr;
+    if (persist) { if (!cached && local.d_tiles) { (void)hipFree(local.d_tiles); if (local.d_deps) (void)hipFree(local.d_deps); if (local.d_flags) (void)hipFree(local.d_flags); } return small_sweep(P, mode, materialise, sw, st); }      // (with the tiles of the launch-by-launch form)
     if (skipDead && sw.haloDoubles > 0 && launch_fill_neg_inf(sw.d_halo, sw.haloDoubles, st)) return 1;
   }
   for (int l = 0; l < nLaunch && ok; ++l) {

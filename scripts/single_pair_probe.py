@@ -17,7 +17,7 @@ em = EvaluatedMachine.fromMachine(Machine.fromFile(os.path.join(ROOT, "tests", "
 dm = capi.DeviceMachine(em)
 b = capi.DeviceBatch(dm, *synth_batch(2, 1, il, ol, em.nInTok, em.nOutTok))
 ref = {}
-for one in ("0", "1"):
+for one in ("0", "1", "2"):
     capi.set_option("MB_SMALL_ONE_LAUNCH", one)
     for name, fn in (("forward", lambda: b.forward(capi.MB_ROLLING)), ("viterbi", lambda: b.viterbi(paths=False)[0]), ("align", lambda: b.viterbi(paths=True)[0])):
         r = fn(); r = fn()

@@ -96,6 +96,64 @@ def test_small_tile_lengths(capi, oracle_mod, machines, monkeypatch, ts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("preset,jsub", [("dnapsw", None), ("dnapsw", "2"), ("dnapsw", "16"), ("protpsw", "64"), ("protpsw", None)])
+def test_small_persistent_strips(capi, oracle_mod, machines, monkeypatch, preset, jsub):
+    """PERSISTENT STRIPS (round 6; `src/api.cpp:31-66`, `target/boss.cpp:796-800`: one matrix object per pair): every
+    strip of every pair is one wavefront of one grid and sweeps its whole strip, the halo column between strips is its own hand-over
+    (a sentinel the host writes, agent-scope stores and loads; mb_small.cpp HALO_EMPTY).  The library's own choice for batches of at
+    most 1 024 strips.  Against the launch-by-launch sweep (MB_SMALL_ONE_LAUNCH=0), bit for bit: log-likelihoods, Forward / Backward /
+    Viterbi matrices, scores and paths, counts (Backward fill through strips, count sweep launch by launch); against the oracle on the
+    short pairs; a batch too large for the rule runs launch by launch; hand-over block lengths 2 ... 64 steps (MB_SMALL_JSUB)."""
+    m, em = machines(preset, None, useDefaults=True, preset=True)
+    L = 1000 if preset == "dnapsw" else 400
+    big = [synth_tokens(900, L, L, em.nInTok, em.nOutTok)]
+    ragged = [synth_tokens(910 + k, a, b, em.nInTok, em.nOutTok) for k, (a, b) in enumerate([(150, 333), (70, 64), (3, 190), (0, 5), (300, 129), (64, 0), (63, 1), (65, 200)])]
+    if jsub: monkeypatch.setenv("MB_SMALL_JSUB", jsub)
+    out = {}
+    for one in ("default", "0"):
+        if one == "0": monkeypatch.setenv("MB_SMALL_ONE_LAUNCH", "0")
+        else: monkeypatch.delenv("MB_SMALL_ONE_LAUNCH", raising=False)
+        dm = capi.DeviceMachine(em)
+        r = {}
+        for name, pairs in (("big", big), ("ragged", ragged)):
+            b = capi.DeviceBatch.from_pairs(dm, pairs)
+            r[name + ".roll"] = b.forward(capi.MB_ROLLING); r[name + ".roll.launches"] = capi.last_launch_count()
+            r[name + ".mat"] = b.forward(capi.MB_MATERIALISE)
+            r[name + ".vit"] = b.viterbi(); r[name + ".vit.launches"] = capi.last_launch_count()
+            r[name + ".cnt"] = b.counts()
+        x, y = ragged[0]
+        for mode in (capi.MB_FORWARD, capi.MB_BACKWARD, capi.MB_VITERBI): r["fill%d" % mode] = dm.fill(mode, x, y)
+        out[one] = r
+        dm.close()
+    a, b_ = out["default"], out["0"]
+    assert a["big.roll.launches"] == 1 and a["ragged.roll.launches"] == 1 and b_["big.roll.launches"] > 10, (a["big.roll.launches"], b_["big.roll.launches"])
+    for k in a:
+        if k.endswith(".launches"): continue
+        if k.endswith(".vit"):
+            for u, v in zip(a[k], b_[k]): assert np.array_equal(np.asarray(u), np.asarray(v)), k
+        elif k.endswith(".cnt"): assert close(a[k][0], b_[k][0], 1e-9, 1e-12) and close(a[k][1], b_[k][1], 1e-12)
+        else: assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), k
+    om = oracle_mod.OracleMachine(em)
+    for k, (x, y) in enumerate(ragged):
+        assert close(a["ragged.roll"][k], om.loglike(x, y, oracle_mod.SUM_EXACT), FAST_REL, FAST_ABS)
+        V = om.viterbi(x, y); vll, off, edges = a["ragged.vit"]
+        assert vll[k] == V[-1, -1, -1]
+        if V[-1, -1, -1] > -math.inf: assert np.array_equal(edges[off[k]:off[k + 1]], om.traceback(x, y, V))
+    # more strips than the rule admits: launch by launch, by the library's own choice
+    if jsub is None and preset == "dnapsw":
+        monkeypatch.delenv("MB_SMALL_ONE_LAUNCH", raising=False)
+        dm = capi.DeviceMachine(em)
+        many = [synth_tokens(3000 + k, 300, 200, em.nInTok, em.nOutTok) for k in range(260)]      # 260 x 5 strips
+        bm = capi.DeviceBatch.from_pairs(dm, many)
+        llm = bm.forward(capi.MB_ROLLING)
+        assert capi.last_launch_count() > 1
+        monkeypatch.setenv("MB_SMALL_ONE_LAUNCH", "2")
+        dm2 = capi.DeviceMachine(em)
+        assert np.array_equal(capi.DeviceBatch.from_pairs(dm2, many).forward(capi.MB_ROLLING), llm) and capi.last_launch_count() == 1
+        dm2.close(); dm.close()
+
+
+@pytest.mark.gpu
 def test_small_one_launch_sweeps(capi, oracle_mod, machines, monkeypatch):
     """ONE launch for a whole sweep (round 6; `src/api.cpp:31-66`, `target/boss.cpp:796-800`: one matrix object per
     pair): a single 1 kb x 1 kb dnapsw pair was a chain of 47 dependent launches -- now every tile of the sweep is in one grid, in
