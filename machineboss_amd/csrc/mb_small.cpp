@@ -805,8 +805,9 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   static bool oneLaunchOff = false;
   const int oneWant = env_int_s("MB_SMALL_ONE_LAUNCH", -1);
   long long nStrips = 0;
-  for (const PairDesc &pd : pairs) nStrips += small_strips(pd.inLen);
-  const bool persist = (oneWant == 2 || (oneWant < 0 && nStrips <= 1024)) && !oneLaunchOff && mode != SM_COUNT && !(sw.d_envStart != nullptr && sw.h_envStart != nullptr);
+  int chain = 0;      // launches of the tile form (64-step tiles): a pair of one or two tiles has no chain to shorten (config 1's 50 x 50 pair: 85 us per call, 95 through the strips)
+  for (const PairDesc &pd : pairs) { nStrips += small_strips(pd.inLen); chain = std::max(chain, 2 * (small_strips(pd.inLen) - 1) + (small_steps(pd.outLen) + 63) / 64); }
+  const bool persist = (oneWant == 2 || (oneWant < 0 && nStrips <= 1024 && chain >= 4)) && !oneLaunchOff && mode != SM_COUNT && !(sw.d_envStart != nullptr && sw.h_envStart != nullptr);
   const int TS = persist ? (1 << 20) : pick_tile_steps(pairs);
   // The tile lists depend on the pairs' shapes (and envelopes) only: built and uploaded once per batch chunk and sweep
   // direction, reused by every later sweep.  With restricted envelopes a tile none of whose cells lies inside its pair's
