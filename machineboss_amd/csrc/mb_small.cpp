@@ -321,12 +321,12 @@ extern "C" __global__ __launch_bounds__(256, JMINWAVES) void JKERNEL(SmallArgs A
   float *rowL = (float *)(haloL + 64 * JHP) + lane * JROWF;  // this lane's usage sums of the match transitions, by output token
   float *outAcc = (float *)(haloL + 64 * JHP) + 64 * JROWF + (JROWF & 1);   // this wavefront's usage sums of the output-only transitions
 #endif
-  for (int j = tid; j < JLDSW; j += 256) wL[j] = (j < JLDSWN) ? A.w[JOFFOUT + j] : 0.0;
+  for (int j = tid; j < JLDSW; j += (int)blockDim.x) wL[j] = (j < JLDSWN) ? A.w[JOFFOUT + j] : 0.0;      // (256 lanes = four tiles, or 64 = one persistent strip)
 #if JMODE == 3
   for (int j = tid; j < JNTRANS; j += 256) accT[j] = 0.0;
 #endif
   __syncthreads();
-  const int tile = A.tileBase + blockIdx.x * 4 + wv;
+  const int tile = A.tileBase + blockIdx.x * (int)(blockDim.x >> 6) + wv;
   if (tile < A.tileEnd) {
     const int4 tl = A.tiles[tile];
     const int pairIdx = tl.x, a = tl.y, b = tl.z;
@@ -795,9 +795,9 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
   // strips is its own hand-over (HALO_EMPTY in the generated source).  For batches that cannot fill the chip -- a single pair, the
   // unchanged `for (seqPair : data.seqPairs)` loops of target/boss.cpp:796-833, src/api.cpp:31-66 -- the sweep is then bound by the
   // lattice's own critical path -- a strip lags its left neighbour by 63 + JSUB steps -- instead of 2 NA + NB launches of 64-step tiles
-  // (two blocks of lag and 3 us of tile set-up per block): one 1 kb x 1 kb dnapsw pair 1.19 -> 0.90 ms (Forward), 0.95 -> 0.74 ms
-  // (Viterbi) on the same box, bit-identical (scripts/single_pair_probe.py; with hand-over blocks of 8 / 16 / 32 steps 0.94 / 0.90 /
-  // 0.95 ms: a step of 16 concurrent strips is 0.36 us, so 1 088 + 15 x 79 steps are 0.82 ms).  Chosen when all strips are co-resident with one workgroup (four strips) per CU at most
+  // (two blocks of lag and 3 us of tile set-up per block): one 1 kb x 1 kb dnapsw pair 1.19 -> 0.84 ms (Forward), 0.97 -> 0.69 ms
+  // (Viterbi) on the same box, bit-identical (scripts/single_pair_probe.py; hand-over blocks of 8 / 16 / 32 steps: 0.94 / 0.90 / 0.95 ms
+  // with four strips per workgroup, 0.84 with one: a step of 16 concurrent strips is 0.36 us, so 1 088 + 15 x 79 steps are 0.82 ms).  Chosen when all strips are co-resident with one workgroup (four strips) per CU at most
   // (<= 1 024 strips; a larger batch fills the chip with tiles and is bound by vector issue either way); not for the count sweep (it
   // adds into the caller's accumulators as it goes: a sweep that gave up could not simply be run again) nor with dead tiles.
   // MB_SMALL_ONE_LAUNCH: 0 never, 2 always, 1 the 64-step TILES of a sweep in one grid with done-flags (measured: no faster than the
@@ -926,7 +926,9 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     A.tileBase = 0; A.tileEnd = (int)nTiles;
     void *args[] = {&A};
     ++g_last_launches;
-    ok = hipModuleLaunchKernel((hipFunction_t)J.func, (unsigned)((nTiles + 3) / 4), 1, 1, 256, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
+    // (persistent strips: ONE strip per workgroup -- a wavefront alone on its CU issues a Forward step in 0.29 us, four strips sharing a CU in 0.36)
+    const unsigned wpb = persist && env_int_s("MB_SMALL_STRIP_PER_WG", 1) ? 1u : 4u;
+    ok = hipModuleLaunchKernel((hipFunction_t)J.func, (unsigned)((nTiles + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, (unsigned)J.ldsBytes, st, args, nullptr) == hipSuccess;
     unsigned e = 0;
     ok = ok && hip_ok(hipGetLastError(), "small tile launch") && hip_ok(hipMemcpyAsync(&e, flags + nTiles, sizeof(e), hipMemcpyDeviceToHost, st), "tile status") && hip_ok(hipStreamSynchronize(st), "small tile kernel");
     lap("one launch");
