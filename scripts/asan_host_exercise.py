@@ -38,4 +38,25 @@ for seed in range(60):
                 capi.debug_jit_source(em, OUT, mode=mode, backward=bw, closure=clos, G=int(rng.choice([1, 2, 4, 8, 16]))); n += 1
     except capi.MbError as e:
         print("refused:", S, str(e)[:80])
+# the one-tape family: retimed planner, the cuts (k workgroups per sequence, merged candidates), the generator of mb_wide_jit.cpp (round 6) --
+# every plan attempt, traceback codes, the fp64 term; random block machines and a profile composite
+from randmachine import random_block_machine
+from machineboss_amd import algebra as A
+from machineboss_amd.hmmer import HmmerModel
+P = lambda name: Machine.fromFile(os.path.join(ROOT, 'tests', 'golden', 'preset', name + '.json'))
+h = HmmerModel.fromFile(os.path.join(ROOT, 'tests', 'golden', 'hmmer', 'fn3.hmm')).truncated(3)
+machines = [EvaluatedMachine.fromMachine(A.composeLeftToRight([h.machine(True), P('simple_introns'), P('translate'), P('dnapsw')]), None, useDefaults=True)]
+for seed in range(12):
+    machines.append(random_block_machine(int(rng.choice([3, 5, 8])), int(rng.choice([6, 12, 25])), 0 if seed % 3 else 3, 3 if seed % 3 else 0, 700 + seed))
+for em in machines:
+    for k in (1, 2, 4):
+        for mode, bw, tb, acc in ((capi.MB_VITERBI, False, False, False), (capi.MB_VITERBI, False, True, False), (capi.MB_FORWARD, False, False, True), (capi.MB_FORWARD, True, False, False)):
+            for attempt in ("0", "2", "3"):
+                os.environ["MB_WIDE_JIT_ATTEMPT"] = attempt
+                try:
+                    capi.debug_wide_jit(em, OUT, k=k, lanes=int(rng.choice([0, 64, 256])), mode=mode, backward=bw, tb_codes=tb, acc=acc); n += 1
+                except (capi.MbError, RuntimeError) as e:
+                    print("refused:", em.nStates, k, str(e)[:80])
+                    break
+os.environ.pop("MB_WIDE_JIT_ATTEMPT", None)
 print("host exercise done:", n, "program builds")
