@@ -1196,11 +1196,12 @@ static int launch_wavefront(const mb_machine *m, MedProgram &P, const MedProgDev
 
 // Steps per parallelogram tile.  Long sweeps take 128 (half the launches, half the tile prologues: +1.5 % on 10 kb
 // outputs); short ones keep 64 so that a pair still cuts into enough tiles to fill the wavefront of launches.
+// Round 6: a sweep over FEW pairs is bound by its chain of launches, not by the tiles' prologues, and a chain of 64-step tiles is the
+// shorter one (482-state E-step: 6 pairs 220 -> 180 ms, 12 pairs 297 -> 280 ms; scripts/c4b_scale_probe.py).
 static int tile_steps(int C, size_t nPairs, int maxOut) {
-  int TS = std::max(C, maxOut >= 4096 ? 128 : 64);
+  int TS = std::max(C, (maxOut >= 4096 && nPairs >= (size_t)env_int_m("MB_MEDIUM_TS_LONG_MIN_PAIRS", 32)) ? 128 : 64);
   const char *e = opt_env("MB_MEDIUM_TS");
   if (e && atoi(e) >= C) TS = atoi(e);
-  (void)nPairs;
   return TS;
 }
 
