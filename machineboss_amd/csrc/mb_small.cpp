@@ -923,6 +923,7 @@ int small_sweep(SmallProgram &P, int mode, bool materialise, const SmSweep &sw, 
     if (!hip_ok(hipMemsetAsync(flags, 0, ((size_t)nTiles + 1) * sizeof(unsigned), st), "memset(tile flags)")) return 1;
     A.deps = (const int4 *)tc.d_deps; A.flags = flags; A.err = flags + nTiles;
     A.timeoutTicks = (long long)std::max(1, env_int_s("MB_SMALL_ONE_LAUNCH_TIMEOUT_S", 20)) * 100000000ll;
+    if (const int us = env_int_s("MB_SMALL_ONE_LAUNCH_TIMEOUT_US", 0)) A.timeoutTicks = (long long)std::max(us, 1) * 100ll;      // (the tests' way to a time-out: a microsecond)
     A.tileBase = 0; A.tileEnd = (int)nTiles;
     void *args[] = {&A};
     ++g_last_launches;

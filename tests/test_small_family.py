@@ -154,6 +154,37 @@ def test_small_persistent_strips(capi, oracle_mod, machines, monkeypatch, preset
 
 
 @pytest.mark.gpu
+def test_small_persistent_strips_fall_back_when_a_row_never_arrives(tmp_path):
+    """A strip that waits longer than its bound for a halo row (a shared device; here: a bound of one microsecond) raises the sweep's
+    error word; the host latches the one-grid forms off for the process and runs the sweep again launch by launch -- the caller gets the
+    right answer and a warning, and the sweeps that follow no longer try.  (A process of its own: the latch is per process.)"""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from machineboss_amd import capi
+from machineboss_amd.machine import Machine
+from machineboss_amd.evalmachine import EvaluatedMachine
+from machineboss_amd.seqgen import synth_tokens
+em = EvaluatedMachine.fromMachine(Machine.fromFile(%r), None, useDefaults=True)
+pairs = [synth_tokens(900, 600, 700, em.nInTok, em.nOutTok)]
+dm = capi.DeviceMachine(em); b = capi.DeviceBatch.from_pairs(dm, pairs)
+capi.set_option("MB_SMALL_ONE_LAUNCH", "0"); ref = b.forward(capi.MB_ROLLING); vref = b.viterbi(); n0 = capi.last_launch_count()
+capi.set_option("MB_SMALL_ONE_LAUNCH", "2"); ok = b.forward(capi.MB_ROLLING); n1 = capi.last_launch_count()
+capi.set_option("MB_SMALL_ONE_LAUNCH_TIMEOUT_US", "1")
+got = b.forward(capi.MB_ROLLING); n2 = capi.last_launch_count()
+capi.set_option("MB_SMALL_ONE_LAUNCH_TIMEOUT_US", "0")
+again = b.forward(capi.MB_ROLLING); n3 = capi.last_launch_count(); vit = b.viterbi()
+assert n0 > 10 and n1 == 1 and n2 > 10 and n3 > 10, (n0, n1, n2, n3)
+assert np.array_equal(ref, ok) and np.array_equal(ref, got) and np.array_equal(ref, again)
+assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(vref, vit))
+print("FELL BACK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), golden_path("preset", "dnapsw.json"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FELL BACK" in r.stdout, (r.stdout + r.stderr)[-2000:]
+    assert "run again launch by launch" in r.stderr
+
+
+@pytest.mark.gpu
 def test_small_one_launch_sweeps(capi, oracle_mod, machines, monkeypatch):
     """ONE launch for a whole sweep (round 6; `src/api.cpp:31-66`, `target/boss.cpp:796-800`: one matrix object per
     pair): a single 1 kb x 1 kb dnapsw pair was a chain of 47 dependent launches -- now every tile of the sweep is in one grid, in
