@@ -1400,7 +1400,7 @@ static int viterbi_chunks(mb_batch *b, double *loglike, int64_t *pathOff, uint32
         WideProgram *W = wide_tb_program(b->m);
         if (!W) { rc = c.p0 > 0 ? 1 : -1; if (rc > 0) set_error("one-tape traceback-code program became unavailable mid-batch"); break; }
         if ((rc = wide_fill_tb(b->m, *W, d_desc, np, b->m->nOut ? b->d_out : b->d_in, (unsigned char *)pool, d_ll, g_stream, hp.data(), device_cus()))) break;
-        g_last_kernel = wide_last_parts() > 1 ? wide_kernel_name(*W) : (W->retGv ? "k_wide_retimed<1,L2,codes>" : "k_wide_retimed<1,codes>");
+        g_last_kernel = wide_kernel_name(*W);      // (the generated kernel or the interpreter, one workgroup or k: asked after the launch)
       } else if (tb) {
         MedEnv me;
         if (b->hasEnv) { me.d_start = b->d_envStart; me.d_end = b->d_envEnd; me.h_start = b->h_envStart.data(); me.h_end = b->h_envEnd.data(); }

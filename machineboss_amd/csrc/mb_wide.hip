@@ -2121,7 +2121,8 @@ const char *wide_kernel_name(const WideProgram &P) {
     return nm;
   }
   if (P.retOk && g_last_jit) return P.viterbi ? (P.tbCodes ? "k_wide_jit<1,codes>" : "k_wide_jit<1>") : "k_wide_jit<0>";
-  if (P.retOk) return P.retGv ? (P.viterbi ? "k_wide_retimed<1,L2>" : "k_wide_retimed<0,L2>") : (P.viterbi ? "k_wide_retimed<1>" : "k_wide_retimed<0>");
+  if (P.retOk) return P.retGv ? (P.viterbi ? (P.tbCodes ? "k_wide_retimed<1,L2,codes>" : "k_wide_retimed<1,L2>") : "k_wide_retimed<0,L2>")
+                              : (P.viterbi ? (P.tbCodes ? "k_wide_retimed<1,codes>" : "k_wide_retimed<1>") : "k_wide_retimed<0>");
   if (P.f32) return "k_wide_sum32";
   if (P.viterbi) return P.vitOk ? "k_wide_viterbi" : "k_wide_sweep<1>";
   return "k_wide_sweep<0>";
