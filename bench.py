@@ -539,7 +539,7 @@ def extra_train(capi, np):
     dm5 = b5 = None
     for it in range(4):
         t0 = time.perf_counter()
-        ev = EvaluatedMachine.fromMachine(m5, params)
+        ev = EvaluatedMachine.fromMachine(m5, params) if dm5 is None else ev.reweighted(m5, params)      # (as fitter.py does: the weight expressions through a program compiled once)
         t_eval = time.perf_counter() - t0; t0 = time.perf_counter()
         if dm5 is None:
             dm5 = capi.DeviceMachine(ev)

@@ -126,6 +126,21 @@ class EvaluatedMachine:
         return cls(machine.nStates(), it, ot, src, dst, itok, otok, tidx, lw, off,
                    [ms.name for ms in machine.state])
 
+    def reweighted(self, machine: Machine, params: Optional[Dict[str, Any]] = None, useDefaults: bool = False) -> "EvaluatedMachine":
+        """The same topology under other parameters: ``EvaluatedMachine.fromMachine(machine, params)`` without rebuilding tokenisers and
+        index arrays, the weight expressions evaluated through a program compiled once per machine (``CompiledWeights``) -- what an EM
+        iteration needs (src/fitter.cpp:28-29 rebuilds the whole object).  Log-weights are the bits ``fromMachine`` gives."""
+        cw = getattr(machine, "_compiledWeights", None)
+        sig = hash(tuple(id(t.weight) for ms in machine.state for t in ms.trans))      # (a transition given another weight object: compile again)
+        if cw is None or cw.nTransitions != self.nTransitions or cw.signature != sig:
+            cw = CompiledWeights(machine)
+            cw.signature = sig
+            machine._compiledWeights = cw
+        defs = machine.getParamDefs(useDefaults)
+        if params:
+            defs.update(params)
+        return self.withLogWeights(cw.logWeights(defs))
+
     def withLogWeights(self, logWeight: np.ndarray) -> "EvaluatedMachine":
         lw = np.ascontiguousarray(logWeight, dtype=np.float64)
         assert lw.shape == self.logWeight.shape
@@ -151,3 +166,107 @@ class EvaluatedMachine:
             if s < d:
                 lvl[d] = max(lvl[d], lvl[s] + 1)
         return lvl
+
+
+class CompiledWeights:
+    """The weight expressions of a machine's transitions (src/weight.cpp:241-300, JSON objects) as ONE flat program, built once:
+    every distinct sub-expression -- by object identity: a composed machine's products share their factors, src/machine.cpp:794-907 --
+    is a node; nodes are evaluated level by level, the four arithmetic opcodes, ``not`` and ``geomsum`` as numpy array operations (IEEE
+    double, the operand order of the expression: the same bits as the scalar evaluation), ``log / exp / pow`` and the final logarithm
+    through ``math`` one by one (a vectorised libm need not round like the scalar one).  Parameters that are themselves expressions
+    (function definitions) are evaluated by ``evalWeight``.  5 063-state composition of BASELINE config 5: 14 691 transitions,
+    101 ms per evaluation through ``EvaluatedMachine.fromMachine`` -> a few ms."""
+
+    _VEC = {"*": 0, "/": 1, "+": 2, "-": 3, "not": 4, "geomsum": 5}
+
+    def __init__(self, machine: Machine):
+        self.nodes: List[tuple] = []          # (kind, a, b): kind "c" constant a / "p" parameter name a / opcode with child indices
+        self._byId: Dict[int, int] = {}
+        self._keep: List[Any] = []            # the expression objects (ids stay valid while they live)
+        self._consts: Dict[Any, int] = {}
+        self.top: List[int] = []
+        for ms in machine.state:
+            for t in ms.trans:
+                self.top.append(self._node(t.weight))
+        self.nTransitions = len(self.top)
+        n = len(self.nodes)
+        depth = [0] * n
+        for i, (kind, a, b) in enumerate(self.nodes):      # children precede parents by construction
+            if kind not in ("c", "p"):
+                depth[i] = 1 + max(depth[a], depth[b] if b is not None else 0)
+        self.constIdx = np.array([i for i, nd in enumerate(self.nodes) if nd[0] == "c"], np.int64)
+        self.constVal = np.array([self.nodes[i][1] for i in self.constIdx], np.float64)
+        self.params = [(i, nd[1]) for i, nd in enumerate(self.nodes) if nd[0] == "p"]
+        groups: Dict[tuple, List[int]] = {}
+        for i, (kind, a, b) in enumerate(self.nodes):
+            if kind not in ("c", "p"):
+                groups.setdefault((depth[i], kind), []).append(i)
+        self.steps = []
+        for (d, kind) in sorted(groups, key=lambda k: k[0]):
+            idx = np.array(groups[(d, kind)], np.int64)
+            a = np.array([self.nodes[i][1] for i in idx], np.int64)
+            b = np.array([self.nodes[i][2] if self.nodes[i][2] is not None else 0 for i in idx], np.int64)
+            self.steps.append((kind, idx, a, b))
+        self.topIdx = np.array(self.top, np.int64)
+        self.signature = None
+
+    def _node(self, w: Any) -> int:
+        if w is None or isinstance(w, (bool, int, float)):
+            v = 0.0 if w is None else (1.0 if w is True else (0.0 if w is False else float(w)))
+            key = (v, math.copysign(1.0, v)) if v == v else "nan"
+            if key not in self._consts:
+                self._consts[key] = len(self.nodes); self.nodes.append(("c", v, None))
+            return self._consts[key]
+        if isinstance(w, str):
+            key = ("p", w)
+            if key not in self._consts:
+                self._consts[key] = len(self.nodes); self.nodes.append(("p", w, None))
+            return self._consts[key]
+        if id(w) in self._byId:
+            return self._byId[id(w)]
+        if isinstance(w, list):
+            raise MachineError("Unexpected type in WeightExpr: array")
+        if not isinstance(w, dict) or len(w) == 0:
+            raise MachineError("WeightExpr must be JSON object with an opcode")
+        op, args = next(iter(w.items()))
+        if op in ("log", "exp", "not", "geomsum"):
+            nd = (op, self._node(args), None)
+        elif op in ("*", "/", "+", "-", "pow"):
+            nd = (op, self._node(args[0]), self._node(args[1]))
+        else:
+            raise MachineError("Unknown opcode %s in JSON" % op)
+        self._byId[id(w)] = len(self.nodes); self._keep.append(w)
+        self.nodes.append(nd)
+        return self._byId[id(w)]
+
+    def values(self, defs: Dict[str, Any]) -> np.ndarray:
+        """Weight of every transition under ``defs`` (parameter values and function definitions)."""
+        v = np.empty(len(self.nodes), np.float64)
+        if len(self.constIdx):
+            v[self.constIdx] = self.constVal
+        for i, name in self.params:
+            v[i] = evalWeight(name, defs)
+        with np.errstate(all="ignore"):
+            for kind, idx, a, b in self.steps:
+                if kind == "*": v[idx] = v[a] * v[b]
+                elif kind == "/":
+                    if np.any(v[b] == 0.0): raise ZeroDivisionError("float division by zero")      # (as the scalar evaluation does)
+                    v[idx] = v[a] / v[b]
+                elif kind == "+": v[idx] = v[a] + v[b]
+                elif kind == "-": v[idx] = v[a] - v[b]
+                elif kind == "not": v[idx] = 1.0 - v[a]
+                elif kind == "geomsum":
+                    if np.any(v[a] == 1.0): raise ZeroDivisionError("float division by zero")
+                    v[idx] = 1.0 / (1.0 - v[a])
+                elif kind == "log":
+                    for i, x in zip(idx, v[a]): v[i] = math.log(x)
+                elif kind == "exp":
+                    for i, x in zip(idx, v[a]): v[i] = math.exp(x)
+                else:
+                    for i, x, y in zip(idx, v[a], v[b]): v[i] = math.pow(x, y)
+        return v[self.topIdx]
+
+    def logWeights(self, defs: Dict[str, Any]) -> np.ndarray:
+        w = self.values(defs)
+        log = math.log
+        return np.array([log(x) if x > 0 else (-math.inf if x == 0 else math.nan) for x in w.tolist()], np.float64)

@@ -231,7 +231,9 @@ class MachineFitter:
             tm = {}
             t0 = time.perf_counter()
             allParams = dict(self.machine.funcs); allParams.update(self.constants); allParams.update(params)
-            ev = EvaluatedMachine.fromMachine(self.machine, allParams)
+            # (later iterations: the same topology under new parameters -- the weight expressions through a program compiled once,
+            #  evalmachine.CompiledWeights; the reference rebuilds the whole EvaluatedMachine, src/fitter.cpp:28-29)
+            ev = EvaluatedMachine.fromMachine(self.machine, allParams) if dm is None else ev.reweighted(self.machine, allParams)
             tm["eval_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
             # the topology is uploaded (and its kernels specialised) once; later iterations only send new log-weights
             # (mb_machine_set_weights) -- the reference rebuilds its EvaluatedMachine every iteration (src/fitter.cpp:28-29)

@@ -278,3 +278,38 @@ def test_vector_issue_model_runs_on_a_generated_kernel(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     k = json.load(open(d / "model.json"))["kernels"]["psw2dna.sum.tiles.fwd.clos.hip"]
     assert k["cells_per_loop"] == 4 * 271 and 150 <= k["loop"]["valu"] <= 400 and 0.15 <= k["issue_slots_per_cell"] <= 0.45
+
+
+def test_compiled_weights_give_the_bits_of_the_scalar_evaluation():
+    """EvaluatedMachine.reweighted (an EM iteration's re-evaluation: the machine's weight expressions as one flat program, compiled once,
+    evaluated level by level with numpy) against EvaluatedMachine.fromMachine (evalWeight per transition, src/weight.cpp:241-300):
+    the same bits on presets, on a composition (shared factors, function definitions), under several parameter sets; an undefined
+    parameter and a division by zero raise as the scalar evaluation does; a transition given another weight object is seen."""
+    import numpy as np
+    from machineboss_amd import algebra as A
+    from machineboss_amd.machine import Machine, MachineError
+    from machineboss_amd.evalmachine import EvaluatedMachine
+    from machineboss_amd.hmmer import HmmerModel
+    P = lambda n: Machine.fromFile(golden_path("preset", n + ".json"))
+    h = HmmerModel.fromFile(golden_path("hmmer", "fn3.hmm")).truncated(2)
+    machines = [P("protpsw"), P("dnapsw"), P("psw2dna"), A.composeLeftToRight([h.machine(True), P("simple_introns"), P("translate"), P("dnapsw")])]
+    rng = np.random.RandomState(4)
+    for m in machines:
+        base = m.getParamDefs(True)
+        e0 = EvaluatedMachine.fromMachine(m, base)
+        for trial in range(3):
+            p = {k: (float(rng.uniform(0.02, 0.98)) if isinstance(v, float) and 0.0 < v < 1.0 and trial else v) for k, v in base.items()}
+            a = EvaluatedMachine.fromMachine(m, p).logWeight; b = e0.reweighted(m, p).logWeight
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    m = machines[0]
+    e0 = EvaluatedMachine.fromMachine(m, m.getParamDefs(True))
+    name = next(k for k, v in m.getParamDefs(True).items() if isinstance(v, float))
+    broken = {k: v for k, v in m.getParamDefs(True).items()}
+    t = m.state[0].trans[0]; keep = t.weight
+    t.weight = {"/": [1.0, {"-": [name, name]}]}
+    with pytest.raises(ZeroDivisionError): EvaluatedMachine.fromMachine(m, broken)
+    with pytest.raises(ZeroDivisionError): e0.reweighted(m, broken)
+    t.weight = "no_such_parameter"
+    with pytest.raises(MachineError): e0.reweighted(m, broken)
+    t.weight = keep
+    assert np.array_equal(e0.reweighted(m, broken).logWeight.view(np.uint64), e0.logWeight.view(np.uint64))
