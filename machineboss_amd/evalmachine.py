@@ -179,11 +179,14 @@ class CompiledWeights:
 
     _VEC = {"*": 0, "/": 1, "+": 2, "-": 3, "not": 4, "geomsum": 5}
 
-    def __init__(self, machine: Machine):
+    def __init__(self, machine: Machine, expand: Optional[Dict[str, Any]] = None, keep: Optional[set] = None):
+        """``expand``: names whose definitions (expressions) become part of the program instead of being evaluated per call -- the
+        M-step's gradient runs through them; ``keep``: names that stay leaves whatever ``expand`` says (the free parameters)."""
         self.nodes: List[tuple] = []          # (kind, a, b): kind "c" constant a / "p" parameter name a / opcode with child indices
         self._byId: Dict[int, int] = {}
         self._keep: List[Any] = []            # the expression objects (ids stay valid while they live)
         self._consts: Dict[Any, int] = {}
+        self._expand = dict(expand or {}); self._leaf = set(keep or ()); self._open: set = set()
         self.top: List[int] = []
         for ms in machine.state:
             for t in ms.trans:
@@ -220,7 +223,13 @@ class CompiledWeights:
         if isinstance(w, str):
             key = ("p", w)
             if key not in self._consts:
-                self._consts[key] = len(self.nodes); self.nodes.append(("p", w, None))
+                d = self._expand.get(w)
+                if d is not None and w not in self._leaf and not isinstance(d, (bool, int, float)) and w not in self._open:
+                    self._open.add(w)      # (a definition in terms of other names: part of the program)
+                    self._consts[key] = self._node(d)
+                    self._open.discard(w)
+                else:
+                    self._consts[key] = len(self.nodes); self.nodes.append(("p", w, None))
             return self._consts[key]
         if id(w) in self._byId:
             return self._byId[id(w)]
@@ -265,6 +274,47 @@ class CompiledWeights:
                 else:
                     for i, x, y in zip(idx, v[a], v[b]): v[i] = math.pow(x, y)
         return v[self.topIdx]
+
+    def objective(self, counts: np.ndarray, defs: Dict[str, Any], wantGrad: bool = True):
+        """E = - sum_e counts[e] log w_e (MachineObjective, src/counts.cpp:122-131) and dE/dp for every parameter leaf, by one reverse
+        sweep over the program (the reference differentiates every transition's expression symbolically, src/weight.cpp deriv)."""
+        v = np.empty(len(self.nodes), np.float64)
+        if len(self.constIdx):
+            v[self.constIdx] = self.constVal
+        for i, name in self.params:
+            v[i] = evalWeight(name, defs)
+        with np.errstate(all="ignore"):
+            for kind, idx, a, b in self.steps:
+                if kind == "*": v[idx] = v[a] * v[b]
+                elif kind == "/": v[idx] = v[a] / v[b]
+                elif kind == "+": v[idx] = v[a] + v[b]
+                elif kind == "-": v[idx] = v[a] - v[b]
+                elif kind == "not": v[idx] = 1.0 - v[a]
+                elif kind == "geomsum": v[idx] = 1.0 / (1.0 - v[a])
+                elif kind == "log": v[idx] = np.log(v[a])
+                elif kind == "exp": v[idx] = np.exp(v[a])
+                else: v[idx] = np.power(v[a], v[b])
+            w = v[self.topIdx]
+            used = counts != 0.0
+            if np.any(~(w[used] > 0.0)) or not np.all(np.isfinite(w[used])):
+                return math.inf, None
+            E = -float(np.sum(counts[used] * np.log(w[used])))
+            if not wantGrad:
+                return E, None
+            bar = np.zeros(len(self.nodes), np.float64)
+            np.add.at(bar, self.topIdx[used], -counts[used] / w[used])
+            for kind, idx, a, b in reversed(self.steps):
+                g = bar[idx]
+                if kind == "*": np.add.at(bar, a, g * v[b]); np.add.at(bar, b, g * v[a])
+                elif kind == "/": np.add.at(bar, a, g / v[b]); np.add.at(bar, b, -g * v[a] / (v[b] * v[b]))
+                elif kind == "+": np.add.at(bar, a, g); np.add.at(bar, b, g)
+                elif kind == "-": np.add.at(bar, a, g); np.add.at(bar, b, -g)
+                elif kind == "not": np.add.at(bar, a, -g)
+                elif kind == "geomsum": np.add.at(bar, a, g * v[idx] * v[idx])
+                elif kind == "log": np.add.at(bar, a, g / v[a])
+                elif kind == "exp": np.add.at(bar, a, g * v[idx])
+                else: np.add.at(bar, a, g * v[b] * np.power(v[a], v[b] - 1.0)); np.add.at(bar, b, g * v[idx] * np.log(v[a]))
+        return E, {name: float(bar[i]) for i, name in self.params}
 
     def logWeights(self, defs: Dict[str, Any]) -> np.ndarray:
         w = self.values(defs)
