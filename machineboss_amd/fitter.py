@@ -141,6 +141,27 @@ class MachineObjective:
             out[p] = x[idx[p]] ** 2
         return out
 
+    def _grad_x(self, x: np.ndarray, idx: Dict[str, int], params: Dict[str, float], dE: Dict[str, float]) -> np.ndarray:
+        """dE/dx from dE/dp through the transform of _to_params, analytically: with z_k = exp(-x_k^2) a normalised group has
+        p_k = N_k (1 - z_k), N_(k+1) = N_k z_k, the last p = N, so dp_k/dz_k = -N_k and dp_q/dz_k = p_q / z_k for the later q."""
+        g = np.zeros(len(idx))
+        for grp in self.constraints.norm:
+            tail = 0.0      # sum over the later parameters q of dE/dp_q p_q
+            zs = [math.exp(-x[idx[p]] ** 2) for p in grp[:-1]]
+            Ns = [1.0]
+            for z in zs: Ns.append(Ns[-1] * z)
+            tail = dE.get(grp[-1], 0.0) * params[grp[-1]]
+            for k in range(len(grp) - 2, -1, -1):
+                p = grp[k]; z = zs[k]
+                dEdz = -Ns[k] * dE.get(p, 0.0) + (tail / z if z > 0.0 else 0.0)
+                g[idx[p]] = dEdz * (-2.0 * x[idx[p]] * z)
+                tail += dE.get(p, 0.0) * params[p]
+        for p in self.constraints.prob:
+            g[idx[p]] = dE.get(p, 0.0) * (-2.0 * x[idx[p]] * params[p])
+        for p in self.constraints.rate:
+            g[idx[p]] = dE.get(p, 0.0) * 2.0 * x[idx[p]]
+        return g
+
     def _seed_x(self, seed: Dict[str, Any], idx: Dict[str, int]) -> np.ndarray:
         x = np.zeros(len(idx))
         for g in self.constraints.norm:
@@ -175,7 +196,6 @@ class MachineObjective:
             from .evalmachine import CompiledWeights
             cw = CompiledWeights(self.machine, expand=self.constantDefs, keep=self.free)
             cvec = np.array([c for c, _ in self.terms], np.float64)
-            names = list(self._to_params(self._seed_x(seed, idx), idx).keys())
 
             def both(x):
                 params = self._to_params(x, idx)
@@ -186,13 +206,7 @@ class MachineObjective:
                     return 1e300, np.zeros(len(idx))
                 if dE is None or not math.isfinite(E):
                     return 1e300, np.zeros(len(idx))
-                g = np.zeros(len(idx))
-                eps = 1e-7
-                for p, j in idx.items():            # dp/dx_j by central differences of the (cheap, exact) transform
-                    xp = x.copy(); xm = x.copy(); xp[j] += eps; xm[j] -= eps
-                    pp, pm = self._to_params(xp, idx), self._to_params(xm, idx)
-                    g[j] = sum(dE.get(q, 0.0) * (pp[q] - pm[q]) / (2 * eps) for q in names)
-                return E, g
+                return E, self._grad_x(x, idx, params, dE)
             res = minimize(both, self._seed_x(seed, idx), jac=True, method="BFGS", options={"gtol": 1e-7, "maxiter": 1000})
             final.update(self._to_params(res.x, idx))
             return final
