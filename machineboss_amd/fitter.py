@@ -194,7 +194,14 @@ class MachineObjective:
         import os as _os
         if _os.environ.get("MB_FITTER_COMPILED", "1") != "0":
             from .evalmachine import CompiledWeights
-            cw = CompiledWeights(self.machine, expand=self.constantDefs, keep=self.free)
+            # (compiled once per machine, free-parameter set and constant definitions: every EM iteration makes a new MachineObjective)
+            key = (hash(tuple(id(t.weight) for ms in self.machine.state for t in ms.trans)), tuple(sorted(self.free)),
+                   tuple(sorted((k, id(v) if isinstance(v, (dict, list)) else v) for k, v in self.constantDefs.items())))
+            cached = getattr(self.machine, "_compiledObjective", None)
+            if cached is None or cached[0] != key:
+                cached = (key, CompiledWeights(self.machine, expand=self.constantDefs, keep=self.free))
+                self.machine._compiledObjective = cached
+            cw = cached[1]
             cvec = np.array([c for c, _ in self.terms], np.float64)
 
             def both(x):
